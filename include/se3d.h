@@ -1,0 +1,179 @@
+/*
+ * se3d.h — C-ABI of libse3d_hip.so: MI355X-native replacement for the hot path of
+ * AIS-Bonn/SmartEdgeSensor3DHumanPose (reference paths are relative to the reference root):
+ *
+ *   stage 1  skeleton_3d  triangulate_persons()   skeleton_3d/src/skeleton_3d_triang_mult_node.cpp:525-997
+ *   stage 2  pose_prior   skeletonCallback() body pose_prior/src/pose_prior_mult_node.cpp:505-921
+ *
+ * The reference has no FFI; its only external contract is the person_msgs topic surface.  This header is
+ * therefore the boundary a maintainer binds at the two internal call sites above:
+ * flat POD mirrors of the person_msgs messages, plain pointers and sizes, int status codes, no C++ types,
+ * no torch types.  All host buffers are caller-owned; the context owns device memory, its HIP stream and the
+ * per-sequence track state.  Calls on one context are serialised by the caller (the reference calls stage 1
+ * from exactly one worker thread, S3D:1069, and stage 2 from the single ros::spin thread, PP:947-950).
+ *
+ * The same POD types are used by the CPU oracle (oracle/se3d_oracle.cpp, test infrastructure only).
+ */
+#ifndef SE3D_H
+#define SE3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SE3D_NUM_KEYPOINTS 17        /* NUM_KEYPOINTS, S3D:56,1098 */
+#define SE3D_NUM_FUSION_KEYPOINTS 21 /* FUSION_BODY_PARTS::NUM_KEYPOINTS, fusion_body_parts.h:24 */
+
+#define SE3D_POSE_SIMPLE 0 /* pose_method "simple" (S3D:1095, PP:930) */
+#define SE3D_POSE_H36M 1   /* pose_method "h36m" */
+
+/* status codes (negative = error); the reference's void functions become int-returning */
+#define SE3D_OK 0
+#define SE3D_ERR_ARG (-1)      /* null pointer / inconsistent sizes */
+#define SE3D_ERR_CAPACITY (-2) /* a frame exceeds the limits given at se3d_create */
+#define SE3D_ERR_DEVICE (-3)   /* HIP runtime error (see se3d_last_error) */
+#define SE3D_ERR_STATE (-4)    /* call sequence error (e.g. fetch before run) */
+
+/* per-frame flag bits in se3d_frame_out.flags */
+#define SE3D_FLAG_HYP_OVERFLOW 1u /* more hypotheses than limits.max_hyp were spawned; result truncated */
+#define SE3D_FLAG_FEW_CAMERAS 2u  /* < 2 cameras with detections: empty result (S3D:557-560) */
+
+/* person_msgs/Keypoint2D.msg */
+typedef struct se3d_keypoint2d {
+  float x, y, score;
+  float cov[3]; /* xx, xy, yy (pixel^2) */
+} se3d_keypoint2d;
+
+/* person_msgs/Person2D.msg with keypoints[] fixed to the 17 the nodes require (S3D:319-320) */
+typedef struct se3d_person2d {
+  float score;
+  float bbox[4];
+  se3d_keypoint2d keypoints[SE3D_NUM_KEYPOINTS];
+} se3d_person2d;
+
+/* person_msgs/KeypointWithCovariance.msg */
+typedef struct se3d_keypoint3d {
+  double joint[3]; /* geometry_msgs/Point */
+  float score;
+  float _pad;
+  double cov[6]; /* xx, xy, xz, yy, yz, zz */
+} se3d_keypoint3d;
+
+/* person_msgs/PersonCov.msg; bbox_center/bbox_size are never written by either node and are omitted */
+typedef struct se3d_person3d {
+  uint32_t id; /* stage 1 leaves 0; stage 2 writes the track id (PP:595-596) */
+  float score; /* left 0 by both stages */
+  se3d_keypoint3d keypoints[SE3D_NUM_FUSION_KEYPOINTS];
+} se3d_person3d;
+
+/* Static per-rig tensors produced once by skeleton_3d main() (S3D:1184-1214). */
+typedef struct se3d_rig {
+  int32_t n_cam;
+  const float *Rt; /* [n_cam][12] row-major 3x4 base->camera extrinsics (S3D:1208-1211) */
+  const float *K;  /* [n_cam][4]  fx, fy, cx, cy (S3D:314-317) */
+  const float *F;  /* [n_cam*(n_cam-1)/2][9] row-major, pair order of get_fundamental_idx (S3D:242-253) */
+} se3d_rig;
+
+/* ROS private parameters of both nodes (S3D:1095-1097, PP:930-932). */
+typedef struct se3d_params {
+  int32_t pose_method;  /* SE3D_POSE_SIMPLE | SE3D_POSE_H36M */
+  int32_t norm_height;  /* pose_prior ~norm_height */
+  double max_epi_dist;  /* skeleton_3d ~max_epi_dist (default 0.050, demo launch 0.045) */
+} se3d_params;
+
+/* Capacities fixed at create time: no allocation per frame after warm-up. */
+typedef struct se3d_limits {
+  int32_t max_frames;      /* frames per batch (B) */
+  int32_t max_det_per_cam; /* detections per camera per frame (P_max) */
+  int32_t max_hyp;         /* person hypotheses per frame (H_max >= P_max) */
+  int32_t max_tracks;      /* stage-2 tracks per sequence */
+} se3d_limits;
+
+/* One synchronised set of per-camera Person2DList messages (input of triangulate_persons, S3D:525). */
+typedef struct se3d_frame_in {
+  int32_t n_cam;
+  const int32_t *det_offset;    /* [n_cam+1] prefix offsets into persons (camera i has det_offset[i+1]-det_offset[i]) */
+  const se3d_person2d *persons; /* [det_offset[n_cam]] */
+  const float *fb_delay;        /* [n_cam] Person2DList.fb_delay, may be NULL (= -1) */
+  double stamp;                 /* header.stamp of the pivot message, seconds (S3D:1060) */
+} se3d_frame_in;
+
+/* PersonCovList payload produced by stage 1 (S3D:1059-1071) plus the association table. */
+typedef struct se3d_frame_out {
+  int32_t capacity;       /* in : persons[]/person_hyp[] hold this many entries */
+  int32_t hyp_capacity;   /* in : hyp_assoc holds this many rows (0 = not wanted) */
+  int32_t n_persons;      /* out: published persons after duplicate merge (S3D:984-996) */
+  int32_t n_hyp;          /* out: hypotheses created by the greedy sweep (S3D:565-674), creation order */
+  uint32_t flags;         /* out: SE3D_FLAG_* */
+  se3d_person3d *persons; /* out: [capacity], canonical order = ascending hypothesis index (serial reference) */
+  int32_t *person_hyp;    /* out: [capacity] hypothesis index each person came from (lower index after a merge) */
+  int32_t *hyp_assoc;     /* out: [hyp_capacity][n_cam] index into that camera's persons[] or -1 */
+} se3d_frame_out;
+
+/* persons3d_fused / persons3d_fused_pred payload produced by stage 2 (PP:905-907). */
+typedef struct se3d_fused_out {
+  int32_t capacity;
+  int32_t n_persons;         /* persons published (tracks with num_obs > 10, PP:845-848) */
+  int32_t n_tracks;          /* live tracks after removal/merge */
+  float pred_delta_t;        /* value written into fb_delay_per_cam (PP:526-531) */
+  se3d_person3d *fused;      /* [capacity] */
+  se3d_person3d *fused_pred; /* [capacity] */
+  int32_t *lm_iterations;    /* [capacity] outer LM iterations used for each published person (diagnostic) */
+} se3d_fused_out;
+
+typedef struct se3d_ctx se3d_ctx;
+
+/* --- rig set-up (host; replaces S3D:1187-1211) ---------------------------------------------------------
+ * T_base_to_cam: [n_cam][16] row-major 4x4 doubles as returned by tf lookupTransform(cam, base).
+ * Writes Rt_out [n_cam][12] floats and F_out [n_cam*(n_cam-1)/2][9] floats (either may be NULL). */
+int se3d_rig_from_transforms(int32_t n_cam, const double *T_base_to_cam, float *Rt_out, float *F_out);
+
+/* --- context ------------------------------------------------------------------------------------------- */
+se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d_limits *limits, int32_t device_id);
+void se3d_destroy(se3d_ctx *ctx);
+const char *se3d_last_error(const se3d_ctx *ctx);
+const char *se3d_version(void);
+
+/* --- stage 1: drop-in for triangulate_persons (S3D:525-997) ------------------------------------------- */
+/* one frame, synchronous (host in, host out) */
+int se3d_triangulate(se3d_ctx *ctx, const se3d_frame_in *frame, se3d_frame_out *out);
+/* B frames, synchronous */
+int se3d_triangulate_batch(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in *frames, se3d_frame_out *outs);
+
+/* resident pipeline for throughput: stage (H2D) once, run many times with inputs in HBM, fetch (D2H) */
+int se3d_stage_frames(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in *frames);
+int se3d_run_stage1(se3d_ctx *ctx); /* asynchronous on the context stream */
+int se3d_sync(se3d_ctx *ctx);
+int se3d_fetch_stage1(se3d_ctx *ctx, int32_t n_frames, se3d_frame_out *outs);
+
+/* --- stage 2: drop-in for the pose_prior skeletonCallback body (PP:505-921) ----------------------------
+ * The context holds n_seq independent sequences (each the global state of one pose_prior node: g_tracks,
+ * g_fb_delay_buffer, g_frame_nr, g_t_prev, g_next_id; PP:54-60,123).  Sequence s consumes, per call, frame
+ * slot s of the most recent stage-1 run (resident path) or host measurements (se3d_refine). */
+int se3d_refine_reset(se3d_ctx *ctx);
+/* one PersonCovList in, fused lists out; seq selects the pose_prior instance */
+int se3d_refine(se3d_ctx *ctx, int32_t seq, int32_t n_det, const se3d_person3d *dets, int32_t n_cam,
+                const float *fb_delay_per_cam, double t, se3d_fused_out *out);
+/* resident: refine frame slot s of the last se3d_run_stage1 for every sequence s < n_seq, stamps t[s] */
+int se3d_run_stage2(se3d_ctx *ctx, int32_t n_seq, const double *t);
+int se3d_fetch_stage2(se3d_ctx *ctx, int32_t n_seq, se3d_fused_out *outs);
+
+/* --- device-side result access for multi-GPU exchange (RCCL all-gather of final skeletons) -------------
+ * Packs the persons of all frames of the last run into a caller-provided DEVICE buffer
+ * [n_frames][max_hyp] se3d_person3d plus counts [n_frames] int32 (device pointers, e.g. torch tensors). */
+int se3d_pack_stage1_device(se3d_ctx *ctx, void *d_persons, void *d_counts);
+int se3d_pack_stage2_device(se3d_ctx *ctx, void *d_persons, void *d_counts);
+
+/* --- measurement: HIP-event timing of the kernels on the context stream -------------------------------- */
+int se3d_profile_enable(se3d_ctx *ctx, int32_t on);
+int se3d_profile_reset(se3d_ctx *ctx);
+/* name in {"normalize","epipolar_pairs","sweep_cost","sweep_assign","triangulate","postprocess",
+ *          "track_assoc","lm_refine","track_update"}; returns accumulated ms and launch count */
+int se3d_profile_get(se3d_ctx *ctx, const char *name, double *ms_total, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SE3D_H */

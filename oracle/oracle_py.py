@@ -1,0 +1,167 @@
+"""ctypes binding of the CPU ORACLE (oracle/libse3d_oracle.so) — TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product package
+(smartedgesensor3dhumanpose_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from smartedgesensor3dhumanpose_amd import person_msgs as pm
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libse3d_oracle.so")
+_REF = os.path.join(_HERE, "_ref", "libhungarian_ref.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "se3d_oracle.cpp")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libse3d_oracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/skeleton_3d/src/Hungarian.cpp") and (force or not os.path.exists(_REF)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.se3d_oracle_pair_cost.restype = C.c_double
+        L.se3d_oracle_pp_create.restype = C.c_void_p
+        L.se3d_oracle_pp_destroy.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def ref_hungarian_available():
+    return os.path.exists(_REF)
+
+
+def ref_hungarian(dist):
+    """The REFERENCE's own HungarianAlgorithm::assignmentoptimal (compiled from /root/reference into oracle/_ref)."""
+    L = C.CDLL(_REF)
+    d = np.asfortranarray(dist, np.float64)
+    nr, nc = d.shape
+    flat = np.ascontiguousarray(d.ravel(order="F"))
+    a = np.zeros(nr, np.int32)
+    cost = C.c_double(0)
+    L.hungarian_ref(a.ctypes.data_as(C.POINTER(C.c_int)), C.byref(cost), flat.ctypes.data_as(C.POINTER(C.c_double)), nr, nc)
+    return a, cost.value
+
+
+def hungarian(dist):
+    d = np.asfortranarray(dist, np.float64)
+    nr, nc = d.shape
+    flat = np.ascontiguousarray(d.ravel(order="F"))
+    a = np.zeros(nr, np.int32)
+    cost = C.c_double(0)
+    rc = lib().se3d_oracle_hungarian(pm.iptr(a), C.byref(cost), flat.ctypes.data_as(C.POINTER(C.c_double)), nr, nc)
+    assert rc == 0
+    return a, cost.value
+
+
+def rig_tensors(rig):
+    """Fills rig.Rt / rig.F with the oracle's restatement of S3D:1187-1211."""
+    Rt = np.zeros((rig.n_cam, 12), np.float32)
+    F = np.zeros((rig.n_pairs, 9), np.float32)
+    rc = lib().se3d_oracle_rig_from_transforms(rig.n_cam, rig.T.ctypes.data_as(C.POINTER(C.c_double)), pm.fptr(Rt), pm.fptr(F))
+    assert rc == 0
+    return Rt, F
+
+
+def _rig_c(rig):
+    assert rig.Rt is not None and rig.F is not None, "rig tensors not set"
+    return pm.Rig(rig.n_cam, pm.fptr(rig.Rt), pm.fptr(rig.K), pm.fptr(rig.F))
+
+
+def triangulate(rig, params, frame, capacity=None, hyp_capacity=None, omp_threads=1):
+    tot = int(frame.det_offset[-1])
+    capacity = capacity or max(tot, 1)
+    hyp_capacity = hyp_capacity or max(tot, 1)
+    res = pm.FrameResult(rig.n_cam, capacity, hyp_capacity)
+    fin = frame.as_c()
+    rc = lib().se3d_oracle_triangulate(C.byref(_rig_c(rig)), C.byref(params), C.byref(fin), C.byref(res.c), int(omp_threads))
+    if rc != 0:
+        raise RuntimeError("se3d_oracle_triangulate failed: %d" % rc)
+    return res
+
+
+def dlt(Rt, pts, weight=True):
+    Rt = np.ascontiguousarray(Rt, np.float32).reshape(-1, 12)
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
+    X = np.zeros(3, np.float32)
+    err = C.c_double(0)
+    rc = lib().se3d_oracle_dlt(len(Rt), pm.fptr(Rt), pm.fptr(pts), int(weight), pm.fptr(X), C.byref(err))
+    assert rc == 0
+    return X, err.value
+
+
+def ut_cov(Rt, pts, cov2, mean):
+    Rt = np.ascontiguousarray(Rt, np.float32).reshape(-1, 12)
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
+    cov2 = np.ascontiguousarray(cov2, np.float32).reshape(-1, 4)
+    mean = np.ascontiguousarray(mean, np.float32)
+    out = np.zeros(9, np.float32)
+    rc = lib().se3d_oracle_ut_cov(len(Rt), pm.fptr(Rt), pm.fptr(pts), pm.fptr(cov2), pm.fptr(mean), pm.fptr(out))
+    assert rc == 0
+    return out.reshape(3, 3)
+
+
+def pair_cost(F9, kp_a, kp_b):
+    F9 = np.ascontiguousarray(F9, np.float32)
+    a = np.ascontiguousarray(kp_a, np.float32)
+    b = np.ascontiguousarray(kp_b, np.float32)
+    n = C.c_int32(0)
+    c = lib().se3d_oracle_pair_cost(pm.fptr(F9), pm.fptr(a), pm.fptr(b), C.byref(n))
+    return c, n.value
+
+
+def lm(init, unary, ranges, want_marginals=True):
+    """unary: list of (key, m[3], cov[3][3]); ranges: list of (k1, k2, L, sigma)."""
+    init = np.ascontiguousarray(init, np.float64).reshape(-1, 3)
+    K = len(init)
+    uk = np.array([u[0] for u in unary], np.int32)
+    um = np.ascontiguousarray([u[1] for u in unary], np.float64).reshape(-1, 3)
+    uc = np.ascontiguousarray([np.asarray(u[2]).reshape(9) for u in unary], np.float64).reshape(-1, 9)
+    r1 = np.array([r[0] for r in ranges], np.int32)
+    r2 = np.array([r[1] for r in ranges], np.int32)
+    rl = np.array([r[2] for r in ranges], np.float64)
+    rs = np.array([r[3] for r in ranges], np.float64)
+    res = np.zeros((K, 3))
+    marg = np.zeros((K, 9))
+    it = C.c_int32(0)
+    err = C.c_double(0)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rc = lib().se3d_oracle_lm(K, dp(init), len(unary), pm.iptr(uk), dp(um), dp(uc), len(ranges), pm.iptr(r1), pm.iptr(r2), dp(rl), dp(rs),
+                              dp(res), dp(marg) if want_marginals else None, C.byref(it), C.byref(err))
+    assert rc == 0, rc
+    return res, marg.reshape(K, 3, 3), it.value, err.value
+
+
+class PosePrior:
+    """Oracle instance of the pose_prior node state + skeletonCallback (PP:505-921)."""
+
+    def __init__(self, params):
+        self._h = lib().se3d_oracle_pp_create(C.byref(params))
+        assert self._h
+
+    def step(self, dets, n_cam, t, fb_delay=None, capacity=None, omp_threads=1):
+        dets = np.ascontiguousarray(dets, pm.person3d_dt)
+        res = pm.FusedResult(capacity or max(len(dets), 1))
+        fb = None if fb_delay is None else pm.fptr(np.ascontiguousarray(fb_delay, np.float32))
+        rc = lib().se3d_oracle_pp_step(C.c_void_p(self._h), len(dets), C.c_void_p(dets.ctypes.data), int(n_cam), fb, C.c_double(t),
+                                       C.byref(res.c), int(omp_threads))
+        if rc != 0:
+            raise RuntimeError("se3d_oracle_pp_step failed: %d" % rc)
+        return res
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().se3d_oracle_pp_destroy(C.c_void_p(self._h))
+            self._h = None

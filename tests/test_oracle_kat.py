@@ -1,0 +1,191 @@
+"""Known-answer tests for the oracle rows that go through un-vendored third-party code in the reference
+(Eigen JacobiSVD: rows T/U; GTSAM LM/Marginals: row R).  These rows are "parity unpinned" (no reference binary, no
+reference golden vectors); the oracle is instead checked against independent float64 numpy/scipy solutions."""
+import numpy as np
+import pytest
+from scipy.optimize import least_squares
+
+from smartedgesensor3dhumanpose_amd import rig as R
+
+
+def _project(rig, X):
+    Xh = np.append(X, 1.0)
+    pts = []
+    for T in rig.T:
+        xc = T[:3] @ Xh
+        pts.append([xc[0] / xc[2], xc[1] / xc[2]])
+    return np.array(pts)
+
+
+def _visible_cams(rig, X):
+    Xh = np.append(X, 1.0)
+    z = np.array([(T[:3] @ Xh)[2] for T in rig.T])
+    p = _project(rig, X)
+    return np.nonzero((z > 0.5) & (np.abs(p[:, 0]) < 0.53) & (np.abs(p[:, 1]) < 0.4))[0]
+
+
+def _random_visible(rig, rng, min_views):
+    while True:
+        X = np.array([rng.uniform(-6, 2), rng.uniform(-3, 3), rng.uniform(0, 2)])
+        ok = _visible_cams(rig, X)
+        if len(ok) >= min_views:
+            n = rng.integers(min_views, len(ok) + 1)
+            return X, np.sort(rng.choice(ok, n, replace=False))
+
+
+def _dlt_f64(Rt, pts, weight):
+    A = []
+    for P, (x, y, c) in zip(Rt.reshape(-1, 3, 4).astype(np.float64), pts.astype(np.float64)):
+        r0 = x * P[2] - P[0]
+        r1 = y * P[2] - P[1]
+        r0 /= np.linalg.norm(r0)
+        r1 /= np.linalg.norm(r1)
+        if weight:
+            r0 *= c
+            r1 *= c
+        A += [r0, r1]
+    v = np.linalg.svd(np.array(A))[2][-1]
+    return v[:3] / v[3]
+
+
+def test_dlt_noise_free_recovers_points(oracle, extr_rig):
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for _ in range(200):
+        X, sel = _random_visible(extr_rig, rng, 2)
+        pts = _project(extr_rig, X)
+        p3 = np.concatenate([pts[sel], rng.uniform(0.3, 1.0, (len(sel), 1))], 1).astype(np.float32)
+        Xo, err = oracle.dlt(extr_rig.Rt[sel], p3, True)
+        worst = max(worst, np.linalg.norm(Xo - X))
+        assert err < 1e-4
+    assert worst < 1e-4  # metres
+
+
+def test_dlt_matches_float64_svd_under_noise(oracle, extr_rig):
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for _ in range(300):
+        X, sel = _random_visible(extr_rig, rng, 3)
+        pts = _project(extr_rig, X) + rng.normal(0, 3e-3, (16, 2))
+        p3 = np.concatenate([pts[sel], rng.uniform(0.3, 1.0, (len(sel), 1))], 1).astype(np.float32)
+        for w in (True, False):
+            Xo, _ = oracle.dlt(extr_rig.Rt[sel], p3, w)
+            Xr = _dlt_f64(extr_rig.Rt[sel], p3, w)
+            worst = max(worst, np.linalg.norm(Xo - Xr))
+    assert worst < 5e-5  # float32 SVD vs float64 SVD: SURVEY probe says <= 0.0054 mm; allow 0.05 mm
+
+
+def test_epipolar_distance_zero_for_consistent_pairs(oracle, extr_rig):
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        i, j = sorted(rng.choice(16, 2, replace=False))
+        Xs = np.stack([rng.uniform(-6, 2, 17), rng.uniform(-3, 3, 17), rng.uniform(0, 2, 17)], 1)
+        a = np.zeros((17, 3), np.float32)
+        b = np.zeros((17, 3), np.float32)
+        for k, X in enumerate(Xs):
+            p = _project(extr_rig, X)
+            a[k] = (*p[i], 0.9)
+            b[k] = (*p[j], 0.9)
+        F = extr_rig.F[R.pair_index(i, j, 16)]
+        c, n = oracle.pair_cost(F, a, b)
+        assert n == 17 and c < 1e-5
+        b2 = b.copy()
+        b2[:, 1] += 0.05  # shift detection by 0.05 in normalised y -> clearly non-zero distance
+        c2, _ = oracle.pair_cost(F, a, b2)
+        assert c2 > 5e-3
+        a[3, 2] = 0.30  # strict '>' gate in calcCost (S3D:354): score == 0.30 is NOT used
+        c3, n3 = oracle.pair_cost(F, a, b)
+        assert n3 == 16
+
+
+def test_fundamental_matrices_match_closed_form(oracle, extr_rig):
+    # F_ij = [e_ij]x P_j P_i^+ ; for P = [R|t], P^+ = P^T (P P^T)^-1  (independent float64 evaluation)
+    for (i, j) in [(0, 1), (3, 9), (14, 15)]:
+        Pi, Pj = extr_rig.T[i][:3], extr_rig.T[j][:3]
+        Ci = np.linalg.inv(extr_rig.T[i])[:, 3]
+        e = Pj @ Ci
+        ex = np.array([[0, -e[2], e[1]], [e[2], 0, -e[0]], [-e[1], e[0], 0]])
+        F = ex @ Pj @ np.linalg.pinv(Pi)
+        got = extr_rig.F[R.pair_index(i, j, 16)].reshape(3, 3)
+        assert np.allclose(got, F.astype(np.float32), rtol=2e-6, atol=2e-6)
+
+
+def test_ut_covariance_matches_monte_carlo(oracle, extr_rig):
+    rng = np.random.default_rng(3)
+    X = np.array([-2.0, 0.5, 1.1])
+    sel = np.array([0, 2, 3, 4, 9, 10, 14, 15])
+    pts = _project(extr_rig, X)[sel]
+    s2 = (2.0 / 600.0) ** 2
+    cov2 = np.tile(np.array([s2, 0.2 * s2, 0.2 * s2, s2], np.float32), (len(sel), 1))
+    p3 = np.concatenate([pts, np.full((len(sel), 1), 0.8)], 1).astype(np.float32)
+    mean, _ = oracle.dlt(extr_rig.Rt[sel], p3, True)
+    cov = oracle.ut_cov(extr_rig.Rt[sel], p3, cov2, mean)
+    L = np.linalg.cholesky(np.array([[s2, 0.2 * s2], [0.2 * s2, s2]]))
+    samples = []
+    for _ in range(4000):
+        q = p3.copy()
+        q[:, :2] += (L @ rng.normal(size=(2, len(sel)))).T
+        samples.append(_dlt_f64(extr_rig.Rt[sel], q, False))
+    mc = np.cov(np.array(samples).T)
+    assert np.allclose(np.sqrt(np.diag(cov)), np.sqrt(np.diag(mc)), rtol=0.08)
+    assert np.linalg.norm(cov - mc) / np.linalg.norm(mc) < 0.15
+    assert np.allclose(cov, cov.T, atol=1e-9)
+
+
+def _residuals(x, K, unary, ranges):
+    q = x.reshape(K, 3)
+    r = []
+    for key, m, cov in unary:
+        W = np.linalg.cholesky(np.linalg.inv(np.asarray(cov))).T
+        r += list(W @ (q[key] - np.asarray(m)))
+    for k1, k2, L, s in ranges:
+        r.append((np.linalg.norm(q[k2] - q[k1]) - L) / s)
+    return np.array(r)
+
+
+def test_lm_two_joint_analytic(oracle):
+    # two joints on the x axis, isotropic unit-variance priors at 0 and 2, bone length 1, sigma_b:
+    # optimum symmetric: x0 = d, x1 = 2 - d; minimise 1/2 [2 d^2 + ((2 - 2d - L)/s)^2]  ->  d = (2 - L) / (s^2 + 2)
+    s = 0.5
+    unary = [(0, [0, 0, 0], np.eye(3)), (1, [2, 0, 0], np.eye(3))]
+    ranges = [(0, 1, 1.0, s)]
+    res, marg, it, err = oracle.lm(np.array([[0., 0, 0], [2, 0, 0]]), unary, ranges)
+    d = (2.0 - 1.0) / (s * s + 2.0)
+    assert np.allclose(res[0], [d, 0, 0], atol=1e-6) and np.allclose(res[1], [2 - d, 0, 0], atol=1e-6)
+    assert 1 <= it <= 10
+
+
+def test_lm_matches_scipy_and_marginals_match_inverse_hessian(oracle):
+    rng = np.random.default_rng(5)
+    K = 8
+    truth = rng.normal(0, 0.5, (K, 3))
+    unary = []
+    for k in range(K):
+        A = rng.normal(size=(3, 3))
+        cov = (A @ A.T) * 1e-3 + np.eye(3) * 1e-4
+        unary.append((k, truth[k] + rng.normal(0, 0.03, 3), cov))
+    ranges = [(k, k + 1, float(np.linalg.norm(truth[k + 1] - truth[k])), 0.03) for k in range(K - 1)] + [(0, 5, 0.7, 0.05)]
+    init = np.array([u[1] for u in unary])
+    res, marg, it, err = oracle.lm(init, unary, ranges)
+    sp = least_squares(_residuals, init.ravel(), args=(K, unary, ranges), method="lm", xtol=1e-14, ftol=1e-14, gtol=1e-14)
+    assert np.abs(res - sp.x.reshape(K, 3)).max() < 2e-4   # LM stops at relative decrease 1e-5, scipy runs to 1e-14
+    assert err <= 0.5 * np.sum(sp.fun ** 2) * (1 + 1e-4) + 1e-9
+    # marginals = diagonal blocks of (J^T J)^-1 at the oracle's optimum
+    J = np.zeros((len(sp.fun), 3 * K))
+    x0 = res.ravel()
+    for c in range(3 * K):
+        e = np.zeros(3 * K)
+        e[c] = 1e-6
+        J[:, c] = (_residuals(x0 + e, K, unary, ranges) - _residuals(x0 - e, K, unary, ranges)) / 2e-6
+    Hinv = np.linalg.inv(J.T @ J)
+    for k in range(K):
+        assert np.allclose(marg[k], Hinv[3 * k:3 * k + 3, 3 * k:3 * k + 3], rtol=1e-4, atol=1e-10)
+
+
+def test_lm_diagonal_covariance_shortcut(oracle):
+    # Gaussian::Covariance with |off-diagonal| <= 1e-9 is treated as Diagonal (GTSAM smart noise model)
+    cov = np.diag([1e-4, 4e-4, 9e-4])
+    cov[0, 1] = cov[1, 0] = 5e-10
+    res, marg, it, err = oracle.lm(np.array([[0.1, 0.1, 0.1]]), [(0, [0, 0, 0], cov)], [])
+    assert np.allclose(res[0], 0, atol=1e-9)
+    assert np.allclose(marg[0], np.diag([1e-4, 4e-4, 9e-4]), rtol=1e-9)
