@@ -160,6 +160,15 @@ int se3d_refine(se3d_ctx *ctx, int32_t seq, int32_t n_det, const se3d_person3d *
 int se3d_run_stage2(se3d_ctx *ctx, int32_t n_seq, const double *t);
 int se3d_fetch_stage2(se3d_ctx *ctx, int32_t n_seq, se3d_fused_out *outs);
 
+/* --- row M as a stand-alone entry: drop-in for HungarianAlgorithm::assignmentoptimal (Hungarian.cpp:60) on the GPU.
+ * dist is column-major [row + n_rows*col] (host memory), n_rows, n_cols <= 256; assignment[row] = col or -1. */
+int se3d_hungarian(se3d_ctx *ctx, int32_t *assignment, double *cost, const double *dist, int32_t n_rows, int32_t n_cols);
+
+/* --- diagnostic accessor: pairwise epipolar cost block of camera pair (cam_a < cam_b) of staged frame `frame` after
+ * se3d_run_stage1: out[det_a * max_det_per_cam + det_b] = mean symmetric epipolar distance (calcCost inner loop,
+ * S3D:353-368) in FILTERED detection slots, -1 where no joint is shared; n_a/n_b receive the valid slot counts. */
+int se3d_get_pair_costs(se3d_ctx *ctx, int32_t frame, int32_t cam_a, int32_t cam_b, double *out, int32_t *n_a, int32_t *n_b);
+
 /* --- device-side result access for multi-GPU exchange (RCCL all-gather of final skeletons) -------------
  * Packs the persons of all frames of the last run into a caller-provided DEVICE buffer
  * [n_frames][max_hyp] se3d_person3d plus counts [n_frames] int32 (device pointers, e.g. torch tensors). */

@@ -1,0 +1,50 @@
+"""Loader of the product library libse3d_hip.so (C-ABI of include/se3d.h).  No fallback: a missing library is an error."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libse3d_hip.so")
+
+# every entry point declared in include/se3d.h (checked against the header in tests/test_abi.py)
+EXPORTS = [
+    "se3d_rig_from_transforms", "se3d_create", "se3d_destroy", "se3d_last_error", "se3d_version",
+    "se3d_triangulate", "se3d_triangulate_batch", "se3d_stage_frames", "se3d_run_stage1", "se3d_sync", "se3d_fetch_stage1",
+    "se3d_refine_reset", "se3d_refine", "se3d_run_stage2", "se3d_fetch_stage2",
+    "se3d_hungarian", "se3d_get_pair_costs", "se3d_pack_stage1_device", "se3d_pack_stage2_device",
+    "se3d_profile_enable", "se3d_profile_reset", "se3d_profile_get",
+]
+
+
+def build(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "se3d.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", src_dir] + (["-B"] if force else []), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libse3d_hip.so is missing (%s): build it with `make -C smartedgesensor3dhumanpose_amd/csrc` "
+                               "or __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.se3d_create.restype = C.c_void_p
+        L.se3d_destroy.argtypes = [C.c_void_p]
+        L.se3d_last_error.restype = C.c_char_p
+        L.se3d_last_error.argtypes = [C.c_void_p]
+        L.se3d_version.restype = C.c_char_p
+        for name in ("se3d_triangulate", "se3d_triangulate_batch", "se3d_stage_frames", "se3d_run_stage1", "se3d_sync", "se3d_fetch_stage1",
+                     "se3d_refine_reset", "se3d_refine", "se3d_run_stage2", "se3d_fetch_stage2", "se3d_pack_stage1_device",
+                     "se3d_pack_stage2_device", "se3d_hungarian", "se3d_get_pair_costs", "se3d_profile_enable", "se3d_profile_reset", "se3d_profile_get"):
+            getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib

@@ -1,0 +1,419 @@
+// se3d_api.hip — host side of libse3d_hip.so: context, HBM residency, staging and the C-ABI of include/se3d.h.
+// The product path runs ONLY the HIP kernels; there is no CPU fallback (a missing/failed device is an error).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "se3d_device.h"
+
+extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st);
+extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled);
+
+#define SE3D_VERSION "se3d-hip 0.1.0 (gfx950)"
+
+namespace {
+enum ProfSlot { PS_NORMALIZE = 0, PS_PAIRS, PS_SWEEP, PS_TRI, PS_POST, PS_COUNT };
+const char *kProfNames[PS_COUNT] = {"normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess"};
+}  // namespace
+
+struct se3d_ctx {
+  Se3dDev D{};
+  se3d_params params{};
+  se3d_limits limits{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<void *> allocs;
+  int2 *pair_ab = nullptr;
+  // pinned host staging
+  se3d_person2d *h_raw = nullptr;
+  int32_t *h_nraw = nullptr;
+  se3d_person3d *h_out = nullptr;
+  int32_t *h_count = nullptr, *h_outhyp = nullptr, *h_outassoc = nullptr, *h_nhyp = nullptr;
+  uint32_t *h_flags = nullptr;
+  int staged_frames = 0;
+  bool ran = false;
+  bool tiled = false;
+  // profiling
+  bool prof = false;
+  hipEvent_t ev[8]{};
+  double prof_ms[PS_COUNT]{};
+  int64_t prof_n[PS_COUNT]{};
+  bool prof_pending = false;
+};
+
+namespace {
+
+bool hip_ok(se3d_ctx *c, hipError_t e, const char *what) {
+  if (e == hipSuccess) return true;
+  c->err = std::string(what) + ": " + hipGetErrorString(e);
+  return false;
+}
+#define HIPCHK(c, call)                                  \
+  do {                                                   \
+    if (!hip_ok((c), (call), #call)) return SE3D_ERR_DEVICE; \
+  } while (0)
+
+template <typename T>
+bool dev_alloc(se3d_ctx *c, T **p, size_t n) {
+  void *q = nullptr;
+  if (!hip_ok(c, hipMalloc(&q, n * sizeof(T)), "hipMalloc")) return false;
+  c->allocs.push_back(q);
+  *p = reinterpret_cast<T *>(q);
+  return true;
+}
+
+void collect_profile(se3d_ctx *c) {
+  if (!c->prof_pending) return;
+  (void)hipEventSynchronize(c->ev[5]);
+  for (int i = 0; i < PS_COUNT; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) {
+      c->prof_ms[i] += ms;
+      c->prof_n[i] += 1;
+    }
+  }
+  c->prof_pending = false;
+}
+
+// 3x4 pseudo-inverse of a full-row-rank P: P^+ = P^T (P P^T)^-1  (host, fp64)
+void pinv34(const double P[12], double out[12]) {
+  double G[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += P[i * 4 + k] * P[j * 4 + k];
+      G[i * 3 + j] = s;
+    }
+  const double a = G[0], b = G[1], cc = G[2], d = G[3], e = G[4], f = G[5], g = G[6], h = G[7], i9 = G[8];
+  const double c00 = e * i9 - f * h, c01 = -(d * i9 - f * g), c02 = d * h - e * g;
+  const double det = a * c00 + b * c01 + cc * c02, id = 1.0 / det;
+  const double Gi[9] = {c00 * id, -(b * i9 - cc * h) * id, (b * f - cc * e) * id, c01 * id, (a * i9 - cc * g) * id,
+                        -(a * f - cc * d) * id, c02 * id, -(a * h - b * g) * id, (a * e - b * d) * id};
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += P[k * 4 + i] * Gi[k * 3 + j];
+      out[i * 3 + j] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *se3d_version(void) { return SE3D_VERSION; }
+
+// Host set-up of the static rig tensors (replaces S3D:1187-1211).  F_ij = [P_j C_i]_x P_j P_i^+ in fp64, stored as float.
+int se3d_rig_from_transforms(int32_t n_cam, const double *T, float *Rt_out, float *F_out) {
+  if (n_cam < 2 || !T) return SE3D_ERR_ARG;
+  if (Rt_out)
+    for (int i = 0; i < n_cam; ++i)
+      for (int k = 0; k < 12; ++k) Rt_out[12 * (size_t)i + k] = (float)T[16 * (size_t)i + k];
+  if (F_out) {
+    size_t idx = 0;
+    for (int i = 0; i < n_cam; ++i) {
+      const double *Mi = T + 16 * (size_t)i;
+      double Ci[4];
+      for (int a = 0; a < 3; ++a) Ci[a] = -(Mi[0 * 4 + a] * Mi[3] + Mi[1 * 4 + a] * Mi[7] + Mi[2 * 4 + a] * Mi[11]);
+      Ci[3] = 1.0;
+      double Pinv[12];
+      pinv34(Mi, Pinv);
+      for (int j = i + 1; j < n_cam; ++j, ++idx) {
+        const double *Pj = T + 16 * (size_t)j;
+        double e[3];
+        for (int a = 0; a < 3; ++a) {
+          e[a] = 0;
+          for (int k = 0; k < 4; ++k) e[a] += Pj[a * 4 + k] * Ci[k];
+        }
+        const double ex[9] = {0, -e[2], e[1], e[2], 0, -e[0], -e[1], e[0], 0};
+        double M[9];
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += Pj[a * 4 + k] * Pinv[k * 3 + b];
+            M[a * 3 + b] = s;
+          }
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += ex[a * 3 + k] * M[k * 3 + b];
+            F_out[9 * idx + a * 3 + b] = (float)s;
+          }
+      }
+    }
+  }
+  return SE3D_OK;
+}
+
+se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d_limits *limits, int32_t device_id) {
+  if (!rig || !params || !limits || !rig->Rt || !rig->K || !rig->F) return nullptr;
+  const int N = rig->n_cam, B = limits->max_frames, P = limits->max_det_per_cam, H = limits->max_hyp;
+  if (N < 2 || N > SE3D_MAX_CAMS || B < 1 || P < 1 || P > SE3D_MUNKRES_MAX || H < P || H > SE3D_MUNKRES_MAX) {
+    fprintf(stderr, "se3d_create: unsupported sizes (n_cam %d [2..%d], det/cam %d [1..%d], hyp %d [det..%d])\n", N, SE3D_MAX_CAMS, P,
+            SE3D_MUNKRES_MAX, H, SE3D_MUNKRES_MAX);
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) {
+    fprintf(stderr, "se3d_create: no usable HIP device (count=%d, requested=%d); there is no CPU fallback\n", ndev, device_id);
+    return nullptr;
+  }
+  se3d_ctx *c = new se3d_ctx();
+  c->params = *params;
+  c->limits = *limits;
+  c->device = device_id;
+  if (!hip_ok(c, hipSetDevice(device_id), "hipSetDevice")) { fprintf(stderr, "%s\n", c->err.c_str()); delete c; return nullptr; }
+  if (!hip_ok(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return nullptr; }
+  for (auto &e : c->ev) (void)hipEventCreate(&e);
+  Se3dDev &D = c->D;
+  const int np = N * (N - 1) / 2;
+  D.d = Se3dDims{B, N, P, H, np, params->pose_method, params->norm_height, params->max_epi_dist};
+  bool ok = true;
+  float *dRt = nullptr, *dK = nullptr, *dF = nullptr;
+  se3d_person2d *draw = nullptr;
+  int32_t *dnraw = nullptr;
+  ok = ok && dev_alloc(c, &dRt, (size_t)N * 12) && dev_alloc(c, &dK, (size_t)N * 4) && dev_alloc(c, &dF, (size_t)np * 9);
+  ok = ok && dev_alloc(c, &draw, (size_t)B * N * P) && dev_alloc(c, &dnraw, (size_t)B * N);
+  ok = ok && dev_alloc(c, &D.kp, (size_t)B * N * P * SE3D_NKP) && dev_alloc(c, &D.kcov, (size_t)B * N * P * SE3D_NKP);
+  ok = ok && dev_alloc(c, &D.pscore, (size_t)B * N * P) && dev_alloc(c, &D.vmask_gt, (size_t)B * N * P) && dev_alloc(c, &D.vmask_ge, (size_t)B * N * P);
+  ok = ok && dev_alloc(c, &D.nvalid, (size_t)B * N) && dev_alloc(c, &D.orig, (size_t)B * N * P);
+  ok = ok && dev_alloc(c, &D.pair, (size_t)B * np * P * P);
+  ok = ok && dev_alloc(c, &D.assoc, (size_t)B * H * N) && dev_alloc(c, &D.nviews, (size_t)B * H) && dev_alloc(c, &D.nhyp, (size_t)B);
+  ok = ok && dev_alloc(c, &D.C, (size_t)B * H * P) && dev_alloc(c, &D.mask, (size_t)B * H * P) && dev_alloc(c, &D.mwork, (size_t)B * H * P);
+  ok = ok && dev_alloc(c, &D.flags, (size_t)B);
+  ok = ok && dev_alloc(c, &D.hypP, (size_t)B * H) && dev_alloc(c, &D.keep, (size_t)B * H) && dev_alloc(c, &D.outP, (size_t)B * H);
+  ok = ok && dev_alloc(c, &D.out_count, (size_t)B) && dev_alloc(c, &D.out_hyp, (size_t)B * H) && dev_alloc(c, &D.out_assoc, (size_t)B * H * N);
+  ok = ok && dev_alloc(c, &c->pair_ab, (size_t)np);
+  if (ok) {
+    D.Rt = dRt; D.K = dK; D.F = dF; D.raw = draw; D.nraw = dnraw;
+    std::vector<int2> ab(np);
+    for (int i = 0, idx = 0; i < N; ++i)
+      for (int j = i + 1; j < N; ++j, ++idx) ab[idx] = make_int2(i, j);
+    ok = ok && hip_ok(c, hipMemcpy(dRt, rig->Rt, sizeof(float) * N * 12, hipMemcpyHostToDevice), "copy Rt");
+    ok = ok && hip_ok(c, hipMemcpy(dK, rig->K, sizeof(float) * N * 4, hipMemcpyHostToDevice), "copy K");
+    ok = ok && hip_ok(c, hipMemcpy(dF, rig->F, sizeof(float) * np * 9, hipMemcpyHostToDevice), "copy F");
+    ok = ok && hip_ok(c, hipMemcpy(c->pair_ab, ab.data(), sizeof(int2) * np, hipMemcpyHostToDevice), "copy pair_ab");
+    ok = ok && hip_ok(c, hipMemset(draw, 0, sizeof(se3d_person2d) * (size_t)B * N * P), "memset raw");
+    ok = ok && hip_ok(c, hipMemset(dnraw, 0, sizeof(int32_t) * (size_t)B * N), "memset nraw");
+    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_raw, sizeof(se3d_person2d) * (size_t)B * N * P, hipHostMallocDefault), "hipHostMalloc raw");
+    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_nraw, sizeof(int32_t) * (size_t)B * N, hipHostMallocDefault), "hipHostMalloc nraw");
+    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_out, sizeof(se3d_person3d) * (size_t)B * H, hipHostMallocDefault), "hipHostMalloc out");
+    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_count, sizeof(int32_t) * (size_t)B, hipHostMallocDefault), "hipHostMalloc");
+    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_nhyp, sizeof(int32_t) * (size_t)B, hipHostMallocDefault), "hipHostMalloc");
+    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_flags, sizeof(uint32_t) * (size_t)B, hipHostMallocDefault), "hipHostMalloc");
+    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_outhyp, sizeof(int32_t) * (size_t)B * H, hipHostMallocDefault), "hipHostMalloc");
+    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_outassoc, sizeof(int32_t) * (size_t)B * H * N, hipHostMallocDefault), "hipHostMalloc");
+  }
+  if (!ok) {
+    fprintf(stderr, "se3d_create failed: %s\n", c->err.c_str());
+    se3d_destroy(c);
+    return nullptr;
+  }
+  c->tiled = P > 16;
+  if (const char *e = getenv("SE3D_PAIRS")) c->tiled = (strcmp(e, "tiled") == 0);
+  return c;
+}
+
+void se3d_destroy(se3d_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (void *p : c->allocs) (void)hipFree(p);
+  if (c->h_raw) (void)hipHostFree(c->h_raw);
+  if (c->h_nraw) (void)hipHostFree(c->h_nraw);
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->h_count) (void)hipHostFree(c->h_count);
+  if (c->h_nhyp) (void)hipHostFree(c->h_nhyp);
+  if (c->h_flags) (void)hipHostFree(c->h_flags);
+  if (c->h_outhyp) (void)hipHostFree(c->h_outhyp);
+  if (c->h_outassoc) (void)hipHostFree(c->h_outassoc);
+  for (auto &e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *se3d_last_error(const se3d_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int se3d_stage_frames(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames) {
+  if (!c || !frames || n_frames < 1) return SE3D_ERR_ARG;
+  const int B = c->D.d.B, N = c->D.d.N, P = c->D.d.P;
+  if (n_frames > B) { c->err = "n_frames exceeds limits.max_frames"; return SE3D_ERR_CAPACITY; }
+  HIPCHK(c, hipSetDevice(c->device));
+  memset(c->h_nraw, 0, sizeof(int32_t) * (size_t)B * N);
+  for (int f = 0; f < n_frames; ++f) {
+    const se3d_frame_in &fr = frames[f];
+    if (fr.n_cam != N || !fr.det_offset || (fr.det_offset[N] > 0 && !fr.persons)) { c->err = "bad frame"; return SE3D_ERR_ARG; }
+    for (int cam = 0; cam < N; ++cam) {
+      const int n = fr.det_offset[cam + 1] - fr.det_offset[cam];
+      if (n < 0) { c->err = "det_offset not monotone"; return SE3D_ERR_ARG; }
+      if (n > P) { c->err = "detections per camera exceed limits.max_det_per_cam"; return SE3D_ERR_CAPACITY; }
+      c->h_nraw[f * N + cam] = n;
+      if (n) memcpy(c->h_raw + ((size_t)(f * N + cam)) * P, fr.persons + fr.det_offset[cam], sizeof(se3d_person2d) * (size_t)n);
+    }
+  }
+  HIPCHK(c, hipMemcpyAsync((void *)c->D.raw, c->h_raw, sizeof(se3d_person2d) * (size_t)n_frames * N * P, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync((void *)c->D.nraw, c->h_nraw, sizeof(int32_t) * (size_t)B * N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->staged_frames = n_frames;
+  c->ran = false;
+  return SE3D_OK;
+}
+
+int se3d_run_stage1(se3d_ctx *c) {
+  if (!c) return SE3D_ERR_ARG;
+  if (c->staged_frames < 1) { c->err = "no frames staged"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const Se3dDev &D = c->D;
+  const int B = D.d.B, N = D.d.N, H = D.d.H;
+  collect_profile(c);
+  HIPCHK(c, hipMemsetAsync(D.assoc, 0xFF, sizeof(int32_t) * (size_t)B * H * N, c->stream));
+  HIPCHK(c, hipMemsetAsync(D.nviews, 0, sizeof(int32_t) * (size_t)B * H, c->stream));
+  HIPCHK(c, hipMemsetAsync(D.nhyp, 0, sizeof(int32_t) * (size_t)B, c->stream));
+  HIPCHK(c, hipMemsetAsync(D.flags, 0, sizeof(uint32_t) * (size_t)B, c->stream));
+  HIPCHK(c, hipMemsetAsync(D.hypP, 0, sizeof(se3d_person3d) * (size_t)B * H, c->stream));
+  se3d_launch_stage1(D, c->pair_ab, c->stream, c->prof ? c->ev : nullptr, c->tiled);
+  HIPCHK(c, hipGetLastError());
+  c->prof_pending = c->prof;
+  c->ran = true;
+  return SE3D_OK;
+}
+
+int se3d_sync(se3d_ctx *c) {
+  if (!c) return SE3D_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  collect_profile(c);
+  return SE3D_OK;
+}
+
+int se3d_fetch_stage1(se3d_ctx *c, int32_t n_frames, se3d_frame_out *outs) {
+  if (!c || !outs || n_frames < 1) return SE3D_ERR_ARG;
+  if (!c->ran || n_frames > c->staged_frames) { c->err = "fetch before run"; return SE3D_ERR_STATE; }
+  const Se3dDev &D = c->D;
+  const int N = D.d.N, H = D.d.H;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->h_out, D.outP, sizeof(se3d_person3d) * (size_t)n_frames * H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_count, D.out_count, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_nhyp, D.nhyp, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_flags, D.flags, sizeof(uint32_t) * (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_outhyp, D.out_hyp, sizeof(int32_t) * (size_t)n_frames * H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_outassoc, D.out_assoc, sizeof(int32_t) * (size_t)n_frames * H * N, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  collect_profile(c);
+  int rc = SE3D_OK;
+  for (int f = 0; f < n_frames; ++f) {
+    se3d_frame_out &o = outs[f];
+    const int np = c->h_count[f];
+    o.n_hyp = c->h_nhyp[f];
+    o.flags = c->h_flags[f];
+    if (np > o.capacity) { o.n_persons = 0; c->err = "output capacity too small"; rc = SE3D_ERR_CAPACITY; continue; }
+    o.n_persons = np;
+    if (np && o.persons) memcpy(o.persons, c->h_out + (size_t)f * H, sizeof(se3d_person3d) * (size_t)np);
+    if (np && o.person_hyp) memcpy(o.person_hyp, c->h_outhyp + (size_t)f * H, sizeof(int32_t) * (size_t)np);
+    if (o.hyp_assoc && o.hyp_capacity > 0) {
+      const int nh = o.n_hyp < o.hyp_capacity ? o.n_hyp : o.hyp_capacity;
+      if (nh) memcpy(o.hyp_assoc, c->h_outassoc + (size_t)f * H * N, sizeof(int32_t) * (size_t)nh * N);
+      if (o.n_hyp > o.hyp_capacity) o.flags |= SE3D_FLAG_HYP_OVERFLOW;
+    }
+  }
+  return rc;
+}
+
+int se3d_triangulate_batch(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames, se3d_frame_out *outs) {
+  int rc = se3d_stage_frames(c, n_frames, frames);
+  if (rc != SE3D_OK) return rc;
+  rc = se3d_run_stage1(c);
+  if (rc != SE3D_OK) return rc;
+  return se3d_fetch_stage1(c, n_frames, outs);
+}
+
+int se3d_triangulate(se3d_ctx *c, const se3d_frame_in *frame, se3d_frame_out *out) { return se3d_triangulate_batch(c, 1, frame, out); }
+
+int se3d_pack_stage1_device(se3d_ctx *c, void *d_persons, void *d_counts) {
+  if (!c || !d_persons || !d_counts) return SE3D_ERR_ARG;
+  if (!c->ran) return SE3D_ERR_STATE;
+  const Se3dDev &D = c->D;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(d_persons, D.outP, sizeof(se3d_person3d) * (size_t)D.d.B * D.d.H, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_counts, D.out_count, sizeof(int32_t) * (size_t)D.d.B, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SE3D_OK;
+}
+
+int se3d_hungarian(se3d_ctx *c, int32_t *assignment, double *cost, const double *dist, int32_t nR, int32_t nC) {
+  if (!c || !assignment || !dist || nR < 0 || nC < 0) return SE3D_ERR_ARG;
+  if (nR > SE3D_MUNKRES_MAX || nC > SE3D_MUNKRES_MAX) { c->err = "se3d_hungarian: at most 256 rows/cols"; return SE3D_ERR_CAPACITY; }
+  if (cost) *cost = 0.0;
+  for (int r = 0; r < nR; ++r) assignment[r] = -1;
+  if (nR == 0 || nC == 0) return SE3D_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  double *d_dist = nullptr;
+  int *d_assign = nullptr, *d_status = nullptr;
+  HIPCHK(c, hipMalloc((void **)&d_dist, sizeof(double) * (size_t)nR * nC));
+  HIPCHK(c, hipMalloc((void **)&d_assign, sizeof(int) * (size_t)(nR + 1)));
+  d_status = d_assign + nR;
+  HIPCHK(c, hipMemcpyAsync(d_dist, dist, sizeof(double) * (size_t)nR * nC, hipMemcpyHostToDevice, c->stream));
+  se3d_launch_munkres(d_dist, d_assign, d_status, nR, nC, c->stream);
+  std::vector<int> h(nR + 1);
+  HIPCHK(c, hipMemcpyAsync(h.data(), d_assign, sizeof(int) * (size_t)(nR + 1), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_dist);
+  (void)hipFree(d_assign);
+  if (h[nR] != 0) { c->err = "se3d_hungarian: iteration guard fired"; return SE3D_ERR_DEVICE; }
+  for (int r = 0; r < nR; ++r) {
+    assignment[r] = h[r];
+    if (cost && h[r] >= 0) *cost += dist[r + (size_t)nR * h[r]];  // computeassignmentcost (HUN:208-218)
+  }
+  return SE3D_OK;
+}
+
+int se3d_get_pair_costs(se3d_ctx *c, int32_t frame, int32_t cam_a, int32_t cam_b, double *out, int32_t *n_a, int32_t *n_b) {
+  if (!c || !out) return SE3D_ERR_ARG;
+  const Se3dDev &D = c->D;
+  if (!c->ran || frame < 0 || frame >= c->staged_frames) return SE3D_ERR_STATE;
+  if (cam_a < 0 || cam_b <= cam_a || cam_b >= D.d.N) return SE3D_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int P = D.d.P;
+  const size_t off = ((size_t)frame * D.d.npairs + se3d_pair_index(cam_a, cam_b, D.d.N)) * P * P;
+  int32_t nv[2];
+  HIPCHK(c, hipMemcpyAsync(out, D.pair + off, sizeof(double) * (size_t)P * P, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&nv[0], D.nvalid + frame * D.d.N + cam_a, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&nv[1], D.nvalid + frame * D.d.N + cam_b, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n_a) *n_a = nv[0];
+  if (n_b) *n_b = nv[1];
+  return SE3D_OK;
+}
+
+int se3d_profile_enable(se3d_ctx *c, int32_t on) {
+  if (!c) return SE3D_ERR_ARG;
+  collect_profile(c);
+  c->prof = on != 0;
+  return SE3D_OK;
+}
+int se3d_profile_reset(se3d_ctx *c) {
+  if (!c) return SE3D_ERR_ARG;
+  collect_profile(c);
+  for (int i = 0; i < PS_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  return SE3D_OK;
+}
+int se3d_profile_get(se3d_ctx *c, const char *name, double *ms_total, int64_t *launches) {
+  if (!c || !name) return SE3D_ERR_ARG;
+  collect_profile(c);
+  for (int i = 0; i < PS_COUNT; ++i)
+    if (strcmp(name, kProfNames[i]) == 0) {
+      if (ms_total) *ms_total = c->prof_ms[i];
+      if (launches) *launches = c->prof_n[i];
+      return SE3D_OK;
+    }
+  return SE3D_ERR_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// se3d_device.h — device-side data layout of libse3d_hip.so (MI355X / gfx950 only).
+//
+// HBM layout (B = frames per batch, N = cameras, P = max detections per camera, H = max hypotheses):
+//   raw      [B][N][P] se3d_person2d      caller's Person2D payloads, dense-padded            (428 B each)
+//   kp       [B][N][P][17] float4         normalised (x, y, conf, 0); filtered slot order     (row N)
+//   kcov     [B][N][P][17] float4         normalised 2x2 covariance (a00, a01, a11, 0)
+//   vmask    [B][N][P] uint32 x2          bit j: conf > 0.30 (calcCost gate) / conf >= 0.30 (triangulation gate)
+//   pair     [B][N(N-1)/2][P][P] double   pairwise mean symmetric epipolar distance, -1 = no joint in common  (row E)
+//   assoc    [B][H][N] int32              filtered detection slot of hypothesis h in camera c, or -1           (row G)
+//   C, mask  [B][H*P] double / uint8      per-step cost matrix, column-major with leading dimension H
+//   hypP     [B][H] se3d_person3d         per-hypothesis triangulated person                                  (rows T,U,X)
+//   out      [B][H] se3d_person3d + counts, person_hyp, hyp_assoc (original detection indices)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/se3d.h"
+
+#define SE3D_NKP 17
+#define SE3D_NFU 21
+#define SE3D_MAX_CAMS 256   // view lists are staged in LDS per wavefront
+#define SE3D_MUNKRES_MAX 256  // rows/cols bit-mask width of the device Munkres (4 x u64)
+
+struct Se3dDims {
+  int B, N, P, H, npairs;
+  int pose_method, norm_height;
+  double max_epi;
+};
+
+struct Se3dDev {
+  Se3dDims d;
+  // rig
+  const float *Rt;  // [N][12]
+  const float *K;   // [N][4]
+  const float *F;   // [npairs][9]
+  // input
+  const se3d_person2d *raw;  // [B][N][P]
+  const int32_t *nraw;       // [B][N]
+  // normalised
+  float4 *kp;         // [B][N][P][17]
+  float4 *kcov;       // [B][N][P][17]
+  float *pscore;      // [B][N][P]
+  uint32_t *vmask_gt; // [B][N][P]
+  uint32_t *vmask_ge; // [B][N][P]
+  int32_t *nvalid;    // [B][N]
+  int32_t *orig;      // [B][N][P]
+  // association
+  double *pair;       // [B][npairs][P][P]
+  int32_t *assoc;     // [B][H][N]
+  int32_t *nviews;    // [B][H]
+  int32_t *nhyp;      // [B]
+  double *C;          // [B][H*P]
+  uint8_t *mask;      // [B][H*P]
+  double *mwork;      // [B][H*P] Munkres working copy
+  uint32_t *flags;    // [B]
+  // triangulation + output
+  se3d_person3d *hypP;   // [B][H]
+  uint8_t *keep;         // [B][H]
+  se3d_person3d *outP;   // [B][H]
+  int32_t *out_count;    // [B]
+  int32_t *out_hyp;      // [B][H]
+  int32_t *out_assoc;    // [B][H][N] original detection indices
+};
+
+__host__ __device__ inline int se3d_pair_index(int i, int j, int n) {  // get_fundamental_idx (S3D:242-253), closed form, i < j
+  return i * n - i * (i + 1) / 2 + (j - i - 1);
+}
+
+// model tables (S3D:100-103, 130-132, 139-145); index [pose_method]
+__device__ __constant__ const int c_kpParent[2][SE3D_NKP] = {{-1, 0, 0, 1, 2, 0, 0, 5, 6, 7, 8, 5, 6, 11, 12, 13, 14},
+                                                            {-1, 0, 0, 2, 3, 2, 2, 5, 6, 7, 8, 4, 4, 11, 12, 13, 14}};
+__device__ __constant__ const double c_limbLength[2][SE3D_NKP] = {
+    {-1, 0.05, 0.05, 0.10, 0.10, -1, -1, 0.28, 0.28, 0.25, 0.25, 0.50, 0.50, 0.45, 0.45, 0.446, 0.446},
+    {-1, 0.115, 0.116, 0.255, 0.238, 0.149, 0.149, 0.28, 0.28, 0.25, 0.25, 0.134, 0.134, 0.449, 0.449, 0.446, 0.446}};
+__device__ __constant__ const double c_limbLSigma[2][SE3D_NKP] = {
+    {-1, 0.05, 0.05, 0.05, 0.05, -1, -1, 0.10, 0.10, 0.10, 0.10, 0.15, 0.15, 0.10, 0.10, 0.10, 0.10},
+    {-1, 0.07, 0.07, 0.15, 0.15, 0.10, 0.10, 0.15, 0.15, 0.15, 0.15, 0.10, 0.10, 0.20, 0.20, 0.20, 0.20}};
+__device__ __constant__ const int c_kp2fusion[2][SE3D_NKP] = {{0, 16, 15, 18, 17, 5, 2, 6, 3, 7, 4, 12, 9, 13, 10, 14, 11},
+                                                             {0, 19, 1, 20, 8, 5, 2, 6, 3, 7, 4, 12, 9, 13, 10, 14, 11}};
+
+// FUSION_BODY_PARTS indices used by the post-processing (FBP:3-24)
+enum { FU_Nose = 0, FU_Neck = 1, FU_RShoulder = 2, FU_LShoulder = 5, FU_MidHip = 8, FU_RHip = 9, FU_RAnkle = 11, FU_LHip = 12, FU_LAnkle = 14, FU_Belly = 20 };

@@ -1,0 +1,886 @@
+// se3d_stage1.hip — CDNA4 (gfx950) kernels for the skeleton_3d hot path: normalisation, pairwise epipolar cost table,
+// greedy cross-view association (cost gather + assignment with device Munkres), per-joint DLT triangulation with
+// outlier rejection and unscented-transform covariance, per-person post-processing and duplicate merge.
+// Reference rows: N S3D:312-333 · E S3D:335-390 · G S3D:565-674 · M HUN:60-397 · T S3D:440-465 ·
+// P S3D:425-438 · O S3D:748-844 · U S3D:471-523 · X S3D:849-973 · D S3D:392-423,984-996.
+//
+// Compile with -ffp-contract=off: the float32 geometry that decides association indices must round exactly like the
+// reference's SSE2 build (no FMA); fp64 kernels that want FMA call __builtin_fma explicitly.
+#include "se3d_device.h"
+#include "se3d_munkres.h"
+
+#define TRI_THRESH 0.30f
+#define REPROJ_MAX 0.050
+#define MAX_COSTS 1e6
+
+// =============================================================================================================
+// row N — normalize_keypoints (S3D:312-333) + ">= 9 valid keypoints" filter (S3D:579, 599) with order-preserving
+// compaction of the surviving detections.  One workgroup per (camera, frame).
+// =============================================================================================================
+__global__ __launch_bounds__(256) void se3d_k_normalize(Se3dDev D) {
+  const int c = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const int N = D.d.N, P = D.d.P;
+  __shared__ int cnt[SE3D_MUNKRES_MAX];
+  __shared__ int slot[SE3D_MUNKRES_MAX];
+  __shared__ unsigned mgt[SE3D_MUNKRES_MAX], mge[SE3D_MUNKRES_MAX];
+  __shared__ int s_nvalid;
+  const int n = min(D.nraw[f * N + c], P);
+  for (int r = tid; r < P; r += blockDim.x) { cnt[r] = 0; mgt[r] = 0; mge[r] = 0; }
+  __syncthreads();
+  const se3d_person2d *raw = D.raw + ((size_t)(f * N + c)) * P;
+  for (int idx = tid; idx < n * SE3D_NKP; idx += blockDim.x) {
+    const int det = idx / SE3D_NKP, j = idx - det * SE3D_NKP;
+    if (raw[det].keypoints[j].score >= TRI_THRESH) atomicAdd(&cnt[det], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int k = 0;
+    for (int det = 0; det < n; ++det) slot[det] = (cnt[det] > SE3D_NKP / 2) ? k++ : -1;
+    s_nvalid = k;
+  }
+  __syncthreads();
+  const float fx = D.K[c * 4 + 0], fy = D.K[c * 4 + 1], cx = D.K[c * 4 + 2], cy = D.K[c * 4 + 3];
+  const size_t base = ((size_t)(f * N + c)) * P;
+  for (int idx = tid; idx < n * SE3D_NKP; idx += blockDim.x) {
+    const int det = idx / SE3D_NKP, j = idx - det * SE3D_NKP;
+    const int k = slot[det];
+    if (k < 0) continue;
+    const se3d_keypoint2d kp = raw[det].keypoints[j];
+    float4 o = make_float4(0.f, 0.f, -1.f, 0.f), oc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kp.score >= TRI_THRESH) {
+      o = make_float4((kp.x - cx) / fx, (kp.y - cy) / fy, kp.score, 0.f);
+      oc = make_float4(kp.cov[0] / (fx * fx), kp.cov[1] / (fx * fy), kp.cov[2] / (fy * fy), 0.f);
+      atomicOr(&mge[k], 1u << j);
+      if (kp.score > TRI_THRESH) atomicOr(&mgt[k], 1u << j);
+    }
+    D.kp[(base + k) * SE3D_NKP + j] = o;
+    D.kcov[(base + k) * SE3D_NKP + j] = oc;
+  }
+  __syncthreads();
+  for (int det = tid; det < n; det += blockDim.x) {
+    const int k = slot[det];
+    if (k >= 0) {
+      D.pscore[base + k] = raw[det].score;
+      D.orig[base + k] = det;
+      D.vmask_gt[base + k] = mgt[k];
+      D.vmask_ge[base + k] = mge[k];
+    }
+  }
+  if (tid == 0) D.nvalid[f * N + c] = s_nvalid;
+}
+
+// =============================================================================================================
+// row E (inner) — symmetric epipolar distance of one (view-a detection, view-b detection) pair, exactly the float
+// expression tree of calcCost (S3D:353-365) with Eigen's fixed-size evaluation order a0 + (a1 + a2).
+// =============================================================================================================
+__device__ __forceinline__ double se3d_pair_cost(const float *__restrict__ F, const float4 *__restrict__ ka, const float4 *__restrict__ kb,
+                                                 unsigned m) {
+  double cost = 0.0;
+  int n = 0;
+  const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
+#pragma unroll
+  for (int k = 0; k < SE3D_NKP; ++k) {
+    if ((m >> k) & 1u) {
+      const float4 A = ka[k], Bq = kb[k];
+      const float p1x = A.x, p1y = A.y, p2x = Bq.x, p2y = Bq.y;
+      const float l1x = f0 * p1x + (f1 * p1y + f2);
+      const float l1y = f3 * p1x + (f4 * p1y + f5);
+      const float l1z = f6 * p1x + (f7 * p1y + f8);
+      const float l2x = f0 * p2x + (f3 * p2y + f6);
+      const float l2y = f1 * p2x + (f4 * p2y + f7);
+      const float l2z = f2 * p2x + (f5 * p2y + f8);
+      const float d1 = fabsf(p2x * l1x + (p2y * l1y + l1z)) / sqrtf(l1x * l1x + l1y * l1y);
+      const float d2 = fabsf(p1x * l2x + (p1y * l2y + l2z)) / sqrtf(l2x * l2x + l2y * l2y);
+      cost += (double)(d1 + d2);
+      ++n;
+    }
+  }
+  return n > 0 ? cost / n : -1.0;
+}
+
+// flat variant: one thread per (frame, pair, det_a, det_b); used for small P
+__global__ __launch_bounds__(256) void se3d_k_pairs_flat(Se3dDev D, const int2 *__restrict__ pair_ab) {
+  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
+  const size_t total = (size_t)D.d.B * np * P * P;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % P);
+    const int p = (int)((i / P) % P);
+    const int pr = (int)((i / ((size_t)P * P)) % np);
+    const int f = (int)(i / ((size_t)P * P * np));
+    const int2 ab = pair_ab[pr];
+    if (p >= D.nvalid[f * N + ab.x] || q >= D.nvalid[f * N + ab.y]) continue;
+    const size_t ia = ((size_t)(f * N + ab.x)) * P + p, ib = ((size_t)(f * N + ab.y)) * P + q;
+    const unsigned m = D.vmask_gt[ia] & D.vmask_gt[ib];
+    D.pair[i] = se3d_pair_cost(D.F + 9 * (size_t)pr, D.kp + ia * SE3D_NKP, D.kp + ib * SE3D_NKP, m);
+  }
+}
+
+// tiled variant for large P: one workgroup per (64x64 tile of det_a x det_b, camera pair, frame).
+// The epipolar line of a point depends on one side only, so l1 = F p1 (+ its norm) is computed once per (det_a, joint)
+// and l2 = F^T p2 once per (det_b, joint) and staged in LDS; the inner loop is 2 dot products, 2 IEEE divides and one
+// fp64 add per pair-joint.  All float operations are the ones of se3d_pair_cost in the same order -> bit-identical.
+#define PT 64
+struct __align__(16) LineLDS { float lx, ly, lz, nrm; };
+__global__ __launch_bounds__(256) void se3d_k_pairs_tiled(Se3dDev D, const int2 *__restrict__ pair_ab) {
+  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
+  const int tiles = (P + PT - 1) / PT;
+  const int tp = blockIdx.x / tiles, tq = blockIdx.x % tiles;
+  const int pr = blockIdx.y, f = blockIdx.z;
+  const int2 ab = pair_ab[pr];
+  const int na = D.nvalid[f * N + ab.x], nb = D.nvalid[f * N + ab.y];
+  const int p0 = tp * PT, q0 = tq * PT;
+  if (p0 >= na || q0 >= nb) return;
+  __shared__ LineLDS L1[SE3D_NKP][PT];  // [joint][det_a]
+  __shared__ LineLDS L2[SE3D_NKP][PT];
+  __shared__ float2 P1[SE3D_NKP][PT];
+  __shared__ float2 P2[SE3D_NKP][PT];
+  __shared__ unsigned M1[PT], M2[PT];
+  const int tid = threadIdx.x;
+  const float *F = D.F + 9 * (size_t)pr;
+  const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
+  const size_t baseA = ((size_t)(f * N + ab.x)) * P, baseB = ((size_t)(f * N + ab.y)) * P;
+  for (int i = tid; i < PT * SE3D_NKP; i += 256) {
+    const int d = i / SE3D_NKP, k = i - d * SE3D_NKP;
+    {
+      const int p = p0 + d;
+      float4 A = make_float4(0.f, 0.f, -1.f, 0.f);
+      if (p < na) A = D.kp[(baseA + p) * SE3D_NKP + k];
+      const float l1x = f0 * A.x + (f1 * A.y + f2);
+      const float l1y = f3 * A.x + (f4 * A.y + f5);
+      const float l1z = f6 * A.x + (f7 * A.y + f8);
+      LineLDS l;
+      l.lx = l1x; l.ly = l1y; l.lz = l1z; l.nrm = sqrtf(l1x * l1x + l1y * l1y);
+      L1[k][d] = l;
+      P1[k][d] = make_float2(A.x, A.y);
+    }
+    {
+      const int q = q0 + d;
+      float4 Bq = make_float4(0.f, 0.f, -1.f, 0.f);
+      if (q < nb) Bq = D.kp[(baseB + q) * SE3D_NKP + k];
+      const float l2x = f0 * Bq.x + (f3 * Bq.y + f6);
+      const float l2y = f1 * Bq.x + (f4 * Bq.y + f7);
+      const float l2z = f2 * Bq.x + (f5 * Bq.y + f8);
+      LineLDS l;
+      l.lx = l2x; l.ly = l2y; l.lz = l2z; l.nrm = sqrtf(l2x * l2x + l2y * l2y);
+      L2[k][d] = l;
+      P2[k][d] = make_float2(Bq.x, Bq.y);
+    }
+  }
+  for (int d = tid; d < PT; d += 256) {
+    M1[d] = (p0 + d < na) ? D.vmask_gt[baseA + p0 + d] : 0u;
+    M2[d] = (q0 + d < nb) ? D.vmask_gt[baseB + q0 + d] : 0u;
+  }
+  __syncthreads();
+  // thread (ty, tx): det_a rows ty + 16*i, det_b cols tx + 16*k   (tx fastest -> coalesced stores over q)
+  const int tx = tid & 15, ty = tid >> 4;
+  double acc[4][4];
+  unsigned mm[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { acc[i][k] = 0.0; mm[i][k] = M1[ty + 16 * i] & M2[tx + 16 * k]; }
+  for (int j = 0; j < SE3D_NKP; ++j) {
+    LineLDS l1[4], l2[4];
+    float2 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { l1[i] = L1[j][ty + 16 * i]; a[i] = P1[j][ty + 16 * i]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { l2[k] = L2[j][tx + 16 * k]; b[k] = P2[j][tx + 16 * k]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d1 = fabsf(b[k].x * l1[i].lx + (b[k].y * l1[i].ly + l1[i].lz)) / l1[i].nrm;
+        const float d2 = fabsf(a[i].x * l2[k].lx + (a[i].y * l2[k].ly + l2[k].lz)) / l2[k].nrm;
+        const float s = d1 + d2;
+        if ((mm[i][k] >> j) & 1u) acc[i][k] += (double)s;
+      }
+  }
+  double *out = D.pair + ((size_t)f * np + pr) * P * P;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = p0 + ty + 16 * i;
+    if (p >= na) continue;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = q0 + tx + 16 * k;
+      if (q >= nb) continue;
+      const int n = __popc(mm[i][k]);
+      out[(size_t)p * P + q] = n > 0 ? acc[i][k] / n : -1.0;
+    }
+  }
+}
+
+// =============================================================================================================
+// row G (cost) — C(hyp, det) of calcCost for sweep step `b` (S3D:616-626 -> 335-390) gathered from the pair table in the
+// reference's accumulation order (ascending attached view).  One workgroup per (hypothesis, frame), lanes over dets.
+// =============================================================================================================
+__global__ __launch_bounds__(128) void se3d_k_sweep_cost(Se3dDev D, int b) {
+  const int h = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
+  if (D.nraw[f * N + b] == 0) return;
+  const int nh = D.nhyp[f];
+  if (nh == 0 || h >= nh) return;
+  const int nd = D.nvalid[f * N + b];
+  if (nd == 0) return;
+  __shared__ int sk[SE3D_MAX_CAMS];
+  __shared__ float ss[SE3D_MAX_CAMS];
+  const int32_t *arow = D.assoc + ((size_t)f * H + h) * N;
+  for (int a = tid; a < b; a += blockDim.x) {
+    const int k = arow[a];
+    sk[a] = k;
+    ss[a] = (k >= 0) ? D.pscore[((size_t)(f * N + a)) * P + k] : 0.f;
+  }
+  __syncthreads();
+  const int n_obs = D.nviews[f * H + h];
+  const double max_epi = D.d.max_epi;
+  const double tolerance = 1.0 - 1.0 / (2 * n_obs), veto_delta = 1.0 / n_obs;
+  const double *tab = D.pair + (size_t)f * np * P * P;
+  for (int q = tid; q < nd; q += blockDim.x) {
+    double total = 0.0;
+    int nused = 0, cnt = 0;
+    for (int a = 0; a < b; ++a) {
+      const int k = sk[a];
+      if (k < 0) continue;
+      const double c = tab[((size_t)se3d_pair_index(a, b, N) * P + k) * P + q];
+      if (c >= 0.0) {  // n_joints_used > 0
+        total += c;
+        ++nused;
+        if (c > max_epi && (ss[a] > 0.5f || n_obs == 1)) ++cnt;
+      }
+    }
+    bool veto = false;
+    if (cnt > 0) {  // tmp_veto accumulates veto_delta once per offending view (S3D:371-381)
+      double tmp = 0.0;
+      for (int i = 0; i < cnt; ++i) tmp += veto_delta;
+      veto = tmp > tolerance;
+    }
+    double C;
+    if (nused > 0) C = total / nused;
+    else { C = MAX_COSTS; veto = true; }
+    D.C[(size_t)f * H * P + h + (size_t)H * q] = C;
+    D.mask[(size_t)f * H * P + h + (size_t)H * q] = (!veto && C < max_epi) ? 1 : 0;
+  }
+}
+
+// =============================================================================================================
+// row G (assignment) + row M — one workgroup per frame: seeding (S3D:565-586), feasibility mask bookkeeping,
+// Hungarian only when ambiguous (S3D:628-634), attach / spawn (S3D:636-673).
+// =============================================================================================================
+__device__ __forceinline__ int se3d_block_excl_scan(bool flag, int *wsum /*LDS[5]*/, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long b = __ballot(flag);
+  const int within = __popcll(b & ((1ull << lane) - 1ull));
+  if (lane == 0) wsum[wave] = __popcll(b);
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wave; ++w) off += wsum[w];
+  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  return off + within;
+}
+
+__global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  if (D.nraw[f * N + b] == 0) return;  // camera without any detection is not part of the sweep (S3D:538-555)
+  const int nh = D.nhyp[f];
+  const int nd = D.nvalid[f * N + b];
+  int32_t *assoc = D.assoc + (size_t)f * H * N;
+  if (nh == 0) {  // seeding from the first camera with a valid person (S3D:565-586)
+    for (int k = tid; k < nd && k < H; k += 256) { assoc[(size_t)k * N + b] = k; D.nviews[f * H + k] = 1; }
+    if (tid == 0) D.nhyp[f] = min(nd, H);
+    return;
+  }
+  if (nd == 0) return;
+  __shared__ MunkresShared S;
+  __shared__ int assign[SE3D_MUNKRES_MAX];
+  __shared__ int spawn[SE3D_MUNKRES_MAX];
+  __shared__ int handled[SE3D_MUNKRES_MAX];
+  __shared__ int s_amb;
+  __shared__ int wsum[4];
+  const uint8_t *mask = D.mask + (size_t)f * H * P;
+  if (tid == 0) s_amb = 0;
+  for (int i = tid; i < SE3D_MUNKRES_MAX; i += 256) { handled[i] = 0; spawn[i] = -1; assign[i] = -1; }
+  __syncthreads();
+  for (int h = tid; h < nh; h += 256) {  // row counts + provisional assignment "last feasible det wins" (S3D:620-623)
+    int cnt = 0, last = -1;
+    for (int q = 0; q < nd; ++q)
+      if (mask[h + (size_t)H * q]) { ++cnt; last = q; }
+    assign[h] = last;
+    if (cnt > 1) s_amb = 1;
+  }
+  for (int q = tid; q < nd; q += 256) {
+    int cnt = 0;
+    for (int h = 0; h < nh; ++h) cnt += mask[h + (size_t)H * q];
+    if (cnt > 1) s_amb = 1;
+  }
+  __syncthreads();
+  if (s_amb) {  // more than one feasible association: Hungarian on the full (unmasked) C (S3D:628-634)
+    const double *C = D.C + (size_t)f * H * P;
+    double *W = D.mwork + (size_t)f * H * P;
+    for (int q = 0; q < nd; ++q)
+      for (int h = tid; h < nh; h += 256) W[h + (size_t)H * q] = C[h + (size_t)H * q];
+    __syncthreads();
+    if (se3d_munkres_block(W, H, nh, nd, S, assign) != 0 && tid == 0) atomicOr(&D.flags[f], 4u);
+  }
+  // attach or spawn (S3D:636-660)
+  bool sp = false;
+  int det = -1;
+  if (tid < nh) {
+    det = assign[tid];
+    if (det >= 0) {
+      handled[det] = 1;
+      if (mask[tid + (size_t)H * det]) {
+        assoc[(size_t)tid * N + b] = det;
+        D.nviews[f * H + tid] += 1;
+      } else {
+        sp = true;
+      }
+    }
+  }
+  __syncthreads();
+  int tot1, tot2;
+  const int i1 = se3d_block_excl_scan(sp, wsum, tot1);
+  if (sp) {
+    const int nhh = nh + i1;
+    if (nhh < H) { assoc[(size_t)nhh * N + b] = det; D.nviews[f * H + nhh] = 1; }
+  }
+  const bool un = (tid < nd) && !handled[tid];  // unassigned detections become new hypotheses (S3D:662-673)
+  const int i2 = se3d_block_excl_scan(un, wsum, tot2);
+  if (un) {
+    const int nhh = nh + tot1 + i2;
+    if (nhh < H) { assoc[(size_t)nhh * N + b] = tid; D.nviews[f * H + nhh] = 1; }
+  }
+  if (tid == 0) {
+    const int nn = nh + tot1 + tot2;
+    if (nn > H) atomicOr(&D.flags[f], SE3D_FLAG_HYP_OVERFLOW);
+    D.nhyp[f] = min(nn, H);
+  }
+}
+
+// =============================================================================================================
+// rows T, P, O, U — one wavefront per (hypothesis, joint).
+// Null vector of the 2n x 4 DLT system = eigenvector of the smallest eigenvalue of the 4x4 Gram matrix A^T A.
+// Rows are built and L2-normalised in float exactly like the reference (S3D:446-453); the Gram matrix is accumulated and
+// decomposed in fp64 (cyclic Jacobi), which is far more accurate than the reference's float JacobiSVD (SURVEY §8a row T:
+// any sound null-vector method is within 0.04 mm).  Leave-one-out candidates and the 4n+1 sigma points of the unscented
+// transform are rank-<=4 updates of the base Gram matrix, spread over the 64 lanes.
+// =============================================================================================================
+__device__ __forceinline__ void se3d_eig4_smallest(const double g[10], double v[4]) {
+  // g packed: 00 01 02 03 11 12 13 22 23 33
+  double a[4][4] = {{g[0], g[1], g[2], g[3]}, {g[1], g[4], g[5], g[6]}, {g[2], g[5], g[7], g[8]}, {g[3], g[6], g[8], g[9]}};
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+#define SE3D_ROT(p, q)                                                                        \
+  {                                                                                           \
+    const double apq = a[p][q];                                                               \
+    const double scale_ = fabs(a[p][p]) + fabs(a[q][q]);                                      \
+    if (fabs(apq) > 1e-40 * scale_ && apq != 0.0) {                                           \
+      const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);                                 \
+      const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
+      const double c = 1.0 / sqrt(t * t + 1.0);                                               \
+      const double s = t * c;                                                                 \
+      a[p][p] -= t * apq;                                                                     \
+      a[q][q] += t * apq;                                                                     \
+      a[p][q] = 0.0;                                                                          \
+      a[q][p] = 0.0;                                                                          \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                         \
+        if (r != p && r != q) {                                                               \
+          const double arp = a[r][p], arq = a[r][q];                                          \
+          a[r][p] = c * arp - s * arq;                                                        \
+          a[p][r] = a[r][p];                                                                  \
+          a[r][q] = s * arp + c * arq;                                                        \
+          a[q][r] = a[r][q];                                                                  \
+        }                                                                                     \
+      }                                                                                       \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                         \
+        const double vrp = V[r][p], vrq = V[r][q];                                            \
+        V[r][p] = c * vrp - s * vrq;                                                          \
+        V[r][q] = s * vrp + c * vrq;                                                          \
+      }                                                                                       \
+    }                                                                                         \
+  }
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[0][3] * a[0][3] + a[1][2] * a[1][2] + a[1][3] * a[1][3] + a[2][3] * a[2][3];
+    const double tr = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]) + fabs(a[3][3]);
+    if (off <= 1e-34 * tr * tr) break;
+    SE3D_ROT(0, 1) SE3D_ROT(0, 2) SE3D_ROT(0, 3) SE3D_ROT(1, 2) SE3D_ROT(1, 3) SE3D_ROT(2, 3)
+  }
+#undef SE3D_ROT
+  int m = 0;
+  double dm = a[0][0];
+  if (a[1][1] < dm) { dm = a[1][1]; m = 1; }
+  if (a[2][2] < dm) { dm = a[2][2]; m = 2; }
+  if (a[3][3] < dm) { dm = a[3][3]; m = 3; }
+  v[0] = (m == 0) ? V[0][0] : (m == 1) ? V[0][1] : (m == 2) ? V[0][2] : V[0][3];
+  v[1] = (m == 0) ? V[1][0] : (m == 1) ? V[1][1] : (m == 2) ? V[1][2] : V[1][3];
+  v[2] = (m == 0) ? V[2][0] : (m == 1) ? V[2][1] : (m == 2) ? V[2][2] : V[2][3];
+  v[3] = (m == 0) ? V[3][0] : (m == 1) ? V[3][1] : (m == 2) ? V[3][2] : V[3][3];
+}
+
+// rows of the DLT system for one view: r0 = normalize(x*P2 - P0), r1 = normalize(y*P2 - P1)  (float, S3D:446-449)
+__device__ __forceinline__ void se3d_dlt_rows(const float *__restrict__ M, float x, float y, float r0[4], float r1[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { r0[k] = x * M[8 + k] - M[k]; r1[k] = y * M[8 + k] - M[4 + k]; }
+  const float z0 = (r0[0] * r0[0] + r0[1] * r0[1]) + (r0[2] * r0[2] + r0[3] * r0[3]);
+  if (z0 > 0.f) { const float nn = sqrtf(z0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r0[k] = r0[k] / nn; }
+  const float z1 = (r1[0] * r1[0] + r1[1] * r1[1]) + (r1[2] * r1[2] + r1[3] * r1[3]);
+  if (z1 > 0.f) { const float nn = sqrtf(z1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r1[k] = r1[k] / nn; }
+}
+
+__device__ __forceinline__ void se3d_gram_add(double g[10], const float r[4], double sgn) {
+  const double a = r[0], b = r[1], c = r[2], d = r[3];
+  g[0] = __builtin_fma(sgn * a, a, g[0]); g[1] = __builtin_fma(sgn * a, b, g[1]); g[2] = __builtin_fma(sgn * a, c, g[2]); g[3] = __builtin_fma(sgn * a, d, g[3]);
+  g[4] = __builtin_fma(sgn * b, b, g[4]); g[5] = __builtin_fma(sgn * b, c, g[5]); g[6] = __builtin_fma(sgn * b, d, g[6]);
+  g[7] = __builtin_fma(sgn * c, c, g[7]); g[8] = __builtin_fma(sgn * c, d, g[8]);
+  g[9] = __builtin_fma(sgn * d, d, g[9]);
+}
+
+__device__ __forceinline__ double se3d_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// reprojection error of float point X in one view (S3D:430-433)
+__device__ __forceinline__ float se3d_reproj1(const float *__restrict__ M, float X, float Y, float Z, float px, float py) {
+  const float hx = (M[0] * X + (M[1] * Y + M[2] * Z)) + M[3];
+  const float hy = (M[4] * X + (M[5] * Y + M[6] * Z)) + M[7];
+  const float hz = (M[8] * X + (M[9] * Y + M[10] * Z)) + M[11];
+  const float dx = hx / hz - px, dy = hy / hz - py;
+  return sqrtf(dx * dx + dy * dy);
+}
+
+struct TriView {  // per-wave view list in LDS (structure of arrays, stride = N)
+  float *x, *y, *cf, *ca, *cb, *cc;
+  float *r0[4], *r1[4];
+  int *cam;
+};
+
+__global__ __launch_bounds__(256) void se3d_k_triangulate(Se3dDev D) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f = blockIdx.y;
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  const int gw = blockIdx.x * 4 + wave;
+  const int h = gw / SE3D_NKP, j = gw - h * SE3D_NKP;
+  if (h >= D.nhyp[f]) return;
+  if (D.nviews[f * H + h] < 2) return;
+  float *base = reinterpret_cast<float *>(smem) + (size_t)wave * 15 * N;
+  TriView T;
+  T.x = base; T.y = base + N; T.cf = base + 2 * N; T.ca = base + 3 * N; T.cb = base + 4 * N; T.cc = base + 5 * N;
+  for (int k = 0; k < 4; ++k) { T.r0[k] = base + (6 + k) * N; T.r1[k] = base + (10 + k) * N; }
+  T.cam = reinterpret_cast<int *>(base + 14 * N);
+
+  // ---- gather the views that see this joint with conf >= 0.30 (S3D:724-732), ascending camera order ----
+  const int32_t *arow = D.assoc + ((size_t)f * H + h) * N;
+  int n = 0;
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int c = c0 + lane;
+    bool ok = false;
+    float4 kp = make_float4(0, 0, -1, 0), kc = make_float4(0, 0, 0, 0);
+    if (c < N) {
+      const int k = arow[c];
+      if (k >= 0) {
+        const size_t idx = (((size_t)(f * N + c)) * P + k) * SE3D_NKP + j;
+        kp = D.kp[idx];
+        ok = kp.z >= TRI_THRESH;
+        if (ok) kc = D.kcov[idx];
+      }
+    }
+    const unsigned long long bl = __ballot(ok);
+    if (ok) {
+      const int pos = n + __popcll(bl & ((1ull << lane) - 1ull));
+      T.x[pos] = kp.x; T.y[pos] = kp.y; T.cf[pos] = kp.z;
+      T.ca[pos] = kc.x; T.cb[pos] = kc.y; T.cc[pos] = kc.z;
+      T.cam[pos] = c;
+    }
+    n += __popcll(bl);
+  }
+  __builtin_amdgcn_wave_barrier();  // view list written by other lanes of this wave is read below
+  if (n < 2) return;  // cannot triangulate (S3D:734-736)
+
+  // ---- rows + Gram matrices: Gw (confidence weighted, S3D:450-453) and Gu (unweighted, used by the UT) ----
+  double gw_[10], gu_[10];
+  double sconf = 0.0;
+  auto build = [&](int nn) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { gw_[k] = 0.0; gu_[k] = 0.0; }
+    sconf = 0.0;
+    for (int v = lane; v < nn; v += 64) {
+      float r0[4], r1[4], w0[4], w1[4];
+      se3d_dlt_rows(D.Rt + 12 * (size_t)T.cam[v], T.x[v], T.y[v], r0, r1);
+      const float cf = T.cf[v];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { T.r0[k][v] = r0[k]; T.r1[k][v] = r1[k]; w0[k] = r0[k] * cf; w1[k] = r1[k] * cf; }
+      se3d_gram_add(gu_, r0, 1.0); se3d_gram_add(gu_, r1, 1.0);
+      se3d_gram_add(gw_, w0, 1.0); se3d_gram_add(gw_, w1, 1.0);
+      sconf += (double)cf;
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { gw_[k] = se3d_wave_sum(gw_[k]); gu_[k] = se3d_wave_sum(gu_[k]); }
+    sconf = se3d_wave_sum(sconf);
+    __builtin_amdgcn_wave_barrier();  // rows in LDS are consumed by other lanes (leave-one-out, sigma points)
+  };
+  // weighted reprojection error of float point (X,Y,Z) over views [0,nn) except `skip` (S3D:425-438)
+  auto reproj = [&](int nn, float X, float Y, float Z) -> double {
+    double se = 0.0, sc = 0.0;
+    for (int v = lane; v < nn; v += 64) {
+      const float e = se3d_reproj1(D.Rt + 12 * (size_t)T.cam[v], X, Y, Z, T.x[v], T.y[v]);
+      se += (double)(T.cf[v] * e);
+      sc += (double)T.cf[v];
+    }
+    return se3d_wave_sum(se) / se3d_wave_sum(sc);
+  };
+  auto remove_view = [&](int nn, int idx) {  // erase entry idx from the LDS list, preserving order
+    // one lane per array-row keeps it simple: entries are tiny
+    if (lane == 0) {
+      for (int v = idx; v + 1 < nn; ++v) {
+        T.x[v] = T.x[v + 1]; T.y[v] = T.y[v + 1]; T.cf[v] = T.cf[v + 1];
+        T.ca[v] = T.ca[v + 1]; T.cb[v] = T.cb[v + 1]; T.cc[v] = T.cc[v + 1]; T.cam[v] = T.cam[v + 1];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  build(n);
+  double ev[4];
+  se3d_eig4_smallest(gw_, ev);
+  float X = (float)(ev[0] / ev[3]), Y = (float)(ev[1] / ev[3]), Z = (float)(ev[2] / ev[3]);
+  double err = reproj(n, X, Y, Z);
+  float avg_score = (float)(sconf / n);
+
+  if (err > REPROJ_MAX && n == 3) {  // S3D:748-792
+    float dcand = 0.f;
+    if (lane < 3) {
+      const int i0 = (lane == 0) ? 1 : 0, i1 = (lane == 2) ? 1 : 2;
+      const float p1x = T.x[i0], p1y = T.y[i0], p2x = T.x[i1], p2y = T.y[i1];
+      const float *F = D.F + 9 * (size_t)se3d_pair_index(T.cam[i0], T.cam[i1], N);
+      const float l1x = F[0] * p1x + (F[1] * p1y + F[2]);
+      const float l1y = F[3] * p1x + (F[4] * p1y + F[5]);
+      const float l1z = F[6] * p1x + (F[7] * p1y + F[8]);
+      const float l2x = F[0] * p2x + (F[3] * p2y + F[6]);
+      const float l2y = F[1] * p2x + (F[4] * p2y + F[7]);
+      const float l2z = F[2] * p2x + (F[5] * p2y + F[8]);
+      const float n1 = p2x * l1x + (p2y * l1y + l1z);
+      const float n2 = p1x * l2x + (p1y * l2y + l2z);
+      dcand = n1 * n1 / (l1x * l1x + l1y * l1y) + n2 * n2 / (l2x * l2x + l2y * l2y);
+    }
+    float best = (float)(err * err);
+    int bestIndex = -1;
+    for (int i = 0; i < 3; ++i) {
+      const float di = __shfl(dcand, i);
+      if (di < best) { best = di; bestIndex = i; }
+    }
+    if (bestIndex != -1) {
+      remove_view(n, bestIndex);
+      n = 2;
+      build(n);
+      se3d_eig4_smallest(gw_, ev);
+      X = (float)(ev[0] / ev[3]); Y = (float)(ev[1] / ev[3]); Z = (float)(ev[2] / ev[3]);
+      err = reproj(n, X, Y, Z);
+      avg_score = (T.cf[0] + T.cf[1]) / 2.0f;
+    }
+  } else if (err > REPROJ_MAX && n >= 4) {  // S3D:793-838: leave-one-out, one candidate per lane
+    double bestErr = err;
+    int bestIdx = -1;
+    float bX = 0, bY = 0, bZ = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      double e_i = 1e300;
+      float cx_ = 0, cy_ = 0, cz_ = 0;
+      if (i < n) {
+        double g[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) g[k] = gw_[k];
+        float w0[4], w1[4];
+        const float cf = T.cf[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { w0[k] = T.r0[k][i] * cf; w1[k] = T.r1[k][i] * cf; }
+        se3d_gram_add(g, w0, -1.0); se3d_gram_add(g, w1, -1.0);
+        double e4[4];
+        se3d_eig4_smallest(g, e4);
+        cx_ = (float)(e4[0] / e4[3]); cy_ = (float)(e4[1] / e4[3]); cz_ = (float)(e4[2] / e4[3]);
+        double se = 0.0, sc = 0.0;
+        for (int v = 0; v < n; ++v) {
+          if (v == i) continue;
+          const float e = se3d_reproj1(D.Rt + 12 * (size_t)T.cam[v], cx_, cy_, cz_, T.x[v], T.y[v]);
+          se += (double)(T.cf[v] * e);
+          sc += (double)T.cf[v];
+        }
+        e_i = se / sc;
+        if (!(e_i < 0.9 * err)) e_i = 1e300;  // "save new best results only if considerably better" (S3D:813)
+      }
+      // wave arg-min, ties -> lowest index (the reference's sequential strict '>' scan)
+      double m = e_i;
+      int mi = i;
+      for (int o = 32; o > 0; o >>= 1) {
+        const double om = __shfl_xor(m, o);
+        const int oi = __shfl_xor(mi, o);
+        if (om < m || (om == m && oi < mi)) { m = om; mi = oi; }
+      }
+      if (m < bestErr) {
+        bestErr = m;
+        bestIdx = mi;
+        const int src = mi - i0;
+        bX = __shfl(cx_, src); bY = __shfl(cy_, src); bZ = __shfl(cz_, src);
+      }
+    }
+    if (bestIdx != -1) {
+      const float cfr = T.cf[bestIdx];
+      remove_view(n, bestIdx);
+      n -= 1;
+      build(n);  // Gu of the kept views for the UT (positions come from the leave-one-out solve, not re-triangulated)
+      X = bX; Y = bY; Z = bZ;
+      err = bestErr;
+      avg_score = (float)((sconf) / n);
+      (void)cfr;
+    }
+  }
+  if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX / err));  // S3D:840-841
+
+  // ---- unscented transform (S3D:471-523): 4n+1 sigma points, each an unweighted re-triangulation ----
+  const int dim = 2 * n;
+  const float bsc = sqrtf((float)dim + 0.5f);
+  const float wgt = 1.0f / (2.0f * ((float)dim + 0.5f));  // all weights equal because 2*kappa == 1
+  double cv[6] = {0, 0, 0, 0, 0, 0};
+  const int nsamp = 4 * n + 1;
+  for (int s0 = 0; s0 < nsamp; s0 += 64) {
+    const int s = s0 + lane;
+    if (s < nsamp) {
+      double g[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) g[k] = gu_[k];
+      if (s > 0) {
+        const int c = (s - 1) >> 2, t = (s - 1) & 3;
+        const float l11 = sqrtf(T.ca[c]);
+        const float l21 = T.cb[c] / l11;
+        const float l22 = sqrtf(T.cc[c] - l21 * l21);
+        const float dx1 = l11 * bsc, dy1 = l21 * bsc, dy2 = l22 * bsc;
+        float px = T.x[c], py = T.y[c];
+        if (t == 0) { px -= dx1; py -= dy1; }
+        else if (t == 1) { py -= dy2; }
+        else if (t == 2) { px += dx1; py += dy1; }
+        else { py += dy2; }
+        float o0[4], o1[4], n0[4], n1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o0[k] = T.r0[k][c]; o1[k] = T.r1[k][c]; }
+        se3d_dlt_rows(D.Rt + 12 * (size_t)T.cam[c], px, py, n0, n1);
+        se3d_gram_add(g, o0, -1.0); se3d_gram_add(g, o1, -1.0);
+        se3d_gram_add(g, n0, 1.0); se3d_gram_add(g, n1, 1.0);
+      }
+      double e4[4];
+      se3d_eig4_smallest(g, e4);
+      const float sx = (float)(e4[0] / e4[3]) - X, sy = (float)(e4[1] / e4[3]) - Y, sz = (float)(e4[2] / e4[3]) - Z;
+      const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
+      cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) cv[k] = se3d_wave_sum(cv[k]);
+  if (lane == 0) {
+    se3d_keypoint3d *kp = &D.hypP[(size_t)f * H + h].keypoints[c_kp2fusion[D.d.pose_method][j]];
+    kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
+    kp->score = avg_score;
+    kp->cov[0] = (double)(float)cv[0]; kp->cov[1] = (double)(float)cv[1]; kp->cov[2] = (double)(float)cv[2];
+    kp->cov[3] = (double)(float)cv[3]; kp->cov[4] = (double)(float)cv[4]; kp->cov[5] = (double)(float)cv[5];
+  }
+}
+
+// =============================================================================================================
+// rows X, D — per-person plausibility post-processing (S3D:861-973), duplicate merge (S3D:984-996) and output
+// compaction.  One workgroup per frame.
+// =============================================================================================================
+__device__ __forceinline__ double se3d_jdist(const double a[3], const double b[3]) {
+  return sqrt((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]));
+}
+__device__ __forceinline__ void se3d_addcov(se3d_keypoint3d &kp, double sigma) {
+  kp.cov[0] += sigma * sigma; kp.cov[3] += sigma * sigma; kp.cov[5] += sigma * sigma;
+}
+__device__ __forceinline__ void se3d_zero_kp(se3d_keypoint3d &kp) {
+  kp.joint[0] = kp.joint[1] = kp.joint[2] = 0.0; kp.score = 0.f; kp._pad = 0.f;
+  for (int i = 0; i < 6; ++i) kp.cov[i] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void se3d_k_postprocess(Se3dDev D) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  const int pm = D.d.pose_method;
+  const int nh = D.nhyp[f];
+  se3d_person3d *persons = D.hypP + (size_t)f * H;
+  __shared__ int alive[SE3D_MUNKRES_MAX];
+  __shared__ int s_ncam;
+  __shared__ int wsum[4];
+  if (tid == 0) s_ncam = 0;
+  __syncthreads();
+  {
+    int local = 0;
+    for (int c = tid; c < N; c += 256) local += (D.nraw[f * N + c] > 0) ? 1 : 0;
+    if (local) atomicAdd(&s_ncam, local);
+  }
+  for (int i = tid; i < SE3D_MUNKRES_MAX; i += 256) alive[i] = 0;
+  __syncthreads();
+  const bool few = s_ncam < 2;  // S3D:557-560
+  for (int h = tid; h < nh && !few; h += 256) {
+    if (D.nviews[f * H + h] < 2) continue;
+    se3d_person3d &p = persons[h];
+    int num_valid = 0;
+    for (int k = 0; k < SE3D_NKP; ++k) num_valid += (p.keypoints[c_kp2fusion[pm][k]].score > 0.f) ? 1 : 0;
+    for (int k = 0; k < SE3D_NKP; ++k) {  // limb-length covariance inflation (S3D:861-883)
+      se3d_keypoint3d &kp = p.keypoints[c_kp2fusion[pm][k]];
+      if (kp.score <= 0.f) continue;
+      const int parent = c_kpParent[pm][k];
+      if (parent >= 0) {
+        const se3d_keypoint3d &pk = p.keypoints[c_kp2fusion[pm][parent]];
+        if (pk.score > 0.f && c_limbLength[pm][k] > 0) {
+          const double jd = se3d_jdist(kp.joint, pk.joint);
+          se3d_addcov(kp, 0.075 * (jd - c_limbLength[pm][k]) / c_limbLSigma[pm][k]);
+        } else if (pm == SE3D_POSE_SIMPLE && k == 6) {  // RShoulder special case (S3D:875-881)
+          se3d_keypoint3d &ls = p.keypoints[c_kp2fusion[pm][5]];
+          if (ls.score > 0.f) {
+            const double jd = se3d_jdist(kp.joint, ls.joint);
+            se3d_addcov(kp, 0.075 * (jd - 0.35) / 0.15);
+            se3d_addcov(ls, 0.075 * (jd - 0.35) / 0.15);
+          }
+        }
+      }
+    }
+    double root[3] = {0, 0, 0};
+    float root_score = 0.f;
+    if (p.keypoints[FU_MidHip].score > 0.f) {
+      for (int a = 0; a < 3; ++a) root[a] = p.keypoints[FU_MidHip].joint[a];
+      root_score = p.keypoints[FU_MidHip].score;
+    } else if (p.keypoints[FU_LHip].score > 0.f && p.keypoints[FU_RHip].score > 0.f) {
+      for (int a = 0; a < 3; ++a) root[a] = (p.keypoints[FU_LHip].joint[a] + p.keypoints[FU_RHip].joint[a]) / 2.;
+      root_score = (p.keypoints[FU_LHip].score + p.keypoints[FU_RHip].score) / 2.f;
+    }
+    if (root_score > 0.f) {  // S3D:937-953
+      for (int k = 0; k < SE3D_NFU; ++k) {
+        se3d_keypoint3d &kp = p.keypoints[k];
+        if (kp.score > 0.f) {
+          if (se3d_jdist(root, kp.joint) > 2.0) { se3d_zero_kp(kp); --num_valid; }
+        } else {
+          se3d_zero_kp(kp);
+          --num_valid;
+        }
+      }
+    }
+    double feet = 0.0;  // S3D:955-966
+    if (p.keypoints[FU_LAnkle].score > 0.f && p.keypoints[FU_RAnkle].score > 0.f)
+      feet = (p.keypoints[FU_LAnkle].joint[2] + p.keypoints[FU_RAnkle].joint[2]) / 2.0;
+    else if (p.keypoints[FU_LAnkle].score > 0.f) feet = p.keypoints[FU_LAnkle].joint[2];
+    else if (p.keypoints[FU_RAnkle].score > 0.f) feet = p.keypoints[FU_RAnkle].joint[2];
+    if (fabs(feet) > 0.50) num_valid = 0;
+    alive[h] = (num_valid > 9) ? 1 : 0;
+  }
+  __syncthreads();
+  // ---- duplicate merge (S3D:984-996): sequential in i, distances to all later j in parallel ----
+  __shared__ int s_first;
+  for (int i = 0; i < nh; ++i) {
+    if (!alive[i]) continue;  // uniform (LDS)
+    int from = i + 1;
+    for (;;) {
+      if (tid == 0) s_first = 0x7fffffff;
+      __syncthreads();
+      const int jj = from + tid;  // nh <= 256 = blockDim
+      if (jj < nh && alive[jj]) {
+        int nu = 0;
+        double dist = 0.0;
+        for (int k = 0; k < SE3D_NFU; ++k) {
+          const se3d_keypoint3d &a = persons[i].keypoints[k], &bb = persons[jj].keypoints[k];
+          if (a.score > 0.f && bb.score > 0.f) {
+            const double dx = a.joint[0] - bb.joint[0], dy = a.joint[1] - bb.joint[1], dz = a.joint[2] - bb.joint[2];
+            dist += sqrt(dx * dx + dy * dy + dz * dz);
+            ++nu;
+          }
+        }
+        const double dd = nu > 0 ? dist / nu : MAX_COSTS;
+        if (dd < 0.20) atomicMin(&s_first, jj);
+      }
+      __syncthreads();
+      const int jm = s_first;
+      __syncthreads();
+      if (jm == 0x7fffffff) break;
+      if (tid < SE3D_NFU) {  // merge_persons (S3D:410-423), one joint per thread
+        se3d_keypoint3d &k1 = persons[i].keypoints[tid];
+        const se3d_keypoint3d &k2 = persons[jm].keypoints[tid];
+        const double total = (double)(k1.score + k2.score);
+        if (total > 0.0) {
+          for (int a = 0; a < 3; ++a) k1.joint[a] = ((double)k1.score * k1.joint[a] + (double)k2.score * k2.joint[a]) / total;
+          k1.score = fmaxf(k1.score, k2.score);
+          for (int a = 0; a < 6; ++a) k1.cov[a] = (k1.cov[a] + k2.cov[a]) / 2.0;
+        }
+      }
+      if (tid == 0) alive[jm] = 0;
+      from = jm + 1;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  // ---- compaction in ascending hypothesis order + association table in original detection indices ----
+  int total;
+  const bool al = (tid < nh) && alive[tid];
+  const int pos = se3d_block_excl_scan(al, wsum, total);
+  if (al) {
+    D.out_hyp[(size_t)f * H + pos] = tid;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&persons[tid]);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&D.outP[(size_t)f * H + pos]);
+    for (int w = 0; w < (int)(sizeof(se3d_person3d) / 4); ++w) dst[w] = src[w];
+  }
+  if (tid == 0) {
+    D.out_count[f] = total;
+    if (few) atomicOr(&D.flags[f], SE3D_FLAG_FEW_CAMERAS);
+  }
+  for (int i = tid; i < nh * N; i += 256) {
+    const int h = i / N, c = i - h * N;
+    const int k = D.assoc[((size_t)f * H + h) * N + c];
+    D.out_assoc[((size_t)f * H + h) * N + c] = (k >= 0) ? D.orig[((size_t)(f * N + c)) * P + k] : -1;
+  }
+}
+
+// stand-alone Munkres (se3d_hungarian): one workgroup, dist column-major with ld = nR
+__global__ __launch_bounds__(256) void se3d_k_munkres(double *dist, int *assign, int *status, int nR, int nC) {
+  __shared__ MunkresShared S;
+  __shared__ int a[SE3D_MUNKRES_MAX];
+  for (int i = threadIdx.x; i < SE3D_MUNKRES_MAX; i += 256) a[i] = -1;
+  __syncthreads();
+  const int rc = se3d_munkres_block(dist, nR, nR, nC, S, a);
+  for (int r = threadIdx.x; r < nR; r += 256) assign[r] = a[r];
+  if (threadIdx.x == 0) *status = rc;
+}
+extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st) {
+  hipLaunchKernelGGL(se3d_k_munkres, dim3(1), dim3(256), 0, st, d_dist, d_assign, d_status, nR, nC);
+}
+
+// =============================================================================================================
+// host-side launch sequence
+// =============================================================================================================
+extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, bool tiled) {
+  const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H;
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  if (tiled) {
+    const int tiles = (P + PT - 1) / PT;
+    hipLaunchKernelGGL(se3d_k_pairs_tiled, dim3(tiles * tiles, D.d.npairs, B), dim3(256), 0, st, D, pair_ab);
+  } else {
+    const size_t total = (size_t)B * D.d.npairs * P * P;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(se3d_k_pairs_flat, dim3(blocks), dim3(256), 0, st, D, pair_ab);
+  }
+  if (ev) (void)hipEventRecord(ev[2], st);
+  for (int b = 0; b < N; ++b) {
+    if (b > 0) hipLaunchKernelGGL(se3d_k_sweep_cost, dim3(H, B), dim3(128), 0, st, D, b);
+    hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), 0, st, D, b);
+  }
+  if (ev) (void)hipEventRecord(ev[3], st);
+  const size_t lds = (size_t)4 * 15 * N * sizeof(float);
+  hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
+  if (ev) (void)hipEventRecord(ev[4], st);
+  hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
+  if (ev) (void)hipEventRecord(ev[5], st);
+}

@@ -1,0 +1,108 @@
+"""Host-side mirror of the reference's skeleton_3d node interface over the HIP C-ABI.
+
+Names and argument meaning follow skeleton_3d_triang_mult_node.cpp: ROS private params `pose_method`, `max_epi_dist`
+(S3D:1095-1097), entry `triangulate_persons(people, ...)` (S3D:525).  All arithmetic happens in libse3d_hip.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import person_msgs as pm
+
+
+class Se3dError(RuntimeError):
+    pass
+
+
+def rig_tensors(rig):
+    """Product-side host set-up of Rt / F (se3d_rig_from_transforms, replaces S3D:1187-1211)."""
+    Rt = np.zeros((rig.n_cam, 12), np.float32)
+    F = np.zeros((rig.n_pairs, 9), np.float32)
+    rc = _lib.lib().se3d_rig_from_transforms(rig.n_cam, rig.T.ctypes.data_as(C.POINTER(C.c_double)), pm.fptr(Rt), pm.fptr(F))
+    if rc != 0:
+        raise Se3dError("se3d_rig_from_transforms failed: %d" % rc)
+    return Rt, F
+
+
+class Skeleton3D:
+    """One skeleton_3d node instance bound to one GPU."""
+
+    def __init__(self, rig, pose_method="simple", max_epi_dist=0.050, norm_height=False, max_frames=1, max_det_per_cam=8, max_hyp=None,
+                 max_tracks=None, device=0):
+        if rig.Rt is None or rig.F is None:
+            rig.set_tensors(*rig_tensors(rig))
+        self.rig = rig
+        self.params = pm.Params(pm.POSE_H36M if pose_method == "h36m" else pm.POSE_SIMPLE, int(bool(norm_height)), float(max_epi_dist))
+        max_hyp = max_hyp or min(256, max(2 * max_det_per_cam, 8))
+        self.limits = pm.Limits(int(max_frames), int(max_det_per_cam), int(max_hyp), int(max_tracks or max_hyp))
+        self._rig_c = pm.Rig(rig.n_cam, pm.fptr(rig.Rt), pm.fptr(rig.K), pm.fptr(rig.F))
+        self._L = _lib.lib()
+        self._h = self._L.se3d_create(C.byref(self._rig_c), C.byref(self.params), C.byref(self.limits), int(device))
+        if not self._h:
+            raise Se3dError("se3d_create failed (no GPU, unsupported sizes or out of memory); there is no CPU fallback")
+        self._staged = 0
+
+    # -- error helper
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise Se3dError("%s failed (%d): %s" % (what, rc, self._L.se3d_last_error(C.c_void_p(self._h)).decode()))
+
+    # -- reference entry point: triangulate_persons for a batch of synchronised frames
+    def triangulate_persons(self, frames, capacity=None):
+        frames = list(frames)
+        arr = (pm.FrameIn * len(frames))(*[f.as_c() for f in frames])
+        res = [pm.FrameResult(self.rig.n_cam, capacity or self.limits.max_hyp, self.limits.max_hyp) for _ in frames]
+        outs = (pm.FrameOut * len(frames))(*[r.c for r in res])
+        self._chk(self._L.se3d_triangulate_batch(C.c_void_p(self._h), len(frames), arr, outs), "se3d_triangulate_batch")
+        for r, o in zip(res, outs):
+            r.c = o
+        return res
+
+    # -- resident pipeline
+    def stage(self, frames):
+        frames = list(frames)
+        arr = (pm.FrameIn * len(frames))(*[f.as_c() for f in frames])
+        self._chk(self._L.se3d_stage_frames(C.c_void_p(self._h), len(frames), arr), "se3d_stage_frames")
+        self._staged = len(frames)
+
+    def run_stage1(self):
+        self._chk(self._L.se3d_run_stage1(C.c_void_p(self._h)), "se3d_run_stage1")
+
+    def sync(self):
+        self._chk(self._L.se3d_sync(C.c_void_p(self._h)), "se3d_sync")
+
+    def fetch_stage1(self, n_frames=None, capacity=None):
+        n = n_frames or self._staged
+        res = [pm.FrameResult(self.rig.n_cam, capacity or self.limits.max_hyp, self.limits.max_hyp) for _ in range(n)]
+        outs = (pm.FrameOut * n)(*[r.c for r in res])
+        self._chk(self._L.se3d_fetch_stage1(C.c_void_p(self._h), n, outs), "se3d_fetch_stage1")
+        for r, o in zip(res, outs):
+            r.c = o
+        return res
+
+    def pack_stage1_device(self, persons_ptr, counts_ptr):
+        self._chk(self._L.se3d_pack_stage1_device(C.c_void_p(self._h), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)), "se3d_pack_stage1_device")
+
+    # -- measurement
+    def profile(self, on=True):
+        self._chk(self._L.se3d_profile_enable(C.c_void_p(self._h), int(on)), "se3d_profile_enable")
+
+    def profile_reset(self):
+        self._chk(self._L.se3d_profile_reset(C.c_void_p(self._h)), "se3d_profile_reset")
+
+    def profile_get(self, name):
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._chk(self._L.se3d_profile_get(C.c_void_p(self._h), name.encode(), C.byref(ms), C.byref(n)), "se3d_profile_get")
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.se3d_destroy(C.c_void_p(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

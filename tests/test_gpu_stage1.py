@@ -1,0 +1,181 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP stage 1 through the C-ABI vs the CPU oracle on the same
+seeded inputs.  Association indices and Hungarian results bit-exact; 3D joints < 1 mm (max); see tests/parity.py."""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from smartedgesensor3dhumanpose_amd import person_msgs as pm
+from smartedgesensor3dhumanpose_amd import rig as R
+from smartedgesensor3dhumanpose_amd import scene as S
+
+sys.path.insert(0, os.path.dirname(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from parity import compare_stage1, normalized_detections  # noqa: E402
+from make_hungarian_golden import make_matrix  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _node(rig, **kw):
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
+    return Skeleton3D(rig, max_epi_dist=0.045, **kw)
+
+
+@pytest.fixture(scope="module")
+def node16(extr_rig):
+    n = _node(extr_rig, max_frames=8, max_det_per_cam=8, max_hyp=32)
+    yield n
+    n.close()
+
+
+def test_loaded_library_is_the_hip_build(node16):
+    from smartedgesensor3dhumanpose_amd import _lib
+    assert b"gfx950" in _lib.lib().se3d_version()
+    maps = open("/proc/self/maps").read()
+    assert "libse3d_hip.so" in maps
+
+
+def test_device_hungarian_matches_reference_goldens(node16):
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hungarian_golden.json")))
+    L = node16._L
+    for case in gold["cases"]:
+        if "matrix" in case:
+            m = np.array(case["matrix"], np.float64).reshape(case["nr"], case["nc"])
+        else:
+            m = make_matrix(case["kind"], case["nr"], case["nc"], case["seed"])
+            assert hashlib.sha256(np.ascontiguousarray(m).tobytes()).hexdigest() == case["sha256"]
+        flat = np.ascontiguousarray(m.ravel(order="F"))
+        a = np.zeros(case["nr"], np.int32)
+        cost = C.c_double(0)
+        rc = L.se3d_hungarian(C.c_void_p(node16._h), pm.iptr(a), C.byref(cost), flat.ctypes.data_as(C.POINTER(C.c_double)), case["nr"], case["nc"])
+        assert rc == 0, L.se3d_last_error(C.c_void_p(node16._h))
+        assert a.tolist() == case["assignment"], (case["kind"], case["nr"], case["nc"], case["seed"])
+        assert cost.value == case["cost"]
+
+
+def test_device_hungarian_fuzz_vs_oracle(node16, oracle):
+    L = node16._L
+    rng = np.random.default_rng(7)
+    for it in range(120):
+        nr, nc = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        m = make_matrix(["uniform", "integer", "maxcost", "epipolar"][it % 4], nr, nc, 50_000 + it)
+        a0, c0 = oracle.hungarian(m)
+        flat = np.ascontiguousarray(m.ravel(order="F"))
+        a = np.zeros(nr, np.int32)
+        cost = C.c_double(0)
+        assert L.se3d_hungarian(C.c_void_p(node16._h), pm.iptr(a), C.byref(cost), flat.ctypes.data_as(C.POINTER(C.c_double)), nr, nc) == 0
+        assert a.tolist() == a0.tolist(), (it, nr, nc)
+        assert cost.value == c0
+
+
+def _pair_costs(node, frame_idx, a, b):
+    P = node.limits.max_det_per_cam
+    out = np.zeros((P, P))
+    na, nb = C.c_int32(0), C.c_int32(0)
+    rc = node._L.se3d_get_pair_costs(C.c_void_p(node._h), frame_idx, a, b, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(na), C.byref(nb))
+    assert rc == 0
+    return out, na.value, nb.value
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_pair_cost_table_is_bit_exact(extr_rig, oracle, demo_params, tiled, monkeypatch):
+    monkeypatch.setenv("SE3D_PAIRS", "tiled" if tiled else "flat")
+    node = _node(extr_rig, max_frames=2, max_det_per_cam=8, max_hyp=32)
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=2, seed=11, p_miss=0.1))
+    node.stage(frames)
+    node.run_stage1()
+    node.sync()
+    checked = 0
+    for fi, fr in enumerate(frames):
+        dets = normalized_detections(extr_rig, fr)
+        for (a, b) in [(0, 1), (0, 4), (2, 9), (3, 15), (9, 10), (14, 15), (1, 12)]:
+            tab, na, nb = _pair_costs(node, fi, a, b)
+            assert na == len(dets[a]) and nb == len(dets[b])
+            F = extr_rig.F[R.pair_index(a, b, 16)]
+            for i, (_, ka) in enumerate(dets[a]):
+                for k, (_, kb) in enumerate(dets[b]):
+                    c, n = oracle.pair_cost(F, ka, kb)
+                    assert tab[i, k] == c, (fi, a, b, i, k, tab[i, k], c)  # bit-exact double
+                    checked += 1
+    assert checked > 300
+    node.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_stage1_parity_16cam_6p(node16, extr_rig, oracle, demo_params, seed):
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=4, seed=seed))
+    res = node16.triangulate_persons(frames)
+    worst = 0.0
+    for fr, g in zip(frames, res):
+        o = oracle.triangulate(extr_rig, demo_params, fr, capacity=32, hyp_capacity=32)
+        st = compare_stage1(g, o)
+        worst = max(worst, st["pos_max_mm"])
+        assert g.n_persons >= 5
+    print("seed", seed, "max joint error vs oracle: %.5f mm" % worst)
+
+
+def test_stage1_ragged_misses_and_low_scores(node16, extr_rig, oracle, demo_params):
+    cfg = S.SceneConfig(n_persons=5, n_frames=4, seed=21, p_miss=0.25, low_score_frac=0.2, min_visible_joints=3)
+    frames, _ = S.generate_sequence(extr_rig, cfg)
+    for fr, g in zip(frames, node16.triangulate_persons(frames)):
+        compare_stage1(g, oracle.triangulate(extr_rig, demo_params, fr, capacity=32, hyp_capacity=32))
+
+
+def test_stage1_outlier_rejection_paths(node16, extr_rig, oracle, demo_params):
+    """Gross 2D errors trigger S3D:748-838 (n == 3 epipolar test and n >= 4 leave-one-out)."""
+    cfg = S.SceneConfig(n_persons=4, n_frames=6, seed=33, outlier_frac=0.04, outlier_px=200.0, p_miss=0.3)
+    frames, _ = S.generate_sequence(extr_rig, cfg)
+    for fr, g in zip(frames, node16.triangulate_persons(frames)):
+        compare_stage1(g, oracle.triangulate(extr_rig, demo_params, fr, capacity=32, hyp_capacity=32))
+
+
+def test_stage1_empty_and_single_camera_frames(node16, extr_rig, oracle, demo_params):
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=3, n_frames=1, seed=5))
+    full = frames[0]
+    empty = pm.Frame(16, np.zeros(17, np.int32), np.zeros(0, pm.person2d_dt))
+    off = np.zeros(17, np.int32)
+    n0 = full.n_det(0)
+    off[1:] = n0
+    single = pm.Frame(16, off, full.persons[:n0])
+    res = node16.triangulate_persons([empty, single, full])
+    assert res[0].n_persons == 0 and res[0].flags & pm.FLAG_FEW_CAMERAS
+    assert res[1].n_persons == 0 and res[1].flags & pm.FLAG_FEW_CAMERAS
+    for fr, g in zip([empty, single, full], res):
+        compare_stage1(g, oracle.triangulate(extr_rig, demo_params, fr, capacity=32, hyp_capacity=32))
+
+
+def test_stage1_h36m_pose_method(extr_rig, oracle):
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
+    node = Skeleton3D(extr_rig, pose_method="h36m", max_epi_dist=0.050, max_frames=2, max_det_per_cam=8, max_hyp=32)
+    params = pm.Params(pm.POSE_H36M, 0, 0.050)
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=4, n_frames=2, seed=8))
+    for fr, g in zip(frames, node.triangulate_persons(frames)):
+        compare_stage1(g, oracle.triangulate(extr_rig, params, fr, capacity=32, hyp_capacity=32))
+    node.close()
+
+
+def test_stage1_parity_ellipse_24cam_20p_tiled(oracle, demo_params):
+    """Larger P: tiled pair kernel + Hungarian in crowded early sweep steps."""
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
+    rig = R.elliptical_rig(24, seed=1)
+    rig.set_tensors(*rig_tensors(rig))
+    node = _node(rig, max_frames=2, max_det_per_cam=24, max_hyp=64)
+    frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=20, n_frames=2, seed=2, min_coverage=6))
+    for fr, g in zip(frames, node.triangulate_persons(frames)):
+        st = compare_stage1(g, oracle.triangulate(rig, demo_params, fr, capacity=64, hyp_capacity=64))
+        assert g.n_persons >= 15
+    node.close()
+
+
+def test_capacity_errors_are_reported(extr_rig):
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Se3dError
+    node = _node(extr_rig, max_frames=1, max_det_per_cam=2, max_hyp=8)
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=2, seed=0))
+    with pytest.raises(Se3dError):
+        node.triangulate_persons(frames[:1])   # 6 detections per camera > limit 2
+    node.close()
