@@ -833,7 +833,10 @@ __global__ __launch_bounds__(256) void se3d_k_postprocess(Se3dDev D) {
   }
   if (tid == 0) {
     D.out_count[f] = total;
-    if (few) atomicOr(&D.flags[f], SE3D_FLAG_FEW_CAMERAS);
+    if (few) {  // the reference returns before building any hypothesis (S3D:557-560)
+      atomicOr(&D.flags[f], SE3D_FLAG_FEW_CAMERAS);
+      D.nhyp[f] = 0;
+    }
   }
   for (int i = tid; i < nh * N; i += 256) {
     const int h = i / N, c = i - h * N;
