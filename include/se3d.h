@@ -178,8 +178,8 @@ int se3d_pack_stage2_device(se3d_ctx *ctx, void *d_persons, void *d_counts);
 /* --- measurement: HIP-event timing of the kernels on the context stream -------------------------------- */
 int se3d_profile_enable(se3d_ctx *ctx, int32_t on);
 int se3d_profile_reset(se3d_ctx *ctx);
-/* name in {"normalize","epipolar_pairs","sweep_cost","sweep_assign","triangulate","postprocess",
- *          "track_assoc","lm_refine","track_update"}; returns accumulated ms and launch count */
+/* name in {"normalize","epipolar_pairs","sweep","triangulate","postprocess","track_assoc","lm_refine",
+ *          "track_update"}; returns accumulated ms and launch count ("sweep" = all cost+assign launches of a run) */
 int se3d_profile_get(se3d_ctx *ctx, const char *name, double *ms_total, int64_t *launches);
 
 #ifdef __cplusplus

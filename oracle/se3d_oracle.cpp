@@ -1538,6 +1538,9 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
     }
     for (int k = 0; k < NFU; ++k) {  // PP:704-719
       if (k == F_MidHip) continue;
+      // "simple": a measured Neck slot plus the derived neck would insert key 1 twice (gtsam::Values::insert throws, the
+      // reference node would die); stage 1 never fills that slot in "simple" mode.  Defined here: the derived neck wins.
+      if (simple && k == F_Neck && neck.score > g_min_score) continue;
       const auto &kp = person.keypoints[k];
       if (kp.score > g_min_score) {
         double cov[9], c[9];

@@ -13,12 +13,14 @@
 
 extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st);
 extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled);
+extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev);
 
 #define SE3D_VERSION "se3d-hip 0.1.0 (gfx950)"
 
 namespace {
-enum ProfSlot { PS_NORMALIZE = 0, PS_PAIRS, PS_SWEEP, PS_TRI, PS_POST, PS_COUNT };
-const char *kProfNames[PS_COUNT] = {"normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess"};
+enum ProfSlot { PS_NORMALIZE = 0, PS_PAIRS, PS_SWEEP, PS_TRI, PS_POST, PS_ASSOC2, PS_LM, PS_UPDATE2, PS_COUNT };
+const int kStage1Slots = 5, kStage2Slots = 3;
+const char *kProfNames[PS_COUNT] = {"normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess", "track_assoc", "lm_refine", "track_update"};
 }  // namespace
 
 struct se3d_ctx {
@@ -45,6 +47,20 @@ struct se3d_ctx {
   double prof_ms[PS_COUNT]{};
   int64_t prof_n[PS_COUNT]{};
   bool prof_pending = false;
+  // stage 2
+  Se3dStage2 Q{};
+  se3d_person3d *d_in2 = nullptr;  // [S][H] host-provided measurements (se3d_refine)
+  int32_t *d_ndet2 = nullptr;      // [S]
+  float *d_fb = nullptr;           // [S][N] fb_delay of the staged frames / of se3d_refine
+  double *d_t = nullptr;           // [S]
+  float *h_fb = nullptr;
+  double *h_t = nullptr;
+  se3d_person3d *h_fused = nullptr, *h_pred = nullptr;
+  int32_t *h_iters = nullptr, *h_nout = nullptr, *h_ntracks = nullptr;
+  double *h_preddt = nullptr;
+  hipEvent_t ev2[4]{};
+  bool prof2_pending = false;
+  bool ran2 = false;
 };
 
 namespace {
@@ -69,16 +85,45 @@ bool dev_alloc(se3d_ctx *c, T **p, size_t n) {
 }
 
 void collect_profile(se3d_ctx *c) {
-  if (!c->prof_pending) return;
-  (void)hipEventSynchronize(c->ev[5]);
-  for (int i = 0; i < PS_COUNT; ++i) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) {
-      c->prof_ms[i] += ms;
-      c->prof_n[i] += 1;
+  if (c->prof_pending) {
+    (void)hipEventSynchronize(c->ev[5]);
+    for (int i = 0; i < kStage1Slots; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) {
+        c->prof_ms[i] += ms;
+        c->prof_n[i] += 1;
+      }
     }
+    c->prof_pending = false;
   }
-  c->prof_pending = false;
+  if (c->prof2_pending) {
+    (void)hipEventSynchronize(c->ev2[3]);
+    for (int i = 0; i < kStage2Slots; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c->ev2[i], c->ev2[i + 1]) == hipSuccess) {
+        c->prof_ms[kStage1Slots + i] += ms;
+        c->prof_n[kStage1Slots + i] += 1;
+      }
+    }
+    c->prof2_pending = false;
+  }
+}
+
+int stage2_reset(se3d_ctx *c) {
+  const Se3dStage2 &Q = c->Q;
+  const size_t S = Q.S, T = Q.T;
+  if (hipMemsetAsync(Q.n_tracks, 0, sizeof(int32_t) * S, c->stream) != hipSuccess) return SE3D_ERR_DEVICE;
+  (void)hipMemsetAsync(Q.used, 0, S * T, c->stream);
+  (void)hipMemsetAsync(Q.next_id, 0, sizeof(int32_t) * S, c->stream);
+  (void)hipMemsetAsync(Q.frame_nr, 0, sizeof(int32_t) * S, c->stream);
+  (void)hipMemsetAsync(Q.t_prev, 0, sizeof(double) * S, c->stream);
+  (void)hipMemsetAsync(Q.flags2, 0, sizeof(uint32_t) * S, c->stream);
+  (void)hipMemsetAsync(Q.n_out, 0, sizeof(int32_t) * S, c->stream);
+  std::vector<double> fb(S * 3, 0.10);  // g_fb_delay_buffer(g_n_mov_avg, g_avg_delay) (PP:54)
+  if (hipMemcpyAsync(Q.fb_buf, fb.data(), sizeof(double) * S * 3, hipMemcpyHostToDevice, c->stream) != hipSuccess) return SE3D_ERR_DEVICE;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return SE3D_ERR_DEVICE;
+  c->ran2 = false;
+  return SE3D_OK;
 }
 
 // 3x4 pseudo-inverse of a full-row-rank P: P^+ = P^T (P P^T)^-1  (host, fp64)
@@ -190,6 +235,36 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
   ok = ok && dev_alloc(c, &D.hypP, (size_t)B * H) && dev_alloc(c, &D.keep, (size_t)B * H) && dev_alloc(c, &D.outP, (size_t)B * H);
   ok = ok && dev_alloc(c, &D.out_count, (size_t)B) && dev_alloc(c, &D.out_hyp, (size_t)B * H) && dev_alloc(c, &D.out_assoc, (size_t)B * H * N);
   ok = ok && dev_alloc(c, &c->pair_ab, (size_t)np);
+  {  // stage 2 state: S = B sequences, T = max_tracks
+    const int T = limits->max_tracks > 0 ? limits->max_tracks : H;
+    if (T > SE3D_MUNKRES_MAX) { fprintf(stderr, "se3d_create: max_tracks %d > %d\n", T, SE3D_MUNKRES_MAX); se3d_destroy(c); return nullptr; }
+    Se3dStage2 &Q = c->Q;
+    const size_t S = B;
+    Q.S = B; Q.T = T; Q.H = H; Q.N = N; Q.pose_method = params->pose_method; Q.norm_height = params->norm_height; Q.seq0 = 0;
+    ok = ok && dev_alloc(c, &Q.fb_buf, S * 3) && dev_alloc(c, &Q.t_prev, S) && dev_alloc(c, &Q.next_id, S) && dev_alloc(c, &Q.frame_nr, S);
+    ok = ok && dev_alloc(c, &Q.n_tracks, S) && dev_alloc(c, &Q.order, S * T) && dev_alloc(c, &Q.pred_dt, S);
+    ok = ok && dev_alloc(c, &Q.used, S * T) && dev_alloc(c, &Q.id, S * T) && dev_alloc(c, &Q.num_obs, S * T) && dev_alloc(c, &Q.has, S * T);
+    ok = ok && dev_alloc(c, &Q.trk_t_prev, S * T) && dev_alloc(c, &Q.height_prev, S * T) && dev_alloc(c, &Q.root_prev, S * T * 3);
+    ok = ok && dev_alloc(c, &Q.prev, S * T * SE3D_NFU * 3) && dev_alloc(c, &Q.vel, S * T * SE3D_NFU * 9);
+    ok = ok && dev_alloc(c, &Q.C, S * H * T) && dev_alloc(c, &Q.W, S * H * T) && dev_alloc(c, &Q.det_slot, S * H) && dev_alloc(c, &Q.pub, S * H);
+    ok = ok && dev_alloc(c, &Q.fused_det, S * H) && dev_alloc(c, &Q.pred_det, S * H) && dev_alloc(c, &Q.iters_det, S * H);
+    ok = ok && dev_alloc(c, &Q.fused, S * H) && dev_alloc(c, &Q.pred, S * H) && dev_alloc(c, &Q.iters, S * H) && dev_alloc(c, &Q.n_out, S);
+    ok = ok && dev_alloc(c, &Q.flags2, S);
+    ok = ok && dev_alloc(c, &c->d_in2, S * H) && dev_alloc(c, &c->d_ndet2, S) && dev_alloc(c, &c->d_fb, S * N) && dev_alloc(c, &c->d_t, S);
+    for (auto &e : c->ev2) (void)hipEventCreate(&e);
+    if (ok) {
+      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_fb, sizeof(float) * S * N, hipHostMallocDefault), "hipHostMalloc");
+      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_t, sizeof(double) * S, hipHostMallocDefault), "hipHostMalloc");
+      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_fused, sizeof(se3d_person3d) * S * H, hipHostMallocDefault), "hipHostMalloc");
+      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_pred, sizeof(se3d_person3d) * S * H, hipHostMallocDefault), "hipHostMalloc");
+      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_iters, sizeof(int32_t) * S * H, hipHostMallocDefault), "hipHostMalloc");
+      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_nout, sizeof(int32_t) * S, hipHostMallocDefault), "hipHostMalloc");
+      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_ntracks, sizeof(int32_t) * S, hipHostMallocDefault), "hipHostMalloc");
+      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_preddt, sizeof(double) * S, hipHostMallocDefault), "hipHostMalloc");
+      ok = ok && hip_ok(c, hipMemset(c->d_fb, 0, sizeof(float) * S * N), "memset fb");
+      ok = ok && (stage2_reset(c) == SE3D_OK);
+    }
+  }
   if (ok) {
     D.Rt = dRt; D.K = dK; D.F = dF; D.raw = draw; D.nraw = dnraw;
     std::vector<int2> ab(np);
@@ -233,6 +308,16 @@ void se3d_destroy(se3d_ctx *c) {
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->h_outhyp) (void)hipHostFree(c->h_outhyp);
   if (c->h_outassoc) (void)hipHostFree(c->h_outassoc);
+  if (c->h_fb) (void)hipHostFree(c->h_fb);
+  if (c->h_t) (void)hipHostFree(c->h_t);
+  if (c->h_fused) (void)hipHostFree(c->h_fused);
+  if (c->h_pred) (void)hipHostFree(c->h_pred);
+  if (c->h_iters) (void)hipHostFree(c->h_iters);
+  if (c->h_nout) (void)hipHostFree(c->h_nout);
+  if (c->h_ntracks) (void)hipHostFree(c->h_ntracks);
+  if (c->h_preddt) (void)hipHostFree(c->h_preddt);
+  for (auto &e : c->ev2)
+    if (e) (void)hipEventDestroy(e);
   for (auto &e : c->ev)
     if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -254,12 +339,14 @@ int se3d_stage_frames(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames
       const int n = fr.det_offset[cam + 1] - fr.det_offset[cam];
       if (n < 0) { c->err = "det_offset not monotone"; return SE3D_ERR_ARG; }
       if (n > P) { c->err = "detections per camera exceed limits.max_det_per_cam"; return SE3D_ERR_CAPACITY; }
+      c->h_fb[(size_t)f * N + cam] = fr.fb_delay ? fr.fb_delay[cam] : -1.0f;
       c->h_nraw[f * N + cam] = n;
       if (n) memcpy(c->h_raw + ((size_t)(f * N + cam)) * P, fr.persons + fr.det_offset[cam], sizeof(se3d_person2d) * (size_t)n);
     }
   }
   HIPCHK(c, hipMemcpyAsync((void *)c->D.raw, c->h_raw, sizeof(se3d_person2d) * (size_t)n_frames * N * P, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync((void *)c->D.nraw, c->h_nraw, sizeof(int32_t) * (size_t)B * N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_fb, c->h_fb, sizeof(float) * (size_t)n_frames * N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->staged_frames = n_frames;
   c->ran = false;
@@ -389,6 +476,100 @@ int se3d_get_pair_costs(se3d_ctx *c, int32_t frame, int32_t cam_a, int32_t cam_b
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (n_a) *n_a = nv[0];
   if (n_b) *n_b = nv[1];
+  return SE3D_OK;
+}
+
+// ---------------- stage 2 ----------------
+int se3d_refine_reset(se3d_ctx *c) {
+  if (!c) return SE3D_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  collect_profile(c);
+  return stage2_reset(c);
+}
+
+static int fetch_stage2_range(se3d_ctx *c, int seq0, int n_seq, se3d_fused_out *outs) {
+  const Se3dStage2 &Q = c->Q;
+  const size_t H = Q.H;
+  HIPCHK(c, hipMemcpyAsync(c->h_fused + seq0 * H, Q.fused + seq0 * H, sizeof(se3d_person3d) * n_seq * H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_pred + seq0 * H, Q.pred + seq0 * H, sizeof(se3d_person3d) * n_seq * H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_iters + seq0 * H, Q.iters + seq0 * H, sizeof(int32_t) * n_seq * H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_nout + seq0, Q.n_out + seq0, sizeof(int32_t) * n_seq, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_ntracks + seq0, Q.n_tracks + seq0, sizeof(int32_t) * n_seq, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_preddt + seq0, Q.pred_dt + seq0, sizeof(double) * n_seq, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  collect_profile(c);
+  int rc = SE3D_OK;
+  for (int k = 0; k < n_seq; ++k) {
+    se3d_fused_out &o = outs[k];
+    const int s = seq0 + k;
+    const int np = c->h_nout[s];
+    o.n_tracks = c->h_ntracks[s];
+    o.pred_delta_t = (float)c->h_preddt[s];
+    if (np > o.capacity) { o.n_persons = 0; c->err = "output capacity too small"; rc = SE3D_ERR_CAPACITY; continue; }
+    o.n_persons = np;
+    if (np && o.fused) memcpy(o.fused, c->h_fused + s * H, sizeof(se3d_person3d) * (size_t)np);
+    if (np && o.fused_pred) memcpy(o.fused_pred, c->h_pred + s * H, sizeof(se3d_person3d) * (size_t)np);
+    if (np && o.lm_iterations) memcpy(o.lm_iterations, c->h_iters + s * H, sizeof(int32_t) * (size_t)np);
+  }
+  return rc;
+}
+
+int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *dets, int32_t n_cam, const float *fb_delay_per_cam, double t,
+                se3d_fused_out *out) {
+  if (!c || !out || n_det < 0 || (n_det > 0 && !dets)) return SE3D_ERR_ARG;
+  Se3dStage2 Q = c->Q;
+  if (seq < 0 || seq >= Q.S) { c->err = "sequence index out of range"; return SE3D_ERR_ARG; }
+  if (n_det > Q.H) { c->err = "detections exceed limits.max_hyp"; return SE3D_ERR_CAPACITY; }
+  HIPCHK(c, hipSetDevice(c->device));
+  collect_profile(c);
+  const size_t H = Q.H, N = Q.N;
+  for (size_t i = 0; i < N; ++i) c->h_fb[seq * N + i] = (fb_delay_per_cam && (int)i < n_cam) ? fb_delay_per_cam[i] : -1.0f;
+  c->h_t[seq] = t;
+  int32_t nd = n_det;
+  if (n_det) HIPCHK(c, hipMemcpyAsync(c->d_in2 + seq * H, dets, sizeof(se3d_person3d) * (size_t)n_det, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_ndet2 + seq, &nd, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_fb + seq * N, c->h_fb + seq * N, sizeof(float) * N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_t + seq, c->h_t + seq, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // nd is a stack variable
+  Q.dets = c->d_in2; Q.n_det = c->d_ndet2; Q.fb_delay = c->d_fb; Q.t = c->d_t;
+  se3d_launch_stage2(Q, seq, 1, c->stream, c->prof ? c->ev2 : nullptr);
+  HIPCHK(c, hipGetLastError());
+  c->prof2_pending = c->prof;
+  c->ran2 = true;
+  return fetch_stage2_range(c, seq, 1, out);
+}
+
+int se3d_run_stage2(se3d_ctx *c, int32_t n_seq, const double *t) {
+  if (!c || !t || n_seq < 1) return SE3D_ERR_ARG;
+  if (!c->ran || n_seq > c->staged_frames) { c->err = "se3d_run_stage2 needs a preceding se3d_run_stage1 over >= n_seq frames"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  collect_profile(c);
+  Se3dStage2 Q = c->Q;
+  memcpy(c->h_t, t, sizeof(double) * (size_t)n_seq);
+  HIPCHK(c, hipMemcpyAsync(c->d_t, c->h_t, sizeof(double) * (size_t)n_seq, hipMemcpyHostToDevice, c->stream));
+  Q.dets = c->D.outP; Q.n_det = c->D.out_count; Q.fb_delay = c->d_fb; Q.t = c->d_t;
+  se3d_launch_stage2(Q, 0, n_seq, c->stream, c->prof ? c->ev2 : nullptr);
+  HIPCHK(c, hipGetLastError());
+  c->prof2_pending = c->prof;
+  c->ran2 = true;
+  return SE3D_OK;
+}
+
+int se3d_fetch_stage2(se3d_ctx *c, int32_t n_seq, se3d_fused_out *outs) {
+  if (!c || !outs || n_seq < 1 || n_seq > c->Q.S) return SE3D_ERR_ARG;
+  if (!c->ran2) { c->err = "fetch before run"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  return fetch_stage2_range(c, 0, n_seq, outs);
+}
+
+int se3d_pack_stage2_device(se3d_ctx *c, void *d_persons, void *d_counts) {
+  if (!c || !d_persons || !d_counts) return SE3D_ERR_ARG;
+  if (!c->ran2) return SE3D_ERR_STATE;
+  const Se3dStage2 &Q = c->Q;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(d_persons, Q.fused, sizeof(se3d_person3d) * (size_t)Q.S * Q.H, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_counts, Q.n_out, sizeof(int32_t) * (size_t)Q.S, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return SE3D_OK;
 }
 

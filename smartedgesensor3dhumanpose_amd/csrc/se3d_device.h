@@ -80,3 +80,51 @@ __device__ __constant__ const int c_kp2fusion[2][SE3D_NKP] = {{0, 16, 15, 18, 17
 
 // FUSION_BODY_PARTS indices used by the post-processing (FBP:3-24)
 enum { FU_Nose = 0, FU_Neck = 1, FU_RShoulder = 2, FU_LShoulder = 5, FU_MidHip = 8, FU_RHip = 9, FU_RAnkle = 11, FU_LHip = 12, FU_LAnkle = 14, FU_Belly = 20 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// stage 2 (pose_prior) device state.  S = sequences (one pose_prior node instance each, = frame slots of stage 1),
+// T = max tracks per sequence.  Track order (the reference's g_tracks vector order, which fixes Hungarian column order
+// and merge precedence) is the indirection order[s][k] -> slot; erasing a track is a stable compaction of `order`.
+// ---------------------------------------------------------------------------------------------------------------
+struct Se3dStage2 {
+  int S, T, H, N;
+  int pose_method, norm_height;
+  // inputs of the current call
+  const se3d_person3d *dets;  // [S][H]
+  const int32_t *n_det;       // [S]
+  const float *fb_delay;      // [S][N]
+  const double *t;            // [S]
+  int seq0;                   // first sequence handled by this launch (blockIdx + seq0)
+  // per-sequence globals (PP:54-60)
+  double *fb_buf;     // [S][3]
+  double *t_prev;     // [S]
+  int32_t *next_id;   // [S]
+  int32_t *frame_nr;  // [S]
+  int32_t *n_tracks;  // [S]
+  int32_t *order;     // [S][T]
+  double *pred_dt;    // [S]
+  // per-track slots (PP:68-76)
+  uint8_t *used;        // [S][T]
+  int32_t *id;          // [S][T]
+  int32_t *num_obs;     // [S][T]
+  uint32_t *has;        // [S][T] bit k: prevEstimate.exists(k)
+  double *trk_t_prev;   // [S][T]
+  double *height_prev;  // [S][T]
+  double *root_prev;    // [S][T][3]
+  double *prev;         // [S][T][21][3]
+  double *vel;          // [S][T][21][3][3]
+  // per-call work
+  double *C;            // [S][H*T] cost matrix (rows = detections), column-major ld = n_det
+  double *W;            // [S][H*T] Munkres working copy
+  int32_t *det_slot;    // [S][H] track slot of each detection (-1: none)
+  uint8_t *pub;         // [S][H] publish flag of each detection
+  se3d_person3d *fused_det;  // [S][H] per detection
+  se3d_person3d *pred_det;   // [S][H]
+  int32_t *iters_det;        // [S][H]
+  // outputs
+  se3d_person3d *fused;   // [S][H] compacted
+  se3d_person3d *pred;    // [S][H]
+  int32_t *iters;         // [S][H]
+  int32_t *n_out;         // [S]
+  uint32_t *flags2;       // [S]
+};

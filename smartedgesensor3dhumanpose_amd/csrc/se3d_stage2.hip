@@ -1,10 +1,767 @@
-// se3d_stage2.hip — pose_prior refinement on gfx950 (placeholder until the LM kernels land in this round).
+// se3d_stage2.hip — pose_prior refinement on CDNA4 (gfx950): track association (PP:548-580), per-person factor graph
+// (unary Gaussian + bone-length range factors, PP:626-744) optimised with Levenberg-Marquardt under GTSAM 4.0.3 default
+// semantics (PP:746-758), marginal covariances (PP:760-793), de-normalisation + velocity prediction (PP:769-852) and
+// track lifecycle (PP:191-211, 867-903).  SURVEY §8a rows Y, A2, F, R, Z, L.
+//
+// One wavefront per person: the whitened Jacobian J (<= 84 x 63) is never materialised — MFMA operands for the dense
+// J^T J (v_mfma_f64_16x16x4_f64, the only MFMA use on the path) are generated on the fly from the compact factor
+// data; H = J^T J + lambda I lives in LDS (64 x 65 doubles), Cholesky / triangular solves / inverse run on the 64 lanes.
 #include "se3d_device.h"
-struct se3d_ctx;
-extern "C" {
-int se3d_refine_reset(se3d_ctx *) { return SE3D_ERR_STATE; }
-int se3d_refine(se3d_ctx *, int32_t, int32_t, const se3d_person3d *, int32_t, const float *, double, se3d_fused_out *) { return SE3D_ERR_STATE; }
-int se3d_run_stage2(se3d_ctx *, int32_t, const double *) { return SE3D_ERR_STATE; }
-int se3d_fetch_stage2(se3d_ctx *, int32_t, se3d_fused_out *) { return SE3D_ERR_STATE; }
-int se3d_pack_stage2_device(se3d_ctx *, void *, void *) { return SE3D_ERR_STATE; }
+#include "se3d_munkres.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __constant__ const double c_vel_sigmas[SE3D_NFU] = {2., 1., 1., 2., 3., 1., 2., 3., 1., 1., 2., 3., 1., 2., 3., 2., 2., 2., 2., 2., 1.};  // FBP:33
+struct Se3dBone { int k1, k2; double L, sigma; int not_belly; };
+// addBinaryFactors: [0] absolute bone lengths (PP:434-479), [1] height-normalised (PP:386-431)
+__device__ __constant__ const Se3dBone c_bones[2][21] = {
+    {{8, 9, 0.134, 0.033, 0},   {8, 12, 0.134, 0.033, 0},  {9, 10, 0.449, 0.051, 0},  {10, 11, 0.446, 0.051, 0}, {12, 13, 0.449, 0.051, 0},
+     {13, 14, 0.446, 0.051, 0}, {1, 0, 0.20, 0.025, 0},    {1, 2, 0.15, 0.042, 0},    {1, 5, 0.15, 0.042, 0},    {2, 3, 0.28, 0.045, 0},
+     {3, 4, 0.25, 0.063, 0},    {5, 6, 0.28, 0.045, 0},    {6, 7, 0.25, 0.063, 0},    {8, 20, 0.23846, 0.071, 0}, {20, 1, 0.25534, 0.035, 0},
+     {0, 19, 0.11500, 0.035, 0}, {8, 1, 0.50, 0.071, 1},   {0, 15, 0.05, 0.035, 0},   {0, 16, 0.05, 0.035, 0},   {15, 17, 0.10, 0.05, 0},
+     {16, 18, 0.10, 0.05, 0}},
+    {{8, 9, 0.17, 0.062, 0},    {8, 12, 0.17, 0.062, 0},   {9, 10, 0.694, 0.111, 0},  {10, 11, 0.708, 0.097, 0}, {12, 13, 0.694, 0.111, 0},
+     {13, 14, 0.708, 0.097, 0}, {1, 0, 0.33, 0.050, 0},    {1, 2, 0.262, 0.092, 0},   {1, 5, 0.262, 0.092, 0},   {2, 3, 0.515, 0.071, 0},
+     {3, 4, 0.444, 0.084, 0},   {5, 6, 0.515, 0.071, 0},   {6, 7, 0.444, 0.084, 0},   {8, 20, 0.49, 0.05, 0},    {20, 1, 0.51, 0.05, 0},
+     {0, 19, 0.23, 0.05, 0},    {8, 1, 1.000, 0.02, 1},    {0, 15, 0.085, 0.06, 0},   {0, 16, 0.085, 0.06, 0},   {15, 17, 0.167, 0.08, 0},
+     {16, 18, 0.167, 0.08, 0}}};
+
+__device__ __forceinline__ int s2_block_excl_scan(bool flag, int *wsum, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long b = __ballot(flag);
+  const int within = __popcll(b & ((1ull << lane) - 1ull));
+  if (lane == 0) wsum[wave] = __popcll(b);
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wave; ++w) off += wsum[w];
+  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  return off + within;
+}
+
+// remove_old_tracks (PP:191-211): stable erase of tracks unobserved for more than 1 s.  blockDim = 256 >= T.
+__device__ void s2_remove_old(const Se3dStage2 &Q, int s, double t, int *wsum, int *tmp /*LDS[256]*/) {
+  const int tid = threadIdx.x, T = Q.T;
+  const int nt = Q.n_tracks[s];
+  int *order = Q.order + (size_t)s * T;
+  int slot = -1;
+  bool keep = false;
+  if (tid < nt) {
+    slot = order[tid];
+    keep = !(t - Q.trk_t_prev[(size_t)s * T + slot] > 1.0);
+    if (!keep) Q.used[(size_t)s * T + slot] = 0;
+  }
+  int total;
+  const int pos = s2_block_excl_scan(keep, wsum, total);
+  if (keep) tmp[pos] = slot;
+  __syncthreads();
+  if (tid < total) order[tid] = tmp[tid];
+  if (tid == 0) Q.n_tracks[s] = total;
+  __syncthreads();
+}
+
+// =============================================================================================================
+// rows Y + A2 — track <-> detection association (PP:513-580).  One workgroup per sequence.
+// =============================================================================================================
+__global__ __launch_bounds__(256) void se3d_k_track_assoc(Se3dStage2 Q) {
+  const int s = blockIdx.x + Q.seq0, tid = threadIdx.x;
+  const int T = Q.T, H = Q.H, N = Q.N;
+  __shared__ MunkresShared MS;
+  __shared__ int assign[SE3D_MUNKRES_MAX];
+  __shared__ int freelist[SE3D_MUNKRES_MAX];
+  __shared__ int wsum[4];
+  const double t = Q.t[s];
+  const int nd = min(Q.n_det[s], H);
+  if (tid == 0) {  // feedback-delay moving average -> pred_delta_t (PP:513-526)
+    double acc = 0.0;
+    int nv = 0;
+    for (int i = 0; i < N; ++i) {
+      const float d = Q.fb_delay ? Q.fb_delay[(size_t)s * N + i] : -1.0f;
+      if (d > 0.0f) { acc += (double)d; ++nv; }
+    }
+    const double cur = nv > 0 ? acc / nv : 0.10;
+    Q.fb_buf[s * 3 + (Q.frame_nr[s] % 3)] = cur;
+    Q.pred_dt[s] = (0.0 + Q.fb_buf[s * 3 + 0] + Q.fb_buf[s * 3 + 1] + Q.fb_buf[s * 3 + 2]) / 3;
+    Q.n_out[s] = 0;
+  }
+  for (int i = tid; i < H; i += 256) { Q.det_slot[(size_t)s * H + i] = -1; Q.pub[(size_t)s * H + i] = 0; }
+  for (int i = tid; i < SE3D_MUNKRES_MAX; i += 256) assign[i] = -1;
+  __syncthreads();
+  if (nd == 0) {  // PP:537-546 (g_frame_nr is not advanced on empty frames)
+    s2_remove_old(Q, s, t, wsum, freelist);
+    if (tid == 0) Q.t_prev[s] = t;
+    return;
+  }
+  const int nt = Q.n_tracks[s];
+  int *order = Q.order + (size_t)s * T;
+  const se3d_person3d *dets = Q.dets + (size_t)s * H;
+  double *C = Q.C + (size_t)s * H * T, *W = Q.W + (size_t)s * H * T;
+  for (int idx = tid; idx < nd * nt; idx += 256) {  // calc_normed_dist (PP:84-101)
+    const int det = idx % nd, tk = idx / nd;
+    const size_t sl = (size_t)s * T + order[tk];
+    const double delta_t = t - Q.trk_t_prev[sl];
+    const double hp = Q.height_prev[sl];
+    const double *rp = Q.root_prev + sl * 3, *pv = Q.prev + sl * SE3D_NFU * 3;
+    const uint32_t has = Q.has[sl];
+    int nj = 0;
+    double dist = 0.0;
+    for (int k = 0; k < SE3D_NFU; ++k) {
+      const se3d_keypoint3d &kp = dets[det].keypoints[k];
+      if (kp.score > 0.10f && ((has >> k) & 1u)) {
+        const double px = pv[k * 3 + 0] * hp + rp[0], py = pv[k * 3 + 1] * hp + rp[1], pz = pv[k * 3 + 2] * hp + rp[2];
+        const double dx = kp.joint[0] - px, dy = kp.joint[1] - py, dz = kp.joint[2] - pz;
+        dist += sqrt(dx * dx + dy * dy + dz * dz) / (c_vel_sigmas[k] * delta_t);
+        ++nj;
+      }
+    }
+    const double c = nj > 0 ? dist / nj : 1e6;
+    C[idx] = c;
+    W[idx] = c;
+  }
+  __syncthreads();
+  if (nt > 0) {
+    if (se3d_munkres_block(W, nd, nd, nt, MS, assign) != 0 && tid == 0) atomicOr(&Q.flags2[s], 4u);
+    if (tid < nd) {  // PP:562-565
+      const int a = assign[tid];
+      if (a >= 0 && C[tid + (size_t)nd * a] > 5.0) assign[tid] = -1;
+    }
+    __syncthreads();
+  }
+  // new tracks for unassigned detections, in detection order (PP:570-580)
+  const bool isnew = (tid < nd) && (nt == 0 || assign[tid] < 0);
+  int total_new, total_free;
+  const int p = s2_block_excl_scan(isnew, wsum, total_new);
+  const bool fr = (tid < T) && !Q.used[(size_t)s * T + tid];
+  const int q = s2_block_excl_scan(fr, wsum, total_free);
+  if (fr) freelist[q] = tid;
+  __syncthreads();
+  if (tid < nd) {
+    if (!isnew) {
+      Q.det_slot[(size_t)s * H + tid] = order[assign[tid]];
+    } else if (nt + p < T && p < total_free) {
+      const int slot = freelist[p];
+      const size_t sl = (size_t)s * T + slot;
+      Q.used[sl] = 1;
+      Q.id[sl] = Q.next_id[s] + p;
+      Q.num_obs[sl] = 0;
+      Q.has[sl] = 0;
+      Q.trk_t_prev[sl] = t;  // the reference leaves t_prev uninitialised until the first update (PP:79-82)
+      Q.height_prev[sl] = -1.0;
+      for (int a = 0; a < 3; ++a) Q.root_prev[sl * 3 + a] = 0.0;
+      for (int a = 0; a < SE3D_NFU * 9; ++a) Q.vel[sl * SE3D_NFU * 9 + a] = 0.0;
+      order[nt + p] = slot;
+      Q.det_slot[(size_t)s * H + tid] = slot;
+    } else {
+      atomicOr(&Q.flags2[s], 1u);  // track capacity exceeded
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int created = min(total_new, min(T - nt, total_free));
+    Q.n_tracks[s] = nt + created;
+    Q.next_id[s] += total_new;
+  }
+}
+
+// =============================================================================================================
+// rows F, R, Z — one wavefront per detection: build the graph, LM, marginals, outputs, track-state update.
+// =============================================================================================================
+#define HS 65  // LDS row stride of H (doubles): column accesses by 64 lanes stay conflict-free
+
+struct LmLds {
+  double Hm[64 * HS];
+  double Rm[SE3D_NFU][9];   // whitening matrix of each variable's unary factor (R^T R = Sigma^-1)
+  double mm[SE3D_NFU][3];   // unary measurement
+  double xc[SE3D_NFU][3];   // current values
+  double xn[SE3D_NFU][3];   // tentative values
+  double bb[88];            // -whitened error (unary rows 3v+i, then range rows)
+  double Hs[21][3];         // range Jacobian direction / sigma
+  double rL[21], rS[21];
+  double gg[64], dl[64];
+  int rv1[21], rv2[21];
+  int keyofcol[SE3D_NFU];
+};
+
+__device__ __forceinline__ double s2_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// noiseModel::Gaussian::Covariance(cov, smart): |off-diagonal| <= 1e-9 (upper triangle) -> Diagonal sigmas, else
+// R = upper Cholesky factor of cov^-1.  Returns false if cov^-1 is not positive definite.
+__device__ bool s2_make_whitener(const double cov[9], double R[9]) {
+  for (int i = 0; i < 9; ++i) R[i] = 0.0;
+  const bool full = fabs(cov[1]) > 1e-9 || fabs(cov[2]) > 1e-9 || fabs(cov[5]) > 1e-9;
+  if (!full) {
+    R[0] = 1.0 / sqrt(cov[0]); R[4] = 1.0 / sqrt(cov[4]); R[8] = 1.0 / sqrt(cov[8]);
+    return true;
+  }
+  const double a = cov[0], b = cov[1], c = cov[2], d = cov[3], e = cov[4], f = cov[5], g = cov[6], h = cov[7], i9 = cov[8];
+  const double c00 = e * i9 - f * h, c01 = -(d * i9 - f * g), c02 = d * h - e * g;
+  const double det = a * c00 + b * c01 + c * c02, id = 1.0 / det;
+  const double inv[9] = {c00 * id, -(b * i9 - c * h) * id, (b * f - c * e) * id, c01 * id, (a * i9 - c * g) * id,
+                         -(a * f - c * d) * id, c02 * id, -(a * h - b * g) * id, (a * e - b * d) * id};
+  const double s01 = 0.5 * (inv[1] + inv[3]), s02 = 0.5 * (inv[2] + inv[6]), s12 = 0.5 * (inv[5] + inv[7]);
+  double l00 = inv[0];
+  if (!(l00 > 0.0)) return false;
+  l00 = sqrt(l00);
+  const double l10 = s01 / l00, l20 = s02 / l00;
+  double l11 = inv[4] - l10 * l10;
+  if (!(l11 > 0.0)) return false;
+  l11 = sqrt(l11);
+  const double l21 = (s12 - l20 * l10) / l11;
+  double l22 = inv[8] - l20 * l20 - l21 * l21;
+  if (!(l22 > 0.0)) return false;
+  l22 = sqrt(l22);
+  R[0] = l00; R[1] = l10; R[2] = l20; R[4] = l11; R[5] = l21; R[8] = l22;  // R = L^T
+  return true;
+}
+
+// 0.5 * sum ||whitened error||^2 at values x (NonlinearFactorGraph::error)
+__device__ __forceinline__ double s2_graph_error(const LmLds &L, const double (*x)[3], int K, int nr, int lane) {
+  double e = 0.0;
+  if (lane < K) {
+    const double r0 = x[lane][0] - L.mm[lane][0], r1 = x[lane][1] - L.mm[lane][1], r2 = x[lane][2] - L.mm[lane][2];
+    for (int i = 0; i < 3; ++i) {
+      const double w = L.Rm[lane][i * 3 + 0] * r0 + L.Rm[lane][i * 3 + 1] * r1 + L.Rm[lane][i * 3 + 2] * r2;
+      e += 0.5 * w * w;
+    }
+  } else if (lane < K + nr) {
+    const int ee = lane - K;
+    const int v1 = L.rv1[ee], v2 = L.rv2[ee];
+    const double dx = x[v2][0] - x[v1][0], dy = x[v2][1] - x[v1][1], dz = x[v2][2] - x[v1][2];
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    const double w = (r - L.rL[ee]) / L.rS[ee];
+    e = 0.5 * w * w;
+  }
+  return s2_wave_sum(e);
+}
+
+// linearise at L.xc: b = -whitened error; range rows keep H/sigma (RangeFactor<Point3>: d/r, or (1,1,1) if r <= 1e-10)
+__device__ __forceinline__ void s2_linearize(LmLds &L, int K, int nr, int lane) {
+  if (lane < K) {
+    const double r0 = L.xc[lane][0] - L.mm[lane][0], r1 = L.xc[lane][1] - L.mm[lane][1], r2 = L.xc[lane][2] - L.mm[lane][2];
+    for (int i = 0; i < 3; ++i)
+      L.bb[3 * lane + i] = -(L.Rm[lane][i * 3 + 0] * r0 + L.Rm[lane][i * 3 + 1] * r1 + L.Rm[lane][i * 3 + 2] * r2);
+  } else if (lane < K + nr) {
+    const int ee = lane - K;
+    const int v1 = L.rv1[ee], v2 = L.rv2[ee];
+    const double dx = L.xc[v2][0] - L.xc[v1][0], dy = L.xc[v2][1] - L.xc[v1][1], dz = L.xc[v2][2] - L.xc[v1][2];
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    double h0 = 1.0, h1 = 1.0, h2 = 1.0;
+    if (fabs(r) > 1e-10) { h0 = dx / r; h1 = dy / r; h2 = dz / r; }
+    const double sg = L.rS[ee];
+    L.Hs[ee][0] = h0 / sg; L.Hs[ee][1] = h1 / sg; L.Hs[ee][2] = h2 / sg;
+    L.bb[3 * K + ee] = -(r - L.rL[ee]) / sg;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// dense J^T J on the matrix cores: operands generated on the fly, result (lower+upper) stored to L.Hm, diag += lambda
+__device__ void s2_jtj_mfma(LmLds &L, int K, int nr, double lambda, int lane) {
+  const int n = 3 * K, mrows = n + nr;
+  const int ksteps = (mrows + 3) >> 2;
+  const int ntile = (n + 15) >> 4;
+  int cv[4], ca[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = 16 * t + (lane & 15);
+    cv[t] = (c < n) ? c / 3 : -1;
+    ca[t] = c % 3;
+  }
+  d4 acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int r = 4 * ks + (lane >> 4);
+    double val[4] = {0.0, 0.0, 0.0, 0.0};
+    if (r < n) {
+      const int u = r / 3, ii = r - 3 * u;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) val[t] = (cv[t] == u) ? L.Rm[u][ii * 3 + ca[t]] : 0.0;
+    } else if (r < mrows) {
+      const int ee = r - n;
+      const int v1 = L.rv1[ee], v2 = L.rv2[ee];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) val[t] = (cv[t] == v1) ? -L.Hs[ee][ca[t]] : (cv[t] == v2) ? L.Hs[ee][ca[t]] : 0.0;
+    }
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[0], val[0], acc[0], 0, 0, 0);
+    if (ntile > 1) {
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[0], val[1], acc[1], 0, 0, 0);
+      acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[1], val[1], acc[4], 0, 0, 0);
+    }
+    if (ntile > 2) {
+      acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[0], val[2], acc[2], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[1], val[2], acc[5], 0, 0, 0);
+      acc[7] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[2], val[2], acc[7], 0, 0, 0);
+    }
+    if (ntile > 3) {
+      acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[0], val[3], acc[3], 0, 0, 0);
+      acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[1], val[3], acc[6], 0, 0, 0);
+      acc[8] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[2], val[3], acc[8], 0, 0, 0);
+      acc[9] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[3], val[3], acc[9], 0, 0, 0);
+    }
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const int ti_of[10] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3}, tj_of[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const int ti = ti_of[i], tj = tj_of[i];
+    if (tj < ntile) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int rr = 16 * ti + (lane >> 4) + 4 * reg, cc = 16 * tj + (lane & 15);
+        double v = acc[i][reg];
+        if (rr == cc && rr < n) v += lambda;  // sqrt(lambda) * I prior per variable (LM damping, diagonalDamping = false)
+        L.Hm[rr * HS + cc] = v;
+        if (ti != tj) L.Hm[cc * HS + rr] = v;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// in-place lower Cholesky of L.Hm[0..n) (left-looking; lane i owns row i).  Returns false if not positive definite.
+__device__ bool s2_cholesky(double *Hm, int n, int lane) {
+  for (int j = 0; j < n; ++j) {
+    double sreg = 0.0;
+    if (lane >= j && lane < n) {
+      sreg = Hm[lane * HS + j];
+      for (int k = 0; k < j; ++k) sreg -= Hm[lane * HS + k] * Hm[j * HS + k];
+    }
+    const double d = __shfl(sreg, j);
+    if (!(d > 0.0)) return false;
+    const double sd = sqrt(d);
+    if (lane == j) Hm[j * HS + j] = sd;
+    else if (lane > j && lane < n) Hm[lane * HS + j] = sreg / sd;
+    __builtin_amdgcn_wave_barrier();
+  }
+  return true;
+}
+
+// solve L L^T x = rhs; lane i holds rhs[i] on entry and x[i] on return (column-oriented substitutions in registers)
+__device__ double s2_chol_solve(const double *Hm, int n, double rhs, int lane) {
+  double b = rhs;
+  for (int k = 0; k < n; ++k) {
+    const double yk = __shfl(b / Hm[k * HS + k], k);
+    if (lane == k) b = yk;
+    else if (lane > k && lane < n) b -= Hm[lane * HS + k] * yk;
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    const double xk = __shfl(b / Hm[k * HS + k], k);
+    if (lane == k) b = xk;
+    else if (lane < k) b -= Hm[k * HS + lane] * xk;
+  }
+  return b;
+}
+
+// in-place inverse of the lower-triangular factor (X = L^-1), lane i owns row i
+__device__ void s2_tri_inverse(double *Hm, int n, int lane) {
+  for (int j = n - 1; j >= 0; --j) {
+    const double xjj = 1.0 / Hm[j * HS + j];
+    double tacc = 0.0;
+    if (lane > j && lane < n)
+      for (int k = j + 1; k <= lane; ++k) tacc += Hm[lane * HS + k] * Hm[k * HS + j];
+    __builtin_amdgcn_wave_barrier();
+    if (lane > j && lane < n) Hm[lane * HS + j] = -tacc * xjj;
+    if (lane == j) Hm[j * HS + j] = xjj;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__device__ __forceinline__ void s2_cov6_to_mat(const double c[6], double M[9]) {
+  M[0] = c[0]; M[1] = c[1]; M[2] = c[2]; M[3] = c[1]; M[4] = c[3]; M[5] = c[4]; M[6] = c[2]; M[7] = c[4]; M[8] = c[5];
+}
+
+__global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
+  extern __shared__ __align__(16) unsigned char s2_smem[];
+  LmLds &L = *reinterpret_cast<LmLds *>(s2_smem);
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x, s = blockIdx.y + Q.seq0;
+  const int H = Q.H, T = Q.T;
+  if (i >= min(Q.n_det[s], H)) return;
+  const int slot = Q.det_slot[(size_t)s * H + i];
+  if (slot < 0) return;
+  const size_t sl = (size_t)s * T + slot;
+  const se3d_person3d &person = Q.dets[(size_t)s * H + i];
+  const bool simple = Q.pose_method == SE3D_POSE_SIMPLE;
+  const double t = Q.t[s];
+
+  // ---- root / neck / height (PP:631-668), identical on every lane ----
+  double root[3] = {0, 0, 0}, neck[3] = {0, 0, 0};
+  float root_score = 0.f, neck_score = 0.f;
+  if (!simple) {
+    for (int a = 0; a < 3; ++a) { root[a] = person.keypoints[FU_MidHip].joint[a]; neck[a] = person.keypoints[FU_Neck].joint[a]; }
+    root_score = person.keypoints[FU_MidHip].score;
+    neck_score = person.keypoints[FU_Neck].score;
+  } else {
+    const se3d_keypoint3d &hl = person.keypoints[FU_LHip], &hr = person.keypoints[FU_RHip];
+    if (hl.score > 0.0f && hr.score > 0.0f) {
+      for (int a = 0; a < 3; ++a) root[a] = (hl.joint[a] + hr.joint[a]) / 2.0;
+      root_score = (hl.score + hr.score) / 2.0f;
+    }
+    const se3d_keypoint3d &sL = person.keypoints[FU_LShoulder], &sR = person.keypoints[FU_RShoulder];
+    if (sL.score > 0.0f && sR.score > 0.0f) {
+      for (int a = 0; a < 3; ++a) neck[a] = (sL.joint[a] + sR.joint[a]) / 2.0;
+      neck_score = (sL.score + sR.score) / 2.0f;
+    }
+  }
+  const bool has_root = root_score > 0.10f;
+  double height = 1.0;
+  if (has_root && Q.norm_height) {
+    if (neck_score > 0.10f) {
+      const double dx = neck[0] - root[0], dy = neck[1] - root[1], dz = neck[2] - root[2];
+      height = sqrt(dx * dx + dy * dy + dz * dz);
+    } else height = 0.60;
+  }
+  if (Q.height_prev[sl] < 0.0) {  // PP:699-702 (uniform; all lanes write the same values)
+    if (lane == 0) { Q.height_prev[sl] = height; for (int a = 0; a < 3; ++a) Q.root_prev[sl * 3 + a] = root[a]; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const double hprev = (Q.height_prev[sl] < 0.0) ? height : Q.height_prev[sl];
+  double rprev[3];
+  for (int a = 0; a < 3; ++a) rprev[a] = (Q.height_prev[sl] < 0.0) ? root[a] : Q.root_prev[sl * 3 + a];
+
+  // ---- measurements: lane k <-> fusion joint k (PP:690-737) ----
+  bool measured = false;
+  double m[3] = {0, 0, 0}, cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float kscore = 0.f;
+  if (lane < SE3D_NFU) {
+    const int k = lane;
+    if (k == FU_MidHip) {
+      if (has_root) {
+        measured = true;
+        if (!simple) s2_cov6_to_mat(person.keypoints[FU_MidHip].cov, cov);
+        else {
+          double cl[9], cr[9];
+          s2_cov6_to_mat(person.keypoints[FU_LHip].cov, cl);
+          s2_cov6_to_mat(person.keypoints[FU_RHip].cov, cr);
+          for (int q = 0; q < 9; ++q) cov[q] = (cl[q] + cr[q]) / 2.0;
+        }
+        for (int q = 0; q < 9; ++q) cov[q] = cov[q] / (height * height) / (100.0 * 100.0);
+        kscore = root_score;
+      }
+    } else if (simple && k == FU_Neck && neck_score > 0.10f) {
+      measured = true;
+      double cl[9], cr[9];
+      s2_cov6_to_mat(person.keypoints[FU_LShoulder].cov, cl);
+      s2_cov6_to_mat(person.keypoints[FU_RShoulder].cov, cr);
+      for (int q = 0; q < 9; ++q) cov[q] = (cl[q] + cr[q]) / 2.0 / (height * height);
+      for (int a = 0; a < 3; ++a) m[a] = (neck[a] - root[a]) / height;
+      kscore = neck_score;
+    } else {
+      const se3d_keypoint3d &kp = person.keypoints[k];
+      if (kp.score > 0.10f) {
+        measured = true;
+        double c9[9];
+        s2_cov6_to_mat(kp.cov, c9);
+        for (int q = 0; q < 9; ++q) cov[q] = c9[q] / (height * height);
+        for (int a = 0; a < 3; ++a) m[a] = (kp.joint[a] - root[a]) / height;
+        kscore = kp.score;
+      }
+    }
+  }
+  const unsigned long long mb = __ballot(measured);
+  const uint32_t measmask = (uint32_t)mb;
+  const int K = __popcll(mb);
+  if (K == 0) return;  // PP:739-741
+  const int col = __popcll(mb & ((1ull << lane) - 1ull));
+  const uint32_t hasprev = Q.has[sl];
+  const bool use_vel = measured && ((hasprev >> lane) & 1u);
+  bool wok = true;
+  double x0[3] = {0, 0, 0};
+  if (measured) {
+    double R[9];
+    wok = s2_make_whitener(cov, R);
+    for (int q = 0; q < 9; ++q) L.Rm[col][q] = R[q];
+    for (int a = 0; a < 3; ++a) {
+      L.mm[col][a] = m[a];
+      x0[a] = use_vel ? Q.prev[(sl * SE3D_NFU + lane) * 3 + a] : m[a];  // setInitialState (PP:483-503)
+      L.xc[col][a] = x0[a];
+    }
+    L.keyofcol[col] = lane;
+  }
+  const bool whiten_ok = __ballot(!wok) == 0ull;
+  // ---- range factors in table order (PP:384-481) ----
+  bool ract = false;
+  Se3dBone bd = c_bones[Q.norm_height ? 1 : 0][lane < 21 ? lane : 0];
+  if (lane < 21) ract = ((measmask >> bd.k1) & 1u) && ((measmask >> bd.k2) & 1u) && (!bd.not_belly || !((measmask >> FU_Belly) & 1u));
+  const unsigned long long rb = __ballot(ract);
+  const int nr = __popcll(rb);
+  if (ract) {
+    const int ee = __popcll(rb & ((1ull << lane) - 1ull));
+    L.rv1[ee] = __popc(measmask & ((1u << bd.k1) - 1u));
+    L.rv2[ee] = __popc(measmask & ((1u << bd.k2) - 1u));
+    L.rL[ee] = bd.L;
+    L.rS[ee] = bd.sigma * (Q.norm_height ? 2.0 : 1.0);  // g_limbLSigmaFactor (PP:934-937)
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int n = 3 * K;
+
+  // ---- LevenbergMarquardtOptimizer(graph, prevEstimate).optimize(), GTSAM 4.0.3 defaults ----
+  int iterations = 0;
+  if (whiten_ok) {
+    double error = s2_graph_error(L, L.xc, K, nr, lane);
+    double lambda = 1e-5;
+    if (!(error <= 0.0)) {
+      for (int outer = 0; outer < 1000; ++outer) {
+        const double currentError = error;
+        s2_linearize(L, K, nr, lane);
+        // g = J^T b (lane c < n)
+        double g = 0.0;
+        if (lane < n) {
+          const int v = lane / 3, a = lane - 3 * v;
+          g = L.Rm[v][0 * 3 + a] * L.bb[3 * v] + L.Rm[v][1 * 3 + a] * L.bb[3 * v + 1] + L.Rm[v][2 * 3 + a] * L.bb[3 * v + 2];
+          for (int ee = 0; ee < nr; ++ee) {
+            const double hv = (v == L.rv1[ee]) ? -L.Hs[ee][a] : (v == L.rv2[ee]) ? L.Hs[ee][a] : 0.0;
+            g += hv * L.bb[n + ee];
+          }
+        }
+        bool stepped = false;
+        for (int tr = 0; tr < 64; ++tr) {  // tryLambda
+          s2_jtj_mfma(L, K, nr, lambda, lane);
+          const bool solved = s2_cholesky(L.Hm, n, lane);
+          bool step_ok = false, stop = false;
+          double newError = 0.0;
+          if (solved) {
+            const double d = s2_chol_solve(L.Hm, n, g, lane);
+            if (lane < n) L.dl[lane] = d;
+            __builtin_amdgcn_wave_barrier();
+            // linear.error(delta) = 0.5 ||J delta - b||^2 over the undamped factors
+            double le = 0.0;
+            for (int r = lane; r < n + nr; r += 64) {
+              double sv;
+              if (r < n) {
+                const int u = r / 3, ii = r - 3 * u;
+                sv = L.Rm[u][ii * 3 + 0] * L.dl[3 * u] + L.Rm[u][ii * 3 + 1] * L.dl[3 * u + 1] + L.Rm[u][ii * 3 + 2] * L.dl[3 * u + 2] - L.bb[r];
+              } else {
+                const int ee = r - n;
+                const int v1 = L.rv1[ee], v2 = L.rv2[ee];
+                sv = L.Hs[ee][0] * (L.dl[3 * v2] - L.dl[3 * v1]) + L.Hs[ee][1] * (L.dl[3 * v2 + 1] - L.dl[3 * v1 + 1]) +
+                     L.Hs[ee][2] * (L.dl[3 * v2 + 2] - L.dl[3 * v1 + 2]) - L.bb[r];
+              }
+              le += 0.5 * sv * sv;
+            }
+            le = s2_wave_sum(le);
+            const double linearizedCostChange = error - le;
+            if (linearizedCostChange >= 0) {
+              if (lane < K)
+                for (int a = 0; a < 3; ++a) L.xn[lane][a] = L.xc[lane][a] + L.dl[3 * lane + a];  // retract
+              __builtin_amdgcn_wave_barrier();
+              newError = s2_graph_error(L, L.xn, K, nr, lane);
+              const double costChange = error - newError;
+              if (linearizedCostChange > 1e-20) {
+                const double modelFidelity = costChange / linearizedCostChange;
+                step_ok = modelFidelity > 1e-3;
+              }
+              if (fabs(costChange) < 1e-5 * error) stop = true;
+            }
+          }
+          if (step_ok) {  // decreaseLambda (useFixedLambdaFactor)
+            if (lane < K)
+              for (int a = 0; a < 3; ++a) L.xc[lane][a] = L.xn[lane][a];
+            __builtin_amdgcn_wave_barrier();
+            error = newError;
+            lambda /= 10.0;
+            if (lambda < 0.0) lambda = 0.0;
+            ++iterations;
+            stepped = true;
+            break;
+          } else if (!stop) {  // increaseLambda
+            lambda *= 10.0;
+            if (lambda >= 1e5) break;
+          } else {
+            break;
+          }
+        }
+        (void)stepped;
+        if (iterations >= 100) break;  // maxIterations
+        if (error <= 0.0) break;       // errorTol
+        const double absoluteDecrease = currentError - error;
+        const double relativeDecrease = absoluteDecrease / currentError;
+        if (relativeDecrease <= 1e-5 || absoluteDecrease <= 1e-5) break;
+        if (!isfinite(currentError)) break;
+      }
+    }
+  } else {
+    if (lane < K)
+      for (int a = 0; a < 3; ++a) L.xc[lane][a] = L.mm[lane][a];  // optimisation failed: output the measurements (PP:751-758)
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- Marginals(graph, result): diagonal 3x3 blocks of (J^T J)^-1 at the optimum (PP:760-793) ----
+  bool use_marg = false;
+  double mc[6] = {0, 0, 0, 0, 0, 0};
+  if (whiten_ok) {
+    s2_linearize(L, K, nr, lane);
+    s2_jtj_mfma(L, K, nr, 0.0, lane);
+    if (s2_cholesky(L.Hm, n, lane)) {
+      use_marg = true;
+      s2_tri_inverse(L.Hm, n, lane);
+      // lane k (measured) gathers its own block: (H^-1)[3c+a][3c+b] = sum_{i >= 3c+b} X[i][3c+a] X[i][3c+b]
+      if (measured) {
+        const int c0 = 3 * col;
+        int q = 0;
+        for (int a = 0; a < 3; ++a)
+          for (int b = a; b < 3; ++b, ++q) {
+            double acc = 0.0;
+            for (int r = c0 + b; r < n; ++r) acc += L.Hm[r * HS + c0 + a] * L.Hm[r * HS + c0 + b];
+            mc[q] = acc;
+          }
+      }
+    }
+  }
+
+  // ---- outputs + track-state update: lane k <-> fusion joint k (PP:769-843) ----
+  se3d_person3d &pf = Q.fused_det[(size_t)s * H + i];
+  se3d_person3d &pp = Q.pred_det[(size_t)s * H + i];
+  {  // zero both persons cooperatively, then fill the measured joints
+    uint32_t *w0 = reinterpret_cast<uint32_t *>(&pf), *w1 = reinterpret_cast<uint32_t *>(&pp);
+    for (int w = lane; w < (int)(sizeof(se3d_person3d) / 4); w += 64) { w0[w] = 0u; w1[w] = 0u; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int track_id = Q.id[sl];
+  if (lane == 0) { pf.id = (uint32_t)track_id; pp.id = (uint32_t)track_id; }
+  const double pred_dt = Q.pred_dt[s];
+  const int fslot = Q.frame_nr[s] % 3;
+  const double gtprev = Q.t_prev[s];
+  if (lane < SE3D_NFU) {
+    double *velk = Q.vel + (sl * SE3D_NFU + lane) * 9;
+    if (measured) {
+      const double q0 = L.xc[col][0], q1 = L.xc[col][1], q2 = L.xc[col][2];
+      const double jf[3] = {q0 * height + root[0], q1 * height + root[1], q2 * height + root[2]};
+      se3d_keypoint3d &kf = pf.keypoints[lane];
+      for (int a = 0; a < 3; ++a) kf.joint[a] = jf[a];
+      kf.score = fmaxf(0.10f, kscore);
+      double c6[6];
+      if (use_marg) for (int a = 0; a < 6; ++a) c6[a] = mc[a] * height * height;
+      else { c6[0] = c6[3] = c6[5] = 0.10 * 0.10; c6[1] = c6[2] = c6[4] = 0.0; }
+      if (lane == FU_MidHip) for (int a = 0; a < 6; ++a) c6[a] *= (100.0 * 100.0);
+      for (int a = 0; a < 6; ++a) kf.cov[a] = c6[a];
+      double jp[3] = {jf[0], jf[1], jf[2]};
+      if (use_vel) {
+        const double pv[3] = {x0[0] * hprev + rprev[0], x0[1] * hprev + rprev[1], x0[2] * hprev + rprev[2]};
+        for (int a = 0; a < 3; ++a) velk[fslot * 3 + a] = (jf[a] - pv[a]) / (t - gtprev);
+        for (int a = 0; a < 3; ++a) {
+          const double acc = ((0.0 + velk[0 * 3 + a]) + velk[1 * 3 + a]) + velk[2 * 3 + a];
+          jp[a] += acc / 3.0 * pred_dt;
+        }
+      }
+      se3d_keypoint3d &kpred = pp.keypoints[lane];
+      for (int a = 0; a < 3; ++a) kpred.joint[a] = jp[a];
+      kpred.score = kf.score;
+      for (int a = 0; a < 6; ++a) kpred.cov[a] = c6[a];
+      kpred.cov[0] += 0.12 * 0.12; kpred.cov[3] += 0.12 * 0.12; kpred.cov[5] += 0.12 * 0.12;  // g_predNoiseSigma (PP:831)
+      for (int a = 0; a < 3; ++a) Q.prev[(sl * SE3D_NFU + lane) * 3 + a] = L.xc[col][a];  // prevEstimate.swap(result)
+    } else if ((hasprev >> lane) & 1u) {
+      for (int a = 0; a < 9; ++a) velk[a] = 0.0;  // joint vanished: reset its velocity buffer (PP:490-493)
+    }
+  }
+  if (lane == 0) {
+    Q.has[sl] = measmask;
+    Q.trk_t_prev[sl] = t;
+    Q.height_prev[sl] = height;
+    for (int a = 0; a < 3; ++a) Q.root_prev[sl * 3 + a] = root[a];
+    const int no = Q.num_obs[sl] + 1;
+    Q.num_obs[sl] = no;
+    Q.pub[(size_t)s * H + i] = (no > 10) ? 1 : 0;  // g_min_num_obs_track (PP:845-848)
+    Q.iters_det[(size_t)s * H + i] = iterations;
+  }
+}
+
+// =============================================================================================================
+// row L + publishing — one workgroup per sequence (PP:845-852, 867-903, 909-910).
+// =============================================================================================================
+__global__ __launch_bounds__(256) void se3d_k_track_update(Se3dStage2 Q) {
+  const int s = blockIdx.x + Q.seq0, tid = threadIdx.x;
+  const int T = Q.T, H = Q.H;
+  __shared__ int wsum[4];
+  __shared__ int tmp[SE3D_MUNKRES_MAX];
+  __shared__ int alive[SE3D_MUNKRES_MAX];
+  __shared__ int srcdet[SE3D_MUNKRES_MAX];
+  const int nd = min(Q.n_det[s], H);
+  if (nd == 0) return;  // handled entirely in se3d_k_track_assoc
+  const double t = Q.t[s];
+  // publish in detection order
+  int n_out;
+  const bool pb = (tid < nd) && Q.pub[(size_t)s * H + tid];
+  const int pos = s2_block_excl_scan(pb, wsum, n_out);
+  if (pb) srcdet[pos] = tid;
+  __syncthreads();
+  const int words = (int)(sizeof(se3d_person3d) / 4);
+  for (int idx = tid; idx < n_out * words; idx += 256) {
+    const int p = idx / words, w = idx - p * words;
+    const size_t src = (size_t)s * H + srcdet[p], dst = (size_t)s * H + p;
+    reinterpret_cast<uint32_t *>(&Q.fused[dst])[w] = reinterpret_cast<const uint32_t *>(&Q.fused_det[src])[w];
+    reinterpret_cast<uint32_t *>(&Q.pred[dst])[w] = reinterpret_cast<const uint32_t *>(&Q.pred_det[src])[w];
+  }
+  if (tid < n_out) Q.iters[(size_t)s * H + tid] = Q.iters_det[(size_t)s * H + srcdet[tid]];
+  __syncthreads();
+  s2_remove_old(Q, s, t, wsum, tmp);
+  // merge overlapping tracks (PP:870-903): sequential in i, all later j in parallel (track i is not modified by a merge)
+  const int nt = Q.n_tracks[s];
+  int *order = Q.order + (size_t)s * T;
+  for (int k = tid; k < SE3D_MUNKRES_MAX; k += 256) alive[k] = (k < nt) ? 1 : 0;
+  __syncthreads();
+  for (int i = 0; i < nt; ++i) {
+    if (!alive[i]) continue;
+    const int j = tid;
+    if (j > i && j < nt && alive[j]) {
+      const size_t si = (size_t)s * T + order[i], sj = (size_t)s * T + order[j];
+      const uint32_t both = Q.has[si] & Q.has[sj];
+      int nj = 0;
+      double dist = 0.0;
+      for (int k = 0; k < SE3D_NFU; ++k)
+        if ((both >> k) & 1u) {
+          double d2 = 0.0;
+          for (int a = 0; a < 3; ++a) {
+            const double pa = Q.prev[(si * SE3D_NFU + k) * 3 + a] * Q.height_prev[si] + Q.root_prev[si * 3 + a];
+            const double pb2 = Q.prev[(sj * SE3D_NFU + k) * 3 + a] * Q.height_prev[sj] + Q.root_prev[sj * 3 + a];
+            d2 += (pa - pb2) * (pa - pb2);
+          }
+          dist += sqrt(d2);
+          ++nj;
+        }
+      const double dd = nj > 0 ? dist / nj : 1e6;
+      if (dd < 0.20) {
+        alive[j] = 0;
+        Q.used[sj] = 0;
+        const uint32_t idj = (uint32_t)Q.id[sj], idi = (uint32_t)Q.id[si];
+        for (int p = 0; p < n_out; ++p)  // re-assign id in the persons messages (PP:893-898)
+          if (Q.fused[(size_t)s * H + p].id == idj) { Q.fused[(size_t)s * H + p].id = idi; Q.pred[(size_t)s * H + p].id = idi; }
+      }
+    }
+    __syncthreads();
+  }
+  int total;
+  const bool kp = (tid < nt) && alive[tid];
+  const int slotv = (tid < nt) ? order[tid] : -1;
+  const int np = s2_block_excl_scan(kp, wsum, total);
+  if (kp) tmp[np] = slotv;
+  __syncthreads();
+  if (tid < total) order[tid] = tmp[tid];
+  if (tid == 0) {
+    Q.n_tracks[s] = total;
+    Q.n_out[s] = n_out;
+    Q.t_prev[s] = t;
+    Q.frame_nr[s] += 1;
+  }
+}
+
+extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev) {
+  Se3dStage2 q = Q;
+  q.seq0 = seq0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmLds));
+    attr_set = true;
+  }
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(se3d_k_track_assoc, dim3(nseq), dim3(256), 0, st, q);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  hipLaunchKernelGGL(se3d_k_lm_refine, dim3(q.H, nseq), dim3(64), sizeof(LmLds), st, q);
+  if (ev) (void)hipEventRecord(ev[2], st);
+  hipLaunchKernelGGL(se3d_k_track_update, dim3(nseq), dim3(256), 0, st, q);
+  if (ev) (void)hipEventRecord(ev[3], st);
 }

@@ -81,6 +81,34 @@ class Skeleton3D:
             r.c = o
         return res
 
+    # -- stage 2 (pose_prior) on the same context: sequence s <-> frame slot s
+    def refine_reset(self):
+        self._chk(self._L.se3d_refine_reset(C.c_void_p(self._h)), "se3d_refine_reset")
+
+    def refine(self, seq, dets, t, fb_delay_per_cam=None, capacity=None):
+        """One pose_prior skeletonCallback (PP:505) for sequence `seq` with host measurements."""
+        dets = np.ascontiguousarray(dets, pm.person3d_dt)
+        res = pm.FusedResult(capacity or self.limits.max_hyp)
+        fb = None if fb_delay_per_cam is None else np.ascontiguousarray(fb_delay_per_cam, np.float32)
+        self._chk(self._L.se3d_refine(C.c_void_p(self._h), int(seq), len(dets), C.c_void_p(dets.ctypes.data), self.rig.n_cam,
+                                      None if fb is None else pm.fptr(fb), C.c_double(t), C.byref(res.c)), "se3d_refine")
+        return res
+
+    def run_stage2(self, t):
+        t = np.ascontiguousarray(t, np.float64)
+        self._chk(self._L.se3d_run_stage2(C.c_void_p(self._h), len(t), t.ctypes.data_as(C.POINTER(C.c_double))), "se3d_run_stage2")
+
+    def fetch_stage2(self, n_seq, capacity=None):
+        res = [pm.FusedResult(capacity or self.limits.max_hyp) for _ in range(n_seq)]
+        outs = (pm.FusedOut * n_seq)(*[r.c for r in res])
+        self._chk(self._L.se3d_fetch_stage2(C.c_void_p(self._h), n_seq, outs), "se3d_fetch_stage2")
+        for r, o in zip(res, outs):
+            r.c = o
+        return res
+
+    def pack_stage2_device(self, persons_ptr, counts_ptr):
+        self._chk(self._L.se3d_pack_stage2_device(C.c_void_p(self._h), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)), "se3d_pack_stage2_device")
+
     def pack_stage1_device(self, persons_ptr, counts_ptr):
         self._chk(self._L.se3d_pack_stage1_device(C.c_void_p(self._h), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)), "se3d_pack_stage1_device")
 

@@ -56,3 +56,35 @@ def compare_stage1(gpu, ora, check_cov=True):
         stats["cov_rel_max"] = float(rel.max())
         assert rel.max() < COV_REL_FRO, "covariance relative Frobenius error %.2e" % rel.max()
     return stats
+
+
+REFINE_TOL_M = 1e-3     # refined joints: < 1 mm vs the CPU restatement (same GTSAM-equivalent LM semantics)
+MARG_COV_RTOL = 1e-4    # marginal covariances are fp64 on both sides
+
+
+def compare_stage2(gpu, ora, check_iters=True):
+    """gpu/ora: FusedResult of one pose_prior callback."""
+    assert gpu.c.n_tracks == ora.c.n_tracks, (gpu.c.n_tracks, ora.c.n_tracks)
+    assert gpu.n_persons == ora.n_persons, (gpu.n_persons, ora.n_persons)
+    assert abs(gpu.c.pred_delta_t - ora.c.pred_delta_t) < 1e-7
+    n = gpu.n_persons
+    stats = {"pos_max_mm": 0.0, "pred_max_mm": 0.0, "cov_rel_max": 0.0}
+    if n == 0:
+        return stats
+    assert np.array_equal(gpu.fused["id"][:n], ora.fused["id"][:n])
+    assert np.array_equal(gpu.fused_pred["id"][:n], ora.fused_pred["id"][:n])
+    for name, tolkey in (("fused", "pos_max_mm"), ("fused_pred", "pred_max_mm")):
+        g, o = getattr(gpu, name)[:n]["keypoints"], getattr(ora, name)[:n]["keypoints"]
+        vg, vo = g["score"] > 0, o["score"] > 0
+        assert np.array_equal(vg, vo)
+        assert np.array_equal(g["score"], o["score"])  # max(0.10, measured score): exact
+        d = np.linalg.norm(g["joint"] - o["joint"], axis=-1)[vo]
+        stats[tolkey] = float(d.max() * 1e3)
+        assert d.max() < REFINE_TOL_M, "%s max joint error %.5f mm" % (name, d.max() * 1e3)
+        cg, co = g["cov"][vo], o["cov"][vo]
+        rel = np.abs(cg - co).max(-1) / np.abs(co).max(-1)
+        stats["cov_rel_max"] = max(stats["cov_rel_max"], float(rel.max()))
+        assert rel.max() < MARG_COV_RTOL, "%s covariance rel error %.2e" % (name, rel.max())
+    if check_iters:
+        assert np.array_equal(gpu.lm_iterations[:n], ora.lm_iterations[:n]), (gpu.lm_iterations[:n], ora.lm_iterations[:n])
+    return stats

@@ -1,0 +1,108 @@
+"""GPU parity tests for stage 2 (pose_prior): HIP track association + LM (fp64 MFMA J^T J) + marginals + prediction +
+track lifecycle vs the CPU oracle on identical measurements.  Refined joints < 1 mm, ids/track counts exact."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from smartedgesensor3dhumanpose_amd import person_msgs as pm
+from smartedgesensor3dhumanpose_amd import rig as R
+from smartedgesensor3dhumanpose_amd import scene as S
+
+sys.path.insert(0, os.path.dirname(__file__))
+from parity import compare_stage2  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _node(rig, **kw):
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
+    kw.setdefault("max_epi_dist", 0.045)
+    return Skeleton3D(rig, **kw)
+
+
+def _sequence_parity(node, rig, oracle, params, cfg, seq=0, drop_frames=()):
+    from smartedgesensor3dhumanpose_amd.pose_prior import PosePrior
+    frames, _ = S.generate_sequence(rig, cfg)
+    res1 = node.triangulate_persons(frames[: node.limits.max_frames]) if len(frames) <= node.limits.max_frames else None
+    node.refine_reset()
+    pp = PosePrior(node, seq)
+    ora = oracle.PosePrior(params)
+    worst = {"pos_max_mm": 0.0, "pred_max_mm": 0.0, "cov_rel_max": 0.0}
+    published = 0
+    for k, fr in enumerate(frames):
+        r1 = res1[k] if res1 is not None else node.triangulate_persons([fr])[0]
+        dets = r1.published() if k not in drop_frames else np.zeros(0, pm.person3d_dt)
+        g = pp.skeleton_callback(dets, fr.stamp, fr.fb_delay)
+        o = ora.step(dets, rig.n_cam, fr.stamp, fr.fb_delay, capacity=node.limits.max_hyp)
+        st = compare_stage2(g, o)
+        published += g.n_persons
+        for key in worst:
+            worst[key] = max(worst[key], st[key])
+    return worst, published
+
+
+def test_stage2_parity_16cam_6p_sequence(extr_rig, oracle, demo_params):
+    node = _node(extr_rig, max_frames=16, max_det_per_cam=8, max_hyp=32)
+    worst, published = _sequence_parity(node, extr_rig, oracle, demo_params, S.SceneConfig(n_persons=6, n_frames=16, seed=0))
+    assert published == 6 * 6  # frames 11..16 publish (num_obs > 10)
+    print("stage-2 worst:", worst)
+    node.close()
+
+
+def test_stage2_ragged_tracks_appear_vanish_timeout(extr_rig, oracle, demo_params):
+    node = _node(extr_rig, max_frames=1, max_det_per_cam=8, max_hyp=32)
+    cfg = S.SceneConfig(n_persons=5, n_frames=24, seed=3, p_miss=0.35, low_score_frac=0.15, dt=0.1)
+    worst, published = _sequence_parity(node, extr_rig, oracle, demo_params, cfg, drop_frames=(5, 6, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23))
+    node.close()
+
+
+def test_stage2_norm_height_and_h36m(extr_rig, oracle):
+    for pose, nh in (("simple", True), ("h36m", False), ("h36m", True)):
+        params = pm.Params(pm.POSE_H36M if pose == "h36m" else pm.POSE_SIMPLE, int(nh), 0.045)
+        node = _node(extr_rig, pose_method=pose, norm_height=nh, max_frames=12, max_det_per_cam=8, max_hyp=32)
+        _sequence_parity(node, extr_rig, oracle, params, S.SceneConfig(n_persons=3, n_frames=12, seed=6))
+        node.close()
+
+
+def test_stage2_resident_pipeline_many_sequences(extr_rig, oracle, demo_params):
+    """Resident path: S independent sequences advance one frame per call; stage 2 consumes stage-1 output in HBM."""
+    S_ = 5
+    T_ = 13
+    node = _node(extr_rig, max_frames=S_, max_det_per_cam=8, max_hyp=32)
+    seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=3 + (s % 3), n_frames=T_, seed=40 + s))[0] for s in range(S_)]
+    oras = [oracle.PosePrior(demo_params) for _ in range(S_)]
+    node.refine_reset()
+    total = 0
+    for k in range(T_):
+        frames = [seqs[s][k] for s in range(S_)]
+        node.stage(frames)
+        node.run_stage1()
+        node.run_stage2([f.stamp for f in frames])
+        r1 = node.fetch_stage1(S_)
+        r2 = node.fetch_stage2(S_)
+        for s in range(S_):
+            o = oras[s].step(r1[s].published(), 16, frames[s].stamp, frames[s].fb_delay, capacity=32)
+            compare_stage2(r2[s], o)
+            total += r2[s].n_persons
+    assert total == sum(3 + (s % 3) for s in range(S_)) * (T_ - 10)
+    node.close()
+
+
+def test_stage2_feedback_delay_moving_average(extr_rig, oracle, demo_params):
+    node = _node(extr_rig, max_frames=1, max_det_per_cam=8, max_hyp=32)
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=2, n_frames=5, seed=2))
+    rng = np.random.default_rng(0)
+    for fr in frames:
+        fr.fb_delay[:] = np.where(rng.random(16) < 0.5, rng.uniform(0.05, 0.2, 16), -1.0).astype(np.float32)
+    from smartedgesensor3dhumanpose_amd.pose_prior import PosePrior
+    node.refine_reset()
+    pp, ora = PosePrior(node, 0), oracle.PosePrior(demo_params)
+    for fr in frames:
+        r1 = node.triangulate_persons([fr])[0]
+        g = pp.skeleton_callback(r1.published(), fr.stamp, fr.fb_delay)
+        o = ora.step(r1.published(), 16, fr.stamp, fr.fb_delay, capacity=32)
+        compare_stage2(g, o)
+        assert abs(g.c.pred_delta_t - o.c.pred_delta_t) < 1e-7
+    node.close()
