@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""bench.py — 3D skeletons/sec of the MI355X-native skeleton_3d (+ pose_prior) hot path on synthetic scenes.
+"""bench.py — 3D skeletons/sec of the MI355X-native skeleton_3d + pose_prior hot path on synthetic scenes.
 
-One "step" = one pass of the hot path over one batch of B synthetic frames that are already resident in HBM.
-`value` = published 3D skeletons (person-frames) per second over all ranks.  See DESIGN.md §measurement.
+One "step" = one pass of the hot path over one batch of synthetic frames that are already resident in HBM:
+  stage 1 (association + DLT triangulation + UT covariance + merge) over all B = S x T frames, then
+  stage 2 (track association + LM refinement + marginals + prediction) walking the T time steps of the S independent
+  sequences.  Time steps are walked forward on even steps and backward on odd steps so that person motion stays
+  continuous, tracks persist and (after warm-up) every person-frame is published (num_obs > 10, PP:845).
+`value` = published refined 3D skeletons (person-frames) per second over all ranks.  See DESIGN.md §measurement.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 16cam6p|64cam32p|256cam128p] [--frames B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 16cam6p|64cam32p|256cam128p] [--seqs S] [--stage 1|12]
 """
 import argparse
 import json
@@ -17,11 +21,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+T_STEPS = 16  # frames per synthetic sequence (>= 16 frames per sequence)
 WORKLOADS = {
-    # name: (n_cam, n_persons, default frames/batch, max_det_per_cam, max_hyp, bytes/skeleton stage 1)
-    "16cam6p": dict(n_cam=16, n_persons=6, frames=2048, max_det=8, max_hyp=16, bytes_per_skel=8972),
-    "64cam32p": dict(n_cam=64, n_persons=32, frames=64, max_det=40, max_hyp=96, bytes_per_skel=30072),
-    "256cam128p": dict(n_cam=256, n_persons=128, frames=4, max_det=160, max_hyp=256, bytes_per_skel=115320),
+    # bytes/skeleton: SURVEY §8d algorithmic bytes (stage 1) ; stage 2 adds 8.9 KB per skeleton
+    "16cam6p": dict(n_cam=16, n_persons=6, seqs=128, max_det=8, max_hyp=16, bytes_s1=8972, bytes_s2=8900),
+    "64cam32p": dict(n_cam=64, n_persons=32, seqs=4, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900),
+    "256cam128p": dict(n_cam=256, n_persons=128, seqs=1, max_det=160, max_hyp=256, bytes_s1=115320, bytes_s2=8900),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -34,39 +39,39 @@ def make_rig(w):
     return rig
 
 
-def make_frames(rig, w, n_frames, seed0):
-    """n_frames synthetic frames: distinct seeded 16-frame sequences, repeated to fill the batch."""
+def make_sequences(rig, w, n_seq, seed0, t_steps):
+    """n_seq synthetic sequences of t_steps frames (up to 8 distinct seeded sequences, repeated)."""
     from smartedgesensor3dhumanpose_amd import scene as S
-    n_unique = min(n_frames, 64)
-    seqs = []
-    f = 0
-    while f < n_unique:
-        cfg = S.SceneConfig(n_persons=w["n_persons"], n_frames=min(16, n_unique - f), seed=seed0 + len(seqs),
-                            min_coverage=4 if w["n_cam"] == 16 else 6)
-        fr, _ = S.generate_sequence(rig, cfg)
-        seqs += fr
-        f += len(fr)
-    return [seqs[i % len(seqs)] for i in range(n_frames)]
+    uniq = []
+    for i in range(min(n_seq, 8)):
+        cfg = S.SceneConfig(n_persons=w["n_persons"], n_frames=t_steps, seed=seed0 + i, min_coverage=4 if w["n_cam"] == 16 else 6)
+        uniq.append(S.generate_sequence(rig, cfg)[0])
+    return [uniq[s % len(uniq)] for s in range(n_seq)]
 
 
-def cpu_baseline(rig, frames, params, budget_s=12.0):
-    """Oracle (CPU restatement of the reference, 'port') timed on this box's host cores on a bounded sample."""
+def cpu_baseline(rig, seq, params, with_stage2, budget_s=12.0):
+    """Oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores on a bounded sample."""
     from oracle import oracle_py as O
     ncores = os.cpu_count() or 1
     out = {}
     for label, thr in (("1t", 1), ("omp", ncores)):
+        pp = O.PosePrior(params) if with_stage2 else None
         t0 = time.perf_counter()
         n_sk, n_fr = 0, 0
-        while time.perf_counter() - t0 < budget_s / 2 and n_fr < len(frames):
-            r = O.triangulate(rig, params, frames[n_fr], capacity=512, hyp_capacity=512, omp_threads=thr)
+        while time.perf_counter() - t0 < budget_s / 2:
+            fr = seq[n_fr % len(seq)]
+            r = O.triangulate(rig, params, fr, capacity=512, hyp_capacity=512, omp_threads=thr)
+            if pp is not None:
+                pp.step(r.published(), rig.n_cam, 100.0 + n_fr / 30.0, fr.fb_delay, capacity=512, omp_threads=thr)
             n_sk += r.n_persons
             n_fr += 1
         dt = time.perf_counter() - t0
         out[label] = (n_sk / dt, n_fr, dt)
-    best = max(out.values(), key=lambda v: v[0])
-    return {"value": round(best[0], 2), "unit": "skeletons/s", "cores": ncores if best is out["omp"] else 1, "kind": "port",
-            "sample": "%d frames of the same workload, stage 1 (single-thread %.1f skel/s over %d frames; OpenMP x%d over hypotheses like S3D:676: %.1f skel/s over %d frames)"
-                      % (best[1], out["1t"][0], out["1t"][1], ncores, out["omp"][0], out["omp"][1])}
+    best = "omp" if out["omp"][0] > out["1t"][0] else "1t"
+    return {"value": round(out[best][0], 2), "unit": "skeletons/s", "cores": ncores if best == "omp" else 1, "kind": "port",
+            "sample": "%d frames of one sequence of the same workload, stage %s; single thread %.1f skel/s (%d frames), OpenMP x%d over "
+                      "hypotheses/persons as in S3D:676 / PP:582: %.1f skel/s (%d frames)"
+                      % (out[best][1], "1+2" if with_stage2 else "1", out["1t"][0], out["1t"][1], ncores, out["omp"][0], out["omp"][1])}
 
 
 def main():
@@ -75,7 +80,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="16cam6p", choices=sorted(WORKLOADS))
-    ap.add_argument("--frames", type=int, default=0, help="frames per batch per GPU (default: workload preset)")
+    ap.add_argument("--seqs", type=int, default=0, help="independent sequences per GPU (default: workload preset)")
+    ap.add_argument("--tsteps", type=int, default=T_STEPS)
+    ap.add_argument("--stage", default="12", choices=["1", "12"], help="1: stage 1 only; 12: stage 1 + stage 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -83,41 +90,58 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    dist = None
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
 
     from smartedgesensor3dhumanpose_amd import person_msgs as pm
     from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
     w = WORKLOADS[args.workload]
-    B = args.frames or w["frames"]
+    S_, T_ = args.seqs or w["seqs"], args.tsteps
+    B = S_ * T_
+    stage2 = args.stage == "12"
     rig = make_rig(w)
-    frames = make_frames(rig, w, B, seed0=1000 * rank)  # every rank works on its own frames (weak scaling)
+    seqs = make_sequences(rig, w, S_, seed0=1000 * rank, t_steps=T_)  # every rank owns its sequences (weak scaling)
+    frames = [seqs[s][k] for k in range(T_) for s in range(S_)]       # frame slot = k * S + s
     node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank)
     node.stage(frames)  # inputs resident in HBM before the timed region
+    dt_frame = 1.0 / 30.0
+    clock = {"t": 100.0, "step": 0}
 
-    # exchange buffers for the all-gather of final skeletons (every rank ends up with all skeletons)
     H = node.limits.max_hyp
-    pack = torch.empty(B * H * pm.person3d_dt.itemsize, dtype=torch.uint8, device="cuda")
-    counts = torch.empty(B, dtype=torch.int32, device="cuda")
-    if dist is not None:
+    if dist is not None:  # exchange buffers: every rank ends up with the final skeletons of all ranks
+        n_slots = S_ if stage2 else B
+        pack = torch.empty(B * H * pm.person3d_dt.itemsize, dtype=torch.uint8, device="cuda")
+        counts = torch.empty(B, dtype=torch.int32, device="cuda")
         gather_p = torch.empty(world * pack.numel(), dtype=torch.uint8, device="cuda")
         gather_c = torch.empty(world * B, dtype=torch.int32, device="cuda")
 
-    def step():
+    def step(collect=None):
         node.run_stage1()
-        if dist is not None:
-            node.pack_stage1_device(pack.data_ptr(), counts.data_ptr())  # syncs the context stream
+        if stage2:
+            order = range(T_) if clock["step"] % 2 == 0 else range(T_ - 1, -1, -1)
+            for k in order:
+                clock["t"] += dt_frame
+                node.run_stage2(np.full(S_, clock["t"]), frame_slot0=k * S_)
+                if collect is not None:
+                    collect.append(sum(r.n_persons for r in node.fetch_stage2(S_)))
+                if dist is not None:
+                    node.pack_stage2_device(pack.data_ptr(), counts.data_ptr())  # syncs the context stream
+                    dist.all_gather_into_tensor(gather_p, pack)
+                    dist.all_gather_into_tensor(gather_c, counts)
+        elif dist is not None:
+            node.pack_stage1_device(pack.data_ptr(), counts.data_ptr())
             dist.all_gather_into_tensor(gather_p, pack)
             dist.all_gather_into_tensor(gather_c, counts)
+        clock["step"] += 1
 
-    for _ in range(args.warmup):
+    node.refine_reset()
+    for _ in range(max(args.warmup, 1 if stage2 else 0)):
         step()
     node.sync()
     node.profile(True)
@@ -133,12 +157,19 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    node.profile(False)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    res = node.fetch_stage1(B)
-    n_skel_local = sum(r.n_persons for r in res)
+    # untimed accounting pass: published skeletons of one (steady-state) step
+    n_s1 = sum(r.n_persons for r in node.fetch_stage1(B))
+    if stage2:
+        per_call = []
+        step(collect=per_call)
+        n_skel_local = sum(per_call)
+    else:
+        n_skel_local = n_s1
     n_skel = n_skel_local
     if dist is not None:
         tot = torch.tensor([n_skel_local], dtype=torch.int64, device="cuda")
@@ -146,27 +177,33 @@ def main():
         n_skel = int(tot.item())
 
     if rank == 0:
-        prof = {k: node.profile_get(k) for k in ("normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess")}
-        dom = max(prof, key=lambda k: prof[k][0])
-        ms_dom = prof[dom][0] / max(prof[dom][1], 1)
-        alg_bytes = w["bytes_per_skel"] * n_skel_local  # algorithmic bytes one launch (= one batch) processes
-        achieved = alg_bytes / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+        names = ["normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess"] + (["track_assoc", "lm_refine", "track_update"] if stage2 else [])
+        prof = {k: node.profile_get(k) for k in names}
+        per_step_ms = {k: v[0] / args.steps for k, v in prof.items()}
+        dom = max(per_step_ms, key=lambda k: per_step_ms[k])
+        ms_dom = prof[dom][0] / max(prof[dom][1], 1)              # average duration of one launch (group) of the dominant kernel
+        launches_per_step = prof[dom][1] / args.steps
+        bytes_per_skel = w["bytes_s1"] if dom in names[:5] else w["bytes_s2"]
+        units_per_launch = n_skel_local / launches_per_step        # skeletons one launch of that kernel processes
+        achieved = bytes_per_skel * units_per_launch / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
         line = {
-            "metric": "3D skeletons/sec (triangulated, with UT covariance) on synthetic multi-view scenes",
+            "metric": "3D skeletons/sec (triangulated + refined, per-joint error < 1 mm vs CPU reference path)",
             "value": round(n_skel * args.steps / dt, 2), "unit": "skeletons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 geometry / f64 accumulation+eigen", "data": "synthetic",
-            "config": {"workload": "%s stage1 (association + DLT triangulation + UT covariance + merge), %d frames/batch/GPU, %d skeletons/batch/GPU"
-                                   % (args.workload, B, n_skel_local), "n_cam": w["n_cam"], "n_persons": w["n_persons"], "n_joints": 17,
-                       "frames_per_batch": B, "sharding": "frames (independent sequences per rank) + all-gather of final skeletons" if world > 1 else "single GPU"},
+            "dtype": "f32 geometry, f64 accumulation/eigen/LM", "data": "synthetic",
+            "config": {"workload": "%s, stage %s, %d sequences x %d frames resident per GPU (%d frames, %d published skeletons per step per GPU; stage-1 persons %d)"
+                                   % (args.workload, "1+2 (association+triangulation+UT covariance, then tracking+LM refinement+marginals)" if stage2 else "1",
+                                      S_, T_, B, n_skel_local, n_s1),
+                       "n_cam": w["n_cam"], "n_persons": w["n_persons"], "n_joints": 17, "frames_per_step": B,
+                       "sharding": ("independent sequences per rank + RCCL all-gather of final skeletons" if world > 1 else "single GPU")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "avg_launch_ms": round(ms_dom, 5),
-                         "note": "path is VALU/latency-bound, not HBM-bound (SURVEY 8d): algorithmic bytes = %d B/skeleton" % w["bytes_per_skel"],
-                         "kernel_ms_per_step": {k: round(v[0] / max(v[1], 1), 5) for k, v in prof.items()}},
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(ms_dom, 5),
+                         "algorithmic_bytes_per_skeleton": bytes_per_skel, "skeletons_per_launch": round(units_per_launch, 1),
+                         "note": "SURVEY 8d: the path is VALU/latency-bound, not HBM-bound; the HBM fraction is reported as north_star asks",
+                         "kernel_ms_per_step": {k: round(v, 5) for k, v in per_step_ms.items()}},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(rig, frames, node.params)
+            line["cpu_baseline"] = cpu_baseline(rig, seqs[0], node.params, stage2)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

@@ -156,8 +156,9 @@ int se3d_refine_reset(se3d_ctx *ctx);
 /* one PersonCovList in, fused lists out; seq selects the pose_prior instance */
 int se3d_refine(se3d_ctx *ctx, int32_t seq, int32_t n_det, const se3d_person3d *dets, int32_t n_cam,
                 const float *fb_delay_per_cam, double t, se3d_fused_out *out);
-/* resident: refine frame slot s of the last se3d_run_stage1 for every sequence s < n_seq, stamps t[s] */
-int se3d_run_stage2(se3d_ctx *ctx, int32_t n_seq, const double *t);
+/* resident: sequence s < n_seq consumes frame slot frame_slot0 + s of the last se3d_run_stage1, stamp t[s]
+ * (a batch staged as [time step k][sequence s] is walked with frame_slot0 = k * n_seq, one call per time step) */
+int se3d_run_stage2(se3d_ctx *ctx, int32_t n_seq, int32_t frame_slot0, const double *t);
 int se3d_fetch_stage2(se3d_ctx *ctx, int32_t n_seq, se3d_fused_out *outs);
 
 /* --- row M as a stand-alone entry: drop-in for HungarianAlgorithm::assignmentoptimal (Hungarian.cpp:60) on the GPU.

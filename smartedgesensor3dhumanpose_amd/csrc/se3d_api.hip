@@ -43,10 +43,11 @@ struct se3d_ctx {
   bool tiled = false;
   // profiling
   bool prof = false;
-  hipEvent_t ev[8]{};
+  static constexpr int kRing = 96;       // event sets in flight before the oldest are harvested
+  hipEvent_t ev[kRing][6]{};             // stage-1 sets
+  int ev_head = 0, ev_pending = 0;
   double prof_ms[PS_COUNT]{};
   int64_t prof_n[PS_COUNT]{};
-  bool prof_pending = false;
   // stage 2
   Se3dStage2 Q{};
   se3d_person3d *d_in2 = nullptr;  // [S][H] host-provided measurements (se3d_refine)
@@ -54,12 +55,14 @@ struct se3d_ctx {
   float *d_fb = nullptr;           // [S][N] fb_delay of the staged frames / of se3d_refine
   double *d_t = nullptr;           // [S]
   float *h_fb = nullptr;
-  double *h_t = nullptr;
+  double *h_t = nullptr;                 // [kRing][S] ring: a slot is reused only after its H2D copy has completed
+  hipEvent_t t_done[kRing]{};
+  int t_head = 0;
   se3d_person3d *h_fused = nullptr, *h_pred = nullptr;
   int32_t *h_iters = nullptr, *h_nout = nullptr, *h_ntracks = nullptr;
   double *h_preddt = nullptr;
-  hipEvent_t ev2[4]{};
-  bool prof2_pending = false;
+  hipEvent_t ev2[kRing][4]{};            // stage-2 sets
+  int ev2_head = 0, ev2_pending = 0;
   bool ran2 = false;
 };
 
@@ -84,29 +87,42 @@ bool dev_alloc(se3d_ctx *c, T **p, size_t n) {
   return true;
 }
 
-void collect_profile(se3d_ctx *c) {
-  if (c->prof_pending) {
-    (void)hipEventSynchronize(c->ev[5]);
+// harvest completed event sets (all of them if `all`, else only enough to free one slot of the ring)
+void collect_profile(se3d_ctx *c, bool all = true) {
+  while (c->ev_pending > 0 && (all || c->ev_pending >= se3d_ctx::kRing)) {
+    const int idx = (c->ev_head - c->ev_pending + 2 * se3d_ctx::kRing) % se3d_ctx::kRing;
+    (void)hipEventSynchronize(c->ev[idx][5]);
     for (int i = 0; i < kStage1Slots; ++i) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) {
-        c->prof_ms[i] += ms;
-        c->prof_n[i] += 1;
-      }
+      if (hipEventElapsedTime(&ms, c->ev[idx][i], c->ev[idx][i + 1]) == hipSuccess) { c->prof_ms[i] += ms; c->prof_n[i] += 1; }
     }
-    c->prof_pending = false;
+    --c->ev_pending;
   }
-  if (c->prof2_pending) {
-    (void)hipEventSynchronize(c->ev2[3]);
+  while (c->ev2_pending > 0 && (all || c->ev2_pending >= se3d_ctx::kRing)) {
+    const int idx = (c->ev2_head - c->ev2_pending + 2 * se3d_ctx::kRing) % se3d_ctx::kRing;
+    (void)hipEventSynchronize(c->ev2[idx][3]);
     for (int i = 0; i < kStage2Slots; ++i) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, c->ev2[i], c->ev2[i + 1]) == hipSuccess) {
-        c->prof_ms[kStage1Slots + i] += ms;
-        c->prof_n[kStage1Slots + i] += 1;
-      }
+      if (hipEventElapsedTime(&ms, c->ev2[idx][i], c->ev2[idx][i + 1]) == hipSuccess) { c->prof_ms[kStage1Slots + i] += ms; c->prof_n[kStage1Slots + i] += 1; }
     }
-    c->prof2_pending = false;
+    --c->ev2_pending;
   }
+}
+hipEvent_t *next_ev1(se3d_ctx *c) {
+  if (!c->prof) return nullptr;
+  collect_profile(c, false);
+  hipEvent_t *e = c->ev[c->ev_head];
+  c->ev_head = (c->ev_head + 1) % se3d_ctx::kRing;
+  ++c->ev_pending;
+  return e;
+}
+hipEvent_t *next_ev2(se3d_ctx *c) {
+  if (!c->prof) return nullptr;
+  collect_profile(c, false);
+  hipEvent_t *e = c->ev2[c->ev2_head];
+  c->ev2_head = (c->ev2_head + 1) % se3d_ctx::kRing;
+  ++c->ev2_pending;
+  return e;
 }
 
 int stage2_reset(se3d_ctx *c) {
@@ -215,7 +231,8 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
   c->device = device_id;
   if (!hip_ok(c, hipSetDevice(device_id), "hipSetDevice")) { fprintf(stderr, "%s\n", c->err.c_str()); delete c; return nullptr; }
   if (!hip_ok(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return nullptr; }
-  for (auto &e : c->ev) (void)hipEventCreate(&e);
+  for (auto &set : c->ev)
+    for (auto &e : set) (void)hipEventCreate(&e);
   Se3dDev &D = c->D;
   const int np = N * (N - 1) / 2;
   D.d = Se3dDims{B, N, P, H, np, params->pose_method, params->norm_height, params->max_epi_dist};
@@ -251,10 +268,12 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     ok = ok && dev_alloc(c, &Q.fused, S * H) && dev_alloc(c, &Q.pred, S * H) && dev_alloc(c, &Q.iters, S * H) && dev_alloc(c, &Q.n_out, S);
     ok = ok && dev_alloc(c, &Q.flags2, S);
     ok = ok && dev_alloc(c, &c->d_in2, S * H) && dev_alloc(c, &c->d_ndet2, S) && dev_alloc(c, &c->d_fb, S * N) && dev_alloc(c, &c->d_t, S);
-    for (auto &e : c->ev2) (void)hipEventCreate(&e);
+    for (auto &set : c->ev2)
+      for (auto &e : set) (void)hipEventCreate(&e);
     if (ok) {
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_fb, sizeof(float) * S * N, hipHostMallocDefault), "hipHostMalloc");
-      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_t, sizeof(double) * S, hipHostMallocDefault), "hipHostMalloc");
+      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_t, sizeof(double) * S * se3d_ctx::kRing, hipHostMallocDefault), "hipHostMalloc");
+      for (auto &e : c->t_done) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_fused, sizeof(se3d_person3d) * S * H, hipHostMallocDefault), "hipHostMalloc");
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_pred, sizeof(se3d_person3d) * S * H, hipHostMallocDefault), "hipHostMalloc");
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_iters, sizeof(int32_t) * S * H, hipHostMallocDefault), "hipHostMalloc");
@@ -316,10 +335,14 @@ void se3d_destroy(se3d_ctx *c) {
   if (c->h_nout) (void)hipHostFree(c->h_nout);
   if (c->h_ntracks) (void)hipHostFree(c->h_ntracks);
   if (c->h_preddt) (void)hipHostFree(c->h_preddt);
-  for (auto &e : c->ev2)
+  for (auto &set : c->ev2)
+    for (auto &e : set)
+      if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->t_done)
     if (e) (void)hipEventDestroy(e);
-  for (auto &e : c->ev)
-    if (e) (void)hipEventDestroy(e);
+  for (auto &set : c->ev)
+    for (auto &e : set)
+      if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -359,15 +382,13 @@ int se3d_run_stage1(se3d_ctx *c) {
   HIPCHK(c, hipSetDevice(c->device));
   const Se3dDev &D = c->D;
   const int B = D.d.B, N = D.d.N, H = D.d.H;
-  collect_profile(c);
   HIPCHK(c, hipMemsetAsync(D.assoc, 0xFF, sizeof(int32_t) * (size_t)B * H * N, c->stream));
   HIPCHK(c, hipMemsetAsync(D.nviews, 0, sizeof(int32_t) * (size_t)B * H, c->stream));
   HIPCHK(c, hipMemsetAsync(D.nhyp, 0, sizeof(int32_t) * (size_t)B, c->stream));
   HIPCHK(c, hipMemsetAsync(D.flags, 0, sizeof(uint32_t) * (size_t)B, c->stream));
   HIPCHK(c, hipMemsetAsync(D.hypP, 0, sizeof(se3d_person3d) * (size_t)B * H, c->stream));
-  se3d_launch_stage1(D, c->pair_ab, c->stream, c->prof ? c->ev : nullptr, c->tiled);
+  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled);
   HIPCHK(c, hipGetLastError());
-  c->prof_pending = c->prof;
   c->ran = true;
   return SE3D_OK;
 }
@@ -524,33 +545,38 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
   collect_profile(c);
   const size_t H = Q.H, N = Q.N;
   for (size_t i = 0; i < N; ++i) c->h_fb[seq * N + i] = (fb_delay_per_cam && (int)i < n_cam) ? fb_delay_per_cam[i] : -1.0f;
-  c->h_t[seq] = t;
+  double *ht = c->h_t + (size_t)c->t_head * Q.S;
+  (void)hipEventSynchronize(c->t_done[c->t_head]);
+  ht[0] = t;
   int32_t nd = n_det;
   if (n_det) HIPCHK(c, hipMemcpyAsync(c->d_in2 + seq * H, dets, sizeof(se3d_person3d) * (size_t)n_det, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_ndet2 + seq, &nd, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_fb + seq * N, c->h_fb + seq * N, sizeof(float) * N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_t + seq, c->h_t + seq, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_t + seq, ht, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->t_done[c->t_head], c->stream));
+  c->t_head = (c->t_head + 1) % se3d_ctx::kRing;
   HIPCHK(c, hipStreamSynchronize(c->stream));  // nd is a stack variable
   Q.dets = c->d_in2; Q.n_det = c->d_ndet2; Q.fb_delay = c->d_fb; Q.t = c->d_t;
-  se3d_launch_stage2(Q, seq, 1, c->stream, c->prof ? c->ev2 : nullptr);
+  se3d_launch_stage2(Q, seq, 1, c->stream, next_ev2(c));
   HIPCHK(c, hipGetLastError());
-  c->prof2_pending = c->prof;
   c->ran2 = true;
   return fetch_stage2_range(c, seq, 1, out);
 }
 
-int se3d_run_stage2(se3d_ctx *c, int32_t n_seq, const double *t) {
-  if (!c || !t || n_seq < 1) return SE3D_ERR_ARG;
-  if (!c->ran || n_seq > c->staged_frames) { c->err = "se3d_run_stage2 needs a preceding se3d_run_stage1 over >= n_seq frames"; return SE3D_ERR_STATE; }
+int se3d_run_stage2(se3d_ctx *c, int32_t n_seq, int32_t frame_slot0, const double *t) {
+  if (!c || !t || n_seq < 1 || frame_slot0 < 0) return SE3D_ERR_ARG;
+  if (!c->ran || frame_slot0 + n_seq > c->staged_frames) { c->err = "se3d_run_stage2 needs a preceding se3d_run_stage1 over >= n_seq frames"; return SE3D_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
-  collect_profile(c);
   Se3dStage2 Q = c->Q;
-  memcpy(c->h_t, t, sizeof(double) * (size_t)n_seq);
-  HIPCHK(c, hipMemcpyAsync(c->d_t, c->h_t, sizeof(double) * (size_t)n_seq, hipMemcpyHostToDevice, c->stream));
-  Q.dets = c->D.outP; Q.n_det = c->D.out_count; Q.fb_delay = c->d_fb; Q.t = c->d_t;
-  se3d_launch_stage2(Q, 0, n_seq, c->stream, c->prof ? c->ev2 : nullptr);
+  double *ht = c->h_t + (size_t)c->t_head * Q.S;
+  (void)hipEventSynchronize(c->t_done[c->t_head]);
+  memcpy(ht, t, sizeof(double) * (size_t)n_seq);
+  HIPCHK(c, hipMemcpyAsync(c->d_t, ht, sizeof(double) * (size_t)n_seq, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->t_done[c->t_head], c->stream));
+  c->t_head = (c->t_head + 1) % se3d_ctx::kRing;
+  Q.dets = c->D.outP + (size_t)frame_slot0 * Q.H; Q.n_det = c->D.out_count + frame_slot0; Q.fb_delay = c->d_fb + (size_t)frame_slot0 * Q.N; Q.t = c->d_t;
+  se3d_launch_stage2(Q, 0, n_seq, c->stream, next_ev2(c));
   HIPCHK(c, hipGetLastError());
-  c->prof2_pending = c->prof;
   c->ran2 = true;
   return SE3D_OK;
 }

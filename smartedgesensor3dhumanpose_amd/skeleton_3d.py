@@ -94,9 +94,9 @@ class Skeleton3D:
                                       None if fb is None else pm.fptr(fb), C.c_double(t), C.byref(res.c)), "se3d_refine")
         return res
 
-    def run_stage2(self, t):
+    def run_stage2(self, t, frame_slot0=0):
         t = np.ascontiguousarray(t, np.float64)
-        self._chk(self._L.se3d_run_stage2(C.c_void_p(self._h), len(t), t.ctypes.data_as(C.POINTER(C.c_double))), "se3d_run_stage2")
+        self._chk(self._L.se3d_run_stage2(C.c_void_p(self._h), len(t), int(frame_slot0), t.ctypes.data_as(C.POINTER(C.c_double))), "se3d_run_stage2")
 
     def fetch_stage2(self, n_seq, capacity=None):
         res = [pm.FusedResult(capacity or self.limits.max_hyp) for _ in range(n_seq)]
