@@ -1,0 +1,78 @@
+"""N>1 path on CPU (gloo, world_size 2): sequence sharding + all-gather of final skeletons reproduce the single-process
+result.  The per-rank compute is stood in for by the oracle (test infrastructure); the exchange code is the product's
+(smartedgesensor3dhumanpose_amd/shard.py), the same functions bench.py uses over RCCL."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_SEQ, MAX_HYP = 5, 16
+
+
+def _scene(seq):
+    from smartedgesensor3dhumanpose_amd import rig as R, scene as S
+    from oracle import oracle_py as O
+    rig = R.extr_rig_16cam()
+    rig.set_tensors(*O.rig_tensors(rig))
+    frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=2 + seq % 3, n_frames=1, seed=70 + seq))
+    return rig, frames[0]
+
+
+def _compute(seq):
+    from smartedgesensor3dhumanpose_amd import person_msgs as pm
+    from oracle import oracle_py as O
+    rig, fr = _scene(seq)
+    return O.triangulate(rig, pm.Params(pm.POSE_SIMPLE, 0, 0.045), fr, capacity=MAX_HYP, hyp_capacity=MAX_HYP).published().copy()
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from smartedgesensor3dhumanpose_amd import shard
+    mine = shard.rank_sequences(N_SEQ, rank, world)
+    n_slots = (N_SEQ + world - 1) // world
+    results = [_compute(s) for s in mine] + [np.zeros(0, dtype=_compute(0).dtype)] * (n_slots - len(mine))
+    packed, counts = shard.pack_host(results, MAX_HYP)
+    gp, gc = shard.gather_skeletons(dist, packed, counts, MAX_HYP)
+    allp = shard.unpack_skeletons(gp, gc, MAX_HYP)
+    # every rank now holds all skeletons: re-assemble in sequence order
+    out = {}
+    for r in range(world):
+        for slot, s in enumerate(shard.rank_sequences(N_SEQ, r, world)):
+            out[s] = allp[r][slot]
+    q.put((rank, {s: v.tobytes() for s, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sequence_sharding_and_allgather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    ref = {s: _compute(s).tobytes() for s in range(N_SEQ)}
+    for rank, out in got:
+        assert sorted(out) == list(range(N_SEQ))
+        for s in range(N_SEQ):
+            assert out[s] == ref[s], (rank, s)
+
+
+def test_rank_sequences_partition():
+    from smartedgesensor3dhumanpose_amd import shard
+    for world in (1, 2, 4, 8):
+        seen = sorted(sum((shard.rank_sequences(13, r, world) for r in range(world)), []))
+        assert seen == list(range(13))
