@@ -9,7 +9,26 @@
 #include "se3d_device.h"
 #include "se3d_munkres.h"
 
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Diagnostic build only (make diag): per-phase cycle stamps of the LM kernel written to a debug buffer (never in the product .so)
+#ifdef SE3D_LM_STAMPS
+__device__ unsigned long long g_lm_stamps[16];
+#define LM_STAMP(idx)                                                                 \
+  {                                                                                   \
+    const unsigned long long now_ = __builtin_readcyclecounter();                     \
+    if (threadIdx.x == 0) atomicAdd(&g_lm_stamps[idx], now_ - stamp_prev_);           \
+    stamp_prev_ = __builtin_readcyclecounter();                                       \
+  }
+#define LM_STAMP_INIT unsigned long long stamp_prev_ = __builtin_readcyclecounter();
+#else
+#define LM_STAMP(idx)
+#define LM_STAMP_INIT
+#endif
 
 __device__ __constant__ const double c_vel_sigmas[SE3D_NFU] = {2., 1., 1., 2., 3., 1., 2., 3., 1., 1., 2., 3., 1., 2., 3., 2., 2., 2., 2., 2., 1.};  // FBP:33
 struct Se3dBone { int k1, k2; double L, sigma; int not_belly; };
@@ -168,8 +187,7 @@ __global__ __launch_bounds__(256) void se3d_k_track_assoc(Se3dStage2 Q) {
 // =============================================================================================================
 #define HS 65  // LDS row stride of H (doubles): column accesses by 64 lanes stay conflict-free
 
-struct LmLds {
-  double Hm[64 * HS];
+struct LmCommon {
   double Rm[SE3D_NFU][9];   // whitening matrix of each variable's unary factor (R^T R = Sigma^-1)
   double mm[SE3D_NFU][3];   // unary measurement
   double xc[SE3D_NFU][3];   // current values
@@ -180,6 +198,22 @@ struct LmLds {
   double gg[64], dl[64];
   int rv1[21], rv2[21];
   int keyofcol[SE3D_NFU];
+};
+struct LmLds : LmCommon {   // dense variant: H = J^T J + lambda I (64 x 65 doubles)
+  double Hm[64 * HS];
+};
+struct LmSchurLds : LmCommon {  // Schur/Woodbury variant: only the <= 21 x 21 bone-factor system is dense
+  double Dv[SE3D_NFU][6];   // (A_v + lambda I)^-1, symmetric 3x3 (xx,xy,xz,yy,yz,zz)
+  double ua[21][3], ub[21][3];  // D^-1 W columns: -D_{v1}^-1 hs_e and +D_{v2}^-1 hs_e
+  double zz[SE3D_NFU][3];   // D^-1 g
+  double Mm[32][33];        // M = I + W^T D^-1 W, later its Cholesky factor
+  double Mi[21][22];        // M^-1 (marginals)
+  double yy[32];
+  double mcov[SE3D_NFU][6];
+  unsigned incA[SE3D_NFU], incB[SE3D_NFU];  // bit e: variable is the first / second end of bone factor e
+  // forest elimination (tree variant)
+  double al[SE3D_NFU], be[SE3D_NFU];
+  int par[SE3D_NFU], lev[SE3D_NFU], pe[SE3D_NFU];
 };
 
 __device__ __forceinline__ double s2_wave_sum(double v) {
@@ -219,7 +253,7 @@ __device__ bool s2_make_whitener(const double cov[9], double R[9]) {
 }
 
 // 0.5 * sum ||whitened error||^2 at values x (NonlinearFactorGraph::error)
-__device__ __forceinline__ double s2_graph_error(const LmLds &L, const double (*x)[3], int K, int nr, int lane) {
+__device__ __forceinline__ double s2_graph_error(const LmCommon &L, const double (*x)[3], int K, int nr, int lane) {
   double e = 0.0;
   if (lane < K) {
     const double r0 = x[lane][0] - L.mm[lane][0], r1 = x[lane][1] - L.mm[lane][1], r2 = x[lane][2] - L.mm[lane][2];
@@ -239,7 +273,7 @@ __device__ __forceinline__ double s2_graph_error(const LmLds &L, const double (*
 }
 
 // linearise at L.xc: b = -whitened error; range rows keep H/sigma (RangeFactor<Point3>: d/r, or (1,1,1) if r <= 1e-10)
-__device__ __forceinline__ void s2_linearize(LmLds &L, int K, int nr, int lane) {
+__device__ __forceinline__ void s2_linearize(LmCommon &L, int K, int nr, int lane) {
   if (lane < K) {
     const double r0 = L.xc[lane][0] - L.mm[lane][0], r1 = L.xc[lane][1] - L.mm[lane][1], r2 = L.xc[lane][2] - L.mm[lane][2];
     for (int i = 0; i < 3; ++i)
@@ -370,13 +404,307 @@ __device__ void s2_tri_inverse(double *Hm, int n, int lane) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Schur / Woodbury form of the damped normal equations.  H = D + W W^T with D = blockdiag(A_v + lambda I) (A_v = R_v^T R_v,
+// the unary information of joint v) and W the whitened bone-length Jacobian (one column per bone factor, 6 non-zeros):
+//   (D + W W^T)^-1 g = z - D^-1 W M^-1 W^T z,   z = D^-1 g,   M = I + W^T (D^-1 W)   (<= 21 x 21, SPD, well conditioned)
+// M - I = W^T U (U = D^-1 W) is the J^T J of the bone factors in the unary metric and is built on the matrix cores
+// (v_mfma_f64_16x16x4_f64, operands generated on the fly); its Cholesky factor, the triangular solves and the inverse
+// live entirely in registers (lane i owns row i, L[i][k] broadcast with v_readlane).  Exact algebra: same solution as the
+// dense 63 x 63 system up to rounding.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double s2_rl(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, src);
+  hi = __builtin_amdgcn_readlane(hi, src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double s2_sel3(const double a[3], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : a[2]); }
+__device__ __forceinline__ void s2_sym3_inv(const double a[6], double o[6]) {
+  const double c00 = a[3] * a[5] - a[4] * a[4], c01 = -(a[1] * a[5] - a[4] * a[2]), c02 = a[1] * a[4] - a[3] * a[2];
+  const double det = a[0] * c00 + a[1] * c01 + a[2] * c02, id = 1.0 / det;
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+  o[3] = (a[0] * a[5] - a[2] * a[2]) * id; o[4] = -(a[0] * a[4] - a[1] * a[2]) * id; o[5] = (a[0] * a[3] - a[1] * a[1]) * id;
+}
+__device__ __forceinline__ void s2_sym3_mul(const double m[6], const double v[3], double o[3]) {
+  o[0] = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  o[1] = m[1] * v[0] + m[3] * v[1] + m[4] * v[2];
+  o[2] = m[2] * v[0] + m[4] * v[1] + m[5] * v[2];
+}
+
+// D^-1, z = D^-1 g, U = D^-1 W, M = I + W^T U (MFMA) -> row[] = row `lane` of M (identity rows beyond nr)
+__device__ void s2_schur_build(LmSchurLds &L, int K, int nr, double lambda, int lane, const double Av[6], const double gv[3], double Di[6],
+                               double zv[3], double row[21]) {
+  if (lane < K) {
+    const double D[6] = {Av[0] + lambda, Av[1], Av[2], Av[3] + lambda, Av[4], Av[5] + lambda};
+    s2_sym3_inv(D, Di);
+    s2_sym3_mul(Di, gv, zv);
+    for (int q = 0; q < 6; ++q) L.Dv[lane][q] = Di[q];
+    for (int a = 0; a < 3; ++a) L.zz[lane][a] = zv[a];
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < nr) {
+    const int v1 = L.rv1[lane], v2 = L.rv2[lane];
+    const double hs[3] = {L.Hs[lane][0], L.Hs[lane][1], L.Hs[lane][2]};
+    double d1[6], d2[6], o1[3], o2[3];
+    for (int q = 0; q < 6; ++q) { d1[q] = L.Dv[v1][q]; d2[q] = L.Dv[v2][q]; }
+    s2_sym3_mul(d1, hs, o1);
+    s2_sym3_mul(d2, hs, o2);
+    for (int a = 0; a < 3; ++a) { L.ua[lane][a] = -o1[a]; L.ub[lane][a] = o2[a]; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int nt = (nr + 15) >> 4, ksteps = (3 * K + 3) >> 2;
+  int ev1[2], ev2[2];
+  double hs_[2][3], ua_[2][3], ub_[2][3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int e = 16 * t + (lane & 15);
+    const bool ok = e < nr;
+    ev1[t] = ok ? L.rv1[e] : -1;
+    ev2[t] = ok ? L.rv2[e] : -1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      hs_[t][a] = ok ? L.Hs[e][a] : 0.0;
+      ua_[t][a] = ok ? L.ua[e][a] : 0.0;
+      ub_[t][a] = ok ? L.ub[e][a] : 0.0;
+    }
+  }
+  d4 a00 = {0, 0, 0, 0}, a01 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int r = 4 * ks + (lane >> 4);
+    const int v = (r < 3 * K) ? r / 3 : -2;
+    const int ii = r - 3 * (r / 3);
+    double w[2], u[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const double h = s2_sel3(hs_[t], ii);
+      w[t] = (v == ev1[t]) ? -h : (v == ev2[t]) ? h : 0.0;
+      u[t] = (v == ev1[t]) ? s2_sel3(ua_[t], ii) : (v == ev2[t]) ? s2_sel3(ub_[t], ii) : 0.0;
+    }
+    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[0], u[0], a00, 0, 0, 0);
+    if (nt > 1) {
+      a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[0], u[1], a01, 0, 0, 0);
+      a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[1], u[0], a10, 0, 0, 0);
+      a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[1], u[1], a11, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {  // C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+    const int rr = (lane >> 4) + 4 * reg, cc = lane & 15;
+    L.Mm[rr][cc] = a00[reg] + (rr == cc ? 1.0 : 0.0);
+    L.Mm[rr][cc + 16] = a01[reg];
+    L.Mm[rr + 16][cc] = a10[reg];
+    L.Mm[rr + 16][cc + 16] = a11[reg] + (rr == cc ? 1.0 : 0.0);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int li = lane < 32 ? lane : 31;
+#pragma unroll
+  for (int k = 0; k < 21; ++k) row[k] = (lane < nr) ? L.Mm[li][k] : (k == lane ? 1.0 : 0.0);
+}
+
+// in-register Cholesky of the (<= 21 x 21) matrix whose row `lane` is row[]; on return row[k] = L[lane][k] for k <= lane
+__device__ __forceinline__ void s2_chol21(double row[21], int lane) {
+#pragma unroll
+  for (int j = 0; j < 21; ++j) {
+    double sreg = row[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) sreg -= row[k] * s2_rl(row[k], j);
+    const double sd = sqrt(s2_rl(sreg, j));
+    row[j] = (lane == j) ? sd : ((lane > j) ? sreg / sd : row[j]);
+  }
+}
+
+// tryLambda solve: delta = (D + W W^T)^-1 g  -> L.dl
+__device__ void s2_schur_solve(LmSchurLds &L, int K, int nr, double lambda, int lane, const double Av[6], const double gv[3]) {
+  double Di[6], zv[3] = {0, 0, 0}, row[21];
+  s2_schur_build(L, K, nr, lambda, lane, Av, gv, Di, zv, row);
+  double b = 0.0;
+  if (lane < nr) {
+    const int v1 = L.rv1[lane], v2 = L.rv2[lane];
+    b = L.Hs[lane][0] * (L.zz[v2][0] - L.zz[v1][0]) + L.Hs[lane][1] * (L.zz[v2][1] - L.zz[v1][1]) + L.Hs[lane][2] * (L.zz[v2][2] - L.zz[v1][2]);
+  }
+  s2_chol21(row, lane);
+#pragma unroll
+  for (int k = 0; k < 21; ++k) {  // forward substitution, column oriented
+    const double yk = s2_rl(b, k) / s2_rl(row[k], k);
+    b = (lane == k) ? yk : ((lane > k) ? b - row[k] * yk : b);
+  }
+  if (lane < 21) {
+#pragma unroll
+    for (int k = 0; k < 21; ++k) L.Mm[lane][k] = row[k];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 20; k >= 0; --k) {  // backward substitution with L^T (factor staged in LDS)
+    const double xk = s2_rl(b, k) / s2_rl(row[k], k);
+    const double lkl = (lane < k) ? L.Mm[k][lane] : 0.0;
+    b = (lane == k) ? xk : ((lane < k) ? b - lkl * xk : b);
+  }
+  if (lane < 32) L.yy[lane] = b;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < K) {
+    double d[3] = {zv[0], zv[1], zv[2]};
+    for (unsigned m = L.incA[lane]; m; m &= m - 1) {
+      const int e = __ffs(m) - 1;
+      const double y = L.yy[e];
+      for (int a = 0; a < 3; ++a) d[a] -= L.ua[e][a] * y;
+    }
+    for (unsigned m = L.incB[lane]; m; m &= m - 1) {
+      const int e = __ffs(m) - 1;
+      const double y = L.yy[e];
+      for (int a = 0; a < 3; ++a) d[a] -= L.ub[e][a] * y;
+    }
+    for (int a = 0; a < 3; ++a) L.dl[3 * lane + a] = d[a];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forest elimination.  The active bone factors always form a forest (the skeleton tree of addBinaryFactors, PP:384-481:
+// MidHip-Neck is only active when Belly is absent, so no cycle can appear), hence the damped normal equations
+//   H: diagonal blocks A_v + lambda I + sum_{e at v} hs_e hs_e^T, off-diagonal blocks -hs_e hs_e^T on the edges
+// have a perfect (fill-free) elimination order: leaves first.  Eliminating child c into parent p over edge h = hs_e:
+//   D_p -= (h^T D_c^-1 h) h h^T,   g_p += (h^T D_c^-1 g_c) h;   back-substitution  d_c = D_c^-1 g_c + D_c^-1 h (h^T d_p).
+// This is the exact block Cholesky solve a multifrontal solver performs with a perfect ordering; lane v owns joint v, all
+// joints of one depth are processed together (<= 6 levels) and only 3x3 symmetric inverses are needed.
+// c_tree_rank[k] = position of fusion joint k in a top-down order of the union skeleton tree rooted at MidHip
+// (8,20,9,12,1,10,13,0,2,5,11,14,15,16,19,3,6,17,18,4,7): every joint's possible parents precede it.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __constant__ const int c_tree_rank[SE3D_NFU] = {7, 4, 8, 15, 19, 9, 16, 20, 0, 2, 5, 10, 3, 6, 11, 12, 13, 17, 18, 14, 1};
+
+struct TreeTopo { int parent, pedge, level, maxlev; unsigned children; bool forest; };
+
+__device__ TreeTopo s2_tree_topology(LmSchurLds &L, int K, int nr, int lane) {
+  TreeTopo tp{-1, -1, 0, 0, 0u, true};
+  int nparents = 0;
+  if (lane < K) {
+    const int myrank = c_tree_rank[L.keyofcol[lane]];
+    for (unsigned m = L.incA[lane] | L.incB[lane]; m; m &= m - 1) {
+      const int e = __ffs(m) - 1;
+      const int other = (L.rv1[e] == lane) ? L.rv2[e] : L.rv1[e];
+      if (c_tree_rank[L.keyofcol[other]] < myrank) { tp.parent = other; tp.pedge = e; ++nparents; }
+      else tp.children |= 1u << other;
+    }
+    L.par[lane] = tp.parent;
+    L.pe[lane] = tp.pedge;
+  }
+  tp.forest = __ballot(nparents > 1) == 0ull;  // cannot fail with the reference's bone tables; guards the assumption
+  __builtin_amdgcn_wave_barrier();
+  if (lane < K) {
+    int lv = 0, p = tp.parent;
+    for (int hop = 0; hop < SE3D_NFU && p >= 0; ++hop) { ++lv; p = L.par[p]; }
+    tp.level = lv;
+  }
+  int mx = (lane < K) ? tp.level : 0;
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
+  tp.maxlev = mx;
+  return tp;
+}
+
+// tryLambda solve by forest elimination: delta -> L.dl
+__device__ void s2_tree_solve(LmSchurLds &L, int K, double lambda, int lane, const double Av[6], const double gv[3], const TreeTopo &tp) {
+  double D[6] = {Av[0] + lambda, Av[1], Av[2], Av[3] + lambda, Av[4], Av[5] + lambda};
+  double g[3] = {gv[0], gv[1], gv[2]};
+  double Di[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0}, z[3] = {0, 0, 0}, h[3] = {0, 0, 0};
+  const bool act = lane < K;
+  if (act) {
+    for (unsigned m = L.incA[lane] | L.incB[lane]; m; m &= m - 1) {
+      const int e = __ffs(m) - 1;
+      const double h0 = L.Hs[e][0], h1 = L.Hs[e][1], h2 = L.Hs[e][2];
+      D[0] += h0 * h0; D[1] += h0 * h1; D[2] += h0 * h2; D[3] += h1 * h1; D[4] += h1 * h2; D[5] += h2 * h2;
+    }
+    if (tp.pedge >= 0) { h[0] = L.Hs[tp.pedge][0]; h[1] = L.Hs[tp.pedge][1]; h[2] = L.Hs[tp.pedge][2]; }
+  }
+  for (int lv = tp.maxlev; lv >= 1; --lv) {  // leaves -> roots
+    if (act && tp.level == lv) {
+      s2_sym3_inv(D, Di);
+      s2_sym3_mul(Di, h, u);
+      s2_sym3_mul(Di, g, z);
+      L.al[lane] = h[0] * u[0] + h[1] * u[1] + h[2] * u[2];
+      L.be[lane] = h[0] * z[0] + h[1] * z[1] + h[2] * z[2];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (act && tp.level == lv - 1) {
+      for (unsigned m = tp.children; m; m &= m - 1) {
+        const int c = __ffs(m) - 1;
+        const int e = L.pe[c];
+        const double h0 = L.Hs[e][0], h1 = L.Hs[e][1], h2 = L.Hs[e][2];
+        const double a = L.al[c], b = L.be[c];
+        D[0] -= a * h0 * h0; D[1] -= a * h0 * h1; D[2] -= a * h0 * h2; D[3] -= a * h1 * h1; D[4] -= a * h1 * h2; D[5] -= a * h2 * h2;
+        g[0] += b * h0; g[1] += b * h1; g[2] += b * h2;
+      }
+    }
+  }
+  double d[3] = {0, 0, 0};
+  if (act && tp.level == 0) {
+    s2_sym3_inv(D, Di);
+    s2_sym3_mul(Di, g, d);
+    for (int a = 0; a < 3; ++a) L.dl[3 * lane + a] = d[a];
+  }
+  for (int lv = 1; lv <= tp.maxlev; ++lv) {  // roots -> leaves
+    __builtin_amdgcn_wave_barrier();
+    if (act && tp.level == lv) {
+      const int p = tp.parent;
+      const double gam = h[0] * L.dl[3 * p] + h[1] * L.dl[3 * p + 1] + h[2] * L.dl[3 * p + 2];
+      for (int a = 0; a < 3; ++a) { d[a] = z[a] + u[a] * gam; L.dl[3 * lane + a] = d[a]; }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Marginals: (H^-1)_vv = D_v^-1 - sum_{e,f incident to v} u_e (M^-1)[e][f] u_f^T  -> L.mcov
+__device__ void s2_schur_marginals(LmSchurLds &L, int K, int nr, int lane, const double Av[6]) {
+  double Di[6] = {0, 0, 0, 0, 0, 0}, zv[3], row[21];
+  const double g0[3] = {0, 0, 0};
+  s2_schur_build(L, K, nr, 0.0, lane, Av, g0, Di, zv, row);
+  s2_chol21(row, lane);
+  double x[21];  // column `lane` of X = L^-1
+#pragma unroll
+  for (int i = 0; i < 21; ++i) {
+    double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) sacc -= s2_rl(row[k], i) * x[k];
+    x[i] = sacc / s2_rl(row[i], i);
+  }
+#pragma unroll
+  for (int f = 0; f < 21; ++f) {  // (M^-1)[lane][f] = sum_{i >= f} X[i][lane] X[i][f]
+    double acc = 0.0;
+#pragma unroll
+    for (int i = f; i < 21; ++i) acc += x[i] * s2_rl(x[i], f);
+    if (lane < 21) L.Mi[lane][f] = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < K) {
+    double c[6] = {Di[0], Di[1], Di[2], Di[3], Di[4], Di[5]};
+    const unsigned mA = L.incA[lane], mB = L.incB[lane];
+    for (unsigned me = mA | mB; me; me &= me - 1) {
+      const int e = __ffs(me) - 1;
+      const double *ue = ((mA >> e) & 1u) ? L.ua[e] : L.ub[e];
+      for (unsigned mf = mA | mB; mf; mf &= mf - 1) {
+        const int f = __ffs(mf) - 1;
+        const double *uf = ((mA >> f) & 1u) ? L.ua[f] : L.ub[f];
+        const double mi = L.Mi[e][f];
+        c[0] -= mi * ue[0] * uf[0]; c[1] -= mi * ue[0] * uf[1]; c[2] -= mi * ue[0] * uf[2];
+        c[3] -= mi * ue[1] * uf[1]; c[4] -= mi * ue[1] * uf[2]; c[5] -= mi * ue[2] * uf[2];
+      }
+    }
+    for (int q = 0; q < 6; ++q) L.mcov[lane][q] = c[q];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void s2_cov6_to_mat(const double c[6], double M[9]) {
   M[0] = c[0]; M[1] = c[1]; M[2] = c[2]; M[3] = c[1]; M[4] = c[3]; M[5] = c[4]; M[6] = c[2]; M[7] = c[4]; M[8] = c[5];
 }
 
+// MODE 0: dense 63x63 H per wavefront; 1: Schur/Woodbury (MFMA) for solve and marginals; 2: forest elimination for the LM
+// solves + Schur/Woodbury (MFMA) for the marginals (default)
+template <int MODE>
 __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
+  constexpr bool SCHUR = MODE != 0;
   extern __shared__ __align__(16) unsigned char s2_smem[];
-  LmLds &L = *reinterpret_cast<LmLds *>(s2_smem);
+  using LdsT = typename std::conditional<SCHUR, LmSchurLds, LmLds>::type;
+  LdsT &L = *reinterpret_cast<LdsT *>(s2_smem);
   const int lane = threadIdx.x;
   const int i = blockIdx.x, s = blockIdx.y + Q.seq0;
   const int H = Q.H, T = Q.T;
@@ -387,6 +715,7 @@ __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
   const se3d_person3d &person = Q.dets[(size_t)s * H + i];
   const bool simple = Q.pose_method == SE3D_POSE_SIMPLE;
   const double t = Q.t[s];
+  LM_STAMP_INIT
 
   // ---- root / neck / height (PP:631-668), identical on every lane ----
   double root[3] = {0, 0, 0}, neck[3] = {0, 0, 0};
@@ -498,7 +827,23 @@ __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
   }
   __builtin_amdgcn_wave_barrier();
   const int n = 3 * K;
+  double Av[6] = {0, 0, 0, 0, 0, 0};  // Schur variant: lane v < K owns variable (column) v
+  if constexpr (SCHUR) {
+    if (lane < K) {
+      const double *R = L.Rm[lane];
+      Av[0] = R[0] * R[0] + R[3] * R[3] + R[6] * R[6]; Av[1] = R[0] * R[1] + R[3] * R[4] + R[6] * R[7];
+      Av[2] = R[0] * R[2] + R[3] * R[5] + R[6] * R[8]; Av[3] = R[1] * R[1] + R[4] * R[4] + R[7] * R[7];
+      Av[4] = R[1] * R[2] + R[4] * R[5] + R[7] * R[8]; Av[5] = R[2] * R[2] + R[5] * R[5] + R[8] * R[8];
+      unsigned ia = 0, ib = 0;
+      for (int ee = 0; ee < nr; ++ee) { if (L.rv1[ee] == lane) ia |= 1u << ee; if (L.rv2[ee] == lane) ib |= 1u << ee; }
+      L.incA[lane] = ia; L.incB[lane] = ib;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  TreeTopo topo{-1, -1, 0, 0, 0u, false};
+  if constexpr (MODE == 2) topo = s2_tree_topology(L, K, nr, lane);
 
+  LM_STAMP(0)  // setup
   // ---- LevenbergMarquardtOptimizer(graph, prevEstimate).optimize(), GTSAM 4.0.3 defaults ----
   int iterations = 0;
   if (whiten_ok) {
@@ -507,10 +852,26 @@ __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
     if (!(error <= 0.0)) {
       for (int outer = 0; outer < 1000; ++outer) {
         const double currentError = error;
+        LM_STAMP(1)  // graph error / loop control
         s2_linearize(L, K, nr, lane);
-        // g = J^T b (lane c < n)
+        // g = J^T b (dense: lane c < n holds g[c]; Schur: lane v < K holds the 3-vector of its variable)
         double g = 0.0;
-        if (lane < n) {
+        double gv[3] = {0, 0, 0};
+        if constexpr (SCHUR) {
+          if (lane < K) {
+            const double *R = L.Rm[lane];
+            const double b0 = L.bb[3 * lane], b1 = L.bb[3 * lane + 1], b2 = L.bb[3 * lane + 2];
+            for (int a = 0; a < 3; ++a) gv[a] = R[0 * 3 + a] * b0 + R[1 * 3 + a] * b1 + R[2 * 3 + a] * b2;
+            for (unsigned mk = L.incA[lane]; mk; mk &= mk - 1) {
+              const int ee = __ffs(mk) - 1;
+              for (int a = 0; a < 3; ++a) gv[a] -= L.Hs[ee][a] * L.bb[n + ee];
+            }
+            for (unsigned mk = L.incB[lane]; mk; mk &= mk - 1) {
+              const int ee = __ffs(mk) - 1;
+              for (int a = 0; a < 3; ++a) gv[a] += L.Hs[ee][a] * L.bb[n + ee];
+            }
+          }
+        } else if (lane < n) {
           const int v = lane / 3, a = lane - 3 * v;
           g = L.Rm[v][0 * 3 + a] * L.bb[3 * v] + L.Rm[v][1 * 3 + a] * L.bb[3 * v + 1] + L.Rm[v][2 * 3 + a] * L.bb[3 * v + 2];
           for (int ee = 0; ee < nr; ++ee) {
@@ -520,14 +881,27 @@ __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
         }
         bool stepped = false;
         for (int tr = 0; tr < 64; ++tr) {  // tryLambda
-          s2_jtj_mfma(L, K, nr, lambda, lane);
-          const bool solved = s2_cholesky(L.Hm, n, lane);
+          bool solved = true;
+          LM_STAMP(2)  // linearize + gradient
+          if constexpr (MODE == 2) {
+            if (topo.forest) s2_tree_solve(L, K, lambda, lane, Av, gv, topo);
+            else s2_schur_solve(L, K, nr, lambda, lane, Av, gv);
+            LM_STAMP(3)  // solve
+          } else if constexpr (MODE == 1) {
+            s2_schur_solve(L, K, nr, lambda, lane, Av, gv);
+            LM_STAMP(3)  // solve
+          } else {
+            s2_jtj_mfma(L, K, nr, lambda, lane);
+            solved = s2_cholesky(L.Hm, n, lane);
+          }
           bool step_ok = false, stop = false;
           double newError = 0.0;
           if (solved) {
-            const double d = s2_chol_solve(L.Hm, n, g, lane);
-            if (lane < n) L.dl[lane] = d;
-            __builtin_amdgcn_wave_barrier();
+            if constexpr (!SCHUR) {
+              const double d = s2_chol_solve(L.Hm, n, g, lane);
+              if (lane < n) L.dl[lane] = d;
+              __builtin_amdgcn_wave_barrier();
+            }
             // linear.error(delta) = 0.5 ||J delta - b||^2 over the undamped factors
             double le = 0.0;
             for (int r = lane; r < n + nr; r += 64) {
@@ -590,10 +964,19 @@ __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
     __builtin_amdgcn_wave_barrier();
   }
 
+  LM_STAMP(4)  // linear error, new error, lambda logic (accumulated remainder of the LM loop)
   // ---- Marginals(graph, result): diagonal 3x3 blocks of (J^T J)^-1 at the optimum (PP:760-793) ----
   bool use_marg = false;
   double mc[6] = {0, 0, 0, 0, 0, 0};
-  if (whiten_ok) {
+  if constexpr (SCHUR) {
+    if (whiten_ok) {
+      s2_linearize(L, K, nr, lane);
+      s2_schur_marginals(L, K, nr, lane, Av);
+      use_marg = true;
+      if (measured)
+        for (int q = 0; q < 6; ++q) mc[q] = L.mcov[col][q];
+    }
+  } else if (whiten_ok) {
     s2_linearize(L, K, nr, lane);
     s2_jtj_mfma(L, K, nr, 0.0, lane);
     if (s2_cholesky(L.Hm, n, lane)) {
@@ -613,6 +996,7 @@ __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
     }
   }
 
+  LM_STAMP(5)  // marginals
   // ---- outputs + track-state update: lane k <-> fusion joint k (PP:769-843) ----
   se3d_person3d &pf = Q.fused_det[(size_t)s * H + i];
   se3d_person3d &pp = Q.pred_det[(size_t)s * H + i];
@@ -668,6 +1052,10 @@ __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
     Q.pub[(size_t)s * H + i] = (no > 10) ? 1 : 0;  // g_min_num_obs_track (PP:845-848)
     Q.iters_det[(size_t)s * H + i] = iterations;
   }
+  LM_STAMP(6)  // outputs
+#ifdef SE3D_LM_STAMPS
+  if (threadIdx.x == 0) { atomicAdd(&g_lm_stamps[8], 1ull); atomicAdd(&g_lm_stamps[9], (unsigned long long)iterations); }
+#endif
 }
 
 // =============================================================================================================
@@ -749,18 +1137,30 @@ __global__ __launch_bounds__(256) void se3d_k_track_update(Se3dStage2 Q) {
   }
 }
 
+#ifdef SE3D_LM_STAMPS
+extern "C" void se3d_diag_lm_stamps(unsigned long long *out16, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lm_stamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lm_stamps), z, sizeof(z)); }
+}
+#endif
 extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev) {
   Se3dStage2 q = Q;
   q.seq0 = seq0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmLds));
-    attr_set = true;
+  static int lm_mode = -1;
+  if (lm_mode < 0) {
+    const char *e = getenv("SE3D_LM");  // A/B evidence switch: dense | schur | tree (default)
+    lm_mode = (e && strcmp(e, "dense") == 0) ? 0 : (e && strcmp(e, "schur") == 0) ? 1 : 2;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmLds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmSchurLds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmSchurLds));
   }
   if (ev) (void)hipEventRecord(ev[0], st);
   hipLaunchKernelGGL(se3d_k_track_assoc, dim3(nseq), dim3(256), 0, st, q);
   if (ev) (void)hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(se3d_k_lm_refine, dim3(q.H, nseq), dim3(64), sizeof(LmLds), st, q);
+  if (lm_mode == 0) hipLaunchKernelGGL(se3d_k_lm_refine<0>, dim3(q.H, nseq), dim3(64), sizeof(LmLds), st, q);
+  else if (lm_mode == 1) hipLaunchKernelGGL(se3d_k_lm_refine<1>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
+  else hipLaunchKernelGGL(se3d_k_lm_refine<2>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
   if (ev) (void)hipEventRecord(ev[2], st);
   hipLaunchKernelGGL(se3d_k_track_update, dim3(nseq), dim3(256), 0, st, q);
   if (ev) (void)hipEventRecord(ev[3], st);

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of se3d_k_lm_refine from the stamp build (make -C .../csrc diag).  Not a benchmark."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from smartedgesensor3dhumanpose_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "smartedgesensor3dhumanpose_amd", "libse3d_hip_diag.so")
+import numpy as np
+import bench
+w = bench.WORKLOADS["16cam6p"]
+rig = bench.make_rig(w)
+S_, T_ = 128, 16
+seqs = bench.make_sequences(rig, w, S_, 0, T_)
+frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
+from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
+node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=16)
+node.stage(frames); node.refine_reset(); node.run_stage1()
+L = _lib.lib()
+out = (C.c_ulonglong * 16)()
+t = 100.0
+for rep in range(3):
+    for k in (range(T_) if rep % 2 == 0 else range(T_ - 1, -1, -1)):
+        t += 1 / 30
+        node.run_stage2(np.full(S_, t), frame_slot0=k * S_)
+    node.sync()
+    L.se3d_diag_lm_stamps(out, 1)
+    v = list(out)
+    n = max(v[8], 1)
+    names = ["setup", "error/ctl", "linearize+grad", "solve", "lm-rest", "marginals", "outputs"]
+    print("rep", rep, "persons", v[8], "avg LM iterations %.2f" % (v[9] / n), "| cycles/person:", {nm: round(v[i] / n) for i, nm in enumerate(names)}, "total", round(sum(v[:7]) / n))
