@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libse3d_hip.so")
+LIB_PATH = os.environ.get("SE3D_LIB_OVERRIDE") or os.path.join(_HERE, "libse3d_hip.so")  # override: ablation/diagnostic builds only
 
 # every entry point declared in include/se3d.h (checked against the header in tests/test_abi.py)
 EXPORTS = [

@@ -9,6 +9,28 @@
 #include "se3d_device.h"
 #include "se3d_munkres.h"
 
+// Diagnostic build only (make diag): cycle stamps of se3d_k_sweep_assign (never in the product .so)
+#ifdef SE3D_LM_STAMPS
+__device__ unsigned long long g_s1_stamps[16];
+#define S1_STAMP(idx)                                                                  \
+  {                                                                                    \
+    const unsigned long long now_ = __builtin_readcyclecounter();                      \
+    if (threadIdx.x == 0) atomicAdd(&g_s1_stamps[idx], now_ - s1_prev_);               \
+    s1_prev_ = __builtin_readcyclecounter();                                           \
+  }
+#define S1_STAMP_INIT unsigned long long s1_prev_ = __builtin_readcyclecounter();
+#define S1_COUNT(idx) if (threadIdx.x == 0) atomicAdd(&g_s1_stamps[idx], 1ull);
+extern "C" void se3d_diag_s1_stamps(unsigned long long *out16, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_s1_stamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_s1_stamps), z, sizeof(z)); }
+}
+#else
+#define S1_STAMP(idx)
+#define S1_STAMP_INIT
+#define S1_COUNT(idx)
+#endif
+
 #define TRI_THRESH 0.30f
 #define REPROJ_MAX 0.050
 #define MAX_COSTS 1e6
@@ -121,6 +143,77 @@ __global__ __launch_bounds__(256) void se3d_k_pairs_flat(Se3dDev D, const int2 *
 // fp64 add per pair-joint.  All float operations are the ones of se3d_pair_cost in the same order -> bit-identical.
 #define PT 64
 struct __align__(16) LineLDS { float lx, ly, lz, nrm; };
+
+// Correctly rounded a / b from y = RN(1/b) (IEEE reciprocal computed once per epipolar line and shared by every pair on
+// that line): one multiply and two FMA-residual corrections (Markstein).  q0 = RN(a y) is within 1.5 ulp, the first
+// correction makes it faithful, the second rounds correctly provided y is the correctly rounded reciprocal, results stay in
+// the normal range and b's significand is not all ones (such lines carry nrm_ok = 0 and take the IEEE divide).
+// tests/test_gpu_stage1.py checks the resulting table bit-for-bit against the plain IEEE-divide kernel and the oracle.
+// Range guard for the shared-reciprocal divide: every operand of a numerator/denominator is 0 or within [2^-30, 2^30].
+// Then a non-zero numerator is >= 2^-84 and a quotient >= 2^-115, so all FMA residuals of se3d_div_markstein are exact
+// (no underflow) and its two correction steps return the correctly rounded quotient; zero numerators give exactly 0.
+__device__ __forceinline__ bool se3d_in_safe_range(float v) {
+  const unsigned ex = (__float_as_uint(v) >> 23) & 0xffu;
+  return (v == 0.f) || (ex >= 97u && ex <= 157u);
+}
+// y = RN(1/b) for divisors where Markstein's theorem applies (normal range, significand not all ones), else 0
+__device__ __forceinline__ float se3d_safe_rcp(float b) {
+  const unsigned u = __float_as_uint(b);
+  const unsigned ex = (u >> 23) & 0xffu;
+  const bool ok = (ex >= 97u && ex <= 157u) && ((u & 0x7fffffu) != 0x7fffffu);
+  return ok ? 1.0f / b : 0.0f;
+}
+__device__ __forceinline__ float se3d_div_markstein(float a, float b, float y) {
+  float q = a * y;
+  float r = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(r, y, q);
+}
+
+#define JT 9  // joints staged per LDS phase (17 = 9 + 8)
+template <bool FAST, int NI, int NK>
+__device__ __forceinline__ void se3d_pairs_tile_compute(const LineLDS (*L1)[PT], const LineLDS (*L2)[PT], const float4 (*P1)[PT], const float4 (*P2)[PT],
+                                                     int jn, int jbase, int tx, int ty, const unsigned (&mm)[4][4], double (&acc)[4][4]) {
+  for (int jj = 0; jj < jn; ++jj) {
+    const int j = jbase + jj;
+    LineLDS l1[NI], l2[NK];
+    float4 a[NI], b[NK];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { l1[i] = L1[jj][ty + 16 * i]; a[i] = P1[jj][ty + 16 * i]; }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { l2[k] = L2[jj][tx + 16 * k]; b[k] = P2[jj][tx + 16 * k]; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const float n1 = fabsf(b[k].x * l1[i].lx + (b[k].y * l1[i].ly + l1[i].lz));
+        const float n2 = fabsf(a[i].x * l2[k].lx + (a[i].y * l2[k].ly + l2[k].lz));
+        float d1, d2;
+        if (FAST) { d1 = se3d_div_markstein(n1, l1[i].nrm, a[i].z); d2 = se3d_div_markstein(n2, l2[k].nrm, b[k].z); }
+        else { d1 = n1 / l1[i].nrm; d2 = n2 / l2[k].nrm; }
+        const float sacc = d1 + d2;
+        acc[i][k] += ((mm[i][k] >> j) & 1u) ? (double)sacc : 0.0;
+      }
+    }
+  }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void se3d_pairs_tile_dispatch(const LineLDS (*L1)[PT], const LineLDS (*L2)[PT], const float4 (*P1)[PT], const float4 (*P2)[PT],
+                                                         int jn, int jbase, int tx, int ty, int ni, int nk, const unsigned (&mm)[4][4],
+                                                         double (&acc)[4][4]) {
+#define SE3D_PT_CASE(NI_, NK_) \
+  case (NI_) * 4 + (NK_) - 5: se3d_pairs_tile_compute<FAST, NI_, NK_>(L1, L2, P1, P2, jn, jbase, tx, ty, mm, acc); break;
+  switch (ni * 4 + nk - 5) {  // block-uniform
+    SE3D_PT_CASE(1, 1) SE3D_PT_CASE(1, 2) SE3D_PT_CASE(1, 3) SE3D_PT_CASE(1, 4)
+    SE3D_PT_CASE(2, 1) SE3D_PT_CASE(2, 2) SE3D_PT_CASE(2, 3) SE3D_PT_CASE(2, 4)
+    SE3D_PT_CASE(3, 1) SE3D_PT_CASE(3, 2) SE3D_PT_CASE(3, 3) SE3D_PT_CASE(3, 4)
+    SE3D_PT_CASE(4, 1) SE3D_PT_CASE(4, 2) SE3D_PT_CASE(4, 3) SE3D_PT_CASE(4, 4)
+  }
+#undef SE3D_PT_CASE
+}
+
 __global__ __launch_bounds__(256) void se3d_k_pairs_tiled(Se3dDev D, const int2 *__restrict__ pair_ab) {
   const int N = D.d.N, P = D.d.P, np = D.d.npairs;
   const int tiles = (P + PT - 1) / PT;
@@ -130,71 +223,76 @@ __global__ __launch_bounds__(256) void se3d_k_pairs_tiled(Se3dDev D, const int2 
   const int na = D.nvalid[f * N + ab.x], nb = D.nvalid[f * N + ab.y];
   const int p0 = tp * PT, q0 = tq * PT;
   if (p0 >= na || q0 >= nb) return;
-  __shared__ LineLDS L1[SE3D_NKP][PT];  // [joint][det_a]
-  __shared__ LineLDS L2[SE3D_NKP][PT];
-  __shared__ float2 P1[SE3D_NKP][PT];
-  __shared__ float2 P2[SE3D_NKP][PT];
+  __shared__ LineLDS L1[JT][PT];  // [joint][det_a]: epipolar line F p1 and its norm
+  __shared__ LineLDS L2[JT][PT];  // [joint][det_b]: F^T p2
+  __shared__ float4 P1[JT][PT];   // (x, y, RN(1/norm) of the own line, -)
+  __shared__ float4 P2[JT][PT];
   __shared__ unsigned M1[PT], M2[PT];
+  __shared__ int s_unsafe;
   const int tid = threadIdx.x;
   const float *F = D.F + 9 * (size_t)pr;
   const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
   const size_t baseA = ((size_t)(f * N + ab.x)) * P, baseB = ((size_t)(f * N + ab.y)) * P;
-  for (int i = tid; i < PT * SE3D_NKP; i += 256) {
-    const int d = i / SE3D_NKP, k = i - d * SE3D_NKP;
-    {
-      const int p = p0 + d;
-      float4 A = make_float4(0.f, 0.f, -1.f, 0.f);
-      if (p < na) A = D.kp[(baseA + p) * SE3D_NKP + k];
-      const float l1x = f0 * A.x + (f1 * A.y + f2);
-      const float l1y = f3 * A.x + (f4 * A.y + f5);
-      const float l1z = f6 * A.x + (f7 * A.y + f8);
-      LineLDS l;
-      l.lx = l1x; l.ly = l1y; l.lz = l1z; l.nrm = sqrtf(l1x * l1x + l1y * l1y);
-      L1[k][d] = l;
-      P1[k][d] = make_float2(A.x, A.y);
-    }
-    {
-      const int q = q0 + d;
-      float4 Bq = make_float4(0.f, 0.f, -1.f, 0.f);
-      if (q < nb) Bq = D.kp[(baseB + q) * SE3D_NKP + k];
-      const float l2x = f0 * Bq.x + (f3 * Bq.y + f6);
-      const float l2y = f1 * Bq.x + (f4 * Bq.y + f7);
-      const float l2z = f2 * Bq.x + (f5 * Bq.y + f8);
-      LineLDS l;
-      l.lx = l2x; l.ly = l2y; l.lz = l2z; l.nrm = sqrtf(l2x * l2x + l2y * l2y);
-      L2[k][d] = l;
-      P2[k][d] = make_float2(Bq.x, Bq.y);
-    }
-  }
+  if (tid == 0) s_unsafe = 0;
   for (int d = tid; d < PT; d += 256) {
     M1[d] = (p0 + d < na) ? D.vmask_gt[baseA + p0 + d] : 0u;
     M2[d] = (q0 + d < nb) ? D.vmask_gt[baseB + q0 + d] : 0u;
   }
   __syncthreads();
-  // thread (ty, tx): det_a rows ty + 16*i, det_b cols tx + 16*k   (tx fastest -> coalesced stores over q)
-  const int tx = tid & 15, ty = tid >> 4;
+  const int tx = tid & 15, ty = tid >> 4;  // thread tile: det_a rows ty + 16 i, det_b cols tx + 16 k (tx fastest: coalesced stores)
+  const int ni = min(4, (na - p0 + 15) >> 4), nk = min(4, (nb - q0 + 15) >> 4);  // 16-wide groups holding valid detections
   double acc[4][4];
   unsigned mm[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int k = 0; k < 4; ++k) { acc[i][k] = 0.0; mm[i][k] = M1[ty + 16 * i] & M2[tx + 16 * k]; }
-  for (int j = 0; j < SE3D_NKP; ++j) {
-    LineLDS l1[4], l2[4];
-    float2 a[4], b[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { l1[i] = L1[j][ty + 16 * i]; a[i] = P1[j][ty + 16 * i]; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { l2[k] = L2[j][tx + 16 * k]; b[k] = P2[j][tx + 16 * k]; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float d1 = fabsf(b[k].x * l1[i].lx + (b[k].y * l1[i].ly + l1[i].lz)) / l1[i].nrm;
-        const float d2 = fabsf(a[i].x * l2[k].lx + (a[i].y * l2[k].ly + l2[k].lz)) / l2[k].nrm;
-        const float s = d1 + d2;
-        if ((mm[i][k] >> j) & 1u) acc[i][k] += (double)s;
+  for (int jbase = 0; jbase < SE3D_NKP; jbase += JT) {
+    const int jn = min(JT, SE3D_NKP - jbase);
+    __syncthreads();  // previous phase finished reading the LDS tiles
+    bool unsafe = false;
+    for (int i = tid; i < PT * jn; i += 256) {
+      const int d = i / jn, jj = i - d * jn, k = jbase + jj;
+      {
+        const int p = p0 + d;
+        float4 A = make_float4(0.f, 0.f, -1.f, 0.f);
+        if (p < na) A = D.kp[(baseA + p) * SE3D_NKP + k];
+        LineLDS l;
+        l.lx = f0 * A.x + (f1 * A.y + f2);
+        l.ly = f3 * A.x + (f4 * A.y + f5);
+        l.lz = f6 * A.x + (f7 * A.y + f8);
+        l.nrm = sqrtf(l.lx * l.lx + l.ly * l.ly);
+        const float y = se3d_safe_rcp(l.nrm);
+        unsafe |= (p < na) && ((M1[d] >> k) & 1u) &&
+                  !(y != 0.f && se3d_in_safe_range(l.lx) && se3d_in_safe_range(l.ly) && se3d_in_safe_range(l.lz) && se3d_in_safe_range(A.x) && se3d_in_safe_range(A.y));
+        L1[jj][d] = l;
+        P1[jj][d] = make_float4(A.x, A.y, y, 0.f);
       }
+      {
+        const int q = q0 + d;
+        float4 Bq = make_float4(0.f, 0.f, -1.f, 0.f);
+        if (q < nb) Bq = D.kp[(baseB + q) * SE3D_NKP + k];
+        LineLDS l;
+        l.lx = f0 * Bq.x + (f3 * Bq.y + f6);
+        l.ly = f1 * Bq.x + (f4 * Bq.y + f7);
+        l.lz = f2 * Bq.x + (f5 * Bq.y + f8);
+        l.nrm = sqrtf(l.lx * l.lx + l.ly * l.ly);
+        const float y = se3d_safe_rcp(l.nrm);
+        unsafe |= (q < nb) && ((M2[d] >> k) & 1u) &&
+                  !(y != 0.f && se3d_in_safe_range(l.lx) && se3d_in_safe_range(l.ly) && se3d_in_safe_range(l.lz) && se3d_in_safe_range(Bq.x) && se3d_in_safe_range(Bq.y));
+        L2[jj][d] = l;
+        P2[jj][d] = make_float4(Bq.x, Bq.y, y, 0.f);
+      }
+    }
+    if (unsafe) s_unsafe = 1;
+    __syncthreads();
+    // block-uniform choice: shared-reciprocal divide (exact under the range guard) or the plain IEEE divide
+#ifndef SE3D_EXP_NOCOMPUTE
+    if (!s_unsafe) se3d_pairs_tile_dispatch<true>(L1, L2, P1, P2, jn, jbase, tx, ty, ni, nk, mm, acc);
+    else se3d_pairs_tile_dispatch<false>(L1, L2, P1, P2, jn, jbase, tx, ty, ni, nk, mm, acc);
+#else
+    acc[0][0] += L1[0][ty].lx + L2[0][tx].ly + P1[0][ty].z + P2[0][tx].z;  // ablation build only
+#endif
   }
   double *out = D.pair + ((size_t)f * np + pr) * P * P;
 #pragma unroll
@@ -206,6 +304,9 @@ __global__ __launch_bounds__(256) void se3d_k_pairs_tiled(Se3dDev D, const int2 
       const int q = q0 + tx + 16 * k;
       if (q >= nb) continue;
       const int n = __popc(mm[i][k]);
+#ifdef SE3D_EXP_NOSTORE
+      if (acc[i][k] == 12345.678)  // ablation build only: keeps the computation alive without the store traffic
+#endif
       out[(size_t)p * P + q] = n > 0 ? acc[i][k] / n : -1.0;
     }
   }
@@ -223,30 +324,46 @@ __global__ __launch_bounds__(128) void se3d_k_sweep_cost(Se3dDev D, int b) {
   if (nh == 0 || h >= nh) return;
   const int nd = D.nvalid[f * N + b];
   if (nd == 0) return;
-  __shared__ int sk[SE3D_MAX_CAMS];
-  __shared__ float ss[SE3D_MAX_CAMS];
+  // compacted list of the views attached to this hypothesis (ascending camera = the reference's obs order)
+  __shared__ unsigned long long s_off[SE3D_MAX_CAMS];  // element offset of the pair-table row (without q)
+  __shared__ unsigned char s_scored[SE3D_MAX_CAMS];    // hyp.score[obs] > 0.5f
+  __shared__ int s_m;
   const int32_t *arow = D.assoc + ((size_t)f * H + h) * N;
-  for (int a = tid; a < b; a += blockDim.x) {
-    const int k = arow[a];
-    sk[a] = k;
-    ss[a] = (k >= 0) ? D.pscore[((size_t)(f * N + a)) * P + k] : 0.f;
+  if (tid < 64) {  // wave 0 compacts in order with ballots
+    int m = 0;
+    for (int a0 = 0; a0 < b; a0 += 64) {
+      const int a = a0 + tid;
+      const int k = (a < b) ? arow[a] : -1;
+      const unsigned long long bl = __ballot(k >= 0);
+      if (k >= 0) {
+        const int pos = m + __popcll(bl & ((1ull << tid) - 1ull));
+        s_off[pos] = ((unsigned long long)se3d_pair_index(a, b, N) * P + k) * P;
+        s_scored[pos] = D.pscore[((size_t)(f * N + a)) * P + k] > 0.5f ? 1 : 0;
+      }
+      m += __popcll(bl);
+    }
+    if (tid == 0) s_m = m;
   }
   __syncthreads();
-  const int n_obs = D.nviews[f * H + h];
+  const int M = s_m;
+  const int n_obs = D.nviews[f * H + h];  // == M
   const double max_epi = D.d.max_epi;
   const double tolerance = 1.0 - 1.0 / (2 * n_obs), veto_delta = 1.0 / n_obs;
   const double *tab = D.pair + (size_t)f * np * P * P;
   for (int q = tid; q < nd; q += blockDim.x) {
     double total = 0.0;
     int nused = 0, cnt = 0;
-    for (int a = 0; a < b; ++a) {
-      const int k = sk[a];
-      if (k < 0) continue;
-      const double c = tab[((size_t)se3d_pair_index(a, b, N) * P + k) * P + q];
-      if (c >= 0.0) {  // n_joints_used > 0
-        total += c;
-        ++nused;
-        if (c > max_epi && (ss[a] > 0.5f || n_obs == 1)) ++cnt;
+    for (int m0 = 0; m0 < M; m0 += 8) {  // 8 independent loads in flight, then the ordered fp64 accumulation
+      double c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = (m0 + u < M) ? tab[s_off[m0 + u] + q] : -1.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (c[u] >= 0.0) {  // n_joints_used > 0 (padding entries are -1 as well)
+          total += c[u];
+          ++nused;
+          if (c[u] > max_epi && (s_scored[m0 + u] || n_obs == 1)) ++cnt;
+        }
       }
     }
     bool veto = false;
@@ -280,7 +397,8 @@ __device__ __forceinline__ int se3d_block_excl_scan(bool flag, int *wsum /*LDS[5
   return off + within;
 }
 
-__global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b) {
+__global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b, int dyn_lds_bytes) {
+  extern __shared__ __align__(16) double s_dynW[];  // Munkres working matrix when it fits (dyn_lds_bytes), else HBM workspace
   const int f = blockIdx.x, tid = threadIdx.x;
   const int N = D.d.N, P = D.d.P, H = D.d.H;
   if (D.nraw[f * N + b] == 0) return;  // camera without any detection is not part of the sweep (S3D:538-555)
@@ -300,6 +418,8 @@ __global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b) {
   __shared__ int s_amb;
   __shared__ int wsum[4];
   const uint8_t *mask = D.mask + (size_t)f * H * P;
+  S1_STAMP_INIT
+  S1_COUNT(8)
   if (tid == 0) s_amb = 0;
   for (int i = tid; i < SE3D_MUNKRES_MAX; i += 256) { handled[i] = 0; spawn[i] = -1; assign[i] = -1; }
   __syncthreads();
@@ -316,14 +436,19 @@ __global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b) {
     if (cnt > 1) s_amb = 1;
   }
   __syncthreads();
+  S1_STAMP(0)  // mask row/column scans
   if (s_amb) {  // more than one feasible association: Hungarian on the full (unmasked) C (S3D:628-634)
+    S1_COUNT(9)
     const double *C = D.C + (size_t)f * H * P;
-    double *W = D.mwork + (size_t)f * H * P;
+    const bool in_lds = (size_t)nh * nd * sizeof(double) <= (size_t)dyn_lds_bytes;
+    double *W = in_lds ? s_dynW : D.mwork + (size_t)f * H * P;
+    const int ldw = in_lds ? nh : H;
     for (int q = 0; q < nd; ++q)
-      for (int h = tid; h < nh; h += 256) W[h + (size_t)H * q] = C[h + (size_t)H * q];
+      for (int h = tid; h < nh; h += 256) W[h + (size_t)ldw * q] = C[h + (size_t)H * q];
     __syncthreads();
-    if (se3d_munkres_block(W, H, nh, nd, S, assign) != 0 && tid == 0) atomicOr(&D.flags[f], 4u);
+    if (se3d_munkres_block(W, ldw, nh, nd, S, assign) != 0 && tid == 0) atomicOr(&D.flags[f], 4u);
   }
+  S1_STAMP(1)  // Hungarian (copy + Munkres)
   // attach or spawn (S3D:636-660)
   bool sp = false;
   int det = -1;
@@ -357,6 +482,7 @@ __global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b) {
     if (nn > H) atomicOr(&D.flags[f], SE3D_FLAG_HYP_OVERFLOW);
     D.nhyp[f] = min(nn, H);
   }
+  S1_STAMP(2)  // attach / spawn
 }
 
 // =============================================================================================================
@@ -876,9 +1002,17 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     hipLaunchKernelGGL(se3d_k_pairs_flat, dim3(blocks), dim3(256), 0, st, D, pair_ab);
   }
   if (ev) (void)hipEventRecord(ev[2], st);
+  // Munkres working matrix in LDS when H*P doubles fit next to the static LDS of the kernel (<= 128 KB)
+  int dynW = (int)((size_t)H * P * sizeof(double));
+  if (dynW > 128 * 1024) dynW = 128 * 1024;
+  static bool assign_attr = false;
+  if (!assign_attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_assign), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    assign_attr = true;
+  }
   for (int b = 0; b < N; ++b) {
     if (b > 0) hipLaunchKernelGGL(se3d_k_sweep_cost, dim3(H, B), dim3(128), 0, st, D, b);
-    hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), 0, st, D, b);
+    hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), (size_t)dynW, st, D, b, dynW);
   }
   if (ev) (void)hipEventRecord(ev[3], st);
   const size_t lds = (size_t)4 * 15 * N * sizeof(float);

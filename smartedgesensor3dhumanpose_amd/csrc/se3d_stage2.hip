@@ -82,7 +82,8 @@ __device__ void s2_remove_old(const Se3dStage2 &Q, int s, double t, int *wsum, i
 // =============================================================================================================
 // rows Y + A2 — track <-> detection association (PP:513-580).  One workgroup per sequence.
 // =============================================================================================================
-__global__ __launch_bounds__(256) void se3d_k_track_assoc(Se3dStage2 Q) {
+__global__ __launch_bounds__(256) void se3d_k_track_assoc(Se3dStage2 Q, int dyn_lds_bytes) {
+  extern __shared__ __align__(16) double s2_dynW[];  // Munkres working matrix when it fits, else HBM workspace
   const int s = blockIdx.x + Q.seq0, tid = threadIdx.x;
   const int T = Q.T, H = Q.H, N = Q.N;
   __shared__ MunkresShared MS;
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(256) void se3d_k_track_assoc(Se3dStage2 Q) {
   const int nt = Q.n_tracks[s];
   int *order = Q.order + (size_t)s * T;
   const se3d_person3d *dets = Q.dets + (size_t)s * H;
-  double *C = Q.C + (size_t)s * H * T, *W = Q.W + (size_t)s * H * T;
+  const bool w_in_lds = (size_t)nd * nt * sizeof(double) <= (size_t)dyn_lds_bytes;
+  double *C = Q.C + (size_t)s * H * T, *W = w_in_lds ? s2_dynW : Q.W + (size_t)s * H * T;
   for (int idx = tid; idx < nd * nt; idx += 256) {  // calc_normed_dist (PP:84-101)
     const int det = idx % nd, tk = idx / nd;
     const size_t sl = (size_t)s * T + order[tk];
@@ -1151,12 +1153,15 @@ extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipS
   if (lm_mode < 0) {
     const char *e = getenv("SE3D_LM");  // A/B evidence switch: dense | schur | tree (default)
     lm_mode = (e && strcmp(e, "dense") == 0) ? 0 : (e && strcmp(e, "schur") == 0) ? 1 : 2;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_track_assoc), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmLds));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmSchurLds));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmSchurLds));
   }
   if (ev) (void)hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(se3d_k_track_assoc, dim3(nseq), dim3(256), 0, st, q);
+  int dynW = (int)((size_t)q.H * q.T * sizeof(double));
+  if (dynW > 128 * 1024) dynW = 128 * 1024;
+  hipLaunchKernelGGL(se3d_k_track_assoc, dim3(nseq), dim3(256), (size_t)dynW, st, q, dynW);
   if (ev) (void)hipEventRecord(ev[1], st);
   if (lm_mode == 0) hipLaunchKernelGGL(se3d_k_lm_refine<0>, dim3(q.H, nseq), dim3(64), sizeof(LmLds), st, q);
   else if (lm_mode == 1) hipLaunchKernelGGL(se3d_k_lm_refine<1>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);

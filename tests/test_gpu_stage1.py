@@ -194,3 +194,27 @@ def test_stage1_parity_ellipse_64cam_32p(oracle, demo_params):
     print("64x32: persons", g.n_persons, "hyps", g.n_hyp, st)
     assert g.n_persons >= 28
     node.close()
+
+
+def test_tiled_pair_kernel_equals_flat_kernel_bitwise_large(oracle, monkeypatch):
+    """The tiled kernel's shared-reciprocal (Markstein) division must reproduce the IEEE-divide kernel bit for bit:
+    every entry of the pair table for a crowded 24-camera scene (tens of thousands of pair costs, ~1e6 divisions)."""
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
+    rig = R.elliptical_rig(24, seed=4)
+    rig.set_tensors(*rig_tensors(rig))
+    frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=40, n_frames=1, seed=9, min_coverage=6, spacing=0.8))
+    tabs = {}
+    for mode in ("flat", "tiled"):
+        monkeypatch.setenv("SE3D_PAIRS", mode)
+        node = _node(rig, max_frames=1, max_det_per_cam=48, max_hyp=96)
+        node.stage(frames)
+        node.run_stage1()
+        node.sync()
+        tabs[mode] = [_pair_costs(node, 0, a, b) for a in range(0, 24, 3) for b in range(a + 1, 24, 2)]
+        node.close()
+    n = 0
+    for (tf, na, nb), (tt, na2, nb2) in zip(tabs["flat"], tabs["tiled"]):
+        assert (na, nb) == (na2, nb2)
+        assert np.array_equal(tf[:na, :nb], tt[:na, :nb])
+        n += na * nb
+    assert n > 30000
