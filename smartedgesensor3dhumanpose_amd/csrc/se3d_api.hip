@@ -263,6 +263,7 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     ok = ok && dev_alloc(c, &Q.used, S * T) && dev_alloc(c, &Q.id, S * T) && dev_alloc(c, &Q.num_obs, S * T) && dev_alloc(c, &Q.has, S * T);
     ok = ok && dev_alloc(c, &Q.trk_t_prev, S * T) && dev_alloc(c, &Q.height_prev, S * T) && dev_alloc(c, &Q.root_prev, S * T * 3);
     ok = ok && dev_alloc(c, &Q.prev, S * T * SE3D_NFU * 3) && dev_alloc(c, &Q.vel, S * T * SE3D_NFU * 9);
+    ok = ok && dev_alloc(c, &Q.near, S * T * 4);
     ok = ok && dev_alloc(c, &Q.C, S * H * T) && dev_alloc(c, &Q.W, S * H * T) && dev_alloc(c, &Q.det_slot, S * H) && dev_alloc(c, &Q.pub, S * H);
     ok = ok && dev_alloc(c, &Q.fused_det, S * H) && dev_alloc(c, &Q.pred_det, S * H) && dev_alloc(c, &Q.iters_det, S * H);
     ok = ok && dev_alloc(c, &Q.fused, S * H) && dev_alloc(c, &Q.pred, S * H) && dev_alloc(c, &Q.iters, S * H) && dev_alloc(c, &Q.n_out, S);

@@ -116,6 +116,7 @@ struct Se3dStage2 {
   // per-call work
   double *C;            // [S][H*T] cost matrix (rows = detections), column-major ld = n_det
   double *W;            // [S][H*T] Munkres working copy
+  unsigned long long *near;  // [S][T][4] bit j of row i: tracks in slots i, j are closer than g_merge_dist_thresh (PP:872)
   int32_t *det_slot;    // [S][H] track slot of each detection (-1: none)
   uint8_t *pub;         // [S][H] publish flag of each detection
   se3d_person3d *fused_det;  // [S][H] per detection

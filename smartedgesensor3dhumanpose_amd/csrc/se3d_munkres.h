@@ -23,52 +23,122 @@ struct MunkresShared {
   short primeCol[SE3D_MUNKRES_MAX];
   unsigned long long covR[4], covC[4];
   double red[4];
+  short crow[SE3D_MUNKRES_MAX];  // step 5: compacted lists of covered rows / covered columns / uncovered columns
+  short ccol[SE3D_MUNKRES_MAX];
+  short ucol[SE3D_MUNKRES_MAX];
+  int ncrow, nccol, nucol;
   int state;  // 0: run step 5 and continue, 1: finished, 2: aborted (iteration guard)
 };
 
 #define SE3D_DBL_EPSILON 2.2204460492503131e-16
 
+#ifdef SE3D_LM_STAMPS  // diagnostic build only
+__device__ unsigned long long g_mk_stamps[16];
+#define MK_ADD(idx, v) if (threadIdx.x == 0) atomicAdd(&g_mk_stamps[idx], (unsigned long long)(v));
+#define MK_CLK() __builtin_readcyclecounter()
+#else
+#define MK_ADD(idx, v)
+#define MK_CLK() 0ull
+#endif
+
 __device__ __forceinline__ int se3d_first_bit4(unsigned long long a0, unsigned long long a1, unsigned long long a2, unsigned long long a3) {
-  if (a0) return __ffsll((long long)a0) - 1;
-  if (a1) return 64 + __ffsll((long long)a1) - 1;
-  if (a2) return 128 + __ffsll((long long)a2) - 1;
-  if (a3) return 192 + __ffsll((long long)a3) - 1;
-  return -1;
+  const int f0 = __ffsll((long long)a0) - 1, f1 = 63 + __ffsll((long long)a1), f2 = 127 + __ffsll((long long)a2), f3 = 191 + __ffsll((long long)a3);
+  return a0 ? f0 : (a1 ? f1 : (a2 ? f2 : (a3 ? f3 : -1)));  // selects, no branches
+}
+
+// 64-row chunk q of the column-major matrix: column c = q / nw, row word w = q % nw (nw = ceil(nR / 64) <= 4).
+// Branch-free on purpose: scalar branches per chunk would serialise the loads of the step-5 loops.
+__device__ __forceinline__ void se3d_mk_chunk(int q, int nw, unsigned inv, int &c, int &w) {
+  c = (int)(((unsigned)q * inv) >> 16);  // inv = ceil(65536 / nw): exact for q < 32768
+  w = q - c * nw;
+}
+__device__ __forceinline__ unsigned long long se3d_mk_word(const unsigned long long m[4], int w) {
+  return (m[0] & (0ull - (unsigned long long)(w == 0))) | (m[1] & (0ull - (unsigned long long)(w == 1))) |
+         (m[2] & (0ull - (unsigned long long)(w == 2))) | (m[3] & (0ull - (unsigned long long)(w == 3)));
 }
 
 // returns 0 on success, 2 if the iteration guard fired.  assignment[r] = column or -1, r < nR.
-__device__ int se3d_munkres_block(double *dist, int ld, int nR, int nC, MunkresShared &S, int *assignment) {
+// Force-inlined so that each call site is specialised for the address space of `dist` (LDS when the matrix fits, else HBM).
+__device__ __forceinline__ int se3d_munkres_block(double *dist, int ld, int nR, int nC, MunkresShared &S, int *assignment) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (nR <= 0 || nC <= 0) return 0;
   const int minDim = nR <= nC ? nR : nC;
+  const int nw = (nR + 63) >> 6;      // row words in use
 
-  // ---- preliminary reduction (HUN:94-119 / 132-154) ----
+  unsigned long long mk_t0 = MK_CLK();
+  (void)mk_t0;
+  MK_ADD(0, 1)
+  for (int i = tid; i < SE3D_MUNKRES_MAX; i += 256) { S.starCol[i] = -1; S.starRow[i] = -1; S.primeCol[i] = -1; }
+  for (int i = tid; i < SE3D_MUNKRES_MAX * 4; i += 256) (&S.zm[0][0])[i] = 0ull;
+  __syncthreads();
+  // ---- preliminary reduction (HUN:94-119 / 132-154) fused with the zero-mask build ----
   if (nR <= nC) {
-    for (int r = tid; r < nR; r += 256) {
-      double mn = dist[r];
-      for (int c = 1; c < nC; ++c) { double v = dist[r + (size_t)ld * c]; if (v < mn) mn = v; }
-      for (int c = 0; c < nC; ++c) dist[r + (size_t)ld * c] -= mn;
+    // thread r owns row r (nR <= 256): lanes of wave w hold rows 64w..64w+63, so a ballot over a column is a mask word
+    const int r = tid;
+    const bool act = r < nR;
+    double mn = 1.7976931348623157e308;
+    if (act) {
+      int c = 0;
+      for (; c + 4 <= nC; c += 4) {
+        const double v0 = dist[r + (size_t)ld * c], v1 = dist[r + (size_t)ld * (c + 1)], v2 = dist[r + (size_t)ld * (c + 2)], v3 = dist[r + (size_t)ld * (c + 3)];
+        if (v0 < mn) mn = v0;
+        if (v1 < mn) mn = v1;
+        if (v2 < mn) mn = v2;
+        if (v3 < mn) mn = v3;
+      }
+      for (; c < nC; ++c) { const double v = dist[r + (size_t)ld * c]; if (v < mn) mn = v; }
+    }
+    if (wave < nw) {
+      for (int c = 0; c < nC; ++c) {
+        double v = 0.0;
+        if (act) { v = dist[r + (size_t)ld * c] - mn; dist[r + (size_t)ld * c] = v; }
+        const unsigned long long m = __ballot(act && fabs(v) < SE3D_DBL_EPSILON);
+        if (lane == 0) S.zm[c][wave] = m;
+      }
     }
   } else {
-    for (int c = wave; c < nC; c += 4) {
-      double mn = 1.7976931348623157e308;
-      for (int r = lane; r < nR; r += 64) { double v = dist[r + (size_t)ld * c]; if (v < mn) mn = v; }
-      for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(mn, o); if (t < mn) mn = t; }
-      for (int r = lane; r < nR; r += 64) dist[r + (size_t)ld * c] -= mn;
+    // wave per column, two columns in flight
+    for (int c0 = wave; c0 < nC; c0 += 8) {
+      const int c1 = c0 + 4;
+      const bool has1 = c1 < nC;
+      double v0[4], v1[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int r = w * 64 + lane;
+        v0[w] = (w < nw && r < nR) ? dist[r + (size_t)ld * c0] : 1.7976931348623157e308;
+        v1[w] = (has1 && w < nw && r < nR) ? dist[r + (size_t)ld * c1] : 1.7976931348623157e308;
+      }
+      double m0 = v0[0], m1 = v1[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { if (v0[w] < m0) m0 = v0[w]; if (v1[w] < m1) m1 = v1[w]; }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double t0 = __shfl_xor(m0, o), t1 = __shfl_xor(m1, o);
+        if (t0 < m0) m0 = t0;
+        if (t1 < m1) m1 = t1;
+      }
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w < nw) {
+          const int r = w * 64 + lane;
+          const bool in = r < nR;
+          const double a0 = v0[w] - m0;
+          if (in) dist[r + (size_t)ld * c0] = a0;
+          const unsigned long long b0 = __ballot(in && fabs(a0) < SE3D_DBL_EPSILON);
+          if (lane == 0) S.zm[c0][w] = b0;
+          if (has1) {
+            const double a1 = v1[w] - m1;
+            if (in) dist[r + (size_t)ld * c1] = a1;
+            const unsigned long long b1 = __ballot(in && fabs(a1) < SE3D_DBL_EPSILON);
+            if (lane == 0) S.zm[c1][w] = b1;
+          }
+        }
+      }
     }
   }
-  for (int i = tid; i < SE3D_MUNKRES_MAX; i += 256) { S.starCol[i] = -1; S.starRow[i] = -1; S.primeCol[i] = -1; }
-  __syncthreads();
-  // zero masks
-  for (int c = wave; c < nC; c += 4)
-    for (int w = 0; w < 4; ++w) {
-      int r = w * 64 + lane;
-      bool z = (r < nR) && (fabs(dist[r + (size_t)ld * c]) < SE3D_DBL_EPSILON);
-      unsigned long long m = __ballot(z);
-      if (lane == 0) S.zm[c][w] = m;
-    }
   __syncthreads();
 
+  MK_ADD(1, MK_CLK() - mk_t0)  // reduction + zero masks
+  mk_t0 = MK_CLK();
   unsigned long long covR[4] = {0, 0, 0, 0}, covC[4] = {0, 0, 0, 0};
   unsigned long long zr[4][4];
   bool first = true;
@@ -104,18 +174,25 @@ __device__ int se3d_munkres_block(double *dist, int ld, int nR, int nC, MunkresS
             }
           }
         } else {
-          for (int c = 0; c < nC; ++c) {
-            unsigned long long m0 = S.zm[c][0] & ~covR[0], m1 = S.zm[c][1] & ~covR[1], m2 = S.zm[c][2] & ~covR[2], m3 = S.zm[c][3] & ~covR[3];
-            int r = se3d_first_bit4(m0, m1, m2, m3);
-            if (r >= 0) {
-              if (lane == 0) { S.starCol[r] = (short)c; S.starRow[c] = (short)r; }
-              covC[c >> 6] |= 1ull << (c & 63);
-              covR[r >> 6] |= 1ull << (r & 63);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            for (int cc = 0; cc < 64 && s * 64 + cc < nC; ++cc) {
+              const int c = s * 64 + cc;
+              const int rloc = se3d_first_bit4(zr[s][0] & ~covR[0], zr[s][1] & ~covR[1], zr[s][2] & ~covR[2], zr[s][3] & ~covR[3]);
+              const int r = __shfl(rloc, cc);  // lane cc owns column c
+              if (r >= 0) {
+                if (lane == 0) { S.starCol[r] = (short)c; S.starRow[c] = (short)r; }
+                covC[s] |= 1ull << cc;
+                const unsigned long long rb = 1ull << (r & 63);
+                const int rw = r >> 6;
+                covR[0] |= (rw == 0) ? rb : 0ull; covR[1] |= (rw == 1) ? rb : 0ull; covR[2] |= (rw == 2) ? rb : 0ull; covR[3] |= (rw == 3) ? rb : 0ull;
+              }
             }
           }
           covR[0] = covR[1] = covR[2] = covR[3] = 0ull;
         }
       }
+      MK_ADD(7, MK_CLK() - mk_t0)  // zr reload + initial starring (first phase only)
       // ---- step 2b / 3 / 4 loop (HUN:245-363) ----
       int st = -1;
       bool need2b = true;
@@ -152,15 +229,21 @@ __device__ int se3d_munkres_block(double *dist, int ld, int nR, int nC, MunkresS
           st = 0;  // step 5
           break;
         }
+        MK_ADD(5, 1)  // step-3 events
         // prime the zero (rf, cf)
         if (lane == 0) S.primeCol[rf] = (short)cf;
         int sc = S.starCol[rf];
         if (sc >= 0) {
-          covR[rf >> 6] |= 1ull << (rf & 63);
-          covC[sc >> 6] &= ~(1ull << (sc & 63));
+          {  // 4-way selects instead of covR[rf >> 6] / covC[sc >> 6]: dynamic indexing would put the masks in scratch
+            const unsigned long long rb = 1ull << (rf & 63), cb = ~(1ull << (sc & 63));
+            const int rw = rf >> 6, cw = sc >> 6;
+            covR[0] |= (rw == 0) ? rb : 0ull; covR[1] |= (rw == 1) ? rb : 0ull; covR[2] |= (rw == 2) ? rb : 0ull; covR[3] |= (rw == 3) ? rb : 0ull;
+            covC[0] &= (cw == 0) ? cb : ~0ull; covC[1] &= (cw == 1) ? cb : ~0ull; covC[2] &= (cw == 2) ? cb : ~0ull; covC[3] &= (cw == 3) ? cb : ~0ull;
+          }
           zerosFound = true;
           cur = cf;
         } else {
+          MK_ADD(6, 1)  // augmentations
           // step 4: augment along the alternating path
           int row = rf, col = cf;
           for (int it = 0; it < 2 * SE3D_MUNKRES_MAX + 2; ++it) {
@@ -189,40 +272,82 @@ __device__ int se3d_munkres_block(double *dist, int ld, int nR, int nC, MunkresS
     }
     __syncthreads();
     const int st = S.state;
+    MK_ADD(2, MK_CLK() - mk_t0)  // serial phase (wave 0)
+    mk_t0 = MK_CLK();
     if (st != 0) break;
-    // ---- step 5 (HUN:366-397) on all waves ----
-    unsigned long long cR[4] = {S.covR[0], S.covR[1], S.covR[2], S.covR[3]};
-    double h = 1.7976931348623157e308;  // DBL_MAX
-    for (int c = wave; c < nC; c += 4) {
-      if ((S.covC[c >> 6] >> (c & 63)) & 1ull) continue;
+    MK_ADD(3, 1)  // step-5 passes
+    // ---- step 5 (HUN:366-397) on all waves.  Only elements that change are touched (bit-identical to the full sweep):
+    //   uncovered columns: every row  (v + h[row covered]) - h      -> zero-mask word rebuilt by ballot
+    //   covered columns  : covered rows only  v + h                 -> single zero-mask bits updated
+    const unsigned long long cR[4] = {S.covR[0], S.covR[1], S.covR[2], S.covR[3]};
+    const unsigned long long cC[4] = {S.covC[0], S.covC[1], S.covC[2], S.covC[3]};
+    if (wave < 3) {  // compacted lists: wave 0 covered rows, wave 1 covered columns, wave 2 uncovered columns
+      int base = 0;
+#pragma unroll
       for (int w = 0; w < 4; ++w) {
-        int r = w * 64 + lane;
-        if (r < nR && !((cR[w] >> lane) & 1ull)) { double v = dist[r + (size_t)ld * c]; if (v < h) h = v; }
+        const int idx = w * 64 + lane;
+        const unsigned long long m = (wave == 0) ? cR[w] : (wave == 1) ? cC[w] : ~cC[w];
+        const int lim = (wave == 0) ? nR : nC;
+        const unsigned long long mv = __ballot(((m >> lane) & 1ull) && idx < lim);
+        if ((mv >> lane) & 1ull) {
+          const int pos = base + __popcll(mv & ((1ull << lane) - 1ull));
+          if (wave == 0) S.crow[pos] = (short)idx;
+          else if (wave == 1) S.ccol[pos] = (short)idx;
+          else S.ucol[pos] = (short)idx;
+        }
+        base += __popcll(mv);
       }
+      if (lane == 0) { if (wave == 0) S.ncrow = base; else if (wave == 1) S.nccol = base; else S.nucol = base; }
+    }
+    __syncthreads();
+    const int ncr = S.ncrow, ncc = S.nccol, nuc = S.nucol;
+    const int nuch = nuc * nw;  // 64-row chunks of the uncovered columns
+    const unsigned inv = (65536u + (unsigned)nw - 1u) / (unsigned)nw;
+    double h = 1.7976931348623157e308;  // DBL_MAX
+    for (int q = wave; q < nuch; q += 4) {
+      int ci, w;
+      se3d_mk_chunk(q, nw, inv, ci, w);
+      const int c = S.ucol[ci], r = w * 64 + lane;
+      const bool ok = (r < nR) && !((se3d_mk_word(cR, w) >> lane) & 1ull);
+      const double t = ok ? dist[(r < nR ? r : nR - 1) + ld * c] : 1.7976931348623157e308;
+      h = t < h ? t : h;
     }
     for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(h, o); if (t < h) h = t; }
     if (lane == 0) S.red[wave] = h;
     __syncthreads();
     h = S.red[0];
     for (int w = 1; w < 4; ++w) if (S.red[w] < h) h = S.red[w];
-    for (int c = wave; c < nC; c += 4) {
-      const bool cc = (S.covC[c >> 6] >> (c & 63)) & 1ull;
-      for (int w = 0; w < 4; ++w) {
-        int r = w * 64 + lane;
-        bool z = false;
-        if (r < nR) {
-          double v = dist[r + (size_t)ld * c];
-          const bool rc = (cR[w] >> lane) & 1ull;
-          if (rc) v = v + h;    // "add h to each covered row"
-          if (!cc) v = v - h;   // "subtract h from each uncovered column"
-          if (rc || !cc) dist[r + (size_t)ld * c] = v;
-          z = fabs(v) < SE3D_DBL_EPSILON;
+    // uncovered columns: "add h to each covered row", then "subtract h from each uncovered column"
+    for (int q = wave; q < nuch; q += 4) {
+      int ci, w;
+      se3d_mk_chunk(q, nw, inv, ci, w);
+      const int c = S.ucol[ci], r = w * 64 + lane;
+      const bool in = r < nR;
+      const double x = (dist[(in ? r : nR - 1) + ld * c] + (((se3d_mk_word(cR, w) >> lane) & 1ull) ? h : 0.0)) - h;
+      if (in) dist[r + ld * c] = x;
+      const unsigned long long m = __ballot(in && (fabs(x) < SE3D_DBL_EPSILON));
+      if (lane == 0) S.zm[c][w] = m;
+    }
+    // covered columns change only at covered rows: "add h to each covered row"; items = (covered row, covered column)
+    {
+      int lg = 0;
+      while ((1 << lg) < ncr) ++lg;            // rows per group: R = 2^lg >= ncr
+      const int R = 1 << lg, i = tid & (R - 1), j0 = tid >> lg, jstep = 256 >> lg;
+      if (i < ncr && jstep > 0) {
+        const int r = S.crow[i];
+        const unsigned long long bit = 1ull << (r & 63);
+        for (int j = j0; j < ncc; j += jstep) {
+          const int c = S.ccol[j];
+          const double x = dist[r + ld * c] + h;
+          dist[r + ld * c] = x;
+          if (fabs(x) < SE3D_DBL_EPSILON) atomicOr(&S.zm[c][r >> 6], bit);
+          else atomicAnd(&S.zm[c][r >> 6], ~bit);
         }
-        unsigned long long m = __ballot(z);
-        if (lane == 0) S.zm[c][w] = m;
       }
     }
     __syncthreads();
+    MK_ADD(4, MK_CLK() - mk_t0)  // step-5 cycles
+    mk_t0 = MK_CLK();
   }
   const int fin = S.state;
   for (int r = tid; r < nR; r += 256) assignment[r] = S.starCol[r];  // buildassignmentvector (HUN:190-205)

@@ -20,6 +20,11 @@ __device__ unsigned long long g_s1_stamps[16];
   }
 #define S1_STAMP_INIT unsigned long long s1_prev_ = __builtin_readcyclecounter();
 #define S1_COUNT(idx) if (threadIdx.x == 0) atomicAdd(&g_s1_stamps[idx], 1ull);
+extern "C" void se3d_diag_mk_stamps(unsigned long long *out16, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mk_stamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mk_stamps), z, sizeof(z)); }
+}
 extern "C" void se3d_diag_s1_stamps(unsigned long long *out16, int reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_s1_stamps), sizeof(unsigned long long) * 16);
@@ -441,12 +446,20 @@ __global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b, int
     S1_COUNT(9)
     const double *C = D.C + (size_t)f * H * P;
     const bool in_lds = (size_t)nh * nd * sizeof(double) <= (size_t)dyn_lds_bytes;
-    double *W = in_lds ? s_dynW : D.mwork + (size_t)f * H * P;
-    const int ldw = in_lds ? nh : H;
-    for (int q = 0; q < nd; ++q)
-      for (int h = tid; h < nh; h += 256) W[h + (size_t)ldw * q] = C[h + (size_t)H * q];
-    __syncthreads();
-    if (se3d_munkres_block(W, ldw, nh, nd, S, assign) != 0 && tid == 0) atomicOr(&D.flags[f], 4u);
+    int rc;
+    if (in_lds) {  // working matrix in LDS (ds_* addressing)
+      for (int q = 0; q < nd; ++q)
+        for (int h = tid; h < nh; h += 256) s_dynW[h + nh * q] = C[h + (size_t)H * q];
+      __syncthreads();
+      rc = se3d_munkres_block(s_dynW, nh, nh, nd, S, assign);
+    } else {       // too large: HBM workspace
+      double *W = D.mwork + (size_t)f * H * P;
+      for (int q = 0; q < nd; ++q)
+        for (int h = tid; h < nh; h += 256) W[h + (size_t)H * q] = C[h + (size_t)H * q];
+      __syncthreads();
+      rc = se3d_munkres_block(W, H, nh, nd, S, assign);
+    }
+    if (rc != 0 && tid == 0) atomicOr(&D.flags[f], 4u);
   }
   S1_STAMP(1)  // Hungarian (copy + Munkres)
   // attach or spawn (S3D:636-660)

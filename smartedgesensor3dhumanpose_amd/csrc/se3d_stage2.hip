@@ -80,6 +80,81 @@ __device__ void s2_remove_old(const Se3dStage2 &Q, int s, double t, int *wsum, i
 }
 
 // =============================================================================================================
+// row Y — calc_normed_dist (PP:84-101) for every (detection, track): one workgroup per (track, sequence), threads over
+// detections; the track's previous estimate is de-normalised once into LDS.  C is column-major [det + n_det * track].
+// =============================================================================================================
+__global__ __launch_bounds__(128) void se3d_k_track_cost(Se3dStage2 Q) {
+  const int tk = blockIdx.x, s = blockIdx.y + Q.seq0, tid = threadIdx.x;
+  const int T = Q.T, H = Q.H;
+  const int nd = min(Q.n_det[s], H), nt = Q.n_tracks[s];
+  if (nd == 0 || tk >= nt) return;
+  __shared__ double pp[SE3D_NFU][3];
+  __shared__ double wgt[SE3D_NFU];
+  const size_t sl = (size_t)s * T + Q.order[(size_t)s * T + tk];
+  const uint32_t has = Q.has[sl];
+  const double delta_t = Q.t[s] - Q.trk_t_prev[sl];
+  if (tid < SE3D_NFU * 3) {
+    const int k = tid / 3, a = tid - 3 * k;
+    pp[k][a] = Q.prev[(sl * SE3D_NFU + k) * 3 + a] * Q.height_prev[sl] + Q.root_prev[sl * 3 + a];
+    if (a == 0) wgt[k] = c_vel_sigmas[k] * delta_t;
+  }
+  __syncthreads();
+  const se3d_person3d *dets = Q.dets + (size_t)s * H;
+  double *C = Q.C + (size_t)s * H * T;
+  for (int det = tid; det < nd; det += blockDim.x) {
+    int nj = 0;
+    double dist = 0.0;
+    for (int k = 0; k < SE3D_NFU; ++k) {
+      const se3d_keypoint3d &kp = dets[det].keypoints[k];
+      if (kp.score > 0.10f && ((has >> k) & 1u)) {
+        const double dx = kp.joint[0] - pp[k][0], dy = kp.joint[1] - pp[k][1], dz = kp.joint[2] - pp[k][2];
+        dist += sqrt(dx * dx + dy * dy + dz * dz) / wgt[k];
+        ++nj;
+      }
+    }
+    C[det + (size_t)nd * tk] = nj > 0 ? dist / nj : 1e6;
+  }
+}
+
+// row L (distance part) — calc_3d_dist (PP:103-119) between every pair of live tracks of a sequence, as a bit matrix over
+// track slots.  Merging never modifies the surviving track (PP:872-876), so all tests can be evaluated up front.
+__global__ __launch_bounds__(64) void se3d_k_track_near(Se3dStage2 Q) {
+  const int si = blockIdx.x, s = blockIdx.y + Q.seq0, lane = threadIdx.x;
+  const int T = Q.T;
+  if (min(Q.n_det[s], Q.H) == 0) return;
+  const size_t sli = (size_t)s * T + si;
+  unsigned long long *row = Q.near + sli * 4;
+  if (!Q.used[sli]) { if (lane < 4) row[lane] = 0ull; return; }
+  __shared__ double pi[SE3D_NFU][3];
+  const uint32_t hasi = Q.has[sli];
+  if (lane < SE3D_NFU)
+    for (int a = 0; a < 3; ++a) pi[lane][a] = Q.prev[(sli * SE3D_NFU + lane) * 3 + a] * Q.height_prev[sli] + Q.root_prev[sli * 3 + a];
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    const int sj = w * 64 + lane;
+    bool nr = false;
+    if (sj < T && sj != si && Q.used[(size_t)s * T + sj]) {
+      const size_t slj = (size_t)s * T + sj;
+      const uint32_t both = hasi & Q.has[slj];
+      const double hj = Q.height_prev[slj];
+      int nj = 0;
+      double dist = 0.0;
+      for (int k = 0; k < SE3D_NFU; ++k)
+        if ((both >> k) & 1u) {
+          const double dx = pi[k][0] - (Q.prev[(slj * SE3D_NFU + k) * 3 + 0] * hj + Q.root_prev[slj * 3 + 0]);
+          const double dy = pi[k][1] - (Q.prev[(slj * SE3D_NFU + k) * 3 + 1] * hj + Q.root_prev[slj * 3 + 1]);
+          const double dz = pi[k][2] - (Q.prev[(slj * SE3D_NFU + k) * 3 + 2] * hj + Q.root_prev[slj * 3 + 2]);
+          dist += sqrt(dx * dx + dy * dy + dz * dz);
+          ++nj;
+        }
+      nr = (nj > 0 ? dist / nj : 1e6) < 0.20;
+    }
+    const unsigned long long b = __ballot(nr);
+    if (lane == 0) row[w] = b;
+  }
+}
+
+// =============================================================================================================
 // rows Y + A2 — track <-> detection association (PP:513-580).  One workgroup per sequence.
 // =============================================================================================================
 __global__ __launch_bounds__(256) void se3d_k_track_assoc(Se3dStage2 Q, int dyn_lds_bytes) {
@@ -114,34 +189,17 @@ __global__ __launch_bounds__(256) void se3d_k_track_assoc(Se3dStage2 Q, int dyn_
   }
   const int nt = Q.n_tracks[s];
   int *order = Q.order + (size_t)s * T;
-  const se3d_person3d *dets = Q.dets + (size_t)s * H;
   const bool w_in_lds = (size_t)nd * nt * sizeof(double) <= (size_t)dyn_lds_bytes;
-  double *C = Q.C + (size_t)s * H * T, *W = w_in_lds ? s2_dynW : Q.W + (size_t)s * H * T;
-  for (int idx = tid; idx < nd * nt; idx += 256) {  // calc_normed_dist (PP:84-101)
-    const int det = idx % nd, tk = idx / nd;
-    const size_t sl = (size_t)s * T + order[tk];
-    const double delta_t = t - Q.trk_t_prev[sl];
-    const double hp = Q.height_prev[sl];
-    const double *rp = Q.root_prev + sl * 3, *pv = Q.prev + sl * SE3D_NFU * 3;
-    const uint32_t has = Q.has[sl];
-    int nj = 0;
-    double dist = 0.0;
-    for (int k = 0; k < SE3D_NFU; ++k) {
-      const se3d_keypoint3d &kp = dets[det].keypoints[k];
-      if (kp.score > 0.10f && ((has >> k) & 1u)) {
-        const double px = pv[k * 3 + 0] * hp + rp[0], py = pv[k * 3 + 1] * hp + rp[1], pz = pv[k * 3 + 2] * hp + rp[2];
-        const double dx = kp.joint[0] - px, dy = kp.joint[1] - py, dz = kp.joint[2] - pz;
-        dist += sqrt(dx * dx + dy * dy + dz * dz) / (c_vel_sigmas[k] * delta_t);
-        ++nj;
-      }
-    }
-    const double c = nj > 0 ? dist / nj : 1e6;
-    C[idx] = c;
-    W[idx] = c;
-  }
+  double *C = Q.C + (size_t)s * H * T, *Wg = Q.W + (size_t)s * H * T;
+  // C from se3d_k_track_cost; Munkres works on a copy (LDS when it fits, else HBM)
+  if (w_in_lds) { for (int idx = tid; idx < nd * nt; idx += 256) s2_dynW[idx] = C[idx]; }
+  else { for (int idx = tid; idx < nd * nt; idx += 256) Wg[idx] = C[idx]; }
   __syncthreads();
   if (nt > 0) {
-    if (se3d_munkres_block(W, nd, nd, nt, MS, assign) != 0 && tid == 0) atomicOr(&Q.flags2[s], 4u);
+    int rc;
+    if (w_in_lds) rc = se3d_munkres_block(s2_dynW, nd, nd, nt, MS, assign);
+    else rc = se3d_munkres_block(Wg, nd, nd, nt, MS, assign);
+    if (rc != 0 && tid == 0) atomicOr(&Q.flags2[s], 4u);
     if (tid < nd) {  // PP:562-565
       const int a = assign[tid];
       if (a >= 0 && C[tid + (size_t)nd * a] > 5.0) assign[tid] = -1;
@@ -1099,21 +1157,8 @@ __global__ __launch_bounds__(256) void se3d_k_track_update(Se3dStage2 Q) {
     const int j = tid;
     if (j > i && j < nt && alive[j]) {
       const size_t si = (size_t)s * T + order[i], sj = (size_t)s * T + order[j];
-      const uint32_t both = Q.has[si] & Q.has[sj];
-      int nj = 0;
-      double dist = 0.0;
-      for (int k = 0; k < SE3D_NFU; ++k)
-        if ((both >> k) & 1u) {
-          double d2 = 0.0;
-          for (int a = 0; a < 3; ++a) {
-            const double pa = Q.prev[(si * SE3D_NFU + k) * 3 + a] * Q.height_prev[si] + Q.root_prev[si * 3 + a];
-            const double pb2 = Q.prev[(sj * SE3D_NFU + k) * 3 + a] * Q.height_prev[sj] + Q.root_prev[sj * 3 + a];
-            d2 += (pa - pb2) * (pa - pb2);
-          }
-          dist += sqrt(d2);
-          ++nj;
-        }
-      const double dd = nj > 0 ? dist / nj : 1e6;
+      const int slot_j = order[j];
+      const double dd = ((Q.near[si * 4 + (slot_j >> 6)] >> (slot_j & 63)) & 1ull) ? 0.0 : 1.0;  // se3d_k_track_near
       if (dd < 0.20) {
         alive[j] = 0;
         Q.used[sj] = 0;
@@ -1161,12 +1206,14 @@ extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipS
   if (ev) (void)hipEventRecord(ev[0], st);
   int dynW = (int)((size_t)q.H * q.T * sizeof(double));
   if (dynW > 128 * 1024) dynW = 128 * 1024;
+  hipLaunchKernelGGL(se3d_k_track_cost, dim3(q.T, nseq), dim3(128), 0, st, q);
   hipLaunchKernelGGL(se3d_k_track_assoc, dim3(nseq), dim3(256), (size_t)dynW, st, q, dynW);
   if (ev) (void)hipEventRecord(ev[1], st);
   if (lm_mode == 0) hipLaunchKernelGGL(se3d_k_lm_refine<0>, dim3(q.H, nseq), dim3(64), sizeof(LmLds), st, q);
   else if (lm_mode == 1) hipLaunchKernelGGL(se3d_k_lm_refine<1>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
   else hipLaunchKernelGGL(se3d_k_lm_refine<2>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
   if (ev) (void)hipEventRecord(ev[2], st);
+  hipLaunchKernelGGL(se3d_k_track_near, dim3(q.T, nseq), dim3(64), 0, st, q);
   hipLaunchKernelGGL(se3d_k_track_update, dim3(nseq), dim3(256), 0, st, q);
   if (ev) (void)hipEventRecord(ev[3], st);
 }

@@ -16,8 +16,12 @@ node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=4, max_det_per_cam=w["max_
 node.stage(frames)
 L = _lib.lib()
 out = (C.c_ulonglong * 16)()
-node.run_stage1(); node.sync(); L.se3d_diag_s1_stamps(out, 1)
-node.run_stage1(); node.sync(); L.se3d_diag_s1_stamps(out, 1)
+mk = (C.c_ulonglong * 16)()
+node.run_stage1(); node.sync(); L.se3d_diag_s1_stamps(out, 1); L.se3d_diag_mk_stamps(mk, 1)
+node.run_stage1(); node.sync(); L.se3d_diag_s1_stamps(out, 1); L.se3d_diag_mk_stamps(mk, 1)
+m = list(mk); n = max(m[0], 1)
+print("munkres calls %d | per call: reduce+masks %.0f cyc, serial %.0f cyc, step5 passes %.1f (%.0f cyc), step-3 events %.1f, augmentations %.1f, reload+init starring %.0f cyc"
+      % (m[0], m[1] / n, m[2] / n, m[3] / n, m[4] / n, m[5] / n, m[6] / n, m[7] / n))
 v = list(out)
 print("assign blocks that reached the scan:", v[8], "ambiguous (Hungarian ran):", v[9])
 print("cycles per block: scans %.0f, hungarian(avg over all) %.0f, hungarian(avg when run) %.0f, apply %.0f"
