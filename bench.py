@@ -24,9 +24,9 @@ sys.path.insert(0, ROOT)
 T_STEPS = 16  # frames per synthetic sequence (>= 16 frames per sequence)
 WORKLOADS = {
     # bytes/skeleton: SURVEY §8d algorithmic bytes (stage 1) ; stage 2 adds 8.9 KB per skeleton
-    "16cam6p": dict(n_cam=16, n_persons=6, seqs=128, max_det=8, max_hyp=16, bytes_s1=8972, bytes_s2=8900),
-    "64cam32p": dict(n_cam=64, n_persons=32, seqs=8, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900),
-    "256cam128p": dict(n_cam=256, n_persons=128, seqs=1, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900),
+    "16cam6p": dict(n_cam=16, n_persons=6, seqs=128, contexts=3, max_det=8, max_hyp=16, bytes_s1=8972, bytes_s2=8900),
+    "64cam32p": dict(n_cam=64, n_persons=32, seqs=8, contexts=3, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900),
+    "256cam128p": dict(n_cam=256, n_persons=128, seqs=1, contexts=3, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--seqs", type=int, default=0, help="independent sequences per GPU (default: workload preset)")
     ap.add_argument("--tsteps", type=int, default=T_STEPS)
     ap.add_argument("--stage", default="12", choices=["1", "12"], help="1: stage 1 only; 12: stage 1 + stage 2")
+    ap.add_argument("--contexts", type=int, default=0, help="independent se3d contexts (HIP streams) per GPU, each with --seqs sequences; "
+                    "their launches interleave so latency-bound phases of one overlap throughput-bound kernels of the other (default: preset)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -106,10 +108,16 @@ def main():
     B = S_ * T_
     stage2 = args.stage == "12"
     rig = make_rig(w)
-    seqs = make_sequences(rig, w, S_, seed0=1000 * rank, t_steps=T_)  # every rank owns its sequences (weak scaling)
-    frames = [seqs[s][k] for k in range(T_) for s in range(S_)]       # frame slot = k * S + s
-    node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank)
-    node.stage(frames)  # inputs resident in HBM before the timed region
+    NC = args.contexts or w["contexts"]
+    nodes, all_seqs = [], []
+    for ci in range(NC):  # every rank (and every context) owns its own sequences: weak scaling, no data-path collective
+        seqs = make_sequences(rig, w, S_, seed0=1000 * rank + 100 * ci, t_steps=T_)
+        frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s
+        nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank)
+        nd_.stage(frames)  # inputs resident in HBM before the timed region
+        nodes.append(nd_)
+        all_seqs.append(seqs)
+    node, seqs = nodes[0], all_seqs[0]
     dt_frame = 1.0 / 30.0
     clock = {"t": 100.0, "step": 0}
 
@@ -122,29 +130,35 @@ def main():
         gather_c = torch.empty(world * B, dtype=torch.int32, device="cuda")
 
     def step(collect=None):
-        node.run_stage1()
+        for nd_ in nodes:
+            nd_.run_stage1()
         if stage2:
             order = range(T_) if clock["step"] % 2 == 0 else range(T_ - 1, -1, -1)
             for k in order:
                 clock["t"] += dt_frame
-                node.run_stage2(np.full(S_, clock["t"]), frame_slot0=k * S_)
+                for nd_ in nodes:
+                    nd_.run_stage2(np.full(S_, clock["t"]), frame_slot0=k * S_)
                 if collect is not None:
-                    collect.append(sum(r.n_persons for r in node.fetch_stage2(S_)))
+                    collect.append(sum(r.n_persons for nd_ in nodes for r in nd_.fetch_stage2(S_)))
                 if dist is not None:
-                    node.pack_stage2_device(pack.data_ptr(), counts.data_ptr())  # syncs the context stream
-                    dist.all_gather_into_tensor(gather_p, pack)
-                    dist.all_gather_into_tensor(gather_c, counts)
+                    for nd_ in nodes:
+                        nd_.pack_stage2_device(pack.data_ptr(), counts.data_ptr())  # syncs that context's stream
+                        dist.all_gather_into_tensor(gather_p, pack)
+                        dist.all_gather_into_tensor(gather_c, counts)
         elif dist is not None:
-            node.pack_stage1_device(pack.data_ptr(), counts.data_ptr())
-            dist.all_gather_into_tensor(gather_p, pack)
-            dist.all_gather_into_tensor(gather_c, counts)
+            for nd_ in nodes:
+                nd_.pack_stage1_device(pack.data_ptr(), counts.data_ptr())
+                dist.all_gather_into_tensor(gather_p, pack)
+                dist.all_gather_into_tensor(gather_c, counts)
         clock["step"] += 1
 
-    node.refine_reset()
+    for nd_ in nodes:
+        nd_.refine_reset()
     for _ in range(max(args.warmup, 1 if stage2 else 0)):
         step()
-    node.sync()
-    node.profile(True)
+    for nd_ in nodes:
+        nd_.sync()
+    node.profile(True)   # HIP-event kernel timing on context 0 (its kernels overlap with the other contexts' by design)
     node.profile_reset()
     if dist is not None:
         dist.barrier()
@@ -152,7 +166,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    node.sync()
+    for nd_ in nodes:
+        nd_.sync()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -163,7 +178,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     # untimed accounting pass: published skeletons of one (steady-state) step
-    n_s1 = sum(r.n_persons for r in node.fetch_stage1(B))
+    n_s1 = sum(r.n_persons for nd_ in nodes for r in nd_.fetch_stage1(B))
     if stage2:
         per_call = []
         step(collect=per_call)
@@ -184,17 +199,17 @@ def main():
         ms_dom = prof[dom][0] / max(prof[dom][1], 1)              # average duration of one launch (group) of the dominant kernel
         launches_per_step = prof[dom][1] / args.steps
         bytes_per_skel = w["bytes_s1"] if dom in names[:5] else w["bytes_s2"]
-        units_per_launch = n_skel_local / launches_per_step        # skeletons one launch of that kernel processes
+        units_per_launch = n_skel_local / NC / launches_per_step   # skeletons one launch of that kernel processes (context 0)
         achieved = bytes_per_skel * units_per_launch / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
         line = {
             "metric": "3D skeletons/sec (triangulated + refined, per-joint error < 1 mm vs CPU reference path)",
             "value": round(n_skel * args.steps / dt, 2), "unit": "skeletons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 geometry, f64 accumulation/eigen/LM", "data": "synthetic",
-            "config": {"workload": "%s, stage %s, %d sequences x %d frames resident per GPU (%d frames, %d published skeletons per step per GPU; stage-1 persons %d)"
+            "config": {"workload": "%s, stage %s, %d contexts x %d sequences x %d frames resident per GPU (%d frames, %d published skeletons per step per GPU; stage-1 persons %d)"
                                    % (args.workload, "1+2 (association+triangulation+UT covariance, then tracking+LM refinement+marginals)" if stage2 else "1",
-                                      S_, T_, B, n_skel_local, n_s1),
-                       "n_cam": w["n_cam"], "n_persons": w["n_persons"], "n_joints": 17, "frames_per_step": B,
+                                      NC, S_, T_, NC * B, n_skel_local, n_s1),
+                       "n_cam": w["n_cam"], "n_persons": w["n_persons"], "n_joints": 17, "frames_per_step": NC * B, "contexts_per_gpu": NC,
                        "sharding": ("independent sequences per rank + RCCL all-gather of final skeletons" if world > 1 else "single GPU")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(ms_dom, 5),
@@ -207,7 +222,8 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
-    node.close()
+    for nd_ in nodes:
+        nd_.close()
     if dist is not None:
         dist.destroy_process_group()
 
