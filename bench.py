@@ -93,7 +93,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: exercises the exchange path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -122,12 +122,22 @@ def main():
     clock = {"t": 100.0, "step": 0}
 
     H = node.limits.max_hyp
-    if dist is not None:  # exchange buffers: every rank ends up with the final skeletons of all ranks
-        n_slots = S_ if stage2 else B
-        pack = torch.empty(B * H * pm.person3d_dt.itemsize, dtype=torch.uint8, device="cuda")
-        counts = torch.empty(B, dtype=torch.int32, device="cuda")
-        gather_p = torch.empty(world * pack.numel(), dtype=torch.uint8, device="cuda")
-        gather_c = torch.empty(world * B, dtype=torch.int32, device="cuda")
+    psz = pm.person3d_dt.itemsize
+    if dist is not None:
+        # Exchange: one RCCL all-gather of the final skeletons per context and step so that every rank holds the
+        # skeletons of all ranks.  Slots: stage 1+2 -> [T][S] (one block per stage-2 time step), stage 1 only -> [B].
+        n_slots = B
+        packs = [torch.zeros(n_slots * H * psz, dtype=torch.uint8, device="cuda") for _ in nodes]
+        cnts = [torch.zeros(n_slots, dtype=torch.int32, device="cuda") for _ in nodes]
+        gath_p = [torch.empty(world * n_slots * H * psz, dtype=torch.uint8, device="cuda") for _ in nodes]
+        gath_c = [torch.empty(world * n_slots, dtype=torch.int32, device="cuda") for _ in nodes]
+
+    def exchange():
+        torch.cuda.synchronize()           # previous step's collectives are done before their source buffers were rewritten
+        for ci, nd_ in enumerate(nodes):
+            nd_.sync()                     # the asynchronous packs of this context have landed
+            dist.all_gather_into_tensor(gath_p[ci], packs[ci])
+            dist.all_gather_into_tensor(gath_c[ci], cnts[ci])
 
     def step(collect=None):
         for nd_ in nodes:
@@ -136,20 +146,17 @@ def main():
             order = range(T_) if clock["step"] % 2 == 0 else range(T_ - 1, -1, -1)
             for k in order:
                 clock["t"] += dt_frame
-                for nd_ in nodes:
+                for ci, nd_ in enumerate(nodes):
                     nd_.run_stage2(np.full(S_, clock["t"]), frame_slot0=k * S_)
+                    if dist is not None:  # async D2D of this time step's fused skeletons into block k of the exchange buffer
+                        nd_.pack_stage2_device(S_, packs[ci].data_ptr() + k * S_ * H * psz, cnts[ci].data_ptr() + 4 * k * S_)
                 if collect is not None:
                     collect.append(sum(r.n_persons for nd_ in nodes for r in nd_.fetch_stage2(S_)))
-                if dist is not None:
-                    for nd_ in nodes:
-                        nd_.pack_stage2_device(pack.data_ptr(), counts.data_ptr())  # syncs that context's stream
-                        dist.all_gather_into_tensor(gather_p, pack)
-                        dist.all_gather_into_tensor(gather_c, counts)
         elif dist is not None:
-            for nd_ in nodes:
-                nd_.pack_stage1_device(pack.data_ptr(), counts.data_ptr())
-                dist.all_gather_into_tensor(gather_p, pack)
-                dist.all_gather_into_tensor(gather_c, counts)
+            for ci, nd_ in enumerate(nodes):
+                nd_.pack_stage1_device(packs[ci].data_ptr(), cnts[ci].data_ptr())
+        if dist is not None:
+            exchange()
         clock["step"] += 1
 
     for nd_ in nodes:

@@ -171,10 +171,12 @@ int se3d_hungarian(se3d_ctx *ctx, int32_t *assignment, double *cost, const doubl
 int se3d_get_pair_costs(se3d_ctx *ctx, int32_t frame, int32_t cam_a, int32_t cam_b, double *out, int32_t *n_a, int32_t *n_b);
 
 /* --- device-side result access for multi-GPU exchange (RCCL all-gather of final skeletons) -------------
- * Packs the persons of all frames of the last run into a caller-provided DEVICE buffer
- * [n_frames][max_hyp] se3d_person3d plus counts [n_frames] int32 (device pointers, e.g. torch tensors). */
+ * Enqueue, on the context stream, device-to-device copies of the results of the last run into caller-provided DEVICE
+ * memory (e.g. torch tensors): persons as [n][max_hyp] se3d_person3d (valid entries first) and counts as [n] int32,
+ * n = staged frames (stage 1) or n_seq sequences (stage 2, results of the last se3d_run_stage2 call).
+ * ASYNCHRONOUS: call se3d_sync before another stream or the host touches the buffers. */
 int se3d_pack_stage1_device(se3d_ctx *ctx, void *d_persons, void *d_counts);
-int se3d_pack_stage2_device(se3d_ctx *ctx, void *d_persons, void *d_counts);
+int se3d_pack_stage2_device(se3d_ctx *ctx, int32_t n_seq, void *d_persons, void *d_counts);
 
 /* --- measurement: HIP-event timing of the kernels on the context stream -------------------------------- */
 int se3d_profile_enable(se3d_ctx *ctx, int32_t on);

@@ -450,10 +450,9 @@ int se3d_pack_stage1_device(se3d_ctx *c, void *d_persons, void *d_counts) {
   if (!c->ran) return SE3D_ERR_STATE;
   const Se3dDev &D = c->D;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(d_persons, D.outP, sizeof(se3d_person3d) * (size_t)D.d.B * D.d.H, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_counts, D.out_count, sizeof(int32_t) * (size_t)D.d.B, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return SE3D_OK;
+  HIPCHK(c, hipMemcpyAsync(d_persons, D.outP, sizeof(se3d_person3d) * (size_t)c->staged_frames * D.d.H, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_counts, D.out_count, sizeof(int32_t) * (size_t)c->staged_frames, hipMemcpyDeviceToDevice, c->stream));
+  return SE3D_OK;  // asynchronous on the context stream: se3d_sync before another stream / the host reads the buffers
 }
 
 int se3d_hungarian(se3d_ctx *c, int32_t *assignment, double *cost, const double *dist, int32_t nR, int32_t nC) {
@@ -589,15 +588,14 @@ int se3d_fetch_stage2(se3d_ctx *c, int32_t n_seq, se3d_fused_out *outs) {
   return fetch_stage2_range(c, 0, n_seq, outs);
 }
 
-int se3d_pack_stage2_device(se3d_ctx *c, void *d_persons, void *d_counts) {
-  if (!c || !d_persons || !d_counts) return SE3D_ERR_ARG;
+int se3d_pack_stage2_device(se3d_ctx *c, int32_t n_seq, void *d_persons, void *d_counts) {
+  if (!c || !d_persons || !d_counts || n_seq < 1 || n_seq > c->Q.S) return SE3D_ERR_ARG;
   if (!c->ran2) return SE3D_ERR_STATE;
   const Se3dStage2 &Q = c->Q;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(d_persons, Q.fused, sizeof(se3d_person3d) * (size_t)Q.S * Q.H, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_counts, Q.n_out, sizeof(int32_t) * (size_t)Q.S, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return SE3D_OK;
+  HIPCHK(c, hipMemcpyAsync(d_persons, Q.fused, sizeof(se3d_person3d) * (size_t)n_seq * Q.H, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_counts, Q.n_out, sizeof(int32_t) * (size_t)n_seq, hipMemcpyDeviceToDevice, c->stream));
+  return SE3D_OK;  // asynchronous on the context stream (ordered after the se3d_run_stage2 that produced the data)
 }
 
 int se3d_profile_enable(se3d_ctx *c, int32_t on) {

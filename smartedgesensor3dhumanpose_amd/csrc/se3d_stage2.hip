@@ -712,6 +712,56 @@ __device__ void s2_tree_solve(LmSchurLds &L, int K, double lambda, int lane, con
   __builtin_amdgcn_wave_barrier();
 }
 
+// Marginal covariances on the forest (lambda = 0): after the leaf-to-root elimination D~_c is the information of joint c
+// given its parent, so  Sigma_root = D~_root^-1  and  Sigma_cc = D~_c^-1 + u (h^T Sigma_pp h) u^T,  u = D~_c^-1 h  (top-down).
+// Same 3x3 diagonal blocks of (J^T J)^-1 as Marginals::marginalCovariance (PP:789), exact algebra.
+__device__ void s2_tree_marginals(LmSchurLds &L, int K, int lane, const double Av[6], const TreeTopo &tp) {
+  double D[6] = {Av[0], Av[1], Av[2], Av[3], Av[4], Av[5]};
+  double Di[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0}, h[3] = {0, 0, 0};
+  const bool act = lane < K;
+  if (act) {
+    for (unsigned m = L.incA[lane] | L.incB[lane]; m; m &= m - 1) {
+      const int e = __ffs(m) - 1;
+      const double h0 = L.Hs[e][0], h1 = L.Hs[e][1], h2 = L.Hs[e][2];
+      D[0] += h0 * h0; D[1] += h0 * h1; D[2] += h0 * h2; D[3] += h1 * h1; D[4] += h1 * h2; D[5] += h2 * h2;
+    }
+    if (tp.pedge >= 0) { h[0] = L.Hs[tp.pedge][0]; h[1] = L.Hs[tp.pedge][1]; h[2] = L.Hs[tp.pedge][2]; }
+  }
+  for (int lv = tp.maxlev; lv >= 1; --lv) {
+    if (act && tp.level == lv) {
+      s2_sym3_inv(D, Di);
+      s2_sym3_mul(Di, h, u);
+      L.al[lane] = h[0] * u[0] + h[1] * u[1] + h[2] * u[2];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (act && tp.level == lv - 1) {
+      for (unsigned m = tp.children; m; m &= m - 1) {
+        const int c = __ffs(m) - 1;
+        const int e = L.pe[c];
+        const double h0 = L.Hs[e][0], h1 = L.Hs[e][1], h2 = L.Hs[e][2];
+        const double a = L.al[c];
+        D[0] -= a * h0 * h0; D[1] -= a * h0 * h1; D[2] -= a * h0 * h2; D[3] -= a * h1 * h1; D[4] -= a * h1 * h2; D[5] -= a * h2 * h2;
+      }
+    }
+  }
+  if (act && tp.level == 0) {
+    s2_sym3_inv(D, Di);
+    for (int q = 0; q < 6; ++q) L.mcov[lane][q] = Di[q];
+  }
+  for (int lv = 1; lv <= tp.maxlev; ++lv) {
+    __builtin_amdgcn_wave_barrier();
+    if (act && tp.level == lv) {
+      double sp[6], sh[3];
+      for (int q = 0; q < 6; ++q) sp[q] = L.mcov[tp.parent][q];
+      s2_sym3_mul(sp, h, sh);
+      const double gam = h[0] * sh[0] + h[1] * sh[1] + h[2] * sh[2];
+      L.mcov[lane][0] = Di[0] + gam * u[0] * u[0]; L.mcov[lane][1] = Di[1] + gam * u[0] * u[1]; L.mcov[lane][2] = Di[2] + gam * u[0] * u[2];
+      L.mcov[lane][3] = Di[3] + gam * u[1] * u[1]; L.mcov[lane][4] = Di[4] + gam * u[1] * u[2]; L.mcov[lane][5] = Di[5] + gam * u[2] * u[2];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // Marginals: (H^-1)_vv = D_v^-1 - sum_{e,f incident to v} u_e (M^-1)[e][f] u_f^T  -> L.mcov
 __device__ void s2_schur_marginals(LmSchurLds &L, int K, int nr, int lane, const double Av[6]) {
   double Di[6] = {0, 0, 0, 0, 0, 0}, zv[3], row[21];
@@ -757,8 +807,8 @@ __device__ __forceinline__ void s2_cov6_to_mat(const double c[6], double M[9]) {
   M[0] = c[0]; M[1] = c[1]; M[2] = c[2]; M[3] = c[1]; M[4] = c[3]; M[5] = c[4]; M[6] = c[2]; M[7] = c[4]; M[8] = c[5];
 }
 
-// MODE 0: dense 63x63 H per wavefront; 1: Schur/Woodbury (MFMA) for solve and marginals; 2: forest elimination for the LM
-// solves + Schur/Woodbury (MFMA) for the marginals (default)
+// MODE 0: dense 63x63 H per wavefront (J^T J on MFMA); 1: Schur/Woodbury (MFMA) for solve and marginals; 2: forest elimination
+// for the LM solves + Schur/Woodbury (MFMA) marginals; 3: forest elimination for solves and marginals (no matrix product left)
 template <int MODE>
 __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
   constexpr bool SCHUR = MODE != 0;
@@ -901,7 +951,7 @@ __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
     __builtin_amdgcn_wave_barrier();
   }
   TreeTopo topo{-1, -1, 0, 0, 0u, false};
-  if constexpr (MODE == 2) topo = s2_tree_topology(L, K, nr, lane);
+  if constexpr (MODE >= 2) topo = s2_tree_topology(L, K, nr, lane);
 
   LM_STAMP(0)  // setup
   // ---- LevenbergMarquardtOptimizer(graph, prevEstimate).optimize(), GTSAM 4.0.3 defaults ----
@@ -943,7 +993,7 @@ __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
         for (int tr = 0; tr < 64; ++tr) {  // tryLambda
           bool solved = true;
           LM_STAMP(2)  // linearize + gradient
-          if constexpr (MODE == 2) {
+          if constexpr (MODE >= 2) {
             if (topo.forest) s2_tree_solve(L, K, lambda, lane, Av, gv, topo);
             else s2_schur_solve(L, K, nr, lambda, lane, Av, gv);
             LM_STAMP(3)  // solve
@@ -1031,7 +1081,8 @@ __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
   if constexpr (SCHUR) {
     if (whiten_ok) {
       s2_linearize(L, K, nr, lane);
-      s2_schur_marginals(L, K, nr, lane, Av);
+      if (MODE == 3 && topo.forest) s2_tree_marginals(L, K, lane, Av, topo);
+      else s2_schur_marginals(L, K, nr, lane, Av);
       use_marg = true;
       if (measured)
         for (int q = 0; q < 6; ++q) mc[q] = L.mcov[col][q];
@@ -1196,12 +1247,13 @@ extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipS
   q.seq0 = seq0;
   static int lm_mode = -1;
   if (lm_mode < 0) {
-    const char *e = getenv("SE3D_LM");  // A/B evidence switch: dense | schur | tree (default)
-    lm_mode = (e && strcmp(e, "dense") == 0) ? 0 : (e && strcmp(e, "schur") == 0) ? 1 : 2;
+    const char *e = getenv("SE3D_LM");  // A/B evidence switch: dense | schur | tree_mfma | tree (default)
+    lm_mode = (e && strcmp(e, "dense") == 0) ? 0 : (e && strcmp(e, "schur") == 0) ? 1 : (e && strcmp(e, "tree_mfma") == 0) ? 2 : 3;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_track_assoc), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmLds));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmSchurLds));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmSchurLds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmSchurLds));
   }
   if (ev) (void)hipEventRecord(ev[0], st);
   int dynW = (int)((size_t)q.H * q.T * sizeof(double));
@@ -1211,7 +1263,8 @@ extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipS
   if (ev) (void)hipEventRecord(ev[1], st);
   if (lm_mode == 0) hipLaunchKernelGGL(se3d_k_lm_refine<0>, dim3(q.H, nseq), dim3(64), sizeof(LmLds), st, q);
   else if (lm_mode == 1) hipLaunchKernelGGL(se3d_k_lm_refine<1>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
-  else hipLaunchKernelGGL(se3d_k_lm_refine<2>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
+  else if (lm_mode == 2) hipLaunchKernelGGL(se3d_k_lm_refine<2>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
+  else hipLaunchKernelGGL(se3d_k_lm_refine<3>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
   if (ev) (void)hipEventRecord(ev[2], st);
   hipLaunchKernelGGL(se3d_k_track_near, dim3(q.T, nseq), dim3(64), 0, st, q);
   hipLaunchKernelGGL(se3d_k_track_update, dim3(nseq), dim3(256), 0, st, q);

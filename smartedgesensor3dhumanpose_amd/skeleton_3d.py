@@ -106,8 +106,9 @@ class Skeleton3D:
             r.c = o
         return res
 
-    def pack_stage2_device(self, persons_ptr, counts_ptr):
-        self._chk(self._L.se3d_pack_stage2_device(C.c_void_p(self._h), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)), "se3d_pack_stage2_device")
+    def pack_stage2_device(self, n_seq, persons_ptr, counts_ptr):
+        """Asynchronous D2D copy of the last run_stage2 results ([n_seq][max_hyp] persons, [n_seq] counts); sync() before use."""
+        self._chk(self._L.se3d_pack_stage2_device(C.c_void_p(self._h), int(n_seq), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)), "se3d_pack_stage2_device")
 
     def pack_stage1_device(self, persons_ptr, counts_ptr):
         self._chk(self._L.se3d_pack_stage1_device(C.c_void_p(self._h), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)), "se3d_pack_stage1_device")

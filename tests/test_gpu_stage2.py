@@ -106,3 +106,34 @@ def test_stage2_feedback_delay_moving_average(extr_rig, oracle, demo_params):
         compare_stage2(g, o)
         assert abs(g.c.pred_delta_t - o.c.pred_delta_t) < 1e-7
     node.close()
+
+
+def test_device_pack_matches_host_fetch(extr_rig):
+    """se3d_pack_stage{1,2}_device (the source of the RCCL all-gather) delivers exactly what the host fetch returns."""
+    import torch
+    from smartedgesensor3dhumanpose_amd import shard
+    S_, H = 3, 32
+    node = _node(extr_rig, max_frames=S_, max_det_per_cam=8, max_hyp=H)
+    seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=3 + s, n_frames=12, seed=90 + s))[0] for s in range(S_)]
+    node.refine_reset()
+    psz = pm.person3d_dt.itemsize
+    p1 = torch.zeros(S_ * H * psz, dtype=torch.uint8, device="cuda")
+    c1 = torch.zeros(S_, dtype=torch.int32, device="cuda")
+    p2 = torch.zeros(S_ * H * psz, dtype=torch.uint8, device="cuda")
+    c2 = torch.zeros(S_, dtype=torch.int32, device="cuda")
+    for k in range(12):
+        frames = [seqs[s][k] for s in range(S_)]
+        node.stage(frames)
+        node.run_stage1()
+        node.run_stage2([f.stamp for f in frames])
+        node.pack_stage1_device(p1.data_ptr(), c1.data_ptr())
+        node.pack_stage2_device(S_, p2.data_ptr(), c2.data_ptr())
+        node.sync()
+    r1, r2 = node.fetch_stage1(S_), node.fetch_stage2(S_)
+    u1 = shard.unpack_skeletons(p1.view(1, -1), c1.view(1, -1), H)[0]
+    u2 = shard.unpack_skeletons(p2.view(1, -1), c2.view(1, -1), H)[0]
+    for s in range(S_):
+        assert u1[s].tobytes() == r1[s].published().tobytes()
+        assert u2[s].tobytes() == r2[s].fused[: r2[s].n_persons].tobytes()
+        assert r2[s].n_persons == 3 + s  # frame 12: num_obs = 12 > 10
+    node.close()
