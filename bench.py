@@ -208,6 +208,10 @@ def main():
         bytes_per_skel = w["bytes_s1"] if dom in names[:5] else w["bytes_s2"]
         units_per_launch = n_skel_local / NC / launches_per_step   # skeletons one launch of that kernel processes (context 0)
         achieved = bytes_per_skel * units_per_launch / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+        traffic = None  # HBM bytes per launch from the committed PMC passes of this exact configuration (profiles/r1/pmc_traffic_*.json)
+        pmc_file = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_%s.json" % args.workload)
+        if os.path.exists(pmc_file) and S_ == w["seqs"] and T_ == T_STEPS and stage2:
+            traffic = json.load(open(pmc_file))["kernels"].get(dom, {}).get("hbm_bytes_per_launch_corrected")
         line = {
             "metric": "3D skeletons/sec (triangulated + refined, per-joint error < 1 mm vs CPU reference path)",
             "value": round(n_skel * args.steps / dt, 2), "unit": "skeletons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -219,7 +223,7 @@ def main():
                        "n_cam": w["n_cam"], "n_persons": w["n_persons"], "n_joints": 17, "frames_per_step": NC * B, "contexts_per_gpu": NC,
                        "sharding": ("independent sequences per rank + RCCL all-gather of final skeletons" if world > 1 else "single GPU")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(ms_dom, 5),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "avg_launch_ms": round(ms_dom, 5),
                          "algorithmic_bytes_per_skeleton": bytes_per_skel, "skeletons_per_launch": round(units_per_launch, 1),
                          "note": "SURVEY 8d: the path is VALU/latency-bound, not HBM-bound; the HBM fraction is reported as north_star asks",
                          "kernel_ms_per_step": {k: round(v, 5) for k, v in per_step_ms.items()}},
