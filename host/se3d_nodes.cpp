@@ -1,0 +1,158 @@
+// se3d_nodes.cpp — see se3d_nodes.hpp.  Host plumbing only; no numerics of the path are evaluated here.
+#include "se3d_nodes.hpp"
+
+#include <chrono>
+#include <cstring>
+#include <iostream>
+
+namespace se3d {
+
+static const double g_max_sync_diff = 0.067;  // S3D:64
+static const char* BASE_FRAME = "base";       // S3D:45
+
+Context::Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam, int max_hyp, int device) {
+  n_cam_ = (int)cams.size();
+  max_hyp_ = max_hyp;
+  if (n_cam_ < 2) throw std::runtime_error("Need at least 2 cameras for triangulation");  // S3D:1133-1136
+  std::vector<double> T(16 * (size_t)n_cam_);
+  Rt_.resize(12 * (size_t)n_cam_);
+  K_.resize(4 * (size_t)n_cam_);
+  F_.resize(9 * (size_t)n_cam_ * (n_cam_ - 1) / 2);
+  for (int i = 0; i < n_cam_; ++i) {
+    std::memcpy(&T[16 * (size_t)i], cams[i].T_base_to_cam.data(), sizeof(double) * 16);
+    K_[4 * i + 0] = (float)cams[i].fx; K_[4 * i + 1] = (float)cams[i].fy; K_[4 * i + 2] = (float)cams[i].cx; K_[4 * i + 3] = (float)cams[i].cy;
+  }
+  if (se3d_rig_from_transforms(n_cam_, T.data(), Rt_.data(), F_.data()) != SE3D_OK) throw std::runtime_error("se3d_rig_from_transforms failed");
+  se3d_rig rig{n_cam_, Rt_.data(), K_.data(), F_.data()};
+  se3d_params p{prm.pose_method == "h36m" ? SE3D_POSE_H36M : SE3D_POSE_SIMPLE, prm.norm_height ? 1 : 0, prm.max_epi_dist};
+  se3d_limits lim{1, max_det_per_cam, max_hyp, max_hyp};
+  ctx_ = se3d_create(&rig, &p, &lim, device);
+  if (!ctx_) throw std::runtime_error("se3d_create failed: no HIP device or unsupported sizes (there is no CPU fallback)");
+}
+Context::~Context() { se3d_destroy(ctx_); }
+
+static void to_pod(const person_msgs::Person2D& p, se3d_person2d& q) {
+  std::memset(&q, 0, sizeof(q));
+  q.score = p.score;
+  for (int k = 0; k < 4; ++k) q.bbox[k] = p.bbox[k];
+  const size_t n = p.keypoints.size() < SE3D_NUM_KEYPOINTS ? p.keypoints.size() : SE3D_NUM_KEYPOINTS;
+  for (size_t k = 0; k < n; ++k) {
+    const auto& kp = p.keypoints[k];
+    q.keypoints[k].x = kp.x; q.keypoints[k].y = kp.y; q.keypoints[k].score = kp.score;
+    for (int a = 0; a < 3; ++a) q.keypoints[k].cov[a] = kp.cov[a];
+  }
+}
+static void from_pod(const se3d_person3d& s, person_msgs::PersonCov& d) {
+  d.id = s.id;
+  d.score = s.score;
+  d.keypoints.resize(SE3D_NUM_FUSION_KEYPOINTS);  // S3D:686
+  for (int k = 0; k < SE3D_NUM_FUSION_KEYPOINTS; ++k) {
+    d.keypoints[k].joint.x = s.keypoints[k].joint[0]; d.keypoints[k].joint.y = s.keypoints[k].joint[1]; d.keypoints[k].joint.z = s.keypoints[k].joint[2];
+    d.keypoints[k].score = s.keypoints[k].score;
+    for (int a = 0; a < 6; ++a) d.keypoints[k].cov[a] = s.keypoints[k].cov[a];
+  }
+}
+static void to_pod3(const person_msgs::PersonCov& s, se3d_person3d& d) {
+  std::memset(&d, 0, sizeof(d));
+  d.id = s.id;
+  d.score = s.score;
+  const size_t n = s.keypoints.size() < SE3D_NUM_FUSION_KEYPOINTS ? s.keypoints.size() : SE3D_NUM_FUSION_KEYPOINTS;
+  for (size_t k = 0; k < n; ++k) {
+    d.keypoints[k].joint[0] = s.keypoints[k].joint.x; d.keypoints[k].joint[1] = s.keypoints[k].joint.y; d.keypoints[k].joint[2] = s.keypoints[k].joint.z;
+    d.keypoints[k].score = s.keypoints[k].score;
+    for (int a = 0; a < 6; ++a) d.keypoints[k].cov[a] = s.keypoints[k].cov[a];
+  }
+}
+
+void Skeleton3DNode::triangulate_persons(const std::vector<person_msgs::Person2DList>& people, person_msgs::PersonCovList& persons3d_msg,
+                                         std::vector<int32_t>* assoc, int* n_hyp) {
+  const int N = ctx_->n_cam();
+  if ((int)people.size() != N) throw std::runtime_error("people.size() != NUM_CAMERAS");  // assert at S3D:534
+  std::vector<int32_t> off(N + 1, 0);
+  std::vector<se3d_person2d> flat;
+  std::vector<float> fb(N, -1.f);
+  for (int i = 0; i < N; ++i) {
+    for (const auto& p : people[i].persons) { flat.emplace_back(); to_pod(p, flat.back()); }
+    off[i + 1] = (int32_t)flat.size();
+    fb[i] = people[i].fb_delay;
+  }
+  const int H = ctx_->max_hyp();
+  std::vector<se3d_person3d> out(H);
+  std::vector<int32_t> hyp(H), asc((size_t)H * N, -1);
+  se3d_frame_in in{N, off.data(), flat.empty() ? nullptr : flat.data(), fb.data(), persons3d_msg.header.stamp};
+  se3d_frame_out res{H, H, 0, 0, 0u, out.data(), hyp.data(), asc.data()};
+  const int rc = se3d_triangulate(ctx_->get(), &in, &res);
+  if (rc != SE3D_OK) throw std::runtime_error(std::string("se3d_triangulate: ") + se3d_last_error(ctx_->get()));
+  persons3d_msg.persons.clear();  // < 2 cameras with detections: the empty list is still published (S3D:557-560, 1071)
+  for (int p = 0; p < res.n_persons; ++p) { persons3d_msg.persons.emplace_back(); from_pod(out[p], persons3d_msg.persons.back()); }
+  if (assoc) assoc->assign(asc.begin(), asc.begin() + (size_t)res.n_hyp * N);
+  if (n_hyp) *n_hyp = res.n_hyp;
+}
+
+bool Skeleton3DNode::skeletonThreadStep(std::vector<person_msgs::Person2DList> people, person_msgs::PersonCovList& persons3d_msg) {
+  const int N = ctx_->n_cam();
+  if ((int)people.size() != N) throw std::runtime_error("people.size() != NUM_CAMERAS");  // assert at S3D:1027
+  double t_max = 0.0;  // most recent message (pivot element), S3D:1029-1036
+  int t_max_idx = -1;
+  for (int i = 0; i < N; ++i)
+    if (people[i].header.stamp > t_max) { t_max = people[i].header.stamp; t_max_idx = i; }
+  if (t_max_idx < 0) return false;
+  const auto t1 = std::chrono::high_resolution_clock::now();
+  const double delta_t = people[t_max_idx].header.stamp - last_stamp_;
+  if (delta_t > 0.17) std::cout << "WARNING: Large frame delay delta_t = " << delta_t << "s (should be < 0.17s)" << std::endl;  // S3D:1040-1042
+  if (delta_t <= 0.0) {  // S3D:1043-1046
+    std::cout << "WARNING: re-using message or jumped backwards in time: delta_t = " << delta_t << "s. Will not process this message!" << std::endl;
+    return false;
+  }
+  last_stamp_ = people[t_max_idx].header.stamp;
+  for (int i = 0; i < N; ++i) {  // S3D:1049-1057: a view older than 67 ms w.r.t. the pivot is replaced by an empty dummy
+    const double dt = t_max - people[i].header.stamp;
+    if (dt > g_max_sync_diff) {
+      person_msgs::Person2DList dummy;
+      dummy.header = people[i].header;
+      dummy.fb_delay = people[i].fb_delay;
+      people[i] = dummy;
+    }
+  }
+  persons3d_msg = person_msgs::PersonCovList();
+  persons3d_msg.header = people[t_max_idx].header;  // S3D:1060-1065
+  for (int i = 0; i < N; ++i) {
+    persons3d_msg.ts_per_cam.push_back(people[i].header.stamp);
+    persons3d_msg.fb_delay_per_cam.push_back(people[i].fb_delay);
+  }
+  persons3d_msg.header.frame_id = BASE_FRAME;
+  triangulate_persons(people, persons3d_msg);
+  const auto t2 = std::chrono::high_resolution_clock::now();
+  const double ms = std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count() / 1000.;  // S3D:1076-1084
+  timings_[0] += ms;
+  ++timing_cnt_[0];
+  const size_t n = persons3d_msg.persons.size();
+  if (n > 0 && n < timings_.size()) { timings_[n] += ms; ++timing_cnt_[n]; }
+  return true;
+}
+
+void PosePriorNode::reset() { se3d_refine_reset(ctx_->get()); }
+
+void PosePriorNode::skeletonCallback(const person_msgs::PersonCovList& persons, person_msgs::PersonCovList& persons_fused,
+                                     person_msgs::PersonCovList& persons_fused_pred) {
+  const int H = ctx_->max_hyp();
+  std::vector<se3d_person3d> dets(persons.persons.size());
+  for (size_t i = 0; i < dets.size(); ++i) to_pod3(persons.persons[i], dets[i]);
+  std::vector<se3d_person3d> fused(H), pred(H);
+  std::vector<int32_t> iters(H);
+  se3d_fused_out fo{H, 0, 0, 0.f, fused.data(), pred.data(), iters.data()};
+  const int rc = se3d_refine(ctx_->get(), seq_, (int32_t)dets.size(), dets.empty() ? nullptr : dets.data(), (int32_t)persons.fb_delay_per_cam.size(),
+                             persons.fb_delay_per_cam.empty() ? nullptr : persons.fb_delay_per_cam.data(), persons.header.stamp, &fo);
+  if (rc != SE3D_OK) throw std::runtime_error(std::string("se3d_refine: ") + se3d_last_error(ctx_->get()));
+  persons_fused = person_msgs::PersonCovList();
+  persons_fused.header = persons.header;  // PP:528-532
+  persons_fused.ts_per_cam = persons.ts_per_cam;
+  persons_fused.fb_delay_per_cam.assign(persons.fb_delay_per_cam.size(), fo.pred_delta_t);
+  persons_fused_pred = persons_fused;
+  for (int p = 0; p < fo.n_persons; ++p) {
+    persons_fused.persons.emplace_back(); from_pod(fused[p], persons_fused.persons.back());
+    persons_fused_pred.persons.emplace_back(); from_pod(pred[p], persons_fused_pred.persons.back());
+  }
+}
+
+}  // namespace se3d

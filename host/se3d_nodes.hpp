@@ -1,0 +1,81 @@
+// se3d_nodes.hpp — C++ host layer above the C-ABI (include/se3d.h), mirroring the reference nodes' internal interfaces:
+//   Skeleton3DNode::triangulate_persons   <->  triangulate_persons(...)            skeleton_3d_triang_mult_node.cpp:525
+//   Skeleton3DNode::skeletonThreadStep    <->  body of skeletonThreadCallback      skeleton_3d_triang_mult_node.cpp:1029-1084
+//   PosePriorNode::skeletonCallback       <->  skeletonCallback(PersonCovList)     pose_prior_mult_node.cpp:505
+// ROS is not available in the build image, so messages are the plain mirrors of host/person_msgs.hpp; a catkin wrapper
+// only has to forward its callbacks to these methods.  All arithmetic runs in libse3d_hip.so on the GPU.
+#pragma once
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../include/se3d.h"
+#include "person_msgs.hpp"
+
+namespace se3d {
+
+struct NodeParams {                 // ROS private parameters (S3D:1095-1097, PP:930-932)
+  std::string pose_method = "simple";
+  double max_epi_dist = 0.050;
+  bool norm_height = false;
+};
+
+struct CameraCalib {
+  std::array<double, 16> T_base_to_cam;  // row-major 4x4: lookupTransform(cam, base) (S3D:166)
+  double fx, fy, cx, cy;                 // CameraInfo K (S3D:226)
+};
+
+class Context {                      // owns one se3d_ctx (one GPU stream, stage-1 workspace, stage-2 track state)
+ public:
+  Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam = 16, int max_hyp = 64, int device = 0);
+  ~Context();
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  se3d_ctx* get() const { return ctx_; }
+  int n_cam() const { return n_cam_; }
+  int max_hyp() const { return max_hyp_; }
+  const std::vector<float>& fundamental() const { return F_; }
+
+ private:
+  se3d_ctx* ctx_ = nullptr;
+  int n_cam_ = 0, max_hyp_ = 0;
+  std::vector<float> Rt_, K_, F_;
+};
+
+class Skeleton3DNode {
+ public:
+  explicit Skeleton3DNode(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) {}
+  // S3D:525 — fills persons3d_msg.persons (21 keypoints each); assoc (optional) receives [n_hyp][n_cam] detection indices
+  void triangulate_persons(const std::vector<person_msgs::Person2DList>& people, person_msgs::PersonCovList& persons3d_msg,
+                           std::vector<int32_t>* assoc = nullptr, int* n_hyp = nullptr);
+  // S3D:1029-1084 — pivot selection, non-monotonic drop, stale-view replacement (> 67 ms), header bookkeeping, timing buckets.
+  // Returns false when the frame is skipped (delta_t <= 0, S3D:1043-1046).
+  bool skeletonThreadStep(std::vector<person_msgs::Person2DList> people, person_msgs::PersonCovList& persons3d_msg);
+  // "avg runtime" report of S3D:1234-1241: index 0 = all frames, n = frames with n output persons (n < 10)
+  const std::vector<double>& timings_ms() const { return timings_; }
+  const std::vector<int>& timing_counts() const { return timing_cnt_; }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  double last_stamp_ = 0.0;
+  std::vector<double> timings_ = std::vector<double>(10, 0.0);
+  std::vector<int> timing_cnt_ = std::vector<int>(10, 0);
+};
+
+class PosePriorNode {
+ public:
+  explicit PosePriorNode(std::shared_ptr<Context> ctx, int seq = 0) : ctx_(std::move(ctx)), seq_(seq) {}
+  void reset();  // PP:182-189
+  // PP:505 — consumes persons_3d, produces persons3d_fused and persons3d_fused_pred (headers / ts_per_cam copied, fb_delay_per_cam
+  // replaced by the predicted latency, PP:528-532)
+  void skeletonCallback(const person_msgs::PersonCovList& persons, person_msgs::PersonCovList& persons_fused,
+                        person_msgs::PersonCovList& persons_fused_pred);
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  int seq_;
+};
+
+}  // namespace se3d

@@ -1,0 +1,88 @@
+// se3d_replay.cpp — ROS-free replay harness: feeds recorded/synthetic per-camera Person2DList streams through the C++ host
+// layer (Skeleton3DNode::skeletonThreadStep -> PosePriorNode::skeletonCallback) exactly like the node pipeline of
+// pose_triangulate_demo.launch would, and dumps what the nodes would publish.  Used by tests/test_gpu_host_cpp.py.
+//   se3d_replay <scene.bin> <out.bin>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include "se3d_nodes.hpp"
+
+template <typename T> static T rd(std::ifstream& f) { T v; f.read(reinterpret_cast<char*>(&v), sizeof(T)); return v; }
+template <typename T> static void wr(std::ofstream& f, const T& v) { f.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
+
+static void write_list(std::ofstream& o, const person_msgs::PersonCovList& l) {
+  wr<double>(o, l.header.stamp);
+  wr<int32_t>(o, (int32_t)l.fb_delay_per_cam.size());
+  for (float v : l.fb_delay_per_cam) wr<float>(o, v);
+  for (double v : l.ts_per_cam) wr<double>(o, v);
+  wr<int32_t>(o, (int32_t)l.persons.size());
+  for (const auto& p : l.persons) {
+    wr<uint32_t>(o, p.id);
+    for (const auto& k : p.keypoints) {
+      wr<double>(o, k.joint.x); wr<double>(o, k.joint.y); wr<double>(o, k.joint.z);
+      wr<float>(o, k.score);
+      for (double c : k.cov) wr<double>(o, c);
+    }
+  }
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
+  std::ifstream in(argv[1], std::ios::binary);
+  char magic[8];
+  in.read(magic, 8);
+  if (std::memcmp(magic, "SE3DSCN1", 8) != 0) { std::fprintf(stderr, "bad scene file\n"); return 2; }
+  const int n_cam = rd<int32_t>(in);
+  std::vector<se3d::CameraCalib> cams(n_cam);
+  for (auto& c : cams) {
+    for (double& v : c.T_base_to_cam) v = rd<double>(in);
+    c.fx = rd<double>(in); c.fy = rd<double>(in); c.cx = rd<double>(in); c.cy = rd<double>(in);
+  }
+  se3d::NodeParams prm;
+  prm.pose_method = rd<int32_t>(in) == 1 ? "h36m" : "simple";
+  prm.norm_height = rd<int32_t>(in) != 0;
+  prm.max_epi_dist = rd<double>(in);
+  const int n_frames = rd<int32_t>(in);
+  try {
+    auto ctx = std::make_shared<se3d::Context>(cams, prm, 16, 64, 0);
+    se3d::Skeleton3DNode skel(ctx);
+    se3d::PosePriorNode prior(ctx);
+    std::ofstream out(argv[2], std::ios::binary);
+    wr<int32_t>(out, n_frames);
+    for (int f = 0; f < n_frames; ++f) {
+      std::vector<person_msgs::Person2DList> people(n_cam);
+      for (int c = 0; c < n_cam; ++c) {
+        people[c].header.stamp = rd<double>(in);
+        people[c].fb_delay = rd<float>(in);
+        const int np = rd<int32_t>(in);
+        people[c].persons.resize(np);
+        for (auto& p : people[c].persons) {
+          p.score = rd<float>(in);
+          for (float& b : p.bbox) b = rd<float>(in);
+          p.keypoints.resize(17);
+          for (auto& k : p.keypoints) { k.x = rd<float>(in); k.y = rd<float>(in); k.score = rd<float>(in); for (float& cv : k.cov) cv = rd<float>(in); }
+        }
+      }
+      person_msgs::PersonCovList persons3d, fused, pred;
+      const bool processed = skel.skeletonThreadStep(people, persons3d);
+      wr<int32_t>(out, processed ? 1 : 0);
+      if (!processed) continue;
+      prior.skeletonCallback(persons3d, fused, pred);
+      write_list(out, persons3d);
+      write_list(out, fused);
+      write_list(out, pred);
+    }
+    for (size_t i = 0; i < skel.timings_ms().size(); ++i)  // S3D:1234-1241
+      if (skel.timing_counts()[i] > 0) {
+        std::cout << "Triangulation: ";
+        if (i > 0) std::cout << i << " detections: ";
+        std::cout << "avg runtime: " << skel.timings_ms()[i] / skel.timing_counts()[i] << "ms" << std::endl;
+      }
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "se3d_replay: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
