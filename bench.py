@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 T_STEPS = 16  # frames per synthetic sequence (>= 16 frames per sequence)
 WORKLOADS = {
     # bytes/skeleton: SURVEY §8d algorithmic bytes (stage 1) ; stage 2 adds 8.9 KB per skeleton
-    "16cam6p": dict(n_cam=16, n_persons=6, seqs=128, contexts=3, max_det=8, max_hyp=16, bytes_s1=8972, bytes_s2=8900),
+    "16cam6p": dict(n_cam=16, n_persons=6, seqs=128, contexts=3, max_det=8, max_hyp=8, bytes_s1=8972, bytes_s2=8900),
     "64cam32p": dict(n_cam=64, n_persons=32, seqs=8, contexts=3, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900),
     "256cam128p": dict(n_cam=256, n_persons=128, seqs=1, contexts=3, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900),
 }
@@ -185,7 +185,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     # untimed accounting pass: published skeletons of one (steady-state) step
-    n_s1 = sum(r.n_persons for nd_ in nodes for r in nd_.fetch_stage1(B))
+    s1 = [r for nd_ in nodes for r in nd_.fetch_stage1(B)]
+    n_s1 = sum(r.n_persons for r in s1)
+    assert not any(r.flags & pm.FLAG_HYP_OVERFLOW for r in s1), "hypothesis capacity (max_hyp) exceeded: results truncated"
     if stage2:
         per_call = []
         step(collect=per_call)

@@ -219,7 +219,7 @@ __device__ __forceinline__ void se3d_pairs_tile_dispatch(const LineLDS (*L1)[PT]
 #undef SE3D_PT_CASE
 }
 
-__global__ __launch_bounds__(256) void se3d_k_pairs_tiled(Se3dDev D, const int2 *__restrict__ pair_ab) {
+__global__ __launch_bounds__(256, 3) void se3d_k_pairs_tiled(Se3dDev D, const int2 *__restrict__ pair_ab) {
   const int N = D.d.N, P = D.d.P, np = D.d.npairs;
   const int tiles = (P + PT - 1) / PT;
   const int tp = blockIdx.x / tiles, tq = blockIdx.x % tiles;
