@@ -13,6 +13,7 @@ static const char* BASE_FRAME = "base";       // S3D:45
 Context::Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam, int max_hyp, int device) {
   n_cam_ = (int)cams.size();
   max_hyp_ = max_hyp;
+  cams_ = cams;
   if (n_cam_ < 2) throw std::runtime_error("Need at least 2 cameras for triangulation");  // S3D:1133-1136
   std::vector<double> T(16 * (size_t)n_cam_);
   Rt_.resize(12 * (size_t)n_cam_);
@@ -153,6 +154,57 @@ void PosePriorNode::skeletonCallback(const person_msgs::PersonCovList& persons, 
     persons_fused.persons.emplace_back(); from_pod(fused[p], persons_fused.persons.back());
     persons_fused_pred.persons.emplace_back(); from_pod(pred[p], persons_fused_pred.persons.back());
   }
+}
+
+ReprojectionNode::ReprojectionNode(std::shared_ptr<Context> ctx) : ctx_(std::move(ctx)) {
+  const auto& cams = ctx_->cameras();
+  std::vector<double> T(16 * cams.size()), P(4 * cams.size());
+  std::vector<int32_t> wh(2 * cams.size());
+  for (size_t i = 0; i < cams.size(); ++i) {
+    std::memcpy(&T[16 * i], cams[i].T_base_to_cam.data(), sizeof(double) * 16);
+    P[4 * i] = cams[i].fx; P[4 * i + 1] = cams[i].fy; P[4 * i + 2] = cams[i].cx; P[4 * i + 3] = cams[i].cy;
+    wh[2 * i] = cams[i].width; wh[2 * i + 1] = cams[i].height;
+  }
+  if (se3d_set_reprojection_cameras(ctx_->get(), T.data(), P.data(), wh.data()) != SE3D_OK)
+    throw std::runtime_error(std::string("se3d_set_reprojection_cameras: ") + se3d_last_error(ctx_->get()));
+}
+
+bool ReprojectionNode::fusedSkeletonCallback(const person_msgs::PersonCovList& humans, std::vector<person_msgs::Person2DList>& humans_in_cam) {
+  const int n_cam = ctx_->n_cam();
+  if (humans.header.frame_id != "base") return false;                       // REPROJ:141-143
+  if ((int)humans.ts_per_cam.size() != n_cam || (int)humans.fb_delay_per_cam.size() != n_cam) return false;  // REPROJ:147
+  std::vector<se3d_person3d> in;
+  in.reserve(humans.persons.size());
+  for (const auto& p : humans.persons) {
+    if (p.keypoints.size() != SE3D_NUM_FUSION_KEYPOINTS) continue;          // REPROJ:151
+    in.emplace_back();
+    to_pod3(p, in.back());
+  }
+  std::vector<int32_t> off(n_cam + 1, 0);
+  std::vector<se3d_person2d> flat((size_t)n_cam * (in.empty() ? 1 : in.size()));
+  se3d_reproj_out out{(int32_t)flat.size(), off.data(), flat.data(), nullptr};
+  const int rc = se3d_reproject(ctx_->get(), (int32_t)in.size(), in.empty() ? nullptr : in.data(), &out);
+  if (rc != SE3D_OK) throw std::runtime_error(std::string("se3d_reproject: ") + se3d_last_error(ctx_->get()));
+  humans_in_cam.assign(n_cam, person_msgs::Person2DList());
+  for (int i = 0; i < n_cam; ++i) {
+    auto& l = humans_in_cam[i];
+    l.header.stamp = humans.ts_per_cam[i];                                   // REPROJ:230-231
+    l.header.frame_id = "cam_" + std::to_string(i);
+    l.fb_delay = humans.fb_delay_per_cam[i];
+    for (int k = off[i]; k < off[i + 1]; ++k) {
+      person_msgs::Person2D p;
+      p.score = flat[k].score;
+      for (int a = 0; a < 4; ++a) p.bbox[a] = flat[k].bbox[a];
+      p.keypoints.resize(SE3D_NUM_KEYPOINTS);
+      for (int j = 0; j < SE3D_NUM_KEYPOINTS; ++j) {
+        const auto& s = flat[k].keypoints[j];
+        p.keypoints[j].x = s.x; p.keypoints[j].y = s.y; p.keypoints[j].score = s.score;
+        for (int a = 0; a < 3; ++a) p.keypoints[j].cov[a] = s.cov[a];
+      }
+      l.persons.push_back(std::move(p));
+    }
+  }
+  return true;
 }
 
 }  // namespace se3d

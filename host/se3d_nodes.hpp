@@ -2,6 +2,7 @@
 //   Skeleton3DNode::triangulate_persons   <->  triangulate_persons(...)            skeleton_3d_triang_mult_node.cpp:525
 //   Skeleton3DNode::skeletonThreadStep    <->  body of skeletonThreadCallback      skeleton_3d_triang_mult_node.cpp:1029-1084
 //   PosePriorNode::skeletonCallback       <->  skeletonCallback(PersonCovList)     pose_prior_mult_node.cpp:505
+//   ReprojectionNode::fusedSkeletonCallback <-> fusedSkeletonCallback(PersonCovList) skeleton_reproj_mult_node.cpp:139
 // ROS is not available in the build image, so messages are the plain mirrors of host/person_msgs.hpp; a catkin wrapper
 // only has to forward its callbacks to these methods.  All arithmetic runs in libse3d_hip.so on the GPU.
 #pragma once
@@ -25,6 +26,7 @@ struct NodeParams {                 // ROS private parameters (S3D:1095-1097, PP
 struct CameraCalib {
   std::array<double, 16> T_base_to_cam;  // row-major 4x4: lookupTransform(cam, base) (S3D:166)
   double fx, fy, cx, cy;                 // CameraInfo K (S3D:226)
+  int width = 640, height = 480;         // CameraInfo width / height (REPROJ:161-162)
 };
 
 class Context {                      // owns one se3d_ctx (one GPU stream, stage-1 workspace, stage-2 track state)
@@ -37,11 +39,13 @@ class Context {                      // owns one se3d_ctx (one GPU stream, stage
   int n_cam() const { return n_cam_; }
   int max_hyp() const { return max_hyp_; }
   const std::vector<float>& fundamental() const { return F_; }
+  const std::vector<CameraCalib>& cameras() const { return cams_; }
 
  private:
   se3d_ctx* ctx_ = nullptr;
   int n_cam_ = 0, max_hyp_ = 0;
   std::vector<float> Rt_, K_, F_;
+  std::vector<CameraCalib> cams_;
 };
 
 class Skeleton3DNode {
@@ -76,6 +80,18 @@ class PosePriorNode {
  private:
   std::shared_ptr<Context> ctx_;
   int seq_;
+};
+
+class ReprojectionNode {
+ public:
+  // uploads the double-precision camera poses / projection matrices / image sizes (REPROJ:77-137, getTransforms + getIntrinsics)
+  explicit ReprojectionNode(std::shared_ptr<Context> ctx);
+  // REPROJ:139-235 — one Person2DList per camera (topic <cam>/skel_pred): header.stamp = ts_per_cam[i], fb_delay = fb_delay_per_cam[i].
+  // Returns false (nothing published) when frame_id != "base" or ts_per_cam has the wrong size (REPROJ:141-147).
+  bool fusedSkeletonCallback(const person_msgs::PersonCovList& humans, std::vector<person_msgs::Person2DList>& humans_in_cam);
+
+ private:
+  std::shared_ptr<Context> ctx_;
 };
 
 }  // namespace se3d

@@ -1,8 +1,11 @@
 // se3d_replay.cpp — ROS-free replay harness: feeds recorded/synthetic per-camera Person2DList streams through the C++ host
 // layer (Skeleton3DNode::skeletonThreadStep -> PosePriorNode::skeletonCallback) exactly like the node pipeline of
 // pose_triangulate_demo.launch would, and dumps what the nodes would publish.  Used by tests/test_gpu_host_cpp.py.
-//   se3d_replay <scene.bin> <out.bin>
+//   se3d_replay <scene.bin> <out.bin> [reproj.bin [width height]]
+// With a third path the predicted skeletons are also fed through ReprojectionNode::fusedSkeletonCallback and the per-camera
+// Person2DList payloads (<cam>/skel_pred) are dumped.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -29,7 +32,7 @@ static void write_list(std::ofstream& o, const person_msgs::PersonCovList& l) {
 }
 
 int main(int argc, char** argv) {
-  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
+  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [reproj.bin [width height]]\n", argv[0]); return 2; }
   std::ifstream in(argv[1], std::ios::binary);
   char magic[8];
   in.read(magic, 8);
@@ -40,6 +43,8 @@ int main(int argc, char** argv) {
     for (double& v : c.T_base_to_cam) v = rd<double>(in);
     c.fx = rd<double>(in); c.fy = rd<double>(in); c.cx = rd<double>(in); c.cy = rd<double>(in);
   }
+  if (argc >= 6)
+    for (auto& c : cams) { c.width = std::atoi(argv[4]); c.height = std::atoi(argv[5]); }
   se3d::NodeParams prm;
   prm.pose_method = rd<int32_t>(in) == 1 ? "h36m" : "simple";
   prm.norm_height = rd<int32_t>(in) != 0;
@@ -51,6 +56,14 @@ int main(int argc, char** argv) {
     se3d::PosePriorNode prior(ctx);
     std::ofstream out(argv[2], std::ios::binary);
     wr<int32_t>(out, n_frames);
+    std::unique_ptr<se3d::ReprojectionNode> reproj;
+    std::ofstream rout;
+    if (argc >= 4) {
+      reproj.reset(new se3d::ReprojectionNode(ctx));
+      rout.open(argv[3], std::ios::binary);
+      wr<int32_t>(rout, n_frames);
+      wr<int32_t>(rout, n_cam);
+    }
     for (int f = 0; f < n_frames; ++f) {
       std::vector<person_msgs::Person2DList> people(n_cam);
       for (int c = 0; c < n_cam; ++c) {
@@ -73,6 +86,21 @@ int main(int argc, char** argv) {
       write_list(out, persons3d);
       write_list(out, fused);
       write_list(out, pred);
+      if (reproj) {
+        pred.header.frame_id = "base";
+        std::vector<person_msgs::Person2DList> per_cam;
+        const bool ok = reproj->fusedSkeletonCallback(pred, per_cam);
+        wr<int32_t>(rout, ok ? 1 : 0);
+        if (ok)
+          for (const auto& l : per_cam) {
+            wr<double>(rout, l.header.stamp); wr<float>(rout, l.fb_delay); wr<int32_t>(rout, (int32_t)l.persons.size());
+            for (const auto& p : l.persons) {
+              wr<float>(rout, p.score);
+              for (float b : p.bbox) wr<float>(rout, b);
+              for (const auto& k : p.keypoints) { wr<float>(rout, k.x); wr<float>(rout, k.y); wr<float>(rout, k.score); for (float cv : k.cov) wr<float>(rout, cv); }
+            }
+          }
+      }
     }
     for (size_t i = 0; i < skel.timings_ms().size(); ++i)  // S3D:1234-1241
       if (skel.timing_counts()[i] > 0) {

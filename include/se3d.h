@@ -161,6 +161,23 @@ int se3d_refine(se3d_ctx *ctx, int32_t seq, int32_t n_det, const se3d_person3d *
 int se3d_run_stage2(se3d_ctx *ctx, int32_t n_seq, int32_t frame_slot0, const double *t);
 int se3d_fetch_stage2(se3d_ctx *ctx, int32_t n_seq, se3d_fused_out *outs);
 
+/* --- feedback reprojection: drop-in for fusedSkeletonCallback (pose_reprojection/src/skeleton_reproj_mult_node.cpp:139-235) --
+ * Projects fused/predicted 3D skeletons and their covariances (7-sigma-point unscented transform, :62-75) into every camera and
+ * returns one Person2DList payload per camera (topic <cam>/skel_pred).  Cameras in double precision as the node uses them:
+ * T_base_to_cam [n_cam][16] row-major 4x4 (tf lookupTransform(cam, base), :82), P [n_cam][4] = fx, fy, cx, cy of the CameraInfo
+ * projection matrix, wh [n_cam][2] = image width, height (:161-162, :207).  Call se3d_set_reprojection_cameras once. */
+typedef struct se3d_reproj_out {
+  int32_t capacity;          /* in : persons[] holds this many entries */
+  int32_t *det_offset;       /* out: [n_cam+1] prefix offsets: camera i received persons[det_offset[i] .. det_offset[i+1]) */
+  se3d_person2d *persons;    /* out: projected persons (score 1.0, bbox = extent of the valid keypoints, :227) */
+  int32_t *person_index;     /* out: [capacity] index into the input persons of each projected person (may be NULL) */
+} se3d_reproj_out;
+int se3d_set_reprojection_cameras(se3d_ctx *ctx, const double *T_base_to_cam, const double *P_fx_fy_cx_cy, const int32_t *wh);
+int se3d_reproject(se3d_ctx *ctx, int32_t n_persons, const se3d_person3d *persons, se3d_reproj_out *out);
+/* Same, on the predicted skeletons (persons3d_fused_pred) that the last se3d_run_stage2 / se3d_refine left in HBM for sequence
+ * `seq`: no host round trip between pose_prior and the reprojection.  out == NULL: launch only (asynchronous). */
+int se3d_reproject_resident(se3d_ctx *ctx, int32_t seq, se3d_reproj_out *out);
+
 /* --- row M as a stand-alone entry: drop-in for HungarianAlgorithm::assignmentoptimal (Hungarian.cpp:60) on the GPU.
  * dist is column-major [row + n_rows*col] (host memory), n_rows, n_cols <= 256; assignment[row] = col or -1. */
 int se3d_hungarian(se3d_ctx *ctx, int32_t *assignment, double *cost, const double *dist, int32_t n_rows, int32_t n_cols);

@@ -144,6 +144,23 @@ def lm(init, unary, ranges, want_marginals=True):
     return res, marg.reshape(K, 3, 3), it.value, err.value
 
 
+def reproject(rig, pose_method, persons, T=None, P=None, wh=None):
+    """pose_reprojection fusedSkeletonCallback (REPROJ:139-235) on the CPU; returns a pm.ReprojResult."""
+    n = rig.n_cam
+    T = np.ascontiguousarray(rig.T if T is None else T, np.float64).reshape(n, 16)
+    P = np.ascontiguousarray(rig.K if P is None else P, np.float64).reshape(n, 4)
+    if wh is None:
+        wh = np.broadcast_to(np.array([rig.width, rig.height]), (n, 2))
+    wh = np.ascontiguousarray(wh, np.int32).reshape(n, 2)
+    persons = np.ascontiguousarray(persons, pm.person3d_dt)
+    res = pm.ReprojResult(n, n * max(len(persons), 1))
+    rc = lib().se3d_oracle_reproject(n, T.ctypes.data_as(C.POINTER(C.c_double)), P.ctypes.data_as(C.POINTER(C.c_double)), pm.iptr(wh),
+                                     pm.POSE_H36M if pose_method == "h36m" else pm.POSE_SIMPLE, len(persons),
+                                     C.c_void_p(persons.ctypes.data), C.byref(res.c))
+    assert rc == 0, rc
+    return res
+
+
 class PosePrior:
     """Oracle instance of the pose_prior node state + skeletonCallback (PP:505-921)."""
 

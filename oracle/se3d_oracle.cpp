@@ -1672,6 +1672,95 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
   return SE3D_OK;
 }
 
+// fusedSkeletonCallback (REPROJ:139-235) + draw_sigma_points (REPROJ:62-75)
+int se3d_oracle_reproject(int32_t n_cam, const double *T, const double *Pm, const int32_t *wh, int32_t pose_method, int32_t n_persons,
+                          const se3d_person3d *persons, se3d_reproj_out *out) {
+  if (!T || !Pm || !wh || !out || (n_persons > 0 && !persons)) return SE3D_ERR_ARG;
+  const int *kp2fusion = (pose_method == SE3D_POSE_H36M) ? kp2fusion_h36m : kp2fusion_simple;
+  const int DIM = 3, N_SAMPLES = 7;
+  std::vector<std::vector<se3d_person2d>> lists(n_cam);
+  std::vector<std::vector<int>> src(n_cam);
+  for (int person_idx = 0; person_idx < n_persons; ++person_idx) {
+    std::vector<se3d_person2d> person_in_cam(n_cam);
+    std::vector<int> num_valid(n_cam, 0);
+    std::vector<double> min_x(n_cam), min_y(n_cam), max_x(n_cam, 0.0), max_y(n_cam, 0.0);
+    for (int i = 0; i < n_cam; ++i) {
+      std::memset(&person_in_cam[i], 0, sizeof(se3d_person2d));
+      person_in_cam[i].score = 1.0f;
+      min_x[i] = wh[2 * i];
+      min_y[i] = wh[2 * i + 1];
+    }
+    for (int kp_idx = 0; kp_idx < NKP; ++kp_idx) {
+      const se3d_keypoint3d &kp = persons[person_idx].keypoints[kp2fusion[kp_idx]];
+      if (kp.score <= 0.0f) continue;
+      const double c[9] = {kp.cov[0], kp.cov[1], kp.cov[2], kp.cov[1], kp.cov[3], kp.cov[4], kp.cov[2], kp.cov[4], kp.cov[5]};
+      // cov.llt().matrixL()
+      double L[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      L[0] = std::sqrt(c[0]);
+      L[3] = c[3] / L[0];
+      L[6] = c[6] / L[0];
+      L[4] = std::sqrt(c[4] - L[3] * L[3]);
+      L[7] = (c[7] - L[6] * L[3]) / L[4];
+      L[8] = std::sqrt(c[8] - L[6] * L[6] - L[7] * L[7]);
+      const double kappa = 0.5;
+      const double b = std::sqrt(DIM + kappa);
+      const double w = 1.0 / (2.0 * (DIM + kappa));  // all weights equal: 2*kappa == 1
+      double samples[7][3];
+      for (int a = 0; a < 3; ++a) samples[0][a] = kp.joint[a];
+      for (int k = 0; k < 3; ++k)
+        for (int a = 0; a < 3; ++a) {
+          samples[1 + k][a] = L[a * 3 + k] * (-b) + kp.joint[a];
+          samples[4 + k][a] = L[a * 3 + k] * b + kp.joint[a];
+        }
+      for (int i = 0; i < n_cam; ++i) {
+        const double *M = T + 16 * (size_t)i;
+        const double fx = Pm[4 * i], fy = Pm[4 * i + 1], cx = Pm[4 * i + 2], cy = Pm[4 * i + 3];
+        double px[7], py[7];
+        for (int sidx = 0; sidx < N_SAMPLES; ++sidx) {
+          const double *X = samples[sidx];
+          const double xc = (M[0] * X[0] + M[1] * X[1] + M[2] * X[2]) + M[3];
+          const double yc = (M[4] * X[0] + M[5] * X[1] + M[6] * X[2]) + M[7];
+          const double zc = (M[8] * X[0] + M[9] * X[1] + M[10] * X[2]) + M[11];
+          px[sidx] = (fx * xc) / zc + cx;  // PinholeCameraModel::project3dToPixel with Tx = Ty = 0
+          py[sidx] = (fy * yc) / zc + cy;
+        }
+        double mx = 0, my = 0;
+        for (int sidx = 0; sidx < N_SAMPLES; ++sidx) { mx += px[sidx] * w; my += py[sidx] * w; }
+        double cxx = 0, cxy = 0, cyy = 0;
+        for (int sidx = 0; sidx < N_SAMPLES; ++sidx) {
+          const double dx = px[sidx] - mx, dy = py[sidx] - my;
+          cxx += dx * w * dx; cxy += dx * w * dy; cyy += dy * w * dy;
+        }
+        if (mx < 0 || mx > wh[2 * i] || my < 0 || my > wh[2 * i + 1]) continue;  // outside of the image plane
+        if (!(mx == mx) || !(my == my)) continue;  // non-SPD covariance (NaN): skipped here; the reference would publish NaN
+        ++num_valid[i];
+        se3d_keypoint2d &o = person_in_cam[i].keypoints[kp_idx];
+        o.x = static_cast<float>(mx); o.y = static_cast<float>(my); o.score = kp.score;
+        o.cov[0] = static_cast<float>(cxx); o.cov[1] = static_cast<float>(cxy); o.cov[2] = static_cast<float>(cyy);
+        if (mx < min_x[i]) min_x[i] = mx;
+        if (my < min_y[i]) min_y[i] = my;
+        if (mx > max_x[i]) max_x[i] = mx;
+        if (my > max_y[i]) max_y[i] = my;
+      }
+    }
+    for (int i = 0; i < n_cam; ++i)
+      if (num_valid[i] > 0) {
+        person_in_cam[i].bbox[0] = (float)min_x[i]; person_in_cam[i].bbox[1] = (float)min_y[i];
+        person_in_cam[i].bbox[2] = (float)max_x[i]; person_in_cam[i].bbox[3] = (float)max_y[i];
+        lists[i].push_back(person_in_cam[i]);
+        src[i].push_back(person_idx);
+      }
+  }
+  size_t tot = 0;
+  out->det_offset[0] = 0;
+  for (int i = 0; i < n_cam; ++i) { tot += lists[i].size(); out->det_offset[i + 1] = (int32_t)tot; }
+  if ((int)tot > out->capacity) return SE3D_ERR_CAPACITY;
+  size_t k = 0;
+  for (int i = 0; i < n_cam; ++i)
+    for (size_t j = 0; j < lists[i].size(); ++j, ++k) { out->persons[k] = lists[i][j]; if (out->person_index) out->person_index[k] = src[i][j]; }
+  return SE3D_OK;
+}
+
 int se3d_oracle_lm(int32_t K, const double *init, int32_t n_unary, const int32_t *u_key, const double *u_meas, const double *u_cov,
                    int32_t n_range, const int32_t *r_k1, const int32_t *r_k2, const double *r_len, const double *r_sigma, double *result,
                    double *marg_cov, int32_t *iterations, double *final_error) {

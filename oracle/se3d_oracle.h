@@ -55,6 +55,10 @@ int se3d_oracle_lm(int32_t K, const double *init /*[K][3]*/, int32_t n_unary, co
                    const int32_t *r_k2, const double *r_len, const double *r_sigma, double *result /*[K][3]*/,
                    double *marg_cov /*[K][9] or NULL*/, int32_t *iterations, double *final_error);
 
+/* pose_reprojection fusedSkeletonCallback (skeleton_reproj_mult_node.cpp:139-235), all double precision. */
+int se3d_oracle_reproject(int32_t n_cam, const double *T_base_to_cam, const double *P_fx_fy_cx_cy, const int32_t *wh, int32_t pose_method,
+                          int32_t n_persons, const se3d_person3d *persons, se3d_reproj_out *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,11 @@ struct se3d_ctx {
   hipEvent_t ev2[kRing][4]{};            // stage-2 sets
   int ev2_head = 0, ev2_pending = 0;
   bool ran2 = false;
+  // feedback reprojection
+  Se3dReproj R{};
+  se3d_person3d *d_rp_in = nullptr;
+  int32_t *h_rp_off = nullptr;
+  bool rp_ready = false;
 };
 
 namespace {
@@ -336,6 +341,7 @@ void se3d_destroy(se3d_ctx *c) {
   if (c->h_nout) (void)hipHostFree(c->h_nout);
   if (c->h_ntracks) (void)hipHostFree(c->h_ntracks);
   if (c->h_preddt) (void)hipHostFree(c->h_preddt);
+  if (c->h_rp_off) (void)hipHostFree(c->h_rp_off);
   for (auto &set : c->ev2)
     for (auto &e : set)
       if (e) (void)hipEventDestroy(e);
@@ -596,6 +602,75 @@ int se3d_pack_stage2_device(se3d_ctx *c, int32_t n_seq, void *d_persons, void *d
   HIPCHK(c, hipMemcpyAsync(d_persons, Q.fused, sizeof(se3d_person3d) * (size_t)n_seq * Q.H, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_counts, Q.n_out, sizeof(int32_t) * (size_t)n_seq, hipMemcpyDeviceToDevice, c->stream));
   return SE3D_OK;  // asynchronous on the context stream (ordered after the se3d_run_stage2 that produced the data)
+}
+
+// ---- feedback reprojection (REPROJ:139-235) ----
+int se3d_set_reprojection_cameras(se3d_ctx *c, const double *T, const double *P, const int32_t *wh) {
+  if (!c || !T || !P || !wh) return SE3D_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int N = c->D.d.N;
+  const int cap = std::max(c->Q.H, c->Q.T);
+  if (!c->rp_ready) {
+    double *cam = nullptr; int32_t *dwh = nullptr;
+    if (!dev_alloc(c, &cam, (size_t)N * 16) || !dev_alloc(c, &dwh, (size_t)N * 2) || !dev_alloc(c, &c->d_rp_in, (size_t)cap) ||
+        !dev_alloc(c, &c->R.dense, (size_t)N * cap) || !dev_alloc(c, &c->R.valid, (size_t)N * cap) || !dev_alloc(c, &c->R.slot, (size_t)N * cap) ||
+        !dev_alloc(c, &c->R.det_offset, (size_t)N + 1) || !dev_alloc(c, &c->R.out, (size_t)N * cap) || !dev_alloc(c, &c->R.out_src, (size_t)N * cap))
+      return SE3D_ERR_DEVICE;
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_rp_off), sizeof(int32_t) * (N + 1)));
+    c->R.cam = cam; c->R.wh = dwh;
+    c->R.N = N; c->R.T = cap; c->R.pose_method = c->params.pose_method;
+  }
+  std::vector<double> cam((size_t)N * 16);
+  for (int i = 0; i < N; ++i) {
+    for (int k = 0; k < 12; ++k) cam[(size_t)i * 16 + k] = T[(size_t)i * 16 + k];
+    for (int k = 0; k < 4; ++k) cam[(size_t)i * 16 + 12 + k] = P[(size_t)i * 4 + k];
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(const_cast<double *>(c->R.cam), cam.data(), sizeof(double) * cam.size(), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(const_cast<int32_t *>(c->R.wh), wh, sizeof(int32_t) * 2 * N, hipMemcpyHostToDevice));
+  c->rp_ready = true;
+  return SE3D_OK;
+}
+
+namespace {
+int reproject_fetch(se3d_ctx *c, se3d_reproj_out *out) {
+  const int N = c->R.N;
+  HIPCHK(c, hipMemcpyAsync(c->h_rp_off, c->R.det_offset, sizeof(int32_t) * (N + 1), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(out->det_offset, c->h_rp_off, sizeof(int32_t) * (N + 1));
+  const int tot = c->h_rp_off[N];
+  if (tot > out->capacity) { c->err = "se3d_reproject: output capacity too small"; return SE3D_ERR_CAPACITY; }
+  if (tot > 0) {
+    HIPCHK(c, hipMemcpy(out->persons, c->R.out, sizeof(se3d_person2d) * (size_t)tot, hipMemcpyDeviceToHost));
+    if (out->person_index) HIPCHK(c, hipMemcpy(out->person_index, c->R.out_src, sizeof(int32_t) * (size_t)tot, hipMemcpyDeviceToHost));
+  }
+  return SE3D_OK;
+}
+}  // namespace
+
+int se3d_reproject(se3d_ctx *c, int32_t n_persons, const se3d_person3d *persons, se3d_reproj_out *out) {
+  if (!c || !out || !out->det_offset || (out->capacity > 0 && !out->persons) || n_persons < 0 || (n_persons > 0 && !persons)) return SE3D_ERR_ARG;
+  if (!c->rp_ready) { c->err = "se3d_reproject: se3d_set_reprojection_cameras was not called"; return SE3D_ERR_STATE; }
+  if (n_persons > c->R.T) { c->err = "se3d_reproject: more persons than limits.max_hyp / max_tracks"; return SE3D_ERR_CAPACITY; }
+  HIPCHK(c, hipSetDevice(c->device));
+  if (n_persons > 0) HIPCHK(c, hipMemcpyAsync(c->d_rp_in, persons, sizeof(se3d_person3d) * (size_t)n_persons, hipMemcpyHostToDevice, c->stream));
+  Se3dReproj R = c->R;
+  R.in = c->d_rp_in; R.n = n_persons; R.n_dev = nullptr;
+  HIPCHK(c, se3d_launch_reproject(R, n_persons, c->stream));
+  return reproject_fetch(c, out);
+}
+
+int se3d_reproject_resident(se3d_ctx *c, int32_t seq, se3d_reproj_out *out) {
+  if (!c || seq < 0 || seq >= c->Q.S) return SE3D_ERR_ARG;
+  if (!c->rp_ready) { c->err = "se3d_reproject_resident: se3d_set_reprojection_cameras was not called"; return SE3D_ERR_STATE; }
+  if (!c->ran2) { c->err = "se3d_reproject_resident: no stage-2 result"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  Se3dReproj R = c->R;
+  R.in = c->Q.pred + (size_t)seq * c->Q.H; R.n = 0; R.n_dev = c->Q.n_out + seq;
+  HIPCHK(c, se3d_launch_reproject(R, c->Q.H, c->stream));
+  if (!out) return SE3D_OK;  // asynchronous: result stays on the device (timing / chaining)
+  if (!out->det_offset || (out->capacity > 0 && !out->persons)) return SE3D_ERR_ARG;
+  return reproject_fetch(c, out);
 }
 
 int se3d_profile_enable(se3d_ctx *c, int32_t on) {

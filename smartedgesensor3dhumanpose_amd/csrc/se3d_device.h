@@ -129,3 +129,21 @@ struct Se3dStage2 {
   int32_t *n_out;         // [S]
   uint32_t *flags2;       // [S]
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// feedback reprojection (pose_reprojection node).  N cameras, T = capacity in persons.
+// ---------------------------------------------------------------------------------------------------------------
+struct Se3dReproj {
+  int N, T, n, pose_method;
+  const int32_t *n_dev;       // optional device-side person count (resident chaining after stage 2); overrides n
+  const double *cam;          // [N][16]: rows of the 3x4 base->camera transform (12), then fx, fy, cx, cy
+  const int32_t *wh;          // [N][2] image width, height
+  const se3d_person3d *in;    // [<=T]
+  se3d_person2d *dense;       // [N][T] projected person per (camera, person)
+  uint8_t *valid;             // [T][N] 1: person has >= 1 keypoint inside camera's image
+  int32_t *slot;              // [T][N] output slot or -1
+  int32_t *det_offset;        // [N+1]
+  se3d_person2d *out;         // [N*T] compacted, camera-major, person order preserved (REPROJ:226-233)
+  int32_t *out_src;           // [N*T] input person index of each output entry
+};
+hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t stream);

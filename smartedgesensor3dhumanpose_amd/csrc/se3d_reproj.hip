@@ -1,0 +1,149 @@
+// se3d_reproj.hip — feedback reprojection (pose_reprojection/src/skeleton_reproj_mult_node.cpp:139-235) for MI355X.
+//
+// One 32-lane half-wave per (person, camera): lane j < 17 owns model joint j, draws the 7 sigma points of the joint's 3-D
+// covariance (REPROJ:62-75), projects them with the camera's double-precision pose and pinhole matrix, and forms the weighted
+// mean / 2x2 covariance (REPROJ:178-205).  Validity count and bounding box (REPROJ:207-223) are half-wave shuffle reductions.
+// The ordered per-camera person lists (REPROJ:226-233) are built by a flag scan (se3d_k_reproj_scan) and a 428-byte gather
+// (se3d_k_reproj_compact).  Everything is fp64 like the node; no FMA contraction (-ffp-contract=off).
+#include "se3d_device.h"
+
+namespace {
+
+constexpr int kCamsPerBlock = 8;  // 8 half-waves of 32 lanes
+
+__global__ __launch_bounds__(256) void se3d_k_reproject(Se3dReproj R) {
+  const int lane = threadIdx.x & 31;
+  const int cam = blockIdx.x * kCamsPerBlock + (threadIdx.x >> 5);
+  const int person = blockIdx.y;
+  const int n = R.n_dev ? *R.n_dev : R.n;
+  if (person >= n || cam >= R.N) return;
+  const int W = R.wh[2 * cam], Hh = R.wh[2 * cam + 1];
+  bool valid = false;
+  double mx = 0., my = 0., cxx = 0., cxy = 0., cyy = 0.;
+  float score = 0.f;
+  if (lane < SE3D_NKP) {
+    const se3d_keypoint3d &kp = R.in[person].keypoints[c_kp2fusion[R.pose_method][lane]];
+    score = kp.score;
+    if (score > 0.f) {  // REPROJ:167-168
+      // cov.llt().matrixL() (REPROJ:70)
+      const double c00 = kp.cov[0], c10 = kp.cov[1], c20 = kp.cov[2], c11 = kp.cov[3], c21 = kp.cov[4], c22 = kp.cov[5];
+      const double l00 = sqrt(c00);
+      const double l10 = c10 / l00, l20 = c20 / l00;
+      const double l11 = sqrt(c11 - l10 * l10);
+      const double l21 = (c21 - l20 * l10) / l11;
+      const double l22 = sqrt(c22 - l20 * l20 - l21 * l21);
+      const double L[3][3] = {{l00, 0., 0.}, {l10, l11, 0.}, {l20, l21, l22}};
+      const double kappa = 0.5;
+      const double b = sqrt(3.0 + kappa);
+      const double w = 1.0 / (2.0 * (3.0 + kappa));  // weights(0) = 2 kappa / (2 (DIM + kappa)) equals the others for kappa = 0.5
+      const double *M = R.cam + 16 * (size_t)cam;
+      const double fx = M[12], fy = M[13], pcx = M[14], pcy = M[15];
+      double px[7], py[7];
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {
+        double X[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (s == 0) X[a] = kp.joint[a];
+          else if (s < 4) X[a] = L[a][s - 1] * (-b) + kp.joint[a];
+          else X[a] = L[a][s - 4] * b + kp.joint[a];
+        }
+        const double xc = (M[0] * X[0] + M[1] * X[1] + M[2] * X[2]) + M[3];
+        const double yc = (M[4] * X[0] + M[5] * X[1] + M[6] * X[2]) + M[7];
+        const double zc = (M[8] * X[0] + M[9] * X[1] + M[10] * X[2]) + M[11];
+        px[s] = (fx * xc) / zc + pcx;  // project3dToPixel (REPROJ:186)
+        py[s] = (fy * yc) / zc + pcy;
+      }
+#pragma unroll
+      for (int s = 0; s < 7; ++s) { mx += px[s] * w; my += py[s] * w; }
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {
+        const double dx = px[s] - mx, dy = py[s] - my;
+        cxx += dx * w * dx; cxy += dx * w * dy; cyy += dy * w * dy;
+      }
+      valid = !(mx < 0. || mx > (double)W || my < 0. || my > (double)Hh) && mx == mx && my == my;  // REPROJ:207 (+ NaN guard)
+    }
+  }
+  // half-wave reductions: count, bbox (REPROJ:153-165, 216-222)
+  int cnt = valid ? 1 : 0;
+  double mnx = valid ? mx : (double)W, mny = valid ? my : (double)Hh, mxx = valid ? mx : 0., mxy = valid ? my : 0.;
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 32);
+    mnx = fmin(mnx, __shfl_xor(mnx, o, 32));
+    mny = fmin(mny, __shfl_xor(mny, o, 32));
+    mxx = fmax(mxx, __shfl_xor(mxx, o, 32));
+    mxy = fmax(mxy, __shfl_xor(mxy, o, 32));
+  }
+  se3d_person2d &o = R.dense[(size_t)cam * R.T + person];
+  if (lane < SE3D_NKP) {
+    se3d_keypoint2d k;
+    if (valid) {
+      k.x = (float)mx; k.y = (float)my; k.score = score;
+      k.cov[0] = (float)cxx; k.cov[1] = (float)cxy; k.cov[2] = (float)cyy;
+    } else {
+      k.x = k.y = k.score = 0.f; k.cov[0] = k.cov[1] = k.cov[2] = 0.f;
+    }
+    o.keypoints[lane] = k;
+  } else if (lane == SE3D_NKP) {
+    o.score = 1.0f;  // REPROJ:154
+    o.bbox[0] = (float)mnx; o.bbox[1] = (float)mny; o.bbox[2] = (float)mxx; o.bbox[3] = (float)mxy;
+    R.valid[(size_t)person * R.N + cam] = cnt > 0 ? 1 : 0;
+  }
+}
+
+// one block, thread c = camera c: per-camera counts -> exclusive offsets -> output slot of every (person, camera)
+__global__ __launch_bounds__(256) void se3d_k_reproj_scan(Se3dReproj R) {
+  __shared__ int s_cnt[256];
+  const int c = threadIdx.x;
+  const int n = R.n_dev ? *R.n_dev : R.n;
+  int cnt = 0;
+  if (c < R.N)
+    for (int p = 0; p < n; ++p) cnt += R.valid[(size_t)p * R.N + c];
+  s_cnt[c] = cnt;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {  // inclusive Hillis-Steele scan
+    const int v = (c >= o) ? s_cnt[c - o] : 0;
+    __syncthreads();
+    s_cnt[c] += v;
+    __syncthreads();
+  }
+  if (c < R.N) {
+    int off = s_cnt[c] - cnt;
+    if (c == 0) R.det_offset[0] = 0;
+    R.det_offset[c + 1] = s_cnt[c];
+    for (int p = 0; p < n; ++p) {
+      const bool v = R.valid[(size_t)p * R.N + c] != 0;
+      R.slot[(size_t)p * R.N + c] = v ? off : -1;
+      off += v ? 1 : 0;
+    }
+  }
+}
+
+// grid (ceil(N/2), n): 128 threads per (person, camera) copy the 107 dwords of a valid projected person to its list slot
+__global__ __launch_bounds__(256) void se3d_k_reproj_compact(Se3dReproj R) {
+  const int cam = blockIdx.x * 2 + (threadIdx.x >> 7);
+  const int person = blockIdx.y;
+  const int t = threadIdx.x & 127;
+  const int n = R.n_dev ? *R.n_dev : R.n;
+  if (person >= n || cam >= R.N) return;
+  const int slot = R.slot[(size_t)person * R.N + cam];
+  if (slot < 0) return;
+  constexpr int kWords = sizeof(se3d_person2d) / 4;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&R.dense[(size_t)cam * R.T + person]);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(&R.out[slot]);
+  if (t < kWords) dst[t] = src[t];
+  if (t == 127) R.out_src[slot] = person;
+}
+
+}  // namespace
+
+hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t stream) {
+  if (n_grid <= 0) {
+    return hipMemsetAsync(R.det_offset, 0, sizeof(int32_t) * (R.N + 1), stream);
+  }
+  hipLaunchKernelGGL(se3d_k_reproject, dim3((R.N + kCamsPerBlock - 1) / kCamsPerBlock, n_grid), dim3(256), 0, stream, R);
+  hipLaunchKernelGGL(se3d_k_reproj_scan, dim3(1), dim3(256), 0, stream, R);
+  hipLaunchKernelGGL(se3d_k_reproj_compact, dim3((R.N + 1) / 2, n_grid), dim3(256), 0, stream, R);
+  return hipGetLastError();
+}

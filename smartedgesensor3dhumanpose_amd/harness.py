@@ -147,3 +147,25 @@ def read_replay_output(path):
         pred, pos = _read_list(buf, pos)
         out.append((p3d, fused, pred))
     return out
+
+
+def read_replay_reproj(path):
+    """Per-frame, per-camera (stamp, fb_delay, persons[person2d_dt]) written by `se3d_replay scene out reproj.bin`; None = not published."""
+    buf = open(path, "rb").read()
+    n_frames, n_cam = struct.unpack_from("<ii", buf, 0)
+    pos, out = 8, []
+    while pos < len(buf):
+        (ok,) = struct.unpack_from("<i", buf, pos)
+        pos += 4
+        if not ok:
+            out.append(None)
+            continue
+        cams = []
+        for _ in range(n_cam):
+            stamp, fb, n = struct.unpack_from("<dfi", buf, pos)
+            pos += 16
+            persons = np.frombuffer(buf, pm.person2d_dt, n, pos).copy()
+            pos += n * pm.person2d_dt.itemsize
+            cams.append((stamp, fb, persons))
+        out.append(cams)
+    return out

@@ -57,6 +57,10 @@ class FusedOut(C.Structure):
                 ("fused", C.c_void_p), ("fused_pred", C.c_void_p), ("lm_iterations", C.POINTER(C.c_int32))]
 
 
+class ReprojOut(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("det_offset", C.POINTER(C.c_int32)), ("persons", C.c_void_p), ("person_index", C.POINTER(C.c_int32))]
+
+
 def fptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -124,3 +128,18 @@ class FusedResult:
     @property
     def n_persons(self):
         return self.c.n_persons
+
+
+class ReprojResult:
+    """Per-camera Person2DList payloads of the reprojection node (skeleton_reproj_mult_node.cpp:226-233)."""
+
+    def __init__(self, n_cam, capacity):
+        self.n_cam = n_cam
+        self.det_offset = np.zeros(n_cam + 1, np.int32)
+        self.persons = np.zeros(max(capacity, 1), person2d_dt)
+        self.person_index = np.full(max(capacity, 1), -1, np.int32)
+        self.c = ReprojOut(int(capacity), iptr(self.det_offset), self.persons.ctypes.data, iptr(self.person_index))
+
+    def camera(self, i):
+        a, b = int(self.det_offset[i]), int(self.det_offset[i + 1])
+        return self.persons[a:b], self.person_index[a:b]

@@ -114,6 +114,31 @@ class Skeleton3D:
         self._chk(self._L.se3d_pack_stage1_device(C.c_void_p(self._h), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)), "se3d_pack_stage1_device")
 
     # -- measurement
+    # -- feedback reprojection (pose_reprojection node)
+    def set_reprojection_cameras(self, T=None, P=None, wh=None):
+        rig = self.rig
+        T = np.ascontiguousarray(rig.T if T is None else T, np.float64).reshape(rig.n_cam, 16)
+        P = np.ascontiguousarray(rig.K if P is None else P, np.float64).reshape(rig.n_cam, 4)
+        if wh is None:
+            wh = np.broadcast_to(np.array([rig.width, rig.height]), (rig.n_cam, 2))
+        wh = np.ascontiguousarray(wh, np.int32).reshape(rig.n_cam, 2)
+        self._chk(self._L.se3d_set_reprojection_cameras(C.c_void_p(self._h), T.ctypes.data_as(C.POINTER(C.c_double)),
+                                                        P.ctypes.data_as(C.POINTER(C.c_double)), pm.iptr(wh)), "se3d_set_reprojection_cameras")
+
+    def reproject(self, persons):
+        persons = np.ascontiguousarray(persons, pm.person3d_dt)
+        res = pm.ReprojResult(self.rig.n_cam, self.rig.n_cam * max(len(persons), 1))
+        self._chk(self._L.se3d_reproject(C.c_void_p(self._h), len(persons), C.c_void_p(persons.ctypes.data), C.byref(res.c)), "se3d_reproject")
+        return res
+
+    def reproject_resident(self, seq=0, fetch=True):
+        if not fetch:
+            self._chk(self._L.se3d_reproject_resident(C.c_void_p(self._h), int(seq), None), "se3d_reproject_resident")
+            return None
+        res = pm.ReprojResult(self.rig.n_cam, self.rig.n_cam * self.limits.max_hyp)
+        self._chk(self._L.se3d_reproject_resident(C.c_void_p(self._h), int(seq), C.byref(res.c)), "se3d_reproject_resident")
+        return res
+
     def profile(self, on=True):
         self._chk(self._L.se3d_profile_enable(C.c_void_p(self._h), int(on)), "se3d_profile_enable")
 

@@ -58,3 +58,32 @@ def test_cpp_replay_matches_oracle(tmp_path, oracle, extr_rig, demo_params):
             assert np.allclose(gfused.fb_delay_per_cam, ofused.fb_delay_per_cam, atol=1e-7)
             n_checked += len(ofused.persons)
     assert got[6] is None and n_checked > 0
+
+
+def test_cpp_replay_reprojection(tmp_path, oracle, extr_rig, demo_params):
+    """skeleton_3d -> pose_prior -> pose_reprojection chain of the C++ host layer: the per-camera skel_pred lists equal the
+    oracle's reprojection of the predicted skeletons the same run published."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")], stdout=subprocess.DEVNULL)
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=4, n_frames=16, seed=5))
+    stream = Hn.stream_from_frames(frames)
+    scene, out, rp = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin"), str(tmp_path / "reproj.bin")
+    Hn.write_replay_scene(scene, extr_rig, demo_params, stream)
+    subprocess.check_call([os.path.join(ROOT, "host", "se3d_replay"), scene, out, rp, str(extr_rig.width), str(extr_rig.height)])
+    got = [g for g in Hn.read_replay_output(out) if g is not None]
+    lists = Hn.read_replay_reproj(rp)
+    assert len(lists) == len(got)
+    n_checked = 0
+    for (p3d, fused, pred), cams in zip(got, lists):
+        assert cams is not None and len(cams) == extr_rig.n_cam
+        ref = oracle.reproject(extr_rig, "simple", pred.persons)
+        for i, (stamp, fb, persons) in enumerate(cams):
+            assert stamp == pred.ts_per_cam[i] and abs(fb - pred.fb_delay_per_cam[i]) < 1e-7
+            rper, _ = ref.camera(i)
+            assert len(persons) == len(rper)
+            if len(persons):
+                assert np.array_equal(persons["keypoints"]["score"], rper["keypoints"]["score"])
+                np.testing.assert_allclose(persons["keypoints"]["x"], rper["keypoints"]["x"], rtol=2e-6, atol=1e-4)
+                np.testing.assert_allclose(persons["keypoints"]["cov"], rper["keypoints"]["cov"], rtol=2e-6, atol=1e-4)
+                np.testing.assert_allclose(persons["bbox"], rper["bbox"], rtol=2e-6, atol=1e-4)
+                n_checked += len(persons)
+    assert n_checked > 50
