@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--stage", default="12", choices=["1", "12"], help="1: stage 1 only; 12: stage 1 + stage 2")
     ap.add_argument("--contexts", type=int, default=0, help="independent se3d contexts (HIP streams) per GPU, each with --seqs sequences; "
                     "their launches interleave so latency-bound phases of one overlap throughput-bound kernels of the other (default: preset)")
+    ap.add_argument("--walk", default="fused", choices=["fused", "steps"], help="stage 2 as one multi-step launch per context and step (default) "
+                    "or as T per-step calls (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -119,7 +121,6 @@ def main():
         all_seqs.append(seqs)
     node, seqs = nodes[0], all_seqs[0]
     dt_frame = 1.0 / 30.0
-    clock = {"t": 100.0, "step": 0}
 
     H = node.limits.max_hyp
     psz = pm.person3d_dt.itemsize
@@ -139,26 +140,53 @@ def main():
             dist.all_gather_into_tensor(gath_p[ci], packs[ci])
             dist.all_gather_into_tensor(gath_c[ci], cnts[ci])
 
-    def step(collect=None):
-        for nd_ in nodes:
-            nd_.run_stage1()
-        if stage2:
-            order = range(T_) if clock["step"] % 2 == 0 else range(T_ - 1, -1, -1)
-            for k in order:
-                clock["t"] += dt_frame
-                for ci, nd_ in enumerate(nodes):
-                    nd_.run_stage2(np.full(S_, clock["t"]), frame_slot0=k * S_)
-                    if dist is not None:  # async D2D of this time step's fused skeletons into block k of the exchange buffer
-                        nd_.pack_stage2_device(S_, packs[ci].data_ptr() + k * S_ * H * psz, cnts[ci].data_ptr() + 4 * k * S_)
+    # One step = per context one stage-1 pass over its B resident frames and one stage-2 walk over the T time steps of its S
+    # sequences (se3d_run_stage2_walk: one launch, a workgroup per sequence; forward on even cycles, backward on odd ones so that
+    # motion stays continuous and tracks persist).  With --walk steps the walk is issued as T per-step calls (se3d_run_stage2).
+    # Contexts are phase-shifted (odd contexts issue walk-then-stage-1) so that the throughput-bound stage-1 kernels of one context
+    # overlap the latency-bound stage-2 walk of another instead of all contexts running the same phase in lockstep.  Stage-1
+    # outputs of a frame slot are a pure function of the resident inputs, so a walk always consumes complete stage-1 results.
+    walks = [{"node": nd_, "ci": ci, "cycle": 0, "t": 100.0} for ci, nd_ in enumerate(nodes)]
+
+    def issue_stage1(wk):
+        wk["node"].run_stage1()
+        if not stage2 and dist is not None:
+            wk["node"].pack_stage1_device(packs[wk["ci"]].data_ptr(), cnts[wk["ci"]].data_ptr())
+
+    def issue_walk(wk, collect):
+        nd_, ci = wk["node"], wk["ci"]
+        ks = list(range(T_)) if wk["cycle"] % 2 == 0 else list(range(T_ - 1, -1, -1))
+        ts = wk["t"] + dt_frame * np.arange(1, T_ + 1)
+        wk["t"] = float(ts[-1])
+        wk["cycle"] += 1
+        if args.walk == "fused":
+            nd_.run_stage2_walk(np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
+            if dist is not None:  # async D2D of all time steps' fused skeletons (frame-slot order) into the exchange buffer
+                nd_.pack_stage2_walk_device(B, packs[ci].data_ptr(), cnts[ci].data_ptr())
+            if collect is not None:
+                collect.append(sum(r.n_persons for k in ks for r in nd_.fetch_stage2_walk(k * S_, S_)))
+        else:
+            for k, t in zip(ks, ts):
+                nd_.run_stage2(np.full(S_, t), frame_slot0=k * S_)
+                if dist is not None:
+                    nd_.pack_stage2_device(S_, packs[ci].data_ptr() + k * S_ * H * psz, cnts[ci].data_ptr() + 4 * k * S_)
                 if collect is not None:
-                    collect.append(sum(r.n_persons for nd_ in nodes for r in nd_.fetch_stage2(S_)))
-        elif dist is not None:
-            for ci, nd_ in enumerate(nodes):
-                nd_.pack_stage1_device(packs[ci].data_ptr(), cnts[ci].data_ptr())
+                    collect.append(sum(r.n_persons for r in nd_.fetch_stage2(S_)))
+
+    def step(collect=None):
+        if not stage2:
+            for wk in walks:
+                issue_stage1(wk)
+        else:
+            for wk in walks:   # phase A
+                issue_stage1(wk) if wk["ci"] % 2 == 0 else issue_walk(wk, collect)
+            for wk in walks:   # phase B
+                issue_walk(wk, collect) if wk["ci"] % 2 == 0 else issue_stage1(wk)
         if dist is not None:
             exchange()
-        clock["step"] += 1
 
+    for nd_ in nodes:
+        nd_.run_stage1()   # phase-shifted contexts start inside the stage-2 walk: their frames need one completed stage-1 pass
     for nd_ in nodes:
         nd_.refine_reset()
     for _ in range(max(args.warmup, 1 if stage2 else 0)):
@@ -201,7 +229,7 @@ def main():
         n_skel = int(tot.item())
 
     if rank == 0:
-        names = ["normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess"] + (["track_assoc", "lm_refine", "track_update"] if stage2 else [])
+        names = ["normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess"] + (["track_assoc", "lm_refine", "track_update", "stage2_walk"] if stage2 else [])
         prof = {k: node.profile_get(k) for k in names}
         per_step_ms = {k: v[0] / args.steps for k, v in prof.items()}
         dom = max(per_step_ms, key=lambda k: per_step_ms[k])

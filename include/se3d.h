@@ -160,6 +160,16 @@ int se3d_refine(se3d_ctx *ctx, int32_t seq, int32_t n_det, const se3d_person3d *
  * (a batch staged as [time step k][sequence s] is walked with frame_slot0 = k * n_seq, one call per time step) */
 int se3d_run_stage2(se3d_ctx *ctx, int32_t n_seq, int32_t frame_slot0, const double *t);
 int se3d_fetch_stage2(se3d_ctx *ctx, int32_t n_seq, se3d_fused_out *outs);
+/* Multi-step replay of resident sequences: equivalent to n_steps consecutive se3d_run_stage2 calls, step k consuming frame slots
+ * frame_slot0[k] .. frame_slot0[k]+n_seq-1 at times t[k*n_seq + s] (n_steps <= 64, n_steps*n_seq <= limits.max_frames).  When the
+ * association problem is small the whole walk is ONE kernel launch (a workgroup per sequence loops over the time steps), which
+ * removes the per-step launch and tail latency; otherwise the per-step kernels are launched back to back.  Results are kept per
+ * frame slot: se3d_fetch_stage2_walk(frame_slot0, n_seq) returns the persons3d_fused / _pred lists of the step that consumed those
+ * slots; se3d_pack_stage2_walk_device copies [n_frames][max_hyp] persons + [n_frames] counts (frame-slot order, asynchronous). */
+int se3d_run_stage2_walk(se3d_ctx *ctx, int32_t n_seq, int32_t n_steps, const int32_t *frame_slot0, const double *t);
+int se3d_fetch_stage2_walk(se3d_ctx *ctx, int32_t frame_slot0, int32_t n_seq, se3d_fused_out *outs);
+int se3d_pack_stage2_walk_device(se3d_ctx *ctx, int32_t n_frames, void *d_persons, void *d_counts);
+
 
 /* --- feedback reprojection: drop-in for fusedSkeletonCallback (pose_reprojection/src/skeleton_reproj_mult_node.cpp:139-235) --
  * Projects fused/predicted 3D skeletons and their covariances (7-sigma-point unscented transform, :62-75) into every camera and

@@ -14,6 +14,7 @@ EXPORTS = [
     "se3d_hungarian", "se3d_get_pair_costs", "se3d_pack_stage1_device", "se3d_pack_stage2_device",
     "se3d_profile_enable", "se3d_profile_reset", "se3d_profile_get",
     "se3d_set_reprojection_cameras", "se3d_reproject", "se3d_reproject_resident",
+    "se3d_run_stage2_walk", "se3d_fetch_stage2_walk", "se3d_pack_stage2_walk_device",
 ]
 
 
@@ -31,12 +32,35 @@ def build(force=False):
 _lib = None
 
 
+def _preload_host_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so.7; the system ROCm has one with the same SONAME.  Whichever is loaded first
+    serves both, and torch does not find its GPUs on the system runtime.  When torch is installed, load its runtime first so that
+    this library and torch (bench.py / shard.py: RCCL exchange, device buffers) can be used in one process in any import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libse3d_hip.so is missing (%s): build it with `make -C smartedgesensor3dhumanpose_amd/csrc` "
                                "or __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+        _preload_host_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.se3d_create.restype = C.c_void_p
         L.se3d_destroy.argtypes = [C.c_void_p]
@@ -46,7 +70,8 @@ def lib():
         for name in ("se3d_triangulate", "se3d_triangulate_batch", "se3d_stage_frames", "se3d_run_stage1", "se3d_sync", "se3d_fetch_stage1",
                      "se3d_refine_reset", "se3d_refine", "se3d_run_stage2", "se3d_fetch_stage2", "se3d_pack_stage1_device",
                      "se3d_pack_stage2_device", "se3d_hungarian", "se3d_get_pair_costs", "se3d_profile_enable", "se3d_profile_reset", "se3d_profile_get",
-                     "se3d_set_reprojection_cameras", "se3d_reproject", "se3d_reproject_resident"):
+                     "se3d_set_reprojection_cameras", "se3d_reproject", "se3d_reproject_resident",
+                     "se3d_run_stage2_walk", "se3d_fetch_stage2_walk", "se3d_pack_stage2_walk_device"):
             getattr(L, name).restype = C.c_int
         _lib = L
     return _lib

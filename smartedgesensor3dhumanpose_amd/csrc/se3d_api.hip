@@ -14,13 +14,14 @@
 extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st);
 extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled);
 extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev);
+extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st);
 
 #define SE3D_VERSION "se3d-hip 0.1.0 (gfx950)"
 
 namespace {
-enum ProfSlot { PS_NORMALIZE = 0, PS_PAIRS, PS_SWEEP, PS_TRI, PS_POST, PS_ASSOC2, PS_LM, PS_UPDATE2, PS_COUNT };
+enum ProfSlot { PS_NORMALIZE = 0, PS_PAIRS, PS_SWEEP, PS_TRI, PS_POST, PS_ASSOC2, PS_LM, PS_UPDATE2, PS_WALK, PS_COUNT };
 const int kStage1Slots = 5, kStage2Slots = 3;
-const char *kProfNames[PS_COUNT] = {"normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess", "track_assoc", "lm_refine", "track_update"};
+const char *kProfNames[PS_COUNT] = {"normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess", "track_assoc", "lm_refine", "track_update", "stage2_walk"};
 }  // namespace
 
 struct se3d_ctx {
@@ -62,6 +63,7 @@ struct se3d_ctx {
   int32_t *h_iters = nullptr, *h_nout = nullptr, *h_ntracks = nullptr;
   double *h_preddt = nullptr;
   hipEvent_t ev2[kRing][4]{};            // stage-2 sets
+  bool ev2_walk[kRing]{};                // set brackets one fused multi-step launch (events 0 and 3 only)
   int ev2_head = 0, ev2_pending = 0;
   bool ran2 = false;
   // feedback reprojection
@@ -106,6 +108,10 @@ void collect_profile(se3d_ctx *c, bool all = true) {
   while (c->ev2_pending > 0 && (all || c->ev2_pending >= se3d_ctx::kRing)) {
     const int idx = (c->ev2_head - c->ev2_pending + 2 * se3d_ctx::kRing) % se3d_ctx::kRing;
     (void)hipEventSynchronize(c->ev2[idx][3]);
+    if (c->ev2_walk[idx]) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c->ev2[idx][0], c->ev2[idx][3]) == hipSuccess) { c->prof_ms[PS_WALK] += ms; c->prof_n[PS_WALK] += 1; }
+    } else
     for (int i = 0; i < kStage2Slots; ++i) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, c->ev2[idx][i], c->ev2[idx][i + 1]) == hipSuccess) { c->prof_ms[kStage1Slots + i] += ms; c->prof_n[kStage1Slots + i] += 1; }
@@ -125,6 +131,7 @@ hipEvent_t *next_ev2(se3d_ctx *c) {
   if (!c->prof) return nullptr;
   collect_profile(c, false);
   hipEvent_t *e = c->ev2[c->ev2_head];
+  c->ev2_walk[c->ev2_head] = false;
   c->ev2_head = (c->ev2_head + 1) % se3d_ctx::kRing;
   ++c->ev2_pending;
   return e;
@@ -584,6 +591,65 @@ int se3d_run_stage2(se3d_ctx *c, int32_t n_seq, int32_t frame_slot0, const doubl
   se3d_launch_stage2(Q, 0, n_seq, c->stream, next_ev2(c));
   HIPCHK(c, hipGetLastError());
   c->ran2 = true;
+  return SE3D_OK;
+}
+
+int se3d_run_stage2_walk(se3d_ctx *c, int32_t n_seq, int32_t n_steps, const int32_t *frame_slot0, const double *t) {
+  if (!c || !t || !frame_slot0 || n_seq < 1 || n_steps < 1 || n_steps > SE3D_WALK_MAX_STEPS) return SE3D_ERR_ARG;
+  if (!c->ran) { c->err = "se3d_run_stage2_walk needs a preceding se3d_run_stage1"; return SE3D_ERR_STATE; }
+  if ((size_t)n_steps * n_seq > (size_t)c->Q.S) { c->err = "se3d_run_stage2_walk: n_steps * n_seq exceeds limits.max_frames"; return SE3D_ERR_CAPACITY; }
+  for (int k = 0; k < n_steps; ++k)
+    if (frame_slot0[k] < 0 || frame_slot0[k] + n_seq > c->staged_frames) { c->err = "se3d_run_stage2_walk: frame slot outside the staged batch"; return SE3D_ERR_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const Se3dStage2 &Q0 = c->Q;
+  double *ht = c->h_t + (size_t)c->t_head * Q0.S;
+  (void)hipEventSynchronize(c->t_done[c->t_head]);
+  memcpy(ht, t, sizeof(double) * (size_t)n_seq * n_steps);
+  HIPCHK(c, hipMemcpyAsync(c->d_t, ht, sizeof(double) * (size_t)n_seq * n_steps, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->t_done[c->t_head], c->stream));
+  c->t_head = (c->t_head + 1) % se3d_ctx::kRing;
+  Se3dWalk Wk{};
+  Wk.n_steps = n_steps;
+  for (int k = 0; k < n_steps; ++k) Wk.slot0[k] = frame_slot0[k];
+  Wk.t = c->d_t; Wk.t_stride = n_seq;
+  Wk.outP = c->D.outP; Wk.out_count = c->D.out_count; Wk.fb = c->d_fb;
+  Wk.Wf = Q0.fused; Wk.Wp = Q0.pred; Wk.Wit = Q0.iters; Wk.Wn = Q0.n_out; Wk.Wdt = Q0.pred_dt;
+  hipEvent_t *ev = next_ev2(c);
+  if (ev) { c->ev2_walk[(c->ev2_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = true; (void)hipEventRecord(ev[0], c->stream); }
+  if (!se3d_launch_stage2_walk(Q0, Wk, n_seq, c->stream)) {
+    for (int k = 0; k < n_steps; ++k) {  // per-step kernels with the same per-step views (large association problems)
+      const size_t f0 = (size_t)frame_slot0[k];
+      Se3dStage2 Q = Q0;
+      Q.dets = Wk.outP + f0 * Q.H; Q.n_det = Wk.out_count + f0; Q.fb_delay = Wk.fb + f0 * Q.N; Q.t = c->d_t + (size_t)k * n_seq;
+      Q.fused = Q0.fused + f0 * Q.H; Q.pred = Q0.pred + f0 * Q.H; Q.iters = Q0.iters + f0 * Q.H; Q.n_out = Q0.n_out + f0; Q.pred_dt = Q0.pred_dt + f0;
+      se3d_launch_stage2(Q, 0, n_seq, c->stream, nullptr);
+    }
+  }
+  if (ev) (void)hipEventRecord(ev[3], c->stream);
+  HIPCHK(c, hipGetLastError());
+  c->ran2 = true;
+  return SE3D_OK;
+}
+
+int se3d_fetch_stage2_walk(se3d_ctx *c, int32_t frame_slot0, int32_t n_seq, se3d_fused_out *outs) {
+  if (!c || !outs || n_seq < 1 || frame_slot0 < 0 || frame_slot0 + n_seq > c->Q.S) return SE3D_ERR_ARG;
+  if (!c->ran2) { c->err = "fetch before run"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int rc = fetch_stage2_range(c, frame_slot0, n_seq, outs);
+  if (frame_slot0 > 0) {  // n_tracks is per-sequence state (current value), not per frame slot
+    HIPCHK(c, hipMemcpy(c->h_ntracks, c->Q.n_tracks, sizeof(int32_t) * (size_t)n_seq, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n_seq; ++k) outs[k].n_tracks = c->h_ntracks[k];
+  }
+  return rc;
+}
+
+int se3d_pack_stage2_walk_device(se3d_ctx *c, int32_t n_frames, void *d_persons, void *d_counts) {
+  if (!c || !d_persons || !d_counts || n_frames < 1 || n_frames > c->Q.S) return SE3D_ERR_ARG;
+  if (!c->ran2) return SE3D_ERR_STATE;
+  const Se3dStage2 &Q = c->Q;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(d_persons, Q.fused, sizeof(se3d_person3d) * (size_t)n_frames * Q.H, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_counts, Q.n_out, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
   return SE3D_OK;
 }
 

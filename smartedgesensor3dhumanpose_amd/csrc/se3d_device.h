@@ -130,6 +130,23 @@ struct Se3dStage2 {
   uint32_t *flags2;       // [S]
 };
 
+// Multi-step stage-2 walk (se3d_run_stage2_walk): step k consumes the stage-1 output of frame slots slot0[k] .. slot0[k]+S-1 and
+// writes its fused / predicted persons into the walk buffers at the same frame slots.
+#define SE3D_WALK_MAX_STEPS 64
+struct Se3dWalk {
+  int n_steps;
+  int slot0[SE3D_WALK_MAX_STEPS];
+  const double *t;             // [n_steps][t_stride] (device)
+  int t_stride;
+  const se3d_person3d *outP;   // stage-1 output [B][H]
+  const int32_t *out_count;    // [B]
+  const float *fb;             // [B][N]
+  se3d_person3d *Wf, *Wp;      // [B][H] fused / predicted persons per frame slot
+  int32_t *Wit;                // [B][H] LM iterations
+  int32_t *Wn;                 // [B] published persons per frame slot
+  double *Wdt;                 // [B] pred_delta_t per frame slot
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // feedback reprojection (pose_reprojection node).  N cameras, T = capacity in persons.
 // ---------------------------------------------------------------------------------------------------------------

@@ -561,34 +561,51 @@ __device__ __forceinline__ void se3d_eig4_smallest(const double g[10], double v[
 // vector of a nearby matrix (the sigma points of the unscented transform perturb two rows of the base system, so the
 // start error is ~1e-3 and the contraction per step is lambda_4 / lambda_3 << 1).  Returns false when 8 steps do not
 // reach a 1e-13 update (caller falls back to the Jacobi solver): same eigenvector, ~15x fewer fp64 operations.
+// 1/x and 1/sqrt(x) to ~1 ulp from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) and two Newton steps; the inverse
+// iteration below only needs them as scale factors, not correctly rounded.
+__device__ __forceinline__ double se3d_rcp64(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  return y;
+}
+__device__ __forceinline__ double se3d_rsq64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = __builtin_fma(__builtin_fma(-x * y, y, 1.0), 0.5 * y, y);
+  y = __builtin_fma(__builtin_fma(-x * y, y, 1.0), 0.5 * y, y);
+  return y;
+}
+
 __device__ __forceinline__ bool se3d_null_invit(const double g[10], const double v0[4], double v[4]) {
   const double tr = g[0] + g[4] + g[7] + g[9];
   const double tiny = 1e-30 * tr;
   double d0 = g[0];
   if (!(d0 > tiny)) return false;
-  const double i0 = 1.0 / d0;
+  const double i0 = se3d_rcp64(d0);
   const double l10 = g[1] * i0, l20 = g[2] * i0, l30 = g[3] * i0;
-  double d1 = g[4] - l10 * g[1];
+  double d1 = __builtin_fma(-l10, g[1], g[4]);
   if (!(d1 > tiny)) return false;
-  const double i1 = 1.0 / d1;
-  const double t21 = g[5] - l20 * g[1], t31 = g[6] - l30 * g[1];
+  const double i1 = se3d_rcp64(d1);
+  const double t21 = __builtin_fma(-l20, g[1], g[5]), t31 = __builtin_fma(-l30, g[1], g[6]);
   const double l21 = t21 * i1, l31 = t31 * i1;
-  double d2 = g[7] - l20 * g[2] - l21 * t21;
+  double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, g[2], g[7]));
   if (!(d2 > tiny)) return false;
-  const double i2 = 1.0 / d2;
-  const double t32 = g[8] - l30 * g[2] - l31 * t21;
+  const double i2 = se3d_rcp64(d2);
+  const double t32 = __builtin_fma(-l31, t21, __builtin_fma(-l30, g[2], g[8]));
   const double l32 = t32 * i2;
-  double d3 = g[9] - l30 * g[3] - l31 * t31 - l32 * t32;
+  double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, t31, __builtin_fma(-l30, g[3], g[9])));
   if (!(d3 > tiny)) d3 = tiny;  // numerically singular: the solve still returns the null direction
-  const double i3 = 1.0 / d3;
+  const double i3 = se3d_rcp64(d3);
   double x0 = v0[0], x1 = v0[1], x2 = v0[2], x3 = v0[3];
   bool conv = false;
   for (int it = 0; it < 8; ++it) {
     // L y = x ; z = D^-1 y ; L^T w = z
-    const double y0 = x0, y1 = x1 - l10 * y0, y2 = x2 - l20 * y0 - l21 * y1, y3 = x3 - l30 * y0 - l31 * y1 - l32 * y2;
-    const double w3 = y3 * i3, w2 = y2 * i2 - l32 * w3, w1 = y1 * i1 - l21 * w2 - l31 * w3, w0 = y0 * i0 - l10 * w1 - l20 * w2 - l30 * w3;
-    const double nn = 1.0 / sqrt(w0 * w0 + w1 * w1 + w2 * w2 + w3 * w3);
-    const double sgn = (w0 * x0 + w1 * x1 + w2 * x2 + w3 * x3) < 0.0 ? -nn : nn;
+    const double y0 = x0, y1 = __builtin_fma(-l10, y0, x1), y2 = __builtin_fma(-l21, y1, __builtin_fma(-l20, y0, x2)),
+                 y3 = __builtin_fma(-l32, y2, __builtin_fma(-l31, y1, __builtin_fma(-l30, y0, x3)));
+    const double w3 = y3 * i3, w2 = __builtin_fma(-l32, w3, y2 * i2), w1 = __builtin_fma(-l31, w3, __builtin_fma(-l21, w2, y1 * i1)),
+                 w0 = __builtin_fma(-l30, w3, __builtin_fma(-l20, w2, __builtin_fma(-l10, w1, y0 * i0)));
+    const double nn = se3d_rsq64(__builtin_fma(w3, w3, __builtin_fma(w2, w2, __builtin_fma(w1, w1, w0 * w0))));
+    const double sgn = __builtin_fma(w3, x3, __builtin_fma(w2, x2, __builtin_fma(w1, x1, w0 * x0))) < 0.0 ? -nn : nn;
     const double n0 = w0 * sgn, n1 = w1 * sgn, n2 = w2 * sgn, n3 = w3 * sgn;
     const double e = fabs(n0 - x0) + fabs(n1 - x1) + fabs(n2 - x2) + fabs(n3 - x3);
     x0 = n0; x1 = n1; x2 = n2; x3 = n3;
@@ -729,7 +746,8 @@ __global__ __launch_bounds__(256) void se3d_k_triangulate(Se3dDev D) {
 
   build(n);
   double ev[4];
-  se3d_eig4_smallest(gw_, ev);
+  const double e4start[4] = {0.0, 0.0, 0.0, 1.0};  // the null vector (X, Y, Z, 1)/|.| of a finite point always has a w component
+  if (!se3d_null_invit(gw_, e4start, ev)) se3d_eig4_smallest(gw_, ev);
   float X = (float)(ev[0] / ev[3]), Y = (float)(ev[1] / ev[3]), Z = (float)(ev[2] / ev[3]);
   double err = reproj(n, X, Y, Z);
   float avg_score = (float)(sconf / n);
@@ -760,7 +778,7 @@ __global__ __launch_bounds__(256) void se3d_k_triangulate(Se3dDev D) {
       remove_view(n, bestIndex);
       n = 2;
       build(n);
-      se3d_eig4_smallest(gw_, ev);
+      if (!se3d_null_invit(gw_, e4start, ev)) se3d_eig4_smallest(gw_, ev);
       X = (float)(ev[0] / ev[3]); Y = (float)(ev[1] / ev[3]); Z = (float)(ev[2] / ev[3]);
       err = reproj(n, X, Y, Z);
       avg_score = (T.cf[0] + T.cf[1]) / 2.0f;
@@ -783,7 +801,7 @@ __global__ __launch_bounds__(256) void se3d_k_triangulate(Se3dDev D) {
         for (int k = 0; k < 4; ++k) { w0[k] = T.r0[k][i] * cf; w1[k] = T.r1[k][i] * cf; }
         se3d_gram_add(g, w0, -1.0); se3d_gram_add(g, w1, -1.0);
         double e4[4];
-        se3d_eig4_smallest(g, e4);
+        if (!se3d_null_invit(g, ev, e4)) se3d_eig4_smallest(g, e4);
         cx_ = (float)(e4[0] / e4[3]); cy_ = (float)(e4[1] / e4[3]); cz_ = (float)(e4[2] / e4[3]);
         double se = 0.0, sc = 0.0;
         for (int v = 0; v < n; ++v) {

@@ -83,13 +83,9 @@ __device__ void s2_remove_old(const Se3dStage2 &Q, int s, double t, int *wsum, i
 // row Y — calc_normed_dist (PP:84-101) for every (detection, track): one workgroup per (track, sequence), threads over
 // detections; the track's previous estimate is de-normalised once into LDS.  C is column-major [det + n_det * track].
 // =============================================================================================================
-__global__ __launch_bounds__(128) void se3d_k_track_cost(Se3dStage2 Q) {
-  const int tk = blockIdx.x, s = blockIdx.y + Q.seq0, tid = threadIdx.x;
+__device__ __forceinline__ void s2_track_cost_body(const Se3dStage2 &Q, int tk, int s, int tid, int nthr, double (*pp)[3], double *wgt) {
   const int T = Q.T, H = Q.H;
-  const int nd = min(Q.n_det[s], H), nt = Q.n_tracks[s];
-  if (nd == 0 || tk >= nt) return;
-  __shared__ double pp[SE3D_NFU][3];
-  __shared__ double wgt[SE3D_NFU];
+  const int nd = min(Q.n_det[s], H);
   const size_t sl = (size_t)s * T + Q.order[(size_t)s * T + tk];
   const uint32_t has = Q.has[sl];
   const double delta_t = Q.t[s] - Q.trk_t_prev[sl];
@@ -101,7 +97,7 @@ __global__ __launch_bounds__(128) void se3d_k_track_cost(Se3dStage2 Q) {
   __syncthreads();
   const se3d_person3d *dets = Q.dets + (size_t)s * H;
   double *C = Q.C + (size_t)s * H * T;
-  for (int det = tid; det < nd; det += blockDim.x) {
+  for (int det = tid; det < nd; det += nthr) {
     int nj = 0;
     double dist = 0.0;
     for (int k = 0; k < SE3D_NFU; ++k) {
@@ -115,21 +111,27 @@ __global__ __launch_bounds__(128) void se3d_k_track_cost(Se3dStage2 Q) {
     C[det + (size_t)nd * tk] = nj > 0 ? dist / nj : 1e6;
   }
 }
+__global__ __launch_bounds__(128) void se3d_k_track_cost(Se3dStage2 Q) {
+  const int tk = blockIdx.x, s = blockIdx.y + Q.seq0;
+  if (min(Q.n_det[s], Q.H) == 0 || tk >= Q.n_tracks[s]) return;
+  __shared__ double pp[SE3D_NFU][3];
+  __shared__ double wgt[SE3D_NFU];
+  s2_track_cost_body(Q, tk, s, threadIdx.x, 128, pp, wgt);
+}
 
 // row L (distance part) — calc_3d_dist (PP:103-119) between every pair of live tracks of a sequence, as a bit matrix over
 // track slots.  Merging never modifies the surviving track (PP:872-876), so all tests can be evaluated up front.
-__global__ __launch_bounds__(64) void se3d_k_track_near(Se3dStage2 Q) {
-  const int si = blockIdx.x, s = blockIdx.y + Q.seq0, lane = threadIdx.x;
+__device__ __forceinline__ void s2_track_near_body(const Se3dStage2 &Q, int si, int s, int lane, double (*pi)[3]) {  // one wavefront
   const int T = Q.T;
-  if (min(Q.n_det[s], Q.H) == 0) return;
   const size_t sli = (size_t)s * T + si;
   unsigned long long *row = Q.near + sli * 4;
   if (!Q.used[sli]) { if (lane < 4) row[lane] = 0ull; return; }
-  __shared__ double pi[SE3D_NFU][3];
   const uint32_t hasi = Q.has[sli];
   if (lane < SE3D_NFU)
     for (int a = 0; a < 3; ++a) pi[lane][a] = Q.prev[(sli * SE3D_NFU + lane) * 3 + a] * Q.height_prev[sli] + Q.root_prev[sli * 3 + a];
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int w = 0; w < 4; ++w) {
     const int sj = w * 64 + lane;
     bool nr = false;
@@ -153,13 +155,18 @@ __global__ __launch_bounds__(64) void se3d_k_track_near(Se3dStage2 Q) {
     if (lane == 0) row[w] = b;
   }
 }
+__global__ __launch_bounds__(64) void se3d_k_track_near(Se3dStage2 Q) {
+  const int si = blockIdx.x, s = blockIdx.y + Q.seq0;
+  if (min(Q.n_det[s], Q.H) == 0) return;
+  __shared__ double pi[SE3D_NFU][3];
+  s2_track_near_body(Q, si, s, threadIdx.x, pi);
+}
 
 // =============================================================================================================
 // rows Y + A2 — track <-> detection association (PP:513-580).  One workgroup per sequence.
 // =============================================================================================================
-__global__ __launch_bounds__(256) void se3d_k_track_assoc(Se3dStage2 Q, int dyn_lds_bytes) {
-  extern __shared__ __align__(16) double s2_dynW[];  // Munkres working matrix when it fits, else HBM workspace
-  const int s = blockIdx.x + Q.seq0, tid = threadIdx.x;
+__device__ __forceinline__ void s2_track_assoc_body(const Se3dStage2 &Q, int s, double *s2_dynW, int dyn_lds_bytes) {  // blockDim.x == 256
+  const int tid = threadIdx.x;
   const int T = Q.T, H = Q.H, N = Q.N;
   __shared__ MunkresShared MS;
   __shared__ int assign[SE3D_MUNKRES_MAX];
@@ -240,6 +247,11 @@ __global__ __launch_bounds__(256) void se3d_k_track_assoc(Se3dStage2 Q, int dyn_
     Q.n_tracks[s] = nt + created;
     Q.next_id[s] += total_new;
   }
+}
+
+__global__ __launch_bounds__(256) void se3d_k_track_assoc(Se3dStage2 Q, int dyn_lds_bytes) {
+  extern __shared__ __align__(16) double s2_dynW_k[];  // Munkres working matrix when it fits, else HBM workspace
+  s2_track_assoc_body(Q, blockIdx.x + Q.seq0, s2_dynW_k, dyn_lds_bytes);
 }
 
 // =============================================================================================================
@@ -810,13 +822,9 @@ __device__ __forceinline__ void s2_cov6_to_mat(const double c[6], double M[9]) {
 // MODE 0: dense 63x63 H per wavefront (J^T J on MFMA); 1: Schur/Woodbury (MFMA) for solve and marginals; 2: forest elimination
 // for the LM solves + Schur/Woodbury (MFMA) marginals; 3: forest elimination for solves and marginals (no matrix product left)
 template <int MODE>
-__global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
+__device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, int lane,
+                                           typename std::conditional<MODE != 0, LmSchurLds, LmLds>::type &L) {  // one wavefront
   constexpr bool SCHUR = MODE != 0;
-  extern __shared__ __align__(16) unsigned char s2_smem[];
-  using LdsT = typename std::conditional<SCHUR, LmSchurLds, LmLds>::type;
-  LdsT &L = *reinterpret_cast<LdsT *>(s2_smem);
-  const int lane = threadIdx.x;
-  const int i = blockIdx.x, s = blockIdx.y + Q.seq0;
   const int H = Q.H, T = Q.T;
   if (i >= min(Q.n_det[s], H)) return;
   const int slot = Q.det_slot[(size_t)s * H + i];
@@ -1168,12 +1176,18 @@ __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
   if (threadIdx.x == 0) { atomicAdd(&g_lm_stamps[8], 1ull); atomicAdd(&g_lm_stamps[9], (unsigned long long)iterations); }
 #endif
 }
+template <int MODE>
+__global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
+  extern __shared__ __align__(16) unsigned char s2_smem[];
+  using LdsT = typename std::conditional<MODE != 0, LmSchurLds, LmLds>::type;
+  s2_lm_body<MODE>(Q, blockIdx.x, blockIdx.y + Q.seq0, threadIdx.x, *reinterpret_cast<LdsT *>(s2_smem));
+}
 
 // =============================================================================================================
 // row L + publishing — one workgroup per sequence (PP:845-852, 867-903, 909-910).
 // =============================================================================================================
-__global__ __launch_bounds__(256) void se3d_k_track_update(Se3dStage2 Q) {
-  const int s = blockIdx.x + Q.seq0, tid = threadIdx.x;
+__device__ __forceinline__ void s2_track_update_body(const Se3dStage2 &Q, int s) {  // blockDim.x == 256
+  const int tid = threadIdx.x;
   const int T = Q.T, H = Q.H;
   __shared__ int wsum[4];
   __shared__ int tmp[SE3D_MUNKRES_MAX];
@@ -1235,6 +1249,65 @@ __global__ __launch_bounds__(256) void se3d_k_track_update(Se3dStage2 Q) {
   }
 }
 
+__global__ __launch_bounds__(256) void se3d_k_track_update(Se3dStage2 Q) { s2_track_update_body(Q, blockIdx.x + Q.seq0); }
+
+// =============================================================================================================
+// Fused multi-step walk: one workgroup per sequence runs track association -> LM refinement -> track lifecycle for all time
+// steps of its sequence inside one launch.  The per-step kernels above are launch- and tail-latency bound when many short
+// sequences are replayed from HBM (every launch waits for the slowest LM wavefront of all sequences); here each sequence
+// advances at its own pace and the phases hand over through LDS / L1 with workgroup barriers only.
+// Same device code as the per-step kernels (s2_*_body), so results are identical.
+// =============================================================================================================
+struct LmWalkLds {  // per-wavefront LM workspace (tree variant) + per-wavefront scratch of se3d_k_track_near
+  LmSchurLds lm;
+};
+__global__ __launch_bounds__(256) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int dyn_lds_bytes) {
+  extern __shared__ __align__(16) unsigned char s2_walk_smem[];
+  __shared__ double pp[SE3D_NFU][3];
+  __shared__ double wgt[SE3D_NFU];
+  __shared__ double pi[4][SE3D_NFU][3];
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = Q.H, T = Q.T;
+  for (int k = 0; k < Wk.n_steps; ++k) {
+    const size_t f0 = (size_t)Wk.slot0[k];
+    Se3dStage2 q = Q;
+    q.dets = Wk.outP + f0 * H;
+    q.n_det = Wk.out_count + f0;
+    q.fb_delay = Wk.fb + f0 * Q.N;
+    q.t = Wk.t + (size_t)k * Wk.t_stride;
+    q.fused = Wk.Wf + f0 * H;
+    q.pred = Wk.Wp + f0 * H;
+    q.iters = Wk.Wit + f0 * H;
+    q.n_out = Wk.Wn + f0;
+    q.pred_dt = Wk.Wdt + f0;
+    const int nd = min(q.n_det[s], H);
+    if (nd > 0) {
+      const int nt = q.n_tracks[s];
+      for (int tk = 0; tk < nt; ++tk) {
+        s2_track_cost_body(q, tk, s, tid, 256, pp, wgt);
+        __syncthreads();
+      }
+    }
+    s2_track_assoc_body(q, s, reinterpret_cast<double *>(s2_walk_smem), dyn_lds_bytes);
+    __syncthreads();
+    if (nd > 0) {
+      LmSchurLds &L = reinterpret_cast<LmSchurLds *>(s2_walk_smem)[wave];
+      for (int i = wave; i < nd; i += 4) {
+        s2_lm_body<3>(q, i, s, lane, L);
+        __builtin_amdgcn_wave_barrier();
+      }
+      __syncthreads();
+      for (int si = wave; si < T; si += 4) {
+        s2_track_near_body(q, si, s, lane, pi[wave]);
+        __builtin_amdgcn_wave_barrier();
+      }
+      __syncthreads();
+      s2_track_update_body(q, s);
+    }
+    __syncthreads();
+  }
+}
+
 #ifdef SE3D_LM_STAMPS
 extern "C" void se3d_diag_lm_stamps(unsigned long long *out16, int reset) {
   (void)hipDeviceSynchronize();
@@ -1242,13 +1315,39 @@ extern "C" void se3d_diag_lm_stamps(unsigned long long *out16, int reset) {
   if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lm_stamps), z, sizeof(z)); }
 }
 #endif
-extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev) {
-  Se3dStage2 q = Q;
-  q.seq0 = seq0;
+static int s2_lm_mode() {
   static int lm_mode = -1;
   if (lm_mode < 0) {
     const char *e = getenv("SE3D_LM");  // A/B evidence switch: dense | schur | tree_mfma | tree (default)
     lm_mode = (e && strcmp(e, "dense") == 0) ? 0 : (e && strcmp(e, "schur") == 0) ? 1 : (e && strcmp(e, "tree_mfma") == 0) ? 2 : 3;
+  }
+  return lm_mode;
+}
+
+// true: the fused kernel was launched; false: not applicable (caller falls back to per-step launches)
+extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st) {
+  static int ok = -1;
+  const size_t lm_bytes = 4 * sizeof(LmSchurLds);
+  const size_t mk_bytes = (size_t)Q.H * Q.T * sizeof(double);
+  if (ok < 0) {
+    const char *e = getenv("SE3D_WALK");  // A/B evidence switch: steps = always use the per-step kernels
+    ok = !(e && strcmp(e, "steps") == 0) && s2_lm_mode() == 3;
+    if (ok) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_stage2_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_bytes);
+  }
+  if (!ok || mk_bytes > lm_bytes || nseq < 1) return false;  // large association problems keep the multi-workgroup per-step path
+  Se3dStage2 q = Q;
+  q.seq0 = 0;
+  hipLaunchKernelGGL(se3d_k_stage2_walk, dim3(nseq), dim3(256), lm_bytes, st, q, Wk, (int)lm_bytes);
+  return true;
+}
+
+extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev) {
+  Se3dStage2 q = Q;
+  q.seq0 = seq0;
+  const int lm_mode = s2_lm_mode();
+  static bool attr_set = false;
+  if (!attr_set) {
+    attr_set = true;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_track_assoc), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmLds));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmSchurLds));

@@ -106,6 +106,26 @@ class Skeleton3D:
             r.c = o
         return res
 
+    def run_stage2_walk(self, t, frame_slot0):
+        """t: [n_steps][n_seq] stamps; frame_slot0: [n_steps] first frame slot of each step.  One launch for the whole walk."""
+        t = np.ascontiguousarray(t, np.float64)
+        slots = np.ascontiguousarray(frame_slot0, np.int32)
+        assert t.ndim == 2 and len(slots) == t.shape[0]
+        self._chk(self._L.se3d_run_stage2_walk(C.c_void_p(self._h), t.shape[1], t.shape[0], pm.iptr(slots), t.ctypes.data_as(C.POINTER(C.c_double))),
+                  "se3d_run_stage2_walk")
+
+    def fetch_stage2_walk(self, frame_slot0, n_seq, capacity=None):
+        res = [pm.FusedResult(capacity or self.limits.max_hyp) for _ in range(n_seq)]
+        outs = (pm.FusedOut * n_seq)(*[r.c for r in res])
+        self._chk(self._L.se3d_fetch_stage2_walk(C.c_void_p(self._h), int(frame_slot0), n_seq, outs), "se3d_fetch_stage2_walk")
+        for r, o in zip(res, outs):
+            r.c = o
+        return res
+
+    def pack_stage2_walk_device(self, n_frames, persons_ptr, counts_ptr):
+        self._chk(self._L.se3d_pack_stage2_walk_device(C.c_void_p(self._h), int(n_frames), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)),
+                  "se3d_pack_stage2_walk_device")
+
     def pack_stage2_device(self, n_seq, persons_ptr, counts_ptr):
         """Asynchronous D2D copy of the last run_stage2 results ([n_seq][max_hyp] persons, [n_seq] counts); sync() before use."""
         self._chk(self._L.se3d_pack_stage2_device(C.c_void_p(self._h), int(n_seq), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)), "se3d_pack_stage2_device")

@@ -137,3 +137,75 @@ def test_device_pack_matches_host_fetch(extr_rig):
         assert u2[s].tobytes() == r2[s].fused[: r2[s].n_persons].tobytes()
         assert r2[s].n_persons == 3 + s  # frame 12: num_obs = 12 > 10
     node.close()
+
+
+@pytest.mark.parametrize("S_,T_,persons,mh", [(5, 14, 4, 16), (3, 16, 6, 8), (2, 12, 9, 64)])
+def test_stage2_walk_equals_per_step_and_oracle(extr_rig, oracle, demo_params, S_, T_, persons, mh):
+    """se3d_run_stage2_walk (one fused launch for all time steps; falls back to per-step kernels for max_hyp = 64) gives exactly what
+    T consecutive se3d_run_stage2 calls give, and matches the oracle; walked forward then backward (bench.py's ping-pong order)."""
+    seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=persons - (s % 2), n_frames=T_, seed=300 + s))[0] for s in range(S_)]
+    frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s
+    a = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=min(10, mh), max_hyp=mh)
+    b = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=min(10, mh), max_hyp=mh)
+    for nd in (a, b):
+        nd.stage(frames)
+        nd.run_stage1()
+        nd.refine_reset()
+    r1 = a.fetch_stage1(S_ * T_)
+    order = list(range(T_)) + list(range(T_ - 1, -1, -1))
+    t_of = [100.0 + (i + 1) / 30.0 for i in range(len(order))]
+    oras = [oracle.PosePrior(demo_params) for _ in range(S_)]
+    total = 0
+    for half in range(2):
+        ks = order[half * T_:(half + 1) * T_]
+        ts = t_of[half * T_:(half + 1) * T_]
+        a.run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in ks])
+        for k, t in zip(ks, ts):
+            b.run_stage2(np.full(S_, t), frame_slot0=k * S_)
+            rb = b.fetch_stage2(S_)
+            ra = a.fetch_stage2_walk(k * S_, S_)
+            for s in range(S_):
+                assert ra[s].n_persons == rb[s].n_persons
+                n = ra[s].n_persons
+                assert ra[s].fused[:n].tobytes() == rb[s].fused[:n].tobytes()
+                assert ra[s].fused_pred[:n].tobytes() == rb[s].fused_pred[:n].tobytes()
+                assert np.array_equal(ra[s].lm_iterations[:n], rb[s].lm_iterations[:n])
+                assert abs(ra[s].c.pred_delta_t - rb[s].c.pred_delta_t) == 0
+                o = oras[s].step(r1[k * S_ + s].published(), 16, t, seqs[s][k].fb_delay, capacity=mh)
+                compare_stage2(ra[s], o)
+                total += n
+    assert total > S_ * T_ * (persons - 1)
+    a.close()
+    b.close()
+
+
+def test_stage2_walk_device_pack(extr_rig):
+    import torch
+    from smartedgesensor3dhumanpose_amd import shard
+    S_, T_, H = 4, 12, 8
+    seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=5, n_frames=T_, seed=70 + s))[0] for s in range(S_)]
+    frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
+    node = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=H)
+    node.stage(frames)
+    node.run_stage1()
+    node.refine_reset()
+    psz = pm.person3d_dt.itemsize
+    p = torch.zeros(S_ * T_ * H * psz, dtype=torch.uint8, device="cuda")
+    c = torch.zeros(S_ * T_, dtype=torch.int32, device="cuda")
+    for rep in range(2):
+        ks = list(range(T_)) if rep == 0 else list(range(T_ - 1, -1, -1))
+        ts = [100.0 + (rep * T_ + i + 1) / 30.0 for i in range(T_)]
+        node.run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in ks])
+    node.pack_stage2_walk_device(S_ * T_, p.data_ptr(), c.data_ptr())
+    node.sync()
+    u = shard.unpack_skeletons(p.view(1, -1), c.view(1, -1), H)[0]
+    got = 0
+    for k in range(T_):
+        r = node.fetch_stage2_walk(k * S_, S_)
+        for s in range(S_):
+            n = r[s].n_persons
+            assert len(u[k * S_ + s]) == n
+            assert u[k * S_ + s].tobytes() == r[s].fused[:n].tobytes()
+            got += n
+    assert got == S_ * T_ * 5
+    node.close()
