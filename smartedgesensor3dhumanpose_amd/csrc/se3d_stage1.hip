@@ -402,14 +402,14 @@ __device__ __forceinline__ int se3d_block_excl_scan(bool flag, int *wsum /*LDS[5
   return off + within;
 }
 
-__global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b, int dyn_lds_bytes) {
-  extern __shared__ __align__(16) double s_dynW[];  // Munkres working matrix when it fits (dyn_lds_bytes), else HBM workspace
-  const int f = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void se3d_sweep_assign_body(const Se3dDev &D, int b, int f, double *s_dynW, int dyn_lds_bytes) {  // blockDim.x == 256
+  const int tid = threadIdx.x;
   const int N = D.d.N, P = D.d.P, H = D.d.H;
   if (D.nraw[f * N + b] == 0) return;  // camera without any detection is not part of the sweep (S3D:538-555)
   const int nh = D.nhyp[f];
   const int nd = D.nvalid[f * N + b];
   int32_t *assoc = D.assoc + (size_t)f * H * N;
+  __syncthreads();  // every wave has read nhyp before thread 0 updates it below
   if (nh == 0) {  // seeding from the first camera with a valid person (S3D:565-586)
     for (int k = tid; k < nd && k < H; k += 256) { assoc[(size_t)k * N + b] = k; D.nviews[f * H + k] = 1; }
     if (tid == 0) D.nhyp[f] = min(nd, H);
@@ -496,6 +496,78 @@ __global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b, int
     D.nhyp[f] = min(nn, H);
   }
   S1_STAMP(2)  // attach / spawn
+}
+__global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b, int dyn_lds_bytes) {
+  extern __shared__ __align__(16) double s_dynW_k[];  // Munkres working matrix when it fits (dyn_lds_bytes), else HBM workspace
+  se3d_sweep_assign_body(D, b, blockIdx.x, s_dynW_k, dyn_lds_bytes);
+}
+
+// Small problems (few cameras, H*P small): the whole camera sweep of a frame in ONE launch.  The per-step kernels above need the
+// whole GPU per step only when the cost gather is large; at 16 cameras x 8 detections the 2 x N dependent launches are pure launch
+// latency.  One workgroup per frame: thread <-> (hypothesis, detection) gathers its cost from the pair table in the reference's
+// accumulation order (ascending attached view), then the same assignment body runs; steps are separated by workgroup barriers.
+__device__ __forceinline__ void se3d_sweep_cost_small(const Se3dDev &D, int b, int f, int tid) {
+  const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
+  if (D.nraw[f * N + b] == 0) return;
+  const int nh = D.nhyp[f];
+  const int nd = D.nvalid[f * N + b];
+  if (nh == 0 || nd == 0) return;
+  const double max_epi = D.d.max_epi;
+  const double *tab = D.pair + (size_t)f * np * P * P;
+  for (int idx = tid; idx < nh * nd; idx += 256) {
+    const int h = idx % nh, q = idx / nh;
+    const int32_t *arow = D.assoc + ((size_t)f * H + h) * N;
+    const int n_obs = D.nviews[f * H + h];
+    const double tolerance = 1.0 - 1.0 / (2 * n_obs), veto_delta = 1.0 / n_obs;
+    double total = 0.0;
+    int nused = 0, cnt = 0;
+    for (int a0 = 0; a0 < b; a0 += 8) {  // 8 independent (assoc -> pair table, score) load chains in flight, ordered accumulation
+      int k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) k[u] = (a0 + u < b) ? arow[a0 + u] : -1;
+      double c[8];
+      float sc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        c[u] = -1.0; sc[u] = 0.f;
+        if (k[u] >= 0) {
+          c[u] = tab[((size_t)se3d_pair_index(a0 + u, b, N) * P + k[u]) * P + q];
+          sc[u] = D.pscore[((size_t)(f * N + a0 + u)) * P + k[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (c[u] >= 0.0) {
+          total += c[u];
+          ++nused;
+          if (c[u] > max_epi && (sc[u] > 0.5f || n_obs == 1)) ++cnt;
+        }
+      }
+    }
+    bool veto = false;
+    if (cnt > 0) {
+      double tmp = 0.0;
+      for (int i = 0; i < cnt; ++i) tmp += veto_delta;
+      veto = tmp > tolerance;
+    }
+    double C;
+    if (nused > 0) C = total / nused;
+    else { C = MAX_COSTS; veto = true; }
+    D.C[(size_t)f * H * P + h + (size_t)H * q] = C;
+    D.mask[(size_t)f * H * P + h + (size_t)H * q] = (!veto && C < max_epi) ? 1 : 0;
+  }
+}
+__global__ __launch_bounds__(256) void se3d_k_sweep_fused(Se3dDev D, int dyn_lds_bytes) {
+  extern __shared__ __align__(16) double s_dynW_f[];
+  const int f = blockIdx.x;
+  for (int b = 0; b < D.d.N; ++b) {
+    if (b > 0) {
+      se3d_sweep_cost_small(D, b, f, threadIdx.x);
+      __syncthreads();
+    }
+    se3d_sweep_assign_body(D, b, f, s_dynW_f, dyn_lds_bytes);
+    __syncthreads();
+  }
 }
 
 // =============================================================================================================
@@ -658,7 +730,7 @@ struct TriView {  // per-wave view list in LDS (structure of arrays, stride = N)
   int *cam;
 };
 
-__global__ __launch_bounds__(256) void se3d_k_triangulate(Se3dDev D) {
+__global__ __launch_bounds__(256, 4) void se3d_k_triangulate(Se3dDev D) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int f = blockIdx.y;
@@ -1087,9 +1159,19 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_assign), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     assign_attr = true;
   }
-  for (int b = 0; b < N; ++b) {
-    if (b > 0) hipLaunchKernelGGL(se3d_k_sweep_cost, dim3(H, B), dim3(128), 0, st, D, b);
-    hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), (size_t)dynW, st, D, b, dynW);
+  static int fused_limit = -1;  // H*P up to which the one-launch sweep is used (SE3D_SWEEP_FUSED_MAX overrides; 0 = never)
+  if (fused_limit < 0) {
+    const char *e = getenv("SE3D_SWEEP_FUSED_MAX");
+    fused_limit = e ? atoi(e) : 256;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  }
+  if (H * P <= fused_limit && dynW <= 64 * 1024) {
+    hipLaunchKernelGGL(se3d_k_sweep_fused, dim3(B), dim3(256), (size_t)dynW, st, D, dynW);
+  } else {
+    for (int b = 0; b < N; ++b) {
+      if (b > 0) hipLaunchKernelGGL(se3d_k_sweep_cost, dim3(H, B), dim3(128), 0, st, D, b);
+      hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), (size_t)dynW, st, D, b, dynW);
+    }
   }
   if (ev) (void)hipEventRecord(ev[3], st);
   const size_t lds = (size_t)4 * 15 * N * sizeof(float);

@@ -1261,7 +1261,7 @@ __global__ __launch_bounds__(256) void se3d_k_track_update(Se3dStage2 Q) { s2_tr
 struct LmWalkLds {  // per-wavefront LM workspace (tree variant) + per-wavefront scratch of se3d_k_track_near
   LmSchurLds lm;
 };
-__global__ __launch_bounds__(256) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int dyn_lds_bytes) {
+__global__ __launch_bounds__(256, 2) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int dyn_lds_bytes) {
   extern __shared__ __align__(16) unsigned char s2_walk_smem[];
   __shared__ double pp[SE3D_NFU][3];
   __shared__ double wgt[SE3D_NFU];
