@@ -11,7 +11,7 @@
 
 #include "se3d_device.h"
 
-extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st);
+extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st, int variant);
 extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled);
 extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev);
 extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st);
@@ -481,7 +481,8 @@ int se3d_hungarian(se3d_ctx *c, int32_t *assignment, double *cost, const double 
   HIPCHK(c, hipMalloc((void **)&d_assign, sizeof(int) * (size_t)(nR + 1)));
   d_status = d_assign + nR;
   HIPCHK(c, hipMemcpyAsync(d_dist, dist, sizeof(double) * (size_t)nR * nC, hipMemcpyHostToDevice, c->stream));
-  se3d_launch_munkres(d_dist, d_assign, d_status, nR, nC, c->stream);
+  const char *mv = getenv("SE3D_MUNKRES");  // A/B switch for the parity tests: block | wave | (automatic)
+  se3d_launch_munkres(d_dist, d_assign, d_status, nR, nC, c->stream, (mv && strcmp(mv, "block") == 0) ? 1 : (mv && strcmp(mv, "wave") == 0) ? 2 : 0);
   std::vector<int> h(nR + 1);
   HIPCHK(c, hipMemcpyAsync(h.data(), d_assign, sizeof(int) * (size_t)(nR + 1), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -135,6 +135,7 @@ struct Se3dStage2 {
 #define SE3D_WALK_MAX_STEPS 64
 struct Se3dWalk {
   int n_steps;
+  int lds_state;               // set by the launcher: per-track state staged in LDS for the duration of the walk
   int slot0[SE3D_WALK_MAX_STEPS];
   const double *t;             // [n_steps][t_stride] (device)
   int t_stride;

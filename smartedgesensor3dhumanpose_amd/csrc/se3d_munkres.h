@@ -354,3 +354,155 @@ __device__ __forceinline__ int se3d_munkres_block(double *dist, int ld, int nR, 
   __syncthreads();
   return fin == 2 ? 2 : 0;
 }
+
+// =============================================================================================================
+// Single-wavefront variant for nR, nC <= 64 (small association problems: 16 cameras x <= 8 detections, track association
+// of a handful of persons).  Same algorithm, same scan orders, same fp64 arithmetic per element as se3d_munkres_block —
+// but lane c owns column c (zero-row mask in a register), lane r owns row r (starCol / primeCol in registers, starRow on
+// the column lane), cover sets are uniform 64-bit masks and there is no workgroup barrier anywhere, so a frame / sequence
+// needs one wavefront instead of four and its latency-bound control flow leaves the other wave slots of the CU free.
+// dist: column-major (row + ld * col), modified in place; lane r touches row r only.  On return lane r < nR holds its column
+// (or -1) in assign_lane.  Returns 0, or 2 if the iteration guard fired.
+// =============================================================================================================
+__device__ __forceinline__ double se3d_wave_min_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t < v ? t : v; }
+  return v;
+}
+
+__device__ __forceinline__ int se3d_munkres_wave(double *dist, int ld, int nR, int nC, int lane, int &assign_lane) {
+  assign_lane = -1;
+  if (nR <= 0 || nC <= 0) return 0;
+  const int minDim = nR <= nC ? nR : nC;
+  const unsigned long long colsMask = nC >= 64 ? ~0ull : ((1ull << nC) - 1ull);
+  const bool inR = lane < nR;
+  const double DMAX = 1.7976931348623157e308;
+  unsigned long long zr = 0ull;  // lane c: rows of column c that hold a zero
+  int starCol = -1, primeCol = -1;  // lane r
+  int starRow = -1;                 // lane c
+  // ---- preliminary reduction (HUN:94-119 / 132-154) + zero masks ----
+  if (nR <= nC) {
+    double mn = DMAX;
+    if (inR)
+      for (int c = 0; c < nC; ++c) { const double v = dist[lane + ld * c]; mn = v < mn ? v : mn; }
+    for (int c = 0; c < nC; ++c) {
+      double v = 1.0;
+      if (inR) { v = dist[lane + ld * c] - mn; dist[lane + ld * c] = v; }
+      const unsigned long long m = __ballot(inR && fabs(v) < SE3D_DBL_EPSILON);
+      if (lane == c) zr = m;
+    }
+  } else {
+    for (int c = 0; c < nC; ++c) {
+      const double v = inR ? dist[lane + ld * c] : DMAX;
+      const double m0 = se3d_wave_min_f64(v);
+      const double a = v - m0;
+      if (inR) dist[lane + ld * c] = a;
+      const unsigned long long m = __ballot(inR && fabs(a) < SE3D_DBL_EPSILON);
+      if (lane == c) zr = m;
+    }
+  }
+  // ---- steps 1 / 2a: initial starring (HUN:121-130 / 156-168) ----
+  unsigned long long covR = 0ull, covC = 0ull;
+  if (nR <= nC) {
+    for (int r = 0; r < nR; ++r) {
+      const bool cand = ((zr >> r) & 1ull) && !((covC >> lane) & 1ull);
+      const unsigned long long b = __ballot(cand);
+      if (b) {
+        const int c = __ffsll((long long)b) - 1;
+        if (lane == r) starCol = c;
+        if (lane == c) starRow = r;
+        covC |= 1ull << c;
+      }
+    }
+  } else {
+    for (int c = 0; c < nC; ++c) {
+      const int rloc = __ffsll((long long)(zr & ~covR)) - 1;
+      const int r = __builtin_amdgcn_readlane(rloc, c);
+      if (r >= 0) {
+        if (lane == r) starCol = c;
+        if (lane == c) starRow = r;
+        covC |= 1ull << c;
+        covR |= 1ull << r;
+      }
+    }
+    covR = 0ull;
+  }
+  int guard = 0, st = -1;
+  for (;;) {
+    // ---- step 2b / 3 / 4 (HUN:245-363) ----
+    st = -1;
+    bool need2b = true, zerosFound = false;
+    int cur = -1;
+    while (st < 0) {
+      if (need2b) {
+        if (__popcll(covC) == minDim) { st = 1; break; }
+        need2b = false;
+        cur = -1;
+        zerosFound = false;
+      }
+      if (++guard > 4000000) { st = 2; break; }
+      const unsigned long long m = zr & ~covR;
+      const bool cand = (lane < nC) && (lane > cur) && !((covC >> lane) & 1ull) && (m != 0ull);
+      const unsigned long long b = __ballot(cand);
+      if (!b) {
+        if (zerosFound) { zerosFound = false; cur = -1; continue; }
+        st = 0;
+        break;
+      }
+      const int cf = __ffsll((long long)b) - 1;
+      const int rf = __builtin_amdgcn_readlane(__ffsll((long long)m) - 1, cf);
+      if (lane == rf) primeCol = cf;
+      const int sc = __builtin_amdgcn_readlane(starCol, rf);
+      if (sc >= 0) {
+        covR |= 1ull << rf;
+        covC &= ~(1ull << sc);
+        zerosFound = true;
+        cur = cf;
+      } else {  // step 4: augment along the alternating path
+        int row = rf, col = cf;
+        for (int it = 0; it < 2 * 64 + 2; ++it) {
+          const int sr = __builtin_amdgcn_readlane(starRow, col);
+          if (lane == row) starCol = col;
+          if (lane == col) starRow = row;
+          if (sr < 0) break;
+          const int pc = __builtin_amdgcn_readlane(primeCol, sr);
+          row = sr;
+          col = pc;
+        }
+        primeCol = -1;
+        covR = 0ull;
+        covC = __ballot(lane < nC && starRow >= 0);  // step 2a
+        need2b = true;
+      }
+    }
+    if (st != 0) break;
+    // ---- step 5 (HUN:366-397): only the elements that change ----
+    const bool rowCov = inR && ((covR >> lane) & 1ull);
+    const bool rowUnc = inR && !rowCov;
+    double h = DMAX;
+    for (unsigned long long cm = ~covC & colsMask; cm; cm &= cm - 1ull) {
+      const int c = __ffsll((long long)cm) - 1;
+      const double t = rowUnc ? dist[lane + ld * c] : DMAX;
+      h = t < h ? t : h;
+    }
+    h = se3d_wave_min_f64(h);
+    const double hadd = rowCov ? h : 0.0;
+    for (unsigned long long cm = ~covC & colsMask; cm; cm &= cm - 1ull) {  // uncovered columns: every row
+      const int c = __ffsll((long long)cm) - 1;
+      double x = 1.0;
+      if (inR) { x = (dist[lane + ld * c] + hadd) - h; dist[lane + ld * c] = x; }
+      const unsigned long long mz = __ballot(inR && fabs(x) < SE3D_DBL_EPSILON);
+      if (lane == c) zr = mz;
+    }
+    const unsigned long long mcov = __ballot(rowCov);
+    for (unsigned long long cm = covC & colsMask; cm; cm &= cm - 1ull) {   // covered columns: covered rows only
+      const int c = __ffsll((long long)cm) - 1;
+      double x = 1.0;
+      if (rowCov) { x = dist[lane + ld * c] + h; dist[lane + ld * c] = x; }
+      const unsigned long long mz = __ballot(rowCov && fabs(x) < SE3D_DBL_EPSILON);
+      if (lane == c) zr = (zr & ~mcov) | mz;
+    }
+  }
+  assign_lane = inR ? starCol : -1;
+  return st == 2 ? 2 : 0;
+}

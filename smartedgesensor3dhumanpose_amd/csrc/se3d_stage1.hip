@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b, int
 // whole GPU per step only when the cost gather is large; at 16 cameras x 8 detections the 2 x N dependent launches are pure launch
 // latency.  One workgroup per frame: thread <-> (hypothesis, detection) gathers its cost from the pair table in the reference's
 // accumulation order (ascending attached view), then the same assignment body runs; steps are separated by workgroup barriers.
-__device__ __forceinline__ void se3d_sweep_cost_small(const Se3dDev &D, int b, int f, int tid) {
+__device__ __forceinline__ void se3d_sweep_cost_small(const Se3dDev &D, int b, int f, int tid, int nthr) {
   const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
   if (D.nraw[f * N + b] == 0) return;
   const int nh = D.nhyp[f];
@@ -514,7 +514,7 @@ __device__ __forceinline__ void se3d_sweep_cost_small(const Se3dDev &D, int b, i
   if (nh == 0 || nd == 0) return;
   const double max_epi = D.d.max_epi;
   const double *tab = D.pair + (size_t)f * np * P * P;
-  for (int idx = tid; idx < nh * nd; idx += 256) {
+  for (int idx = tid; idx < nh * nd; idx += nthr) {
     const int h = idx % nh, q = idx / nh;
     const int32_t *arow = D.assoc + ((size_t)f * H + h) * N;
     const int n_obs = D.nviews[f * H + h];
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void se3d_k_sweep_fused(Se3dDev D, int dyn_lds
   const int f = blockIdx.x;
   for (int b = 0; b < D.d.N; ++b) {
     if (b > 0) {
-      se3d_sweep_cost_small(D, b, f, threadIdx.x);
+      se3d_sweep_cost_small(D, b, f, threadIdx.x, 256);
       __syncthreads();
     }
     se3d_sweep_assign_body(D, b, f, s_dynW_f, dyn_lds_bytes);
@@ -1120,6 +1120,81 @@ __global__ __launch_bounds__(256) void se3d_k_postprocess(Se3dDev D) {
   }
 }
 
+// Single-wavefront sweep for H, P <= 64: same decisions as se3d_sweep_assign_body (seeding, feasibility counts, "last feasible
+// detection wins", Hungarian on the unmasked costs only when ambiguous, attach / spawn order), expressed with ballots.
+__device__ __forceinline__ void se3d_sweep_assign_wave(const Se3dDev &D, int b, int f, int lane, double *W) {
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  if (D.nraw[f * N + b] == 0) return;  // S3D:538-555
+  const int nh = D.nhyp[f];
+  const int nd = D.nvalid[f * N + b];
+  int32_t *assoc = D.assoc + (size_t)f * H * N;
+  if (nh == 0) {  // seeding (S3D:565-586)
+    if (lane < nd && lane < H) { assoc[(size_t)lane * N + b] = lane; D.nviews[f * H + lane] = 1; }
+    if (lane == 0) D.nhyp[f] = min(nd, H);
+    return;
+  }
+  if (nd == 0) return;
+  const uint8_t *mask = D.mask + (size_t)f * H * P;
+  int cnt = 0, assign = -1;
+  if (lane < nh)
+    for (int q = 0; q < nd; ++q)
+      if (mask[lane + (size_t)H * q]) { ++cnt; assign = q; }   // S3D:620-623
+  int ccnt = 0;
+  if (lane < nd)
+    for (int h = 0; h < nh; ++h) ccnt += mask[h + (size_t)H * lane];
+  if (__ballot(cnt > 1 || ccnt > 1)) {  // S3D:628-634
+    const double *C = D.C + (size_t)f * H * P;
+    if (lane < nh)
+      for (int q = 0; q < nd; ++q) W[lane + nh * q] = C[lane + (size_t)H * q];
+    const int rc = se3d_munkres_wave(W, nh, nh, nd, lane, assign);
+    if (rc != 0 && lane == 0) atomicOr(&D.flags[f], 4u);
+  }
+  // attach or spawn (S3D:636-660)
+  bool sp = false;
+  const int det = (lane < nh) ? assign : -1;
+  if (det >= 0) {
+    if (mask[lane + (size_t)H * det]) {
+      assoc[(size_t)lane * N + b] = det;
+      D.nviews[f * H + lane] += 1;
+    } else {
+      sp = true;
+    }
+  }
+  bool handled = false;
+  for (int h = 0; h < nh; ++h) handled |= (__builtin_amdgcn_readlane(det, h) == lane);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned long long spb = __ballot(sp);
+  const int tot1 = __popcll(spb);
+  if (sp) {
+    const int nhh = nh + __popcll(spb & lt);
+    if (nhh < H) { assoc[(size_t)nhh * N + b] = det; D.nviews[f * H + nhh] = 1; }
+  }
+  const bool un = (lane < nd) && !handled;  // S3D:662-673
+  const unsigned long long unb = __ballot(un);
+  const int tot2 = __popcll(unb);
+  if (un) {
+    const int nhh = nh + tot1 + __popcll(unb & lt);
+    if (nhh < H) { assoc[(size_t)nhh * N + b] = lane; D.nviews[f * H + nhh] = 1; }
+  }
+  if (lane == 0) {
+    const int nn = nh + tot1 + tot2;
+    if (nn > H) atomicOr(&D.flags[f], SE3D_FLAG_HYP_OVERFLOW);
+    D.nhyp[f] = min(nn, H);
+  }
+}
+__global__ __launch_bounds__(64) void se3d_k_sweep_fused_wave(Se3dDev D) {
+  extern __shared__ __align__(16) double s_dynW_w[];
+  const int f = blockIdx.x, lane = threadIdx.x;
+  for (int b = 0; b < D.d.N; ++b) {
+    if (b > 0) {
+      se3d_sweep_cost_small(D, b, f, lane, 64);
+      __syncthreads();  // one wavefront: orders the global C / mask stores before the loads of other lanes
+    }
+    se3d_sweep_assign_wave(D, b, f, lane, s_dynW_w);
+    __syncthreads();
+  }
+}
+
 // stand-alone Munkres (se3d_hungarian): one workgroup, dist column-major with ld = nR
 __global__ __launch_bounds__(256) void se3d_k_munkres(double *dist, int *assign, int *status, int nR, int nC) {
   __shared__ MunkresShared S;
@@ -1130,8 +1205,17 @@ __global__ __launch_bounds__(256) void se3d_k_munkres(double *dist, int *assign,
   for (int r = threadIdx.x; r < nR; r += 256) assign[r] = a[r];
   if (threadIdx.x == 0) *status = rc;
 }
-extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st) {
-  hipLaunchKernelGGL(se3d_k_munkres, dim3(1), dim3(256), 0, st, d_dist, d_assign, d_status, nR, nC);
+__global__ __launch_bounds__(64) void se3d_k_munkres_wave(double *dist, int *assign, int *status, int nR, int nC) {
+  int a;
+  const int rc = se3d_munkres_wave(dist, nR, nR, nC, threadIdx.x, a);
+  if ((int)threadIdx.x < nR) assign[threadIdx.x] = a;
+  if (threadIdx.x == 0) *status = rc;
+}
+// variant: 0 = automatic (single-wavefront code for problems up to 64 x 64), 1 = block-cooperative, 2 = single wavefront
+extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st, int variant) {
+  const bool small = nR <= 64 && nC <= 64;
+  if (small && variant != 1) hipLaunchKernelGGL(se3d_k_munkres_wave, dim3(1), dim3(64), 0, st, d_dist, d_assign, d_status, nR, nC);
+  else hipLaunchKernelGGL(se3d_k_munkres, dim3(1), dim3(256), 0, st, d_dist, d_assign, d_status, nR, nC);
 }
 
 // =============================================================================================================
@@ -1165,7 +1249,11 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     fused_limit = e ? atoi(e) : 256;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   }
-  if (H * P <= fused_limit && dynW <= 64 * 1024) {
+  static int sweep_wave = -1;  // SE3D_SWEEP_WAVE=0 keeps the 256-thread workgroup per frame (A/B evidence)
+  if (sweep_wave < 0) { const char *e = getenv("SE3D_SWEEP_WAVE"); sweep_wave = e ? atoi(e) : 1; }
+  if (sweep_wave && H <= 64 && P <= 64 && H * P <= 8 * fused_limit) {
+    hipLaunchKernelGGL(se3d_k_sweep_fused_wave, dim3(B), dim3(64), (size_t)dynW, st, D);
+  } else if (H * P <= fused_limit && dynW <= 64 * 1024) {
     hipLaunchKernelGGL(se3d_k_sweep_fused, dim3(B), dim3(256), (size_t)dynW, st, D, dynW);
   } else {
     for (int b = 0; b < N; ++b) {

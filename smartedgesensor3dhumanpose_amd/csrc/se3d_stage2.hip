@@ -1124,11 +1124,16 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
     for (int w = lane; w < (int)(sizeof(se3d_person3d) / 4); w += 64) { w0[w] = 0u; w1[w] = 0u; }
   }
   __builtin_amdgcn_wave_barrier();
+  LM_STAMP(7)  // (diag) outputs: zero fill
   const int track_id = Q.id[sl];
   if (lane == 0) { pf.id = (uint32_t)track_id; pp.id = (uint32_t)track_id; }
   const double pred_dt = Q.pred_dt[s];
   const int fslot = Q.frame_nr[s] % 3;
   const double gtprev = Q.t_prev[s];
+#ifdef SE3D_LM_STAMPS
+  if (pred_dt + gtprev + fslot + track_id == -12345.678) return;  // force the loads to complete before the stamp
+#endif
+  LM_STAMP(15)  // (diag) outputs: scalar loads
   if (lane < SE3D_NFU) {
     double *velk = Q.vel + (sl * SE3D_NFU + lane) * 9;
     if (measured) {
@@ -1258,53 +1263,288 @@ __global__ __launch_bounds__(256) void se3d_k_track_update(Se3dStage2 Q) { s2_tr
 // advances at its own pace and the phases hand over through LDS / L1 with workgroup barriers only.
 // Same device code as the per-step kernels (s2_*_body), so results are identical.
 // =============================================================================================================
-struct LmWalkLds {  // per-wavefront LM workspace (tree variant) + per-wavefront scratch of se3d_k_track_near
-  LmSchurLds lm;
-};
-__global__ __launch_bounds__(256, 2) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int dyn_lds_bytes) {
+__device__ __forceinline__ void s2_wave_mem_sync() {  // stores of this wavefront visible to its other lanes' loads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---- single-wavefront forms of the per-sequence bookkeeping (T, H <= 64): same decisions, ballots instead of barriers ----
+__device__ __forceinline__ int s2_nth_set_bit(unsigned long long m, int n) {  // index of the n-th (0-based) set bit, -1 if none
+  for (int i = 0; i < n; ++i) m &= m - 1ull;
+  return m ? __ffsll((long long)m) - 1 : -1;
+}
+
+// calc_normed_dist (PP:84-101) for every (detection, track) pair, flattened over the threads of the workgroup
+__device__ __forceinline__ void s2_track_cost_flat(const Se3dStage2 &Q, int s, int tid, int nthr) {
+  const int T = Q.T, H = Q.H;
+  const int nd = min(Q.n_det[s], H), nt = Q.n_tracks[s];
+  const se3d_person3d *dets = Q.dets + (size_t)s * H;
+  double *C = Q.C + (size_t)s * H * T;
+  const double t = Q.t[s];
+  for (int idx = tid; idx < nd * nt; idx += nthr) {
+    const int det = idx % nd, tk = idx / nd;
+    const size_t sl = (size_t)s * T + Q.order[(size_t)s * T + tk];
+    const uint32_t has = Q.has[sl];
+    const double delta_t = t - Q.trk_t_prev[sl];
+    const double hp = Q.height_prev[sl];
+    const double r0 = Q.root_prev[sl * 3 + 0], r1 = Q.root_prev[sl * 3 + 1], r2 = Q.root_prev[sl * 3 + 2];
+    int nj = 0;
+    double dist = 0.0;
+    for (int k = 0; k < SE3D_NFU; ++k) {
+      const se3d_keypoint3d &kp = dets[det].keypoints[k];
+      if (kp.score > 0.10f && ((has >> k) & 1u)) {
+        const double *pv = Q.prev + (sl * SE3D_NFU + k) * 3;
+        const double dx = kp.joint[0] - (pv[0] * hp + r0), dy = kp.joint[1] - (pv[1] * hp + r1), dz = kp.joint[2] - (pv[2] * hp + r2);
+        dist += sqrt(dx * dx + dy * dy + dz * dz) / (c_vel_sigmas[k] * delta_t);
+        ++nj;
+      }
+    }
+    C[det + (size_t)nd * tk] = nj > 0 ? dist / nj : 1e6;
+  }
+}
+
+__device__ __forceinline__ void s2_remove_old_wave(const Se3dStage2 &Q, int s, double t, int lane) {  // PP:191-211
+  const int T = Q.T;
+  const int nt = Q.n_tracks[s];
+  int *order = Q.order + (size_t)s * T;
+  int slot = -1;
+  bool keep = false;
+  if (lane < nt) {
+    slot = order[lane];
+    keep = !(t - Q.trk_t_prev[(size_t)s * T + slot] > 1.0);
+    if (!keep) Q.used[(size_t)s * T + slot] = 0;
+  }
+  const unsigned long long km = __ballot(keep);
+  if (keep) order[__popcll(km & ((1ull << lane) - 1ull))] = slot;
+  if (lane == 0) Q.n_tracks[s] = __popcll(km);
+}
+
+// rows Y + A2 (PP:513-580) by one wavefront.  W: LDS scratch of nd * nt doubles.
+__device__ __forceinline__ void s2_track_assoc_wave(const Se3dStage2 &Q, int s, int lane, double *W) {
+  const int T = Q.T, H = Q.H, N = Q.N;
+  const double t = Q.t[s];
+  const int nd = min(Q.n_det[s], H);
+  const int nt = Q.n_tracks[s];
+  if (lane == 0) {  // feedback-delay moving average -> pred_delta_t (PP:513-526)
+    double acc = 0.0;
+    int nv = 0;
+    for (int i = 0; i < N; ++i) {
+      const float d = Q.fb_delay ? Q.fb_delay[(size_t)s * N + i] : -1.0f;
+      if (d > 0.0f) { acc += (double)d; ++nv; }
+    }
+    const double cur = nv > 0 ? acc / nv : 0.10;
+    Q.fb_buf[s * 3 + (Q.frame_nr[s] % 3)] = cur;
+    Q.pred_dt[s] = (0.0 + Q.fb_buf[s * 3 + 0] + Q.fb_buf[s * 3 + 1] + Q.fb_buf[s * 3 + 2]) / 3;
+    Q.n_out[s] = 0;
+  }
+  if (lane < H) { Q.det_slot[(size_t)s * H + lane] = -1; Q.pub[(size_t)s * H + lane] = 0; }
+  if (nd == 0) {  // PP:537-546
+    s2_remove_old_wave(Q, s, t, lane);
+    if (lane == 0) Q.t_prev[s] = t;
+    return;
+  }
+  int *order = Q.order + (size_t)s * T;
+  const double *C = Q.C + (size_t)s * H * T;
+  int assign = -1;
+  if (nt > 0) {
+    if (lane < nd)
+      for (int tk = 0; tk < nt; ++tk) W[lane + nd * tk] = C[lane + (size_t)nd * tk];
+    const int rc = se3d_munkres_wave(W, nd, nd, nt, lane, assign);
+    if (rc != 0 && lane == 0) atomicOr(&Q.flags2[s], 4u);
+    if (lane < nd && assign >= 0 && C[lane + (size_t)nd * assign] > 5.0) assign = -1;  // PP:562-565
+  }
+  // new tracks for unassigned detections, in detection order (PP:570-580)
+  const bool isnew = (lane < nd) && (nt == 0 || assign < 0);
+  const unsigned long long nb = __ballot(isnew);
+  const int p = __popcll(nb & ((1ull << lane) - 1ull)), total_new = __popcll(nb);
+  const unsigned long long frb = __ballot((lane < T) && !Q.used[(size_t)s * T + lane]);
+  const int total_free = __popcll(frb);
+  const int next_id = Q.next_id[s];
+  if (lane < nd) {
+    if (!isnew) {
+      Q.det_slot[(size_t)s * H + lane] = order[assign];
+    } else if (nt + p < T && p < total_free) {
+      const int slot = s2_nth_set_bit(frb, p);
+      const size_t sl = (size_t)s * T + slot;
+      Q.used[sl] = 1;
+      Q.id[sl] = next_id + p;
+      Q.num_obs[sl] = 0;
+      Q.has[sl] = 0;
+      Q.trk_t_prev[sl] = t;
+      Q.height_prev[sl] = -1.0;
+      for (int a = 0; a < 3; ++a) Q.root_prev[sl * 3 + a] = 0.0;
+      for (int a = 0; a < SE3D_NFU * 9; ++a) Q.vel[sl * SE3D_NFU * 9 + a] = 0.0;
+      order[nt + p] = slot;
+      Q.det_slot[(size_t)s * H + lane] = slot;
+    } else {
+      atomicOr(&Q.flags2[s], 1u);  // track capacity exceeded
+    }
+  }
+  if (lane == 0) {
+    const int created = min(total_new, min(T - nt, total_free));
+    Q.n_tracks[s] = nt + created;
+    Q.next_id[s] = next_id + total_new;
+  }
+}
+
+// row L + publishing (PP:845-852, 867-903, 909-910) by one wavefront
+__device__ __forceinline__ void s2_track_update_wave(const Se3dStage2 &Q, int s, int lane) {
+  const int T = Q.T, H = Q.H;
+  const int nd = min(Q.n_det[s], H);
+  if (nd == 0) return;
+  const double t = Q.t[s];
+  const bool pb = (lane < nd) && Q.pub[(size_t)s * H + lane];
+  const unsigned long long pbm = __ballot(pb);
+  const int n_out = __popcll(pbm);
+  const int words = (int)(sizeof(se3d_person3d) / 4);
+  int p = 0;
+  for (unsigned long long m = pbm; m; m &= m - 1ull, ++p) {  // publish in detection order
+    const int srcd = __ffsll((long long)m) - 1;
+    const size_t src = (size_t)s * H + srcd, dst = (size_t)s * H + p;
+    const uint32_t *f0 = reinterpret_cast<const uint32_t *>(&Q.fused_det[src]), *p0 = reinterpret_cast<const uint32_t *>(&Q.pred_det[src]);
+    uint32_t *f1 = reinterpret_cast<uint32_t *>(&Q.fused[dst]), *p1 = reinterpret_cast<uint32_t *>(&Q.pred[dst]);
+    for (int w = lane; w < words; w += 64) { f1[w] = f0[w]; p1[w] = p0[w]; }
+    if (lane == 0) Q.iters[dst] = Q.iters_det[src];
+  }
+  s2_remove_old_wave(Q, s, t, lane);
+  s2_wave_mem_sync();  // order[] / n_tracks / fused[].id written above by other lanes of this wavefront
+  // merge overlapping tracks (PP:870-903): sequential in i, all later j in parallel (track i is not modified by a merge)
+  const int nt = Q.n_tracks[s];
+  int *order = Q.order + (size_t)s * T;
+  const int slotv = (lane < nt) ? order[lane] : 0;
+  unsigned long long alive = nt >= 64 ? ~0ull : ((1ull << nt) - 1ull);
+  for (int i = 0; i < nt; ++i) {
+    if (!((alive >> i) & 1ull)) continue;
+    const int slot_i = __builtin_amdgcn_readlane(slotv, i);
+    const size_t si = (size_t)s * T + slot_i;
+    bool kill = false;
+    if (lane > i && lane < nt && ((alive >> lane) & 1ull)) {
+      const size_t sj = (size_t)s * T + slotv;
+      if ((Q.near[si * 4 + (slotv >> 6)] >> (slotv & 63)) & 1ull) {  // se3d_k_track_near: closer than g_merge_dist_thresh
+        kill = true;
+        Q.used[sj] = 0;
+        const uint32_t idj = (uint32_t)Q.id[sj], idi = (uint32_t)Q.id[si];
+        for (int pp2 = 0; pp2 < n_out; ++pp2)  // re-assign id in the persons messages (PP:893-898)
+          if (Q.fused[(size_t)s * H + pp2].id == idj) { Q.fused[(size_t)s * H + pp2].id = idi; Q.pred[(size_t)s * H + pp2].id = idi; }
+      }
+    }
+    alive &= ~__ballot(kill);
+  }
+  const bool kp = (lane < nt) && ((alive >> lane) & 1ull);
+  const unsigned long long km = __ballot(kp);
+  if (kp) order[__popcll(km & ((1ull << lane) - 1ull))] = slotv;
+  if (lane == 0) {
+    Q.n_tracks[s] = __popcll(km);
+    Q.n_out[s] = n_out;
+    Q.t_prev[s] = t;
+    Q.frame_nr[s] += 1;
+  }
+}
+
+#define S2_WALK_WAVES 4
+#ifdef SE3D_LM_STAMPS
+#define WK_STAMP_INIT unsigned long long wk_prev_ = __builtin_readcyclecounter();
+#define WK_STAMP(idx) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_lm_stamps[idx], now_ - wk_prev_); wk_prev_ = now_; }
+#else
+#define WK_STAMP_INIT
+#define WK_STAMP(idx)
+#endif
+__global__ __launch_bounds__(64 * S2_WALK_WAVES) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk) {
   extern __shared__ __align__(16) unsigned char s2_walk_smem[];
-  __shared__ double pp[SE3D_NFU][3];
-  __shared__ double wgt[SE3D_NFU];
-  __shared__ double pi[4][SE3D_NFU][3];
+  __shared__ double pi[S2_WALK_WAVES][SE3D_NFU][3];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = Q.H, T = Q.T;
+  constexpr int NT = 64 * S2_WALK_WAVES;
+  // Per-track state of this sequence lives in LDS for the duration of the walk when it fits (Wk.lds_state): every phase touches
+  // it through the same Se3dStage2 pointers (rebased generic pointers), at LDS instead of HBM/L2 latency.
+  Se3dStage2 Qs = Q;
+  double *l_prev = nullptr, *l_vel = nullptr, *l_root = nullptr, *l_height = nullptr, *l_tprev = nullptr;
+  uint32_t *l_has = nullptr;
+  int32_t *l_id = nullptr, *l_nobs = nullptr;
+  uint8_t *l_used = nullptr;
+  if (Wk.lds_state) {
+    double *b = reinterpret_cast<double *>(s2_walk_smem + S2_WALK_WAVES * sizeof(LmSchurLds));
+    l_prev = b; b += (size_t)T * SE3D_NFU * 3;
+    l_vel = b; b += (size_t)T * SE3D_NFU * 9;
+    l_root = b; b += (size_t)T * 3;
+    l_height = b; b += T;
+    l_tprev = b; b += T;
+    l_has = reinterpret_cast<uint32_t *>(b);
+    l_id = reinterpret_cast<int32_t *>(l_has + T);
+    l_nobs = l_id + T;
+    l_used = reinterpret_cast<uint8_t *>(l_nobs + T);
+    const size_t g0 = (size_t)s * T;
+    for (int i = tid; i < T * SE3D_NFU * 3; i += NT) l_prev[i] = Q.prev[g0 * SE3D_NFU * 3 + i];
+    for (int i = tid; i < T * SE3D_NFU * 9; i += NT) l_vel[i] = Q.vel[g0 * SE3D_NFU * 9 + i];
+    for (int i = tid; i < T * 3; i += NT) l_root[i] = Q.root_prev[g0 * 3 + i];
+    for (int i = tid; i < T; i += NT) {
+      l_height[i] = Q.height_prev[g0 + i]; l_tprev[i] = Q.trk_t_prev[g0 + i]; l_has[i] = Q.has[g0 + i];
+      l_id[i] = Q.id[g0 + i]; l_nobs[i] = Q.num_obs[g0 + i]; l_used[i] = Q.used[g0 + i];
+    }
+    Qs.prev = l_prev; Qs.vel = l_vel; Qs.root_prev = l_root; Qs.height_prev = l_height; Qs.trk_t_prev = l_tprev;
+    Qs.has = l_has; Qs.id = l_id; Qs.num_obs = l_nobs; Qs.used = l_used;
+    __syncthreads();
+  }
+  {  // every per-sequence array is rebased to this sequence, so the phase bodies run with sequence index 0
+    const size_t g0 = (size_t)s * T;
+    if (!Wk.lds_state) {
+      Qs.prev += g0 * SE3D_NFU * 3; Qs.vel += g0 * SE3D_NFU * 9; Qs.root_prev += g0 * 3; Qs.height_prev += g0; Qs.trk_t_prev += g0;
+      Qs.has += g0; Qs.id += g0; Qs.num_obs += g0; Qs.used += g0;
+    }
+    Qs.fb_buf += (size_t)s * 3; Qs.t_prev += s; Qs.next_id += s; Qs.frame_nr += s; Qs.n_tracks += s; Qs.order += g0;
+    Qs.C += (size_t)s * H * T; Qs.W += (size_t)s * H * T; Qs.near += g0 * 4; Qs.det_slot += (size_t)s * H; Qs.pub += (size_t)s * H;
+    Qs.fused_det += (size_t)s * H; Qs.pred_det += (size_t)s * H; Qs.iters_det += (size_t)s * H; Qs.flags2 += s;
+  }
+  const int s0 = 0;
   for (int k = 0; k < Wk.n_steps; ++k) {
-    const size_t f0 = (size_t)Wk.slot0[k];
-    Se3dStage2 q = Q;
+    const size_t f0 = (size_t)Wk.slot0[k] + s;
+    Se3dStage2 q = Qs;
     q.dets = Wk.outP + f0 * H;
     q.n_det = Wk.out_count + f0;
     q.fb_delay = Wk.fb + f0 * Q.N;
-    q.t = Wk.t + (size_t)k * Wk.t_stride;
+    q.t = Wk.t + (size_t)k * Wk.t_stride + s;
     q.fused = Wk.Wf + f0 * H;
     q.pred = Wk.Wp + f0 * H;
     q.iters = Wk.Wit + f0 * H;
     q.n_out = Wk.Wn + f0;
     q.pred_dt = Wk.Wdt + f0;
-    const int nd = min(q.n_det[s], H);
-    if (nd > 0) {
-      const int nt = q.n_tracks[s];
-      for (int tk = 0; tk < nt; ++tk) {
-        s2_track_cost_body(q, tk, s, tid, 256, pp, wgt);
-        __syncthreads();
-      }
-    }
-    s2_track_assoc_body(q, s, reinterpret_cast<double *>(s2_walk_smem), dyn_lds_bytes);
+    const int nd = min(q.n_det[s0], H);
+    WK_STAMP_INIT
+    if (nd > 0) s2_track_cost_flat(q, s0, tid, 64 * S2_WALK_WAVES);
     __syncthreads();
+    WK_STAMP(10)  // track cost
+    if (wave == 0) s2_track_assoc_wave(q, s0, lane, reinterpret_cast<double *>(s2_walk_smem));
+    __syncthreads();
+    WK_STAMP(11)  // association (Munkres)
     if (nd > 0) {
       LmSchurLds &L = reinterpret_cast<LmSchurLds *>(s2_walk_smem)[wave];
-      for (int i = wave; i < nd; i += 4) {
-        s2_lm_body<3>(q, i, s, lane, L);
+      for (int i = wave; i < nd; i += S2_WALK_WAVES) {
+        s2_lm_body<3>(q, i, s0, lane, L);
         __builtin_amdgcn_wave_barrier();
       }
       __syncthreads();
-      for (int si = wave; si < T; si += 4) {
-        s2_track_near_body(q, si, s, lane, pi[wave]);
+      WK_STAMP(12)  // LM (slowest wavefront of the sequence)
+      for (int si = wave; si < T; si += S2_WALK_WAVES) {
+        s2_track_near_body(q, si, s0, lane, pi[wave]);
         __builtin_amdgcn_wave_barrier();
       }
       __syncthreads();
-      s2_track_update_body(q, s);
+      WK_STAMP(13)  // merge-distance bit matrix
+      if (wave == 0) s2_track_update_wave(q, s0, lane);
     }
     __syncthreads();
+    WK_STAMP(14)  // publish + lifecycle
+  }
+  if (Wk.lds_state) {  // write the track state back
+    const size_t g0 = (size_t)s * T;
+    for (int i = tid; i < T * SE3D_NFU * 3; i += NT) Q.prev[g0 * SE3D_NFU * 3 + i] = l_prev[i];
+    for (int i = tid; i < T * SE3D_NFU * 9; i += NT) Q.vel[g0 * SE3D_NFU * 9 + i] = l_vel[i];
+    for (int i = tid; i < T * 3; i += NT) Q.root_prev[g0 * 3 + i] = l_root[i];
+    for (int i = tid; i < T; i += NT) {
+      Q.height_prev[g0 + i] = l_height[i]; Q.trk_t_prev[g0 + i] = l_tprev[i]; Q.has[g0 + i] = l_has[i];
+      Q.id[g0 + i] = l_id[i]; Q.num_obs[g0 + i] = l_nobs[i]; Q.used[g0 + i] = l_used[i];
+    }
   }
 }
 
@@ -1327,17 +1567,26 @@ static int s2_lm_mode() {
 // true: the fused kernel was launched; false: not applicable (caller falls back to per-step launches)
 extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st) {
   static int ok = -1;
-  const size_t lm_bytes = 4 * sizeof(LmSchurLds);
-  const size_t mk_bytes = (size_t)Q.H * Q.T * sizeof(double);
+  const size_t lm_bytes = S2_WALK_WAVES * sizeof(LmSchurLds);
   if (ok < 0) {
     const char *e = getenv("SE3D_WALK");  // A/B evidence switch: steps = always use the per-step kernels
     ok = !(e && strcmp(e, "steps") == 0) && s2_lm_mode() == 3;
     if (ok) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_stage2_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_bytes);
   }
-  if (!ok || mk_bytes > lm_bytes || nseq < 1) return false;  // large association problems keep the multi-workgroup per-step path
+  if (!ok || Q.H > 64 || Q.T > 64 || nseq < 1) return false;  // large association problems keep the multi-workgroup per-step path
   Se3dStage2 q = Q;
   q.seq0 = 0;
-  hipLaunchKernelGGL(se3d_k_stage2_walk, dim3(nseq), dim3(256), lm_bytes, st, q, Wk, (int)lm_bytes);
+  // per-track state in LDS when it fits next to the LM workspaces: prev 63 + vel 189 + root 3 + height + t_prev doubles, 4 words
+  const size_t state_bytes = (size_t)Q.T * ((SE3D_NFU * 12 + 5) * sizeof(double) + 16);
+  static int lds_max = -1;
+  if (lds_max < 0) {
+    lds_max = 160 * 1024 - 4096;  // 160 KB per CU minus the kernel's static LDS
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_stage2_walk), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+  }
+  Se3dWalk w = Wk;
+  w.lds_state = (lm_bytes + state_bytes <= (size_t)lds_max) ? 1 : 0;
+  const size_t dyn = lm_bytes + (w.lds_state ? state_bytes : 0);
+  hipLaunchKernelGGL(se3d_k_stage2_walk, dim3(nseq), dim3(64 * S2_WALK_WAVES), dyn, st, q, w);
   return true;
 }
 

@@ -40,7 +40,10 @@ def test_loaded_library_is_the_hip_build(node16):
     assert "libse3d_hip.so" in maps
 
 
-def test_device_hungarian_matches_reference_goldens(node16):
+@pytest.mark.parametrize("variant", ["auto", "block"])
+def test_device_hungarian_matches_reference_goldens(node16, monkeypatch, variant):
+    """auto: problems up to 64 x 64 run the single-wavefront Munkres, larger ones the block-cooperative one; block: all sizes on the latter."""
+    monkeypatch.setenv("SE3D_MUNKRES", variant)
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hungarian_golden.json")))
     L = node16._L
     for case in gold["cases"]:
@@ -64,6 +67,24 @@ def test_device_hungarian_fuzz_vs_oracle(node16, oracle):
     for it in range(120):
         nr, nc = int(rng.integers(1, 200)), int(rng.integers(1, 200))
         m = make_matrix(["uniform", "integer", "maxcost", "epipolar"][it % 4], nr, nc, 50_000 + it)
+        a0, c0 = oracle.hungarian(m)
+        flat = np.ascontiguousarray(m.ravel(order="F"))
+        a = np.zeros(nr, np.int32)
+        cost = C.c_double(0)
+        assert L.se3d_hungarian(C.c_void_p(node16._h), pm.iptr(a), C.byref(cost), flat.ctypes.data_as(C.POINTER(C.c_double)), nr, nc) == 0
+        assert a.tolist() == a0.tolist(), (it, nr, nc)
+        assert cost.value == c0
+
+
+def test_device_hungarian_wave_fuzz_small(node16, oracle):
+    """Single-wavefront Munkres (<= 64 x 64): ties, rectangular shapes, saturated costs; bit-exact vs the oracle (= reference goldens)."""
+    L = node16._L
+    rng = np.random.default_rng(11)
+    for it in range(300):
+        nr, nc = int(rng.integers(1, 65)), int(rng.integers(1, 65))
+        if it % 5 == 0:
+            nr = nc
+        m = make_matrix(["uniform", "integer", "maxcost", "epipolar"][it % 4], nr, nc, 90_000 + it)
         a0, c0 = oracle.hungarian(m)
         flat = np.ascontiguousarray(m.ravel(order="F"))
         a = np.zeros(nr, np.int32)

@@ -13,7 +13,7 @@ S_, T_ = 128, 16
 seqs = bench.make_sequences(rig, w, S_, 0, T_)
 frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
 from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
-node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=16)
+node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=8)
 node.stage(frames); node.refine_reset(); node.run_stage1()
 L = _lib.lib()
 out = (C.c_ulonglong * 16)()
@@ -27,4 +27,18 @@ for rep in range(3):
     v = list(out)
     n = max(v[8], 1)
     names = ["setup", "error/ctl", "linearize+grad", "solve", "lm-rest", "marginals", "outputs"]
-    print("rep", rep, "persons", v[8], "avg LM iterations %.2f" % (v[9] / n), "| cycles/person:", {nm: round(v[i] / n) for i, nm in enumerate(names)}, "total", round(sum(v[:7]) / n))
+    print("rep", rep, "persons", v[8], "avg LM iterations %.2f" % (v[9] / n), "| cycles/person:", {nm: round(v[i] / n) for i, nm in enumerate(names)}, "total", round(sum(v[:7]) / n), "| outputs split: zero-fill", round(v[7] / n), "scalar loads", round(v[15] / n))
+
+# fused walk (se3d_run_stage2_walk): per-phase cycles of thread 0 of each sequence's workgroup, per (sequence, time step)
+L.se3d_diag_lm_stamps(out, 1)
+for rep in range(2):
+    ks = list(range(T_)) if rep % 2 == 0 else list(range(T_ - 1, -1, -1))
+    ts = t + np.arange(1, T_ + 1) / 30.0
+    t = float(ts[-1])
+    node.run_stage2_walk(np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
+    node.sync()
+    L.se3d_diag_lm_stamps(out, 1)
+    v = list(out)
+    n = S_ * T_
+    names = ["track_cost", "assoc", "lm(max of seq)", "near", "update"]
+    print("walk rep", rep, "| cycles per (sequence, step):", {nm: round(v[10 + i] / n) for i, nm in enumerate(names)}, "total", round(sum(v[10:15]) / n))
