@@ -196,8 +196,9 @@ def main():
         step()
     for nd_ in nodes:
         nd_.sync()
-    node.profile(True)   # HIP-event kernel timing on context 0 (its kernels overlap with the other contexts' by design)
-    node.profile_reset()
+    for nd_ in nodes:    # HIP-event kernel timing on every context's own stream (kernels of different contexts overlap by design)
+        nd_.profile(True)
+        nd_.profile_reset()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -210,7 +211,8 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    node.profile(False)
+    for nd_ in nodes:
+        nd_.profile(False)
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -233,11 +235,11 @@ def main():
 
     if rank == 0:
         names = ["normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess"] + (["track_assoc", "lm_refine", "track_update", "stage2_walk"] if stage2 else [])
-        prof = {k: node.profile_get(k) for k in names}
-        per_step_ms = {k: v[0] / args.steps for k, v in prof.items()}
+        prof = {k: tuple(sum(x) for x in zip(*[nd_.profile_get(k) for nd_ in nodes])) for k in names}   # (ms, launches) over all contexts
+        per_step_ms = {k: v[0] / args.steps / NC for k, v in prof.items()}                              # per context and step
         dom = max(per_step_ms, key=lambda k: per_step_ms[k])
         ms_dom = prof[dom][0] / max(prof[dom][1], 1)              # average duration of one launch (group) of the dominant kernel
-        launches_per_step = prof[dom][1] / args.steps
+        launches_per_step = prof[dom][1] / args.steps / NC
         bytes_per_skel = w["bytes_s1"] if dom in names[:5] else w["bytes_s2"]
         units_per_launch = n_skel_local / NC / launches_per_step   # skeletons one launch of that kernel processes (context 0)
         achieved = bytes_per_skel * units_per_launch / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0

@@ -709,6 +709,11 @@ __device__ __forceinline__ void se3d_gram_add(double g[10], const float r[4], do
   g[9] = __builtin_fma(sgn * d, d, g[9]);
 }
 
+__device__ __forceinline__ double se3d_readlane_f64(double v, int l) {  // l uniform
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double se3d_wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -737,6 +742,10 @@ __global__ __launch_bounds__(256, 4) void se3d_k_triangulate(Se3dDev D) {
   const int N = D.d.N, P = D.d.P, H = D.d.H;
   const int gw = blockIdx.x * 4 + wave;
   const int h = gw / SE3D_NKP, j = gw - h * SE3D_NKP;
+  // camera matrices of the rig staged once per workgroup (every view of every wavefront reads its 3x4 row block several times)
+  float *sRt = reinterpret_cast<float *>(smem) + (size_t)4 * 15 * N;
+  for (int i = threadIdx.x; i < 12 * N; i += 256) sRt[i] = D.Rt[i];
+  __syncthreads();
   if (h >= D.nhyp[f]) return;
   if (D.nviews[f * H + h] < 2) return;
   float *base = reinterpret_cast<float *>(smem) + (size_t)wave * 15 * N;
@@ -776,13 +785,44 @@ __global__ __launch_bounds__(256, 4) void se3d_k_triangulate(Se3dDev D) {
   // ---- rows + Gram matrices: Gw (confidence weighted, S3D:450-453) and Gu (unweighted, used by the UT) ----
   double gw_[10], gu_[10];
   double sconf = 0.0;
+  // Gram entry owned by this lane in the small-n path: lanes 0-9 unweighted (00 01 02 03 11 12 13 22 23 33), 10-19 weighted, 20 sum of conf
+  const int ge = lane < 10 ? lane : (lane < 20 ? lane - 10 : 0);
+  const int gi = (int)((0x3221110000ull >> (4 * ge)) & 0xFull), gj = (int)((0x3323213210ull >> (4 * ge)) & 0xFull);
   auto build = [&](int nn) {
+    if (nn <= 24) {
+      // few views: rows by the first nn lanes, then every Gram entry is accumulated by its own lane over the views (broadcast LDS
+      // reads, no cross-lane reduction) and handed to all lanes with v_readlane
+      if (lane < nn) {
+        float r0[4], r1[4];
+        se3d_dlt_rows(sRt + 12 * T.cam[lane], T.x[lane], T.y[lane], r0, r1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { T.r0[k][lane] = r0[k]; T.r1[k][lane] = r1[k]; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      double acc = 0.0;
+      if (lane <= 20) {
+        const float *ri0 = base + (6 + gi) * N, *rj0 = base + (6 + gj) * N, *ri1 = base + (10 + gi) * N, *rj1 = base + (10 + gj) * N;
+        const bool weighted = lane >= 10;
+        for (int v = 0; v < nn; ++v) {
+          const float cf = T.cf[v];
+          if (lane == 20) { acc += (double)cf; continue; }
+          float a0 = ri0[v], b0 = rj0[v], a1 = ri1[v], b1 = rj1[v];
+          if (weighted) { a0 = a0 * cf; b0 = b0 * cf; a1 = a1 * cf; b1 = b1 * cf; }
+          acc = __builtin_fma((double)a0, (double)b0, acc);
+          acc = __builtin_fma((double)a1, (double)b1, acc);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 10; ++k) { gu_[k] = se3d_readlane_f64(acc, k); gw_[k] = se3d_readlane_f64(acc, 10 + k); }
+      sconf = se3d_readlane_f64(acc, 20);
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 10; ++k) { gw_[k] = 0.0; gu_[k] = 0.0; }
     sconf = 0.0;
     for (int v = lane; v < nn; v += 64) {
       float r0[4], r1[4], w0[4], w1[4];
-      se3d_dlt_rows(D.Rt + 12 * (size_t)T.cam[v], T.x[v], T.y[v], r0, r1);
+      se3d_dlt_rows(sRt + 12 * T.cam[v], T.x[v], T.y[v], r0, r1);
       const float cf = T.cf[v];
 #pragma unroll
       for (int k = 0; k < 4; ++k) { T.r0[k][v] = r0[k]; T.r1[k][v] = r1[k]; w0[k] = r0[k] * cf; w1[k] = r1[k] * cf; }
@@ -799,7 +839,7 @@ __global__ __launch_bounds__(256, 4) void se3d_k_triangulate(Se3dDev D) {
   auto reproj = [&](int nn, float X, float Y, float Z) -> double {
     double se = 0.0, sc = 0.0;
     for (int v = lane; v < nn; v += 64) {
-      const float e = se3d_reproj1(D.Rt + 12 * (size_t)T.cam[v], X, Y, Z, T.x[v], T.y[v]);
+      const float e = se3d_reproj1(sRt + 12 * T.cam[v], X, Y, Z, T.x[v], T.y[v]);
       se += (double)(T.cf[v] * e);
       sc += (double)T.cf[v];
     }
@@ -878,7 +918,7 @@ __global__ __launch_bounds__(256, 4) void se3d_k_triangulate(Se3dDev D) {
         double se = 0.0, sc = 0.0;
         for (int v = 0; v < n; ++v) {
           if (v == i) continue;
-          const float e = se3d_reproj1(D.Rt + 12 * (size_t)T.cam[v], cx_, cy_, cz_, T.x[v], T.y[v]);
+          const float e = se3d_reproj1(sRt + 12 * T.cam[v], cx_, cy_, cz_, T.x[v], T.y[v]);
           se += (double)(T.cf[v] * e);
           sc += (double)T.cf[v];
         }
@@ -944,7 +984,7 @@ __global__ __launch_bounds__(256, 4) void se3d_k_triangulate(Se3dDev D) {
         float o0[4], o1[4], n0[4], n1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o0[k] = T.r0[k][c]; o1[k] = T.r1[k][c]; }
-        se3d_dlt_rows(D.Rt + 12 * (size_t)T.cam[c], px, py, n0, n1);
+        se3d_dlt_rows(sRt + 12 * T.cam[c], px, py, n0, n1);
         se3d_gram_add(g, o0, -1.0); se3d_gram_add(g, o1, -1.0);
         se3d_gram_add(g, n0, 1.0); se3d_gram_add(g, n1, 1.0);
       }
@@ -1262,7 +1302,7 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     }
   }
   if (ev) (void)hipEventRecord(ev[3], st);
-  const size_t lds = (size_t)4 * 15 * N * sizeof(float);
+  const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
   hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
   if (ev) (void)hipEventRecord(ev[4], st);
   hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
