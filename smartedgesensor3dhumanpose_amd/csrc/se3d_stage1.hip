@@ -735,7 +735,7 @@ struct TriView {  // per-wave view list in LDS (structure of arrays, stride = N)
   int *cam;
 };
 
-__global__ __launch_bounds__(256, 4) void se3d_k_triangulate(Se3dDev D) {
+__global__ __launch_bounds__(256, 3) void se3d_k_triangulate(Se3dDev D) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int f = blockIdx.y;
@@ -1021,28 +1021,8 @@ __device__ __forceinline__ void se3d_zero_kp(se3d_keypoint3d &kp) {
   for (int i = 0; i < 6; ++i) kp.cov[i] = 0.0;
 }
 
-__global__ __launch_bounds__(256) void se3d_k_postprocess(Se3dDev D) {
-  const int f = blockIdx.x, tid = threadIdx.x;
-  const int N = D.d.N, P = D.d.P, H = D.d.H;
-  const int pm = D.d.pose_method;
-  const int nh = D.nhyp[f];
-  se3d_person3d *persons = D.hypP + (size_t)f * H;
-  __shared__ int alive[SE3D_MUNKRES_MAX];
-  __shared__ int s_ncam;
-  __shared__ int wsum[4];
-  if (tid == 0) s_ncam = 0;
-  __syncthreads();
-  {
-    int local = 0;
-    for (int c = tid; c < N; c += 256) local += (D.nraw[f * N + c] > 0) ? 1 : 0;
-    if (local) atomicAdd(&s_ncam, local);
-  }
-  for (int i = tid; i < SE3D_MUNKRES_MAX; i += 256) alive[i] = 0;
-  __syncthreads();
-  const bool few = s_ncam < 2;  // S3D:557-560
-  for (int h = tid; h < nh && !few; h += 256) {
-    if (D.nviews[f * H + h] < 2) continue;
-    se3d_person3d &p = persons[h];
+// per-person plausibility post-processing (S3D:861-973) on one person (global or LDS); returns the surviving keypoint count
+__device__ __forceinline__ int se3d_post_filter(se3d_person3d &p, int pm) {
     int num_valid = 0;
     for (int k = 0; k < SE3D_NKP; ++k) num_valid += (p.keypoints[c_kp2fusion[pm][k]].score > 0.f) ? 1 : 0;
     for (int k = 0; k < SE3D_NKP; ++k) {  // limb-length covariance inflation (S3D:861-883)
@@ -1090,6 +1070,119 @@ __global__ __launch_bounds__(256) void se3d_k_postprocess(Se3dDev D) {
     else if (p.keypoints[FU_LAnkle].score > 0.f) feet = p.keypoints[FU_LAnkle].joint[2];
     else if (p.keypoints[FU_RAnkle].score > 0.f) feet = p.keypoints[FU_RAnkle].joint[2];
     if (fabs(feet) > 0.50) num_valid = 0;
+    return num_valid;
+}
+
+// Small problems (H <= 16): one wavefront per frame, the frame's hypotheses staged in LDS (27 KB at most) so that the serial
+// per-person filters, the duplicate merge and the ordered compaction run at LDS instead of L2/HBM latency, without workgroup barriers.
+#define SE3D_POST_SMALL_H 16
+__global__ __launch_bounds__(64) void se3d_k_postprocess_wave(Se3dDev D) {
+  __shared__ se3d_person3d sp[SE3D_POST_SMALL_H];
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  const int pm = D.d.pose_method;
+  const int nh = D.nhyp[f];
+  const se3d_person3d *persons = D.hypP + (size_t)f * H;
+  constexpr int words = (int)(sizeof(se3d_person3d) / 4);
+  int ncam = 0;
+  for (int c = lane; c < N; c += 64) ncam += (D.nraw[f * N + c] > 0) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) ncam += __shfl_xor(ncam, o);
+  const bool few = ncam < 2;  // S3D:557-560
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(persons);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(sp);
+    for (int w = lane; w < nh * words; w += 64) dst[w] = src[w];
+  }
+  __syncthreads();
+  bool al = false;
+  if (lane < nh && !few && D.nviews[f * H + lane] >= 2) al = se3d_post_filter(sp[lane], pm) > 9;
+  __syncthreads();
+  unsigned long long alive = __ballot(al);
+  // ---- duplicate merge (S3D:984-996): sequential in i, distances to all later j in parallel ----
+  for (int i = 0; i < nh; ++i) {
+    if (!((alive >> i) & 1ull)) continue;
+    int from = i + 1;
+    for (;;) {
+      const int jj = from + lane;
+      bool hit = false;
+      if (jj < nh && ((alive >> jj) & 1ull)) {
+        int nu = 0;
+        double dist = 0.0;
+        for (int k = 0; k < SE3D_NFU; ++k) {
+          const se3d_keypoint3d &a = sp[i].keypoints[k], &bb = sp[jj].keypoints[k];
+          if (a.score > 0.f && bb.score > 0.f) {
+            const double dx = a.joint[0] - bb.joint[0], dy = a.joint[1] - bb.joint[1], dz = a.joint[2] - bb.joint[2];
+            dist += sqrt(dx * dx + dy * dy + dz * dz);
+            ++nu;
+          }
+        }
+        hit = (nu > 0 ? dist / nu : MAX_COSTS) < 0.20;
+      }
+      const unsigned long long hb = __ballot(hit);
+      if (!hb) break;
+      const int jm = from + __ffsll((long long)hb) - 1;
+      __syncthreads();
+      if (lane < SE3D_NFU) {  // merge_persons (S3D:410-423), one joint per lane
+        se3d_keypoint3d &k1 = sp[i].keypoints[lane];
+        const se3d_keypoint3d &k2 = sp[jm].keypoints[lane];
+        const double total = (double)(k1.score + k2.score);
+        if (total > 0.0) {
+          for (int a = 0; a < 3; ++a) k1.joint[a] = ((double)k1.score * k1.joint[a] + (double)k2.score * k2.joint[a]) / total;
+          k1.score = fmaxf(k1.score, k2.score);
+          for (int a = 0; a < 6; ++a) k1.cov[a] = (k1.cov[a] + k2.cov[a]) / 2.0;
+        }
+      }
+      __syncthreads();
+      alive &= ~(1ull << jm);
+      from = jm + 1;
+    }
+  }
+  // ---- compaction in ascending hypothesis order + association table in original detection indices ----
+  const int total = __popcll(alive);
+  int pos = 0;
+  for (unsigned long long m = alive; m; m &= m - 1ull, ++pos) {
+    const int h = __ffsll((long long)m) - 1;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&sp[h]);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&D.outP[(size_t)f * H + pos]);
+    for (int w = lane; w < words; w += 64) dst[w] = src[w];
+    if (lane == 0) D.out_hyp[(size_t)f * H + pos] = h;
+  }
+  if (lane == 0) {
+    D.out_count[f] = total;
+    if (few) {  // the reference returns before building any hypothesis (S3D:557-560)
+      atomicOr(&D.flags[f], SE3D_FLAG_FEW_CAMERAS);
+      D.nhyp[f] = 0;
+    }
+  }
+  for (int i = lane; i < nh * N; i += 64) {
+    const int h = i / N, c = i - h * N;
+    const int k = D.assoc[((size_t)f * H + h) * N + c];
+    D.out_assoc[((size_t)f * H + h) * N + c] = (k >= 0) ? D.orig[((size_t)(f * N + c)) * P + k] : -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void se3d_k_postprocess(Se3dDev D) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  const int pm = D.d.pose_method;
+  const int nh = D.nhyp[f];
+  se3d_person3d *persons = D.hypP + (size_t)f * H;
+  __shared__ int alive[SE3D_MUNKRES_MAX];
+  __shared__ int s_ncam;
+  __shared__ int wsum[4];
+  if (tid == 0) s_ncam = 0;
+  __syncthreads();
+  {
+    int local = 0;
+    for (int c = tid; c < N; c += 256) local += (D.nraw[f * N + c] > 0) ? 1 : 0;
+    if (local) atomicAdd(&s_ncam, local);
+  }
+  for (int i = tid; i < SE3D_MUNKRES_MAX; i += 256) alive[i] = 0;
+  __syncthreads();
+  const bool few = s_ncam < 2;  // S3D:557-560
+  for (int h = tid; h < nh && !few; h += 256) {
+    if (D.nviews[f * H + h] < 2) continue;
+    const int num_valid = se3d_post_filter(persons[h], pm);
     alive[h] = (num_valid > 9) ? 1 : 0;
   }
   __syncthreads();
@@ -1305,6 +1398,7 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
   hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
   if (ev) (void)hipEventRecord(ev[4], st);
-  hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
+  if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), 0, st, D);
+  else hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
   if (ev) (void)hipEventRecord(ev[5], st);
 }
