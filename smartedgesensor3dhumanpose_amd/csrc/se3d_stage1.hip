@@ -9,6 +9,9 @@
 #include "se3d_device.h"
 #include "se3d_munkres.h"
 
+#include <cstdlib>
+#include <cstring>
+
 // Diagnostic build only (make diag): cycle stamps of se3d_k_sweep_assign (never in the product .so)
 #ifdef SE3D_LM_STAMPS
 __device__ unsigned long long g_s1_stamps[16];
@@ -1376,15 +1379,18 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_assign), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     assign_attr = true;
   }
-  static int fused_limit = -1;  // H*P up to which the one-launch sweep is used (SE3D_SWEEP_FUSED_MAX overrides; 0 = never)
-  if (fused_limit < 0) {
-    const char *e = getenv("SE3D_SWEEP_FUSED_MAX");
-    fused_limit = e ? atoi(e) : 256;
+  // A/B switches (read per launch so that the parity tests can compare the variants in one process):
+  //   SE3D_SWEEP_FUSED_MAX = H*P up to which the one-launch 256-thread sweep is used (0 = never), SE3D_SWEEP_WAVE=0 disables the
+  //   one-wavefront sweep
+  static bool fused_attr = false;
+  if (!fused_attr) {
+    fused_attr = true;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   }
-  static int sweep_wave = -1;  // SE3D_SWEEP_WAVE=0 keeps the 256-thread workgroup per frame (A/B evidence)
-  if (sweep_wave < 0) { const char *e = getenv("SE3D_SWEEP_WAVE"); sweep_wave = e ? atoi(e) : 1; }
-  if (sweep_wave && H <= 64 && P <= 64 && H * P <= 8 * fused_limit) {
+  const char *e_fused = getenv("SE3D_SWEEP_FUSED_MAX"), *e_wave = getenv("SE3D_SWEEP_WAVE");
+  const int fused_limit = e_fused ? atoi(e_fused) : 256;
+  const int sweep_wave = e_wave ? atoi(e_wave) : 1;
+  if (sweep_wave && H <= 64 && P <= 64 && H * P <= 2048) {
     hipLaunchKernelGGL(se3d_k_sweep_fused_wave, dim3(B), dim3(64), (size_t)dynW, st, D);
   } else if (H * P <= fused_limit && dynW <= 64 * 1024) {
     hipLaunchKernelGGL(se3d_k_sweep_fused, dim3(B), dim3(256), (size_t)dynW, st, D, dynW);

@@ -1566,13 +1566,9 @@ static int s2_lm_mode() {
 
 // true: the fused kernel was launched; false: not applicable (caller falls back to per-step launches)
 extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st) {
-  static int ok = -1;
   const size_t lm_bytes = S2_WALK_WAVES * sizeof(LmSchurLds);
-  if (ok < 0) {
-    const char *e = getenv("SE3D_WALK");  // A/B evidence switch: steps = always use the per-step kernels
-    ok = !(e && strcmp(e, "steps") == 0) && s2_lm_mode() == 3;
-    if (ok) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_stage2_walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_bytes);
-  }
+  const char *e = getenv("SE3D_WALK");  // A/B evidence switch (read per launch): steps = always use the per-step kernels
+  const bool ok = !(e && strcmp(e, "steps") == 0) && s2_lm_mode() == 3;
   if (!ok || Q.H > 64 || Q.T > 64 || nseq < 1) return false;  // large association problems keep the multi-workgroup per-step path
   Se3dStage2 q = Q;
   q.seq0 = 0;
