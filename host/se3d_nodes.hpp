@@ -3,9 +3,13 @@
 //   Skeleton3DNode::skeletonThreadStep    <->  body of skeletonThreadCallback      skeleton_3d_triang_mult_node.cpp:1029-1084
 //   PosePriorNode::skeletonCallback       <->  skeletonCallback(PersonCovList)     pose_prior_mult_node.cpp:505
 //   ReprojectionNode::fusedSkeletonCallback <-> fusedSkeletonCallback(PersonCovList) skeleton_reproj_mult_node.cpp:139
+//   Skeleton3DFrontEnd                    <->  the approximate-time synchroniser in front of skeletonCallback   S3D:1218-1223
 // ROS is not available in the build image, so messages are the plain mirrors of host/person_msgs.hpp; a catkin wrapper
 // only has to forward its callbacks to these methods.  All arithmetic runs in libse3d_hip.so on the GPU.
 #pragma once
+#include <algorithm>
+#include <cmath>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -14,6 +18,7 @@
 
 #include "../include/se3d.h"
 #include "person_msgs.hpp"
+#include "se3d_sync.hpp"
 
 namespace se3d {
 
@@ -66,6 +71,25 @@ class Skeleton3DNode {
   double last_stamp_ = 0.0;
   std::vector<double> timings_ = std::vector<double>(10, 0.0);
   std::vector<int> timing_cnt_ = std::vector<int>(10, 0);
+};
+
+// The N per-camera Person2DList subscriptions of main() (S3D:1140-1160, 1218-1223): messages go through the approximate-time
+// synchroniser with the node's parameters (queue max(3, 1 + N/4), 20 ms lower bound, age penalty 2.0); every published tuple is
+// handed to `on_tuple` (the reference's skeletonCallback stores it for the worker thread, S3D:999-1027).
+class Skeleton3DFrontEnd {
+ public:
+  using Tuple = std::vector<std::shared_ptr<const person_msgs::Person2DList>>;
+  Skeleton3DFrontEnd(int num_cameras, std::function<void(const Tuple&)> on_tuple)
+      : sync_(std::max(3u, 1u + (unsigned)num_cameras / 4u), num_cameras,
+              [](const person_msgs::Person2DList& m) { return (int64_t)std::llround(m.header.stamp * 1e9); }) {
+    sync_.setInterMessageLowerBound(20000000);
+    sync_.setAgePenalty(2.0);
+    sync_.registerCallback(std::move(on_tuple));
+  }
+  void add(std::shared_ptr<const person_msgs::Person2DList> msg, int cam) { sync_.add(std::move(msg), cam); }
+
+ private:
+  ApproximateTimeSync<person_msgs::Person2DList> sync_;
 };
 
 class PosePriorNode {

@@ -64,24 +64,13 @@ int main(int argc, char** argv) {
       wr<int32_t>(rout, n_frames);
       wr<int32_t>(rout, n_cam);
     }
-    for (int f = 0; f < n_frames; ++f) {
-      std::vector<person_msgs::Person2DList> people(n_cam);
-      for (int c = 0; c < n_cam; ++c) {
-        people[c].header.stamp = rd<double>(in);
-        people[c].fb_delay = rd<float>(in);
-        const int np = rd<int32_t>(in);
-        people[c].persons.resize(np);
-        for (auto& p : people[c].persons) {
-          p.score = rd<float>(in);
-          for (float& b : p.bbox) b = rd<float>(in);
-          p.keypoints.resize(17);
-          for (auto& k : p.keypoints) { k.x = rd<float>(in); k.y = rd<float>(in); k.score = rd<float>(in); for (float& cv : k.cov) cv = rd<float>(in); }
-        }
-      }
+    int n_tuples = 0;
+    auto handle_tuple = [&](const std::vector<person_msgs::Person2DList>& people) {
+      ++n_tuples;
       person_msgs::PersonCovList persons3d, fused, pred;
       const bool processed = skel.skeletonThreadStep(people, persons3d);
       wr<int32_t>(out, processed ? 1 : 0);
-      if (!processed) continue;
+      if (!processed) return;
       prior.skeletonCallback(persons3d, fused, pred);
       write_list(out, persons3d);
       write_list(out, fused);
@@ -101,7 +90,36 @@ int main(int argc, char** argv) {
             }
           }
       }
+    };
+    std::unique_ptr<se3d::Skeleton3DFrontEnd> front;
+    if (std::getenv("SE3D_REPLAY_SYNC"))
+      front.reset(new se3d::Skeleton3DFrontEnd(n_cam, [&](const se3d::Skeleton3DFrontEnd::Tuple& t) {
+        std::vector<person_msgs::Person2DList> people;
+        for (const auto& m : t) people.push_back(*m);
+        handle_tuple(people);
+      }));
+    for (int f = 0; f < n_frames; ++f) {
+      std::vector<person_msgs::Person2DList> people(n_cam);
+      for (int c = 0; c < n_cam; ++c) {
+        people[c].header.stamp = rd<double>(in);
+        people[c].fb_delay = rd<float>(in);
+        const int np = rd<int32_t>(in);
+        people[c].persons.resize(np);
+        for (auto& p : people[c].persons) {
+          p.score = rd<float>(in);
+          for (float& b : p.bbox) b = rd<float>(in);
+          p.keypoints.resize(17);
+          for (auto& k : p.keypoints) { k.x = rd<float>(in); k.y = rd<float>(in); k.score = rd<float>(in); for (float& cv : k.cov) cv = rd<float>(in); }
+        }
+      }
+      if (front) {  // SE3D_REPLAY_SYNC=1: the messages of this frame arrive one by one at the approximate-time synchroniser
+        for (int c = 0; c < n_cam; ++c) front->add(std::make_shared<const person_msgs::Person2DList>(people[c]), c);
+      } else {
+        handle_tuple(people);
+      }
     }
+    out.seekp(0);
+    wr<int32_t>(out, n_tuples);  // tuples actually handled (with the synchroniser in front the last frames may still be held back)
     for (size_t i = 0; i < skel.timings_ms().size(); ++i)  // S3D:1234-1241
       if (skel.timing_counts()[i] > 0) {
         std::cout << "Triangulation: ";

@@ -169,3 +169,138 @@ def read_replay_reproj(path):
             cams.append((stamp, fb, persons))
         out.append(cams)
     return out
+
+
+class ApproximateTimeSync:
+    """Python twin of host/se3d_sync.hpp (the reference's my_message_filters ApproximateTimeVec policy, SYNC:170-626): N FIFOs,
+    candidate = FIFO heads, pivot = latest head of the first candidate, improvement test with the age penalty, optimality proof with
+    the inter-message lower bound, overflow drop.  Messages are (stamp_ns, payload) pairs; `callback(list_of_messages)`."""
+
+    def __init__(self, queue_size, num_inputs, callback, age_penalty=0.1, lower_bound_ns=0, max_interval_ns=None):
+        self.qs, self.n, self.cb = queue_size, num_inputs, callback
+        self.pen, self.max_interval = age_penalty, max_interval_ns
+        self.fifo = [[] for _ in range(num_inputs)]
+        self.past = [[] for _ in range(num_inputs)]
+        self.dropped = [False] * num_inputs
+        self.warned = [False] * num_inputs
+        self.lb = [lower_bound_ns] * num_inputs
+        self.non_empty, self.pivot, self.cand = 0, -1, None
+        self.pivot_time = self.c_start = self.c_end = 0
+        self.warnings = 0
+
+    @staticmethod
+    def _scaled(ns, scale):  # ros::Duration * double
+        s, r = divmod(ns, 1000000000)
+        d = (float(s) + 1e-9 * float(r)) * scale
+        fl = np.floor(d)
+        frac = (d - fl) * 1e9
+        return int(fl) * 1000000000 + int(np.floor(frac + 0.5) if frac >= 0 else np.ceil(frac - 0.5))
+
+    def _not_better(self, end, start_ref):
+        return self._scaled(end - self.c_end, 1.0 + self.pen) >= start_ref - self.c_start
+
+    def add(self, msg, i):
+        q = self.fifo[i]
+        q.append(msg)
+        if len(q) == 1:
+            self.non_empty += 1
+            if self.non_empty == self.n:
+                self._process()
+        elif not self.warned[i]:
+            now, prev = q[-1][0], q[-2][0]
+            if now < prev or now - prev < self.lb[i]:
+                self.warned[i] = True
+                self.warnings += 1
+        if len(q) + len(self.past[i]) > self.qs:
+            self.non_empty = 0
+            for j in range(self.n):
+                self._restore(len(self.past[j]), j)
+            q.pop(0)
+            self.dropped[i] = True
+            if self.pivot >= 0:
+                self.cand, self.pivot = None, -1
+                self._process()
+
+    def _pop_front(self, i):
+        self.fifo[i].pop(0)
+        if not self.fifo[i]:
+            self.non_empty -= 1
+
+    def _front_to_past(self, i):
+        self.past[i].append(self.fifo[i][0])
+        self._pop_front(i)
+
+    def _restore(self, count, i):
+        for _ in range(count):
+            self.fifo[i].insert(0, self.past[i].pop())
+        if self.fifo[i]:
+            self.non_empty += 1
+
+    def _take(self):
+        self.cand = [q[0] for q in self.fifo]
+        for p in self.past:
+            p.clear()
+
+    def _publish(self):
+        self.cb(self.cand)
+        self.cand, self.pivot, self.non_empty = None, -1, 0
+        for i in range(self.n):
+            while self.past[i]:
+                self.fifo[i].insert(0, self.past[i].pop())
+            self.fifo[i].pop(0)
+            if self.fifo[i]:
+                self.non_empty += 1
+
+    def _boundary(self, times, end):
+        t, idx = times[0], 0
+        for i, ti in enumerate(times):
+            if i and ((ti < t) != end):
+                t, idx = ti, i
+        return idx, t
+
+    def _virtual(self, i):
+        if not self.fifo[i]:
+            return max(self.past[i][-1][0] + self.lb[i], self.pivot_time)
+        return self.fifo[i][0][0]
+
+    def _process(self):
+        while self.non_empty == self.n:
+            heads = [q[0][0] for q in self.fifo]
+            e_idx, e_t = self._boundary(heads, True)
+            s_idx, s_t = self._boundary(heads, False)
+            for i in range(self.n):
+                if i != e_idx:
+                    self.dropped[i] = False
+            if self.pivot < 0:
+                if (self.max_interval is not None and e_t - s_t > self.max_interval) or self.dropped[e_idx]:
+                    self._pop_front(s_idx)
+                    continue
+                self._take()
+                self.c_start, self.c_end, self.pivot, self.pivot_time = s_t, e_t, e_idx, e_t
+                self._front_to_past(s_idx)
+            elif self._not_better(e_t, s_t):
+                self._front_to_past(s_idx)
+            else:
+                self._take()
+                self.c_start, self.c_end = s_t, e_t
+                self._front_to_past(s_idx)
+            if s_idx == self.pivot:
+                self._publish()
+            elif self._not_better(e_t, self.pivot_time):
+                self._publish()
+            elif self.non_empty < self.n:
+                moved = [0] * self.n
+                while True:
+                    vt = [self._virtual(i) for i in range(self.n)]
+                    _, ve_t = self._boundary(vt, True)
+                    vs_idx, vs_t = self._boundary(vt, False)
+                    if self._not_better(ve_t, self.pivot_time):
+                        self._publish()
+                        break
+                    if not self._not_better(ve_t, vs_t):
+                        self.non_empty = 0
+                        for i in range(self.n):
+                            self._restore(moved[i], i)
+                        break
+                    self._front_to_past(vs_idx)
+                    moved[vs_idx] += 1

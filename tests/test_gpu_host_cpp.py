@@ -87,3 +87,30 @@ def test_cpp_replay_reprojection(tmp_path, oracle, extr_rig, demo_params):
                 np.testing.assert_allclose(persons["bbox"], rper["bbox"], rtol=2e-6, atol=1e-4)
                 n_checked += len(persons)
     assert n_checked > 50
+
+
+def test_cpp_replay_through_time_synchroniser(tmp_path, extr_rig, demo_params):
+    """With SE3D_REPLAY_SYNC=1 the per-camera messages (stamps jittered by a few ms inside each frame) go through
+    se3d::Skeleton3DFrontEnd (approximate-time synchroniser, node parameters of S3D:1219-1221) before skeletonThreadStep: every
+    tuple it publishes must be the frame itself, so the published 3-D lists equal the directly fed replay."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")], stdout=subprocess.DEVNULL)
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=4, n_frames=14, seed=23))
+    stream = Hn.stream_from_frames(frames)
+    rng = np.random.default_rng(1)
+    for msgs in stream:
+        for m in msgs:
+            m.stamp = round(m.stamp + float(rng.uniform(-0.003, 0.003)), 6)
+    scene, out_a, out_b = str(tmp_path / "scene.bin"), str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    Hn.write_replay_scene(scene, extr_rig, demo_params, stream)
+    exe = os.path.join(ROOT, "host", "se3d_replay")
+    subprocess.check_call([exe, scene, out_a])
+    subprocess.check_call([exe, scene, out_b], env=dict(os.environ, SE3D_REPLAY_SYNC="1"))
+    a, b = Hn.read_replay_output(out_a), Hn.read_replay_output(out_b)
+    assert len(a) == len(stream) and len(stream) - 2 <= len(b) <= len(stream)   # the synchroniser may still hold the last frames
+    for ra, rb in zip(a, b):
+        assert (ra is None) == (rb is None)
+        if ra is None:
+            continue
+        for la, lb in zip(ra, rb):
+            assert la.stamp == lb.stamp and la.ts_per_cam == lb.ts_per_cam
+            assert la.persons.tobytes() == lb.persons.tobytes()
