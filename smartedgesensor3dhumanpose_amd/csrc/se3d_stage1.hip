@@ -145,6 +145,48 @@ __global__ __launch_bounds__(256) void se3d_k_pairs_flat(Se3dDev D, const int2 *
   }
 }
 
+// packed variant for small P: one workgroup per frame; the valid (det_a, det_b) entries of all camera pairs are enumerated densely
+// (prefix sums of n_a * n_b over the pairs), so no lane works on padding when cameras hold fewer than P detections
+// (16 cameras x 6 persons at P = 8: 36 of 64 entries per pair are valid; the flat kernel is VALU-bound at 100 % busy there).
+// Same per-entry arithmetic (se3d_pair_cost) -> identical table; padding entries are never read by the sweep.
+__global__ __launch_bounds__(256) void se3d_k_pairs_packed(Se3dDev D, const int2 *__restrict__ pair_ab) {
+  extern __shared__ int s_cum[];  // [np + 1] exclusive prefix of n_a * n_b
+  __shared__ int s_part[4];
+  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int32_t *nv = D.nvalid + (size_t)f * N;
+  int carry = 0;
+  for (int base = 0; base < np; base += 256) {  // block-wide exclusive scan, 256 pairs per round
+    const int pr = base + tid;
+    int v = 0;
+    if (pr < np) { const int2 ab = pair_ab[pr]; v = nv[ab.x] * nv[ab.y]; }
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_part[wave] = inc;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wave; ++w) off += s_part[w];
+    if (pr < np) s_cum[pr] = off + inc - v;
+    carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+  }
+  if (tid == 0) s_cum[np] = carry;
+  __syncthreads();
+  const int total = s_cum[np];
+  for (int e = tid; e < total; e += 256) {
+    int lo = 0, hi = np;  // largest pr with s_cum[pr] <= e
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cum[mid] <= e) lo = mid; else hi = mid; }
+    const int pr = lo;
+    const int2 ab = pair_ab[pr];
+    const int nb = nv[ab.y];
+    const int r = e - s_cum[pr];
+    const int p = r / nb, q = r - p * nb;
+    const size_t ia = ((size_t)(f * N + ab.x)) * P + p, ib = ((size_t)(f * N + ab.y)) * P + q;
+    const unsigned m = D.vmask_gt[ia] & D.vmask_gt[ib];
+    D.pair[(((size_t)f * np + pr) * P + p) * P + q] = se3d_pair_cost(D.F + 9 * (size_t)pr, D.kp + ia * SE3D_NKP, D.kp + ib * SE3D_NKP, m);
+  }
+}
+
 // tiled variant for large P: one workgroup per (64x64 tile of det_a x det_b, camera pair, frame).
 // The epipolar line of a point depends on one side only, so l1 = F p1 (+ its norm) is computed once per (det_a, joint)
 // and l2 = F^T p2 once per (det_b, joint) and staged in LDS; the inner loop is 2 dot products, 2 IEEE divides and one
@@ -1365,6 +1407,8 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   if (tiled) {
     const int tiles = (P + PT - 1) / PT;
     hipLaunchKernelGGL(se3d_k_pairs_tiled, dim3(tiles * tiles, D.d.npairs, B), dim3(256), 0, st, D, pair_ab);
+  } else if (!(getenv("SE3D_PAIRS") && strcmp(getenv("SE3D_PAIRS"), "flat") == 0) && D.d.npairs < 12000) {  // SE3D_PAIRS=flat|tiled: A/B switch
+    hipLaunchKernelGGL(se3d_k_pairs_packed, dim3(B), dim3(256), sizeof(int) * (D.d.npairs + 1), st, D, pair_ab);
   } else {
     const size_t total = (size_t)B * D.d.npairs * P * P;
     const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);

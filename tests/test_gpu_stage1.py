@@ -105,6 +105,27 @@ def test_sweep_variants_agree_exactly(monkeypatch, rig_name, persons, max_det, m
     assert n_hyp >= 8 * persons * 0.8
 
 
+def test_packed_pair_kernel_equals_flat_kernel_bitwise(extr_rig, monkeypatch):
+    """Small P: the packed kernel (dense enumeration of the valid entries of all camera pairs) writes exactly the flat kernel's table
+    on every valid entry, including frames with low-confidence joints and cameras without detections."""
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=7, n_frames=6, seed=31, low_score_frac=0.2, p_miss=0.15))
+    tabs = {}
+    for mode in ("flat", "packed"):
+        monkeypatch.setenv("SE3D_PAIRS", mode)
+        node = _node(extr_rig, max_frames=6, max_det_per_cam=8, max_hyp=32)
+        node.stage(frames)
+        node.run_stage1()
+        node.sync()
+        tabs[mode] = [_pair_costs(node, fi, a, b) for fi in range(6) for a in range(16) for b in range(a + 1, 16)]
+        node.close()
+    n = 0
+    for (tf, na, nb), (tt, na2, nb2) in zip(tabs["flat"], tabs["packed"]):
+        assert (na, nb) == (na2, nb2)
+        assert np.array_equal(tf[:na, :nb], tt[:na, :nb])
+        n += na * nb
+    assert n > 4000
+
+
 def test_device_hungarian_wave_fuzz_small(node16, oracle):
     """Single-wavefront Munkres (<= 64 x 64): ties, rectangular shapes, saturated costs; bit-exact vs the oracle (= reference goldens)."""
     L = node16._L
