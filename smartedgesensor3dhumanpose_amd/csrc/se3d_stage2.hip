@@ -1450,7 +1450,7 @@ __device__ __forceinline__ void s2_track_update_wave(const Se3dStage2 &Q, int s,
 #define WK_STAMP_INIT
 #define WK_STAMP(idx)
 #endif
-__global__ __launch_bounds__(64 * S2_WALK_WAVES) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk) {
+__global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk) {
   extern __shared__ __align__(16) unsigned char s2_walk_smem[];
   __shared__ double pi[S2_WALK_WAVES][SE3D_NFU][3];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
