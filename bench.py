@@ -129,19 +129,33 @@ def main():
     psz = pm.person3d_dt.itemsize
     if dist is not None:
         # Exchange: one RCCL all-gather of the final skeletons per context and step so that every rank holds the
-        # skeletons of all ranks.  Slots: stage 1+2 -> [T][S] (one block per stage-2 time step), stage 1 only -> [B].
+        # skeletons of all ranks ([B][max_hyp] persons + [B] counts per context, frame-slot order).  Stream-ordered, no host
+        # synchronisation: the collective is enqueued behind the context's asynchronous pack (its HIP stream is handed to torch as an
+        # ExternalStream) and runs on RCCL's stream while the context's next step computes; the pack buffers are double-buffered and a
+        # buffer is rewritten only after the collective that read it two steps earlier has completed (device-side wait).
         n_slots = B
-        packs = [torch.zeros(n_slots * H * psz, dtype=torch.uint8, device="cuda") for _ in nodes]
-        cnts = [torch.zeros(n_slots, dtype=torch.int32, device="cuda") for _ in nodes]
+        streams = [torch.cuda.ExternalStream(nd_.stream_handle()) for nd_ in nodes]
+        packs = [[torch.zeros(n_slots * H * psz, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in nodes]
+        cnts = [[torch.zeros(n_slots, dtype=torch.int32, device="cuda") for _ in range(2)] for _ in nodes]
         gath_p = [torch.empty(world * n_slots * H * psz, dtype=torch.uint8, device="cuda") for _ in nodes]
         gath_c = [torch.empty(world * n_slots, dtype=torch.int32, device="cuda") for _ in nodes]
+        works = [[None, None] for _ in nodes]
+        parity = [0] * len(nodes)
 
-    def exchange():
-        torch.cuda.synchronize()           # previous step's collectives are done before their source buffers were rewritten
-        for ci, nd_ in enumerate(nodes):
-            nd_.sync()                     # the asynchronous packs of this context have landed
-            dist.all_gather_into_tensor(gath_p[ci], packs[ci])
-            dist.all_gather_into_tensor(gath_c[ci], cnts[ci])
+    def pack_target(ci):
+        p = parity[ci]
+        if works[ci][p] is not None:
+            with torch.cuda.stream(streams[ci]):
+                for w_ in works[ci][p]:
+                    w_.wait()
+        return packs[ci][p], cnts[ci][p]
+
+    def exchange(ci):
+        p = parity[ci]
+        with torch.cuda.stream(streams[ci]):
+            works[ci][p] = (dist.all_gather_into_tensor(gath_p[ci], packs[ci][p], async_op=True),
+                            dist.all_gather_into_tensor(gath_c[ci], cnts[ci][p], async_op=True))
+        parity[ci] ^= 1
 
     # One step = per context one stage-1 pass over its B resident frames and one stage-2 walk over the T time steps of its S
     # sequences (se3d_run_stage2_walk: one launch, a workgroup per sequence; forward on even cycles, backward on odd ones so that
@@ -154,7 +168,9 @@ def main():
     def issue_stage1(wk):
         wk["node"].run_stage1()
         if not stage2 and dist is not None:
-            wk["node"].pack_stage1_device(packs[wk["ci"]].data_ptr(), cnts[wk["ci"]].data_ptr())
+            pk, cn = pack_target(wk["ci"])
+            wk["node"].pack_stage1_device(pk.data_ptr(), cn.data_ptr())
+            exchange(wk["ci"])
 
     def issue_walk(wk, collect):
         nd_, ci = wk["node"], wk["ci"]
@@ -165,16 +181,21 @@ def main():
         if args.walk == "fused":
             nd_.run_stage2_walk(np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
             if dist is not None:  # async D2D of all time steps' fused skeletons (frame-slot order) into the exchange buffer
-                nd_.pack_stage2_walk_device(B, packs[ci].data_ptr(), cnts[ci].data_ptr())
+                pk, cn = pack_target(ci)
+                nd_.pack_stage2_walk_device(B, pk.data_ptr(), cn.data_ptr())
+                exchange(ci)
             if collect is not None:
                 collect.append(sum(r.n_persons for k in ks for r in nd_.fetch_stage2_walk(k * S_, S_)))
         else:
+            pk, cn = pack_target(ci) if dist is not None else (None, None)
             for k, t in zip(ks, ts):
                 nd_.run_stage2(np.full(S_, t), frame_slot0=k * S_)
                 if dist is not None:
-                    nd_.pack_stage2_device(S_, packs[ci].data_ptr() + k * S_ * H * psz, cnts[ci].data_ptr() + 4 * k * S_)
+                    nd_.pack_stage2_device(S_, pk.data_ptr() + k * S_ * H * psz, cn.data_ptr() + 4 * k * S_)
                 if collect is not None:
                     collect.append(sum(r.n_persons for r in nd_.fetch_stage2(S_)))
+            if dist is not None:
+                exchange(ci)
 
     def step(collect=None):
         if not stage2:
@@ -185,8 +206,6 @@ def main():
                 issue_stage1(wk) if wk["ci"] % 2 == 0 else issue_walk(wk, collect)
             for wk in walks:   # phase B
                 issue_walk(wk, collect) if wk["ci"] % 2 == 0 else issue_stage1(wk)
-        if dist is not None:
-            exchange()
 
     for nd_ in nodes:
         nd_.run_stage1()   # phase-shifted contexts start inside the stage-2 walk: their frames need one completed stage-1 pass

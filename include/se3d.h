@@ -146,6 +146,9 @@ int se3d_triangulate_batch(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in 
 int se3d_stage_frames(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in *frames);
 int se3d_run_stage1(se3d_ctx *ctx); /* asynchronous on the context stream */
 int se3d_sync(se3d_ctx *ctx);
+/* The context's HIP stream (hipStream_t) so that a host framework can order its own work (e.g. an RCCL collective on the packed
+ * skeletons) after the asynchronous calls of this context without a host-side synchronisation. */
+void *se3d_stream_handle(se3d_ctx *ctx);
 int se3d_fetch_stage1(se3d_ctx *ctx, int32_t n_frames, se3d_frame_out *outs);
 
 /* --- stage 2: drop-in for the pose_prior skeletonCallback body (PP:505-921) ----------------------------

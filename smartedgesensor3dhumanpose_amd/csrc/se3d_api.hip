@@ -415,6 +415,8 @@ int se3d_sync(se3d_ctx *c) {
   return SE3D_OK;
 }
 
+void *se3d_stream_handle(se3d_ctx *c) { return c ? reinterpret_cast<void *>(c->stream) : nullptr; }
+
 int se3d_fetch_stage1(se3d_ctx *c, int32_t n_frames, se3d_frame_out *outs) {
   if (!c || !outs || n_frames < 1) return SE3D_ERR_ARG;
   if (!c->ran || n_frames > c->staged_frames) { c->err = "fetch before run"; return SE3D_ERR_STATE; }

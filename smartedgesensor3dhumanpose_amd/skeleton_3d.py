@@ -69,6 +69,10 @@ class Skeleton3D:
     def run_stage1(self):
         self._chk(self._L.se3d_run_stage1(C.c_void_p(self._h)), "se3d_run_stage1")
 
+    def stream_handle(self):
+        """hipStream_t of this context as an integer (e.g. for torch.cuda.ExternalStream)."""
+        return int(self._L.se3d_stream_handle(C.c_void_p(self._h)) or 0)
+
     def sync(self):
         self._chk(self._L.se3d_sync(C.c_void_p(self._h)), "se3d_sync")
 
