@@ -1442,7 +1442,7 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   const char *e_fused = getenv("SE3D_SWEEP_FUSED_MAX"), *e_wave = getenv("SE3D_SWEEP_WAVE");
   const int fused_limit = e_fused ? atoi(e_fused) : 256;
   const int sweep_wave = e_wave ? atoi(e_wave) : 1;
-  if (sweep_wave && H <= 64 && P <= 64 && H * P <= 2048) {
+  if (sweep_wave && H <= 64 && P <= 64 && H * P <= 2048) {  // larger problems: one wavefront per frame is too little parallelism
     hipLaunchKernelGGL(se3d_k_sweep_fused_wave, dim3(B), dim3(64), (size_t)dynW, st, D);
   } else if (H * P <= fused_limit && dynW <= 64 * 1024) {
     hipLaunchKernelGGL(se3d_k_sweep_fused, dim3(B), dim3(256), (size_t)dynW, st, D, dynW);

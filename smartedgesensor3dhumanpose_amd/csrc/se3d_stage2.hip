@@ -1569,7 +1569,9 @@ extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk,
   const size_t lm_bytes = S2_WALK_WAVES * sizeof(LmSchurLds);
   const char *e = getenv("SE3D_WALK");  // A/B evidence switch (read per launch): steps = always use the per-step kernels
   const bool ok = !(e && strcmp(e, "steps") == 0) && s2_lm_mode() == 3;
-  if (!ok || Q.H > 64 || Q.T > 64 || nseq < 1) return false;  // large association problems keep the multi-workgroup per-step path
+  // The fused walk gives each sequence one workgroup (4 LM wavefronts): right for many short sequences of few persons.  Large
+  // association problems (> 64) and few sequences of many persons keep the per-step kernels (a wavefront per person over the GPU).
+  if (!ok || Q.H > 64 || Q.T > 64 || nseq < 1 || (Q.H > 16 && nseq < 32)) return false;
   Se3dStage2 q = Q;
   q.seq0 = 0;
   // per-track state in LDS when it fits next to the LM workspaces: prev 63 + vel 189 + root 3 + height + t_prev doubles, 4 words
