@@ -13,7 +13,8 @@ import sys
 out, tag = sys.argv[1], sys.argv[2]
 args = sys.argv[3:]
 
-NAMES = {"se3d_k_normalize": "normalize", "se3d_k_pairs_flat": "epipolar_pairs", "se3d_k_pairs_tiled": "epipolar_pairs",
+NAMES = {"se3d_k_normalize": "normalize", "se3d_k_pairs_flat": "epipolar_pairs", "se3d_k_pairs_packed": "epipolar_pairs",
+         "se3d_k_postprocess_wave": "postprocess", "se3d_k_pairs_tiled": "epipolar_pairs",
          "se3d_k_sweep_fused_wave": "sweep", "se3d_k_sweep_fused": "sweep", "se3d_k_sweep_cost": "sweep_cost", "se3d_k_sweep_assign": "sweep_assign",
          "se3d_k_triangulate": "triangulate", "se3d_k_postprocess": "postprocess", "se3d_k_stage2_walk": "stage2_walk",
          "se3d_k_track_cost": "track_cost", "se3d_k_track_assoc": "track_assoc", "se3d_k_lm_refine": "lm_refine",
@@ -25,8 +26,12 @@ def short(name):
     return NAMES.get(n, n)
 
 
+def newest(files):  # gpurun merges the outputs of successive runs into the same local directory: keep the latest run only
+    return sorted(files, key=os.path.getmtime)[-1:] if files else []
+
+
 def counters(sub, cname):
-    files = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)
+    files = newest(glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True))
     tot, cnt = collections.Counter(), collections.Counter()
     for f in files:
         for r in csv.DictReader(open(f)):
@@ -37,7 +42,7 @@ def counters(sub, cname):
     return tot, cnt
 
 
-stats = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
+stats = newest(glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True))
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     with open(os.path.join(out, "kernel_stats.csv"), "w") as f:
@@ -52,7 +57,7 @@ def arg(name, default):
 
 
 K, W = arg("--steps", 20), arg("--warmup", 3)
-trace = glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True)
+trace = newest(glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True))
 if trace:
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(trace[0])):
