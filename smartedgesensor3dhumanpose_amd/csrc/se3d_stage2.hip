@@ -13,6 +13,11 @@
 #include <cstring>
 #include <type_traits>
 
+// Stage 2 is fp64 optimisation with a stated tolerance (refined joints < 1 mm, GTSAM 4.0.3 control flow), not a bit-exact float
+// expression tree like stage 1: let the compiler contract a*b+c into v_fma_f64 here (shorter dependency chains in the LM solves).
+// The Munkres code included above only adds, subtracts and compares, so its bit-exactness is unaffected.
+#pragma clang fp contract(fast)
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // Diagnostic build only (make diag): per-phase cycle stamps of the LM kernel written to a debug buffer (never in the product .so)
