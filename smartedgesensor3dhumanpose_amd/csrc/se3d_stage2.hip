@@ -1447,6 +1447,69 @@ __device__ __forceinline__ void s2_track_update_wave(const Se3dStage2 &Q, int s,
   }
 }
 
+// De-normalised previous pose of every track slot of the sequence, prev * height_prev + root_prev (what calc_normed_dist PP:84-101
+// and calc_3d_dist PP:103-119 compare against), staged once per phase in LDS: [T][21][3] doubles.
+__device__ __forceinline__ void s2_fill_track_pos(const Se3dStage2 &Q, int s, int tid, int nthr, double *tpos) {
+  const int T = Q.T;
+  for (int idx = tid; idx < T * SE3D_NFU * 3; idx += nthr) {
+    const int slot = idx / (SE3D_NFU * 3), r = idx - slot * (SE3D_NFU * 3), a = r % 3;
+    const size_t sl = (size_t)s * T + slot;
+    tpos[idx] = Q.used[sl] ? Q.prev[sl * SE3D_NFU * 3 + r] * Q.height_prev[sl] + Q.root_prev[sl * 3 + a] : 0.0;
+  }
+}
+__device__ __forceinline__ void s2_track_cost_lds(const Se3dStage2 &Q, int s, int tid, int nthr, const double *tpos) {
+  const int T = Q.T, H = Q.H;
+  const int nd = min(Q.n_det[s], H), nt = Q.n_tracks[s];
+  const se3d_person3d *dets = Q.dets + (size_t)s * H;
+  double *C = Q.C + (size_t)s * H * T;
+  const double t = Q.t[s];
+  for (int idx = tid; idx < nd * nt; idx += nthr) {
+    const int det = idx % nd, tk = idx / nd;
+    const int slot = Q.order[(size_t)s * T + tk];
+    const size_t sl = (size_t)s * T + slot;
+    const uint32_t has = Q.has[sl];
+    const double delta_t = t - Q.trk_t_prev[sl];
+    const double *pp = tpos + (size_t)slot * SE3D_NFU * 3;
+    int nj = 0;
+    double dist = 0.0;
+    for (int k = 0; k < SE3D_NFU; ++k) {
+      const se3d_keypoint3d &kp = dets[det].keypoints[k];
+      if (kp.score > 0.10f && ((has >> k) & 1u)) {
+        const double dx = kp.joint[0] - pp[3 * k], dy = kp.joint[1] - pp[3 * k + 1], dz = kp.joint[2] - pp[3 * k + 2];
+        dist += sqrt(dx * dx + dy * dy + dz * dz) / (c_vel_sigmas[k] * delta_t);
+        ++nj;
+      }
+    }
+    C[det + (size_t)nd * tk] = nj > 0 ? dist / nj : 1e6;
+  }
+}
+// row `si` of the merge-distance bit matrix (T <= 64: word 0 only) from the staged positions; one wavefront, lane <-> slot j
+__device__ __forceinline__ void s2_track_near_lds(const Se3dStage2 &Q, int si, int s, int lane, const double *tpos) {
+  const int T = Q.T;
+  const size_t sli = (size_t)s * T + si;
+  unsigned long long *row = Q.near + sli * 4;
+  if (!Q.used[sli]) { if (lane < 4) row[lane] = 0ull; return; }
+  const uint32_t hasi = Q.has[sli];
+  const double *pi = tpos + (size_t)si * SE3D_NFU * 3;
+  bool nr = false;
+  if (lane < T && lane != si && Q.used[(size_t)s * T + lane]) {
+    const uint32_t both = hasi & Q.has[(size_t)s * T + lane];
+    const double *pj = tpos + (size_t)lane * SE3D_NFU * 3;
+    int nj = 0;
+    double dist = 0.0;
+    for (int k = 0; k < SE3D_NFU; ++k)
+      if ((both >> k) & 1u) {
+        const double dx = pi[3 * k] - pj[3 * k], dy = pi[3 * k + 1] - pj[3 * k + 1], dz = pi[3 * k + 2] - pj[3 * k + 2];
+        dist += sqrt(dx * dx + dy * dy + dz * dz);
+        ++nj;
+      }
+    nr = (nj > 0 ? dist / nj : 1e6) < 0.20;
+  }
+  const unsigned long long b = __ballot(nr);
+  if (lane == 0) row[0] = b;
+  if (lane >= 1 && lane < 4) row[lane] = 0ull;
+}
+
 #define S2_WALK_WAVES 4
 #ifdef SE3D_LM_STAMPS
 #define WK_STAMP_INIT unsigned long long wk_prev_ = __builtin_readcyclecounter();
@@ -1457,10 +1520,11 @@ __device__ __forceinline__ void s2_track_update_wave(const Se3dStage2 &Q, int s,
 #endif
 __global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk) {
   extern __shared__ __align__(16) unsigned char s2_walk_smem[];
-  __shared__ double pi[S2_WALK_WAVES][SE3D_NFU][3];
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = Q.H, T = Q.T;
   constexpr int NT = 64 * S2_WALK_WAVES;
+  // dynamic LDS: [S2_WALK_WAVES] LM workspaces | [T][63] de-normalised track positions | optional per-track state
+  double *tpos = reinterpret_cast<double *>(s2_walk_smem + S2_WALK_WAVES * sizeof(LmSchurLds));
   // Per-track state of this sequence lives in LDS for the duration of the walk when it fits (Wk.lds_state): every phase touches
   // it through the same Se3dStage2 pointers (rebased generic pointers), at LDS instead of HBM/L2 latency.
   Se3dStage2 Qs = Q;
@@ -1469,7 +1533,7 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3d
   int32_t *l_id = nullptr, *l_nobs = nullptr;
   uint8_t *l_used = nullptr;
   if (Wk.lds_state) {
-    double *b = reinterpret_cast<double *>(s2_walk_smem + S2_WALK_WAVES * sizeof(LmSchurLds));
+    double *b = tpos + (size_t)T * SE3D_NFU * 3;
     l_prev = b; b += (size_t)T * SE3D_NFU * 3;
     l_vel = b; b += (size_t)T * SE3D_NFU * 9;
     l_root = b; b += (size_t)T * 3;
@@ -1516,7 +1580,11 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3d
     q.pred_dt = Wk.Wdt + f0;
     const int nd = min(q.n_det[s0], H);
     WK_STAMP_INIT
-    if (nd > 0) s2_track_cost_flat(q, s0, tid, 64 * S2_WALK_WAVES);
+    if (nd > 0) {
+      s2_fill_track_pos(q, s0, tid, NT, tpos);
+      __syncthreads();
+      s2_track_cost_lds(q, s0, tid, NT, tpos);
+    }
     __syncthreads();
     WK_STAMP(10)  // track cost
     if (wave == 0) s2_track_assoc_wave(q, s0, lane, reinterpret_cast<double *>(s2_walk_smem));
@@ -1530,10 +1598,9 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3d
       }
       __syncthreads();
       WK_STAMP(12)  // LM (slowest wavefront of the sequence)
-      for (int si = wave; si < T; si += S2_WALK_WAVES) {
-        s2_track_near_body(q, si, s0, lane, pi[wave]);
-        __builtin_amdgcn_wave_barrier();
-      }
+      s2_fill_track_pos(q, s0, tid, NT, tpos);  // the LM phase has updated the tracks
+      __syncthreads();
+      for (int si = wave; si < T; si += S2_WALK_WAVES) s2_track_near_lds(q, si, s0, lane, tpos);
       __syncthreads();
       WK_STAMP(13)  // merge-distance bit matrix
       if (wave == 0) s2_track_update_wave(q, s0, lane);
@@ -1586,9 +1653,10 @@ extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk,
     lds_max = 160 * 1024 - 4096;  // 160 KB per CU minus the kernel's static LDS
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_stage2_walk), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   }
+  const size_t tpos_bytes = (size_t)Q.T * SE3D_NFU * 3 * sizeof(double);
   Se3dWalk w = Wk;
-  w.lds_state = (lm_bytes + state_bytes <= (size_t)lds_max) ? 1 : 0;
-  const size_t dyn = lm_bytes + (w.lds_state ? state_bytes : 0);
+  w.lds_state = (lm_bytes + tpos_bytes + state_bytes <= (size_t)lds_max) ? 1 : 0;
+  const size_t dyn = lm_bytes + tpos_bytes + (w.lds_state ? state_bytes : 0);
   hipLaunchKernelGGL(se3d_k_stage2_walk, dim3(nseq), dim3(64 * S2_WALK_WAVES), dyn, st, q, w);
   return true;
 }
