@@ -31,3 +31,11 @@ def smoke_stage2(node, rig, frames, res, O):
         g = pp.skeleton_callback(r.published(), fr.stamp, fr.fb_delay)
         o = ora.step(r.published(), rig.n_cam, fr.stamp, fr.fb_delay, capacity=node.limits.max_hyp)
         compare_stage2(g, o)
+    # feedback reprojection of the stage-1 persons of the last frame (pose_reprojection) against the oracle
+    node.set_reprojection_cameras()
+    got = node.reproject(res[-1].published())
+    ref = O.reproject(rig, "simple", res[-1].published())
+    assert np.array_equal(got.det_offset, ref.det_offset) and got.det_offset[-1] > 0
+    n = int(ref.det_offset[-1])
+    assert np.array_equal(got.person_index[:n], ref.person_index[:n])
+    assert np.allclose(got.persons[:n]["keypoints"]["x"], ref.persons[:n]["keypoints"]["x"], rtol=2e-6, atol=1e-4)
