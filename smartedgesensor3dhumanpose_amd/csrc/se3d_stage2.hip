@@ -1520,6 +1520,7 @@ __device__ __forceinline__ void s2_track_near_lds(const Se3dStage2 &Q, int si, i
 #endif
 __global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk) {
   extern __shared__ __align__(16) unsigned char s2_walk_smem[];
+  __shared__ int s_next_person;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = Q.H, T = Q.T;
   constexpr int NT = 64 * S2_WALK_WAVES;
@@ -1588,11 +1589,16 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3d
     __syncthreads();
     WK_STAMP(10)  // track cost
     if (wave == 0) s2_track_assoc_wave(q, s0, lane, reinterpret_cast<double *>(s2_walk_smem));
+    if (tid == 0) s_next_person = 0;
     __syncthreads();
     WK_STAMP(11)  // association (Munkres)
     if (nd > 0) {
       LmSchurLds &L = reinterpret_cast<LmSchurLds *>(s2_walk_smem)[wave];
-      for (int i = wave; i < nd; i += S2_WALK_WAVES) {
+      for (;;) {  // persons are handed out dynamically: LM iteration counts vary from 2 to 60, a static split waits for the unlucky wavefront
+        int i = 0;
+        if (lane == 0) i = atomicAdd(&s_next_person, 1);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= nd) break;
         s2_lm_body<3>(q, i, s0, lane, L);
         __builtin_amdgcn_wave_barrier();
       }
