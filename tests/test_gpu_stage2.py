@@ -209,3 +209,35 @@ def test_stage2_walk_device_pack(extr_rig):
             got += n
     assert got == S_ * T_ * 5
     node.close()
+
+
+def test_stage2_walk_then_per_step_share_track_state(extr_rig):
+    """Track state written back by a fused walk (it lives in LDS during the walk) is what later per-step calls continue from."""
+    S_, T_ = 3, 16
+    seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=5, n_frames=T_, seed=500 + s))[0] for s in range(S_)]
+    frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
+    a = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=8)
+    b = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=8)
+    for nd in (a, b):
+        nd.stage(frames)
+        nd.run_stage1()
+        nd.refine_reset()
+    ts = [100.0 + (i + 1) / 30.0 for i in range(T_)]
+    half = T_ // 2
+    a.run_stage2_walk(np.repeat(np.array(ts[:half])[:, None], S_, 1), [k * S_ for k in range(half)])
+    for k in range(half):
+        b.run_stage2(np.full(S_, ts[k]), frame_slot0=k * S_)
+    published = 0
+    for k in range(half, T_):
+        for nd in (a, b):
+            nd.run_stage2(np.full(S_, ts[k]), frame_slot0=k * S_)
+        ra, rb = a.fetch_stage2(S_), b.fetch_stage2(S_)
+        for s in range(S_):
+            n = ra[s].n_persons
+            assert n == rb[s].n_persons and ra[s].c.n_tracks == rb[s].c.n_tracks
+            assert ra[s].fused[:n].tobytes() == rb[s].fused[:n].tobytes()
+            assert ra[s].fused_pred[:n].tobytes() == rb[s].fused_pred[:n].tobytes()
+            published += n
+    assert published > 0
+    a.close()
+    b.close()
