@@ -30,7 +30,10 @@ __device__ unsigned long long g_lm_stamps[16];
     stamp_prev_ = __builtin_readcyclecounter();                                       \
   }
 #define LM_STAMP_INIT unsigned long long stamp_prev_ = __builtin_readcyclecounter();
+__device__ int g_lm_ablate;  // diagnostic build only: bit 0 = stop after one LM iteration, bit 1 = skip marginals, bit 2 = skip the LM loop
+#define LM_ABLATE(bit) (g_lm_ablate & (bit))
 #else
+#define LM_ABLATE(bit) 0
 #define LM_STAMP(idx)
 #define LM_STAMP_INIT
 #endif
@@ -279,18 +282,26 @@ struct LmCommon {
 struct LmLds : LmCommon {   // dense variant: H = J^T J + lambda I (64 x 65 doubles)
   double Hm[64 * HS];
 };
-struct LmSchurLds : LmCommon {  // Schur/Woodbury variant: only the <= 21 x 21 bone-factor system is dense
+struct LmSchurBase : LmCommon {  // Schur/Woodbury + forest variants: only the <= 21 x 21 bone-factor system is dense
   double Dv[SE3D_NFU][6];   // (A_v + lambda I)^-1, symmetric 3x3 (xx,xy,xz,yy,yz,zz)
   double ua[21][3], ub[21][3];  // D^-1 W columns: -D_{v1}^-1 hs_e and +D_{v2}^-1 hs_e
   double zz[SE3D_NFU][3];   // D^-1 g
-  double Mm[32][33];        // M = I + W^T D^-1 W, later its Cholesky factor
-  double Mi[21][22];        // M^-1 (marginals)
   double yy[32];
   double mcov[SE3D_NFU][6];
   unsigned incA[SE3D_NFU], incB[SE3D_NFU];  // bit e: variable is the first / second end of bone factor e
   // forest elimination (tree variant)
   double al[SE3D_NFU], be[SE3D_NFU];
   int par[SE3D_NFU], lev[SE3D_NFU], pe[SE3D_NFU];
+};
+#define S2_MM_DOUBLES (32 * 33)  // M = I + W^T D^-1 W, later its Cholesky factor
+#define S2_MI_DOUBLES (21 * 22)  // M^-1 (marginals)
+struct LmSchurLds : LmSchurBase {  // dense bone-factor system in LDS (per-step kernels)
+  double Mm[32][33];
+  double Mi[21][22];
+};
+struct LmTreeLds : LmSchurBase {   // fused walk: M / M^-1 are needed only by the non-forest fallback (never taken with the reference's
+  double (*Mm)[33];                // bone tables) and live in a per-wavefront HBM scratch, which halves the LDS footprint of a sequence
+  double (*Mi)[22];
 };
 
 __device__ __forceinline__ double s2_wave_sum(double v) {
@@ -510,7 +521,8 @@ __device__ __forceinline__ void s2_sym3_mul(const double m[6], const double v[3]
 }
 
 // D^-1, z = D^-1 g, U = D^-1 W, M = I + W^T U (MFMA) -> row[] = row `lane` of M (identity rows beyond nr)
-__device__ void s2_schur_build(LmSchurLds &L, int K, int nr, double lambda, int lane, const double Av[6], const double gv[3], double Di[6],
+template <class LT>
+__device__ void s2_schur_build(LT &L, int K, int nr, double lambda, int lane, const double Av[6], const double gv[3], double Di[6],
                                double zv[3], double row[21]) {
   if (lane < K) {
     const double D[6] = {Av[0] + lambda, Av[1], Av[2], Av[3] + lambda, Av[4], Av[5] + lambda};
@@ -592,7 +604,8 @@ __device__ __forceinline__ void s2_chol21(double row[21], int lane) {
 }
 
 // tryLambda solve: delta = (D + W W^T)^-1 g  -> L.dl
-__device__ void s2_schur_solve(LmSchurLds &L, int K, int nr, double lambda, int lane, const double Av[6], const double gv[3]) {
+template <class LT>
+__device__ void s2_schur_solve(LT &L, int K, int nr, double lambda, int lane, const double Av[6], const double gv[3]) {
   double Di[6], zv[3] = {0, 0, 0}, row[21];
   s2_schur_build(L, K, nr, lambda, lane, Av, gv, Di, zv, row);
   double b = 0.0;
@@ -651,7 +664,7 @@ __device__ __constant__ const int c_tree_rank[SE3D_NFU] = {7, 4, 8, 15, 19, 9, 1
 
 struct TreeTopo { int parent, pedge, level, maxlev; unsigned children; bool forest; };
 
-__device__ TreeTopo s2_tree_topology(LmSchurLds &L, int K, int nr, int lane) {
+__device__ TreeTopo s2_tree_topology(LmSchurBase &L, int K, int nr, int lane) {
   TreeTopo tp{-1, -1, 0, 0, 0u, true};
   int nparents = 0;
   if (lane < K) {
@@ -679,7 +692,7 @@ __device__ TreeTopo s2_tree_topology(LmSchurLds &L, int K, int nr, int lane) {
 }
 
 // tryLambda solve by forest elimination: delta -> L.dl
-__device__ void s2_tree_solve(LmSchurLds &L, int K, double lambda, int lane, const double Av[6], const double gv[3], const TreeTopo &tp) {
+__device__ void s2_tree_solve(LmSchurBase &L, int K, double lambda, int lane, const double Av[6], const double gv[3], const TreeTopo &tp) {
   double D[6] = {Av[0] + lambda, Av[1], Av[2], Av[3] + lambda, Av[4], Av[5] + lambda};
   double g[3] = {gv[0], gv[1], gv[2]};
   double Di[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0}, z[3] = {0, 0, 0}, h[3] = {0, 0, 0};
@@ -732,7 +745,7 @@ __device__ void s2_tree_solve(LmSchurLds &L, int K, double lambda, int lane, con
 // Marginal covariances on the forest (lambda = 0): after the leaf-to-root elimination D~_c is the information of joint c
 // given its parent, so  Sigma_root = D~_root^-1  and  Sigma_cc = D~_c^-1 + u (h^T Sigma_pp h) u^T,  u = D~_c^-1 h  (top-down).
 // Same 3x3 diagonal blocks of (J^T J)^-1 as Marginals::marginalCovariance (PP:789), exact algebra.
-__device__ void s2_tree_marginals(LmSchurLds &L, int K, int lane, const double Av[6], const TreeTopo &tp) {
+__device__ void s2_tree_marginals(LmSchurBase &L, int K, int lane, const double Av[6], const TreeTopo &tp) {
   double D[6] = {Av[0], Av[1], Av[2], Av[3], Av[4], Av[5]};
   double Di[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0}, h[3] = {0, 0, 0};
   const bool act = lane < K;
@@ -780,7 +793,8 @@ __device__ void s2_tree_marginals(LmSchurLds &L, int K, int lane, const double A
 }
 
 // Marginals: (H^-1)_vv = D_v^-1 - sum_{e,f incident to v} u_e (M^-1)[e][f] u_f^T  -> L.mcov
-__device__ void s2_schur_marginals(LmSchurLds &L, int K, int nr, int lane, const double Av[6]) {
+template <class LT>
+__device__ void s2_schur_marginals(LT &L, int K, int nr, int lane, const double Av[6]) {
   double Di[6] = {0, 0, 0, 0, 0, 0}, zv[3], row[21];
   const double g0[3] = {0, 0, 0};
   s2_schur_build(L, K, nr, 0.0, lane, Av, g0, Di, zv, row);
@@ -826,9 +840,8 @@ __device__ __forceinline__ void s2_cov6_to_mat(const double c[6], double M[9]) {
 
 // MODE 0: dense 63x63 H per wavefront (J^T J on MFMA); 1: Schur/Woodbury (MFMA) for solve and marginals; 2: forest elimination
 // for the LM solves + Schur/Woodbury (MFMA) marginals; 3: forest elimination for solves and marginals (no matrix product left)
-template <int MODE>
-__device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, int lane,
-                                           typename std::conditional<MODE != 0, LmSchurLds, LmLds>::type &L) {  // one wavefront
+template <int MODE, class LT = typename std::conditional<MODE != 0, LmSchurLds, LmLds>::type>
+__device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, int lane, LT &L) {  // one wavefront
   constexpr bool SCHUR = MODE != 0;
   const int H = Q.H, T = Q.T;
   if (i >= min(Q.n_det[s], H)) return;
@@ -972,7 +985,7 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
   if (whiten_ok) {
     double error = s2_graph_error(L, L.xc, K, nr, lane);
     double lambda = 1e-5;
-    if (!(error <= 0.0)) {
+    if (!(error <= 0.0) && !LM_ABLATE(4)) {
       for (int outer = 0; outer < 1000; ++outer) {
         const double currentError = error;
         LM_STAMP(1)  // graph error / loop control
@@ -1074,6 +1087,7 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
         }
         (void)stepped;
         if (iterations >= 100) break;  // maxIterations
+        if (LM_ABLATE(1)) break;
         if (error <= 0.0) break;       // errorTol
         const double absoluteDecrease = currentError - error;
         const double relativeDecrease = absoluteDecrease / currentError;
@@ -1092,7 +1106,7 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
   bool use_marg = false;
   double mc[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (SCHUR) {
-    if (whiten_ok) {
+    if (whiten_ok && !LM_ABLATE(2)) {
       s2_linearize(L, K, nr, lane);
       if (MODE == 3 && topo.forest) s2_tree_marginals(L, K, lane, Av, topo);
       else s2_schur_marginals(L, K, nr, lane, Av);
@@ -1525,7 +1539,7 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3d
   const int H = Q.H, T = Q.T;
   constexpr int NT = 64 * S2_WALK_WAVES;
   // dynamic LDS: [S2_WALK_WAVES] LM workspaces | [T][63] de-normalised track positions | optional per-track state
-  double *tpos = reinterpret_cast<double *>(s2_walk_smem + S2_WALK_WAVES * sizeof(LmSchurLds));
+  double *tpos = reinterpret_cast<double *>(s2_walk_smem + S2_WALK_WAVES * sizeof(LmTreeLds));
   // Per-track state of this sequence lives in LDS for the duration of the walk when it fits (Wk.lds_state): every phase touches
   // it through the same Se3dStage2 pointers (rebased generic pointers), at LDS instead of HBM/L2 latency.
   Se3dStage2 Qs = Q;
@@ -1593,13 +1607,19 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3d
     __syncthreads();
     WK_STAMP(11)  // association (Munkres)
     if (nd > 0) {
-      LmSchurLds &L = reinterpret_cast<LmSchurLds *>(s2_walk_smem)[wave];
+      LmTreeLds &L = reinterpret_cast<LmTreeLds *>(s2_walk_smem)[wave];
+      if (lane == 0) {  // the association phase used this LDS as Munkres scratch
+        double *scr = Q.lm_scratch + ((size_t)blockIdx.x * S2_WALK_WAVES + wave) * (S2_MM_DOUBLES + S2_MI_DOUBLES);
+        L.Mm = reinterpret_cast<double (*)[33]>(scr);
+        L.Mi = reinterpret_cast<double (*)[22]>(scr + S2_MM_DOUBLES);
+      }
+      __builtin_amdgcn_wave_barrier();
       for (;;) {  // persons are handed out dynamically: LM iteration counts vary from 2 to 60, a static split waits for the unlucky wavefront
         int i = 0;
         if (lane == 0) i = atomicAdd(&s_next_person, 1);
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= nd) break;
-        s2_lm_body<3>(q, i, s0, lane, L);
+        s2_lm_body<3, LmTreeLds>(q, i, s0, lane, L);
         __builtin_amdgcn_wave_barrier();
       }
       __syncthreads();
@@ -1627,6 +1647,7 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3d
 }
 
 #ifdef SE3D_LM_STAMPS
+extern "C" void se3d_diag_lm_ablate(int bits) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lm_ablate), &bits, sizeof(int)); }
 extern "C" void se3d_diag_lm_stamps(unsigned long long *out16, int reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lm_stamps), sizeof(unsigned long long) * 16);
@@ -1644,7 +1665,7 @@ static int s2_lm_mode() {
 
 // true: the fused kernel was launched; false: not applicable (caller falls back to per-step launches)
 extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st) {
-  const size_t lm_bytes = S2_WALK_WAVES * sizeof(LmSchurLds);
+  const size_t lm_bytes = S2_WALK_WAVES * sizeof(LmTreeLds);
   const char *e = getenv("SE3D_WALK");  // A/B evidence switch (read per launch): steps = always use the per-step kernels
   const bool ok = !(e && strcmp(e, "steps") == 0) && s2_lm_mode() == 3;
   // The fused walk gives each sequence one workgroup (4 LM wavefronts): right for many short sequences of few persons.  Large
