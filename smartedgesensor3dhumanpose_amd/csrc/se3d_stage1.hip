@@ -242,8 +242,15 @@ __device__ __forceinline__ void se3d_pairs_tile_compute(const LineLDS (*L1)[PT],
         float d1, d2;
         if (FAST) { d1 = se3d_div_markstein(n1, l1[i].nrm, a[i].z); d2 = se3d_div_markstein(n2, l2[k].nrm, b[k].z); }
         else { d1 = n1 / l1[i].nrm; d2 = n2 / l2[k].nrm; }
-        const float sacc = d1 + d2;
-        acc[i][k] += ((mm[i][k] >> j) & 1u) ? (double)sacc : 0.0;
+        // joint validity as 0/1 weights staged with the points (P*.w): (d1 + d2) * 1 is exact, (d1 + d2) * 0 adds +0.0 — the same sum as
+        // the masked accumulation, two multiplies instead of a bit test and a 64-bit select per pair-joint (all operands are finite)
+        if (FAST) {
+          const float sacc = (d1 + d2) * (a[i].w * b[k].w);  // finite: the shared-reciprocal divide returns 0 for a zero / out-of-range norm
+          acc[i][k] += (double)sacc;
+        } else {
+          const float sacc = d1 + d2;                          // IEEE divide: an invalid joint may be inf / NaN, select instead of multiply
+          acc[i][k] += ((mm[i][k] >> j) & 1u) ? (double)sacc : 0.0;
+        }
       }
     }
   }
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256, 3) void se3d_k_pairs_tiled(Se3dDev D, const in
         unsafe |= (p < na) && ((M1[d] >> k) & 1u) &&
                   !(y != 0.f && se3d_in_safe_range(l.lx) && se3d_in_safe_range(l.ly) && se3d_in_safe_range(l.lz) && se3d_in_safe_range(A.x) && se3d_in_safe_range(A.y));
         L1[jj][d] = l;
-        P1[jj][d] = make_float4(A.x, A.y, y, 0.f);
+        P1[jj][d] = make_float4(A.x, A.y, y, (p < na && ((M1[d] >> k) & 1u)) ? 1.f : 0.f);
       }
       {
         const int q = q0 + d;
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256, 3) void se3d_k_pairs_tiled(Se3dDev D, const in
         unsafe |= (q < nb) && ((M2[d] >> k) & 1u) &&
                   !(y != 0.f && se3d_in_safe_range(l.lx) && se3d_in_safe_range(l.ly) && se3d_in_safe_range(l.lz) && se3d_in_safe_range(Bq.x) && se3d_in_safe_range(Bq.y));
         L2[jj][d] = l;
-        P2[jj][d] = make_float4(Bq.x, Bq.y, y, 0.f);
+        P2[jj][d] = make_float4(Bq.x, Bq.y, y, (q < nb && ((M2[d] >> k) & 1u)) ? 1.f : 0.f);
       }
     }
     if (unsafe) s_unsafe = 1;
