@@ -1,0 +1,124 @@
+"""CPU tests of the ROS-free rosbag v2.0 / person_msgs wire-format reader and writer.  No bag of the reference
+is available here, so the checks are: hand-built records with a known byte layout, writer -> reader round trips (multi-chunk, bz2
+chunks), and the chain bag -> per-camera streams -> approximate-time synchroniser -> frames."""
+import bz2
+import struct
+
+import numpy as np
+
+from smartedgesensor3dhumanpose_amd import person_msgs as pm
+from smartedgesensor3dhumanpose_amd import rosbag_io as rb
+from smartedgesensor3dhumanpose_amd import scene as S
+from smartedgesensor3dhumanpose_amd.harness import ApproximateTimeSync, stream_from_frames
+from smartedgesensor3dhumanpose_amd.rig import extr_rig_16cam
+
+
+def test_person2dlist_wire_layout_known_bytes():
+    p = np.zeros(1, pm.person2d_dt)
+    p[0]["score"] = 0.5
+    p[0]["bbox"] = [1, 2, 3, 4]
+    p[0]["keypoints"]["x"] = np.arange(17)
+    p[0]["keypoints"]["cov"][:, 2] = 7.0
+    buf = rb.serialize_person2d_list(12 * 10**9 + 34, p, fb_delay=0.25, frame_id="cam_3", seq=9)
+    # std_msgs/Header: seq, stamp.secs, stamp.nsecs, string frame_id ; float32 fb_delay ; Person2D[] (uint32 count)
+    assert buf[:12] == struct.pack("<III", 9, 12, 34)
+    assert buf[12:21] == struct.pack("<I", 5) + b"cam_3"
+    assert buf[21:29] == struct.pack("<fI", 0.25, 1)
+    # Person2D: float32 score ; Keypoint2D[] (uint32 count, 6 float32 each) ; float32[4] bbox (fixed array: no count)
+    assert buf[29:37] == struct.pack("<fI", 0.5, 17)
+    assert buf[37:61] == struct.pack("<6f", 0, 0, 0, 0, 0, 7.0)
+    assert buf[37 + 24:37 + 48] == struct.pack("<6f", 1, 0, 0, 0, 0, 7.0)
+    assert buf[-16:] == struct.pack("<4f", 1, 2, 3, 4) and len(buf) == 37 + 17 * 24 + 16
+    m = rb.deserialize_person2d_list(buf)
+    assert (m["seq"], m["stamp_ns"], m["frame_id"], m["fb_delay"], m["skipped"]) == (9, 12 * 10**9 + 34, "cam_3", 0.25, 0)
+    assert m["persons"].tobytes() == p.tobytes()
+    # a person with a different keypoint count is skipped like the node does (S3D:319-320)
+    odd = buf[:25] + struct.pack("<I", 2) + buf[29:] + struct.pack("<fI", 0.1, 3) + bytes(3 * 24) + bytes(16)
+    m2 = rb.deserialize_person2d_list(odd)
+    assert len(m2["persons"]) == 1 and m2["skipped"] == 1
+
+
+def test_personcovlist_round_trip():
+    rng = np.random.default_rng(0)
+    P = np.zeros(3, pm.person3d_dt)
+    P["id"] = [4, 9, 11]
+    P["score"] = [0.1, 0.2, 0.3]
+    P["keypoints"]["joint"] = rng.normal(size=(3, 21, 3))
+    P["keypoints"]["score"] = rng.uniform(size=(3, 21)).astype(np.float32)
+    P["keypoints"]["cov"] = rng.normal(size=(3, 21, 6))
+    ts = [5 * 10**9 + i for i in range(16)]
+    buf = rb.serialize_person_cov_list(7 * 10**9, P, ts, np.full(16, 0.05, np.float32))
+    # per person: id, score, count, 21 x (3 f64 + f32 + 6 f64) + Pose (7 f64) + Vector3 (3 f64)
+    assert len(buf) == 16 + 4 + (4 + 16 * 8) + (4 + 16 * 4) + 4 + 3 * (12 + 21 * 76 + 80)
+    m = rb.deserialize_person_cov_list(buf)
+    assert m["ts_per_cam_ns"] == ts and m["frame_id"] == "base" and m["stamp_ns"] == 7 * 10**9
+    for f in ("id", "score"):
+        assert np.array_equal(m["persons"][f], P[f])
+    for f in ("joint", "score", "cov"):
+        assert np.array_equal(m["persons"]["keypoints"][f], P["keypoints"][f])
+
+
+def test_md5_algorithm_on_known_types():
+    # geometry_msgs/Pose = md5("<md5(Point)> position\n<md5(Quaternion)> orientation"): checks the composition rule on published sums
+    import hashlib
+    txt = "%s position\n%s orientation" % (rb.KNOWN_MD5["geometry_msgs/Point"], rb.KNOWN_MD5["geometry_msgs/Quaternion"])
+    assert hashlib.md5(txt.encode()).hexdigest() == rb.KNOWN_MD5["geometry_msgs/Pose"]
+    assert hashlib.md5(b"float64 x\nfloat64 y\nfloat64 z").hexdigest() == rb.KNOWN_MD5["geometry_msgs/Point"]
+    assert len(rb.msg_md5("person_msgs/Person2DList")) == 32 and rb.msg_md5("person_msgs/Person2DList") != rb.msg_md5("person_msgs/PersonCovList")
+
+
+def _scene_messages(n_frames=6):
+    rig = extr_rig_16cam()
+    frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=4, n_frames=n_frames, seed=3))
+    stream = stream_from_frames(frames)
+    rng = np.random.default_rng(2)
+    msgs = []
+    for k, cams in enumerate(stream):
+        for c, m in enumerate(cams):
+            st = int(round(m.stamp * 1e9)) + int(rng.integers(-2_000_000, 2_000_000))
+            msgs.append(("/cam_%d/skel" % c, "person_msgs/Person2DList", st + 5_000_000, rb.serialize_person2d_list(st, m.persons, m.fb_delay, "cam_%d" % c, k)))
+    msgs.sort(key=lambda x: x[2])
+    return rig, frames, msgs
+
+
+def test_bag_round_trip_multichunk_and_bz2(tmp_path):
+    rig, frames, msgs = _scene_messages()
+    path = str(tmp_path / "poses2D.bag")
+    rb.write_bag(path, msgs, chunk_messages=20)
+    raw = open(path, "rb").read()
+    assert raw.startswith(rb.MAGIC) and raw[len(rb.MAGIC) + 4096 - 1:len(rb.MAGIC) + 4096] == b" "  # padded bag header record
+    conns, got = rb.read_bag(path)
+    assert len(conns) == 16 and all(c["type"] == "person_msgs/Person2DList" for c in conns.values())
+    assert [(t, ts, p) for t, _, ts, p in msgs] == got
+    # re-pack the first chunk with bz2 compression: the reader must give the same messages
+    pos = len(rb.MAGIC) + 4096
+    (hl,) = struct.unpack_from("<I", raw, pos)
+    hdr = rb._parse_fields(raw[pos + 4:pos + 4 + hl])
+    (dl,) = struct.unpack_from("<I", raw, pos + 4 + hl)
+    data = raw[pos + 8 + hl:pos + 8 + hl + dl]
+    assert hdr["op"][0] == rb.OP_CHUNK and hdr["compression"] == b"none"
+    comp = bz2.compress(data)
+    rec = rb._record({"op": bytes([rb.OP_CHUNK]), "compression": b"bz2", "size": struct.pack("<I", len(data))}, comp)
+    p2 = str(tmp_path / "poses2D_bz2.bag")
+    open(p2, "wb").write(raw[:pos] + rec + raw[pos + 8 + hl + dl:])
+    assert rb.read_bag(p2)[1] == got
+
+
+def test_bag_to_synchronised_frames(tmp_path):
+    rig, frames, msgs = _scene_messages(n_frames=8)
+    path = str(tmp_path / "poses2D.bag")
+    rb.write_bag(path, msgs)
+    streams = rb.read_person2d_stream(path)
+    topics = ["/cam_%d/skel" % c for c in range(16)]
+    assert sorted(streams) == sorted(topics) and all(len(v) == 8 for v in streams.values())
+    out = []
+    sync = ApproximateTimeSync(max(3, 1 + 16 // 4), 16, lambda tup: out.append(tup), age_penalty=2.0, lower_bound_ns=20_000_000)
+    arrival = sorted((int(round(m.stamp * 1e9)), c, m) for c, t in enumerate(topics) for m in streams[t])
+    for st, c, m in arrival:
+        sync.add((st, m), c)
+    assert len(out) >= 6
+    for k, tup in enumerate(out):
+        for c, (st, m) in enumerate(tup):
+            fr = frames[k]
+            ref = fr.persons[fr.det_offset[c]:fr.det_offset[c + 1]]
+            assert m.persons.tobytes() == ref.tobytes()
