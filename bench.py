@@ -129,15 +129,16 @@ def main():
     psz = pm.person3d_dt.itemsize
     if dist is not None:
         # Exchange: one RCCL all-gather of the final skeletons per context and step so that every rank holds the
-        # skeletons of all ranks ([B][max_hyp] persons + [B] counts per context, frame-slot order).  Stream-ordered, no host
+        # skeletons of all ranks ([B][n_persons + 2] person slots + [B] counts per context, frame-slot order).  Stream-ordered, no host
         # synchronisation: the collective is enqueued behind the context's asynchronous pack (its HIP stream is handed to torch as an
         # ExternalStream) and runs on RCCL's stream while the context's next step computes; the pack buffers are double-buffered and a
         # buffer is rewritten only after the collective that read it two steps earlier has completed (device-side wait).
         n_slots = B
+        XH = min(H, w["n_persons"] + 2) if stage2 and args.walk == "fused" else H   # person slots per frame carried by the exchange
         streams = [torch.cuda.ExternalStream(nd_.stream_handle()) for nd_ in nodes]
-        packs = [[torch.zeros(n_slots * H * psz, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in nodes]
+        packs = [[torch.zeros(n_slots * XH * psz, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in nodes]
         cnts = [[torch.zeros(n_slots, dtype=torch.int32, device="cuda") for _ in range(2)] for _ in nodes]
-        gath_p = [torch.empty(world * n_slots * H * psz, dtype=torch.uint8, device="cuda") for _ in nodes]
+        gath_p = [torch.empty(world * n_slots * XH * psz, dtype=torch.uint8, device="cuda") for _ in nodes]
         gath_c = [torch.empty(world * n_slots, dtype=torch.int32, device="cuda") for _ in nodes]
         works = [[None, None] for _ in nodes]
         parity = [0] * len(nodes)
@@ -182,10 +183,12 @@ def main():
             nd_.run_stage2_walk(np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
             if dist is not None:  # async D2D of all time steps' fused skeletons (frame-slot order) into the exchange buffer
                 pk, cn = pack_target(ci)
-                nd_.pack_stage2_walk_device(B, pk.data_ptr(), cn.data_ptr())
+                nd_.pack_stage2_walk_device_slots(B, XH, pk.data_ptr(), cn.data_ptr())
                 exchange(ci)
             if collect is not None:
-                collect.append(sum(r.n_persons for k in ks for r in nd_.fetch_stage2_walk(k * S_, S_)))
+                per_frame = [r.n_persons for k in ks for r in nd_.fetch_stage2_walk(k * S_, S_)]
+                assert dist is None or max(per_frame) <= XH, "exchange slots per frame too small: skeletons would be truncated"
+                collect.append(sum(per_frame))
         else:
             pk, cn = pack_target(ci) if dist is not None else (None, None)
             for k, t in zip(ks, ts):

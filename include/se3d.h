@@ -172,6 +172,10 @@ int se3d_fetch_stage2(se3d_ctx *ctx, int32_t n_seq, se3d_fused_out *outs);
 int se3d_run_stage2_walk(se3d_ctx *ctx, int32_t n_seq, int32_t n_steps, const int32_t *frame_slot0, const double *t);
 int se3d_fetch_stage2_walk(se3d_ctx *ctx, int32_t frame_slot0, int32_t n_seq, se3d_fused_out *outs);
 int se3d_pack_stage2_walk_device(se3d_ctx *ctx, int32_t n_frames, void *d_persons, void *d_counts);
+/* Same with a caller-chosen number of person slots per frame (1 <= slots <= max_hyp): [n_frames][slots] persons.  Lets an exchange
+ * carry only as many slots as the scene can publish instead of the full hypothesis capacity; frames that published more than
+ * `slots` persons are truncated in the copy (their count is still the true one, so the receiver can detect it). */
+int se3d_pack_stage2_walk_device_slots(se3d_ctx *ctx, int32_t n_frames, int32_t slots, void *d_persons, void *d_counts);
 
 
 /* --- feedback reprojection: drop-in for fusedSkeletonCallback (pose_reprojection/src/skeleton_reproj_mult_node.cpp:139-235) --

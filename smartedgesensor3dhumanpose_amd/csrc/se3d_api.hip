@@ -657,6 +657,17 @@ int se3d_pack_stage2_walk_device(se3d_ctx *c, int32_t n_frames, void *d_persons,
   return SE3D_OK;
 }
 
+int se3d_pack_stage2_walk_device_slots(se3d_ctx *c, int32_t n_frames, int32_t slots, void *d_persons, void *d_counts) {
+  if (!c || !d_persons || !d_counts || n_frames < 1 || n_frames > c->Q.S || slots < 1 || slots > c->Q.H) return SE3D_ERR_ARG;
+  if (!c->ran2) return SE3D_ERR_STATE;
+  const Se3dStage2 &Q = c->Q;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy2DAsync(d_persons, sizeof(se3d_person3d) * (size_t)slots, Q.fused, sizeof(se3d_person3d) * (size_t)Q.H,
+                             sizeof(se3d_person3d) * (size_t)slots, (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_counts, Q.n_out, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
+  return SE3D_OK;
+}
+
 int se3d_fetch_stage2(se3d_ctx *c, int32_t n_seq, se3d_fused_out *outs) {
   if (!c || !outs || n_seq < 1 || n_seq > c->Q.S) return SE3D_ERR_ARG;
   if (!c->ran2) { c->err = "fetch before run"; return SE3D_ERR_STATE; }

@@ -29,8 +29,8 @@ def gather_skeletons(dist, packed_u8, counts_i32, max_hyp):
 
 def unpack_skeletons(gathered_u8, gathered_counts, max_hyp):
     """Host view: list over ranks of list over slots of person3d arrays (valid entries only)."""
-    g = gathered_u8.cpu().numpy()
-    c = gathered_counts.cpu().numpy()
+    g = gathered_u8.cpu().numpy() if hasattr(gathered_u8, "cpu") else np.asarray(gathered_u8)
+    c = gathered_counts.cpu().numpy() if hasattr(gathered_counts, "cpu") else np.asarray(gathered_counts)
     out = []
     for r in range(g.shape[0]):
         persons = g[r].view(pm.person3d_dt).reshape(-1, max_hyp)

@@ -130,6 +130,11 @@ class Skeleton3D:
         self._chk(self._L.se3d_pack_stage2_walk_device(C.c_void_p(self._h), int(n_frames), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)),
                   "se3d_pack_stage2_walk_device")
 
+    def pack_stage2_walk_device_slots(self, n_frames, slots, persons_ptr, counts_ptr):
+        """[n_frames][slots] persons (slots <= max_hyp) + [n_frames] true counts; asynchronous."""
+        self._chk(self._L.se3d_pack_stage2_walk_device_slots(C.c_void_p(self._h), int(n_frames), int(slots), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)),
+                  "se3d_pack_stage2_walk_device_slots")
+
     def pack_stage2_device(self, n_seq, persons_ptr, counts_ptr):
         """Asynchronous D2D copy of the last run_stage2 results ([n_seq][max_hyp] persons, [n_seq] counts); sync() before use."""
         self._chk(self._L.se3d_pack_stage2_device(C.c_void_p(self._h), int(n_seq), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)), "se3d_pack_stage2_device")

@@ -31,3 +31,46 @@ def extr_rig(oracle):
 def demo_params():
     from smartedgesensor3dhumanpose_amd import person_msgs as pm
     return pm.Params(pm.POSE_SIMPLE, 0, 0.045)  # pose_triangulate_demo.launch:4-5,12-14,26-27
+
+
+class DeviceBuffer:
+    """Raw HIP device allocation for the device-pack tests (ctypes on the already loaded HIP runtime): the GPU test-suite never
+    initialises torch.cuda, whose first use on a fresh box can page in its GPU code objects for minutes."""
+
+    def __init__(self, nbytes):
+        import ctypes as C
+        from smartedgesensor3dhumanpose_amd import _lib
+        _lib.lib()
+        self._C, self.nbytes = C, int(nbytes)
+        self._hip = C.CDLL("libamdhip64.so")
+        p = C.c_void_p()
+        assert self._hip.hipMalloc(C.byref(p), C.c_size_t(self.nbytes)) == 0
+        self.ptr = p.value
+        assert self._hip.hipMemset(C.c_void_p(self.ptr), 0, C.c_size_t(self.nbytes)) == 0
+
+    def data_ptr(self):
+        return self.ptr
+
+    def numpy(self, dtype):
+        import numpy as np
+        out = np.zeros(self.nbytes, np.uint8)
+        assert self._hip.hipMemcpy(out.ctypes.data_as(self._C.c_void_p), self._C.c_void_p(self.ptr), self._C.c_size_t(self.nbytes), 2) == 0  # D2H
+        return out.view(dtype)
+
+    def free(self):
+        if self.ptr:
+            self._hip.hipFree(self._C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+@pytest.fixture
+def device_buffer():
+    made = []
+
+    def make(nbytes):
+        made.append(DeviceBuffer(nbytes))
+        return made[-1]
+
+    yield make
+    for b in made:
+        b.free()

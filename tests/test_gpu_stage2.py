@@ -108,19 +108,15 @@ def test_stage2_feedback_delay_moving_average(extr_rig, oracle, demo_params):
     node.close()
 
 
-def test_device_pack_matches_host_fetch(extr_rig):
+def test_device_pack_matches_host_fetch(extr_rig, device_buffer):
     """se3d_pack_stage{1,2}_device (the source of the RCCL all-gather) delivers exactly what the host fetch returns."""
-    import torch
     from smartedgesensor3dhumanpose_amd import shard
     S_, H = 3, 32
     node = _node(extr_rig, max_frames=S_, max_det_per_cam=8, max_hyp=H)
     seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=3 + s, n_frames=12, seed=90 + s))[0] for s in range(S_)]
     node.refine_reset()
     psz = pm.person3d_dt.itemsize
-    p1 = torch.zeros(S_ * H * psz, dtype=torch.uint8, device="cuda")
-    c1 = torch.zeros(S_, dtype=torch.int32, device="cuda")
-    p2 = torch.zeros(S_ * H * psz, dtype=torch.uint8, device="cuda")
-    c2 = torch.zeros(S_, dtype=torch.int32, device="cuda")
+    p1, c1, p2, c2 = device_buffer(S_ * H * psz), device_buffer(4 * S_), device_buffer(S_ * H * psz), device_buffer(4 * S_)
     for k in range(12):
         frames = [seqs[s][k] for s in range(S_)]
         node.stage(frames)
@@ -130,8 +126,8 @@ def test_device_pack_matches_host_fetch(extr_rig):
         node.pack_stage2_device(S_, p2.data_ptr(), c2.data_ptr())
         node.sync()
     r1, r2 = node.fetch_stage1(S_), node.fetch_stage2(S_)
-    u1 = shard.unpack_skeletons(p1.view(1, -1), c1.view(1, -1), H)[0]
-    u2 = shard.unpack_skeletons(p2.view(1, -1), c2.view(1, -1), H)[0]
+    u1 = shard.unpack_skeletons(p1.numpy(np.uint8).reshape(1, -1), c1.numpy(np.int32).reshape(1, -1), H)[0]
+    u2 = shard.unpack_skeletons(p2.numpy(np.uint8).reshape(1, -1), c2.numpy(np.int32).reshape(1, -1), H)[0]
     for s in range(S_):
         assert u1[s].tobytes() == r1[s].published().tobytes()
         assert u2[s].tobytes() == r2[s].fused[: r2[s].n_persons].tobytes()
@@ -179,8 +175,7 @@ def test_stage2_walk_equals_per_step_and_oracle(extr_rig, oracle, demo_params, S
     b.close()
 
 
-def test_stage2_walk_device_pack(extr_rig):
-    import torch
+def test_stage2_walk_device_pack(extr_rig, device_buffer):
     from smartedgesensor3dhumanpose_amd import shard
     S_, T_, H = 4, 12, 8
     seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=5, n_frames=T_, seed=70 + s))[0] for s in range(S_)]
@@ -190,15 +185,19 @@ def test_stage2_walk_device_pack(extr_rig):
     node.run_stage1()
     node.refine_reset()
     psz = pm.person3d_dt.itemsize
-    p = torch.zeros(S_ * T_ * H * psz, dtype=torch.uint8, device="cuda")
-    c = torch.zeros(S_ * T_, dtype=torch.int32, device="cuda")
+    p, c = device_buffer(S_ * T_ * H * psz), device_buffer(4 * S_ * T_)
     for rep in range(2):
         ks = list(range(T_)) if rep == 0 else list(range(T_ - 1, -1, -1))
         ts = [100.0 + (rep * T_ + i + 1) / 30.0 for i in range(T_)]
         node.run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in ks])
     node.pack_stage2_walk_device(S_ * T_, p.data_ptr(), c.data_ptr())
+    XH = 6   # compact exchange layout: 6 of the 8 person slots per frame
+    p6, c6 = device_buffer(S_ * T_ * XH * psz), device_buffer(4 * S_ * T_)
+    node.pack_stage2_walk_device_slots(S_ * T_, XH, p6.data_ptr(), c6.data_ptr())
     node.sync()
-    u = shard.unpack_skeletons(p.view(1, -1), c.view(1, -1), H)[0]
+    u = shard.unpack_skeletons(p.numpy(np.uint8).reshape(1, -1), c.numpy(np.int32).reshape(1, -1), H)[0]
+    u6 = shard.unpack_skeletons(p6.numpy(np.uint8).reshape(1, -1), c6.numpy(np.int32).reshape(1, -1), XH)[0]
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(u, u6))
     got = 0
     for k in range(T_):
         r = node.fetch_stage2_walk(k * S_, S_)
