@@ -396,12 +396,7 @@ int se3d_run_stage1(se3d_ctx *c) {
   if (c->staged_frames < 1) { c->err = "no frames staged"; return SE3D_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   const Se3dDev &D = c->D;
-  const int B = D.d.B, N = D.d.N, H = D.d.H;
-  HIPCHK(c, hipMemsetAsync(D.assoc, 0xFF, sizeof(int32_t) * (size_t)B * H * N, c->stream));
-  HIPCHK(c, hipMemsetAsync(D.nviews, 0, sizeof(int32_t) * (size_t)B * H, c->stream));
-  HIPCHK(c, hipMemsetAsync(D.nhyp, 0, sizeof(int32_t) * (size_t)B, c->stream));
-  HIPCHK(c, hipMemsetAsync(D.flags, 0, sizeof(uint32_t) * (size_t)B, c->stream));
-  HIPCHK(c, hipMemsetAsync(D.hypP, 0, sizeof(se3d_person3d) * (size_t)B * H, c->stream));
+  // the per-frame workspace (assoc, nviews, nhyp, flags, hypP) is reset by se3d_k_normalize, the first kernel of the pass
   se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled);
   HIPCHK(c, hipGetLastError());
   c->ran = true;

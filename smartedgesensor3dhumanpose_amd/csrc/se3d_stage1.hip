@@ -56,6 +56,17 @@ __global__ __launch_bounds__(256) void se3d_k_normalize(Se3dDev D) {
   __shared__ int s_nvalid;
   const int n = min(D.nraw[f * N + c], P);
   for (int r = tid; r < P; r += blockDim.x) { cnt[r] = 0; mgt[r] = 0; mge[r] = 0; }
+  {  // per-frame workspace reset (was five memsets per pass): the N workgroups of a frame share the work
+    const int H = D.d.H;
+    for (int h = tid; h < H; h += blockDim.x) D.assoc[((size_t)f * H + h) * N + c] = -1;
+    const size_t words = (size_t)H * (sizeof(se3d_person3d) / 4);
+    uint32_t *hp = reinterpret_cast<uint32_t *>(D.hypP + (size_t)f * H);
+    for (size_t w = (size_t)c * blockDim.x + tid; w < words; w += (size_t)N * blockDim.x) hp[w] = 0u;
+    if (c == 0) {
+      for (int h = tid; h < H; h += blockDim.x) D.nviews[f * H + h] = 0;
+      if (tid == 0) { D.nhyp[f] = 0; D.flags[f] = 0u; }
+    }
+  }
   __syncthreads();
   const se3d_person2d *raw = D.raw + ((size_t)(f * N + c)) * P;
   for (int idx = tid; idx < n * SE3D_NKP; idx += blockDim.x) {
