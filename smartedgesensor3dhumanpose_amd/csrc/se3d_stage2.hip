@@ -1294,35 +1294,6 @@ __device__ __forceinline__ int s2_nth_set_bit(unsigned long long m, int n) {  //
   return m ? __ffsll((long long)m) - 1 : -1;
 }
 
-// calc_normed_dist (PP:84-101) for every (detection, track) pair, flattened over the threads of the workgroup
-__device__ __forceinline__ void s2_track_cost_flat(const Se3dStage2 &Q, int s, int tid, int nthr) {
-  const int T = Q.T, H = Q.H;
-  const int nd = min(Q.n_det[s], H), nt = Q.n_tracks[s];
-  const se3d_person3d *dets = Q.dets + (size_t)s * H;
-  double *C = Q.C + (size_t)s * H * T;
-  const double t = Q.t[s];
-  for (int idx = tid; idx < nd * nt; idx += nthr) {
-    const int det = idx % nd, tk = idx / nd;
-    const size_t sl = (size_t)s * T + Q.order[(size_t)s * T + tk];
-    const uint32_t has = Q.has[sl];
-    const double delta_t = t - Q.trk_t_prev[sl];
-    const double hp = Q.height_prev[sl];
-    const double r0 = Q.root_prev[sl * 3 + 0], r1 = Q.root_prev[sl * 3 + 1], r2 = Q.root_prev[sl * 3 + 2];
-    int nj = 0;
-    double dist = 0.0;
-    for (int k = 0; k < SE3D_NFU; ++k) {
-      const se3d_keypoint3d &kp = dets[det].keypoints[k];
-      if (kp.score > 0.10f && ((has >> k) & 1u)) {
-        const double *pv = Q.prev + (sl * SE3D_NFU + k) * 3;
-        const double dx = kp.joint[0] - (pv[0] * hp + r0), dy = kp.joint[1] - (pv[1] * hp + r1), dz = kp.joint[2] - (pv[2] * hp + r2);
-        dist += sqrt(dx * dx + dy * dy + dz * dz) / (c_vel_sigmas[k] * delta_t);
-        ++nj;
-      }
-    }
-    C[det + (size_t)nd * tk] = nj > 0 ? dist / nj : 1e6;
-  }
-}
-
 __device__ __forceinline__ void s2_remove_old_wave(const Se3dStage2 &Q, int s, double t, int lane) {  // PP:191-211
   const int T = Q.T;
   const int nt = Q.n_tracks[s];
