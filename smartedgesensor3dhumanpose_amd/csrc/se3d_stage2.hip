@@ -1495,7 +1495,9 @@ __device__ __forceinline__ void s2_track_near_lds(const Se3dStage2 &Q, int si, i
   if (lane >= 1 && lane < 4) row[lane] = 0ull;
 }
 
+#ifndef S2_WALK_WAVES
 #define S2_WALK_WAVES 4
+#endif
 #ifdef SE3D_LM_STAMPS
 #define WK_STAMP_INIT unsigned long long wk_prev_ = __builtin_readcyclecounter();
 #define WK_STAMP(idx) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_lm_stamps[idx], now_ - wk_prev_); wk_prev_ = now_; }
@@ -1503,81 +1505,94 @@ __device__ __forceinline__ void s2_track_near_lds(const Se3dStage2 &Q, int si, i
 #define WK_STAMP_INIT
 #define WK_STAMP(idx)
 #endif
-__global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk) {
+// S2_WALK_SEQS sequences share a workgroup: their persons feed one LM work queue (the slowest person of a sequence-step no longer
+// idles three wavefronts: the other sequence's persons fill them), their association / lifecycle phases run on different
+// wavefronts at the same time, and a sequence costs half the registers / wave slots of a one-sequence workgroup.
+#define S2_WALK_SEQS 2
+__global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int nseq) {
   extern __shared__ __align__(16) unsigned char s2_walk_smem[];
   __shared__ int s_next_person;
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sb = blockIdx.x * S2_WALK_SEQS, ns = min(S2_WALK_SEQS, nseq - sb);  // sequences sb .. sb + ns - 1 (local index 0 .. ns - 1)
   const int H = Q.H, T = Q.T;
   constexpr int NT = 64 * S2_WALK_WAVES;
-  // dynamic LDS: [S2_WALK_WAVES] LM workspaces | [T][63] de-normalised track positions | optional per-track state
+  // dynamic LDS: [S2_WALK_WAVES] LM workspaces | [SEQS][T][63] de-normalised track positions | optional per-track state [SEQS][T]...
   double *tpos = reinterpret_cast<double *>(s2_walk_smem + S2_WALK_WAVES * sizeof(LmTreeLds));
-  // Per-track state of this sequence lives in LDS for the duration of the walk when it fits (Wk.lds_state): every phase touches
-  // it through the same Se3dStage2 pointers (rebased generic pointers), at LDS instead of HBM/L2 latency.
+  const size_t tpos_stride = (size_t)T * SE3D_NFU * 3;
+  // Per-track state of the sequences lives in LDS for the duration of the walk when it fits (Wk.lds_state): every phase touches it
+  // through the same Se3dStage2 pointers (generic pointers), at LDS instead of HBM/L2 latency.
   Se3dStage2 Qs = Q;
   double *l_prev = nullptr, *l_vel = nullptr, *l_root = nullptr, *l_height = nullptr, *l_tprev = nullptr;
   uint32_t *l_has = nullptr;
   int32_t *l_id = nullptr, *l_nobs = nullptr;
   uint8_t *l_used = nullptr;
+  const int TT = S2_WALK_SEQS * T;       // LDS state capacity (track slots of all sequences of the workgroup)
+  const int tn = ns * T;                 // track slots in use
+  const size_t g0 = (size_t)sb * T;
   if (Wk.lds_state) {
-    double *b = tpos + (size_t)T * SE3D_NFU * 3;
-    l_prev = b; b += (size_t)T * SE3D_NFU * 3;
-    l_vel = b; b += (size_t)T * SE3D_NFU * 9;
-    l_root = b; b += (size_t)T * 3;
-    l_height = b; b += T;
-    l_tprev = b; b += T;
+    double *b = tpos + S2_WALK_SEQS * tpos_stride;
+    l_prev = b; b += (size_t)TT * SE3D_NFU * 3;
+    l_vel = b; b += (size_t)TT * SE3D_NFU * 9;
+    l_root = b; b += (size_t)TT * 3;
+    l_height = b; b += TT;
+    l_tprev = b; b += TT;
     l_has = reinterpret_cast<uint32_t *>(b);
-    l_id = reinterpret_cast<int32_t *>(l_has + T);
-    l_nobs = l_id + T;
-    l_used = reinterpret_cast<uint8_t *>(l_nobs + T);
-    const size_t g0 = (size_t)s * T;
-    for (int i = tid; i < T * SE3D_NFU * 3; i += NT) l_prev[i] = Q.prev[g0 * SE3D_NFU * 3 + i];
-    for (int i = tid; i < T * SE3D_NFU * 9; i += NT) l_vel[i] = Q.vel[g0 * SE3D_NFU * 9 + i];
-    for (int i = tid; i < T * 3; i += NT) l_root[i] = Q.root_prev[g0 * 3 + i];
-    for (int i = tid; i < T; i += NT) {
+    l_id = reinterpret_cast<int32_t *>(l_has + TT);
+    l_nobs = l_id + TT;
+    l_used = reinterpret_cast<uint8_t *>(l_nobs + TT);
+    for (int i = tid; i < tn * SE3D_NFU * 3; i += NT) l_prev[i] = Q.prev[g0 * SE3D_NFU * 3 + i];
+    for (int i = tid; i < tn * SE3D_NFU * 9; i += NT) l_vel[i] = Q.vel[g0 * SE3D_NFU * 9 + i];
+    for (int i = tid; i < tn * 3; i += NT) l_root[i] = Q.root_prev[g0 * 3 + i];
+    for (int i = tid; i < tn; i += NT) {
       l_height[i] = Q.height_prev[g0 + i]; l_tprev[i] = Q.trk_t_prev[g0 + i]; l_has[i] = Q.has[g0 + i];
       l_id[i] = Q.id[g0 + i]; l_nobs[i] = Q.num_obs[g0 + i]; l_used[i] = Q.used[g0 + i];
     }
     Qs.prev = l_prev; Qs.vel = l_vel; Qs.root_prev = l_root; Qs.height_prev = l_height; Qs.trk_t_prev = l_tprev;
     Qs.has = l_has; Qs.id = l_id; Qs.num_obs = l_nobs; Qs.used = l_used;
     __syncthreads();
+  } else {
+    Qs.prev += g0 * SE3D_NFU * 3; Qs.vel += g0 * SE3D_NFU * 9; Qs.root_prev += g0 * 3; Qs.height_prev += g0; Qs.trk_t_prev += g0;
+    Qs.has += g0; Qs.id += g0; Qs.num_obs += g0; Qs.used += g0;
   }
-  {  // every per-sequence array is rebased to this sequence, so the phase bodies run with sequence index 0
-    const size_t g0 = (size_t)s * T;
-    if (!Wk.lds_state) {
-      Qs.prev += g0 * SE3D_NFU * 3; Qs.vel += g0 * SE3D_NFU * 9; Qs.root_prev += g0 * 3; Qs.height_prev += g0; Qs.trk_t_prev += g0;
-      Qs.has += g0; Qs.id += g0; Qs.num_obs += g0; Qs.used += g0;
-    }
-    Qs.fb_buf += (size_t)s * 3; Qs.t_prev += s; Qs.next_id += s; Qs.frame_nr += s; Qs.n_tracks += s; Qs.order += g0;
-    Qs.C += (size_t)s * H * T; Qs.W += (size_t)s * H * T; Qs.near += g0 * 4; Qs.det_slot += (size_t)s * H; Qs.pub += (size_t)s * H;
-    Qs.fused_det += (size_t)s * H; Qs.pred_det += (size_t)s * H; Qs.iters_det += (size_t)s * H; Qs.flags2 += s;
-  }
-  const int s0 = 0;
+  // every per-sequence array is rebased to the first sequence of the workgroup: the phase bodies run with the local sequence index
+  Qs.fb_buf += (size_t)sb * 3; Qs.t_prev += sb; Qs.next_id += sb; Qs.frame_nr += sb; Qs.n_tracks += sb; Qs.order += g0;
+  Qs.C += (size_t)sb * H * T; Qs.W += (size_t)sb * H * T; Qs.near += g0 * 4; Qs.det_slot += (size_t)sb * H; Qs.pub += (size_t)sb * H;
+  Qs.fused_det += (size_t)sb * H; Qs.pred_det += (size_t)sb * H; Qs.iters_det += (size_t)sb * H; Qs.flags2 += sb;
+  const bool par_assoc = (size_t)H * T * sizeof(double) <= sizeof(LmTreeLds);  // each association wavefront has its own Munkres scratch
   for (int k = 0; k < Wk.n_steps; ++k) {
-    const size_t f0 = (size_t)Wk.slot0[k] + s;
+    const size_t f0 = (size_t)Wk.slot0[k] + sb;
     Se3dStage2 q = Qs;
     q.dets = Wk.outP + f0 * H;
     q.n_det = Wk.out_count + f0;
     q.fb_delay = Wk.fb + f0 * Q.N;
-    q.t = Wk.t + (size_t)k * Wk.t_stride + s;
+    q.t = Wk.t + (size_t)k * Wk.t_stride + sb;
     q.fused = Wk.Wf + f0 * H;
     q.pred = Wk.Wp + f0 * H;
     q.iters = Wk.Wit + f0 * H;
     q.n_out = Wk.Wn + f0;
     q.pred_dt = Wk.Wdt + f0;
-    const int nd = min(q.n_det[s0], H);
+    int nd[S2_WALK_SEQS];
+#pragma unroll
+    for (int s = 0; s < S2_WALK_SEQS; ++s) nd[s] = (s < ns) ? min(q.n_det[s], H) : 0;
     WK_STAMP_INIT
-    if (nd > 0) {
-      s2_fill_track_pos(q, s0, tid, NT, tpos);
-      __syncthreads();
-      s2_track_cost_lds(q, s0, tid, NT, tpos);
-    }
+#pragma unroll
+    for (int s = 0; s < S2_WALK_SEQS; ++s)
+      if (nd[s] > 0) s2_fill_track_pos(q, s, tid, NT, tpos + s * tpos_stride);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < S2_WALK_SEQS; ++s)
+      if (nd[s] > 0) s2_track_cost_lds(q, s, tid, NT, tpos + s * tpos_stride);
     __syncthreads();
     WK_STAMP(10)  // track cost
-    if (wave == 0) s2_track_assoc_wave(q, s0, lane, reinterpret_cast<double *>(s2_walk_smem));
+    if (par_assoc) {
+      if (wave < ns) s2_track_assoc_wave(q, wave, lane, reinterpret_cast<double *>(s2_walk_smem + wave * sizeof(LmTreeLds)));
+    } else if (wave == 0) {
+      for (int s = 0; s < ns; ++s) s2_track_assoc_wave(q, s, lane, reinterpret_cast<double *>(s2_walk_smem));
+    }
     if (tid == 0) s_next_person = 0;
     __syncthreads();
     WK_STAMP(11)  // association (Munkres)
-    if (nd > 0) {
+    {
       LmTreeLds &L = reinterpret_cast<LmTreeLds *>(s2_walk_smem)[wave];
       if (lane == 0) {  // the association phase used this LDS as Munkres scratch
         double *scr = Q.lm_scratch + ((size_t)blockIdx.x * S2_WALK_WAVES + wave) * (S2_MM_DOUBLES + S2_MI_DOUBLES);
@@ -1585,37 +1600,53 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES, 3) void se3d_k_stage2_walk(Se3d
         L.Mi = reinterpret_cast<double (*)[22]>(scr + S2_MM_DOUBLES);
       }
       __builtin_amdgcn_wave_barrier();
-      for (;;) {  // persons are handed out dynamically: LM iteration counts vary from 2 to 60, a static split waits for the unlucky wavefront
-        int i = 0;
-        if (lane == 0) i = atomicAdd(&s_next_person, 1);
-        i = __builtin_amdgcn_readfirstlane(i);
-        if (i >= nd) break;
-        s2_lm_body<3, LmTreeLds>(q, i, s0, lane, L);
+      int total = 0;
+#pragma unroll
+      for (int s = 0; s < S2_WALK_SEQS; ++s) total += nd[s];
+      for (;;) {  // persons of all sequences are handed out dynamically: LM iteration counts vary from 2 to 60
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(&s_next_person, 1);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= total) break;
+        int s = 0, i = idx;
+#pragma unroll
+        for (int ss = 0; ss + 1 < S2_WALK_SEQS; ++ss)
+          if (s == ss && i >= nd[ss]) { i -= nd[ss]; s = ss + 1; }
+        s2_lm_body<3, LmTreeLds>(q, i, s, lane, L);
         __builtin_amdgcn_wave_barrier();
       }
-      __syncthreads();
-      WK_STAMP(12)  // LM (slowest wavefront of the sequence)
-      s2_fill_track_pos(q, s0, tid, NT, tpos);  // the LM phase has updated the tracks
-      __syncthreads();
-      for (int si = wave; si < T; si += S2_WALK_WAVES) s2_track_near_lds(q, si, s0, lane, tpos);
-      __syncthreads();
-      WK_STAMP(13)  // merge-distance bit matrix
-      if (wave == 0) s2_track_update_wave(q, s0, lane);
+    }
+    __syncthreads();
+    WK_STAMP(12)  // LM
+#pragma unroll
+    for (int s = 0; s < S2_WALK_SEQS; ++s)
+      if (nd[s] > 0) s2_fill_track_pos(q, s, tid, NT, tpos + s * tpos_stride);  // the LM phase has updated the tracks
+    __syncthreads();
+    for (int it = wave; it < ns * T; it += S2_WALK_WAVES) {
+      const int s = it / T, si = it - s * T;
+      const int nds = (s == 0) ? nd[0] : nd[S2_WALK_SEQS - 1];
+      if (nds > 0) s2_track_near_lds(q, si, s, lane, tpos + s * tpos_stride);
+    }
+    __syncthreads();
+    WK_STAMP(13)  // merge-distance bit matrix
+    if (wave < ns) {
+      const int ndw = (wave == 0) ? nd[0] : nd[S2_WALK_SEQS - 1];
+      if (ndw > 0) s2_track_update_wave(q, wave, lane);
     }
     __syncthreads();
     WK_STAMP(14)  // publish + lifecycle
   }
   if (Wk.lds_state) {  // write the track state back
-    const size_t g0 = (size_t)s * T;
-    for (int i = tid; i < T * SE3D_NFU * 3; i += NT) Q.prev[g0 * SE3D_NFU * 3 + i] = l_prev[i];
-    for (int i = tid; i < T * SE3D_NFU * 9; i += NT) Q.vel[g0 * SE3D_NFU * 9 + i] = l_vel[i];
-    for (int i = tid; i < T * 3; i += NT) Q.root_prev[g0 * 3 + i] = l_root[i];
-    for (int i = tid; i < T; i += NT) {
+    for (int i = tid; i < tn * SE3D_NFU * 3; i += NT) Q.prev[g0 * SE3D_NFU * 3 + i] = l_prev[i];
+    for (int i = tid; i < tn * SE3D_NFU * 9; i += NT) Q.vel[g0 * SE3D_NFU * 9 + i] = l_vel[i];
+    for (int i = tid; i < tn * 3; i += NT) Q.root_prev[g0 * 3 + i] = l_root[i];
+    for (int i = tid; i < tn; i += NT) {
       Q.height_prev[g0 + i] = l_height[i]; Q.trk_t_prev[g0 + i] = l_tprev[i]; Q.has[g0 + i] = l_has[i];
       Q.id[g0 + i] = l_id[i]; Q.num_obs[g0 + i] = l_nobs[i]; Q.used[g0 + i] = l_used[i];
     }
   }
 }
+static_assert(S2_WALK_SEQS == 2 && S2_WALK_SEQS <= S2_WALK_WAVES, "the per-sequence count selection in se3d_k_stage2_walk assumes two sequences per workgroup");
 
 #ifdef SE3D_LM_STAMPS
 extern "C" void se3d_diag_lm_ablate(int bits) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lm_ablate), &bits, sizeof(int)); }
@@ -1651,11 +1682,12 @@ extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk,
     lds_max = 160 * 1024 - 4096;  // 160 KB per CU minus the kernel's static LDS
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_stage2_walk), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   }
-  const size_t tpos_bytes = (size_t)Q.T * SE3D_NFU * 3 * sizeof(double);
+  const size_t tpos_bytes = (size_t)S2_WALK_SEQS * Q.T * SE3D_NFU * 3 * sizeof(double);
   Se3dWalk w = Wk;
-  w.lds_state = (lm_bytes + tpos_bytes + state_bytes <= (size_t)lds_max) ? 1 : 0;
-  const size_t dyn = lm_bytes + tpos_bytes + (w.lds_state ? state_bytes : 0);
-  hipLaunchKernelGGL(se3d_k_stage2_walk, dim3(nseq), dim3(64 * S2_WALK_WAVES), dyn, st, q, w);
+  w.lds_state = (lm_bytes + tpos_bytes + S2_WALK_SEQS * state_bytes <= (size_t)lds_max) ? 1 : 0;
+  const size_t dyn = lm_bytes + tpos_bytes + (w.lds_state ? S2_WALK_SEQS * state_bytes : 0);
+  if (dyn > (size_t)lds_max) return false;
+  hipLaunchKernelGGL(se3d_k_stage2_walk, dim3((nseq + S2_WALK_SEQS - 1) / S2_WALK_SEQS), dim3(64 * S2_WALK_WAVES), dyn, st, q, w, nseq);
   return true;
 }
 
