@@ -1508,7 +1508,9 @@ __device__ __forceinline__ void s2_track_near_lds(const Se3dStage2 &Q, int si, i
 // S2_WALK_SEQS sequences share a workgroup: their persons feed one LM work queue (the slowest person of a sequence-step no longer
 // idles three wavefronts: the other sequence's persons fill them), their association / lifecycle phases run on different
 // wavefronts at the same time, and a sequence costs half the registers / wave slots of a one-sequence workgroup.
+#ifndef S2_WALK_SEQS
 #define S2_WALK_SEQS 2
+#endif
 __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int nseq) {
   extern __shared__ __align__(16) unsigned char s2_walk_smem[];
   __shared__ int s_next_person;
@@ -1624,13 +1626,17 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
     __syncthreads();
     for (int it = wave; it < ns * T; it += S2_WALK_WAVES) {
       const int s = it / T, si = it - s * T;
-      const int nds = (s == 0) ? nd[0] : nd[S2_WALK_SEQS - 1];
+      int nds = 0;
+#pragma unroll
+      for (int ss = 0; ss < S2_WALK_SEQS; ++ss) nds = (s == ss) ? nd[ss] : nds;
       if (nds > 0) s2_track_near_lds(q, si, s, lane, tpos + s * tpos_stride);
     }
     __syncthreads();
     WK_STAMP(13)  // merge-distance bit matrix
     if (wave < ns) {
-      const int ndw = (wave == 0) ? nd[0] : nd[S2_WALK_SEQS - 1];
+      int ndw = 0;
+#pragma unroll
+      for (int ss = 0; ss < S2_WALK_SEQS; ++ss) ndw = (wave == ss) ? nd[ss] : ndw;
       if (ndw > 0) s2_track_update_wave(q, wave, lane);
     }
     __syncthreads();
@@ -1646,7 +1652,7 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
     }
   }
 }
-static_assert(S2_WALK_SEQS == 2 && S2_WALK_SEQS <= S2_WALK_WAVES, "the per-sequence count selection in se3d_k_stage2_walk assumes two sequences per workgroup");
+static_assert(S2_WALK_SEQS >= 1 && S2_WALK_SEQS <= S2_WALK_WAVES, "one association / lifecycle wavefront per sequence of the workgroup");
 
 #ifdef SE3D_LM_STAMPS
 extern "C" void se3d_diag_lm_ablate(int bits) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lm_ablate), &bits, sizeof(int)); }
