@@ -802,20 +802,10 @@ struct TriView {  // per-wave view list in LDS (structure of arrays, stride = N)
   int *cam;
 };
 
-__global__ __launch_bounds__(256, 3) void se3d_k_triangulate(Se3dDev D) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int f = blockIdx.y;
+// One (hypothesis, joint): rows T, P, O, U for a single joint by one wavefront.  `base`: 15 N floats of LDS owned by the wavefront,
+// `sRt`: the rig's camera matrices in LDS.
+__device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int h, int j, int lane, float *base, const float *sRt) {
   const int N = D.d.N, P = D.d.P, H = D.d.H;
-  const int gw = blockIdx.x * 4 + wave;
-  const int h = gw / SE3D_NKP, j = gw - h * SE3D_NKP;
-  // camera matrices of the rig staged once per workgroup (every view of every wavefront reads its 3x4 row block several times)
-  float *sRt = reinterpret_cast<float *>(smem) + (size_t)4 * 15 * N;
-  for (int i = threadIdx.x; i < 12 * N; i += 256) sRt[i] = D.Rt[i];
-  __syncthreads();
-  if (h >= D.nhyp[f]) return;
-  if (D.nviews[f * H + h] < 2) return;
-  float *base = reinterpret_cast<float *>(smem) + (size_t)wave * 15 * N;
   TriView T;
   T.x = base; T.y = base + N; T.cf = base + 2 * N; T.ca = base + 3 * N; T.cb = base + 4 * N; T.cc = base + 5 * N;
   for (int k = 0; k < 4; ++k) { T.r0[k] = base + (6 + k) * N; T.r1[k] = base + (10 + k) * N; }
@@ -1074,6 +1064,228 @@ __global__ __launch_bounds__(256, 3) void se3d_k_triangulate(Se3dDev D) {
     kp->score = avg_score;
     kp->cov[0] = (double)(float)cv[0]; kp->cov[1] = (double)(float)cv[1]; kp->cov[2] = (double)(float)cv[2];
     kp->cov[3] = (double)(float)cv[3]; kp->cov[4] = (double)(float)cv[4]; kp->cov[5] = (double)(float)cv[5];
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void se3d_k_triangulate(Se3dDev D) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f = blockIdx.y;
+  const int N = D.d.N, H = D.d.H;
+  const int gw = blockIdx.x * 4 + wave;
+  const int h = gw / SE3D_NKP, j = gw - h * SE3D_NKP;
+  // camera matrices of the rig staged once per workgroup (every view of every wavefront reads its 3x4 row block several times)
+  float *sRt = reinterpret_cast<float *>(smem) + (size_t)4 * 15 * N;
+  for (int i = threadIdx.x; i < 12 * N; i += 256) sRt[i] = D.Rt[i];
+  __syncthreads();
+  if (h >= D.nhyp[f]) return;
+  if (D.nviews[f * H + h] < 2) return;
+  se3d_tri_joint_body(D, f, h, j, lane, reinterpret_cast<float *>(smem) + (size_t)wave * 15 * N, sRt);
+}
+
+// =============================================================================================================
+// Small rigs (N <= 16): one wavefront per HYPOTHESIS instead of one per (hypothesis, joint).  The per-joint kernel above spends most
+// of its 1.9 k instructions per joint on work that uses a fraction of the wavefront (row build: n <= 16 lanes; the weighted solve:
+// the same 4x4 problem on all 64 lanes; 4n+1 ~ 37 sigma points on 64 lanes).  Here the 17 joints of a hypothesis share the
+// wavefront: (joint, view) pairs fill the lanes for the point / row phases, the 17 weighted solves run on 17 lanes at once, and the
+// sigma points of all joints are enumerated densely (17 x 37 samples = 10 rounds of 64 instead of 17 rounds).  Same device functions
+// and the same per-sample arithmetic as the per-joint kernel (identical triangulated points; covariance and error sums are taken
+// sequentially instead of by a butterfly).  Joints that need outlier rejection (reprojection error above the threshold with >= 3
+// views, S3D:748-838) are rare and go through the per-joint routine afterwards.
+// =============================================================================================================
+#define TH_MAXV 16
+struct TriHypLds {
+  float x[SE3D_NKP][TH_MAXV], y[SE3D_NKP][TH_MAXV], cf[SE3D_NKP][TH_MAXV];  // normalised point and confidence per (joint, attached view); cf < 0: unusable
+  float ca[SE3D_NKP][TH_MAXV], cb[SE3D_NKP][TH_MAXV], cc[SE3D_NKP][TH_MAXV];  // Cholesky factor of the 2x2 keypoint covariance
+  union {
+    float rows[SE3D_NKP][TH_MAXV][8];                 // DLT rows r0, r1 (Gram phase only)
+    float dev[SE3D_NKP * (4 * TH_MAXV + 1)][3];       // sigma-point deviations from the weighted solution
+  } u;
+  double G[SE3D_NKP][21];                             // unweighted Gram (10), weighted Gram (10), sum of confidences
+  float X[SE3D_NKP], Y[SE3D_NKP], Z[SE3D_NKP];
+  int cam[TH_MAXV], det[TH_MAXV];
+  int n[SE3D_NKP];
+  unsigned char vidx[SE3D_NKP][TH_MAXV];              // usable views of a joint in ascending camera order
+  float slow[15 * TH_MAXV];                           // view list of the per-joint routine (outlier path)
+};
+
+__device__ __noinline__ void se3d_tri_joint_slow(const Se3dDev *D, int f, int h, int j, int lane, float *base, const float *sRt) {
+  se3d_tri_joint_body(*D, f, h, j, lane, base, sRt);
+}
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) void se3d_k_triangulate_hyp(Se3dDev D) {
+  __shared__ TriHypLds S2[2];
+  __shared__ float sRt[12 * TH_MAXV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f = blockIdx.y, h = blockIdx.x * 2 + wave;
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  for (int i = threadIdx.x; i < 12 * N; i += 128) sRt[i] = D.Rt[i];
+  __syncthreads();
+  if (h >= D.nhyp[f]) return;
+  if (D.nviews[f * H + h] < 2) return;
+  TriHypLds &S = S2[wave];
+  // ---- attached cameras of the hypothesis, ascending ----
+  int nv;
+  {
+    const int k = (lane < N) ? D.assoc[((size_t)f * H + h) * N + lane] : -1;
+    const unsigned long long bl = __ballot(k >= 0);
+    nv = __popcll(bl);
+    if (k >= 0) { const int pos = __popcll(bl & ((1ull << lane) - 1ull)); S.cam[pos] = lane; S.det[pos] = k; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- points: lanes over (joint, view) ----
+  for (int idx = lane; idx < SE3D_NKP * nv; idx += 64) {
+    const int j = idx / nv, v = idx - j * nv;
+    const size_t gi = (((size_t)(f * N + S.cam[v])) * P + S.det[v]) * SE3D_NKP + j;
+    const float4 kp = D.kp[gi];
+    const bool ok = kp.z >= TRI_THRESH;  // S3D:724-732
+    S.x[j][v] = kp.x; S.y[j][v] = kp.y; S.cf[j][v] = ok ? kp.z : -1.f;
+    if (ok) {
+      const float4 kc = D.kcov[gi];
+      const float l11 = sqrtf(kc.x);       // lower Cholesky factor of the 2x2 keypoint covariance (S3D:476-480)
+      const float l21 = kc.y / l11;
+      S.ca[j][v] = l11; S.cb[j][v] = l21; S.cc[j][v] = sqrtf(kc.z - l21 * l21);
+      float r0[4], r1[4];
+      se3d_dlt_rows(sRt + 12 * S.cam[v], kp.x, kp.y, r0, r1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { S.u.rows[j][v][k] = r0[k]; S.u.rows[j][v][4 + k] = r1[k]; }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < SE3D_NKP) {
+    int n = 0;
+    for (int v = 0; v < nv; ++v)
+      if (S.cf[lane][v] >= 0.f) S.vidx[lane][n++] = (unsigned char)v;
+    S.n[lane] = n;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- Gram matrices: lanes over (joint, entry); accumulation over the views in list order like the per-joint kernel ----
+  for (int it = lane; it < SE3D_NKP * 21; it += 64) {
+    const int j = it / 21, e = it - j * 21;
+    const int nn = S.n[j];
+    double acc = 0.0;
+    if (nn >= 2) {
+      const int ge = e < 10 ? e : (e < 20 ? e - 10 : 0);
+      const int gi = (int)((0x3221110000ull >> (4 * ge)) & 0xFull), gj = (int)((0x3323213210ull >> (4 * ge)) & 0xFull);
+      const bool weighted = e >= 10;
+      for (int k = 0; k < nn; ++k) {
+        const int v = S.vidx[j][k];
+        const float cf = S.cf[j][v];
+        if (e == 20) { acc += (double)cf; continue; }
+        float a0 = S.u.rows[j][v][gi], b0 = S.u.rows[j][v][gj], a1 = S.u.rows[j][v][4 + gi], b1 = S.u.rows[j][v][4 + gj];
+        if (weighted) { a0 = a0 * cf; b0 = b0 * cf; a1 = a1 * cf; b1 = b1 * cf; }
+        acc = __builtin_fma((double)a0, (double)b0, acc);
+        acc = __builtin_fma((double)a1, (double)b1, acc);
+      }
+    }
+    S.G[j][e] = acc;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- weighted solve, reprojection error and score: lane <-> joint ----
+  const int nj = (lane < SE3D_NKP) ? S.n[lane] : 0;
+  const bool active = nj >= 2;
+  bool slow = false;
+  float X = 0.f, Y = 0.f, Z = 0.f, avg_score = 0.f;
+  if (active) {
+    double gw_[10], ev[4];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) gw_[k] = S.G[lane][10 + k];
+    const double e4start[4] = {0.0, 0.0, 0.0, 1.0};
+    if (!se3d_null_invit(gw_, e4start, ev)) se3d_eig4_smallest(gw_, ev);
+    const double iw0 = se3d_rcp64(ev[3]);
+    X = (float)(ev[0] * iw0); Y = (float)(ev[1] * iw0); Z = (float)(ev[2] * iw0);
+    double se = 0.0, sc = 0.0;
+    for (int k = 0; k < nj; ++k) {
+      const int v = S.vidx[lane][k];
+      const float cf = S.cf[lane][v];
+      const float e = se3d_reproj1(sRt + 12 * S.cam[v], X, Y, Z, S.x[lane][v], S.y[lane][v]);
+      se += (double)(cf * e);
+      sc += (double)cf;
+    }
+    const double err = se / sc;
+    avg_score = (float)(S.G[lane][20] / nj);
+    slow = err > REPROJ_MAX && nj >= 3;  // outlier rejection needed (S3D:748-838): per-joint routine below
+    if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX / err));  // S3D:840-841
+    S.X[lane] = X; S.Y[lane] = Y; S.Z[lane] = Z;
+  }
+  const unsigned long long slowmask = __ballot(slow);
+  // ---- sigma points of all joints, enumerated densely (S3D:471-523) ----
+  int cnt = (active && !slow) ? 4 * nj + 1 : 0, incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  const int off = incl - cnt;
+  const int total = __builtin_amdgcn_readlane(incl, SE3D_NKP - 1);
+  __builtin_amdgcn_wave_barrier();
+  for (int g = lane; g < total; g += 64) {
+    int j = 0, offj = 0;
+#pragma unroll
+    for (int jj = 1; jj < SE3D_NKP; ++jj) {
+      const int oj = __builtin_amdgcn_readlane(off, jj);
+      if (g >= oj) { j = jj; offj = oj; }   // joints without samples share the offset of the next one: the last match wins
+    }
+    const int s = g - offj;
+    const int n = S.n[j];
+    const float Xj = S.X[j], Yj = S.Y[j], Zj = S.Z[j];
+    const int dim = 2 * n;
+    const float bsc = sqrtf((float)dim + 0.5f);
+    double vstart[4];
+    {
+      const double hn = 1.0 / sqrt((double)Xj * Xj + (double)Yj * Yj + (double)Zj * Zj + 1.0);
+      vstart[0] = Xj * hn; vstart[1] = Yj * hn; vstart[2] = Zj * hn; vstart[3] = hn;
+    }
+    double gq[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) gq[k] = S.G[j][k];
+    if (s > 0) {
+      const int c = (s - 1) >> 2, t = (s - 1) & 3;
+      const int v = S.vidx[j][c];
+      const float l11 = S.ca[j][v], l21 = S.cb[j][v], l22 = S.cc[j][v];
+      const float dx1 = l11 * bsc, dy1 = l21 * bsc, dy2 = l22 * bsc;
+      const float x0 = S.x[j][v], y0 = S.y[j][v];
+      float px = x0, py = y0;
+      if (t == 0) { px -= dx1; py -= dy1; }
+      else if (t == 1) { py -= dy2; }
+      else if (t == 2) { px += dx1; py += dy1; }
+      else { py += dy2; }
+      float o0[4], o1[4], n0[4], n1[4];
+      const float *M = sRt + 12 * S.cam[v];
+      se3d_dlt_rows(M, x0, y0, o0, o1);   // the rows buffer is reused for the deviations: rebuild the view's own rows
+      se3d_dlt_rows(M, px, py, n0, n1);
+      se3d_gram_add<true>(gq, o0); se3d_gram_add<true>(gq, o1);
+      se3d_gram_add(gq, n0); se3d_gram_add(gq, n1);
+    }
+    double e4[4];
+    if (!se3d_null_invit(gq, vstart, e4)) se3d_eig4_smallest(gq, e4);
+    const double iw = se3d_rcp64(e4[3]);
+    S.u.dev[g][0] = (float)(e4[0] * iw) - Xj; S.u.dev[g][1] = (float)(e4[1] * iw) - Yj; S.u.dev[g][2] = (float)(e4[2] * iw) - Zj;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // ---- covariance: lanes over (joint, entry) ----
+  se3d_person3d &person = D.hypP[(size_t)f * H + h];
+  const int pm_ = D.d.pose_method;
+  for (int it = lane; it < SE3D_NKP * 6; it += 64) {
+    const int j = it / 6, e = it - j * 6;
+    const int n = S.n[j];
+    const int offj = __shfl(off, j), cntj = __shfl(cnt, j);
+    if (cntj == 0) continue;
+    const float wgt = 1.0f / (2.0f * ((float)(2 * n) + 0.5f));  // all weights equal because 2*kappa == 1
+    const int ea = e < 3 ? 0 : (e < 5 ? 1 : 2), eb = e < 3 ? e : (e < 5 ? e - 2 : 2);
+    double acc = 0.0;
+    for (int q = 0; q < cntj; ++q) {
+      const float da = S.u.dev[offj + q][ea], db = S.u.dev[offj + q][eb];
+      acc += (double)(da * wgt) * db;
+    }
+    person.keypoints[c_kp2fusion[pm_][j]].cov[e] = (double)(float)acc;
+  }
+  if (active && !slow) {
+    se3d_keypoint3d *kp = &person.keypoints[c_kp2fusion[pm_][lane]];
+    kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
+    kp->score = avg_score;
+  }
+  // ---- joints that need outlier rejection: the per-joint routine, one after the other ----
+  for (unsigned long long m = slowmask; m; m &= m - 1ull) {
+    __builtin_amdgcn_wave_barrier();
+    se3d_tri_joint_slow(&D, f, h, __ffsll((long long)m) - 1, lane, S.slow, sRt);
   }
 }
 
@@ -1472,7 +1684,9 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   }
   if (ev) (void)hipEventRecord(ev[3], st);
   const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
-  hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
+  const char *e_tri = getenv("SE3D_TRI");  // A/B switch (read per launch): joint = always one wavefront per (hypothesis, joint)
+  if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3((H + 1) / 2, B), dim3(128), 0, st, D);
+  else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
   if (ev) (void)hipEventRecord(ev[4], st);
   if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), 0, st, D);
   else hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);

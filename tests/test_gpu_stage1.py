@@ -126,6 +126,30 @@ def test_packed_pair_kernel_equals_flat_kernel_bitwise(extr_rig, monkeypatch):
     assert n > 4000
 
 
+@pytest.mark.parametrize("outliers", [0.0, 0.08])
+def test_hypothesis_wave_triangulation_equals_per_joint_kernel(extr_rig, monkeypatch, outliers):
+    """N <= 16: the one-wavefront-per-hypothesis kernel gives the per-joint kernel's triangulated points bit for bit (same solves on the
+    same Gram matrices); scores and covariances differ only by the summation order of the error / covariance sums.  With gross 2-D
+    outliers the rejection branches (S3D:748-838) run through the per-joint routine inside the new kernel."""
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=8, seed=61, low_score_frac=0.1, p_miss=0.1,
+                                                            outlier_frac=outliers, pixel_noise=3.0))
+    res = {}
+    for mode in ("joint", "hyp"):
+        monkeypatch.setenv("SE3D_TRI", mode)
+        node = _node(extr_rig, max_frames=8, max_det_per_cam=8, max_hyp=16)
+        res[mode] = node.triangulate_persons(frames)
+        node.close()
+    n = 0
+    for a, b in zip(res["joint"], res["hyp"]):
+        assert a.n_hyp == b.n_hyp and a.n_persons == b.n_persons and np.array_equal(a.assoc(), b.assoc())
+        pa, pb = a.published(), b.published()
+        assert np.array_equal(pa["keypoints"]["joint"], pb["keypoints"]["joint"])
+        np.testing.assert_allclose(pa["keypoints"]["score"], pb["keypoints"]["score"], rtol=1e-6, atol=0)
+        np.testing.assert_allclose(pa["keypoints"]["cov"], pb["keypoints"]["cov"], rtol=2e-5, atol=1e-12)
+        n += a.n_persons
+    assert n >= 25
+
+
 def test_device_hungarian_wave_fuzz_small(node16, oracle):
     """Single-wavefront Munkres (<= 64 x 64): ties, rectangular shapes, saturated costs; bit-exact vs the oracle (= reference goldens)."""
     L = node16._L
