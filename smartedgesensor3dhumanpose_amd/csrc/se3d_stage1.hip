@@ -1113,17 +1113,16 @@ __device__ __noinline__ void se3d_tri_joint_slow(const Se3dDev *D, int f, int h,
   se3d_tri_joint_body(*D, f, h, j, lane, base, sRt);
 }
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) void se3d_k_triangulate_hyp(Se3dDev D) {
-  __shared__ TriHypLds S2[2];
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void se3d_k_triangulate_hyp(Se3dDev D) {
+  __shared__ TriHypLds S;   // one wavefront per workgroup: 25 KB of LDS fit next to two resident stage-2 walk workgroups of another context
   __shared__ float sRt[12 * TH_MAXV];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int f = blockIdx.y, h = blockIdx.x * 2 + wave;
+  const int lane = threadIdx.x;
+  const int f = blockIdx.y, h = blockIdx.x;
   const int N = D.d.N, P = D.d.P, H = D.d.H;
-  for (int i = threadIdx.x; i < 12 * N; i += 128) sRt[i] = D.Rt[i];
-  __syncthreads();
   if (h >= D.nhyp[f]) return;
   if (D.nviews[f * H + h] < 2) return;
-  TriHypLds &S = S2[wave];
+  for (int i = lane; i < 12 * N; i += 64) sRt[i] = D.Rt[i];
+  __syncthreads();
   // ---- attached cameras of the hypothesis, ascending ----
   int nv;
   {
@@ -1685,7 +1684,7 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   if (ev) (void)hipEventRecord(ev[3], st);
   const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
   const char *e_tri = getenv("SE3D_TRI");  // A/B switch (read per launch): joint = always one wavefront per (hypothesis, joint)
-  if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3((H + 1) / 2, B), dim3(128), 0, st, D);
+  if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(H, B), dim3(64), 0, st, D);
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
   if (ev) (void)hipEventRecord(ev[4], st);
   if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), 0, st, D);
