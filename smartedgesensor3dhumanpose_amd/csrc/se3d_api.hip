@@ -278,7 +278,7 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     ok = ok && dev_alloc(c, &Q.near, S * T * 4);
     ok = ok && dev_alloc(c, &Q.C, S * H * T) && dev_alloc(c, &Q.W, S * H * T) && dev_alloc(c, &Q.det_slot, S * H) && dev_alloc(c, &Q.pub, S * H);
     ok = ok && dev_alloc(c, &Q.fused_det, S * H) && dev_alloc(c, &Q.pred_det, S * H) && dev_alloc(c, &Q.iters_det, S * H);
-    ok = ok && dev_alloc(c, &Q.lm_scratch, S * 4 * (32 * 33 + 21 * 22));
+    ok = ok && dev_alloc(c, &Q.lm_scratch, S * 4 * 1865);  // [S][4 wavefronts][S2_SCHUR_SCRATCH_DOUBLES] (se3d_stage2.hip)
     ok = ok && dev_alloc(c, &Q.fused, S * H) && dev_alloc(c, &Q.pred, S * H) && dev_alloc(c, &Q.iters, S * H) && dev_alloc(c, &Q.n_out, S);
     ok = ok && dev_alloc(c, &Q.flags2, S);
     ok = ok && dev_alloc(c, &c->d_in2, S * H) && dev_alloc(c, &c->d_ndet2, S) && dev_alloc(c, &c->d_fb, S * N) && dev_alloc(c, &c->d_t, S);

@@ -128,7 +128,7 @@ struct Se3dStage2 {
   int32_t *iters;         // [S][H]
   int32_t *n_out;         // [S]
   uint32_t *flags2;       // [S]
-  double *lm_scratch;     // [S][4][32*33 + 21*22] HBM scratch of the fused walk's non-forest LM fallback
+  double *lm_scratch;     // [S][4][1865] HBM Schur workspace of the fused walk's non-forest LM fallback
 };
 
 // Multi-step stage-2 walk (se3d_run_stage2_walk): step k consumes the stage-1 output of frame slots slot0[k] .. slot0[k]+S-1 and

@@ -282,26 +282,43 @@ struct LmCommon {
 struct LmLds : LmCommon {   // dense variant: H = J^T J + lambda I (64 x 65 doubles)
   double Hm[64 * HS];
 };
-struct LmSchurBase : LmCommon {  // Schur/Woodbury + forest variants: only the <= 21 x 21 bone-factor system is dense
-  double Dv[SE3D_NFU][6];   // (A_v + lambda I)^-1, symmetric 3x3 (xx,xy,xz,yy,yz,zz)
-  double ua[21][3], ub[21][3];  // D^-1 W columns: -D_{v1}^-1 hs_e and +D_{v2}^-1 hs_e
-  double zz[SE3D_NFU][3];   // D^-1 g
-  double yy[32];
+struct LmSchurBase : LmCommon {  // what the forest (tree) elimination needs besides the factor data
   double mcov[SE3D_NFU][6];
   unsigned incA[SE3D_NFU], incB[SE3D_NFU];  // bit e: variable is the first / second end of bone factor e
-  // forest elimination (tree variant)
   double al[SE3D_NFU], be[SE3D_NFU];
   int par[SE3D_NFU], lev[SE3D_NFU], pe[SE3D_NFU];
 };
-#define S2_MM_DOUBLES (32 * 33)  // M = I + W^T D^-1 W, later its Cholesky factor
-#define S2_MI_DOUBLES (21 * 22)  // M^-1 (marginals)
-struct LmSchurLds : LmSchurBase {  // dense bone-factor system in LDS (per-step kernels)
+// Schur/Woodbury workspace: only the <= 21 x 21 bone-factor system is dense
+#define S2_DV_DOUBLES (SE3D_NFU * 6)   // (A_v + lambda I)^-1, symmetric 3x3 (xx,xy,xz,yy,yz,zz)
+#define S2_U_DOUBLES (21 * 3)          // D^-1 W columns: -D_{v1}^-1 hs_e (ua) and +D_{v2}^-1 hs_e (ub); D^-1 g (zz)
+#define S2_YY_DOUBLES 32
+#define S2_MM_DOUBLES (32 * 33)        // M = I + W^T D^-1 W, later its Cholesky factor
+#define S2_MI_DOUBLES (21 * 22)        // M^-1 (marginals)
+#define S2_SCHUR_SCRATCH_DOUBLES (S2_DV_DOUBLES + 3 * S2_U_DOUBLES + S2_YY_DOUBLES + S2_MM_DOUBLES + S2_MI_DOUBLES)
+struct LmSchurLds : LmSchurBase {  // Schur workspace in LDS (per-step kernels)
+  double Dv[SE3D_NFU][6];
+  double ua[21][3], ub[21][3];
+  double zz[SE3D_NFU][3];
+  double yy[32];
   double Mm[32][33];
   double Mi[21][22];
 };
-struct LmTreeLds : LmSchurBase {   // fused walk: M / M^-1 are needed only by the non-forest fallback (never taken with the reference's
-  double (*Mm)[33];                // bone tables) and live in a per-wavefront HBM scratch, which halves the LDS footprint of a sequence
+struct LmTreeLds : LmSchurBase {   // fused walk: the Schur workspace is needed only by the non-forest fallback (never taken with the
+  double (*Dv)[6];                 // reference's bone tables) and lives in a per-wavefront HBM scratch: 7.5 KB of LDS per LM wavefront
+  double (*ua)[3], (*ub)[3];       // instead of 22.5 KB
+  double (*zz)[3];
+  double *yy;
+  double (*Mm)[33];
   double (*Mi)[22];
+  __device__ void bind(double *scr) {
+    Dv = reinterpret_cast<double (*)[6]>(scr); scr += S2_DV_DOUBLES;
+    ua = reinterpret_cast<double (*)[3]>(scr); scr += S2_U_DOUBLES;
+    ub = reinterpret_cast<double (*)[3]>(scr); scr += S2_U_DOUBLES;
+    zz = reinterpret_cast<double (*)[3]>(scr); scr += S2_U_DOUBLES;
+    yy = scr; scr += S2_YY_DOUBLES;
+    Mm = reinterpret_cast<double (*)[33]>(scr); scr += S2_MM_DOUBLES;
+    Mi = reinterpret_cast<double (*)[22]>(scr);
+  }
 };
 
 __device__ __forceinline__ double s2_wave_sum(double v) {
@@ -1596,9 +1613,7 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
     {
       LmTreeLds &L = reinterpret_cast<LmTreeLds *>(s2_walk_smem)[wave];
       if (lane == 0) {  // the association phase used this LDS as Munkres scratch
-        double *scr = Q.lm_scratch + ((size_t)blockIdx.x * S2_WALK_WAVES + wave) * (S2_MM_DOUBLES + S2_MI_DOUBLES);
-        L.Mm = reinterpret_cast<double (*)[33]>(scr);
-        L.Mi = reinterpret_cast<double (*)[22]>(scr + S2_MM_DOUBLES);
+        L.bind(Q.lm_scratch + ((size_t)blockIdx.x * S2_WALK_WAVES + wave) * S2_SCHUR_SCRATCH_DOUBLES);
       }
       __builtin_amdgcn_wave_barrier();
       int total = 0;
@@ -1650,6 +1665,7 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
     }
   }
 }
+static_assert(S2_SCHUR_SCRATCH_DOUBLES == 1865, "se3d_api.hip allocates lm_scratch with this size");
 static_assert(S2_WALK_SEQS >= 1 && S2_WALK_SEQS <= S2_WALK_WAVES, "one association / lifecycle wavefront per sequence of the workgroup");
 
 #ifdef SE3D_LM_STAMPS
