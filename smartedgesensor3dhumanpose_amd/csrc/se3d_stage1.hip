@@ -1094,19 +1094,21 @@ __global__ __launch_bounds__(256, 3) void se3d_k_triangulate(Se3dDev D) {
 // views, S3D:748-838) are rare and go through the per-joint routine afterwards.
 // =============================================================================================================
 #define TH_MAXV 16
+#define TH_JOINTS 9   // joints per workgroup: a hypothesis is split into two one-wavefront workgroups (9 + 8 joints) of 13 KB LDS each,
+                      // so that four of them fit beside two resident stage-2 walk workgroups of another context
 struct TriHypLds {
-  float x[SE3D_NKP][TH_MAXV], y[SE3D_NKP][TH_MAXV], cf[SE3D_NKP][TH_MAXV];  // normalised point and confidence per (joint, attached view); cf < 0: unusable
-  float ca[SE3D_NKP][TH_MAXV], cb[SE3D_NKP][TH_MAXV], cc[SE3D_NKP][TH_MAXV];  // Cholesky factor of the 2x2 keypoint covariance
+  float x[TH_JOINTS][TH_MAXV], y[TH_JOINTS][TH_MAXV], cf[TH_JOINTS][TH_MAXV];  // normalised point and confidence per (joint, attached view); cf < 0: unusable
+  float ca[TH_JOINTS][TH_MAXV], cb[TH_JOINTS][TH_MAXV], cc[TH_JOINTS][TH_MAXV];  // Cholesky factor of the 2x2 keypoint covariance
   union {
-    float rows[SE3D_NKP][TH_MAXV][8];                 // DLT rows r0, r1 (Gram phase only)
-    float dev[SE3D_NKP * (4 * TH_MAXV + 1)][3];       // sigma-point deviations from the weighted solution
+    float rows[TH_JOINTS][TH_MAXV][8];                 // DLT rows r0, r1 (Gram phase only)
+    float dev[TH_JOINTS * (4 * TH_MAXV + 1)][3];       // sigma-point deviations from the weighted solution
+    float slow[15 * TH_MAXV];                         // view list of the per-joint routine (outlier path, runs last)
   } u;
-  double G[SE3D_NKP][21];                             // unweighted Gram (10), weighted Gram (10), sum of confidences
-  float X[SE3D_NKP], Y[SE3D_NKP], Z[SE3D_NKP];
+  double G[TH_JOINTS][21];                             // unweighted Gram (10), weighted Gram (10), sum of confidences
+  float X[TH_JOINTS], Y[TH_JOINTS], Z[TH_JOINTS];
   int cam[TH_MAXV], det[TH_MAXV];
-  int n[SE3D_NKP];
-  unsigned char vidx[SE3D_NKP][TH_MAXV];              // usable views of a joint in ascending camera order
-  float slow[15 * TH_MAXV];                           // view list of the per-joint routine (outlier path)
+  int n[TH_JOINTS];
+  unsigned char vidx[TH_JOINTS][TH_MAXV];              // usable views of a joint in ascending camera order
 };
 
 __device__ __noinline__ void se3d_tri_joint_slow(const Se3dDev *D, int f, int h, int j, int lane, float *base, const float *sRt) {
@@ -1117,7 +1119,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   __shared__ TriHypLds S;   // one wavefront per workgroup: 25 KB of LDS fit next to two resident stage-2 walk workgroups of another context
   __shared__ float sRt[12 * TH_MAXV];
   const int lane = threadIdx.x;
-  const int f = blockIdx.y, h = blockIdx.x;
+  const int f = blockIdx.y, h = blockIdx.x >> 1;
+  const int jbase = (blockIdx.x & 1) * TH_JOINTS, JN = min(TH_JOINTS, SE3D_NKP - jbase);  // joints jbase .. jbase + JN - 1
   const int N = D.d.N, P = D.d.P, H = D.d.H;
   if (h >= D.nhyp[f]) return;
   if (D.nviews[f * H + h] < 2) return;
@@ -1133,9 +1136,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   }
   __builtin_amdgcn_wave_barrier();
   // ---- points: lanes over (joint, view) ----
-  for (int idx = lane; idx < SE3D_NKP * nv; idx += 64) {
+  for (int idx = lane; idx < JN * nv; idx += 64) {
     const int j = idx / nv, v = idx - j * nv;
-    const size_t gi = (((size_t)(f * N + S.cam[v])) * P + S.det[v]) * SE3D_NKP + j;
+    const size_t gi = (((size_t)(f * N + S.cam[v])) * P + S.det[v]) * SE3D_NKP + jbase + j;
     const float4 kp = D.kp[gi];
     const bool ok = kp.z >= TRI_THRESH;  // S3D:724-732
     S.x[j][v] = kp.x; S.y[j][v] = kp.y; S.cf[j][v] = ok ? kp.z : -1.f;
@@ -1151,7 +1154,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     }
   }
   __builtin_amdgcn_wave_barrier();
-  if (lane < SE3D_NKP) {
+  if (lane < JN) {
     int n = 0;
     for (int v = 0; v < nv; ++v)
       if (S.cf[lane][v] >= 0.f) S.vidx[lane][n++] = (unsigned char)v;
@@ -1159,7 +1162,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   }
   __builtin_amdgcn_wave_barrier();
   // ---- Gram matrices: lanes over (joint, entry); accumulation over the views in list order like the per-joint kernel ----
-  for (int it = lane; it < SE3D_NKP * 21; it += 64) {
+  for (int it = lane; it < JN * 21; it += 64) {
     const int j = it / 21, e = it - j * 21;
     const int nn = S.n[j];
     double acc = 0.0;
@@ -1181,7 +1184,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   }
   __builtin_amdgcn_wave_barrier();
   // ---- weighted solve, reprojection error and score: lane <-> joint ----
-  const int nj = (lane < SE3D_NKP) ? S.n[lane] : 0;
+  const int nj = (lane < JN) ? S.n[lane] : 0;
   const bool active = nj >= 2;
   bool slow = false;
   float X = 0.f, Y = 0.f, Z = 0.f, avg_score = 0.f;
@@ -1213,12 +1216,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 #pragma unroll
   for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
   const int off = incl - cnt;
-  const int total = __builtin_amdgcn_readlane(incl, SE3D_NKP - 1);
+  const int total = __builtin_amdgcn_readlane(incl, TH_JOINTS - 1);
   __builtin_amdgcn_wave_barrier();
   for (int g = lane; g < total; g += 64) {
     int j = 0, offj = 0;
 #pragma unroll
-    for (int jj = 1; jj < SE3D_NKP; ++jj) {
+    for (int jj = 1; jj < TH_JOINTS; ++jj) {
       const int oj = __builtin_amdgcn_readlane(off, jj);
       if (g >= oj) { j = jj; offj = oj; }   // joints without samples share the offset of the next one: the last match wins
     }
@@ -1262,7 +1265,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
   // ---- covariance: lanes over (joint, entry) ----
   se3d_person3d &person = D.hypP[(size_t)f * H + h];
   const int pm_ = D.d.pose_method;
-  for (int it = lane; it < SE3D_NKP * 6; it += 64) {
+  for (int it = lane; it < JN * 6; it += 64) {
     const int j = it / 6, e = it - j * 6;
     const int n = S.n[j];
     const int offj = __shfl(off, j), cntj = __shfl(cnt, j);
@@ -1274,17 +1277,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
       const float da = S.u.dev[offj + q][ea], db = S.u.dev[offj + q][eb];
       acc += (double)(da * wgt) * db;
     }
-    person.keypoints[c_kp2fusion[pm_][j]].cov[e] = (double)(float)acc;
+    person.keypoints[c_kp2fusion[pm_][jbase + j]].cov[e] = (double)(float)acc;
   }
   if (active && !slow) {
-    se3d_keypoint3d *kp = &person.keypoints[c_kp2fusion[pm_][lane]];
+    se3d_keypoint3d *kp = &person.keypoints[c_kp2fusion[pm_][jbase + lane]];
     kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
     kp->score = avg_score;
   }
   // ---- joints that need outlier rejection: the per-joint routine, one after the other ----
   for (unsigned long long m = slowmask; m; m &= m - 1ull) {
     __builtin_amdgcn_wave_barrier();
-    se3d_tri_joint_slow(&D, f, h, __ffsll((long long)m) - 1, lane, S.slow, sRt);
+    se3d_tri_joint_slow(&D, f, h, jbase + __ffsll((long long)m) - 1, lane, S.u.slow, sRt);
   }
 }
 
@@ -1684,7 +1687,7 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   if (ev) (void)hipEventRecord(ev[3], st);
   const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
   const char *e_tri = getenv("SE3D_TRI");  // A/B switch (read per launch): joint = always one wavefront per (hypothesis, joint)
-  if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(H, B), dim3(64), 0, st, D);
+  if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(2 * H, B), dim3(64), 0, st, D);
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
   if (ev) (void)hipEventRecord(ev[4], st);
   if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), 0, st, D);

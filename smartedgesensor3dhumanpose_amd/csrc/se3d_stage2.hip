@@ -275,7 +275,7 @@ struct LmCommon {
   double bb[88];            // -whitened error (unary rows 3v+i, then range rows)
   double Hs[21][3];         // range Jacobian direction / sigma
   double rL[21], rS[21];
-  double gg[64], dl[64];
+  double dl[64];
   int rv1[21], rv2[21];
   int keyofcol[SE3D_NFU];
 };
