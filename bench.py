@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 T_STEPS = 16  # frames per synthetic sequence (>= 16 frames per sequence)
 WORKLOADS = {
     # bytes/skeleton: SURVEY §8d algorithmic bytes (stage 1) ; stage 2 adds 8.9 KB per skeleton
-    "16cam6p": dict(n_cam=16, n_persons=6, seqs=128, contexts=8, max_det=8, max_hyp=12, bytes_s1=8972, bytes_s2=8900),
+    "16cam6p": dict(n_cam=16, n_persons=6, seqs=128, contexts=12, max_det=8, max_hyp=12, bytes_s1=8972, bytes_s2=8900),
     "64cam32p": dict(n_cam=64, n_persons=32, seqs=32, contexts=3, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900),
     "256cam128p": dict(n_cam=256, n_persons=128, seqs=1, contexts=3, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900),
 }
@@ -128,35 +128,44 @@ def main():
     H = node.limits.max_hyp
     psz = pm.person3d_dt.itemsize
     if dist is not None:
-        # Exchange: one RCCL all-gather of the final skeletons per context and step so that every rank holds the
-        # skeletons of all ranks ([B][n_persons + 2] person slots + [B] counts per context, frame-slot order).  Stream-ordered, no host
-        # synchronisation: the collective is enqueued behind the context's asynchronous pack (its HIP stream is handed to torch as an
-        # ExternalStream) and runs on RCCL's stream while the context's next step computes; the pack buffers are double-buffered and a
-        # buffer is rewritten only after the collective that read it two steps earlier has completed (device-side wait).
+        # Exchange: ONE RCCL all-gather of the final skeletons per step so that every rank holds the skeletons of all ranks
+        # ([contexts][B][n_persons + 2] person slots + [contexts][B] counts, frame-slot order).  Stream-ordered, no host
+        # synchronisation: every context packs its slice asynchronously on its own HIP stream (handed to torch as an ExternalStream) and
+        # records an event; a dedicated exchange stream waits for the events of all contexts and enqueues the collective, which runs on
+        # RCCL's stream while the contexts compute their next step; the pack buffers are double-buffered and a slice is rewritten only
+        # after the collective that read it two steps earlier has completed (device-side wait on the context stream).
         n_slots = B
         XH = min(H, w["n_persons"] + 2) if stage2 and args.walk == "fused" else H   # person slots per frame carried by the exchange
         streams = [torch.cuda.ExternalStream(nd_.stream_handle()) for nd_ in nodes]
-        packs = [[torch.zeros(n_slots * XH * psz, dtype=torch.uint8, device="cuda") for _ in range(2)] for _ in nodes]
-        cnts = [[torch.zeros(n_slots, dtype=torch.int32, device="cuda") for _ in range(2)] for _ in nodes]
-        gath_p = [torch.empty(world * n_slots * XH * psz, dtype=torch.uint8, device="cuda") for _ in nodes]
-        gath_c = [torch.empty(world * n_slots, dtype=torch.int32, device="cuda") for _ in nodes]
-        works = [[None, None] for _ in nodes]
-        parity = [0] * len(nodes)
+        xstream = torch.cuda.Stream()
+        slice_p, slice_c = n_slots * XH * psz, n_slots
+        packs = [torch.zeros(NC * slice_p, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        cnts = [torch.zeros(NC * slice_c, dtype=torch.int32, device="cuda") for _ in range(2)]
+        gath_p = torch.empty(world * NC * slice_p, dtype=torch.uint8, device="cuda")
+        gath_c = torch.empty(world * NC * slice_c, dtype=torch.int32, device="cuda")
+        works = [None, None]
+        packed_ev = [None] * NC
+        xstate = {"parity": 0}
 
     def pack_target(ci):
-        p = parity[ci]
-        if works[ci][p] is not None:
+        p = xstate["parity"]
+        if works[p] is not None:
             with torch.cuda.stream(streams[ci]):
-                for w_ in works[ci][p]:
+                for w_ in works[p]:
                     w_.wait()
-        return packs[ci][p], cnts[ci][p]
+        return packs[p][ci * slice_p:(ci + 1) * slice_p], cnts[p][ci * slice_c:(ci + 1) * slice_c]
 
-    def exchange(ci):
-        p = parity[ci]
-        with torch.cuda.stream(streams[ci]):
-            works[ci][p] = (dist.all_gather_into_tensor(gath_p[ci], packs[ci][p], async_op=True),
-                            dist.all_gather_into_tensor(gath_c[ci], cnts[ci][p], async_op=True))
-        parity[ci] ^= 1
+    def packed(ci):
+        packed_ev[ci] = streams[ci].record_event()
+
+    def exchange():
+        p = xstate["parity"]
+        with torch.cuda.stream(xstream):
+            for ev in packed_ev:
+                xstream.wait_event(ev)
+            works[p] = (dist.all_gather_into_tensor(gath_p, packs[p], async_op=True),
+                        dist.all_gather_into_tensor(gath_c, cnts[p], async_op=True))
+        xstate["parity"] ^= 1
 
     # One step = per context one stage-1 pass over its B resident frames and one stage-2 walk over the T time steps of its S
     # sequences (se3d_run_stage2_walk: one launch, a workgroup per sequence; forward on even cycles, backward on odd ones so that
@@ -171,7 +180,7 @@ def main():
         if not stage2 and dist is not None:
             pk, cn = pack_target(wk["ci"])
             wk["node"].pack_stage1_device(pk.data_ptr(), cn.data_ptr())
-            exchange(wk["ci"])
+            packed(wk["ci"])
 
     def issue_walk(wk, collect):
         nd_, ci = wk["node"], wk["ci"]
@@ -184,7 +193,7 @@ def main():
             if dist is not None:  # async D2D of all time steps' fused skeletons (frame-slot order) into the exchange buffer
                 pk, cn = pack_target(ci)
                 nd_.pack_stage2_walk_device_slots(B, XH, pk.data_ptr(), cn.data_ptr())
-                exchange(ci)
+                packed(ci)
             if collect is not None:
                 per_frame = [r.n_persons for k in ks for r in nd_.fetch_stage2_walk(k * S_, S_)]
                 assert dist is None or max(per_frame) <= XH, "exchange slots per frame too small: skeletons would be truncated"
@@ -198,7 +207,7 @@ def main():
                 if collect is not None:
                     collect.append(sum(r.n_persons for r in nd_.fetch_stage2(S_)))
             if dist is not None:
-                exchange(ci)
+                packed(ci)
 
     def step(collect=None):
         if not stage2:
@@ -209,6 +218,8 @@ def main():
                 issue_stage1(wk) if wk["ci"] % 2 == 0 else issue_walk(wk, collect)
             for wk in walks:   # phase B
                 issue_walk(wk, collect) if wk["ci"] % 2 == 0 else issue_stage1(wk)
+        if dist is not None:
+            exchange()
 
     for nd_ in nodes:
         nd_.run_stage1()   # phase-shifted contexts start inside the stage-2 walk: their frames need one completed stage-1 pass

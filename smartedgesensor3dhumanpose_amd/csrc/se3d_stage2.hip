@@ -1541,7 +1541,7 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
   // Per-track state of the sequences lives in LDS for the duration of the walk when it fits (Wk.lds_state): every phase touches it
   // through the same Se3dStage2 pointers (generic pointers), at LDS instead of HBM/L2 latency.
   Se3dStage2 Qs = Q;
-  double *l_prev = nullptr, *l_root = nullptr, *l_height = nullptr, *l_tprev = nullptr;
+  double *l_root = nullptr, *l_height = nullptr, *l_tprev = nullptr;
   uint32_t *l_has = nullptr;
   int32_t *l_id = nullptr, *l_nobs = nullptr;
   uint8_t *l_used = nullptr;
@@ -1550,7 +1550,6 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
   const size_t g0 = (size_t)sb * T;
   if (Wk.lds_state) {
     double *b = tpos + S2_WALK_SEQS * tpos_stride;
-    l_prev = b; b += (size_t)TT * SE3D_NFU * 3;
     l_root = b; b += (size_t)TT * 3;
     l_height = b; b += TT;
     l_tprev = b; b += TT;
@@ -1558,21 +1557,23 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
     l_id = reinterpret_cast<int32_t *>(l_has + TT);
     l_nobs = l_id + TT;
     l_used = reinterpret_cast<uint8_t *>(l_nobs + TT);
-    for (int i = tid; i < tn * SE3D_NFU * 3; i += NT) l_prev[i] = Q.prev[g0 * SE3D_NFU * 3 + i];
     for (int i = tid; i < tn * 3; i += NT) l_root[i] = Q.root_prev[g0 * 3 + i];
     for (int i = tid; i < tn; i += NT) {
       l_height[i] = Q.height_prev[g0 + i]; l_tprev[i] = Q.trk_t_prev[g0 + i]; l_has[i] = Q.has[g0 + i];
       l_id[i] = Q.id[g0 + i]; l_nobs[i] = Q.num_obs[g0 + i]; l_used[i] = Q.used[g0 + i];
     }
-    Qs.prev = l_prev; Qs.root_prev = l_root; Qs.height_prev = l_height; Qs.trk_t_prev = l_tprev;
+    Qs.root_prev = l_root; Qs.height_prev = l_height; Qs.trk_t_prev = l_tprev;
     Qs.has = l_has; Qs.id = l_id; Qs.num_obs = l_nobs; Qs.used = l_used;
     __syncthreads();
   } else {
-    Qs.prev += g0 * SE3D_NFU * 3; Qs.root_prev += g0 * 3; Qs.height_prev += g0; Qs.trk_t_prev += g0;
+    Qs.root_prev += g0 * 3; Qs.height_prev += g0; Qs.trk_t_prev += g0;
     Qs.has += g0; Qs.id += g0; Qs.num_obs += g0; Qs.used += g0;
   }
   // every per-sequence array is rebased to the first sequence of the workgroup: the phase bodies run with the local sequence index
-  Qs.vel += g0 * SE3D_NFU * 9;  // the velocity ring (1.5 KB per track, touched once per person and step) stays in HBM / L2
+  // the normalised previous pose (0.5 KB per track) and the velocity ring (1.5 KB), touched once per person and step, stay in HBM / L2;
+  // the phases that compare against every track (cost, merge distance) read the de-normalised table `tpos` in LDS
+  Qs.prev += g0 * SE3D_NFU * 3;
+  Qs.vel += g0 * SE3D_NFU * 9;
   Qs.fb_buf += (size_t)sb * 3; Qs.t_prev += sb; Qs.next_id += sb; Qs.frame_nr += sb; Qs.n_tracks += sb; Qs.order += g0;
   Qs.C += (size_t)sb * H * T; Qs.W += (size_t)sb * H * T; Qs.near += g0 * 4; Qs.det_slot += (size_t)sb * H; Qs.pub += (size_t)sb * H;
   Qs.fused_det += (size_t)sb * H; Qs.pred_det += (size_t)sb * H; Qs.iters_det += (size_t)sb * H; Qs.flags2 += sb;
@@ -1657,7 +1658,6 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
     WK_STAMP(14)  // publish + lifecycle
   }
   if (Wk.lds_state) {  // write the track state back
-    for (int i = tid; i < tn * SE3D_NFU * 3; i += NT) Q.prev[g0 * SE3D_NFU * 3 + i] = l_prev[i];
     for (int i = tid; i < tn * 3; i += NT) Q.root_prev[g0 * 3 + i] = l_root[i];
     for (int i = tid; i < tn; i += NT) {
       Q.height_prev[g0 + i] = l_height[i]; Q.trk_t_prev[g0 + i] = l_tprev[i]; Q.has[g0 + i] = l_has[i];
@@ -1695,8 +1695,8 @@ extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk,
   if (!ok || Q.H > 64 || Q.T > 64 || nseq < 1 || (Q.H > 16 && nseq < 32)) return false;
   Se3dStage2 q = Q;
   q.seq0 = 0;
-  // per-track state in LDS when it fits next to the LM workspaces: prev 63 + root 3 + height + t_prev doubles, 4 words
-  const size_t state_bytes = (size_t)Q.T * ((SE3D_NFU * 3 + 5) * sizeof(double) + 16);
+  // small per-track state in LDS when it fits next to the LM workspaces: root 3 + height + t_prev doubles, 4 words
+  const size_t state_bytes = (size_t)Q.T * (5 * sizeof(double) + 16);
   static int lds_max = -1;
   if (lds_max < 0) {
     lds_max = 160 * 1024 - 4096;  // 160 KB per CU minus the kernel's static LDS
