@@ -1102,7 +1102,6 @@ struct TriHypLds {
   union {
     float rows[TH_JOINTS][TH_MAXV][8];                 // DLT rows r0, r1 (Gram phase only)
     float dev[TH_JOINTS * (4 * TH_MAXV + 1)][3];       // sigma-point deviations from the weighted solution
-    float slow[15 * TH_MAXV];                         // view list of the per-joint routine (outlier path, runs last)
   } u;
   double G[TH_JOINTS][21];                             // unweighted Gram (10), weighted Gram (10), sum of confidences
   float X[TH_JOINTS], Y[TH_JOINTS], Z[TH_JOINTS];
@@ -1111,11 +1110,7 @@ struct TriHypLds {
   unsigned char vidx[TH_JOINTS][TH_MAXV];              // usable views of a joint in ascending camera order
 };
 
-__device__ __noinline__ void se3d_tri_joint_slow(const Se3dDev *D, int f, int h, int j, int lane, float *base, const float *sRt) {
-  se3d_tri_joint_body(*D, f, h, j, lane, base, sRt);
-}
-
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void se3d_k_triangulate_hyp(Se3dDev D) {
+__global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
   __shared__ TriHypLds S;   // one wavefront per workgroup: 25 KB of LDS fit next to two resident stage-2 walk workgroups of another context
   __shared__ float sRt[12 * TH_MAXV];
   const int lane = threadIdx.x;
@@ -1284,10 +1279,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
     kp->score = avg_score;
   }
-  // ---- joints that need outlier rejection: the per-joint routine, one after the other ----
-  for (unsigned long long m = slowmask; m; m &= m - 1ull) {
-    __builtin_amdgcn_wave_barrier();
-    se3d_tri_joint_slow(&D, f, h, jbase + __ffsll((long long)m) - 1, lane, S.u.slow, sRt);
+  // ---- joints that need outlier rejection are redone by se3d_k_triangulate_slow (per-joint routine) ----
+  if (lane == 0) D.tri_slow[((size_t)f * H + h) * 2 + (blockIdx.x & 1)] = (uint32_t)slowmask << jbase;
+}
+
+// Outlier-rejection path of the hypothesis kernel: one wavefront per hypothesis redoes the flagged joints (usually none) with the
+// per-joint routine.  A separate launch on purpose: calling the routine from se3d_k_triangulate_hyp (out of line, descriptor by
+// address) made every wavefront spill the kernel arguments to scratch at entry — 445 MB of writes per launch (PMC WRITE_SIZE).
+__global__ __launch_bounds__(64) void se3d_k_triangulate_slow(Se3dDev D) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x, f = blockIdx.y, h = blockIdx.x;
+  const int N = D.d.N, H = D.d.H;
+  if (h >= D.nhyp[f]) return;
+  if (D.nviews[f * H + h] < 2) return;
+  const uint32_t mask = D.tri_slow[((size_t)f * H + h) * 2] | D.tri_slow[((size_t)f * H + h) * 2 + 1];
+  if (!mask) return;
+  float *base = reinterpret_cast<float *>(smem), *sRt = base + (size_t)15 * N;
+  for (int i = lane; i < 12 * N; i += 64) sRt[i] = D.Rt[i];
+  __syncthreads();
+  for (uint32_t m = mask; m; m &= m - 1u) {
+    se3d_tri_joint_body(D, f, h, __ffs((int)m) - 1, lane, base, sRt);
+    __syncthreads();
   }
 }
 
@@ -1687,7 +1699,10 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   if (ev) (void)hipEventRecord(ev[3], st);
   const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
   const char *e_tri = getenv("SE3D_TRI");  // A/B switch (read per launch): joint = always one wavefront per (hypothesis, joint)
-  if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(2 * H, B), dim3(64), 0, st, D);
+  if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) {
+    hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(2 * H, B), dim3(64), 0, st, D);
+    hipLaunchKernelGGL(se3d_k_triangulate_slow, dim3(H, B), dim3(64), (size_t)27 * N * sizeof(float), st, D);
+  }
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
   if (ev) (void)hipEventRecord(ev[4], st);
   if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), 0, st, D);
