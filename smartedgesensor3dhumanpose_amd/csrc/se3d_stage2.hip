@@ -321,10 +321,27 @@ struct LmTreeLds : LmSchurBase {   // fused walk: the Schur workspace is needed 
   }
 };
 
+// Wavefront sum without the LDS crossbar: four DPP steps reduce every 16-lane row in the VALU (xor 1, xor 2, half-mirror, mirror),
+// v_readlane collects the four row sums.  ds_bpermute-based butterflies cost ~1.2 k cycles of dependent latency per sum and sit on
+// the critical path of every LM trial step (linearised error, non-linear error).
+template <int CTRL>
+__device__ __forceinline__ double s2_dpp_f64(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double s2_readlane_f64(double v, int l) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double s2_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += s2_dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += s2_dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += s2_dpp_f64<0x141>(v);   // row_half_mirror
+  v += s2_dpp_f64<0x140>(v);   // row_mirror
+  return (s2_readlane_f64(v, 0) + s2_readlane_f64(v, 16)) + (s2_readlane_f64(v, 32) + s2_readlane_f64(v, 48));
 }
 
 // noiseModel::Gaussian::Covariance(cov, smart): |off-diagonal| <= 1e-9 (upper triangle) -> Diagonal sigmas, else
