@@ -30,7 +30,8 @@ __device__ unsigned long long g_lm_stamps[16];
     stamp_prev_ = __builtin_readcyclecounter();                                       \
   }
 #define LM_STAMP_INIT unsigned long long stamp_prev_ = __builtin_readcyclecounter();
-__device__ int g_lm_ablate;  // diagnostic build only: bit 0 = stop after one LM iteration, bit 1 = skip marginals, bit 2 = skip the LM loop
+__device__ int g_lm_ablate;  // diagnostic build only: 1 = stop after one LM iteration, 2 = skip marginals, 4 = skip the LM loop,
+                             // (with 1:) 8 = skip the solve, 16 = skip linearize, 32 = skip the linearised error, 64 = skip the new error
 #define LM_ABLATE(bit) (g_lm_ablate & (bit))
 #else
 #define LM_ABLATE(bit) 0
@@ -1023,7 +1024,7 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
       for (int outer = 0; outer < 1000; ++outer) {
         const double currentError = error;
         LM_STAMP(1)  // graph error / loop control
-        s2_linearize(L, K, nr, lane);
+        if (!LM_ABLATE(16)) s2_linearize(L, K, nr, lane);
         // g = J^T b (dense: lane c < n holds g[c]; Schur: lane v < K holds the 3-vector of its variable)
         double g = 0.0;
         double gv[3] = {0, 0, 0};
@@ -1054,7 +1055,8 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
           bool solved = true;
           LM_STAMP(2)  // linearize + gradient
           if constexpr (MODE >= 2) {
-            if (topo.forest) s2_tree_solve(L, K, lambda, lane, Av, gv, topo);
+            if (LM_ABLATE(8)) { /* diagnostic: keep the previous delta */ }
+            else if (topo.forest) s2_tree_solve(L, K, lambda, lane, Av, gv, topo);
             else s2_schur_solve(L, K, nr, lambda, lane, Av, gv);
             LM_STAMP(3)  // solve
           } else if constexpr (MODE == 1) {
@@ -1074,7 +1076,7 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
             }
             // linear.error(delta) = 0.5 ||J delta - b||^2 over the undamped factors
             double le = 0.0;
-            for (int r = lane; r < n + nr; r += 64) {
+            for (int r = lane; r < n + nr && !LM_ABLATE(32); r += 64) {
               double sv;
               if (r < n) {
                 const int u = r / 3, ii = r - 3 * u;
@@ -1093,7 +1095,7 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
               if (lane < K)
                 for (int a = 0; a < 3; ++a) L.xn[lane][a] = L.xc[lane][a] + L.dl[3 * lane + a];  // retract
               __builtin_amdgcn_wave_barrier();
-              newError = s2_graph_error(L, L.xn, K, nr, lane);
+              newError = LM_ABLATE(64) ? error * 0.5 : s2_graph_error(L, L.xn, K, nr, lane);
               const double costChange = error - newError;
               if (linearizedCostChange > 1e-20) {
                 const double modelFidelity = costChange / linearizedCostChange;

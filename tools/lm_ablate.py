@@ -23,7 +23,9 @@ def walk(rep):
     ts = t[0] + np.arange(1, T_ + 1) / 30.0
     t[0] = float(ts[-1])
     node.run_stage2_walk(np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
-for bits, name in ((0, "full"), (2, "no marginals"), (1, "one LM iteration"), (3, "one iteration, no marginals"), (4, "no LM loop"), (6, "no LM loop, no marginals")):
+for bits, name in ((0, "full"), (2, "no marginals"), (1, "one LM iteration"), (1 + 8, "one iteration, no solve"), (1 + 16, "one iteration, no linearize"),
+                   (1 + 32, "one iteration, no linear error"), (1 + 64, "one iteration, no new error"), (1 + 8 + 16 + 32 + 64, "one iteration, loop control only"),
+                   (4, "no LM loop"), (6, "no LM loop, no marginals")):
     L.se3d_diag_lm_ablate(bits)
     for r in range(4): walk(r)
     node.sync()
