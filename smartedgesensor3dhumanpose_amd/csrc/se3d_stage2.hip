@@ -10,6 +10,7 @@
 #include "se3d_munkres.h"
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <type_traits>
 
@@ -1324,6 +1325,493 @@ __device__ __forceinline__ void s2_wave_mem_sync() {  // stores of this wavefron
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// =============================================================================================================
+// Three persons per wavefront ("trio") — the LM of the fused walk.
+// A person's factor graph has at most 21 variables (fusion joints) and, with the reference's bone tables, its range factors form a
+// forest: every joint has at most one bone towards the root side (c_tree_rank); the only joint with two candidate parents is the
+// neck (belly-neck, or midhip-neck when the belly is not measured: mutually exclusive).  So a lane can own joint j's variable, its
+// unary factor AND the range factor of its parent bone, which makes a person 21 lanes wide: lanes 21 g + j, g = 0..2, carry three
+// persons through the same instruction stream.  The LM control flow (GTSAM 4.0.3, as in s2_lm_body) is a per-person state machine
+// held in group-uniform lane registers; one trip of the loop is one tryLambda trial for every person that is still running.
+// Same algebra as s2_lm_body<3> (forest elimination for solves and marginals); sums run in a different order (rounding only).
+// =============================================================================================================
+struct LmTrioGroup {
+  double xc[3][SE3D_NFU];                     // current values, by joint
+  double xn[3][SE3D_NFU], dl[3][SE3D_NFU];    // tentative values, solution of the damped system; after the loop: marginal blocks
+  double hs[3][SE3D_NFU];                     // parent-bone Jacobian direction / sigma of joint j (d = x[k2] - x[k1])
+  double eb[SE3D_NFU];                        // parent-bone -whitened error, signed so that g_child += hs * eb, g_parent -= hs * eb
+  double al[SE3D_NFU], be[SE3D_NFU];
+};
+struct LmTrioLds { LmTrioGroup g[3]; double red[2][64]; };
+static_assert(offsetof(LmTrioGroup, dl) == offsetof(LmTrioGroup, xn) + sizeof(double) * 3 * SE3D_NFU, "marginal blocks alias xn + dl");
+
+// sum over the 21 lanes of each group, identical on every lane of the group (fixed order)
+__device__ __forceinline__ double s2_trio_sum(double v, double *red, int lane, int gb) {
+  red[lane] = v;
+  __builtin_amdgcn_wave_barrier();
+  const double *r = red + gb;
+  const double a0 = r[0] + r[1], a1 = r[2] + r[3], a2 = r[4] + r[5], a3 = r[6] + r[7], a4 = r[8] + r[9];
+  const double a5 = r[10] + r[11], a6 = r[12] + r[13], a7 = r[14] + r[15], a8 = r[16] + r[17], a9 = r[18] + r[19];
+  const double b0 = a0 + a1, b1 = a2 + a3, b2 = a4 + a5, b3 = a6 + a7, b4 = (a8 + a9) + r[20];
+  const double tot = ((b0 + b1) + (b2 + b3)) + b4;
+  __builtin_amdgcn_wave_barrier();
+  return tot;
+}
+
+// two sums at once (one LDS round trip)
+__device__ __forceinline__ void s2_trio_sum2(double &v0, double &v1, double (*red)[64], int lane, int gb) {
+  red[0][lane] = v0; red[1][lane] = v1;
+  __builtin_amdgcn_wave_barrier();
+  double tot[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const double *r = red[q] + gb;
+    const double a0 = r[0] + r[1], a1 = r[2] + r[3], a2 = r[4] + r[5], a3 = r[6] + r[7], a4 = r[8] + r[9];
+    const double a5 = r[10] + r[11], a6 = r[12] + r[13], a7 = r[14] + r[15], a8 = r[16] + r[17], a9 = r[18] + r[19];
+    const double b0 = a0 + a1, b1 = a2 + a3, b2 = a4 + a5, b3 = a6 + a7, b4 = (a8 + a9) + r[20];
+    tot[q] = ((b0 + b1) + (b2 + b3)) + b4;
+  }
+  __builtin_amdgcn_wave_barrier();
+  v0 = tot[0]; v1 = tot[1];
+}
+
+// upper-triangular whitener R (R0 R1 R2; 0 R4 R5; 0 0 R8) times a 3-vector
+__device__ __forceinline__ void s2_trio_Rmul(const double R[6], const double v[3], double o[3]) {
+  o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  o[1] = R[3] * v[1] + R[4] * v[2];
+  o[2] = R[5] * v[2];
+}
+
+// s, i, have: sequence (local index), detection and validity of the person of this lane's group (uniform within a group)
+__device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int i, bool have, int lane, LmTrioLds &W) {
+  const int H = Q.H, T = Q.T;
+  const int g3 = lane / SE3D_NFU;
+  const int g = g3 > 2 ? 2 : g3, j = lane - SE3D_NFU * g3, gb = SE3D_NFU * g;   // lane 63: no group
+  LmTrioGroup &L = W.g[g];
+  have = have && g3 < 3 && i < min(Q.n_det[have ? s : 0], H);
+  const int slot = have ? Q.det_slot[(size_t)s * H + i] : -1;
+  have = have && slot >= 0;
+  const size_t sl = have ? (size_t)s * T + slot : 0;
+  const se3d_person3d &person = Q.dets[have ? (size_t)s * H + i : 0];
+  const bool simple = Q.pose_method == SE3D_POSE_SIMPLE;
+  const double t = Q.t[have ? s : 0];
+  const unsigned gmask = 0x1FFFFFu;
+
+  // ---- root / neck / height (PP:631-668), identical on every lane of the group ----
+  double root[3] = {0, 0, 0}, neck[3] = {0, 0, 0};
+  float root_score = 0.f, neck_score = 0.f;
+  double height = 1.0, hprev = 1.0, rprev[3] = {0, 0, 0};
+  bool has_root = false;
+  if (have) {
+    if (!simple) {
+      for (int a = 0; a < 3; ++a) { root[a] = person.keypoints[FU_MidHip].joint[a]; neck[a] = person.keypoints[FU_Neck].joint[a]; }
+      root_score = person.keypoints[FU_MidHip].score;
+      neck_score = person.keypoints[FU_Neck].score;
+    } else {
+      const se3d_keypoint3d &hl = person.keypoints[FU_LHip], &hr = person.keypoints[FU_RHip];
+      if (hl.score > 0.0f && hr.score > 0.0f) {
+        for (int a = 0; a < 3; ++a) root[a] = (hl.joint[a] + hr.joint[a]) / 2.0;
+        root_score = (hl.score + hr.score) / 2.0f;
+      }
+      const se3d_keypoint3d &sL = person.keypoints[FU_LShoulder], &sR = person.keypoints[FU_RShoulder];
+      if (sL.score > 0.0f && sR.score > 0.0f) {
+        for (int a = 0; a < 3; ++a) neck[a] = (sL.joint[a] + sR.joint[a]) / 2.0;
+        neck_score = (sL.score + sR.score) / 2.0f;
+      }
+    }
+    has_root = root_score > 0.10f;
+    if (has_root && Q.norm_height) {
+      if (neck_score > 0.10f) {
+        const double dx = neck[0] - root[0], dy = neck[1] - root[1], dz = neck[2] - root[2];
+        height = sqrt(dx * dx + dy * dy + dz * dz);
+      } else height = 0.60;
+    }
+    const double hp_old = Q.height_prev[sl];
+    const bool first = hp_old < 0.0;  // PP:699-702
+    hprev = first ? height : hp_old;
+    for (int a = 0; a < 3; ++a) rprev[a] = first ? root[a] : Q.root_prev[sl * 3 + a];
+    if (first && j == 0) { Q.height_prev[sl] = height; for (int a = 0; a < 3; ++a) Q.root_prev[sl * 3 + a] = root[a]; }
+  }
+
+  // ---- measurements: lane 21 g + k <-> fusion joint k of person g (PP:690-737) ----
+  bool measured = false;
+  double m[3] = {0, 0, 0}, cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  float kscore = 0.f;
+  if (have) {
+    const int k = j;
+    if (k == FU_MidHip) {
+      if (has_root) {
+        measured = true;
+        if (!simple) s2_cov6_to_mat(person.keypoints[FU_MidHip].cov, cov);
+        else {
+          double cl[9], cr[9];
+          s2_cov6_to_mat(person.keypoints[FU_LHip].cov, cl);
+          s2_cov6_to_mat(person.keypoints[FU_RHip].cov, cr);
+          for (int q = 0; q < 9; ++q) cov[q] = (cl[q] + cr[q]) / 2.0;
+        }
+        for (int q = 0; q < 9; ++q) cov[q] = cov[q] / (height * height) / (100.0 * 100.0);
+        kscore = root_score;
+      }
+    } else if (simple && k == FU_Neck && neck_score > 0.10f) {
+      measured = true;
+      double cl[9], cr[9];
+      s2_cov6_to_mat(person.keypoints[FU_LShoulder].cov, cl);
+      s2_cov6_to_mat(person.keypoints[FU_RShoulder].cov, cr);
+      for (int q = 0; q < 9; ++q) cov[q] = (cl[q] + cr[q]) / 2.0 / (height * height);
+      for (int a = 0; a < 3; ++a) m[a] = (neck[a] - root[a]) / height;
+      kscore = neck_score;
+    } else {
+      const se3d_keypoint3d &kp = person.keypoints[k];
+      if (kp.score > 0.10f) {
+        measured = true;
+        double c9[9];
+        s2_cov6_to_mat(kp.cov, c9);
+        for (int q = 0; q < 9; ++q) cov[q] = c9[q] / (height * height);
+        for (int a = 0; a < 3; ++a) m[a] = (kp.joint[a] - root[a]) / height;
+        kscore = kp.score;
+      }
+    }
+  }
+  const uint32_t measmask = (uint32_t)(__ballot(measured) >> gb) & gmask;
+  const bool valid = have && measmask != 0u;  // PP:739-741: a person without measured joints is skipped
+  const uint32_t hasprev = valid ? Q.has[sl] : 0u;
+  const bool use_vel = measured && ((hasprev >> j) & 1u);
+  bool wok = true;
+  double R[6] = {0, 0, 0, 0, 0, 0}, x0[3] = {0, 0, 0}, x[3] = {0, 0, 0};
+  if (measured) {
+    double R9[9];
+    wok = s2_make_whitener(cov, R9);
+    R[0] = R9[0]; R[1] = R9[1]; R[2] = R9[2]; R[3] = R9[4]; R[4] = R9[5]; R[5] = R9[8];
+    for (int a = 0; a < 3; ++a) {
+      x0[a] = use_vel ? Q.prev[(sl * SE3D_NFU + j) * 3 + a] : m[a];  // setInitialState (PP:483-503)
+      x[a] = x0[a];
+      L.xc[a][j] = x[a];
+    }
+  }
+  bool wh_ok = ((uint32_t)(__ballot(measured && !wok) >> gb) & gmask) == 0u;
+
+  // ---- range factors (PP:384-481): lane 21 g + e evaluates bone e of the table; joint j then finds its parent bone and children ----
+  const int variant = Q.norm_height ? 1 : 0;
+  bool ract = false;
+  {
+    const Se3dBone bd = c_bones[0][j];
+    ract = valid && ((measmask >> bd.k1) & 1u) && ((measmask >> bd.k2) & 1u) && (!bd.not_belly || !((measmask >> FU_Belly) & 1u));
+  }
+  const uint32_t rbg = (uint32_t)(__ballot(ract) >> gb) & gmask;
+  int pe = -1, parent = -1, npar = 0;
+  bool child_is_k2 = true;
+  unsigned children = 0u;
+  double bL = 0.0, bS = 1.0;
+#pragma unroll
+  for (int e = 0; e < 21; ++e) {
+    const int k1 = c_bones[0][e].k1, k2 = c_bones[0][e].k2;  // the two tables share the bone ends
+    const bool k1_child = c_tree_rank[k1] > c_tree_rank[k2];
+    const int ch = k1_child ? k1 : k2, pa = k1_child ? k2 : k1;
+    const bool on = (rbg >> e) & 1u;
+    if (on && j == ch) { pe = e; parent = pa; ++npar; child_is_k2 = !k1_child; bL = c_bones[variant][e].L; bS = c_bones[variant][e].sigma; }
+    if (on && j == pa) children |= 1u << ch;
+  }
+  bS *= (Q.norm_height ? 2.0 : 1.0);  // g_limbLSigmaFactor (PP:934-937)
+  if (!measured) { pe = -1; parent = -1; children = 0u; }
+  if (((uint32_t)(__ballot(measured && npar > 1) >> gb) & gmask) != 0u) {  // not a forest: impossible with the bone tables above
+    wh_ok = false;
+    if (valid && j == 0) atomicOr(&Q.flags2[s], 8u);
+  }
+  int level = 0;
+  {
+    int cur = parent;
+    while (__ballot(cur >= 0)) {
+      if (cur >= 0) ++level;
+      const int nxt = __shfl(parent, gb + (cur >= 0 ? cur : 0));
+      cur = cur >= 0 ? nxt : -1;
+    }
+  }
+  int maxlev = 0;
+  for (int lv = SE3D_NFU - 1; lv > 0; --lv)
+    if (__ballot(measured && level == lv)) { maxlev = lv; break; }
+  const bool edge = pe >= 0;
+
+  double Av[6] = {0, 0, 0, 0, 0, 0};  // R^T R
+  if (measured) {
+    Av[0] = R[0] * R[0]; Av[1] = R[0] * R[1]; Av[2] = R[0] * R[2];
+    Av[3] = R[1] * R[1] + R[3] * R[3]; Av[4] = R[1] * R[2] + R[3] * R[4]; Av[5] = R[2] * R[2] + R[4] * R[4] + R[5] * R[5];
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // 0.5 * ||whitened error||^2 of this lane's factors at xv (own joint) with the parent joint taken from X
+  auto lane_error = [&](const double xv[3], const double (*X)[SE3D_NFU]) -> double {
+    double e = 0.0;
+    if (measured) {
+      const double r3[3] = {xv[0] - m[0], xv[1] - m[1], xv[2] - m[2]};
+      double w3[3];
+      s2_trio_Rmul(R, r3, w3);
+      e = 0.5 * w3[0] * w3[0] + 0.5 * w3[1] * w3[1] + 0.5 * w3[2] * w3[2];
+      if (edge) {
+        const double dx = X[0][parent] - xv[0], dy = X[1][parent] - xv[1], dz = X[2][parent] - xv[2];  // sign does not matter here
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        const double w = (r - bL) / bS;
+        e += 0.5 * w * w;
+      }
+    }
+    return e;
+  };
+  // linearise this lane's factors at x: unary rhs bu, parent-bone direction hsv / rhs (LDS for the parent lane); returns the bone rhs
+  double bu[3] = {0, 0, 0}, hsv[3] = {0, 0, 0}, ebu = 0.0;
+  auto linearize = [&]() {
+    if (measured) {
+      const double r3[3] = {x[0] - m[0], x[1] - m[1], x[2] - m[2]};
+      double w3[3];
+      s2_trio_Rmul(R, r3, w3);
+      bu[0] = -w3[0]; bu[1] = -w3[1]; bu[2] = -w3[2];
+      if (edge) {
+        const double px = L.xc[0][parent], py = L.xc[1][parent], pz = L.xc[2][parent];
+        const double dx = child_is_k2 ? x[0] - px : px - x[0], dy = child_is_k2 ? x[1] - py : py - x[1], dz = child_is_k2 ? x[2] - pz : pz - x[2];
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        double h0 = 1.0, h1 = 1.0, h2 = 1.0;
+        if (fabs(r) > 1e-10) { h0 = dx / r; h1 = dy / r; h2 = dz / r; }
+        hsv[0] = h0 / bS; hsv[1] = h1 / bS; hsv[2] = h2 / bS;
+        ebu = -(r - bL) / bS;
+        L.hs[0][j] = hsv[0]; L.hs[1][j] = hsv[1]; L.hs[2][j] = hsv[2];
+        L.eb[j] = child_is_k2 ? ebu : -ebu;
+      }
+    }
+  };
+
+  // ---- LevenbergMarquardtOptimizer(graph, prevEstimate).optimize(), GTSAM 4.0.3 defaults ----
+  int iterations = 0, tr = 0, outer = 0;
+  double error = 0.0, lambda = 1e-5, currentError = 0.0;
+  bool running = false, need_lin = true;
+  {
+    const double e0 = s2_trio_sum(lane_error(x, L.xc), W.red[0], lane, gb);
+    error = e0;
+    running = valid && wh_ok && !(error <= 0.0);
+  }
+  double A0[6] = {0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
+  while (__ballot(running)) {
+    const bool lin = running && need_lin;
+    if (__ballot(lin)) {
+      if (lin) { currentError = error; tr = 0; need_lin = false; linearize(); }
+      __builtin_amdgcn_wave_barrier();
+      if (lin && measured) {  // gradient J^T b and block diagonal J^T J of this joint
+        gv[0] = R[0] * bu[0]; gv[1] = R[1] * bu[0] + R[3] * bu[1]; gv[2] = R[2] * bu[0] + R[4] * bu[1] + R[5] * bu[2];
+        for (int q = 0; q < 6; ++q) A0[q] = Av[q];
+        if (edge) {
+          const double sb = child_is_k2 ? ebu : -ebu;
+          gv[0] += hsv[0] * sb; gv[1] += hsv[1] * sb; gv[2] += hsv[2] * sb;
+          A0[0] += hsv[0] * hsv[0]; A0[1] += hsv[0] * hsv[1]; A0[2] += hsv[0] * hsv[2];
+          A0[3] += hsv[1] * hsv[1]; A0[4] += hsv[1] * hsv[2]; A0[5] += hsv[2] * hsv[2];
+        }
+        for (unsigned cm = children; cm; cm &= cm - 1) {
+          const int c = __ffs(cm) - 1;
+          const double h0 = L.hs[0][c], h1 = L.hs[1][c], h2 = L.hs[2][c], sb = L.eb[c];
+          gv[0] -= h0 * sb; gv[1] -= h1 * sb; gv[2] -= h2 * sb;
+          A0[0] += h0 * h0; A0[1] += h0 * h1; A0[2] += h0 * h2; A0[3] += h1 * h1; A0[4] += h1 * h2; A0[5] += h2 * h2;
+        }
+      }
+    }
+    // ---- tryLambda: delta = (J^T J + lambda I)^-1 J^T b by forest elimination ----
+    const bool act = running && measured;
+    double D[6] = {A0[0] + lambda, A0[1], A0[2], A0[3] + lambda, A0[4], A0[5] + lambda};
+    double gg[3] = {gv[0], gv[1], gv[2]};
+    double Di[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0}, z[3] = {0, 0, 0}, d[3] = {0, 0, 0}, dp[3] = {0, 0, 0};
+    for (int lv = maxlev; lv >= 1; --lv) {  // leaves -> roots
+      if (act && level == lv) {
+        s2_sym3_inv(D, Di);
+        s2_sym3_mul(Di, hsv, u);
+        s2_sym3_mul(Di, gg, z);
+        L.al[j] = hsv[0] * u[0] + hsv[1] * u[1] + hsv[2] * u[2];
+        L.be[j] = hsv[0] * z[0] + hsv[1] * z[1] + hsv[2] * z[2];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (act && level == lv - 1) {
+        for (unsigned cm = children; cm; cm &= cm - 1) {
+          const int c = __ffs(cm) - 1;
+          const double h0 = L.hs[0][c], h1 = L.hs[1][c], h2 = L.hs[2][c];
+          const double a = L.al[c], b = L.be[c];
+          D[0] -= a * h0 * h0; D[1] -= a * h0 * h1; D[2] -= a * h0 * h2; D[3] -= a * h1 * h1; D[4] -= a * h1 * h2; D[5] -= a * h2 * h2;
+          gg[0] += b * h0; gg[1] += b * h1; gg[2] += b * h2;
+        }
+      }
+    }
+    if (act && level == 0) {
+      s2_sym3_inv(D, Di);
+      s2_sym3_mul(Di, gg, d);
+      for (int a = 0; a < 3; ++a) L.dl[a][j] = d[a];
+    }
+    for (int lv = 1; lv <= maxlev; ++lv) {  // roots -> leaves
+      __builtin_amdgcn_wave_barrier();
+      if (act && level == lv) {
+        for (int a = 0; a < 3; ++a) dp[a] = L.dl[a][parent];
+        const double gam = hsv[0] * dp[0] + hsv[1] * dp[1] + hsv[2] * dp[2];
+        for (int a = 0; a < 3; ++a) { d[a] = z[a] + u[a] * gam; L.dl[a][j] = d[a]; }
+      }
+    }
+    // linear.error(delta) = 0.5 ||J delta - b||^2 over the undamped factors; retract; non-linear error at the tentative values
+    double le = 0.0, xn[3] = {x[0] + d[0], x[1] + d[1], x[2] + d[2]};
+    if (act) {
+      double w3[3];
+      s2_trio_Rmul(R, d, w3);
+      for (int a = 0; a < 3; ++a) { const double sv = w3[a] - bu[a]; le += 0.5 * sv * sv; }
+      if (edge) {
+        const double e0 = child_is_k2 ? d[0] - dp[0] : dp[0] - d[0], e1 = child_is_k2 ? d[1] - dp[1] : dp[1] - d[1],
+                     e2 = child_is_k2 ? d[2] - dp[2] : dp[2] - d[2];
+        const double sv = hsv[0] * e0 + hsv[1] * e1 + hsv[2] * e2 - ebu;
+        le += 0.5 * sv * sv;
+      }
+      for (int a = 0; a < 3; ++a) L.xn[a][j] = xn[a];
+    }
+    __builtin_amdgcn_wave_barrier();  // xn visible to the children
+    double newError = act ? lane_error(xn, L.xn) : 0.0;
+    s2_trio_sum2(le, newError, W.red, lane, gb);
+    if (running) {
+      const double linearizedCostChange = error - le;
+      bool step_ok = false, stop = false;
+      if (linearizedCostChange >= 0) {
+        const double costChange = error - newError;
+        if (linearizedCostChange > 1e-20) step_ok = costChange / linearizedCostChange > 1e-3;
+        if (fabs(costChange) < 1e-5 * error) stop = true;
+      }
+      bool end_outer = false;
+      if (step_ok) {  // decreaseLambda (useFixedLambdaFactor)
+        if (measured)
+          for (int a = 0; a < 3; ++a) { x[a] = xn[a]; L.xc[a][j] = xn[a]; }
+        error = newError;
+        lambda /= 10.0;
+        if (lambda < 0.0) lambda = 0.0;
+        ++iterations;
+        end_outer = true;
+      } else if (!stop) {  // increaseLambda
+        lambda *= 10.0;
+        if (lambda >= 1e5 || ++tr >= 64) end_outer = true;
+      } else {
+        end_outer = true;
+      }
+      if (end_outer) {
+        const double absoluteDecrease = currentError - error;
+        const double relativeDecrease = absoluteDecrease / currentError;
+        ++outer;
+        if (iterations >= 100 || error <= 0.0 || relativeDecrease <= 1e-5 || absoluteDecrease <= 1e-5 || !isfinite(currentError) || outer >= 1000)
+          running = false;
+        need_lin = true;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (valid && !wh_ok && measured) { x[0] = m[0]; x[1] = m[1]; x[2] = m[2]; }  // optimisation failed: output the measurements (PP:751-758)
+
+  // ---- Marginals(graph, result): diagonal 3x3 blocks of (J^T J)^-1 at the optimum (PP:760-793), top-down over the forest ----
+  const bool use_marg = valid && wh_ok;
+  double mc[6] = {0, 0, 0, 0, 0, 0};
+  if (__ballot(use_marg)) {
+    const bool act = use_marg && measured;
+    double *MC = &L.xn[0][0];  // [6][21] over xn + dl
+    if (act) linearize();
+    __builtin_amdgcn_wave_barrier();
+    double D[6] = {Av[0], Av[1], Av[2], Av[3], Av[4], Av[5]}, Di[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0};
+    if (act) {
+      if (edge) {
+        D[0] += hsv[0] * hsv[0]; D[1] += hsv[0] * hsv[1]; D[2] += hsv[0] * hsv[2]; D[3] += hsv[1] * hsv[1]; D[4] += hsv[1] * hsv[2]; D[5] += hsv[2] * hsv[2];
+      }
+      for (unsigned cm = children; cm; cm &= cm - 1) {
+        const int c = __ffs(cm) - 1;
+        const double h0 = L.hs[0][c], h1 = L.hs[1][c], h2 = L.hs[2][c];
+        D[0] += h0 * h0; D[1] += h0 * h1; D[2] += h0 * h2; D[3] += h1 * h1; D[4] += h1 * h2; D[5] += h2 * h2;
+      }
+    }
+    for (int lv = maxlev; lv >= 1; --lv) {
+      if (act && level == lv) {
+        s2_sym3_inv(D, Di);
+        s2_sym3_mul(Di, hsv, u);
+        L.al[j] = hsv[0] * u[0] + hsv[1] * u[1] + hsv[2] * u[2];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (act && level == lv - 1) {
+        for (unsigned cm = children; cm; cm &= cm - 1) {
+          const int c = __ffs(cm) - 1;
+          const double h0 = L.hs[0][c], h1 = L.hs[1][c], h2 = L.hs[2][c];
+          const double a = L.al[c];
+          D[0] -= a * h0 * h0; D[1] -= a * h0 * h1; D[2] -= a * h0 * h2; D[3] -= a * h1 * h1; D[4] -= a * h1 * h2; D[5] -= a * h2 * h2;
+        }
+      }
+    }
+    if (act && level == 0) {
+      s2_sym3_inv(D, Di);
+      for (int q = 0; q < 6; ++q) { mc[q] = Di[q]; MC[q * SE3D_NFU + j] = Di[q]; }
+    }
+    for (int lv = 1; lv <= maxlev; ++lv) {
+      __builtin_amdgcn_wave_barrier();
+      if (act && level == lv) {
+        double sp[6], sh[3];
+        for (int q = 0; q < 6; ++q) sp[q] = MC[q * SE3D_NFU + parent];
+        s2_sym3_mul(sp, hsv, sh);
+        const double gam = hsv[0] * sh[0] + hsv[1] * sh[1] + hsv[2] * sh[2];
+        mc[0] = Di[0] + gam * u[0] * u[0]; mc[1] = Di[1] + gam * u[0] * u[1]; mc[2] = Di[2] + gam * u[0] * u[2];
+        mc[3] = Di[3] + gam * u[1] * u[1]; mc[4] = Di[4] + gam * u[1] * u[2]; mc[5] = Di[5] + gam * u[2] * u[2];
+        for (int q = 0; q < 6; ++q) MC[q * SE3D_NFU + j] = mc[q];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- outputs + track-state update (PP:769-843): every lane writes the whole keypoint of its joint in both persons ----
+  if (valid) {
+    se3d_person3d &pf = Q.fused_det[(size_t)s * H + i];
+    se3d_person3d &pp = Q.pred_det[(size_t)s * H + i];
+    const int track_id = Q.id[sl];
+    if (j == 0) { pf.id = (uint32_t)track_id; pf.score = 0.f; pp.id = (uint32_t)track_id; pp.score = 0.f; }
+    const double pred_dt = Q.pred_dt[s];
+    const int fslot = Q.frame_nr[s] % 3;
+    const double gtprev = Q.t_prev[s];
+    double *velk = Q.vel + (sl * SE3D_NFU + j) * 9;
+    se3d_keypoint3d kf, kpred;
+    for (int a = 0; a < 3; ++a) { kf.joint[a] = 0.0; kpred.joint[a] = 0.0; }
+    for (int a = 0; a < 6; ++a) { kf.cov[a] = 0.0; kpred.cov[a] = 0.0; }
+    kf.score = 0.f; kf._pad = 0.f; kpred.score = 0.f; kpred._pad = 0.f;
+    if (measured) {
+      const double jf[3] = {x[0] * height + root[0], x[1] * height + root[1], x[2] * height + root[2]};
+      for (int a = 0; a < 3; ++a) kf.joint[a] = jf[a];
+      kf.score = fmaxf(0.10f, kscore);
+      double c6[6];
+      if (use_marg) for (int a = 0; a < 6; ++a) c6[a] = mc[a] * height * height;
+      else { c6[0] = c6[3] = c6[5] = 0.10 * 0.10; c6[1] = c6[2] = c6[4] = 0.0; }
+      if (j == FU_MidHip) for (int a = 0; a < 6; ++a) c6[a] *= (100.0 * 100.0);
+      for (int a = 0; a < 6; ++a) kf.cov[a] = c6[a];
+      double jp[3] = {jf[0], jf[1], jf[2]};
+      if (use_vel) {
+        const double pv[3] = {x0[0] * hprev + rprev[0], x0[1] * hprev + rprev[1], x0[2] * hprev + rprev[2]};
+        double vk[9];
+        for (int a = 0; a < 9; ++a) vk[a] = velk[a];
+        for (int a = 0; a < 3; ++a) {
+          const double vnew = (jf[a] - pv[a]) / (t - gtprev);
+          velk[fslot * 3 + a] = vnew;
+          vk[0 * 3 + a] = fslot == 0 ? vnew : vk[0 * 3 + a]; vk[1 * 3 + a] = fslot == 1 ? vnew : vk[1 * 3 + a]; vk[2 * 3 + a] = fslot == 2 ? vnew : vk[2 * 3 + a];
+          const double acc = ((0.0 + vk[0 * 3 + a]) + vk[1 * 3 + a]) + vk[2 * 3 + a];
+          jp[a] += acc / 3.0 * pred_dt;
+        }
+      }
+      for (int a = 0; a < 3; ++a) kpred.joint[a] = jp[a];
+      kpred.score = kf.score;
+      for (int a = 0; a < 6; ++a) kpred.cov[a] = c6[a];
+      kpred.cov[0] += 0.12 * 0.12; kpred.cov[3] += 0.12 * 0.12; kpred.cov[5] += 0.12 * 0.12;  // g_predNoiseSigma (PP:831)
+      for (int a = 0; a < 3; ++a) Q.prev[(sl * SE3D_NFU + j) * 3 + a] = x[a];  // prevEstimate.swap(result)
+    } else if ((hasprev >> j) & 1u) {
+      for (int a = 0; a < 9; ++a) velk[a] = 0.0;  // joint vanished: reset its velocity buffer (PP:490-493)
+    }
+    pf.keypoints[j] = kf;
+    pp.keypoints[j] = kpred;
+    if (j == 0) {
+      Q.has[sl] = measmask;
+      Q.trk_t_prev[sl] = t;
+      Q.height_prev[sl] = height;
+      for (int a = 0; a < 3; ++a) Q.root_prev[sl * 3 + a] = root[a];
+      const int no = Q.num_obs[sl] + 1;
+      Q.num_obs[sl] = no;
+      Q.pub[(size_t)s * H + i] = (no > 10) ? 1 : 0;  // g_min_num_obs_track (PP:845-848)
+      Q.iters_det[(size_t)s * H + i] = iterations;
+    }
+  }
+}
+
 // ---- single-wavefront forms of the per-sequence bookkeeping (T, H <= 64): same decisions, ballots instead of barriers ----
 __device__ __forceinline__ int s2_nth_set_bit(unsigned long long m, int n) {  // index of the n-th (0-based) set bit, -1 if none
   for (int i = 0; i < n; ++i) m &= m - 1ull;
@@ -1531,6 +2019,45 @@ __device__ __forceinline__ void s2_track_near_lds(const Se3dStage2 &Q, int si, i
   if (lane >= 1 && lane < 4) row[lane] = 0ull;
 }
 
+// the whole merge-distance bit matrix by one wavefront (T <= 64): (si, j) pairs flattened over the lanes, row bits collected from the
+// ballots of each pass by the lane that owns the row.  Same decisions as s2_track_near_lds row by row.
+__device__ __forceinline__ void s2_track_near_flat(const Se3dStage2 &Q, int s, int lane, const double *tpos) {
+  const int T = Q.T;
+  const size_t s0 = (size_t)s * T;
+  unsigned long long rowbits = 0ull;
+  for (int p0 = 0; p0 < T * T; p0 += 64) {
+    const int idx = p0 + lane;
+    bool nr = false;
+    if (idx < T * T) {
+      const int si = idx / T, j = idx - si * T;
+      if (si != j && Q.used[s0 + si] && Q.used[s0 + j]) {
+        const uint32_t both = Q.has[s0 + si] & Q.has[s0 + j];
+        const double *pi = tpos + (size_t)si * SE3D_NFU * 3, *pj = tpos + (size_t)j * SE3D_NFU * 3;
+        int nj = 0;
+        double dist = 0.0;
+        for (int k = 0; k < SE3D_NFU; ++k)
+          if ((both >> k) & 1u) {
+            const double dx = pi[3 * k] - pj[3 * k], dy = pi[3 * k + 1] - pj[3 * k + 1], dz = pi[3 * k + 2] - pj[3 * k + 2];
+            dist += sqrt(dx * dx + dy * dy + dz * dz);
+            ++nj;
+          }
+        nr = (nj > 0 ? dist / nj : 1e6) < 0.20;
+      }
+    }
+    const unsigned long long b = __ballot(nr);   // bit l <-> pair p0 + l
+    const int lo = max(lane * T, p0), hi = min(lane * T + T, p0 + 64);  // this lane's row within the window
+    if (lane < T && lo < hi) {
+      const int w = hi - lo;
+      const unsigned long long m = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+      rowbits |= ((b >> (lo - p0)) & m) << (lo - lane * T);
+    }
+  }
+  if (lane < T) {
+    unsigned long long *row = Q.near + (s0 + lane) * 4;
+    row[0] = rowbits; row[1] = 0ull; row[2] = 0ull; row[3] = 0ull;
+  }
+}
+
 #ifndef S2_WALK_WAVES
 #define S2_WALK_WAVES 4
 #endif
@@ -1547,16 +2074,26 @@ __device__ __forceinline__ void s2_track_near_lds(const Se3dStage2 &Q, int si, i
 #ifndef S2_WALK_SEQS
 #define S2_WALK_SEQS 2
 #endif
-__global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int nseq) {
+// TRIO: three persons per LM wavefront (s2_lm_trio_body); otherwise one person per wavefront (s2_lm_body<3>, kept as A/B evidence)
+// WV wavefronts per workgroup, SQ sequences per workgroup.  <4, 2>: few sequences per launch (latency: a sequence-step spreads its
+// persons over four wavefronts).  <1, 1>: one wavefront walks one sequence on its own — no workgroup barriers, no wavefront ever
+// waits for a slower one (LM trial counts vary from 2 to 60), every resident wavefront slot does useful work: the throughput shape
+// for launches of many sequences.  Its LM workspace, Munkres scratch and track-position table share one LDS region (the phases of
+// a single wavefront are sequential).
+template <bool TRIO, int WV, int SQ>
+__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(3, 3))) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int nseq) {
+  using WaveLds = typename std::conditional<TRIO, LmTrioLds, LmTreeLds>::type;
   extern __shared__ __align__(16) unsigned char s2_walk_smem[];
   __shared__ int s_next_person;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sb = blockIdx.x * S2_WALK_SEQS, ns = min(S2_WALK_SEQS, nseq - sb);  // sequences sb .. sb + ns - 1 (local index 0 .. ns - 1)
+  const int sb = blockIdx.x * SQ, ns = min(SQ, nseq - sb);  // sequences sb .. sb + ns - 1 (local index 0 .. ns - 1)
   const int H = Q.H, T = Q.T;
-  constexpr int NT = 64 * S2_WALK_WAVES;
-  // dynamic LDS: [S2_WALK_WAVES] LM workspaces | [SEQS][T][63] de-normalised track positions | optional per-track state [SEQS][T]...
-  double *tpos = reinterpret_cast<double *>(s2_walk_smem + S2_WALK_WAVES * sizeof(LmTreeLds));
+  constexpr int NT = 64 * WV;
+  // dynamic LDS: [WV] LM workspaces | [SEQS][T][63] de-normalised track positions | optional per-track state [SEQS][T]...
   const size_t tpos_stride = (size_t)T * SE3D_NFU * 3;
+  // one wavefront: one region for everything (same formula as se3d_launch_stage2_walk)
+  const size_t shared_bytes = (max(max(sizeof(WaveLds), tpos_stride * sizeof(double)), (size_t)H * T * sizeof(double)) + 15) & ~(size_t)15;
+  double *tpos = reinterpret_cast<double *>(s2_walk_smem + (WV == 1 ? 0 : WV * sizeof(WaveLds)));
   // Per-track state of the sequences lives in LDS for the duration of the walk when it fits (Wk.lds_state): every phase touches it
   // through the same Se3dStage2 pointers (generic pointers), at LDS instead of HBM/L2 latency.
   Se3dStage2 Qs = Q;
@@ -1564,11 +2101,11 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
   uint32_t *l_has = nullptr;
   int32_t *l_id = nullptr, *l_nobs = nullptr;
   uint8_t *l_used = nullptr;
-  const int TT = S2_WALK_SEQS * T;       // LDS state capacity (track slots of all sequences of the workgroup)
+  const int TT = SQ * T;       // LDS state capacity (track slots of all sequences of the workgroup)
   const int tn = ns * T;                 // track slots in use
   const size_t g0 = (size_t)sb * T;
   if (Wk.lds_state) {
-    double *b = tpos + S2_WALK_SEQS * tpos_stride;
+    double *b = WV == 1 ? reinterpret_cast<double *>(s2_walk_smem + shared_bytes) : tpos + SQ * tpos_stride;
     l_root = b; b += (size_t)TT * 3;
     l_height = b; b += TT;
     l_tprev = b; b += TT;
@@ -1596,7 +2133,7 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
   Qs.fb_buf += (size_t)sb * 3; Qs.t_prev += sb; Qs.next_id += sb; Qs.frame_nr += sb; Qs.n_tracks += sb; Qs.order += g0;
   Qs.C += (size_t)sb * H * T; Qs.W += (size_t)sb * H * T; Qs.near += g0 * 4; Qs.det_slot += (size_t)sb * H; Qs.pub += (size_t)sb * H;
   Qs.fused_det += (size_t)sb * H; Qs.pred_det += (size_t)sb * H; Qs.iters_det += (size_t)sb * H; Qs.flags2 += sb;
-  const bool par_assoc = (size_t)H * T * sizeof(double) <= sizeof(LmTreeLds);  // each association wavefront has its own Munkres scratch
+  const bool par_assoc = WV > 1 && (size_t)H * T * sizeof(double) <= sizeof(WaveLds);  // each association wavefront has its own Munkres scratch
   for (int k = 0; k < Wk.n_steps; ++k) {
     const size_t f0 = (size_t)Wk.slot0[k] + sb;
     Se3dStage2 q = Qs;
@@ -1609,21 +2146,21 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
     q.iters = Wk.Wit + f0 * H;
     q.n_out = Wk.Wn + f0;
     q.pred_dt = Wk.Wdt + f0;
-    int nd[S2_WALK_SEQS];
+    int nd[SQ];
 #pragma unroll
-    for (int s = 0; s < S2_WALK_SEQS; ++s) nd[s] = (s < ns) ? min(q.n_det[s], H) : 0;
+    for (int s = 0; s < SQ; ++s) nd[s] = (s < ns) ? min(q.n_det[s], H) : 0;
     WK_STAMP_INIT
 #pragma unroll
-    for (int s = 0; s < S2_WALK_SEQS; ++s)
+    for (int s = 0; s < SQ; ++s)
       if (nd[s] > 0) s2_fill_track_pos(q, s, tid, NT, tpos + s * tpos_stride);
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < S2_WALK_SEQS; ++s)
+    for (int s = 0; s < SQ; ++s)
       if (nd[s] > 0) s2_track_cost_lds(q, s, tid, NT, tpos + s * tpos_stride);
     __syncthreads();
     WK_STAMP(10)  // track cost
     if (par_assoc) {
-      if (wave < ns) s2_track_assoc_wave(q, wave, lane, reinterpret_cast<double *>(s2_walk_smem + wave * sizeof(LmTreeLds)));
+      if (wave < ns) s2_track_assoc_wave(q, wave, lane, reinterpret_cast<double *>(s2_walk_smem + wave * sizeof(WaveLds)));
     } else if (wave == 0) {
       for (int s = 0; s < ns; ++s) s2_track_assoc_wave(q, s, lane, reinterpret_cast<double *>(s2_walk_smem));
     }
@@ -1631,38 +2168,60 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
     __syncthreads();
     WK_STAMP(11)  // association (Munkres)
     {
-      LmTreeLds &L = reinterpret_cast<LmTreeLds *>(s2_walk_smem)[wave];
-      if (lane == 0) {  // the association phase used this LDS as Munkres scratch
-        L.bind(Q.lm_scratch + ((size_t)blockIdx.x * S2_WALK_WAVES + wave) * S2_SCHUR_SCRATCH_DOUBLES);
-      }
-      __builtin_amdgcn_wave_barrier();
       int total = 0;
 #pragma unroll
-      for (int s = 0; s < S2_WALK_SEQS; ++s) total += nd[s];
-      for (;;) {  // persons of all sequences are handed out dynamically: LM iteration counts vary from 2 to 60
-        int idx = 0;
-        if (lane == 0) idx = atomicAdd(&s_next_person, 1);
-        idx = __builtin_amdgcn_readfirstlane(idx);
-        if (idx >= total) break;
-        int s = 0, i = idx;
+      for (int s = 0; s < SQ; ++s) total += nd[s];
+      if constexpr (TRIO) {
+        LmTrioLds &W = reinterpret_cast<LmTrioLds *>(s2_walk_smem)[wave];
+        const int chunk = min(3, max(1, (total + WV - 1) / WV));  // persons per grab: spread them over the wavefronts
+        for (;;) {
+          int idx = 0;
+          if (lane == 0) idx = atomicAdd(&s_next_person, chunk);
+          idx = __builtin_amdgcn_readfirstlane(idx);
+          if (idx >= total) break;
+          const int g3 = lane / SE3D_NFU;
+          const bool have = g3 < chunk && idx + g3 < total;
+          int s = 0, i = idx + g3;
 #pragma unroll
-        for (int ss = 0; ss + 1 < S2_WALK_SEQS; ++ss)
-          if (s == ss && i >= nd[ss]) { i -= nd[ss]; s = ss + 1; }
-        s2_lm_body<3, LmTreeLds>(q, i, s, lane, L);
+          for (int ss = 0; ss + 1 < SQ; ++ss)
+            if (s == ss && i >= nd[ss]) { i -= nd[ss]; s = ss + 1; }
+          s2_lm_trio_body(q, s, i, have, lane, W);
+          __builtin_amdgcn_wave_barrier();
+        }
+      } else {
+        LmTreeLds &L = reinterpret_cast<LmTreeLds *>(s2_walk_smem)[wave];
+        if (lane == 0) {  // the association phase used this LDS as Munkres scratch
+          L.bind(Q.lm_scratch + ((size_t)blockIdx.x * WV + wave) * S2_SCHUR_SCRATCH_DOUBLES);
+        }
         __builtin_amdgcn_wave_barrier();
+        for (;;) {  // persons of all sequences are handed out dynamically: LM iteration counts vary from 2 to 60
+          int idx = 0;
+          if (lane == 0) idx = atomicAdd(&s_next_person, 1);
+          idx = __builtin_amdgcn_readfirstlane(idx);
+          if (idx >= total) break;
+          int s = 0, i = idx;
+#pragma unroll
+          for (int ss = 0; ss + 1 < SQ; ++ss)
+            if (s == ss && i >= nd[ss]) { i -= nd[ss]; s = ss + 1; }
+          s2_lm_body<3, LmTreeLds>(q, i, s, lane, L);
+          __builtin_amdgcn_wave_barrier();
+        }
       }
     }
     __syncthreads();
     WK_STAMP(12)  // LM
 #pragma unroll
-    for (int s = 0; s < S2_WALK_SEQS; ++s)
+    for (int s = 0; s < SQ; ++s)
       if (nd[s] > 0) s2_fill_track_pos(q, s, tid, NT, tpos + s * tpos_stride);  // the LM phase has updated the tracks
     __syncthreads();
-    for (int it = wave; it < ns * T; it += S2_WALK_WAVES) {
+    if constexpr (WV == 1) {
+      if (nd[0] > 0) s2_track_near_flat(q, 0, lane, tpos);
+    } else
+    for (int it = wave; it < ns * T; it += WV) {
       const int s = it / T, si = it - s * T;
       int nds = 0;
 #pragma unroll
-      for (int ss = 0; ss < S2_WALK_SEQS; ++ss) nds = (s == ss) ? nd[ss] : nds;
+      for (int ss = 0; ss < SQ; ++ss) nds = (s == ss) ? nd[ss] : nds;
       if (nds > 0) s2_track_near_lds(q, si, s, lane, tpos + s * tpos_stride);
     }
     __syncthreads();
@@ -1670,7 +2229,7 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
     if (wave < ns) {
       int ndw = 0;
 #pragma unroll
-      for (int ss = 0; ss < S2_WALK_SEQS; ++ss) ndw = (wave == ss) ? nd[ss] : ndw;
+      for (int ss = 0; ss < SQ; ++ss) ndw = (wave == ss) ? nd[ss] : ndw;
       if (ndw > 0) s2_track_update_wave(q, wave, lane);
     }
     __syncthreads();
@@ -1686,6 +2245,26 @@ __global__ __launch_bounds__(64 * S2_WALK_WAVES) __attribute__((amdgpu_waves_per
 }
 static_assert(S2_SCHUR_SCRATCH_DOUBLES == 1865, "se3d_api.hip allocates lm_scratch with this size");
 static_assert(S2_WALK_SEQS >= 1 && S2_WALK_SEQS <= S2_WALK_WAVES, "one association / lifecycle wavefront per sequence of the workgroup");
+template <bool TRIO, int WV, int SQ>
+static bool s2_launch_walk_shape(const Se3dStage2 &q, const Se3dWalk &Wk, int nseq, hipStream_t st) {
+  static int lds_max = -1;
+  if (lds_max < 0) {
+    lds_max = 160 * 1024 - 4096;  // 160 KB per CU minus the kernel's static LDS
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_stage2_walk<TRIO, WV, SQ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+  }
+  using WaveLds = typename std::conditional<TRIO, LmTrioLds, LmTreeLds>::type;
+  const size_t tpos_bytes = (size_t)SQ * q.T * SE3D_NFU * 3 * sizeof(double);
+  const size_t work_bytes = WV == 1 ? ((std::max(std::max(sizeof(WaveLds), tpos_bytes), (size_t)q.H * q.T * sizeof(double)) + 15) & ~(size_t)15)
+                                    : WV * sizeof(WaveLds) + tpos_bytes;
+  // small per-track state in LDS when it fits: root 3 + height + t_prev doubles, 4 words
+  const size_t state_bytes = (size_t)SQ * q.T * (5 * sizeof(double) + 16);
+  Se3dWalk w = Wk;
+  w.lds_state = (work_bytes + state_bytes <= (size_t)lds_max) ? 1 : 0;
+  const size_t dyn = work_bytes + (w.lds_state ? state_bytes : 0);
+  if (dyn > (size_t)lds_max) return false;
+  hipLaunchKernelGGL((se3d_k_stage2_walk<TRIO, WV, SQ>), dim3((nseq + SQ - 1) / SQ), dim3(64 * WV), dyn, st, q, w, nseq);
+  return true;
+}
 
 #ifdef SE3D_LM_STAMPS
 extern "C" void se3d_diag_lm_ablate(int bits) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lm_ablate), &bits, sizeof(int)); }
@@ -1706,28 +2285,23 @@ static int s2_lm_mode() {
 
 // true: the fused kernel was launched; false: not applicable (caller falls back to per-step launches)
 extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st) {
-  const size_t lm_bytes = S2_WALK_WAVES * sizeof(LmTreeLds);
-  const char *e = getenv("SE3D_WALK");  // A/B evidence switch (read per launch): steps = always use the per-step kernels
+  const char *el = getenv("SE3D_WALK_LM");     // A/B evidence switches (read per launch): solo = one person per LM wavefront
+  const char *es = getenv("SE3D_WALK_SHAPE");  // wg = 4 wavefronts / 2 sequences per workgroup, wave = one wavefront per sequence
+  const bool trio = !(el && strcmp(el, "solo") == 0);
+  const char *e = getenv("SE3D_WALK");  // steps = always use the per-step kernels
   const bool ok = !(e && strcmp(e, "steps") == 0) && s2_lm_mode() == 3;
-  // The fused walk gives each sequence one workgroup (4 LM wavefronts): right for many short sequences of few persons.  Large
-  // association problems (> 64) and few sequences of many persons keep the per-step kernels (a wavefront per person over the GPU).
+  // The fused walk is right for many short sequences of few persons.  Large association problems (> 64) and few sequences of many
+  // persons keep the per-step kernels (a wavefront per person over the whole GPU).
   if (!ok || Q.H > 64 || Q.T > 64 || nseq < 1 || (Q.H > 16 && nseq < 32)) return false;
   Se3dStage2 q = Q;
   q.seq0 = 0;
-  // small per-track state in LDS when it fits next to the LM workspaces: root 3 + height + t_prev doubles, 4 words
-  const size_t state_bytes = (size_t)Q.T * (5 * sizeof(double) + 16);
-  static int lds_max = -1;
-  if (lds_max < 0) {
-    lds_max = 160 * 1024 - 4096;  // 160 KB per CU minus the kernel's static LDS
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_stage2_walk), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-  }
-  const size_t tpos_bytes = (size_t)S2_WALK_SEQS * Q.T * SE3D_NFU * 3 * sizeof(double);
-  Se3dWalk w = Wk;
-  w.lds_state = (lm_bytes + tpos_bytes + S2_WALK_SEQS * state_bytes <= (size_t)lds_max) ? 1 : 0;
-  const size_t dyn = lm_bytes + tpos_bytes + (w.lds_state ? S2_WALK_SEQS * state_bytes : 0);
-  if (dyn > (size_t)lds_max) return false;
-  hipLaunchKernelGGL(se3d_k_stage2_walk, dim3((nseq + S2_WALK_SEQS - 1) / S2_WALK_SEQS), dim3(64 * S2_WALK_WAVES), dyn, st, q, w, nseq);
-  return true;
+  // one wavefront per sequence once a launch brings enough sequences to fill wavefront slots that way (and a sequence-step is a few
+  // trios at most); otherwise the latency shape
+  bool wave_shape = trio && Q.H <= 16 && nseq >= 256;
+  if (es) wave_shape = trio && strcmp(es, "wave") == 0;
+  if (wave_shape && s2_launch_walk_shape<true, 1, 1>(q, Wk, nseq, st)) return true;
+  return trio ? s2_launch_walk_shape<true, S2_WALK_WAVES, S2_WALK_SEQS>(q, Wk, nseq, st)
+              : s2_launch_walk_shape<false, S2_WALK_WAVES, S2_WALK_SEQS>(q, Wk, nseq, st);
 }
 
 extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev) {

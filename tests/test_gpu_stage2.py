@@ -135,19 +135,33 @@ def test_device_pack_matches_host_fetch(extr_rig, device_buffer):
     node.close()
 
 
+def _close_persons(x, y, n):
+    """same ids / scores / measured joints; joints within 1e-9 m, covariances within 1e-6 relative (different summation order)"""
+    for f in ("id", "score"):
+        assert np.array_equal(x[f][:n], y[f][:n])
+    kx, ky = x["keypoints"][:n], y["keypoints"][:n]
+    assert np.array_equal(kx["score"], ky["score"])
+    assert np.allclose(kx["joint"], ky["joint"], rtol=0, atol=1e-9)
+    assert np.allclose(kx["cov"], ky["cov"], rtol=1e-6, atol=1e-12)
+
+
 @pytest.mark.parametrize("S_,T_,persons,mh", [(5, 14, 4, 16), (3, 16, 6, 8), (2, 12, 9, 64)])
-def test_stage2_walk_equals_per_step_and_oracle(extr_rig, oracle, demo_params, S_, T_, persons, mh):
-    """se3d_run_stage2_walk (one fused launch for all time steps; falls back to per-step kernels for max_hyp = 64) gives exactly what
-    T consecutive se3d_run_stage2 calls give, and matches the oracle; walked forward then backward (bench.py's ping-pong order)."""
+def test_stage2_walk_equals_per_step_and_oracle(extr_rig, oracle, demo_params, monkeypatch, S_, T_, persons, mh):
+    """se3d_run_stage2_walk (one fused launch for all time steps; falls back to per-step kernels for max_hyp = 64) against T
+    consecutive se3d_run_stage2 calls and the oracle; walked forward then backward (bench.py's ping-pong order).  Variants of the
+    fused kernel: one person per LM wavefront ("solo": the per-step device code, bitwise equal to the per-step calls), three persons
+    per LM wavefront in the workgroup shape and in the one-wavefront-per-sequence shape (same arithmetic in another summation
+    order: bitwise equal to each other, equal decisions and iteration counts, joints within 1e-9 m of the per-step calls)."""
     seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=persons - (s % 2), n_frames=T_, seed=300 + s))[0] for s in range(S_)]
     frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s
-    a = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=min(10, mh), max_hyp=mh)
-    b = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=min(10, mh), max_hyp=mh)
-    for nd in (a, b):
+    variants = {"solo": {"SE3D_WALK_LM": "solo"}, "trio_wg": {"SE3D_WALK_SHAPE": "wg"}, "trio_wave": {"SE3D_WALK_SHAPE": "wave"}}
+    nodes = {name: _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=min(10, mh), max_hyp=mh) for name in list(variants) + ["steps"]}
+    for nd in nodes.values():
         nd.stage(frames)
         nd.run_stage1()
         nd.refine_reset()
-    r1 = a.fetch_stage1(S_ * T_)
+    b = nodes["steps"]
+    r1 = b.fetch_stage1(S_ * T_)
     order = list(range(T_)) + list(range(T_ - 1, -1, -1))
     t_of = [100.0 + (i + 1) / 30.0 for i in range(len(order))]
     oras = [oracle.PosePrior(demo_params) for _ in range(S_)]
@@ -155,24 +169,36 @@ def test_stage2_walk_equals_per_step_and_oracle(extr_rig, oracle, demo_params, S
     for half in range(2):
         ks = order[half * T_:(half + 1) * T_]
         ts = t_of[half * T_:(half + 1) * T_]
-        a.run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in ks])
+        for name, env in variants.items():
+            for key in ("SE3D_WALK_LM", "SE3D_WALK_SHAPE"):
+                monkeypatch.delenv(key, raising=False)
+            for key, val in env.items():
+                monkeypatch.setenv(key, val)
+            nodes[name].run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in ks])
+            nodes[name].sync()
         for k, t in zip(ks, ts):
             b.run_stage2(np.full(S_, t), frame_slot0=k * S_)
             rb = b.fetch_stage2(S_)
-            ra = a.fetch_stage2_walk(k * S_, S_)
+            ra = {name: nodes[name].fetch_stage2_walk(k * S_, S_) for name in variants}
             for s in range(S_):
-                assert ra[s].n_persons == rb[s].n_persons
-                n = ra[s].n_persons
-                assert ra[s].fused[:n].tobytes() == rb[s].fused[:n].tobytes()
-                assert ra[s].fused_pred[:n].tobytes() == rb[s].fused_pred[:n].tobytes()
-                assert np.array_equal(ra[s].lm_iterations[:n], rb[s].lm_iterations[:n])
-                assert abs(ra[s].c.pred_delta_t - rb[s].c.pred_delta_t) == 0
+                n = rb[s].n_persons
+                for name in variants:
+                    assert ra[name][s].n_persons == n
+                    assert np.array_equal(ra[name][s].lm_iterations[:n], rb[s].lm_iterations[:n])
+                    assert abs(ra[name][s].c.pred_delta_t - rb[s].c.pred_delta_t) == 0
+                assert ra["solo"][s].fused[:n].tobytes() == rb[s].fused[:n].tobytes()
+                assert ra["solo"][s].fused_pred[:n].tobytes() == rb[s].fused_pred[:n].tobytes()
+                assert ra["trio_wg"][s].fused[:n].tobytes() == ra["trio_wave"][s].fused[:n].tobytes()
+                assert ra["trio_wg"][s].fused_pred[:n].tobytes() == ra["trio_wave"][s].fused_pred[:n].tobytes()
+                _close_persons(ra["trio_wave"][s].fused, rb[s].fused, n)
+                _close_persons(ra["trio_wave"][s].fused_pred, rb[s].fused_pred, n)
                 o = oras[s].step(r1[k * S_ + s].published(), 16, t, seqs[s][k].fb_delay, capacity=mh)
-                compare_stage2(ra[s], o)
+                compare_stage2(ra["trio_wave"][s], o)
+                compare_stage2(ra["trio_wg"][s], o)
                 total += n
     assert total > S_ * T_ * (persons - 1)
-    a.close()
-    b.close()
+    for nd in nodes.values():
+        nd.close()
 
 
 def test_stage2_walk_device_pack(extr_rig, device_buffer):
@@ -210,8 +236,12 @@ def test_stage2_walk_device_pack(extr_rig, device_buffer):
     node.close()
 
 
-def test_stage2_walk_then_per_step_share_track_state(extr_rig):
-    """Track state written back by a fused walk (it lives in LDS during the walk) is what later per-step calls continue from."""
+@pytest.mark.parametrize("variant", ["solo", "trio"])
+def test_stage2_walk_then_per_step_share_track_state(extr_rig, monkeypatch, variant):
+    """Track state written back by a fused walk (it lives in LDS during the walk) is what later per-step calls continue from:
+    bitwise with the one-person-per-wavefront LM (the per-step device code), within rounding with three persons per wavefront."""
+    if variant == "solo":
+        monkeypatch.setenv("SE3D_WALK_LM", "solo")
     S_, T_ = 3, 16
     seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=5, n_frames=T_, seed=500 + s))[0] for s in range(S_)]
     frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
@@ -234,8 +264,12 @@ def test_stage2_walk_then_per_step_share_track_state(extr_rig):
         for s in range(S_):
             n = ra[s].n_persons
             assert n == rb[s].n_persons and ra[s].c.n_tracks == rb[s].c.n_tracks
-            assert ra[s].fused[:n].tobytes() == rb[s].fused[:n].tobytes()
-            assert ra[s].fused_pred[:n].tobytes() == rb[s].fused_pred[:n].tobytes()
+            if variant == "solo":
+                assert ra[s].fused[:n].tobytes() == rb[s].fused[:n].tobytes()
+                assert ra[s].fused_pred[:n].tobytes() == rb[s].fused_pred[:n].tobytes()
+            else:
+                _close_persons(ra[s].fused, rb[s].fused, n)
+                _close_persons(ra[s].fused_pred, rb[s].fused_pred, n)
             published += n
     assert published > 0
     a.close()

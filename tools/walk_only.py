@@ -6,7 +6,7 @@ import bench as Bn
 from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
 w = Bn.WORKLOADS["16cam6p"]
 rig = Bn.make_rig(w)
-S_, T_, NC = 128, 16, int(sys.argv[1])
+S_, T_, NC = (int(sys.argv[2]) if len(sys.argv) > 2 else 128), 16, int(sys.argv[1])
 nodes = []
 for ci in range(NC):
     seqs = Bn.make_sequences(rig, w, S_, seed0=100 * ci, t_steps=T_)
