@@ -692,11 +692,13 @@ __device__ void s2_schur_solve(LT &L, int K, int nr, double lambda, int lane, co
 // have a perfect (fill-free) elimination order: leaves first.  Eliminating child c into parent p over edge h = hs_e:
 //   D_p -= (h^T D_c^-1 h) h h^T,   g_p += (h^T D_c^-1 g_c) h;   back-substitution  d_c = D_c^-1 g_c + D_c^-1 h (h^T d_p).
 // This is the exact block Cholesky solve a multifrontal solver performs with a perfect ordering; lane v owns joint v, all
-// joints of one depth are processed together (<= 6 levels) and only 3x3 symmetric inverses are needed.
-// c_tree_rank[k] = position of fusion joint k in a top-down order of the union skeleton tree rooted at MidHip
-// (8,20,9,12,1,10,13,0,2,5,11,14,15,16,19,3,6,17,18,4,7): every joint's possible parents precede it.
+// joints of one depth are processed together and only 3x3 symmetric inverses are needed.
+// c_tree_rank[k] = position of fusion joint k in a breadth-first order of the union skeleton tree rooted at the belly
+// (20,1,8,0,2,5,9,12,3,6,10,13,15,16,19,4,7,11,14,17,18): every joint's possible parents precede it.  Rooted there the forest is
+// four levels deep (belly-neck-shoulder-elbow-wrist, belly-midhip-hip-knee-ankle; without the belly: neck-midhip-hip-knee-ankle),
+// one less than from the MidHip: the levels are the sequential part of every solve.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __constant__ const int c_tree_rank[SE3D_NFU] = {7, 4, 8, 15, 19, 9, 16, 20, 0, 2, 5, 10, 3, 6, 11, 12, 13, 17, 18, 14, 1};
+__device__ __constant__ const int c_tree_rank[SE3D_NFU] = {3, 1, 4, 8, 15, 5, 9, 16, 2, 6, 10, 17, 7, 11, 18, 12, 13, 19, 20, 14, 0};
 
 struct TreeTopo { int parent, pedge, level, maxlev; unsigned children; bool forest; };
 
@@ -1358,6 +1360,27 @@ __device__ __forceinline__ double s2_trio_sum(double v, double *red, int lane, i
   return tot;
 }
 
+// 1/x and 1/sqrt(x) from the hardware seeds + two Newton steps (<= 1 ulp): the full-precision expansions of '/' and sqrt() are
+// 10-20 dependent instructions each and sit on the critical path of every LM trial of a wavefront that walks its sequence alone
+__device__ __forceinline__ double s2_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+  return y;
+}
+__device__ __forceinline__ double s2_rsq(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = __builtin_fma(__builtin_fma(-x * y, y, 1.0), 0.5 * y, y);
+  y = __builtin_fma(__builtin_fma(-x * y, y, 1.0), 0.5 * y, y);
+  return y;
+}
+__device__ __forceinline__ void s2_sym3_inv_fast(const double a[6], double o[6]) {
+  const double c00 = a[3] * a[5] - a[4] * a[4], c01 = -(a[1] * a[5] - a[4] * a[2]), c02 = a[1] * a[4] - a[3] * a[2];
+  const double det = a[0] * c00 + a[1] * c01 + a[2] * c02, id = s2_rcp(det);
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+  o[3] = (a[0] * a[5] - a[2] * a[2]) * id; o[4] = -(a[0] * a[4] - a[1] * a[2]) * id; o[5] = (a[0] * a[3] - a[1] * a[1]) * id;
+}
+
 // two sums at once (one LDS round trip)
 __device__ __forceinline__ void s2_trio_sum2(double &v0, double &v1, double (*red)[64], int lane, int gb) {
   red[0][lane] = v0; red[1][lane] = v1;
@@ -1396,6 +1419,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
   const bool simple = Q.pose_method == SE3D_POSE_SIMPLE;
   const double t = Q.t[have ? s : 0];
   const unsigned gmask = 0x1FFFFFu;
+  LM_STAMP_INIT
 
   // ---- root / neck / height (PP:631-668), identical on every lane of the group ----
   double root[3] = {0, 0, 0}, neck[3] = {0, 0, 0};
@@ -1512,8 +1536,9 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
     if (on && j == pa) children |= 1u << ch;
   }
   bS *= (Q.norm_height ? 2.0 : 1.0);  // g_limbLSigmaFactor (PP:934-937)
+  const double invS = 1.0 / bS;
   if (!measured) { pe = -1; parent = -1; children = 0u; }
-  if (((uint32_t)(__ballot(measured && npar > 1) >> gb) & gmask) != 0u) {  // not a forest: impossible with the bone tables above
+  if (((uint32_t)(__ballot(measured && (npar > 1 || __popc(children) > 4)) >> gb) & gmask) != 0u) {  // impossible with the bone tables above
     wh_ok = false;
     if (valid && j == 0) atomicOr(&Q.flags2[s], 8u);
   }
@@ -1531,112 +1556,132 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
     if (__ballot(measured && level == lv)) { maxlev = lv; break; }
   const bool edge = pe >= 0;
 
-  double Av[6] = {0, 0, 0, 0, 0, 0};  // R^T R
-  if (measured) {
-    Av[0] = R[0] * R[0]; Av[1] = R[0] * R[1]; Av[2] = R[0] * R[2];
-    Av[3] = R[1] * R[1] + R[3] * R[3]; Av[4] = R[1] * R[2] + R[3] * R[4]; Av[5] = R[2] * R[2] + R[4] * R[4] + R[5] * R[5];
+  // children of this joint (at most four with the bone tables), visited two at a time: their LDS rows are fetched together
+  int chv[4];
+  const int nch = __popc(children);
+  {
+    unsigned cm = children;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { chv[q] = cm ? __ffs(cm) - 1 : j; cm &= cm - 1; }
   }
+  const int nbatch = __ballot(nch > 2) != 0ull ? 4 : 2;
   __builtin_amdgcn_wave_barrier();
 
-  // 0.5 * ||whitened error||^2 of this lane's factors at xv (own joint) with the parent joint taken from X
-  auto lane_error = [&](const double xv[3], const double (*X)[SE3D_NFU]) -> double {
-    double e = 0.0;
+  // Whitened errors of this lane's factors at xv (own joint; parent joint from X): unary part eu, parent-bone part ee.  The evaluation
+  // leaves what a linearisation at the same point needs in registers (whitened unary residual, bone vector, length, 1 / length): LM
+  // only ever re-linearises at a point whose error it has just evaluated (the initial values, an accepted step).
+  double ev_w[3] = {0, 0, 0}, ev_d[3] = {0, 0, 0}, ev_r = 0.0, ev_ir = 0.0;
+  auto evaluate = [&](const double xv[3], const double (*X)[SE3D_NFU], double &eu, double &ee) {
+    eu = 0.0; ee = 0.0;
     if (measured) {
       const double r3[3] = {xv[0] - m[0], xv[1] - m[1], xv[2] - m[2]};
-      double w3[3];
-      s2_trio_Rmul(R, r3, w3);
-      e = 0.5 * w3[0] * w3[0] + 0.5 * w3[1] * w3[1] + 0.5 * w3[2] * w3[2];
+      s2_trio_Rmul(R, r3, ev_w);
+      eu = 0.5 * ev_w[0] * ev_w[0] + 0.5 * ev_w[1] * ev_w[1] + 0.5 * ev_w[2] * ev_w[2];
       if (edge) {
-        const double dx = X[0][parent] - xv[0], dy = X[1][parent] - xv[1], dz = X[2][parent] - xv[2];  // sign does not matter here
-        const double r = sqrt(dx * dx + dy * dy + dz * dz);
-        const double w = (r - bL) / bS;
-        e += 0.5 * w * w;
+        const double px = X[0][parent], py = X[1][parent], pz = X[2][parent];
+        ev_d[0] = child_is_k2 ? xv[0] - px : px - xv[0]; ev_d[1] = child_is_k2 ? xv[1] - py : py - xv[1]; ev_d[2] = child_is_k2 ? xv[2] - pz : pz - xv[2];
+        const double r2 = ev_d[0] * ev_d[0] + ev_d[1] * ev_d[1] + ev_d[2] * ev_d[2];
+        ev_ir = r2 > 0.0 ? s2_rsq(r2) : 0.0;
+        ev_r = r2 * ev_ir;
+        const double w = (ev_r - bL) * invS;
+        ee = 0.5 * w * w;
       }
     }
-    return e;
   };
-  // linearise this lane's factors at x: unary rhs bu, parent-bone direction hsv / rhs (LDS for the parent lane); returns the bone rhs
-  double bu[3] = {0, 0, 0}, hsv[3] = {0, 0, 0}, ebu = 0.0;
-  auto linearize = [&]() {
-    if (measured) {
-      const double r3[3] = {x[0] - m[0], x[1] - m[1], x[2] - m[2]};
-      double w3[3];
-      s2_trio_Rmul(R, r3, w3);
-      bu[0] = -w3[0]; bu[1] = -w3[1]; bu[2] = -w3[2];
+  // Linearisation at the evaluated point, for the groups with `on`: parent-bone direction / sigma hsv and rhs ebu (LDS copies for the
+  // parent lane), gradient gv = J^T b and block diagonal A0 = (J^T J)_jj of this joint (own unary and parent bone, children's bones).
+  double hsv[3] = {0, 0, 0}, ebu = 0.0, A0[6] = {0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
+  auto relinearize = [&](bool on) {
+    on = on && measured;
+    if (on) {
+      gv[0] = -(R[0] * ev_w[0]); gv[1] = -(R[1] * ev_w[0] + R[3] * ev_w[1]); gv[2] = -(R[2] * ev_w[0] + R[4] * ev_w[1] + R[5] * ev_w[2]);
+      A0[0] = R[0] * R[0]; A0[1] = R[0] * R[1]; A0[2] = R[0] * R[2];   // R^T R
+      A0[3] = R[1] * R[1] + R[3] * R[3]; A0[4] = R[1] * R[2] + R[3] * R[4]; A0[5] = R[2] * R[2] + R[4] * R[4] + R[5] * R[5];
       if (edge) {
-        const double px = L.xc[0][parent], py = L.xc[1][parent], pz = L.xc[2][parent];
-        const double dx = child_is_k2 ? x[0] - px : px - x[0], dy = child_is_k2 ? x[1] - py : py - x[1], dz = child_is_k2 ? x[2] - pz : pz - x[2];
-        const double r = sqrt(dx * dx + dy * dy + dz * dz);
         double h0 = 1.0, h1 = 1.0, h2 = 1.0;
-        if (fabs(r) > 1e-10) { h0 = dx / r; h1 = dy / r; h2 = dz / r; }
-        hsv[0] = h0 / bS; hsv[1] = h1 / bS; hsv[2] = h2 / bS;
-        ebu = -(r - bL) / bS;
+        if (fabs(ev_r) > 1e-10) { h0 = ev_d[0] * ev_ir; h1 = ev_d[1] * ev_ir; h2 = ev_d[2] * ev_ir; }
+        hsv[0] = h0 * invS; hsv[1] = h1 * invS; hsv[2] = h2 * invS;
+        ebu = -(ev_r - bL) * invS;
+        const double sb = child_is_k2 ? ebu : -ebu;
         L.hs[0][j] = hsv[0]; L.hs[1][j] = hsv[1]; L.hs[2][j] = hsv[2];
-        L.eb[j] = child_is_k2 ? ebu : -ebu;
+        L.eb[j] = sb;
+        gv[0] += hsv[0] * sb; gv[1] += hsv[1] * sb; gv[2] += hsv[2] * sb;
+        A0[0] += hsv[0] * hsv[0]; A0[1] += hsv[0] * hsv[1]; A0[2] += hsv[0] * hsv[2];
+        A0[3] += hsv[1] * hsv[1]; A0[4] += hsv[1] * hsv[2]; A0[5] += hsv[2] * hsv[2];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (on) {
+      for (int q0 = 0; q0 < nbatch; q0 += 2) {
+        double c0[2], c1[2], c2[2], cb[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int c = chv[q0 + q]; c0[q] = L.hs[0][c]; c1[q] = L.hs[1][c]; c2[q] = L.hs[2][c]; cb[q] = L.eb[c]; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (q0 + q < nch) {
+            const double h0 = c0[q], h1 = c1[q], h2 = c2[q], sb = cb[q];
+            gv[0] -= h0 * sb; gv[1] -= h1 * sb; gv[2] -= h2 * sb;
+            A0[0] += h0 * h0; A0[1] += h0 * h1; A0[2] += h0 * h2; A0[3] += h1 * h1; A0[4] += h1 * h2; A0[5] += h2 * h2;
+          }
       }
     }
   };
 
   // ---- LevenbergMarquardtOptimizer(graph, prevEstimate).optimize(), GTSAM 4.0.3 defaults ----
+  // GTSAM's two nested loops (iterate / tryLambda) as one loop of trials: `tr` counts the trials of the current iteration, an accepted
+  // step (or giving up on lambda) ends the iteration and runs its convergence checks.
   int iterations = 0, tr = 0, outer = 0;
   double error = 0.0, lambda = 1e-5, currentError = 0.0;
-  bool running = false, need_lin = true;
+  bool running = false;
   {
-    const double e0 = s2_trio_sum(lane_error(x, L.xc), W.red[0], lane, gb);
-    error = e0;
+    double eu, ee;
+    evaluate(x, L.xc, eu, ee);
+    error = s2_trio_sum(eu + ee, W.red[0], lane, gb);
     running = valid && wh_ok && !(error <= 0.0);
+    currentError = error;
+    if (__ballot(running)) relinearize(running);
   }
-  double A0[6] = {0, 0, 0, 0, 0, 0}, gv[3] = {0, 0, 0};
+  LM_STAMP(0)  // setup + initial error + first linearisation
+  bool pending = false;
   while (__ballot(running)) {
-    const bool lin = running && need_lin;
-    if (__ballot(lin)) {
-      if (lin) { currentError = error; tr = 0; need_lin = false; linearize(); }
-      __builtin_amdgcn_wave_barrier();
-      if (lin && measured) {  // gradient J^T b and block diagonal J^T J of this joint
-        gv[0] = R[0] * bu[0]; gv[1] = R[1] * bu[0] + R[3] * bu[1]; gv[2] = R[2] * bu[0] + R[4] * bu[1] + R[5] * bu[2];
-        for (int q = 0; q < 6; ++q) A0[q] = Av[q];
-        if (edge) {
-          const double sb = child_is_k2 ? ebu : -ebu;
-          gv[0] += hsv[0] * sb; gv[1] += hsv[1] * sb; gv[2] += hsv[2] * sb;
-          A0[0] += hsv[0] * hsv[0]; A0[1] += hsv[0] * hsv[1]; A0[2] += hsv[0] * hsv[2];
-          A0[3] += hsv[1] * hsv[1]; A0[4] += hsv[1] * hsv[2]; A0[5] += hsv[2] * hsv[2];
-        }
-        for (unsigned cm = children; cm; cm &= cm - 1) {
-          const int c = __ffs(cm) - 1;
-          const double h0 = L.hs[0][c], h1 = L.hs[1][c], h2 = L.hs[2][c], sb = L.eb[c];
-          gv[0] -= h0 * sb; gv[1] -= h1 * sb; gv[2] -= h2 * sb;
-          A0[0] += h0 * h0; A0[1] += h0 * h1; A0[2] += h0 * h2; A0[3] += h1 * h1; A0[4] += h1 * h2; A0[5] += h2 * h2;
-        }
-      }
-    }
+    if (__ballot(pending)) { relinearize(pending); pending = false; }   // at the accepted values, from their evaluation
+    LM_STAMP(1)  // linearise + gradient
     // ---- tryLambda: delta = (J^T J + lambda I)^-1 J^T b by forest elimination ----
     const bool act = running && measured;
-    double D[6] = {A0[0] + lambda, A0[1], A0[2], A0[3] + lambda, A0[4], A0[5] + lambda};
-    double gg[3] = {gv[0], gv[1], gv[2]};
-    double Di[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0}, z[3] = {0, 0, 0}, d[3] = {0, 0, 0}, dp[3] = {0, 0, 0};
-    for (int lv = maxlev; lv >= 1; --lv) {  // leaves -> roots
-      if (act && level == lv) {
-        s2_sym3_inv(D, Di);
-        s2_sym3_mul(Di, hsv, u);
-        s2_sym3_mul(Di, gg, z);
-        L.al[j] = hsv[0] * u[0] + hsv[1] * u[1] + hsv[2] * u[2];
-        L.be[j] = hsv[0] * z[0] + hsv[1] * z[1] + hsv[2] * z[2];
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (act && level == lv - 1) {
-        for (unsigned cm = children; cm; cm &= cm - 1) {
-          const int c = __ffs(cm) - 1;
-          const double h0 = L.hs[0][c], h1 = L.hs[1][c], h2 = L.hs[2][c];
-          const double a = L.al[c], b = L.be[c];
-          D[0] -= a * h0 * h0; D[1] -= a * h0 * h1; D[2] -= a * h0 * h2; D[3] -= a * h1 * h1; D[4] -= a * h1 * h2; D[5] -= a * h2 * h2;
-          gg[0] += b * h0; gg[1] += b * h1; gg[2] += b * h2;
+    double u[3] = {0, 0, 0}, z[3] = {0, 0, 0}, d[3] = {0, 0, 0}, dp[3] = {0, 0, 0};
+    {
+      double D[6] = {A0[0] + lambda, A0[1], A0[2], A0[3] + lambda, A0[4], A0[5] + lambda};
+      double gg[3] = {gv[0], gv[1], gv[2]};
+      double Di[6] = {0, 0, 0, 0, 0, 0};
+      for (int lv = maxlev; lv >= 1; --lv) {  // leaves -> roots
+        if (act && level == lv) {
+          s2_sym3_inv_fast(D, Di);
+          s2_sym3_mul(Di, hsv, u);
+          s2_sym3_mul(Di, gg, z);
+          L.al[j] = hsv[0] * u[0] + hsv[1] * u[1] + hsv[2] * u[2];
+          L.be[j] = hsv[0] * z[0] + hsv[1] * z[1] + hsv[2] * z[2];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (act && level == lv - 1) {
+          for (int q0 = 0; q0 < nbatch; q0 += 2) {
+            double c0[2], c1[2], c2[2], ca[2], cb[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { const int c = chv[q0 + q]; c0[q] = L.hs[0][c]; c1[q] = L.hs[1][c]; c2[q] = L.hs[2][c]; ca[q] = L.al[c]; cb[q] = L.be[c]; }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              if (q0 + q < nch) {
+                const double h0 = c0[q], h1 = c1[q], h2 = c2[q], a_ = ca[q], b_ = cb[q];
+                D[0] -= a_ * h0 * h0; D[1] -= a_ * h0 * h1; D[2] -= a_ * h0 * h2; D[3] -= a_ * h1 * h1; D[4] -= a_ * h1 * h2; D[5] -= a_ * h2 * h2;
+                gg[0] += b_ * h0; gg[1] += b_ * h1; gg[2] += b_ * h2;
+              }
+          }
         }
       }
-    }
-    if (act && level == 0) {
-      s2_sym3_inv(D, Di);
-      s2_sym3_mul(Di, gg, d);
-      for (int a = 0; a < 3; ++a) L.dl[a][j] = d[a];
+      if (act && level == 0) {
+        s2_sym3_inv_fast(D, Di);
+        s2_sym3_mul(Di, gg, d);
+        for (int a = 0; a < 3; ++a) L.dl[a][j] = d[a];
+      }
     }
     for (int lv = 1; lv <= maxlev; ++lv) {  // roots -> leaves
       __builtin_amdgcn_wave_barrier();
@@ -1646,29 +1691,35 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
         for (int a = 0; a < 3; ++a) { d[a] = z[a] + u[a] * gam; L.dl[a][j] = d[a]; }
       }
     }
-    // linear.error(delta) = 0.5 ||J delta - b||^2 over the undamped factors; retract; non-linear error at the tentative values
-    double le = 0.0, xn[3] = {x[0] + d[0], x[1] + d[1], x[2] + d[2]};
+    LM_STAMP(2)  // solve
+    // Retract, then both errors of the trial.  linear.error(delta) = 0.5 ||J delta - b||^2 over the undamped factors: a unary factor
+    // is linear, so its linearised error at delta IS its error at the tentative values; only the bones differ.
+    const double xn[3] = {x[0] + d[0], x[1] + d[1], x[2] + d[2]};
+    double le = 0.0, newError = 0.0;
     if (act) {
-      double w3[3];
-      s2_trio_Rmul(R, d, w3);
-      for (int a = 0; a < 3; ++a) { const double sv = w3[a] - bu[a]; le += 0.5 * sv * sv; }
       if (edge) {
         const double e0 = child_is_k2 ? d[0] - dp[0] : dp[0] - d[0], e1 = child_is_k2 ? d[1] - dp[1] : dp[1] - d[1],
                      e2 = child_is_k2 ? d[2] - dp[2] : dp[2] - d[2];
         const double sv = hsv[0] * e0 + hsv[1] * e1 + hsv[2] * e2 - ebu;
-        le += 0.5 * sv * sv;
+        le = 0.5 * sv * sv;
       }
       for (int a = 0; a < 3; ++a) L.xn[a][j] = xn[a];
     }
     __builtin_amdgcn_wave_barrier();  // xn visible to the children
-    double newError = act ? lane_error(xn, L.xn) : 0.0;
+    if (act) {
+      double eu, ee;
+      evaluate(xn, L.xn, eu, ee);
+      le += eu;
+      newError = eu + ee;
+    }
     s2_trio_sum2(le, newError, W.red, lane, gb);
+    bool accepted = false;
     if (running) {
       const double linearizedCostChange = error - le;
       bool step_ok = false, stop = false;
       if (linearizedCostChange >= 0) {
         const double costChange = error - newError;
-        if (linearizedCostChange > 1e-20) step_ok = costChange / linearizedCostChange > 1e-3;
+        if (linearizedCostChange > 1e-20) step_ok = costChange > 1e-3 * linearizedCostChange;  // modelFidelity > minModelFidelity
         if (fabs(costChange) < 1e-5 * error) stop = true;
       }
       bool end_outer = false;
@@ -1686,16 +1737,23 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
       } else {
         end_outer = true;
       }
-      if (end_outer) {
+      if (end_outer) {  // checks at the end of an iteration; without an accepted step the error is unchanged and they stop the loop
         const double absoluteDecrease = currentError - error;
-        const double relativeDecrease = absoluteDecrease / currentError;
         ++outer;
-        if (iterations >= 100 || error <= 0.0 || relativeDecrease <= 1e-5 || absoluteDecrease <= 1e-5 || !isfinite(currentError) || outer >= 1000)
+        if (iterations >= 100 || error <= 0.0 || absoluteDecrease <= 1e-5 * currentError /* relativeDecrease <= relativeErrorTol */ ||
+            absoluteDecrease <= 1e-5 || !isfinite(currentError) || outer >= 1000)
           running = false;
-        need_lin = true;
+        currentError = error;
+        tr = 0;
+        accepted = step_ok && running;
       }
     }
+    LM_STAMP(3)  // errors, sums, control
+    pending = accepted;
     __builtin_amdgcn_wave_barrier();
+#ifdef SE3D_LM_STAMPS
+    if (threadIdx.x == 0) atomicAdd(&g_lm_stamps[9], 1ull);
+#endif
   }
   if (valid && !wh_ok && measured) { x[0] = m[0]; x[1] = m[1]; x[2] = m[2]; }  // optimisation failed: output the measurements (PP:751-758)
 
@@ -1705,37 +1763,35 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
   if (__ballot(use_marg)) {
     const bool act = use_marg && measured;
     double *MC = &L.xn[0][0];  // [6][21] over xn + dl
-    if (act) linearize();
-    __builtin_amdgcn_wave_barrier();
-    double D[6] = {Av[0], Av[1], Av[2], Av[3], Av[4], Av[5]}, Di[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0};
-    if (act) {
-      if (edge) {
-        D[0] += hsv[0] * hsv[0]; D[1] += hsv[0] * hsv[1]; D[2] += hsv[0] * hsv[2]; D[3] += hsv[1] * hsv[1]; D[4] += hsv[1] * hsv[2]; D[5] += hsv[2] * hsv[2];
-      }
-      for (unsigned cm = children; cm; cm &= cm - 1) {
-        const int c = __ffs(cm) - 1;
-        const double h0 = L.hs[0][c], h1 = L.hs[1][c], h2 = L.hs[2][c];
-        D[0] += h0 * h0; D[1] += h0 * h1; D[2] += h0 * h2; D[3] += h1 * h1; D[4] += h1 * h2; D[5] += h2 * h2;
-      }
+    {
+      double eu, ee;
+      evaluate(x, L.xc, eu, ee);   // the last trial may have been rejected: evaluate at the result
+      relinearize(use_marg);       // A0 = block diagonal of J^T J
     }
+    double D[6] = {A0[0], A0[1], A0[2], A0[3], A0[4], A0[5]}, Di[6] = {0, 0, 0, 0, 0, 0}, u[3] = {0, 0, 0};
     for (int lv = maxlev; lv >= 1; --lv) {
       if (act && level == lv) {
-        s2_sym3_inv(D, Di);
+        s2_sym3_inv_fast(D, Di);
         s2_sym3_mul(Di, hsv, u);
         L.al[j] = hsv[0] * u[0] + hsv[1] * u[1] + hsv[2] * u[2];
       }
       __builtin_amdgcn_wave_barrier();
       if (act && level == lv - 1) {
-        for (unsigned cm = children; cm; cm &= cm - 1) {
-          const int c = __ffs(cm) - 1;
-          const double h0 = L.hs[0][c], h1 = L.hs[1][c], h2 = L.hs[2][c];
-          const double a = L.al[c];
-          D[0] -= a * h0 * h0; D[1] -= a * h0 * h1; D[2] -= a * h0 * h2; D[3] -= a * h1 * h1; D[4] -= a * h1 * h2; D[5] -= a * h2 * h2;
+        for (int q0 = 0; q0 < nbatch; q0 += 2) {
+          double c0[2], c1[2], c2[2], ca[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) { const int c = chv[q0 + q]; c0[q] = L.hs[0][c]; c1[q] = L.hs[1][c]; c2[q] = L.hs[2][c]; ca[q] = L.al[c]; }
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            if (q0 + q < nch) {
+              const double h0 = c0[q], h1 = c1[q], h2 = c2[q], a_ = ca[q];
+              D[0] -= a_ * h0 * h0; D[1] -= a_ * h0 * h1; D[2] -= a_ * h0 * h2; D[3] -= a_ * h1 * h1; D[4] -= a_ * h1 * h2; D[5] -= a_ * h2 * h2;
+            }
         }
       }
     }
     if (act && level == 0) {
-      s2_sym3_inv(D, Di);
+      s2_sym3_inv_fast(D, Di);
       for (int q = 0; q < 6; ++q) { mc[q] = Di[q]; MC[q * SE3D_NFU + j] = Di[q]; }
     }
     for (int lv = 1; lv <= maxlev; ++lv) {
@@ -1753,6 +1809,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
     __builtin_amdgcn_wave_barrier();
   }
 
+  LM_STAMP(5)  // marginals
   // ---- outputs + track-state update (PP:769-843): every lane writes the whole keypoint of its joint in both persons ----
   if (valid) {
     se3d_person3d &pf = Q.fused_det[(size_t)s * H + i];
@@ -1810,6 +1867,10 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
       Q.iters_det[(size_t)s * H + i] = iterations;
     }
   }
+  LM_STAMP(6)  // outputs
+#ifdef SE3D_LM_STAMPS
+  if (threadIdx.x == 0) atomicAdd(&g_lm_stamps[8], 1ull);
+#endif
 }
 
 // ---- single-wavefront forms of the per-sequence bookkeeping (T, H <= 64): same decisions, ballots instead of barriers ----
@@ -2081,7 +2142,7 @@ __device__ __forceinline__ void s2_track_near_flat(const Se3dStage2 &Q, int s, i
 // for launches of many sequences.  Its LM workspace, Munkres scratch and track-position table share one LDS region (the phases of
 // a single wavefront are sequential).
 template <bool TRIO, int WV, int SQ>
-__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(3, 3))) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int nseq) {
+__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 2 : 3, TRIO ? 2 : 3))) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int nseq) {
   using WaveLds = typename std::conditional<TRIO, LmTrioLds, LmTreeLds>::type;
   extern __shared__ __align__(16) unsigned char s2_walk_smem[];
   __shared__ int s_next_person;

@@ -40,5 +40,10 @@ for rep in range(2):
     L.se3d_diag_lm_stamps(out, 1)
     v = list(out)
     n = S_ * T_
+    if v[8]:
+        nt = v[8]
+        tn = ["setup", "linearize+grad", "solve", "errors/ctl", "-", "marginals", "outputs"]
+        print("  trios (thread 0's wavefront)", nt, "avg trips %.2f" % (v[9] / nt), "| cycles/trio:", {nm: round(v[i] / nt) for i, nm in enumerate(tn) if nm != "-"},
+              "| per trip:", {nm: round(v[i] / max(v[9], 1)) for i, nm in enumerate(tn) if nm in ("linearize+grad", "solve", "errors/ctl")})
     names = ["track_cost", "assoc", "lm(max of seq)", "near", "update"]
     print("walk rep", rep, "| cycles per (sequence, step):", {nm: round(v[10 + i] / n) for i, nm in enumerate(names)}, "total", round(sum(v[10:15]) / n))
