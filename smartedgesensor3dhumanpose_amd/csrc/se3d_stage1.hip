@@ -711,7 +711,11 @@ __device__ __forceinline__ double se3d_rsq64(double x) {
   return y;
 }
 
-__device__ __forceinline__ bool se3d_null_invit(const double g[10], const double v0[4], double v[4]) {
+// tol: exit once two successive unit iterates differ by less than tol (L1).  The main solves use 1e-13.  The unscented-transform
+// samples (SIGMA_TOL) are rounded to float32 and differenced against the float32 centre: the iterate returned is one contraction
+// (typically 1e-4 .. 1e-6) more accurate than the test, far below float32 resolution, and one iteration per sample is saved.
+#define SE3D_SIGMA_TOL 1e-9
+__device__ __forceinline__ bool se3d_null_invit(const double g[10], const double v0[4], double v[4], const double tol = 1e-13) {
   const double tr = g[0] + g[4] + g[7] + g[9];
   const double tiny = 1e-30 * tr;
   double d0 = g[0];
@@ -744,7 +748,7 @@ __device__ __forceinline__ bool se3d_null_invit(const double g[10], const double
     const double n0 = w0 * sgn, n1 = w1 * sgn, n2 = w2 * sgn, n3 = w3 * sgn;
     const double e = fabs(n0 - x0) + fabs(n1 - x1) + fabs(n2 - x2) + fabs(n3 - x3);
     x0 = n0; x1 = n1; x2 = n2; x3 = n3;
-    if (e < 1e-13) { conv = true; break; }
+    if (e < tol) { conv = true; break; }
   }
   v[0] = x0; v[1] = x1; v[2] = x2; v[3] = x3;
   return conv && (x0 == x0);
@@ -1049,7 +1053,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
         se3d_gram_add(g, n0); se3d_gram_add(g, n1);
       }
       double e4[4];
-      if (!se3d_null_invit(g, vstart, e4)) se3d_eig4_smallest(g, e4);
+      if (!se3d_null_invit(g, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(g, e4);
       const double iw = se3d_rcp64(e4[3]);
       const float sx = (float)(e4[0] * iw) - X, sy = (float)(e4[1] * iw) - Y, sz = (float)(e4[2] * iw) - Z;
       const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
@@ -1103,6 +1107,8 @@ struct TriHypLds {
     float rows[TH_JOINTS][TH_MAXV][8];                 // DLT rows r0, r1 (Gram phase only)
     float dev[TH_JOINTS * (4 * TH_MAXV + 1)][3];       // sigma-point deviations from the weighted solution
   } u;
+  float re[TH_JOINTS][TH_MAXV];                        // reprojection error of the weighted solution per (joint, view)
+  double vs[TH_JOINTS][4];                             // unit homogeneous start vector of the sigma-point solves
   double G[TH_JOINTS][21];                             // unweighted Gram (10), weighted Gram (10), sum of confidences
   float X[TH_JOINTS], Y[TH_JOINTS], Z[TH_JOINTS];
   int cam[TH_MAXV], det[TH_MAXV];
@@ -1191,11 +1197,22 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
     if (!se3d_null_invit(gw_, e4start, ev)) se3d_eig4_smallest(gw_, ev);
     const double iw0 = se3d_rcp64(ev[3]);
     X = (float)(ev[0] * iw0); Y = (float)(ev[1] * iw0); Z = (float)(ev[2] * iw0);
+    S.X[lane] = X; S.Y[lane] = Y; S.Z[lane] = Z;
+    const double hn = 1.0 / sqrt((double)X * X + (double)Y * Y + (double)Z * Z + 1.0);
+    S.vs[lane][0] = X * hn; S.vs[lane][1] = Y * hn; S.vs[lane][2] = Z * hn; S.vs[lane][3] = hn;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int idx = lane; idx < JN * nv; idx += 64) {  // reprojection errors: lanes over (joint, view)
+    const int j = idx / nv, v = idx - j * nv;
+    if (S.n[j] >= 2 && S.cf[j][v] >= 0.f) S.re[j][v] = se3d_reproj1(sRt + 12 * S.cam[v], S.X[j], S.Y[j], S.Z[j], S.x[j][v], S.y[j][v]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (active) {
     double se = 0.0, sc = 0.0;
-    for (int k = 0; k < nj; ++k) {
+    for (int k = 0; k < nj; ++k) {  // summed in view order like the per-joint kernel
       const int v = S.vidx[lane][k];
       const float cf = S.cf[lane][v];
-      const float e = se3d_reproj1(sRt + 12 * S.cam[v], X, Y, Z, S.x[lane][v], S.y[lane][v]);
+      const float e = S.re[lane][v];
       se += (double)(cf * e);
       sc += (double)cf;
     }
@@ -1203,7 +1220,6 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
     avg_score = (float)(S.G[lane][20] / nj);
     slow = err > REPROJ_MAX && nj >= 3;  // outlier rejection needed (S3D:748-838): per-joint routine below
     if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX / err));  // S3D:840-841
-    S.X[lane] = X; S.Y[lane] = Y; S.Z[lane] = Z;
   }
   const unsigned long long slowmask = __ballot(slow);
   // ---- sigma points of all joints, enumerated densely (S3D:471-523) ----
@@ -1225,11 +1241,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
     const float Xj = S.X[j], Yj = S.Y[j], Zj = S.Z[j];
     const int dim = 2 * n;
     const float bsc = sqrtf((float)dim + 0.5f);
-    double vstart[4];
-    {
-      const double hn = 1.0 / sqrt((double)Xj * Xj + (double)Yj * Yj + (double)Zj * Zj + 1.0);
-      vstart[0] = Xj * hn; vstart[1] = Yj * hn; vstart[2] = Zj * hn; vstart[3] = hn;
-    }
+    const double vstart[4] = {S.vs[j][0], S.vs[j][1], S.vs[j][2], S.vs[j][3]};
     double gq[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) gq[k] = S.G[j][k];
@@ -1252,7 +1264,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
       se3d_gram_add(gq, n0); se3d_gram_add(gq, n1);
     }
     double e4[4];
-    if (!se3d_null_invit(gq, vstart, e4)) se3d_eig4_smallest(gq, e4);
+    if (!se3d_null_invit(gq, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(gq, e4);
     const double iw = se3d_rcp64(e4[3]);
     S.u.dev[g][0] = (float)(e4[0] * iw) - Xj; S.u.dev[g][1] = (float)(e4[1] * iw) - Yj; S.u.dev[g][2] = (float)(e4[2] * iw) - Zj;
   }

@@ -1565,6 +1565,9 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
     for (int q = 0; q < 4; ++q) { chv[q] = cm ? __ffs(cm) - 1 : j; cm &= cm - 1; }
   }
   const int nbatch = __ballot(nch > 2) != 0ull ? 4 : 2;
+  unsigned wide_levels = 0u;  // bit l: some joint of level l has more than two children
+  for (int lv = 0; lv < maxlev; ++lv)
+    if (__ballot(measured && level == lv && nch > 2)) wide_levels |= 1u << lv;
   __builtin_amdgcn_wave_barrier();
 
   // Whitened errors of this lane's factors at xv (own joint; parent joint from X): unary part eu, parent-bone part ee.  The evaluation
@@ -1663,7 +1666,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
         }
         __builtin_amdgcn_wave_barrier();
         if (act && level == lv - 1) {
-          for (int q0 = 0; q0 < nbatch; q0 += 2) {
+          for (int q0 = 0; q0 < (((wide_levels >> (lv - 1)) & 1u) ? 4 : 2); q0 += 2) {
             double c0[2], c1[2], c2[2], ca[2], cb[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) { const int c = chv[q0 + q]; c0[q] = L.hs[0][c]; c1[q] = L.hs[1][c]; c2[q] = L.hs[2][c]; ca[q] = L.al[c]; cb[q] = L.be[c]; }
@@ -1777,7 +1780,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
       }
       __builtin_amdgcn_wave_barrier();
       if (act && level == lv - 1) {
-        for (int q0 = 0; q0 < nbatch; q0 += 2) {
+        for (int q0 = 0; q0 < (((wide_levels >> (lv - 1)) & 1u) ? 4 : 2); q0 += 2) {
           double c0[2], c1[2], c2[2], ca[2];
 #pragma unroll
           for (int q = 0; q < 2; ++q) { const int c = chv[q0 + q]; c0[q] = L.hs[0][c]; c1[q] = L.hs[1][c]; c2[q] = L.hs[2][c]; ca[q] = L.al[c]; }
