@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic (make -C .../csrc diag): wall time of the fused stage-2 walk at 16cam6p with parts of the LM switched off, to attribute
-the walk time without in-kernel stamps (which perturb memory phases).  Results with ablation bits set are wrong by construction."""
+the walk time without in-kernel stamps (which perturb memory phases).  Results with ablation bits set are wrong by construction.
+The switches live in the one-person-per-wavefront LM (s2_lm_body), so the tool runs the walk with SE3D_WALK_LM=solo."""
 import ctypes as C, os, sys, time
+os.environ["SE3D_WALK_LM"] = "solo"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from smartedgesensor3dhumanpose_amd import _lib
