@@ -62,9 +62,10 @@ REFINE_TOL_M = 1e-3     # refined joints: < 1 mm vs the CPU restatement (same GT
 MARG_COV_RTOL = 1e-4    # marginal covariances are fp64 on both sides
 
 
-def compare_stage2(gpu, ora, check_iters=True):
-    """gpu/ora: FusedResult of one pose_prior callback."""
-    assert gpu.c.n_tracks == ora.c.n_tracks, (gpu.c.n_tracks, ora.c.n_tracks)
+def compare_stage2(gpu, ora, check_iters=True, check_tracks=True):
+    """gpu/ora: FusedResult of one pose_prior callback.  check_tracks=False for results fetched after a fused multi-step walk: the
+    track count is sequence state (what it is after the last step of the walk), not a per-step output."""
+    assert not check_tracks or gpu.c.n_tracks == ora.c.n_tracks, (gpu.c.n_tracks, ora.c.n_tracks)
     assert gpu.n_persons == ora.n_persons, (gpu.n_persons, ora.n_persons)
     assert abs(gpu.c.pred_delta_t - ora.c.pred_delta_t) < 1e-7
     n = gpu.n_persons
