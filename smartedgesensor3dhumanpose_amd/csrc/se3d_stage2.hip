@@ -1411,7 +1411,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
   const int g3 = lane / SE3D_NFU;
   const int g = g3 > 2 ? 2 : g3, j = lane - SE3D_NFU * g3, gb = SE3D_NFU * g;   // lane 63: no group
   LmTrioGroup &L = W.g[g];
-  have = have && g3 < 3 && i < min(Q.n_det[have ? s : 0], H);
+  have = have && g3 < 3;   // the caller hands out detections i < min(n_det, H) only
   const int slot = have ? Q.det_slot[(size_t)s * H + i] : -1;
   have = have && slot >= 0;
   const size_t sl = have ? (size_t)s * T + slot : 0;
@@ -1421,26 +1421,42 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
   const unsigned gmask = 0x1FFFFFu;
   LM_STAMP_INIT
 
-  // ---- root / neck / height (PP:631-668), identical on every lane of the group ----
+  // ---- root / neck / height (PP:631-668), identical on every lane of the group; measurements: lane 21 g + k <-> fusion joint k
+  // of person g (PP:690-737).  Everything the branches below may need is fetched up front (one memory round trip): the four
+  // keypoints root and neck derive from, this lane's own keypoint, the track's previous height / root.
   double root[3] = {0, 0, 0}, neck[3] = {0, 0, 0};
   float root_score = 0.f, neck_score = 0.f;
   double height = 1.0, hprev = 1.0, rprev[3] = {0, 0, 0};
-  bool has_root = false;
+  bool has_root = false, measured = false;
+  double m[3] = {0, 0, 0}, cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xprev[3] = {0, 0, 0};
+  float kscore = 0.f;
   if (have) {
+    const int ia = simple ? FU_LHip : FU_MidHip, ib = simple ? FU_RHip : FU_MidHip, ic = simple ? FU_LShoulder : FU_Neck, id = simple ? FU_RShoulder : FU_Neck;
+    const se3d_keypoint3d &ka = person.keypoints[ia], &kb = person.keypoints[ib], &kc = person.keypoints[ic], &kd = person.keypoints[id];
+    const se3d_keypoint3d &kown = person.keypoints[j];
+    double ja[3], jb[3], jc[3], jd[3], jo[3], ca6[6], cb6[6], co6[6];
+    for (int a = 0; a < 3; ++a) { ja[a] = ka.joint[a]; jb[a] = kb.joint[a]; jc[a] = kc.joint[a]; jd[a] = kd.joint[a]; jo[a] = kown.joint[a]; }
+    const float sa = ka.score, sb = kb.score, sc = kc.score, sd = kd.score, so = kown.score;
+    // covariances: own keypoint; MidHip lane: of the two hips (simple) / own; Neck lane (simple): of the two shoulders
+    const bool hip_lane = j == FU_MidHip, neck_lane = simple && j == FU_Neck;
+    const se3d_keypoint3d &kca = hip_lane ? ka : kc, &kcb = hip_lane ? kb : kd;
+    for (int q = 0; q < 6; ++q) { co6[q] = kown.cov[q]; ca6[q] = kca.cov[q]; cb6[q] = kcb.cov[q]; }
+    const double hp_old = Q.height_prev[sl];
+    double rp_old[3];
+    for (int a = 0; a < 3; ++a) { rp_old[a] = Q.root_prev[sl * 3 + a]; xprev[a] = Q.prev[(sl * SE3D_NFU + j) * 3 + a]; }
+
     if (!simple) {
-      for (int a = 0; a < 3; ++a) { root[a] = person.keypoints[FU_MidHip].joint[a]; neck[a] = person.keypoints[FU_Neck].joint[a]; }
-      root_score = person.keypoints[FU_MidHip].score;
-      neck_score = person.keypoints[FU_Neck].score;
+      for (int a = 0; a < 3; ++a) { root[a] = ja[a]; neck[a] = jc[a]; }
+      root_score = sa;
+      neck_score = sc;
     } else {
-      const se3d_keypoint3d &hl = person.keypoints[FU_LHip], &hr = person.keypoints[FU_RHip];
-      if (hl.score > 0.0f && hr.score > 0.0f) {
-        for (int a = 0; a < 3; ++a) root[a] = (hl.joint[a] + hr.joint[a]) / 2.0;
-        root_score = (hl.score + hr.score) / 2.0f;
+      if (sa > 0.0f && sb > 0.0f) {
+        for (int a = 0; a < 3; ++a) root[a] = (ja[a] + jb[a]) / 2.0;
+        root_score = (sa + sb) / 2.0f;
       }
-      const se3d_keypoint3d &sL = person.keypoints[FU_LShoulder], &sR = person.keypoints[FU_RShoulder];
-      if (sL.score > 0.0f && sR.score > 0.0f) {
-        for (int a = 0; a < 3; ++a) neck[a] = (sL.joint[a] + sR.joint[a]) / 2.0;
-        neck_score = (sL.score + sR.score) / 2.0f;
+      if (sc > 0.0f && sd > 0.0f) {
+        for (int a = 0; a < 3; ++a) neck[a] = (jc[a] + jd[a]) / 2.0;
+        neck_score = (sc + sd) / 2.0f;
       }
     }
     has_root = root_score > 0.10f;
@@ -1450,50 +1466,39 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
         height = sqrt(dx * dx + dy * dy + dz * dz);
       } else height = 0.60;
     }
-    const double hp_old = Q.height_prev[sl];
     const bool first = hp_old < 0.0;  // PP:699-702
     hprev = first ? height : hp_old;
-    for (int a = 0; a < 3; ++a) rprev[a] = first ? root[a] : Q.root_prev[sl * 3 + a];
+    for (int a = 0; a < 3; ++a) rprev[a] = first ? root[a] : rp_old[a];
     if (first && j == 0) { Q.height_prev[sl] = height; for (int a = 0; a < 3; ++a) Q.root_prev[sl * 3 + a] = root[a]; }
-  }
 
-  // ---- measurements: lane 21 g + k <-> fusion joint k of person g (PP:690-737) ----
-  bool measured = false;
-  double m[3] = {0, 0, 0}, cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  float kscore = 0.f;
-  if (have) {
-    const int k = j;
-    if (k == FU_MidHip) {
+    if (hip_lane) {
       if (has_root) {
         measured = true;
-        if (!simple) s2_cov6_to_mat(person.keypoints[FU_MidHip].cov, cov);
+        if (!simple) s2_cov6_to_mat(co6, cov);
         else {
           double cl[9], cr[9];
-          s2_cov6_to_mat(person.keypoints[FU_LHip].cov, cl);
-          s2_cov6_to_mat(person.keypoints[FU_RHip].cov, cr);
+          s2_cov6_to_mat(ca6, cl);
+          s2_cov6_to_mat(cb6, cr);
           for (int q = 0; q < 9; ++q) cov[q] = (cl[q] + cr[q]) / 2.0;
         }
         for (int q = 0; q < 9; ++q) cov[q] = cov[q] / (height * height) / (100.0 * 100.0);
         kscore = root_score;
       }
-    } else if (simple && k == FU_Neck && neck_score > 0.10f) {
+    } else if (neck_lane && neck_score > 0.10f) {
       measured = true;
       double cl[9], cr[9];
-      s2_cov6_to_mat(person.keypoints[FU_LShoulder].cov, cl);
-      s2_cov6_to_mat(person.keypoints[FU_RShoulder].cov, cr);
+      s2_cov6_to_mat(ca6, cl);
+      s2_cov6_to_mat(cb6, cr);
       for (int q = 0; q < 9; ++q) cov[q] = (cl[q] + cr[q]) / 2.0 / (height * height);
       for (int a = 0; a < 3; ++a) m[a] = (neck[a] - root[a]) / height;
       kscore = neck_score;
-    } else {
-      const se3d_keypoint3d &kp = person.keypoints[k];
-      if (kp.score > 0.10f) {
-        measured = true;
-        double c9[9];
-        s2_cov6_to_mat(kp.cov, c9);
-        for (int q = 0; q < 9; ++q) cov[q] = c9[q] / (height * height);
-        for (int a = 0; a < 3; ++a) m[a] = (kp.joint[a] - root[a]) / height;
-        kscore = kp.score;
-      }
+    } else if (so > 0.10f) {
+      measured = true;
+      double c9[9];
+      s2_cov6_to_mat(co6, c9);
+      for (int q = 0; q < 9; ++q) cov[q] = c9[q] / (height * height);
+      for (int a = 0; a < 3; ++a) m[a] = (jo[a] - root[a]) / height;
+      kscore = so;
     }
   }
   const uint32_t measmask = (uint32_t)(__ballot(measured) >> gb) & gmask;
@@ -1507,7 +1512,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
     wok = s2_make_whitener(cov, R9);
     R[0] = R9[0]; R[1] = R9[1]; R[2] = R9[2]; R[3] = R9[4]; R[4] = R9[5]; R[5] = R9[8];
     for (int a = 0; a < 3; ++a) {
-      x0[a] = use_vel ? Q.prev[(sl * SE3D_NFU + j) * 3 + a] : m[a];  // setInitialState (PP:483-503)
+      x0[a] = use_vel ? xprev[a] : m[a];  // setInitialState (PP:483-503)
       x[a] = x0[a];
       L.xc[a][j] = x[a];
     }
@@ -1975,14 +1980,25 @@ __device__ __forceinline__ void s2_track_update_wave(const Se3dStage2 &Q, int s,
   const bool pb = (lane < nd) && Q.pub[(size_t)s * H + lane];
   const unsigned long long pbm = __ballot(pb);
   const int n_out = __popcll(pbm);
-  const int words = (int)(sizeof(se3d_person3d) / 4);
+  static_assert(sizeof(se3d_person3d) % 8 == 0 && sizeof(se3d_person3d) / 8 <= 4 * 64, "person copy below: four 8-byte words per lane");
+  constexpr int words = (int)(sizeof(se3d_person3d) / 8);
   int p = 0;
   for (unsigned long long m = pbm; m; m &= m - 1ull, ++p) {  // publish in detection order
     const int srcd = __ffsll((long long)m) - 1;
     const size_t src = (size_t)s * H + srcd, dst = (size_t)s * H + p;
-    const uint32_t *f0 = reinterpret_cast<const uint32_t *>(&Q.fused_det[src]), *p0 = reinterpret_cast<const uint32_t *>(&Q.pred_det[src]);
-    uint32_t *f1 = reinterpret_cast<uint32_t *>(&Q.fused[dst]), *p1 = reinterpret_cast<uint32_t *>(&Q.pred[dst]);
-    for (int w = lane; w < words; w += 64) { f1[w] = f0[w]; p1[w] = p0[w]; }
+    const uint2 *__restrict__ f0 = reinterpret_cast<const uint2 *>(&Q.fused_det[src]), *__restrict__ p0 = reinterpret_cast<const uint2 *>(&Q.pred_det[src]);
+    uint2 *__restrict__ f1 = reinterpret_cast<uint2 *>(&Q.fused[dst]), *__restrict__ p1 = reinterpret_cast<uint2 *>(&Q.pred[dst]);
+    uint2 a[4], b[4];   // all loads of a person in flight before the first store (one memory round trip per person, not one per word)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int w = lane + 64 * q;
+      if (w < words) { a[q] = f0[w]; b[q] = p0[w]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int w = lane + 64 * q;
+      if (w < words) { f1[w] = a[q]; p1[w] = b[q]; }
+    }
     if (lane == 0) Q.iters[dst] = Q.iters_det[src];
   }
   s2_remove_old_wave(Q, s, t, lane);
@@ -2045,12 +2061,23 @@ __device__ __forceinline__ void s2_track_cost_lds(const Se3dStage2 &Q, int s, in
     const double *pp = tpos + (size_t)slot * SE3D_NFU * 3;
     int nj = 0;
     double dist = 0.0;
-    for (int k = 0; k < SE3D_NFU; ++k) {
-      const se3d_keypoint3d &kp = dets[det].keypoints[k];
-      if (kp.score > 0.10f && ((has >> k) & 1u)) {
-        const double dx = kp.joint[0] - pp[3 * k], dy = kp.joint[1] - pp[3 * k + 1], dz = kp.joint[2] - pp[3 * k + 2];
-        dist += sqrt(dx * dx + dy * dy + dz * dz) / (c_vel_sigmas[k] * delta_t);
-        ++nj;
+    static_assert(SE3D_NFU % 7 == 0, "joints are fetched seven at a time");
+    for (int k0 = 0; k0 < SE3D_NFU; k0 += 7) {  // seven keypoints in flight per memory round trip (a load per joint behind its own test: 21 trips)
+      double jx[7], jy[7], jz[7];
+      float sc[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const se3d_keypoint3d &kp = dets[det].keypoints[k0 + q];
+        jx[q] = kp.joint[0]; jy[q] = kp.joint[1]; jz[q] = kp.joint[2]; sc[q] = kp.score;
+      }
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const int k = k0 + q;
+        if (sc[q] > 0.10f && ((has >> k) & 1u)) {
+          const double dx = jx[q] - pp[3 * k], dy = jy[q] - pp[3 * k + 1], dz = jz[q] - pp[3 * k + 2];
+          dist += sqrt(dx * dx + dy * dy + dz * dz) / (c_vel_sigmas[k] * delta_t);
+          ++nj;
+        }
       }
     }
     C[det + (size_t)nd * tk] = nj > 0 ? dist / nj : 1e6;
