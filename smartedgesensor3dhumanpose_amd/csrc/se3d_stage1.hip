@@ -1099,14 +1099,11 @@ __global__ __launch_bounds__(256, 3) void se3d_k_triangulate(Se3dDev D) {
 // =============================================================================================================
 #define TH_MAXV 16
 #define TH_JOINTS 9   // joints per workgroup: a hypothesis is split into two one-wavefront workgroups (9 + 8 joints) of 13 KB LDS each,
-                      // so that four of them fit beside two resident stage-2 walk workgroups of another context
+                      // of ~7 KB LDS each
 struct TriHypLds {
   float x[TH_JOINTS][TH_MAXV], y[TH_JOINTS][TH_MAXV], cf[TH_JOINTS][TH_MAXV];  // normalised point and confidence per (joint, attached view); cf < 0: unusable
   float ca[TH_JOINTS][TH_MAXV], cb[TH_JOINTS][TH_MAXV], cc[TH_JOINTS][TH_MAXV];  // Cholesky factor of the 2x2 keypoint covariance
-  union {
-    float rows[TH_JOINTS][TH_MAXV][8];                 // DLT rows r0, r1 (Gram phase only)
-    float dev[TH_JOINTS * (4 * TH_MAXV + 1)][3];       // sigma-point deviations from the weighted solution
-  } u;
+  float rows[TH_JOINTS][TH_MAXV][8];                   // DLT rows r0, r1 of every (joint, view); at the very end: 64 x 6 partial covariance sums
   float re[TH_JOINTS][TH_MAXV];                        // reprojection error of the weighted solution per (joint, view)
   double vs[TH_JOINTS][4];                             // unit homogeneous start vector of the sigma-point solves
   double G[TH_JOINTS][21];                             // unweighted Gram (10), weighted Gram (10), sum of confidences
@@ -1151,7 +1148,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
       float r0[4], r1[4];
       se3d_dlt_rows(sRt + 12 * S.cam[v], kp.x, kp.y, r0, r1);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { S.u.rows[j][v][k] = r0[k]; S.u.rows[j][v][4 + k] = r1[k]; }
+      for (int k = 0; k < 4; ++k) { S.rows[j][v][k] = r0[k]; S.rows[j][v][4 + k] = r1[k]; }
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -1175,7 +1172,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
         const int v = S.vidx[j][k];
         const float cf = S.cf[j][v];
         if (e == 20) { acc += (double)cf; continue; }
-        float a0 = S.u.rows[j][v][gi], b0 = S.u.rows[j][v][gj], a1 = S.u.rows[j][v][4 + gi], b1 = S.u.rows[j][v][4 + gj];
+        float a0 = S.rows[j][v][gi], b0 = S.rows[j][v][gj], a1 = S.rows[j][v][4 + gi], b1 = S.rows[j][v][4 + gj];
         if (weighted) { a0 = a0 * cf; b0 = b0 * cf; a1 = a1 * cf; b1 = b1 * cf; }
         acc = __builtin_fma((double)a0, (double)b0, acc);
         acc = __builtin_fma((double)a1, (double)b1, acc);
@@ -1222,69 +1219,64 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
     if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX / err));  // S3D:840-841
   }
   const unsigned long long slowmask = __ballot(slow);
-  // ---- sigma points of all joints, enumerated densely (S3D:471-523) ----
-  int cnt = (active && !slow) ? 4 * nj + 1 : 0, incl = cnt;
-#pragma unroll
-  for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-  const int off = incl - cnt;
-  const int total = __builtin_amdgcn_readlane(incl, TH_JOINTS - 1);
-  __builtin_amdgcn_wave_barrier();
-  for (int g = lane; g < total; g += 64) {
-    int j = 0, offj = 0;
-#pragma unroll
-    for (int jj = 1; jj < TH_JOINTS; ++jj) {
-      const int oj = __builtin_amdgcn_readlane(off, jj);
-      if (g >= oj) { j = jj; offj = oj; }   // joints without samples share the offset of the next one: the last match wins
-    }
-    const int s = g - offj;
-    const int n = S.n[j];
-    const float Xj = S.X[j], Yj = S.Y[j], Zj = S.Z[j];
-    const int dim = 2 * n;
-    const float bsc = sqrtf((float)dim + 0.5f);
-    const double vstart[4] = {S.vs[j][0], S.vs[j][1], S.vs[j][2], S.vs[j][3]};
-    double gq[10];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) gq[k] = S.G[j][k];
-    if (s > 0) {
-      const int c = (s - 1) >> 2, t = (s - 1) & 3;
-      const int v = S.vidx[j][c];
-      const float l11 = S.ca[j][v], l21 = S.cb[j][v], l22 = S.cc[j][v];
-      const float dx1 = l11 * bsc, dy1 = l21 * bsc, dy2 = l22 * bsc;
-      const float x0 = S.x[j][v], y0 = S.y[j][v];
-      float px = x0, py = y0;
-      if (t == 0) { px -= dx1; py -= dy1; }
-      else if (t == 1) { py -= dy2; }
-      else if (t == 2) { px += dx1; py += dy1; }
-      else { py += dy2; }
-      float o0[4], o1[4], n0[4], n1[4];
-      const float *M = sRt + 12 * S.cam[v];
-      se3d_dlt_rows(M, x0, y0, o0, o1);   // the rows buffer is reused for the deviations: rebuild the view's own rows
-      se3d_dlt_rows(M, px, py, n0, n1);
-      se3d_gram_add<true>(gq, o0); se3d_gram_add<true>(gq, o1);
-      se3d_gram_add(gq, n0); se3d_gram_add(gq, n1);
-    }
-    double e4[4];
-    if (!se3d_null_invit(gq, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(gq, e4);
-    const double iw = se3d_rcp64(e4[3]);
-    S.u.dev[g][0] = (float)(e4[0] * iw) - Xj; S.u.dev[g][1] = (float)(e4[1] * iw) - Yj; S.u.dev[g][2] = (float)(e4[2] * iw) - Zj;
-  }
-  __builtin_amdgcn_wave_barrier();
-  // ---- covariance: lanes over (joint, entry) ----
+  // ---- sigma points (S3D:471-523): lanes are tied to joints (64 / JN lanes each) and stride over the joint's 4n + 1 samples, so the
+  // joint's Gram matrix, start vector and centre stay in registers and the weighted outer products of the deviations are
+  // accumulated in registers as the samples are solved (no sample buffer: 7 KB of LDS less, the DLT rows of the views stay
+  // resident instead of being rebuilt for every sample); the partial sums of a joint's lanes are added in lane order.
+  const int cnt = (active && !slow) ? 4 * nj + 1 : 0;
   se3d_person3d &person = D.hypP[(size_t)f * H + h];
   const int pm_ = D.d.pose_method;
-  for (int it = lane; it < JN * 6; it += 64) {
-    const int j = it / 6, e = it - j * 6;
+  {
+    const int LPJ = 64 / JN;                       // 7 lanes per joint (9 joints) or 8 (8 joints)
+    const int jl = lane / LPJ, j = min(jl, JN - 1), s0 = lane - LPJ * jl;
+    const int cntj = jl < JN ? __shfl(cnt, j) : 0;
     const int n = S.n[j];
-    const int offj = __shfl(off, j), cntj = __shfl(cnt, j);
-    if (cntj == 0) continue;
+    const float Xj = S.X[j], Yj = S.Y[j], Zj = S.Z[j];
+    const float bsc = sqrtf((float)(2 * n) + 0.5f);
     const float wgt = 1.0f / (2.0f * ((float)(2 * n) + 0.5f));  // all weights equal because 2*kappa == 1
-    const int ea = e < 3 ? 0 : (e < 5 ? 1 : 2), eb = e < 3 ? e : (e < 5 ? e - 2 : 2);
-    double acc = 0.0;
-    for (int q = 0; q < cntj; ++q) {
-      const float da = S.u.dev[offj + q][ea], db = S.u.dev[offj + q][eb];
-      acc += (double)(da * wgt) * db;
+    const double vstart[4] = {S.vs[j][0], S.vs[j][1], S.vs[j][2], S.vs[j][3]};
+    double cv[6] = {0, 0, 0, 0, 0, 0};
+    for (int s = s0; s < cntj; s += LPJ) {
+      double gq[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) gq[k] = S.G[j][k];
+      if (s > 0) {
+        const int c = (s - 1) >> 2, t = (s - 1) & 3;
+        const int v = S.vidx[j][c];
+        const float l11 = S.ca[j][v], l21 = S.cb[j][v], l22 = S.cc[j][v];
+        const float dx1 = l11 * bsc, dy1 = l21 * bsc, dy2 = l22 * bsc;
+        float px = S.x[j][v], py = S.y[j][v];
+        if (t == 0) { px -= dx1; py -= dy1; }
+        else if (t == 1) { py -= dy2; }
+        else if (t == 2) { px += dx1; py += dy1; }
+        else { py += dy2; }
+        float o0[4], o1[4], n0[4], n1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o0[k] = S.rows[j][v][k]; o1[k] = S.rows[j][v][4 + k]; }
+        se3d_dlt_rows(sRt + 12 * S.cam[v], px, py, n0, n1);
+        se3d_gram_add<true>(gq, o0); se3d_gram_add<true>(gq, o1);
+        se3d_gram_add(gq, n0); se3d_gram_add(gq, n1);
+      }
+      double e4[4];
+      if (!se3d_null_invit(gq, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(gq, e4);
+      const double iw = se3d_rcp64(e4[3]);
+      const float sx = (float)(e4[0] * iw) - Xj, sy = (float)(e4[1] * iw) - Yj, sz = (float)(e4[2] * iw) - Zj;
+      const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
+      cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
     }
-    person.keypoints[c_kp2fusion[pm_][jbase + j]].cov[e] = (double)(float)acc;
+    __builtin_amdgcn_wave_barrier();   // all samples done: the rows are dead, their LDS takes the partial sums
+    static_assert(sizeof(S.rows) >= 64 * 6 * sizeof(double) && offsetof(TriHypLds, rows) % 8 == 0, "partial sums alias the rows");
+    double (*part)[6] = reinterpret_cast<double (*)[6]>(&S.rows[0][0][0]);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) part[lane][e] = cv[e];
+    __builtin_amdgcn_wave_barrier();
+    for (int it = lane; it < JN * 6; it += 64) {
+      const int jj = it / 6, e = it - jj * 6;
+      if (__shfl(cnt, jj) == 0) continue;
+      double acc = 0.0;
+      for (int q = 0; q < LPJ; ++q) acc += part[jj * LPJ + q][e];
+      person.keypoints[c_kp2fusion[pm_][jbase + jj]].cov[e] = (double)(float)acc;
+    }
   }
   if (active && !slow) {
     se3d_keypoint3d *kp = &person.keypoints[c_kp2fusion[pm_][jbase + lane]];
