@@ -1235,11 +1235,13 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
     const float bsc = sqrtf((float)(2 * n) + 0.5f);
     const float wgt = 1.0f / (2.0f * ((float)(2 * n) + 0.5f));  // all weights equal because 2*kappa == 1
     const double vstart[4] = {S.vs[j][0], S.vs[j][1], S.vs[j][2], S.vs[j][3]};
-    double cv[6] = {0, 0, 0, 0, 0, 0};
+    double gj[10], cv[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 10; ++k) gj[k] = S.G[j][k];
     for (int s = s0; s < cntj; s += LPJ) {
       double gq[10];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) gq[k] = S.G[j][k];
+      for (int k = 0; k < 10; ++k) gq[k] = gj[k];
       if (s > 0) {
         const int c = (s - 1) >> 2, t = (s - 1) & 3;
         const int v = S.vidx[j][c];
