@@ -210,6 +210,48 @@ def test_stage2_walk_equals_per_step_and_oracle(extr_rig, oracle, demo_params, m
         nd.close()
 
 
+@pytest.mark.parametrize("pose,nh", [("simple", True), ("h36m", False), ("h36m", True)])
+def test_stage2_walk_norm_height_and_h36m(extr_rig, oracle, monkeypatch, pose, nh):
+    """The fused walk (three persons per LM wavefront, both kernel shapes) with height normalisation and with the H36M joint set,
+    where the belly is measured and the bone forest is rooted there: against the per-step kernels and the oracle."""
+    params = pm.Params(pm.POSE_H36M if pose == "h36m" else pm.POSE_SIMPLE, int(nh), 0.045)
+    S_, T_, mh = 3, 14, 8
+    seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=4 - (s % 2), n_frames=T_, seed=900 + s))[0] for s in range(S_)]
+    frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
+    nodes = {name: _node(extr_rig, pose_method=pose, norm_height=nh, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=mh) for name in ("wg", "wave", "steps")}
+    for nd in nodes.values():
+        nd.stage(frames)
+        nd.run_stage1()
+        nd.refine_reset()
+    b = nodes["steps"]
+    r1 = b.fetch_stage1(S_ * T_)
+    ts = [100.0 + (i + 1) / 30.0 for i in range(T_)]
+    for name in ("wg", "wave"):
+        monkeypatch.setenv("SE3D_WALK_SHAPE", name)
+        nodes[name].run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in range(T_)])
+        nodes[name].sync()
+    oras = [oracle.PosePrior(params) for _ in range(S_)]
+    total = 0
+    for k, t in enumerate(ts):
+        b.run_stage2(np.full(S_, t), frame_slot0=k * S_)
+        rb = b.fetch_stage2(S_)
+        ra = {name: nodes[name].fetch_stage2_walk(k * S_, S_) for name in ("wg", "wave")}
+        for s in range(S_):
+            n = rb[s].n_persons
+            o = oras[s].step(r1[k * S_ + s].published(), 16, t, seqs[s][k].fb_delay, capacity=mh)
+            for name in ("wg", "wave"):
+                assert ra[name][s].n_persons == n
+                assert np.array_equal(ra[name][s].lm_iterations[:n], rb[s].lm_iterations[:n])
+                _close_persons(ra[name][s].fused, rb[s].fused, n)
+                _close_persons(ra[name][s].fused_pred, rb[s].fused_pred, n)
+                compare_stage2(ra[name][s], o, check_tracks=k == T_ - 1)
+            assert ra["wg"][s].fused[:n].tobytes() == ra["wave"][s].fused[:n].tobytes()
+            total += n
+    assert total > 0
+    for nd in nodes.values():
+        nd.close()
+
+
 def test_stage2_walk_device_pack(extr_rig, device_buffer):
     from smartedgesensor3dhumanpose_amd import shard
     S_, T_, H = 4, 12, 8
