@@ -110,12 +110,22 @@ __device__ __forceinline__ void s2_track_cost_body(const Se3dStage2 &Q, int tk, 
   for (int det = tid; det < nd; det += nthr) {
     int nj = 0;
     double dist = 0.0;
-    for (int k = 0; k < SE3D_NFU; ++k) {
-      const se3d_keypoint3d &kp = dets[det].keypoints[k];
-      if (kp.score > 0.10f && ((has >> k) & 1u)) {
-        const double dx = kp.joint[0] - pp[k][0], dy = kp.joint[1] - pp[k][1], dz = kp.joint[2] - pp[k][2];
-        dist += sqrt(dx * dx + dy * dy + dz * dz) / wgt[k];
-        ++nj;
+    for (int k0 = 0; k0 < SE3D_NFU; k0 += 7) {  // seven keypoints in flight per memory round trip (a load per joint behind its own test: 21 trips)
+      double jx[7], jy[7], jz[7];
+      float sc[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const se3d_keypoint3d &kp = dets[det].keypoints[k0 + q];
+        jx[q] = kp.joint[0]; jy[q] = kp.joint[1]; jz[q] = kp.joint[2]; sc[q] = kp.score;
+      }
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const int k = k0 + q;
+        if (sc[q] > 0.10f && ((has >> k) & 1u)) {
+          const double dx = jx[q] - pp[k][0], dy = jy[q] - pp[k][1], dz = jz[q] - pp[k][2];
+          dist += sqrt(dx * dx + dy * dy + dz * dz) / wgt[k];
+          ++nj;
+        }
       }
     }
     C[det + (size_t)nd * tk] = nj > 0 ? dist / nj : 1e6;
@@ -213,8 +223,15 @@ __device__ __forceinline__ void s2_track_assoc_body(const Se3dStage2 &Q, int s, 
   else { for (int idx = tid; idx < nd * nt; idx += 256) Wg[idx] = C[idx]; }
   __syncthreads();
   if (nt > 0) {
-    int rc;
-    if (w_in_lds) rc = se3d_munkres_block(s2_dynW, nd, nd, nt, MS, assign);
+    int rc = 0;
+    if (w_in_lds && nd <= 64 && nt <= 64) {  // actual problem fits one wavefront (whatever the capacities H, T): register-resident Munkres
+      if (tid < 64) {
+        int a = -1;
+        rc = se3d_munkres_wave(s2_dynW, nd, nd, nt, tid, a);
+        if (tid < nd) assign[tid] = a;
+      }
+      __syncthreads();
+    } else if (w_in_lds) rc = se3d_munkres_block(s2_dynW, nd, nd, nt, MS, assign);
     else rc = se3d_munkres_block(Wg, nd, nd, nt, MS, assign);
     if (rc != 0 && tid == 0) atomicOr(&Q.flags2[s], 4u);
     if (tid < nd) {  // PP:562-565
