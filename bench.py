@@ -114,9 +114,10 @@ def main():
     stage2 = args.stage == "12"
     rig = make_rig(w)
     NC = args.contexts or w["contexts"]
+    seed_rank = int(os.environ.get("SE3D_BENCH_SEED_RANK", rank))  # diagnostic: run another rank's synthetic scenes on this GPU (tools/check_rank_scenes.sh)
     nodes, all_seqs = [], []
     for ci in range(NC):  # every rank (and every context) owns its own sequences: weak scaling, no data-path collective
-        seqs = make_sequences(rig, w, S_, seed0=1000 * rank + 100 * ci, t_steps=T_)
+        seqs = make_sequences(rig, w, S_, seed0=1000 * seed_rank + 100 * ci, t_steps=T_)
         frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s
         nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank)
         nd_.stage(frames)  # inputs resident in HBM before the timed region
@@ -197,6 +198,7 @@ def main():
             if collect is not None:
                 per_frame = [r.n_persons for k in ks for r in nd_.fetch_stage2_walk(k * S_, S_)]
                 assert dist is None or max(per_frame) <= XH, "exchange slots per frame too small: skeletons would be truncated"
+                max_pub[0] = max(max_pub[0], max(per_frame))
                 collect.append(sum(per_frame))
         else:
             pk, cn = pack_target(ci) if dist is not None else (None, None)
@@ -209,6 +211,7 @@ def main():
             if dist is not None:
                 packed(ci)
 
+    max_pub = [0]   # most skeletons any frame published (accounting pass): the exchange carries n_persons + 2 slots per frame
     def step(collect=None):
         if not stage2:
             for wk in walks:
@@ -289,6 +292,7 @@ def main():
                                    % (args.workload, "1+2 (association+triangulation+UT covariance, then tracking+LM refinement+marginals)" if stage2 else "1",
                                       NC, S_, T_, NC * B, n_skel_local, n_s1),
                        "n_cam": w["n_cam"], "n_persons": w["n_persons"], "n_joints": 17, "frames_per_step": NC * B, "contexts_per_gpu": NC,
+                       "max_hypotheses_per_frame": int(max(r.n_hyp for r in s1)), "max_published_per_frame": int(max_pub[0]),
                        "sharding": ("independent sequences per rank + RCCL all-gather of final skeletons" if world > 1 else "single GPU")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "avg_launch_ms": round(ms_dom, 5),
