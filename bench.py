@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 T_STEPS = 16  # frames per synthetic sequence (>= 16 frames per sequence)
 WORKLOADS = {
     # bytes/skeleton: SURVEY §8d algorithmic bytes (stage 1) ; stage 2 adds 8.9 KB per skeleton
-    "16cam6p": dict(n_cam=16, n_persons=6, seqs=256, contexts=12, max_det=8, max_hyp=12, bytes_s1=8972, bytes_s2=8900),
+    "16cam6p": dict(n_cam=16, n_persons=6, seqs=512, contexts=12, max_det=8, max_hyp=12, bytes_s1=8972, bytes_s2=8900),
     "64cam32p": dict(n_cam=64, n_persons=32, seqs=32, contexts=3, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900),
     "256cam128p": dict(n_cam=256, n_persons=128, seqs=1, contexts=3, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900),
 }
