@@ -2205,7 +2205,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
   // Per-track state of the sequences lives in LDS for the duration of the walk when it fits (Wk.lds_state): every phase touches it
   // through the same Se3dStage2 pointers (generic pointers), at LDS instead of HBM/L2 latency.
   Se3dStage2 Qs = Q;
-  double *l_root = nullptr, *l_height = nullptr, *l_tprev = nullptr;
+  double *l_root = nullptr, *l_height = nullptr, *l_tprev = nullptr, *l_prev = nullptr;
   uint32_t *l_has = nullptr;
   int32_t *l_id = nullptr, *l_nobs = nullptr;
   uint8_t *l_used = nullptr;
@@ -2221,6 +2221,10 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
     l_id = reinterpret_cast<int32_t *>(l_has + TT);
     l_nobs = l_id + TT;
     l_used = reinterpret_cast<uint8_t *>(l_nobs + TT);
+    if (Wk.lds_state & 2) {  // the normalised previous poses too (T x 63 doubles per sequence), behind the small state (8-byte aligned)
+      l_prev = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(b) + (((size_t)TT * 16 + 7) & ~(size_t)7));
+      for (int i = tid; i < tn * SE3D_NFU * 3; i += NT) l_prev[i] = Q.prev[g0 * SE3D_NFU * 3 + i];
+    }
     for (int i = tid; i < tn * 3; i += NT) l_root[i] = Q.root_prev[g0 * 3 + i];
     for (int i = tid; i < tn; i += NT) {
       l_height[i] = Q.height_prev[g0 + i]; l_tprev[i] = Q.trk_t_prev[g0 + i]; l_has[i] = Q.has[g0 + i];
@@ -2236,7 +2240,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
   // every per-sequence array is rebased to the first sequence of the workgroup: the phase bodies run with the local sequence index
   // the normalised previous pose (0.5 KB per track) and the velocity ring (1.5 KB), touched once per person and step, stay in HBM / L2;
   // the phases that compare against every track (cost, merge distance) read the de-normalised table `tpos` in LDS
-  Qs.prev += g0 * SE3D_NFU * 3;
+  if (l_prev) Qs.prev = l_prev; else Qs.prev += g0 * SE3D_NFU * 3;
   Qs.vel += g0 * SE3D_NFU * 9;
   Qs.fb_buf += (size_t)sb * 3; Qs.t_prev += sb; Qs.next_id += sb; Qs.frame_nr += sb; Qs.n_tracks += sb; Qs.order += g0;
   Qs.C += (size_t)sb * H * T; Qs.W += (size_t)sb * H * T; Qs.near += g0 * 4; Qs.det_slot += (size_t)sb * H; Qs.pub += (size_t)sb * H;
@@ -2344,6 +2348,8 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
     WK_STAMP(14)  // publish + lifecycle
   }
   if (Wk.lds_state) {  // write the track state back
+    if (l_prev)
+      for (int i = tid; i < tn * SE3D_NFU * 3; i += NT) Q.prev[g0 * SE3D_NFU * 3 + i] = l_prev[i];
     for (int i = tid; i < tn * 3; i += NT) Q.root_prev[g0 * 3 + i] = l_root[i];
     for (int i = tid; i < tn; i += NT) {
       Q.height_prev[g0 + i] = l_height[i]; Q.trk_t_prev[g0 + i] = l_tprev[i]; Q.has[g0 + i] = l_has[i];
@@ -2368,7 +2374,10 @@ static bool s2_launch_walk_shape(const Se3dStage2 &q, const Se3dWalk &Wk, int ns
   const size_t state_bytes = (size_t)SQ * q.T * (5 * sizeof(double) + 16);
   Se3dWalk w = Wk;
   w.lds_state = (work_bytes + state_bytes <= (size_t)lds_max) ? 1 : 0;
-  const size_t dyn = work_bytes + (w.lds_state ? state_bytes : 0);
+  // ... and the normalised previous poses (0.5 KB per track) when the one-wavefront shape still fits eight workgroups per CU with them
+  const size_t prev_bytes = (size_t)SQ * q.T * SE3D_NFU * 3 * sizeof(double) + 8;
+  if (WV == 1 && w.lds_state && work_bytes + state_bytes + prev_bytes <= 19 * 1024) w.lds_state |= 2;
+  const size_t dyn = work_bytes + (w.lds_state ? state_bytes : 0) + ((w.lds_state & 2) ? prev_bytes : 0);
   if (dyn > (size_t)lds_max) return false;
   hipLaunchKernelGGL((se3d_k_stage2_walk<TRIO, WV, SQ>), dim3((nseq + SQ - 1) / SQ), dim3(64 * WV), dyn, st, q, w, nseq);
   return true;
