@@ -141,7 +141,7 @@ void PosePriorNode::skeletonCallback(const person_msgs::PersonCovList& persons, 
   for (size_t i = 0; i < dets.size(); ++i) to_pod3(persons.persons[i], dets[i]);
   std::vector<se3d_person3d> fused(H), pred(H);
   std::vector<int32_t> iters(H);
-  se3d_fused_out fo{H, 0, 0, 0.f, fused.data(), pred.data(), iters.data()};
+  se3d_fused_out fo{H, 0, 0, 0.f, fused.data(), pred.data(), iters.data(), 0u};
   const int rc = se3d_refine(ctx_->get(), seq_, (int32_t)dets.size(), dets.empty() ? nullptr : dets.data(), (int32_t)persons.fb_delay_per_cam.size(),
                              persons.fb_delay_per_cam.empty() ? nullptr : persons.fb_delay_per_cam.data(), persons.header.stamp, &fo);
   if (rc != SE3D_OK) throw std::runtime_error(std::string("se3d_refine: ") + se3d_last_error(ctx_->get()));

@@ -121,7 +121,14 @@ typedef struct se3d_fused_out {
   se3d_person3d *fused;      /* [capacity] */
   se3d_person3d *fused_pred; /* [capacity] */
   int32_t *lm_iterations;    /* [capacity] outer LM iterations used for each published person (diagnostic) */
+  uint32_t flags;            /* out: SE3D_S2FLAG_* of the sequence, sticky since se3d_refine_reset */
 } se3d_fused_out;
+
+/* per-sequence flag bits in se3d_fused_out.flags */
+#define SE3D_S2FLAG_TRACK_OVERFLOW 1u    /* more live tracks than limits.max_tracks: a detection got no track */
+#define SE3D_S2FLAG_ASSIGNMENT_FAILED 4u /* the track-association Hungarian did not terminate (cannot happen with finite costs) */
+#define SE3D_S2FLAG_NOT_A_FOREST 8u      /* bone factors of a person did not form a forest (impossible with the reference's bone tables):
+                                            that person was published at its measurements, as after a failed optimisation (PP:751-758) */
 
 typedef struct se3d_ctx se3d_ctx;
 

@@ -61,6 +61,7 @@ struct se3d_ctx {
   int t_head = 0;
   se3d_person3d *h_fused = nullptr, *h_pred = nullptr;
   int32_t *h_iters = nullptr, *h_nout = nullptr, *h_ntracks = nullptr;
+  uint32_t *h_flags2 = nullptr;
   double *h_preddt = nullptr;
   hipEvent_t ev2[kRing][4]{};            // stage-2 sets
   bool ev2_walk[kRing]{};                // set brackets one fused multi-step launch (events 0 and 3 only)
@@ -294,6 +295,7 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_iters, sizeof(int32_t) * S * H, hipHostMallocDefault), "hipHostMalloc");
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_nout, sizeof(int32_t) * S, hipHostMallocDefault), "hipHostMalloc");
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_ntracks, sizeof(int32_t) * S, hipHostMallocDefault), "hipHostMalloc");
+      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_flags2, sizeof(uint32_t) * S, hipHostMallocDefault), "hipHostMalloc");
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_preddt, sizeof(double) * S, hipHostMallocDefault), "hipHostMalloc");
       ok = ok && hip_ok(c, hipMemset(c->d_fb, 0, sizeof(float) * S * N), "memset fb");
       ok = ok && (stage2_reset(c) == SE3D_OK);
@@ -349,6 +351,7 @@ void se3d_destroy(se3d_ctx *c) {
   if (c->h_iters) (void)hipHostFree(c->h_iters);
   if (c->h_nout) (void)hipHostFree(c->h_nout);
   if (c->h_ntracks) (void)hipHostFree(c->h_ntracks);
+  if (c->h_flags2) (void)hipHostFree(c->h_flags2);
   if (c->h_preddt) (void)hipHostFree(c->h_preddt);
   if (c->h_rp_off) (void)hipHostFree(c->h_rp_off);
   for (auto &set : c->ev2)
@@ -529,6 +532,7 @@ static int fetch_stage2_range(se3d_ctx *c, int seq0, int n_seq, se3d_fused_out *
   HIPCHK(c, hipMemcpyAsync(c->h_iters + seq0 * H, Q.iters + seq0 * H, sizeof(int32_t) * n_seq * H, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_nout + seq0, Q.n_out + seq0, sizeof(int32_t) * n_seq, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_ntracks + seq0, Q.n_tracks + seq0, sizeof(int32_t) * n_seq, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_flags2 + seq0, Q.flags2 + seq0, sizeof(uint32_t) * n_seq, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_preddt + seq0, Q.pred_dt + seq0, sizeof(double) * n_seq, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   collect_profile(c);
@@ -538,6 +542,7 @@ static int fetch_stage2_range(se3d_ctx *c, int seq0, int n_seq, se3d_fused_out *
     const int s = seq0 + k;
     const int np = c->h_nout[s];
     o.n_tracks = c->h_ntracks[s];
+    o.flags = c->h_flags2[s];
     o.pred_delta_t = (float)c->h_preddt[s];
     if (np > o.capacity) { o.n_persons = 0; c->err = "output capacity too small"; rc = SE3D_ERR_CAPACITY; continue; }
     o.n_persons = np;
@@ -636,9 +641,10 @@ int se3d_fetch_stage2_walk(se3d_ctx *c, int32_t frame_slot0, int32_t n_seq, se3d
   if (!c->ran2) { c->err = "fetch before run"; return SE3D_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   const int rc = fetch_stage2_range(c, frame_slot0, n_seq, outs);
-  if (frame_slot0 > 0) {  // n_tracks is per-sequence state (current value), not per frame slot
+  if (frame_slot0 > 0) {  // n_tracks and the flags are per-sequence state (current value), not per frame slot
     HIPCHK(c, hipMemcpy(c->h_ntracks, c->Q.n_tracks, sizeof(int32_t) * (size_t)n_seq, hipMemcpyDeviceToHost));
-    for (int k = 0; k < n_seq; ++k) outs[k].n_tracks = c->h_ntracks[k];
+    HIPCHK(c, hipMemcpy(c->h_flags2, c->Q.flags2, sizeof(uint32_t) * (size_t)n_seq, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n_seq; ++k) { outs[k].n_tracks = c->h_ntracks[k]; outs[k].flags = c->h_flags2[k]; }
   }
   return rc;
 }

@@ -11,6 +11,7 @@ import numpy as np
 NUM_KEYPOINTS = 17
 NUM_FUSION_KEYPOINTS = 21
 POSE_SIMPLE, POSE_H36M = 0, 1
+S2FLAG_TRACK_OVERFLOW, S2FLAG_ASSIGNMENT_FAILED, S2FLAG_NOT_A_FOREST = 1, 4, 8   # se3d_fused_out.flags (sticky per sequence)
 
 FLAG_HYP_OVERFLOW, FLAG_FEW_CAMERAS = 1, 2
 
@@ -54,7 +55,7 @@ class FrameOut(C.Structure):
 
 class FusedOut(C.Structure):
     _fields_ = [("capacity", C.c_int32), ("n_persons", C.c_int32), ("n_tracks", C.c_int32), ("pred_delta_t", C.c_float),
-                ("fused", C.c_void_p), ("fused_pred", C.c_void_p), ("lm_iterations", C.POINTER(C.c_int32))]
+                ("fused", C.c_void_p), ("fused_pred", C.c_void_p), ("lm_iterations", C.POINTER(C.c_int32)), ("flags", C.c_uint32)]
 
 
 class ReprojOut(C.Structure):

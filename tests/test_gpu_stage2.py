@@ -252,6 +252,33 @@ def test_stage2_walk_norm_height_and_h36m(extr_rig, oracle, monkeypatch, pose, n
         nd.close()
 
 
+@pytest.mark.parametrize("walk", [False, True])
+def test_stage2_track_capacity_flag(extr_rig, walk):
+    """Five persons on a context with room for three tracks: the overflow is reported (sticky, per sequence) instead of passing silently;
+    a second sequence with two persons stays clean.  Per-step kernels and the fused walk."""
+    T_ = 4
+    seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=n, n_frames=T_, seed=20 + n))[0] for n in (5, 2)]
+    frames = [seqs[s][k] for k in range(T_) for s in range(2)]
+    node = _node(extr_rig, max_frames=2 * T_, max_det_per_cam=8, max_hyp=8, max_tracks=3)
+    node.stage(frames)
+    node.run_stage1()
+    node.refine_reset()
+    ts = [100.0 + (i + 1) / 30.0 for i in range(T_)]
+    if walk:
+        node.run_stage2_walk(np.repeat(np.array(ts)[:, None], 2, 1), [k * 2 for k in range(T_)])
+        r = node.fetch_stage2_walk((T_ - 1) * 2, 2)
+    else:
+        for k in range(T_):
+            node.run_stage2(np.full(2, ts[k]), frame_slot0=k * 2)
+        r = node.fetch_stage2(2)
+    assert r[0].c.flags & pm.S2FLAG_TRACK_OVERFLOW and r[0].c.n_tracks == 3
+    assert r[1].c.flags == 0 and r[1].c.n_tracks == 2
+    node.refine_reset()
+    node.run_stage2(np.full(2, 200.0), frame_slot0=0)
+    assert node.fetch_stage2(2)[1].c.flags == 0
+    node.close()
+
+
 def test_stage2_walk_device_pack(extr_rig, device_buffer):
     from smartedgesensor3dhumanpose_amd import shard
     S_, T_, H = 4, 12, 8
