@@ -308,6 +308,43 @@ def test_stage2_walk_is_deterministic_and_sequences_do_not_interact(extr_rig, mo
     assert sum(v[0] for v in outs[0].values()) > S_ * 3
 
 
+def test_stage2_walk_at_bench_size(extr_rig, oracle, demo_params, monkeypatch):
+    """The bench.py shape of 16 cam x 6 persons: 256 sequences x 16 frames in one launch (the launcher picks the one-wavefront-per-sequence
+    kernel from 256 sequences).  The eight distinct sequences are checked against the oracle step by step, every replica must be bitwise
+    equal to its prototype, and the steady-state pass publishes every person of every frame."""
+    import bench
+    monkeypatch.delenv("SE3D_WALK_SHAPE", raising=False)
+    monkeypatch.delenv("SE3D_WALK_LM", raising=False)
+    w = bench.WORKLOADS["16cam6p"]
+    S_, T_, U = 256, 16, 8
+    seqs = bench.make_sequences(extr_rig, w, S_, seed0=4000, t_steps=T_)
+    frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
+    node = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"])
+    node.stage(frames)
+    node.run_stage1()
+    node.refine_reset()
+    r1 = node.fetch_stage1(S_ * T_)
+    oras = [oracle.PosePrior(demo_params) for _ in range(U)]
+    t = 100.0
+    for rep in range(2):   # forward, then backward (bench.py's ping-pong): the second pass is in steady state
+        ks = list(range(T_)) if rep == 0 else list(range(T_ - 1, -1, -1))
+        ts = t + np.arange(1, T_ + 1) / 30.0
+        t = float(ts[-1])
+        node.run_stage2_walk(np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
+        published = 0
+        for k, tk in zip(ks, ts):
+            r = node.fetch_stage2_walk(k * S_, S_)
+            for u in range(U):
+                o = oras[u].step(r1[k * S_ + u].published(), 16, float(tk), seqs[u][k].fb_delay, capacity=w["max_hyp"])
+                compare_stage2(r[u], o, check_tracks=(k == ks[-1]))
+            for s in range(S_):
+                n = r[s].n_persons
+                assert n == r[s % U].n_persons and r[s].fused[:n].tobytes() == r[s % U].fused[:n].tobytes()
+                published += n
+    assert published == S_ * T_ * w["n_persons"]
+    node.close()
+
+
 def test_stage2_walk_device_pack(extr_rig, device_buffer):
     from smartedgesensor3dhumanpose_amd import shard
     S_, T_, H = 4, 12, 8
