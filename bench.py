@@ -43,10 +43,10 @@ def make_rig(w):
 
 
 def make_sequences(rig, w, n_seq, seed0, t_steps):
-    """n_seq synthetic sequences of t_steps frames (up to 8 distinct seeded sequences, repeated)."""
+    """n_seq synthetic sequences of t_steps frames (up to 32 distinct seeded sequences per context, repeated)."""
     from smartedgesensor3dhumanpose_amd import scene as S
     uniq = []
-    for i in range(min(n_seq, 8)):
+    for i in range(min(n_seq, 32)):
         cfg = S.SceneConfig(n_persons=w["n_persons"], n_frames=t_steps, seed=seed0 + i, min_coverage=4 if w["n_cam"] == 16 else 6)
         uniq.append(S.generate_sequence(rig, cfg)[0])
     return [uniq[s % len(uniq)] for s in range(n_seq)]

@@ -310,13 +310,13 @@ def test_stage2_walk_is_deterministic_and_sequences_do_not_interact(extr_rig, mo
 
 def test_stage2_walk_at_bench_size(extr_rig, oracle, demo_params, monkeypatch):
     """The bench.py shape of 16 cam x 6 persons: 256 sequences x 16 frames in one launch (the launcher picks the one-wavefront-per-sequence
-    kernel from 256 sequences).  The eight distinct sequences are checked against the oracle step by step, every replica must be bitwise
+    kernel from 256 sequences).  The distinct sequences are checked against the oracle step by step, every replica must be bitwise
     equal to its prototype, and the steady-state pass publishes every person of every frame."""
     import bench
     monkeypatch.delenv("SE3D_WALK_SHAPE", raising=False)
     monkeypatch.delenv("SE3D_WALK_LM", raising=False)
     w = bench.WORKLOADS["16cam6p"]
-    S_, T_, U = 256, 16, 8
+    S_, T_, U = 256, 16, 32
     seqs = bench.make_sequences(extr_rig, w, S_, seed0=4000, t_steps=T_)
     frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
     node = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"])
