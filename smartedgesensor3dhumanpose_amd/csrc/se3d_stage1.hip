@@ -1292,20 +1292,30 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
 // Outlier-rejection path of the hypothesis kernel: one wavefront per hypothesis redoes the flagged joints (usually none) with the
 // per-joint routine.  A separate launch on purpose: calling the routine from se3d_k_triangulate_hyp (out of line, descriptor by
 // address) made every wavefront spill the kernel arguments to scratch at entry — 445 MB of writes per launch (PMC WRITE_SIZE).
-__global__ __launch_bounds__(64) void se3d_k_triangulate_slow(Se3dDev D) {
+__global__ __launch_bounds__(64) void se3d_k_triangulate_slow(Se3dDev D, int n_entries) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x, f = blockIdx.y, h = blockIdx.x;
+  const int lane = threadIdx.x;
   const int N = D.d.N, H = D.d.H;
-  if (h >= D.nhyp[f]) return;
-  if (D.nviews[f * H + h] < 2) return;
-  const uint32_t mask = D.tri_slow[((size_t)f * H + h) * 2] | D.tri_slow[((size_t)f * H + h) * 2 + 1];
-  if (!mask) return;
+  // each lane looks at one (frame, hypothesis) entry; the wavefront then works through the flagged ones (usually none: one load and out)
+  const int e = blockIdx.x * 64 + lane;
+  uint32_t mymask = 0u;
+  if (e < n_entries) {
+    const int f = e / H, h = e - f * H;
+    if (h < D.nhyp[f] && D.nviews[e] >= 2) mymask = D.tri_slow[(size_t)e * 2] | D.tri_slow[(size_t)e * 2 + 1];
+  }
+  unsigned long long todo = __ballot(mymask != 0u);
+  if (!todo) return;
   float *base = reinterpret_cast<float *>(smem), *sRt = base + (size_t)15 * N;
   for (int i = lane; i < 12 * N; i += 64) sRt[i] = D.Rt[i];
   __syncthreads();
-  for (uint32_t m = mask; m; m &= m - 1u) {
-    se3d_tri_joint_body(D, f, h, __ffs((int)m) - 1, lane, base, sRt);
-    __syncthreads();
+  for (; todo; todo &= todo - 1ull) {
+    const int src = __ffsll((long long)todo) - 1;
+    const int ee = blockIdx.x * 64 + src, f = ee / H, h = ee - f * H;
+    const uint32_t mask = (uint32_t)__shfl((int)mymask, src);
+    for (uint32_t m = mask; m; m &= m - 1u) {
+      se3d_tri_joint_body(D, f, h, __ffs((int)m) - 1, lane, base, sRt);
+      __syncthreads();
+    }
   }
 }
 
@@ -1707,7 +1717,7 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   const char *e_tri = getenv("SE3D_TRI");  // A/B switch (read per launch): joint = always one wavefront per (hypothesis, joint)
   if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) {
     hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(2 * H, B), dim3(64), 0, st, D);
-    hipLaunchKernelGGL(se3d_k_triangulate_slow, dim3(H, B), dim3(64), (size_t)27 * N * sizeof(float), st, D);
+    hipLaunchKernelGGL(se3d_k_triangulate_slow, dim3((B * H + 63) / 64), dim3(64), (size_t)27 * N * sizeof(float), st, D, B * H);
   }
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
   if (ev) (void)hipEventRecord(ev[4], st);
