@@ -6,13 +6,24 @@ One "step" = one pass of the hot path over one batch of synthetic frames that ar
   stage 2 (track association + LM refinement + marginals + prediction) walking the T time steps of the S independent
   sequences.  Time steps are walked forward on even steps and backward on odd steps so that person motion stays
   continuous, tracks persist and (after warm-up) every person-frame is published (num_obs > 10, PP:845).
-`value` = published refined 3D skeletons (person-frames) per second over all ranks.  See DESIGN.md §measurement.
+`value` = published refined 3D skeletons (person-frames) per second over all ranks.  See DESIGN.md §5.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 16cam6p|64cam32p|256cam128p] [--seqs S] [--stage 1|12]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 16cam6p|64cam32p|256cam128p] [--seqs S] [--stage 1|12|dlt]
+
+The JSON line of a default run carries, next to the headline (16cam6p, the first configuration BASELINE.json's metric is quoted on):
+  "secondary": the same measurement at 256cam128p (the second configuration of the metric),
+  "serial":    ONE context holding all sequences, kernels strictly one after the other on one stream — the per-kernel times that
+               "roofline" is computed from (the kernels of the headline's contexts overlap by design; their durations are not
+               per-kernel evidence),
+  "cpu_baseline": the CPU oracle timed on this box's cores (N = 1 only).
+With --gpus N > 1 and no RANK in the environment bench.py launches its N ranks itself (python -m torch.distributed.run, one fresh child
+process per GPU; the parent never touches the GPU); under an external torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,30 +37,60 @@ sys.path.insert(0, ROOT)
 
 T_STEPS = 16  # frames per synthetic sequence (>= 16 frames per sequence)
 WORKLOADS = {
-    # bytes/skeleton: SURVEY §8d algorithmic bytes (stage 1) ; stage 2 adds 8.9 KB per skeleton
-    "16cam6p": dict(n_cam=16, n_persons=6, seqs=512, contexts=12, max_det=8, max_hyp=12, bytes_s1=8972, bytes_s2=8900),
-    "64cam32p": dict(n_cam=64, n_persons=32, seqs=32, contexts=3, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900),
-    "256cam128p": dict(n_cam=256, n_persons=128, seqs=1, contexts=3, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900),
+    # bytes/skeleton: SURVEY §8d algorithmic bytes (stage 1); stage 2 adds 8.9 KB per skeleton.  flop_s1: SURVEY §8d minimal-work
+    # flops per skeleton (association + triangulation/UT covariance, fp32-class); stage 2: 0.74 MFLOP (fp64) per LM iteration (+1 for
+    # the marginals).
+    "16cam6p": dict(n_cam=16, n_persons=6, seqs=512, contexts=12, max_det=8, max_hyp=12, bytes_s1=8972, bytes_s2=8900, flop_s1=0.12e6 + 1.86e6),
+    "64cam32p": dict(n_cam=64, n_persons=32, seqs=32, contexts=3, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900, flop_s1=11.0e6 + 7.28e6),
+    "256cam128p": dict(n_cam=256, n_persons=128, seqs=1, contexts=3, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900, flop_s1=0.71e9 + 29.0e6),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FLOP_S2_PER_LM_ITER = 0.74e6
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (fp64 vector: half of it)
+STAGE1_KERNELS = ["normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess"]
+STAGE2_KERNELS = ["track_assoc", "lm_refine", "track_update", "stage2_walk"]
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N starts N ranks (fresh children; nothing in this process has touched the GPU yet)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def self_launch(n):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# synthetic scenes (generated in worker processes forked BEFORE anything touches the GPU)
+# ---------------------------------------------------------------------------------------------------------------------------------
 def make_rig(w):
     from smartedgesensor3dhumanpose_amd import rig as R
     from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
     rig = R.extr_rig_16cam() if w["n_cam"] == 16 else R.elliptical_rig(w["n_cam"], seed=0)
-    rig.set_tensors(*rig_tensors(rig))
+    rig.set_tensors(*rig_tensors(rig))   # host code of the library (se3d_rig_from_transforms): no GPU call
     return rig
 
 
-def make_sequences(rig, w, n_seq, seed0, t_steps):
-    """n_seq synthetic sequences of t_steps frames (up to 32 distinct seeded sequences per context, repeated)."""
-    from smartedgesensor3dhumanpose_amd import scene as S
-    uniq = []
-    for i in range(min(n_seq, 32)):
-        cfg = S.SceneConfig(n_persons=w["n_persons"], n_frames=t_steps, seed=seed0 + i, min_coverage=4 if w["n_cam"] == 16 else 6)
-        uniq.append(S.generate_sequence(rig, cfg)[0])
-    return [uniq[s % len(uniq)] for s in range(n_seq)]
+def _gen_one(job):
+    n_cam, n_persons, t_steps, seed = job
+    from smartedgesensor3dhumanpose_amd import rig as R, scene as S
+    rig = R.extr_rig_16cam() if n_cam == 16 else R.elliptical_rig(n_cam, seed=0)
+    cfg = S.SceneConfig(n_persons=n_persons, n_frames=t_steps, seed=seed, min_coverage=4 if n_cam == 16 else 6)
+    return S.generate_sequence(rig, cfg)[0]
+
+
+def make_sequences(pool, w, n_ctx, n_seq, seed_rank, t_steps):
+    """Per context: n_seq synthetic sequences of t_steps frames (up to 32 distinct seeded sequences per context, repeated)."""
+    n_uniq = min(n_seq, 32)
+    jobs = [(w["n_cam"], w["n_persons"], t_steps, 1000 * seed_rank + 100 * ci + i) for ci in range(n_ctx) for i in range(n_uniq)]
+    uniq = pool.map(_gen_one, jobs, chunksize=1) if pool is not None else [_gen_one(j) for j in jobs]
+    return [[uniq[ci * n_uniq + s % n_uniq] for s in range(n_seq)] for ci in range(n_ctx)]
 
 
 def cpu_baseline(rig, seq, params, with_stage2, budget_s=12.0):
@@ -77,111 +118,55 @@ def cpu_baseline(rig, seq, params, with_stage2, budget_s=12.0):
                       % (out[best][1], "1+2" if with_stage2 else "1", out["1t"][0], out["1t"][1], ncores, out["omp"][0], out["omp"][1])}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="16cam6p", choices=sorted(WORKLOADS))
-    ap.add_argument("--seqs", type=int, default=0, help="independent sequences per GPU (default: workload preset)")
-    ap.add_argument("--tsteps", type=int, default=T_STEPS)
-    ap.add_argument("--stage", default="12", choices=["1", "12"], help="1: stage 1 only; 12: stage 1 + stage 2")
-    ap.add_argument("--contexts", type=int, default=0, help="independent se3d contexts (HIP streams) per GPU, each with --seqs sequences; "
-                    "their launches interleave so latency-bound phases of one overlap throughput-bound kernels of the other (default: preset)")
-    ap.add_argument("--walk", default="fused", choices=["fused", "steps"], help="stage 2 as one multi-step launch per context and step (default) "
-                    "or as T per-step calls (A/B)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
+# ---------------------------------------------------------------------------------------------------------------------------------
+# one measurement: NC contexts x S sequences x T frames resident on this rank's GPU
+# ---------------------------------------------------------------------------------------------------------------------------------
+def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank, stage2, verify_exchange=True):
+    """seqs_per_ctx: list over contexts of lists of sequences.  Returns a dict (all ranks; `value` etc. are whole-job figures)."""
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: exercises the exchange path)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-
     from smartedgesensor3dhumanpose_amd import person_msgs as pm
+    from smartedgesensor3dhumanpose_amd import shard
     from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
-    w = WORKLOADS[args.workload]
-    S_, T_ = args.seqs or w["seqs"], args.tsteps
+    w = WORKLOADS[name]
+    NC, S_, T_ = len(seqs_per_ctx), len(seqs_per_ctx[0]), len(seqs_per_ctx[0][0])
     B = S_ * T_
-    stage2 = args.stage == "12"
-    rig = make_rig(w)
-    NC = args.contexts or w["contexts"]
-    seed_rank = int(os.environ.get("SE3D_BENCH_SEED_RANK", rank))  # diagnostic: run another rank's synthetic scenes on this GPU (tools/check_rank_scenes.sh)
-    nodes, all_seqs = [], []
-    for ci in range(NC):  # every rank (and every context) owns its own sequences: weak scaling, no data-path collective
-        seqs = make_sequences(rig, w, S_, seed0=1000 * seed_rank + 100 * ci, t_steps=T_)
+    world = dist.get_world_size() if dist is not None else 1
+    nodes = []
+    for seqs in seqs_per_ctx:   # every rank (and every context) owns its own sequences: weak scaling, no data-path collective
         frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s
         nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank)
         nd_.stage(frames)  # inputs resident in HBM before the timed region
         nodes.append(nd_)
-        all_seqs.append(seqs)
-    node, seqs = nodes[0], all_seqs[0]
+    node = nodes[0]
     dt_frame = 1.0 / 30.0
-
     H = node.limits.max_hyp
     psz = pm.person3d_dt.itemsize
+    fused_walk = args.walk == "fused"
+    ex = None
     if dist is not None:
         # Exchange (SURVEY 8e): ONE RCCL all-gather of the final skeletons per step so that every rank holds the skeletons of all ranks
-        # ([contexts][B][n_persons + 2] person slots + [contexts][B] counts, frame-slot order).  Stream-ordered, no host
-        # synchronisation: every context packs its slice asynchronously on its own HIP stream (handed to torch as an ExternalStream) and
-        # records an event; a dedicated exchange stream waits for the events of all contexts and enqueues the collective, which runs on
-        # RCCL's stream while the contexts compute their next step; the pack buffers are double-buffered and a slice is rewritten only
-        # after the collective that read it two steps earlier has completed (device-side wait on the context stream).
-        n_slots = B
-        XH = min(H, w["n_persons"] + 2) if stage2 and args.walk == "fused" else H   # person slots per frame carried by the exchange
+        # ([contexts][B][XH] person slots + [contexts][B] counts, frame-slot order); stream-ordered and double-buffered
+        # (shard.SkeletonExchange, covered by tests/test_distributed_gloo.py with two gloo ranks).
+        XH = min(H, w["n_persons"] + 2) if stage2 and fused_walk else H   # person slots per frame carried by the exchange
         streams = [torch.cuda.ExternalStream(nd_.stream_handle()) for nd_ in nodes]
-        xstream = torch.cuda.Stream()
-        slice_p, slice_c = n_slots * XH * psz, n_slots
-        packs = [torch.zeros(NC * slice_p, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        cnts = [torch.zeros(NC * slice_c, dtype=torch.int32, device="cuda") for _ in range(2)]
-        gath_p = torch.empty(world * NC * slice_p, dtype=torch.uint8, device="cuda")
-        gath_c = torch.empty(world * NC * slice_c, dtype=torch.int32, device="cuda")
-        works = [None, None]
-        packed_ev = [None] * NC
-        xstate = {"parity": 0}
-
-    def pack_target(ci):
-        p = xstate["parity"]
-        if works[p] is not None:
-            with torch.cuda.stream(streams[ci]):
-                for w_ in works[p]:
-                    w_.wait()
-        return packs[p][ci * slice_p:(ci + 1) * slice_p], cnts[p][ci * slice_c:(ci + 1) * slice_c]
-
-    def packed(ci):
-        packed_ev[ci] = streams[ci].record_event()
-
-    def exchange():
-        p = xstate["parity"]
-        with torch.cuda.stream(xstream):
-            for ev in packed_ev:
-                xstream.wait_event(ev)
-            works[p] = (dist.all_gather_into_tensor(gath_p, packs[p], async_op=True),
-                        dist.all_gather_into_tensor(gath_c, cnts[p], async_op=True))
-        xstate["parity"] ^= 1
+        ex = shard.SkeletonExchange(dist, NC, B * XH * psz, B, torch.device("cuda", local_rank), streams)
 
     # One step = per context one stage-1 pass over its B resident frames and one stage-2 walk over the T time steps of its S
-    # sequences (se3d_run_stage2_walk: one launch, a workgroup per sequence; forward on even cycles, backward on odd ones so that
-    # motion stays continuous and tracks persist).  With --walk steps the walk is issued as T per-step calls (se3d_run_stage2).
+    # sequences (se3d_run_stage2_walk: one launch, a wavefront or workgroup per sequence; forward on even cycles, backward on odd
+    # ones so that motion stays continuous and tracks persist).  With --walk steps the walk is issued as T per-step calls.
     # Contexts are phase-shifted (odd contexts issue walk-then-stage-1) so that the throughput-bound stage-1 kernels of one context
     # overlap the latency-bound stage-2 walk of another instead of all contexts running the same phase in lockstep.  Stage-1
     # outputs of a frame slot are a pure function of the resident inputs, so a walk always consumes complete stage-1 results.
     walks = [{"node": nd_, "ci": ci, "cycle": 0, "t": 100.0} for ci, nd_ in enumerate(nodes)]
+    max_pub = [0]   # most skeletons any frame published (accounting pass): the exchange carries n_persons + 2 slots per frame
+    lm_iters = []
 
     def issue_stage1(wk):
         wk["node"].run_stage1()
-        if not stage2 and dist is not None:
-            pk, cn = pack_target(wk["ci"])
+        if not stage2 and ex is not None:
+            pk, cn = ex.pack_target(wk["ci"])
             wk["node"].pack_stage1_device(pk.data_ptr(), cn.data_ptr())
-            packed(wk["ci"])
+            ex.packed(wk["ci"])
 
     def issue_walk(wk, collect):
         nd_, ci = wk["node"], wk["ci"]
@@ -189,29 +174,33 @@ def main():
         ts = wk["t"] + dt_frame * np.arange(1, T_ + 1)
         wk["t"] = float(ts[-1])
         wk["cycle"] += 1
-        if args.walk == "fused":
+        if fused_walk:
             nd_.run_stage2_walk(np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
-            if dist is not None:  # async D2D of all time steps' fused skeletons (frame-slot order) into the exchange buffer
-                pk, cn = pack_target(ci)
+            if ex is not None:  # async D2D of all time steps' fused skeletons (frame-slot order) into the exchange buffer
+                pk, cn = ex.pack_target(ci)
                 nd_.pack_stage2_walk_device_slots(B, XH, pk.data_ptr(), cn.data_ptr())
-                packed(ci)
+                ex.packed(ci)
             if collect is not None:
-                per_frame = [r.n_persons for k in ks for r in nd_.fetch_stage2_walk(k * S_, S_)]
-                assert dist is None or max(per_frame) <= XH, "exchange slots per frame too small: skeletons would be truncated"
+                res = [r for k in ks for r in nd_.fetch_stage2_walk(k * S_, S_)]
+                per_frame = [r.n_persons for r in res]
+                assert ex is None or max(per_frame) <= XH, "exchange slots per frame too small: skeletons would be truncated"
                 max_pub[0] = max(max_pub[0], max(per_frame))
                 collect.append(sum(per_frame))
+                if ci == 0:
+                    lm_iters.extend(int(v) for r in res[: 4 * S_] for v in r.lm_iterations[: r.n_persons])
         else:
-            pk, cn = pack_target(ci) if dist is not None else (None, None)
+            pk, cn = ex.pack_target(ci) if ex is not None else (None, None)
             for k, t in zip(ks, ts):
                 nd_.run_stage2(np.full(S_, t), frame_slot0=k * S_)
-                if dist is not None:
+                if ex is not None:
                     nd_.pack_stage2_device(S_, pk.data_ptr() + k * S_ * H * psz, cn.data_ptr() + 4 * k * S_)
                 if collect is not None:
-                    collect.append(sum(r.n_persons for r in nd_.fetch_stage2(S_)))
-            if dist is not None:
-                packed(ci)
+                    res = nd_.fetch_stage2(S_)
+                    collect.append(sum(r.n_persons for r in res))
+                    max_pub[0] = max([max_pub[0]] + [r.n_persons for r in res])
+            if ex is not None:
+                ex.packed(ci)
 
-    max_pub = [0]   # most skeletons any frame published (accounting pass): the exchange carries n_persons + 2 slots per frame
     def step(collect=None):
         if not stage2:
             for wk in walks:
@@ -221,29 +210,28 @@ def main():
                 issue_stage1(wk) if wk["ci"] % 2 == 0 else issue_walk(wk, collect)
             for wk in walks:   # phase B
                 issue_walk(wk, collect) if wk["ci"] % 2 == 0 else issue_stage1(wk)
-        if dist is not None:
-            exchange()
+        return ex.exchange() if ex is not None else None
 
     for nd_ in nodes:
         nd_.run_stage1()   # phase-shifted contexts start inside the stage-2 walk: their frames need one completed stage-1 pass
     for nd_ in nodes:
         nd_.refine_reset()
-    for _ in range(max(args.warmup, 1 if stage2 else 0)):
+    for _ in range(max(warmup, 1 if stage2 else 0)):
         step()
     for nd_ in nodes:
         nd_.sync()
-    for nd_ in nodes:    # HIP-event kernel timing on every context's own stream (kernels of different contexts overlap by design)
+    for nd_ in nodes:    # HIP-event kernel timing on every context's own stream
         nd_.profile(True)
         nd_.profile_reset()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for _ in range(steps):
+        last_parity = step()
     for nd_ in nodes:
         nd_.sync()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()   # includes the exchange stream and RCCL's stream
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -253,14 +241,25 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    exchange_ok = None
+    if ex is not None and verify_exchange:   # every rank's gathered buffer == concatenation of all ranks' packs (last timed step)
+        ok = torch.tensor([1 if ex.verify(last_parity) else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        exchange_ok = bool(ok.item())
+        assert exchange_ok, "RCCL exchange: a gathered buffer differs from the ranks' pack buffers"
     # untimed accounting pass: published skeletons of one (steady-state) step
     s1 = [r for nd_ in nodes for r in nd_.fetch_stage1(B)]
     n_s1 = sum(r.n_persons for r in s1)
     assert not any(r.flags & pm.FLAG_HYP_OVERFLOW for r in s1), "hypothesis capacity (max_hyp) exceeded: results truncated"
+    assert not any(r.flags & pm.FLAG_ASSIGNMENT_FAILED for r in s1), "the sweep's Hungarian hit its iteration guard"
     if stage2:
         per_call = []
         step(collect=per_call)
         n_skel_local = sum(per_call)
+        if ex is not None:
+            ex.finish()
+            _, gc = ex.gathered(ex.parity ^ 1)   # gathered counts of the accounting step: nothing truncated on any rank
+            assert int(gc.max().item()) <= XH, "a remote rank published more skeletons in a frame than the exchange carries"
     else:
         n_skel_local = n_s1
     n_skel = n_skel_local
@@ -268,46 +267,187 @@ def main():
         tot = torch.tensor([n_skel_local], dtype=torch.int64, device="cuda")
         dist.all_reduce(tot)
         n_skel = int(tot.item())
-
-    if rank == 0:
-        names = ["normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess"] + (["track_assoc", "lm_refine", "track_update", "stage2_walk"] if stage2 else [])
-        prof = {k: tuple(sum(x) for x in zip(*[nd_.profile_get(k) for nd_ in nodes])) for k in names}   # (ms, launches) over all contexts
-        per_step_ms = {k: v[0] / args.steps / NC for k, v in prof.items()}                              # per context and step
-        dom = max(per_step_ms, key=lambda k: per_step_ms[k])
-        ms_dom = prof[dom][0] / max(prof[dom][1], 1)              # average duration of one launch (group) of the dominant kernel
-        launches_per_step = prof[dom][1] / args.steps / NC
-        bytes_per_skel = w["bytes_s1"] if dom in names[:5] else w["bytes_s2"]
-        units_per_launch = n_skel_local / NC / launches_per_step   # skeletons one launch of that kernel processes (context 0)
-        achieved = bytes_per_skel * units_per_launch / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
-        traffic = None  # HBM bytes per launch from the committed PMC passes of this exact configuration (profiles/r1/pmc_traffic_*.json)
-        pmc_file = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_%s.json" % args.workload)
-        if os.path.exists(pmc_file) and S_ == w["seqs"] and T_ == T_STEPS and stage2:
-            traffic = json.load(open(pmc_file))["kernels"].get(dom, {}).get("hbm_bytes_per_launch_corrected")
-        line = {
-            "metric": "3D skeletons/sec (triangulated + refined, per-joint error < 1 mm vs CPU reference path)",
-            "value": round(n_skel * args.steps / dt, 2), "unit": "skeletons/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 geometry, f64 accumulation/eigen/LM", "data": "synthetic",
-            "config": {"workload": "%s, stage %s, %d contexts x %d sequences x %d frames resident per GPU (%d frames, %d published skeletons per step per GPU; stage-1 persons %d)"
-                                   % (args.workload, "1+2 (association+triangulation+UT covariance, then tracking+LM refinement+marginals)" if stage2 else "1",
-                                      NC, S_, T_, NC * B, n_skel_local, n_s1),
-                       "n_cam": w["n_cam"], "n_persons": w["n_persons"], "n_joints": 17, "frames_per_step": NC * B, "contexts_per_gpu": NC,
-                       "max_hypotheses_per_frame": int(max(r.n_hyp for r in s1)), "max_published_per_frame": int(max_pub[0]),
-                       "sharding": ("independent sequences per rank + RCCL all-gather of final skeletons" if world > 1 else "single GPU")},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "avg_launch_ms": round(ms_dom, 5),
-                         "algorithmic_bytes_per_skeleton": bytes_per_skel, "skeletons_per_launch": round(units_per_launch, 1),
-                         "note": "SURVEY 8d: the path is VALU/latency-bound, not HBM-bound; the HBM fraction is reported as north_star asks",
-                         "kernel_ms_per_step": {k: round(v, 5) for k, v in per_step_ms.items()}},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(rig, seqs[0], node.params, stage2)
-        else:
-            line["cpu_baseline"] = None
-        print(json.dumps(line))
+    names = STAGE1_KERNELS + (STAGE2_KERNELS if stage2 else [])
+    prof = {k: tuple(sum(x) for x in zip(*[nd_.profile_get(k) for nd_ in nodes])) for k in names}   # (ms, launches) over all contexts
+    res = {
+        "workload": name, "value": n_skel * steps / dt, "ms_per_step": dt / steps * 1e3, "n_skel": n_skel, "n_skel_local": n_skel_local,
+        "n_s1": n_s1, "NC": NC, "S": S_, "T": T_, "B": B, "steps": steps, "warmup": warmup, "prof": prof,
+        "kernel_ms_per_step": {k: v[0] / steps / NC for k, v in prof.items()},   # per context and step
+        "max_hyp_per_frame": int(max(r.n_hyp for r in s1)), "max_published_per_frame": int(max_pub[0]), "exchange_verified": exchange_ok,
+        "lm_iterations_mean": float(np.mean(lm_iters)) if lm_iters else None, "params": node.params,
+    }
     for nd_ in nodes:
         nd_.close()
+    return res
+
+
+def roofline_of(res, w, stage2, source):
+    """HBM roofline of the dominant kernel of a measurement: achieved = algorithmic bytes per skeleton x skeletons per launch / average
+    launch duration (HIP events on the kernel's own stream)."""
+    prof, NC, steps = res["prof"], res["NC"], res["steps"]
+    per_step_ms = res["kernel_ms_per_step"]
+    dom = max(per_step_ms, key=lambda k: per_step_ms[k])
+    ms_dom = prof[dom][0] / max(prof[dom][1], 1)              # average duration of one launch (group) of the dominant kernel
+    launches_per_step = prof[dom][1] / steps / NC
+    bytes_per_skel = w["bytes_s1"] if dom in STAGE1_KERNELS else w["bytes_s2"]
+    units_per_launch = res["n_skel_local"] / NC / max(launches_per_step, 1e-9)
+    achieved = bytes_per_skel * units_per_launch / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(ms_dom, 5),
+            "algorithmic_bytes_per_skeleton": bytes_per_skel, "skeletons_per_launch": round(units_per_launch, 1), "source": source,
+            "sum_kernel_ms_per_step": round(sum(per_step_ms.values()), 4),
+            "kernel_ms_per_step": {k: round(v, 5) for k, v in per_step_ms.items()}}
+
+
+def valu_of(res, w, stage2, pmc):
+    """Vector-ALU roofline (SURVEY 8d asks for both): algorithmic flops per skeleton x skeletons/s against the fp32 vector peak."""
+    it = res.get("lm_iterations_mean") or 0.0
+    flop = w["flop_s1"] + (FLOP_S2_PER_LM_ITER * (it + 1.0) if stage2 else 0.0)
+    tf = flop * res["value_per_gpu"] / 1e12
+    out = {"algorithmic_flop_per_skeleton": round(flop), "stage1_flop": round(w["flop_s1"]), "stage2_flop_per_lm_iteration": FLOP_S2_PER_LM_ITER if stage2 else 0,
+           "lm_iterations_mean": round(it, 3), "achieved": round(tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 6),
+           "note": "minimal-work flops of SURVEY 8d (the kernels issue more: IEEE-exact divides, fp64 solves); fp64 work counted at face value against the fp32 vector peak"}
+    if pmc:
+        out["measured_valu_issue_utilisation"] = pmc.get("valu_issue_utilisation")
+        out["measured_source"] = pmc.get("source")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: 16cam6p headline + 256cam128p secondary + serial pass")
+    ap.add_argument("--seqs", type=int, default=0, help="independent sequences per context (default: workload preset)")
+    ap.add_argument("--tsteps", type=int, default=T_STEPS)
+    ap.add_argument("--stage", default="12", choices=["1", "12", "dlt"], help="1: stage 1 only; 12: stage 1 + stage 2; dlt: config 2 "
+                    "(batched DLT triangulation + UT covariance with the association given)")
+    ap.add_argument("--contexts", type=int, default=0, help="independent se3d contexts (HIP streams) per GPU, each with --seqs sequences; "
+                    "their launches interleave so latency-bound phases of one overlap throughput-bound kernels of the other (default: preset)")
+    ap.add_argument("--walk", default="fused", choices=["fused", "steps"], help="stage 2 as one multi-step launch per context and step (default) "
+                    "or as T per-step calls (A/B)")
+    ap.add_argument("--serial", action="store_true", help="ONLY the serial pass: one context with contexts x seqs sequences, one stream "
+                    "(the run rocprofv3 --kernel-trace --stats is pointed at for profiles/*/serial_*)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 256cam128p secondary measurement of a default run")
+    ap.add_argument("--no-serial", action="store_true", help="skip the serial per-kernel pass of a default run")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))   # the children print the JSON line (rank 0)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" in os.environ and world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.stage == "dlt":
+        from tools_dlt_bench import run_dlt   # noqa: F401  (replaced below)
+
+    default_run = args.workload is None and not args.serial
+    headline = args.workload or "16cam6p"
+    stage2 = args.stage == "12"
+    w = WORKLOADS[headline]
+    S_, T_ = args.seqs or w["seqs"], args.tsteps
+    NC = args.contexts or w["contexts"]
+    seed_rank = int(os.environ.get("SE3D_BENCH_SEED_RANK", rank))  # diagnostic: run another rank's synthetic scenes on this GPU (tools/check_rank_scenes.sh)
+
+    # ---- scenes first: worker processes are forked before this process initialises the GPU ----
+    import multiprocessing as mp
+    nproc = max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
+    pool = mp.get_context("fork").Pool(nproc) if nproc > 1 else None
+    t_gen = time.perf_counter()
+    rig = make_rig(w)
+    seqs_head = make_sequences(pool, w, NC, S_, seed_rank, T_)
+    want_secondary = default_run and not args.no_secondary and stage2
+    if want_secondary:
+        w2 = WORKLOADS["256cam128p"]
+        rig2 = make_rig(w2)
+        seqs_sec = make_sequences(pool, w2, w2["contexts"], w2["seqs"], seed_rank, T_)
+    if pool is not None:
+        pool.close()
+        pool.join()
+    t_gen = time.perf_counter() - t_gen
+
+    import torch
+    dist = None
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: exercises the exchange path)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+
+    head = None
+    if not args.serial:
+        head = run_workload(headline, seqs_head, rig, args, args.steps, args.warmup, dist, local_rank, stage2)
+        head["value_per_gpu"] = head["value"] / world
+    # ---- serial pass: ONE context with all NC x S sequences on one stream; no other context runs -> per-kernel durations that do not
+    # overlap anything (rank 0's GPU only; the other ranks wait at the next barrier) ----
+    serial = None
+    if (args.serial or (default_run and not args.no_serial)) and rank == 0:
+        all_seqs = [s for ctx_seqs in seqs_head for s in ctx_seqs]
+        serial = run_workload(headline, [all_seqs], rig, args, max(3, args.steps // 4), 1, None, local_rank, stage2)
+        serial["value_per_gpu"] = serial["value"]
+    del seqs_head
+    sec = None
+    if want_secondary:
+        sec = run_workload("256cam128p", seqs_sec, rig2, args, max(3, args.steps // 4), 1, dist, local_rank, True)
+        sec["value_per_gpu"] = sec["value"] / world
+
+    if rank == 0:
+        main_res = head or serial
+        pmc_dir = os.path.join(ROOT, "profiles", "r2")
+
+        def load(fn):
+            p = os.path.join(pmc_dir, fn)
+            return json.load(open(p)) if os.path.exists(p) else None
+        roof_src = serial or head
+        roof = roofline_of(roof_src, w, stage2, "serial pass: one context, one stream, %d sequences x %d frames (%.0f skeletons/s alone)"
+                           % (roof_src["S"], roof_src["T"], roof_src["value"]) if serial else "overlapped contexts (no serial pass in this run)")
+        tr = load("pmc_traffic_%s_serial.json" % headline)   # committed PMC passes of `bench.py --serial` (tools/profile_bench.sh)
+        if tr and serial and serial["S"] == tr.get("sequences"):
+            roof["traffic"] = tr["kernels"].get(roof["kernel"], {}).get("hbm_bytes_per_launch_corrected")
+        roof["valu"] = valu_of(main_res, w, stage2, load("pmc_valu_%s.json" % headline))
+        line = {
+            "metric": "3D skeletons/sec (triangulated + refined; parity vs the CPU oracle is asserted by tests/ and smoke(), not here)",
+            "value": round(main_res["value"], 2), "unit": "skeletons/s", "n_gpus": world, "steps": main_res["steps"], "warmup": main_res["warmup"],
+            "ms_per_step": round(main_res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 geometry, f64 accumulation/eigen/LM", "data": "synthetic",
+            "config": {"workload": "%s, stage %s, %d contexts x %d sequences x %d frames resident per GPU (%d frames, %d published skeletons per step per GPU; stage-1 persons %d)"
+                                   % (headline, "1+2 (association+triangulation+UT covariance, then tracking+LM refinement+marginals)" if stage2 else "1",
+                                      main_res["NC"], main_res["S"], main_res["T"], main_res["NC"] * main_res["B"], main_res["n_skel_local"], main_res["n_s1"]),
+                       "n_cam": w["n_cam"], "n_persons": w["n_persons"], "n_joints": 17, "frames_per_step": main_res["NC"] * main_res["B"],
+                       "contexts_per_gpu": main_res["NC"], "max_hypotheses_per_frame": main_res["max_hyp_per_frame"],
+                       "max_published_per_frame": main_res["max_published_per_frame"], "scene_generation_s": round(t_gen, 1),
+                       "sharding": ("independent sequences per rank + RCCL all-gather of final skeletons (verified: %s)" % main_res["exchange_verified"]
+                                    if dist is not None else "single GPU")},
+            "roofline": roof,
+        }
+        if head is not None:
+            line["overlapped_kernel_ms_per_step"] = {k: round(v, 5) for k, v in head["kernel_ms_per_step"].items()}
+        if serial is not None and head is not None:
+            line["serial"] = {"value": round(serial["value"], 2), "ms_per_step": round(serial["ms_per_step"], 4), "steps": serial["steps"],
+                              "sequences": serial["S"], "n_gpus": 1}
+        if sec is not None:
+            roof2 = roofline_of(sec, WORKLOADS["256cam128p"], True, "overlapped contexts (%d per GPU)" % sec["NC"])
+            roof2["valu"] = valu_of(sec, WORKLOADS["256cam128p"], True, load("pmc_valu_256cam128p.json"))
+            line["secondary"] = {"workload": "256cam128p, stage 1+2, %d contexts x %d sequences x %d frames per GPU" % (sec["NC"], sec["S"], sec["T"]),
+                                 "value": round(sec["value"], 2), "unit": "skeletons/s", "n_gpus": world, "value_per_gpu": round(sec["value_per_gpu"], 2),
+                                 "ms_per_step": round(sec["ms_per_step"], 3), "steps": sec["steps"], "warmup": sec["warmup"],
+                                 "skeletons_per_step_per_gpu": sec["n_skel_local"], "max_hypotheses_per_frame": sec["max_hyp_per_frame"],
+                                 "target": "north_star: >= 1e5 skeletons/s on 8 GPUs = 12 500 per GPU", "exchange_verified": sec["exchange_verified"],
+                                 "roofline": roof2}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(rig, _gen_one((w["n_cam"], w["n_persons"], T_, 1000 * seed_rank)), main_res["params"], stage2)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

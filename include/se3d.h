@@ -39,6 +39,8 @@ extern "C" {
 /* per-frame flag bits in se3d_frame_out.flags */
 #define SE3D_FLAG_HYP_OVERFLOW 1u /* more hypotheses than limits.max_hyp were spawned; result truncated */
 #define SE3D_FLAG_FEW_CAMERAS 2u  /* < 2 cameras with detections: empty result (S3D:557-560) */
+#define SE3D_FLAG_ASSIGNMENT_FAILED 4u /* the sweep's Hungarian hit its iteration guard (cannot happen with finite costs): that camera
+                                          step kept the provisional assignment */
 
 /* person_msgs/Keypoint2D.msg */
 typedef struct se3d_keypoint2d {
@@ -198,9 +200,10 @@ typedef struct se3d_reproj_out {
 } se3d_reproj_out;
 int se3d_set_reprojection_cameras(se3d_ctx *ctx, const double *T_base_to_cam, const double *P_fx_fy_cx_cy, const int32_t *wh);
 int se3d_reproject(se3d_ctx *ctx, int32_t n_persons, const se3d_person3d *persons, se3d_reproj_out *out);
-/* Same, on the predicted skeletons (persons3d_fused_pred) that the last se3d_run_stage2 / se3d_refine left in HBM for sequence
- * `seq`: no host round trip between pose_prior and the reprojection.  out == NULL: launch only (asynchronous). */
-int se3d_reproject_resident(se3d_ctx *ctx, int32_t seq, se3d_reproj_out *out);
+/* Same, on the predicted skeletons (persons3d_fused_pred) that stage 2 left in HBM: no host round trip between pose_prior and the
+ * reprojection.  `slot` selects the result: the sequence index after se3d_run_stage2 / se3d_refine, the FRAME slot (frame_slot0[k] + s)
+ * after se3d_run_stage2_walk, whose results are kept per frame slot.  out == NULL: launch only (asynchronous). */
+int se3d_reproject_resident(se3d_ctx *ctx, int32_t slot, se3d_reproj_out *out);
 
 /* --- row M as a stand-alone entry: drop-in for HungarianAlgorithm::assignmentoptimal (Hungarian.cpp:60) on the GPU.
  * dist is column-major [row + n_rows*col] (host memory), n_rows, n_cols <= 256; assignment[row] = col or -1. */

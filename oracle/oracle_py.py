@@ -92,6 +92,33 @@ def triangulate(rig, params, frame, capacity=None, hyp_capacity=None, omp_thread
     return res
 
 
+STAT_NAMES = ["sweep_hungarian", "spawn_unmasked", "outlier3_removed", "outlier_loo_removed", "score_downweighted", "nan_covariance",
+              "root_dist_reset", "feet_reject", "person_rejected", "duplicate_merge", "empty_frame", "track_assoc_rejected", "track_timeout",
+              "joint_vanished", "lm_failed", "marginals_failed", "track_merge", "id_rewrite"]   # enum order of se3d_oracle.h
+
+
+def stats_reset():
+    lib().se3d_oracle_stats_reset()
+
+
+def stats():
+    """Branch counters since the last stats_reset(): dict name -> count."""
+    out = np.zeros(len(STAT_NAMES), np.int64)
+    lib().se3d_oracle_stats_get(out.ctypes.data_as(C.POINTER(C.c_int64)))
+    return dict(zip(STAT_NAMES, (int(v) for v in out)))
+
+
+def triangulate_assoc(rig, params, frame, assoc):
+    """Config 2: rows N, T, P, O, U with the association given.  assoc [n_hyp][n_cam] original detection indices or -1."""
+    assoc = np.ascontiguousarray(assoc, np.int32).reshape(-1, rig.n_cam)
+    out = np.zeros(len(assoc), pm.person3d_dt)
+    fin = frame.as_c()
+    rc = lib().se3d_oracle_triangulate_assoc(C.byref(_rig_c(rig)), C.byref(params), C.byref(fin), len(assoc), pm.iptr(assoc), C.c_void_p(out.ctypes.data))
+    if rc != 0:
+        raise RuntimeError("se3d_oracle_triangulate_assoc failed: %d" % rc)
+    return out
+
+
 def dlt(Rt, pts, weight=True):
     Rt = np.ascontiguousarray(Rt, np.float32).reshape(-1, 12)
     pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)

@@ -21,7 +21,13 @@
 #include <omp.h>
 #endif
 
+#include <atomic>
+
 namespace {
+
+// Branch counters (se3d_oracle_stats_*): every data-dependent branch of the reference that a test must PROVE it exercised bumps one.
+std::atomic<long long> g_stat[SE3D_ORACLE_STAT_COUNT];
+inline void stat(int i, long long n = 1) { g_stat[i].fetch_add(n, std::memory_order_relaxed); }
 
 // ------------------------------------------------------------------------------------------------------------
 // constants (row K)
@@ -580,11 +586,13 @@ void calc_covariance(float cov[9], const V3f &mean_sample, const std::vector<V3f
   for (float &w : weights) w /= (2.0f * (dim + kappa));
   std::vector<std::vector<V3f>> sigma_points(num_samples, pts);
   const float b = std::sqrt(dim + kappa);
+  bool not_spd = false;
   for (int c = 0; c < num_cameras; ++c) {
     const M2f &A = covs[c];
     const float l11 = std::sqrt(A.a00);
     const float l21 = A.a10 / l11;
     const float l22 = std::sqrt(A.a11 - l21 * l21);
+    if (!(std::isfinite(l11) && std::isfinite(l21) && std::isfinite(l22))) not_spd = true;
     const float dx1 = l11 * b, dy1 = l21 * b, dy2 = l22 * b;
     sigma_points[4 * c + 1][c].x -= dx1;
     sigma_points[4 * c + 1][c].y -= dy1;
@@ -592,6 +600,13 @@ void calc_covariance(float cov[9], const V3f &mean_sample, const std::vector<V3f
     sigma_points[4 * c + 3][c].x += dx1;
     sigma_points[4 * c + 3][c].y += dy1;
     sigma_points[4 * c + 4][c].y += dy2;
+  }
+  if (not_spd) {
+    // DEFINED POLICY (the reference is undefined here): mod_samples takes square roots of the 2-D covariance entries
+    // (S3D:473-475), so a view whose keypoint covariance is not SPD yields NaN sigma points, and what Eigen's JacobiSVD returns for a NaN
+    // matrix is unspecified.  This library defines: the joint keeps its position and score, all entries of its 3-D covariance are NaN.
+    for (int i = 0; i < 9; ++i) cov[i] = std::numeric_limits<float>::quiet_NaN();
+    return;
   }
   std::vector<V3f> centered(num_samples);
   for (int s = 0; s < num_samples; ++s) {
@@ -645,11 +660,12 @@ void merge_persons(se3d_person3d &p1, const se3d_person3d &p2) {  // S3D:410-423
   }
 }
 
-// per-hypothesis body of the OpenMP loop (S3D:681-975).  Returns true if the person is published.
-bool triangulate_hypothesis(const PersonHypothesis &hyp, const ModelTables &T, const float *Fs, int n_cam, se3d_person3d &person_3d) {
+// per-hypothesis body of the OpenMP loop, first half (S3D:681-857): per-joint triangulation, outlier rejection, unscented covariance,
+// scatter into the 21-slot fusion layout.  Returns the number of triangulated joints, -1 if the hypothesis has < 2 views.
+int triangulate_joints(const PersonHypothesis &hyp, const ModelTables &T, const float *Fs, int n_cam, se3d_person3d &person_3d) {
   std::memset(&person_3d, 0, sizeof(person_3d));
   const int n_obs = (int)hyp.cameraIDs.size();
-  if (n_obs < 2) return false;
+  if (n_obs < 2) return -1;
   int num_valid_keypoints = 0;
   for (int kp_idx = 0; kp_idx < NKP; ++kp_idx) {
     std::vector<V3f> jointOnEachCamera;
@@ -695,6 +711,7 @@ bool triangulate_hypothesis(const PersonHypothesis &hyp, const ModelTables &T, c
         if (squared_symm_dist < bestDist) { bestDist = squared_symm_dist; bestIndex = i; }
       }
       if (bestIndex != -1) {
+        stat(SE3D_ORACLE_STAT_OUTLIER3_REMOVED);
         cameraMatrices.erase(cameraMatrices.begin() + bestIndex);
         jointOnEachCamera.erase(jointOnEachCamera.begin() + bestIndex);
         covarianceOnEachCamera.erase(covarianceOnEachCamera.begin() + bestIndex);
@@ -724,6 +741,7 @@ bool triangulate_hypothesis(const PersonHypothesis &hyp, const ModelTables &T, c
         }
       }
       if (bestReprojectionIndex != -1) {
+        stat(SE3D_ORACLE_STAT_OUTLIER_LOO_REMOVED);
         cameraMatrices.erase(cameraMatrices.begin() + bestReprojectionIndex);
         jointOnEachCamera.erase(jointOnEachCamera.begin() + bestReprojectionIndex);
         covarianceOnEachCamera.erase(covarianceOnEachCamera.begin() + bestReprojectionIndex);
@@ -733,7 +751,7 @@ bool triangulate_hypothesis(const PersonHypothesis &hyp, const ModelTables &T, c
         avg_score = bestScore;
       }
     }
-    if (reprojError > g_reproj_error_max_acceptable) avg_score *= (g_reproj_error_max_acceptable / reprojError);  // S3D:840-844
+    if (reprojError > g_reproj_error_max_acceptable) { avg_score *= (g_reproj_error_max_acceptable / reprojError); stat(SE3D_ORACLE_STAT_SCORE_DOWNWEIGHTED); }  // S3D:840-844
 
     float covariance[9];
     calc_covariance(covariance, reconstructedPoint, jointOnEachCamera, covarianceOnEachCamera, cameraMatrices);
@@ -745,9 +763,14 @@ bool triangulate_hypothesis(const PersonHypothesis &hyp, const ModelTables &T, c
     kp.score = avg_score;
     kp.cov[0] = covariance[0]; kp.cov[1] = covariance[1]; kp.cov[2] = covariance[2];  // setKeypointCovariance (S3D:255-262)
     kp.cov[3] = covariance[4]; kp.cov[4] = covariance[5]; kp.cov[5] = covariance[8];
+    if (covariance[0] != covariance[0]) stat(SE3D_ORACLE_STAT_NAN_COVARIANCE);  // non-SPD 2-D keypoint covariance: sqrt of a negative (S3D:473-475)
     ++num_valid_keypoints;
   }
+  return num_valid_keypoints;
+}
 
+// second half (S3D:861-973): plausibility post-processing.  Returns true if the person is published.
+bool post_filter(se3d_person3d &person_3d, const ModelTables &T, int num_valid_keypoints) {
   for (int kp_idx = 0; kp_idx < NKP; ++kp_idx) {  // limb-length covariance inflation (S3D:861-883)
     auto &kp = person_3d.keypoints[T.kp2fusion[kp_idx]];
     if (kp.score <= 0) continue;
@@ -780,7 +803,7 @@ bool triangulate_hypothesis(const PersonHypothesis &hyp, const ModelTables &T, c
       auto &kp = person_3d.keypoints[k];
       if (kp.score > 0) {
         double joint_dist = calcJointDist(root.joint, kp.joint);
-        if (joint_dist > g_max_joint_dist_to_root) { std::memset(&kp, 0, sizeof(kp)); --num_valid_keypoints; }
+        if (joint_dist > g_max_joint_dist_to_root) { std::memset(&kp, 0, sizeof(kp)); --num_valid_keypoints; stat(SE3D_ORACLE_STAT_ROOT_DIST_RESET); }
       } else {
         std::memset(&kp, 0, sizeof(kp));
         --num_valid_keypoints;
@@ -792,8 +815,15 @@ bool triangulate_hypothesis(const PersonHypothesis &hyp, const ModelTables &T, c
     feet_height = (person_3d.keypoints[F_LAnkle].joint[2] + person_3d.keypoints[F_RAnkle].joint[2]) / 2.0;
   else if (person_3d.keypoints[F_LAnkle].score > 0) feet_height = person_3d.keypoints[F_LAnkle].joint[2];
   else if (person_3d.keypoints[F_RAnkle].score > 0) feet_height = person_3d.keypoints[F_RAnkle].joint[2];
-  if (std::abs(feet_height) > 0.50) num_valid_keypoints = 0;
+  if (std::abs(feet_height) > 0.50) { num_valid_keypoints = 0; stat(SE3D_ORACLE_STAT_FEET_REJECT); }
+  if (!(num_valid_keypoints > g_min_num_valid_keypoints)) stat(SE3D_ORACLE_STAT_PERSON_REJECTED);
   return num_valid_keypoints > g_min_num_valid_keypoints;  // S3D:968
+}
+
+bool triangulate_hypothesis(const PersonHypothesis &hyp, const ModelTables &T, const float *Fs, int n_cam, se3d_person3d &person_3d) {
+  const int n = triangulate_joints(hyp, T, Fs, n_cam, person_3d);
+  if (n < 0) return false;
+  return post_filter(person_3d, T, n);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1315,6 +1345,7 @@ int se3d_oracle_triangulate(const se3d_rig *rig, const se3d_params *params, cons
     }
     if (ambiguous) {
       double cost = 0.0;
+      stat(SE3D_ORACLE_STAT_SWEEP_HUNGARIAN);
       hungarian(assignment.data(), &cost, C.data(), n_hyp, n_det);
     }
     auto new_hyp_from_det = [&](int det_idx) {
@@ -1333,6 +1364,7 @@ int se3d_oracle_triangulate(const se3d_rig *rig, const se3d_params *params, cons
       if (det_idx >= 0) {
         det_handled[det_idx] = 1;
         if (!mask[hyp_idx + (size_t)n_hyp * det_idx]) {
+          stat(SE3D_ORACLE_STAT_SPAWN_UNMASKED);
           new_hyp_from_det(det_idx);
         } else {
           PersonHypothesis &h = H[hyp_idx];
@@ -1381,6 +1413,7 @@ int se3d_oracle_triangulate(const se3d_rig *rig, const se3d_params *params, cons
   for (size_t i = 0; i < list.size(); ++i)  // S3D:984-996
     for (size_t j = i + 1; j < list.size();) {
       if (calc_3D_dist(list[i], list[j]) < g_merge_dist_thresh) {
+        stat(SE3D_ORACLE_STAT_DUPLICATE_MERGE);
         merge_persons(list[i], list[j]);
         list.erase(list.begin() + j);
         list_hyp.erase(list_hyp.begin() + j);
@@ -1397,6 +1430,44 @@ int se3d_oracle_triangulate(const se3d_rig *rig, const se3d_params *params, cons
 }
 
 // ---------------- stage 2 ----------------
+// Config 2 of SURVEY 8d: rows N, T, P, O, U with the association GIVEN (no sweep, no post-processing, no merge).
+int se3d_oracle_triangulate_assoc(const se3d_rig *rig, const se3d_params *params, const se3d_frame_in *frame, int32_t n_hyp,
+                                  const int32_t *assoc, se3d_person3d *persons_out) {
+  if (!rig || !params || !frame || !assoc || !persons_out || n_hyp < 0) return SE3D_ERR_ARG;
+  const int N = rig->n_cam;
+  if (frame->n_cam != N) return SE3D_ERR_ARG;
+  const ModelTables T = tables_for(params->pose_method);
+  for (int h = 0; h < n_hyp; ++h) {
+    PersonHypothesis hyp;
+    for (int c = 0; c < N; ++c) {  // ascending camera order = the order the sweep attaches views in (S3D:588)
+      const int det = assoc[(size_t)h * N + c];
+      if (det < 0) continue;
+      if (det >= frame->det_offset[c + 1] - frame->det_offset[c]) return SE3D_ERR_ARG;
+      const se3d_person2d &human = frame->persons[frame->det_offset[c] + det];
+      std::array<V3f, NKP> kps;
+      kps.fill(V3f{0.f, 0.f, -1.f});
+      std::array<M2f, NKP> covs;
+      covs.fill(M2f{0, 0, 0, 0});
+      if (normalize_keypoints(kps, covs, rig->K + 4 * (size_t)c, human) <= NKP / 2) continue;  // the sweep never attaches such a detection (S3D:579, 599)
+      hyp.cameraExtrinsics.push_back(rig->Rt + 12 * (size_t)c);
+      hyp.cameraIDs.push_back(c);
+      hyp.score.push_back(human.score);
+      hyp.detIdx.push_back(det);
+      hyp.keypoints_normalized.push_back(kps);
+      hyp.keypoints_cov_normalized.push_back(covs);
+    }
+    triangulate_joints(hyp, T, rig->F, N, persons_out[h]);
+  }
+  return SE3D_OK;
+}
+
+void se3d_oracle_stats_reset(void) {
+  for (auto &c : g_stat) c.store(0);
+}
+void se3d_oracle_stats_get(int64_t *out) {
+  for (int i = 0; i < SE3D_ORACLE_STAT_COUNT; ++i) out[i] = (int64_t)g_stat[i].load();
+}
+
 se3d_oracle_pp *se3d_oracle_pp_create(const se3d_params *params) {
   if (!params) return nullptr;
   se3d_oracle_pp *pp = new se3d_oracle_pp();
@@ -1434,11 +1505,13 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
   out->pred_delta_t = (float)pred_delta_t;
 
   auto remove_old_tracks = [&]() {  // PP:191-211
+    for (const auto &tr : g_tracks) if (t - tr.t_prev > g_t_max_unobserved) stat(SE3D_ORACLE_STAT_TRACK_TIMEOUT);
     g_tracks.erase(std::remove_if(g_tracks.begin(), g_tracks.end(), [&](const TrackingHypothesis &tr) { return t - tr.t_prev > g_t_max_unobserved; }),
                    g_tracks.end());
   };
   const int n_hyp = (int)g_tracks.size();
   if (n_det == 0) {  // PP:537-546
+    stat(SE3D_ORACLE_STAT_EMPTY_FRAME);
     remove_old_tracks();
     pp->t_prev = t;
     out->n_tracks = (int)g_tracks.size();
@@ -1454,7 +1527,7 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
       for (int p = 0; p < n_det; ++p) C[p + (size_t)n_det * tr] = g_tracks[tr].calc_normed_dist(dets[p], t);
     hungarian(assignment.data(), &cost, C.data(), n_det, n_hyp);
     for (int i = 0; i < n_det; ++i)
-      if (assignment[i] >= 0 && C[i + (size_t)n_det * assignment[i]] > g_dist_threshold) assignment[i] = -1;
+      if (assignment[i] >= 0 && C[i + (size_t)n_det * assignment[i]] > g_dist_threshold) { assignment[i] = -1; stat(SE3D_ORACLE_STAT_TRACK_ASSOC_REJECTED); }
   }
   std::vector<int> track_ids(n_det);
   for (int p = 0; p < n_det; ++p) {  // PP:570-580
@@ -1571,6 +1644,7 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
       for (const auto &kv : curr_track.prevEstimate)
         if (!measurements.count(kv.first)) keys_to_remove.push_back(kv.first);
       for (int key : keys_to_remove) {
+        stat(SE3D_ORACLE_STAT_JOINT_VANISHED);
         curr_track.prevEstimate.erase(key);
         for (auto &v : curr_track.velBuffer[key]) v = V3d{0, 0, 0};
       }
@@ -1584,11 +1658,12 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
     Values result;
     int iters = 0;
     if (whiten_ok) result = lm_optimize(graph, curr_track.prevEstimate, &iters, nullptr);
-    else result = measurements;  // optimisation failed -> output measurements (PP:751-758)
+    else { result = measurements; stat(SE3D_ORACLE_STAT_LM_FAILED); }  // optimisation failed -> output measurements (PP:751-758)
     lm_iters[person_idx] = iters;
 
     std::map<int, std::array<double, 9>> marg;
     bool use_marginals = whiten_ok && marginal_covariances(graph, result, marg);  // PP:760-767
+    if (!use_marginals) stat(SE3D_ORACLE_STAT_MARGINALS_FAILED);  // -> default covariance (PP:788-793)
 
     for (const auto &kv : result) {  // PP:770-837
       const int k = kv.first;
@@ -1661,8 +1736,9 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
       if (g_tracks[i].calc_3d_dist(g_tracks[j]) < g_merge_dist_thresh) {
         const int id_to_remove = g_tracks[j].id;
         g_tracks.erase(g_tracks.begin() + j);
+        stat(SE3D_ORACLE_STAT_TRACK_MERGE);
         for (int p = 0; p < out->n_persons; ++p)
-          if ((int)out->fused[p].id == id_to_remove) { out->fused[p].id = g_tracks[i].id; out->fused_pred[p].id = g_tracks[i].id; }
+          if ((int)out->fused[p].id == id_to_remove) { out->fused[p].id = g_tracks[i].id; out->fused_pred[p].id = g_tracks[i].id; stat(SE3D_ORACLE_STAT_ID_REWRITE); }
       } else
         ++j;
     }

@@ -41,6 +41,38 @@ double se3d_oracle_pair_cost(const float *F9, const float *kp_a /*[17][3]*/, con
 int se3d_oracle_triangulate(const se3d_rig *rig, const se3d_params *params, const se3d_frame_in *frame,
                             se3d_frame_out *out, int32_t omp_threads);
 
+/* Config 2 of SURVEY 8d — batched DLT with the association GIVEN: rows N (S3D:312-333), T (:440-465), P (:425-438), O (:748-844),
+ * U (:471-523) per hypothesis and joint, scattered into the 21-slot fusion layout (:849-857); no sweep, no post-processing, no merge.
+ * assoc: [n_hyp][n_cam] index into that camera's persons[] or -1; persons_out: [n_hyp]. */
+int se3d_oracle_triangulate_assoc(const se3d_rig *rig, const se3d_params *params, const se3d_frame_in *frame, int32_t n_hyp,
+                                  const int32_t *assoc, se3d_person3d *persons_out);
+
+/* Branch counters: how often each data-dependent branch of the reference fired since the last reset (process-wide).  The branch
+ * tests (tests/test_gpu_branches.py, tests/test_oracle_branches.py) assert > 0 so that a green parity test proves the branch ran. */
+enum {
+  SE3D_ORACLE_STAT_SWEEP_HUNGARIAN = 0,  /* ambiguous mask -> Hungarian on the unmasked C (S3D:628-634) */
+  SE3D_ORACLE_STAT_SPAWN_UNMASKED,       /* assigned but not feasible -> detection spawns a hypothesis (S3D:640-648) */
+  SE3D_ORACLE_STAT_OUTLIER3_REMOVED,     /* n == 3: camera dropped by the pairwise epipolar test (S3D:748-792) */
+  SE3D_ORACLE_STAT_OUTLIER_LOO_REMOVED,  /* n >= 4: leave-one-out re-triangulation kept (S3D:793-838) */
+  SE3D_ORACLE_STAT_SCORE_DOWNWEIGHTED,   /* still-large reprojection error (S3D:840-844) */
+  SE3D_ORACLE_STAT_NAN_COVARIANCE,       /* non-SPD 2-D covariance -> NaN 3-D covariance (S3D:473-475) */
+  SE3D_ORACLE_STAT_ROOT_DIST_RESET,      /* joint > 2 m from the root reset (S3D:937-953) */
+  SE3D_ORACLE_STAT_FEET_REJECT,          /* |feet height| > 0.5 m (S3D:955-966) */
+  SE3D_ORACLE_STAT_PERSON_REJECTED,      /* <= 9 valid joints left (S3D:968) */
+  SE3D_ORACLE_STAT_DUPLICATE_MERGE,      /* persons closer than 0.20 m merged (S3D:984-996) */
+  SE3D_ORACLE_STAT_EMPTY_FRAME,          /* pose_prior: no detections (PP:537-546) */
+  SE3D_ORACLE_STAT_TRACK_ASSOC_REJECTED, /* assignment with cost > 5.0 undone (PP:562-565) */
+  SE3D_ORACLE_STAT_TRACK_TIMEOUT,        /* track unobserved > 1 s removed (PP:191-211) */
+  SE3D_ORACLE_STAT_JOINT_VANISHED,       /* prevEstimate key erased, velocity buffer zeroed (PP:483-503) */
+  SE3D_ORACLE_STAT_LM_FAILED,            /* optimisation failed -> measurements (PP:751-758) */
+  SE3D_ORACLE_STAT_MARGINALS_FAILED,     /* indeterminate marginals -> 0.10^2 I (PP:788-793) */
+  SE3D_ORACLE_STAT_TRACK_MERGE,          /* tracks closer than 0.20 m merged (PP:870-903) */
+  SE3D_ORACLE_STAT_ID_REWRITE,           /* published id rewritten to the surviving track's (PP:892-899) */
+  SE3D_ORACLE_STAT_COUNT
+};
+void se3d_oracle_stats_reset(void);
+void se3d_oracle_stats_get(int64_t *out /* [SE3D_ORACLE_STAT_COUNT] */);
+
 /* pose_prior node state + callback (PP:505-921). */
 typedef struct se3d_oracle_pp se3d_oracle_pp;
 se3d_oracle_pp *se3d_oracle_pp_create(const se3d_params *params);

@@ -15,6 +15,8 @@ extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status
 extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled);
 extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev);
 extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st);
+extern "C" hipError_t se3d_stage1_init_device(void);
+extern "C" hipError_t se3d_stage2_init_device(void);
 
 #define SE3D_VERSION "se3d-hip 0.1.0 (gfx950)"
 
@@ -53,7 +55,12 @@ struct se3d_ctx {
   Se3dStage2 Q{};
   se3d_person3d *d_in2 = nullptr;  // [S][H] host-provided measurements (se3d_refine)
   int32_t *d_ndet2 = nullptr;      // [S]
-  float *d_fb = nullptr;           // [S][N] fb_delay of the staged frames / of se3d_refine
+  float *d_fb = nullptr;           // [S][N] fb_delay of the staged frames (resident path)
+  float *d_fb_ref = nullptr;       // [S][N] fb_delay rows of se3d_refine (host path): its own buffer, so mixing the two paths on one
+                                   // context cannot overwrite the staged batch's values
+  float *h_fb_ref = nullptr;
+  double *d_hung = nullptr;        // se3d_hungarian scratch: 256 x 256 cost matrix + assignment + status
+  int *d_hung_assign = nullptr;
   double *d_t = nullptr;           // [S]
   float *h_fb = nullptr;
   double *h_t = nullptr;                 // [kRing][S] ring: a slot is reused only after its H2D copy has completed
@@ -244,6 +251,13 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
   c->device = device_id;
   if (!hip_ok(c, hipSetDevice(device_id), "hipSetDevice")) { fprintf(stderr, "%s\n", c->err.c_str()); delete c; return nullptr; }
   if (!hip_ok(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return nullptr; }
+  // dynamic-LDS limits of the large-LDS kernels: a per-device attribute, so it is set for every context's device
+  if (!hip_ok(c, se3d_stage1_init_device(), "hipFuncSetAttribute (stage 1)") || !hip_ok(c, se3d_stage2_init_device(), "hipFuncSetAttribute (stage 2)")) {
+    fprintf(stderr, "se3d_create: %s\n", c->err.c_str());
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return nullptr;
+  }
   for (auto &set : c->ev)
     for (auto &e : set) (void)hipEventCreate(&e);
   Se3dDev &D = c->D;
@@ -284,10 +298,13 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     ok = ok && dev_alloc(c, &Q.fused, S * H) && dev_alloc(c, &Q.pred, S * H) && dev_alloc(c, &Q.iters, S * H) && dev_alloc(c, &Q.n_out, S);
     ok = ok && dev_alloc(c, &Q.flags2, S);
     ok = ok && dev_alloc(c, &c->d_in2, S * H) && dev_alloc(c, &c->d_ndet2, S) && dev_alloc(c, &c->d_fb, S * N) && dev_alloc(c, &c->d_t, S);
+    ok = ok && dev_alloc(c, &c->d_fb_ref, S * N) && dev_alloc(c, &c->d_hung, (size_t)SE3D_MUNKRES_MAX * SE3D_MUNKRES_MAX) &&
+         dev_alloc(c, &c->d_hung_assign, (size_t)SE3D_MUNKRES_MAX + 1);
     for (auto &set : c->ev2)
       for (auto &e : set) (void)hipEventCreate(&e);
     if (ok) {
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_fb, sizeof(float) * S * N, hipHostMallocDefault), "hipHostMalloc");
+      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_fb_ref, sizeof(float) * S * N, hipHostMallocDefault), "hipHostMalloc");
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_t, sizeof(double) * S * se3d_ctx::kRing, hipHostMallocDefault), "hipHostMalloc");
       for (auto &e : c->t_done) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_fused, sizeof(se3d_person3d) * S * H, hipHostMallocDefault), "hipHostMalloc");
@@ -345,6 +362,7 @@ void se3d_destroy(se3d_ctx *c) {
   if (c->h_outhyp) (void)hipHostFree(c->h_outhyp);
   if (c->h_outassoc) (void)hipHostFree(c->h_outassoc);
   if (c->h_fb) (void)hipHostFree(c->h_fb);
+  if (c->h_fb_ref) (void)hipHostFree(c->h_fb_ref);
   if (c->h_t) (void)hipHostFree(c->h_t);
   if (c->h_fused) (void)hipHostFree(c->h_fused);
   if (c->h_pred) (void)hipHostFree(c->h_pred);
@@ -399,7 +417,8 @@ int se3d_run_stage1(se3d_ctx *c) {
   if (!c) return SE3D_ERR_ARG;
   if (c->staged_frames < 1) { c->err = "no frames staged"; return SE3D_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
-  const Se3dDev &D = c->D;
+  Se3dDev D = c->D;
+  D.d.B = c->staged_frames;  // grids cover the staged frames only (array strides do not depend on B)
   // the per-frame workspace (assoc, nviews, nhyp, flags, hypP) is reset by se3d_k_normalize, the first kernel of the pass
   se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled);
   HIPCHK(c, hipGetLastError());
@@ -477,19 +496,14 @@ int se3d_hungarian(se3d_ctx *c, int32_t *assignment, double *cost, const double 
   for (int r = 0; r < nR; ++r) assignment[r] = -1;
   if (nR == 0 || nC == 0) return SE3D_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  double *d_dist = nullptr;
-  int *d_assign = nullptr, *d_status = nullptr;
-  HIPCHK(c, hipMalloc((void **)&d_dist, sizeof(double) * (size_t)nR * nC));
-  HIPCHK(c, hipMalloc((void **)&d_assign, sizeof(int) * (size_t)(nR + 1)));
-  d_status = d_assign + nR;
+  double *d_dist = c->d_hung;           // preallocated in the context (no allocation per call, nothing to leak on an error return)
+  int *d_assign = c->d_hung_assign, *d_status = d_assign + nR;
   HIPCHK(c, hipMemcpyAsync(d_dist, dist, sizeof(double) * (size_t)nR * nC, hipMemcpyHostToDevice, c->stream));
   const char *mv = getenv("SE3D_MUNKRES");  // A/B switch for the parity tests: block | wave | (automatic)
   se3d_launch_munkres(d_dist, d_assign, d_status, nR, nC, c->stream, (mv && strcmp(mv, "block") == 0) ? 1 : (mv && strcmp(mv, "wave") == 0) ? 2 : 0);
   std::vector<int> h(nR + 1);
   HIPCHK(c, hipMemcpyAsync(h.data(), d_assign, sizeof(int) * (size_t)(nR + 1), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_dist);
-  (void)hipFree(d_assign);
   if (h[nR] != 0) { c->err = "se3d_hungarian: iteration guard fired"; return SE3D_ERR_DEVICE; }
   for (int r = 0; r < nR; ++r) {
     assignment[r] = h[r];
@@ -562,19 +576,19 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
   HIPCHK(c, hipSetDevice(c->device));
   collect_profile(c);
   const size_t H = Q.H, N = Q.N;
-  for (size_t i = 0; i < N; ++i) c->h_fb[seq * N + i] = (fb_delay_per_cam && (int)i < n_cam) ? fb_delay_per_cam[i] : -1.0f;
+  for (size_t i = 0; i < N; ++i) c->h_fb_ref[seq * N + i] = (fb_delay_per_cam && (int)i < n_cam) ? fb_delay_per_cam[i] : -1.0f;
   double *ht = c->h_t + (size_t)c->t_head * Q.S;
   (void)hipEventSynchronize(c->t_done[c->t_head]);
   ht[0] = t;
   int32_t nd = n_det;
   if (n_det) HIPCHK(c, hipMemcpyAsync(c->d_in2 + seq * H, dets, sizeof(se3d_person3d) * (size_t)n_det, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_ndet2 + seq, &nd, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_fb + seq * N, c->h_fb + seq * N, sizeof(float) * N, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_fb_ref + seq * N, c->h_fb_ref + seq * N, sizeof(float) * N, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_t + seq, ht, sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipEventRecord(c->t_done[c->t_head], c->stream));
   c->t_head = (c->t_head + 1) % se3d_ctx::kRing;
   HIPCHK(c, hipStreamSynchronize(c->stream));  // nd is a stack variable
-  Q.dets = c->d_in2; Q.n_det = c->d_ndet2; Q.fb_delay = c->d_fb; Q.t = c->d_t;
+  Q.dets = c->d_in2; Q.n_det = c->d_ndet2; Q.fb_delay = c->d_fb_ref; Q.t = c->d_t;
   se3d_launch_stage2(Q, seq, 1, c->stream, next_ev2(c));
   HIPCHK(c, hipGetLastError());
   c->ran2 = true;
@@ -743,7 +757,8 @@ int se3d_reproject(se3d_ctx *c, int32_t n_persons, const se3d_person3d *persons,
   return reproject_fetch(c, out);
 }
 
-int se3d_reproject_resident(se3d_ctx *c, int32_t seq, se3d_reproj_out *out) {
+int se3d_reproject_resident(se3d_ctx *c, int32_t slot, se3d_reproj_out *out) {
+  const int seq = slot;  // result slot: the sequence index after se3d_run_stage2 / se3d_refine, the FRAME slot after se3d_run_stage2_walk
   if (!c || seq < 0 || seq >= c->Q.S) return SE3D_ERR_ARG;
   if (!c->rp_ready) { c->err = "se3d_reproject_resident: se3d_set_reprojection_cameras was not called"; return SE3D_ERR_STATE; }
   if (!c->ran2) { c->err = "se3d_reproject_resident: no stage-2 result"; return SE3D_ERR_STATE; }

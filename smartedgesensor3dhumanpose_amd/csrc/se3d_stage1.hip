@@ -522,7 +522,7 @@ __device__ __forceinline__ void se3d_sweep_assign_body(const Se3dDev &D, int b, 
       __syncthreads();
       rc = se3d_munkres_block(W, H, nh, nd, S, assign);
     }
-    if (rc != 0 && tid == 0) atomicOr(&D.flags[f], 4u);
+    if (rc != 0 && tid == 0) atomicOr(&D.flags[f], SE3D_FLAG_ASSIGNMENT_FAILED);
   }
   S1_STAMP(1)  // Hungarian (copy + Munkres)
   // attach or spawn (S3D:636-660)
@@ -1020,6 +1020,11 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX / err));  // S3D:840-841
 
   // ---- unscented transform (S3D:471-523): 4n+1 sigma points, each an unweighted re-triangulation ----
+  // Defined policy: a kept view whose 2x2 keypoint covariance is not SPD (NaN / inf Cholesky factor, S3D:473-475) makes
+  // all entries of the joint's 3-D covariance NaN; position and score are unaffected.
+  bool cov_bad = false;
+  for (int v = lane; v < n; v += 64) cov_bad |= !(isfinite(T.ca[v]) && isfinite(T.cb[v]) && isfinite(T.cc[v]));
+  cov_bad = __ballot(cov_bad) != 0ull;
   const int dim = 2 * n;
   const float bsc = sqrtf((float)dim + 0.5f);
   const float wgt = 1.0f / (2.0f * ((float)dim + 0.5f));  // all weights equal because 2*kappa == 1
@@ -1061,7 +1066,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
     }
   }
 #pragma unroll
-  for (int k = 0; k < 6; ++k) cv[k] = se3d_wave_sum(cv[k]);
+  for (int k = 0; k < 6; ++k) cv[k] = cov_bad ? (double)__builtin_nanf("") : se3d_wave_sum(cv[k]);
   if (lane == 0) {
     se3d_keypoint3d *kp = &D.hypP[(size_t)f * H + h].keypoints[c_kp2fusion[D.d.pose_method][j]];
     kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
@@ -1110,6 +1115,7 @@ struct TriHypLds {
   float X[TH_JOINTS], Y[TH_JOINTS], Z[TH_JOINTS];
   int cam[TH_MAXV], det[TH_MAXV];
   int n[TH_JOINTS];
+  int bad[TH_JOINTS];                                  // a usable view's 2x2 covariance is not SPD: the joint's 3-D covariance is NaN
   unsigned char vidx[TH_JOINTS][TH_MAXV];              // usable views of a joint in ascending camera order
 };
 
@@ -1154,9 +1160,14 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
   __builtin_amdgcn_wave_barrier();
   if (lane < JN) {
     int n = 0;
+    bool bad = false;
     for (int v = 0; v < nv; ++v)
-      if (S.cf[lane][v] >= 0.f) S.vidx[lane][n++] = (unsigned char)v;
+      if (S.cf[lane][v] >= 0.f) {
+        S.vidx[lane][n++] = (unsigned char)v;
+        bad |= !(isfinite(S.ca[lane][v]) && isfinite(S.cb[lane][v]) && isfinite(S.cc[lane][v]));
+      }
     S.n[lane] = n;
+    S.bad[lane] = bad ? 1 : 0;
   }
   __builtin_amdgcn_wave_barrier();
   // ---- Gram matrices: lanes over (joint, entry); accumulation over the views in list order like the per-joint kernel ----
@@ -1277,6 +1288,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
       if (__shfl(cnt, jj) == 0) continue;
       double acc = 0.0;
       for (int q = 0; q < LPJ; ++q) acc += part[jj * LPJ + q][e];
+      if (S.bad[jj]) acc = (double)__builtin_nanf("");
       person.keypoints[c_kp2fusion[pm_][jbase + jj]].cov[e] = (double)(float)acc;
     }
   }
@@ -1593,7 +1605,7 @@ __device__ __forceinline__ void se3d_sweep_assign_wave(const Se3dDev &D, int b, 
     if (lane < nh)
       for (int q = 0; q < nd; ++q) W[lane + nh * q] = C[lane + (size_t)H * q];
     const int rc = se3d_munkres_wave(W, nh, nh, nd, lane, assign);
-    if (rc != 0 && lane == 0) atomicOr(&D.flags[f], 4u);
+    if (rc != 0 && lane == 0) atomicOr(&D.flags[f], SE3D_FLAG_ASSIGNMENT_FAILED);
   }
   // attach or spawn (S3D:636-660)
   bool sp = false;
@@ -1667,6 +1679,12 @@ extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status
 // =============================================================================================================
 // host-side launch sequence
 // =============================================================================================================
+// Kernel attributes are per DEVICE in HIP: called by se3d_create for the context's device (after hipSetDevice), not once per process.
+extern "C" hipError_t se3d_stage1_init_device(void) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_assign), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+}
 extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, bool tiled) {
   const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H;
   if (ev) (void)hipEventRecord(ev[0], st);
@@ -1686,19 +1704,10 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   // Munkres working matrix in LDS when H*P doubles fit next to the static LDS of the kernel (<= 128 KB)
   int dynW = (int)((size_t)H * P * sizeof(double));
   if (dynW > 128 * 1024) dynW = 128 * 1024;
-  static bool assign_attr = false;
-  if (!assign_attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_assign), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    assign_attr = true;
-  }
+  // (the dynamic-LDS limits of se3d_k_sweep_assign / se3d_k_sweep_fused are raised per device by se3d_stage1_init_device)
   // A/B switches (read per launch so that the parity tests can compare the variants in one process):
   //   SE3D_SWEEP_FUSED_MAX = H*P up to which the one-launch 256-thread sweep is used (0 = never), SE3D_SWEEP_WAVE=0 disables the
   //   one-wavefront sweep
-  static bool fused_attr = false;
-  if (!fused_attr) {
-    fused_attr = true;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  }
   const char *e_fused = getenv("SE3D_SWEEP_FUSED_MAX"), *e_wave = getenv("SE3D_SWEEP_WAVE");
   const int fused_limit = e_fused ? atoi(e_fused) : 256;
   const int sweep_wave = e_wave ? atoi(e_wave) : 1;

@@ -2359,13 +2359,10 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
 }
 static_assert(S2_SCHUR_SCRATCH_DOUBLES == 1865, "se3d_api.hip allocates lm_scratch with this size");
 static_assert(S2_WALK_SEQS >= 1 && S2_WALK_SEQS <= S2_WALK_WAVES, "one association / lifecycle wavefront per sequence of the workgroup");
+#define S2_WALK_LDS_MAX (160 * 1024 - 4096)  // 160 KB per CU minus the kernel's static LDS
 template <bool TRIO, int WV, int SQ>
 static bool s2_launch_walk_shape(const Se3dStage2 &q, const Se3dWalk &Wk, int nseq, hipStream_t st) {
-  static int lds_max = -1;
-  if (lds_max < 0) {
-    lds_max = 160 * 1024 - 4096;  // 160 KB per CU minus the kernel's static LDS
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_stage2_walk<TRIO, WV, SQ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-  }
+  const int lds_max = S2_WALK_LDS_MAX;  // raised per device by se3d_stage2_init_device
   using WaveLds = typename std::conditional<TRIO, LmTrioLds, LmTreeLds>::type;
   const size_t tpos_bytes = (size_t)SQ * q.T * SE3D_NFU * 3 * sizeof(double);
   const size_t work_bytes = WV == 1 ? ((std::max(std::max(sizeof(WaveLds), tpos_bytes), (size_t)q.H * q.T * sizeof(double)) + 15) & ~(size_t)15)
@@ -2392,12 +2389,8 @@ extern "C" void se3d_diag_lm_stamps(unsigned long long *out16, int reset) {
 }
 #endif
 static int s2_lm_mode() {
-  static int lm_mode = -1;
-  if (lm_mode < 0) {
-    const char *e = getenv("SE3D_LM");  // A/B evidence switch: dense | schur | tree_mfma | tree (default)
-    lm_mode = (e && strcmp(e, "dense") == 0) ? 0 : (e && strcmp(e, "schur") == 0) ? 1 : (e && strcmp(e, "tree_mfma") == 0) ? 2 : 3;
-  }
-  return lm_mode;
+  const char *e = getenv("SE3D_LM");  // A/B evidence switch, read per launch: dense | schur | tree_mfma | tree (default)
+  return (e && strcmp(e, "dense") == 0) ? 0 : (e && strcmp(e, "schur") == 0) ? 1 : (e && strcmp(e, "tree_mfma") == 0) ? 2 : 3;
 }
 
 // true: the fused kernel was launched; false: not applicable (caller falls back to per-step launches)
@@ -2421,19 +2414,29 @@ extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk,
               : s2_launch_walk_shape<false, S2_WALK_WAVES, S2_WALK_SEQS>(q, Wk, nseq, st);
 }
 
+// Kernel attributes are per DEVICE in HIP: called by se3d_create for the context's device (after hipSetDevice), not once per process.
+extern "C" hipError_t se3d_stage2_init_device(void) {
+  const struct { const void *fn; int bytes; } attrs[] = {
+      {reinterpret_cast<const void *>(se3d_k_track_assoc), 128 * 1024},
+      {reinterpret_cast<const void *>(se3d_k_lm_refine<0>), (int)sizeof(LmLds)},
+      {reinterpret_cast<const void *>(se3d_k_lm_refine<1>), (int)sizeof(LmSchurLds)},
+      {reinterpret_cast<const void *>(se3d_k_lm_refine<2>), (int)sizeof(LmSchurLds)},
+      {reinterpret_cast<const void *>(se3d_k_lm_refine<3>), (int)sizeof(LmSchurLds)},
+      {reinterpret_cast<const void *>(se3d_k_stage2_walk<true, 1, 1>), S2_WALK_LDS_MAX},
+      {reinterpret_cast<const void *>(se3d_k_stage2_walk<true, S2_WALK_WAVES, S2_WALK_SEQS>), S2_WALK_LDS_MAX},
+      {reinterpret_cast<const void *>(se3d_k_stage2_walk<false, S2_WALK_WAVES, S2_WALK_SEQS>), S2_WALK_LDS_MAX},
+  };
+  for (const auto &a : attrs) {
+    const hipError_t e = hipFuncSetAttribute(a.fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.bytes);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev) {
   Se3dStage2 q = Q;
   q.seq0 = seq0;
   const int lm_mode = s2_lm_mode();
-  static bool attr_set = false;
-  if (!attr_set) {
-    attr_set = true;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_track_assoc), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmLds));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmSchurLds));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmSchurLds));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_lm_refine<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LmSchurLds));
-  }
   if (ev) (void)hipEventRecord(ev[0], st);
   int dynW = (int)((size_t)q.H * q.T * sizeof(double));
   if (dynW > 128 * 1024) dynW = 128 * 1024;

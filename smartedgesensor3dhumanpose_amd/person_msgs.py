@@ -13,7 +13,7 @@ NUM_FUSION_KEYPOINTS = 21
 POSE_SIMPLE, POSE_H36M = 0, 1
 S2FLAG_TRACK_OVERFLOW, S2FLAG_ASSIGNMENT_FAILED, S2FLAG_NOT_A_FOREST = 1, 4, 8   # se3d_fused_out.flags (sticky per sequence)
 
-FLAG_HYP_OVERFLOW, FLAG_FEW_CAMERAS = 1, 2
+FLAG_HYP_OVERFLOW, FLAG_FEW_CAMERAS, FLAG_ASSIGNMENT_FAILED = 1, 2, 4
 
 keypoint2d_dt = np.dtype([("x", "<f4"), ("y", "<f4"), ("score", "<f4"), ("cov", "<f4", (3,))])
 person2d_dt = np.dtype([("score", "<f4"), ("bbox", "<f4", (4,)), ("keypoints", keypoint2d_dt, (NUM_KEYPOINTS,))])

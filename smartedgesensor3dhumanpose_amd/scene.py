@@ -5,6 +5,7 @@ substitute input for every config of BASELINE.json.  Output is the exact input o
 (skeleton_3d_triang_mult_node.cpp:525): one ragged list of Person2D per camera and frame.
 """
 from dataclasses import dataclass
+from typing import Optional
 
 import numpy as np
 
@@ -57,6 +58,11 @@ class SceneConfig:
     joint_jitter: float = 0.005
     t0: float = 100.0
     shuffle: bool = True           # random per-camera detection order
+    # explicit scene layout for the branch tests (None: seeded random placement as above)
+    positions: Optional[np.ndarray] = None     # [P,2] ground positions
+    yaws: Optional[np.ndarray] = None          # [P]
+    velocities: Optional[np.ndarray] = None    # [P,2] m/s
+    joint_offset: Optional[np.ndarray] = None  # [P,17,3] added to the body-frame joints after rotation (e.g. a wrist 2.5 m away, a person 0.6 m above ground)
 
 
 def _place_persons(rig, n_persons, rng, spacing, min_coverage):
@@ -102,15 +108,21 @@ def generate_sequence(rig, cfg: SceneConfig):
     """Returns (frames, gt): frames = list of person_msgs.Frame; gt = dict with ground truth for analysis."""
     rng = np.random.default_rng(cfg.seed)
     P, T, N = cfg.n_persons, cfg.n_frames, rig.n_cam
-    pos = _place_persons(rig, P, rng, cfg.spacing, cfg.min_coverage)
+    pos = _place_persons(rig, P, rng, cfg.spacing, cfg.min_coverage) if cfg.positions is None else np.asarray(cfg.positions, np.float64).reshape(P, 2)
     yaw = rng.uniform(0, 2 * np.pi, P)
     speed = rng.uniform(0, cfg.max_speed, P)
     heading = rng.uniform(0, 2 * np.pi, P)
     vel = np.stack([speed * np.cos(heading), speed * np.sin(heading)], 1)
+    if cfg.yaws is not None:
+        yaw = np.asarray(cfg.yaws, np.float64).reshape(P)
+    if cfg.velocities is not None:
+        vel = np.asarray(cfg.velocities, np.float64).reshape(P, 2)
     cy, sy = np.cos(yaw), np.sin(yaw)
     Rz = np.zeros((P, 3, 3))
     Rz[:, 0, 0], Rz[:, 0, 1], Rz[:, 1, 0], Rz[:, 1, 1], Rz[:, 2, 2] = cy, -sy, sy, cy, 1.0
     body = np.einsum("pij,kj->pki", Rz, CANONICAL)  # [P,17,3]
+    if cfg.joint_offset is not None:
+        body = body + np.asarray(cfg.joint_offset, np.float64).reshape(P, NUM_KEYPOINTS, 3)
     frames, gt_joints, gt_ids = [], [], []
     for f in range(T):
         base = np.concatenate([pos + vel * (f * cfg.dt), np.zeros((P, 1))], 1)
@@ -136,18 +148,22 @@ def generate_sequence(rig, cfg: SceneConfig):
             if cfg.shuffle:
                 idx = rng.permutation(idx)
             arr = np.zeros(len(idx), person2d_dt)
-            for k, p in enumerate(idx):
-                v = vis[c, p]
-                kp = arr[k]["keypoints"]
-                kp["x"] = np.where(v, uv[c, p, :, 0], 0.0)
-                kp["y"] = np.where(v, uv[c, p, :, 1], 0.0)
-                kp["score"] = np.where(v, score[c, p], 0.0)
-                kp["cov"][:, 0] = np.where(v, s2, 0.0)
-                kp["cov"][:, 1] = np.where(v, rho[c, p] * s2, 0.0)
-                kp["cov"][:, 2] = np.where(v, s2, 0.0)
-                arr[k]["score"] = kp["score"][v].mean() if v.any() else 0.0
-                if v.any():
-                    arr[k]["bbox"] = (kp["x"][v].min(), kp["y"][v].min(), kp["x"][v].max(), kp["y"][v].max())
+            if len(idx):  # all detections of the camera at once (256 cameras x 128 persons: 32 k detections per frame)
+                v = vis[c, idx]                      # [n, 17]
+                kp = arr["keypoints"]
+                kp["x"] = np.where(v, uv[c, idx, :, 0], 0.0)
+                kp["y"] = np.where(v, uv[c, idx, :, 1], 0.0)
+                kp["score"] = np.where(v, score[c, idx], 0.0)
+                kp["cov"][..., 0] = np.where(v, s2, 0.0)
+                kp["cov"][..., 1] = np.where(v, rho[c, idx] * s2, 0.0)
+                kp["cov"][..., 2] = np.where(v, s2, 0.0)
+                big = np.float32(3e38)
+                xs, ys = kp["x"], kp["y"]
+                bbox = np.stack([np.where(v, xs, big).min(1), np.where(v, ys, big).min(1), np.where(v, xs, -big).max(1), np.where(v, ys, -big).max(1)], 1)
+                anyv = v.any(1)
+                arr["bbox"] = np.where(anyv[:, None], bbox, 0.0)
+                for k in np.nonzero(anyv)[0]:        # float32 mean over the visible joints only (summation order of the compacted array)
+                    arr[k]["score"] = kp["score"][k][v[k]].mean()
             persons.append(arr)
             ids.append(idx)
             det_offset[c + 1] = det_offset[c] + len(idx)

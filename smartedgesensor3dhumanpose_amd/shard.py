@@ -1,4 +1,5 @@
-"""Multi-GPU sharding of the path: ranks own disjoint sets of independent sequences (stage 1 is stateless per
+"""Multi-GPU sharding of the path (the reference axes are its OpenMP loops over hypotheses S3D:676-681 and detections
+PP:582-587): ranks own disjoint sets of independent sequences (stage 1 is stateless per
 frame, stage-2 track state is per sequence, so no data-path collective is needed); the only exchange is the all-gather
 of the final 3D skeletons so that every rank (in particular the publisher, rank 0) holds all of them."""
 import numpy as np
@@ -47,3 +48,89 @@ def pack_host(results, max_hyp):
         cnt[s] = len(p)
         buf[s, : len(p)] = p
     return torch.from_numpy(buf.view(np.uint8).reshape(-1).copy()), torch.from_numpy(cnt)
+
+
+class SkeletonExchange:
+    """Stream-ordered, double-buffered all-gather of the final skeletons (the path's only exchange).
+
+    Every rank owns `n_ctx` contexts; context ci packs its results of a step into slice ci of a pack buffer
+    ([slice_person_bytes] bytes of se3d_person3d slots + [slice_counts] int32 counts) on ITS OWN stream, then `packed(ci)` records an
+    event; `exchange()` makes a dedicated exchange stream wait for the events of all contexts and enqueues ONE all-gather pair
+    (persons, counts) asynchronously, so there is no host synchronisation in a step.  The pack buffers are double-buffered and
+    `pack_target(ci)` makes context ci's stream wait (device side) for the collective that read the slice two steps earlier before
+    handing it out again.  `streams` = one torch stream per context (torch.cuda.ExternalStream of se3d_stream_handle); None on CPU
+    (gloo), where every call is synchronous and the ordering is trivially the program order.
+    Layout of a gathered buffer: [world][n_ctx][slice] — rank r's pack buffer verbatim at offset r * n_ctx * slice.
+    """
+
+    def __init__(self, dist, n_ctx, slice_person_bytes, slice_counts, device, streams=None):
+        self.dist, self.n_ctx, self.sp, self.sc = dist, int(n_ctx), int(slice_person_bytes), int(slice_counts)
+        self.world = dist.get_world_size()
+        self.cuda = streams is not None
+        self.streams = streams
+        self.xstream = torch.cuda.Stream() if self.cuda else None
+        self.packs = [torch.zeros(self.n_ctx * self.sp, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.cnts = [torch.zeros(self.n_ctx * self.sc, dtype=torch.int32, device=device) for _ in range(2)]
+        self.gath_p = [torch.empty(self.world * self.n_ctx * self.sp, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.gath_c = [torch.empty(self.world * self.n_ctx * self.sc, dtype=torch.int32, device=device) for _ in range(2)]
+        self.works = [None, None]
+        self.events = [None] * self.n_ctx
+        self.parity = 0
+        self.n_exchanges = 0
+
+    def pack_target(self, ci):
+        """(persons_u8, counts_i32) slices context ci may overwrite for the current step."""
+        p = self.parity
+        if self.works[p] is not None and self.cuda:
+            with torch.cuda.stream(self.streams[ci]):
+                for w in self.works[p]:
+                    w.wait()
+        return self.packs[p][ci * self.sp:(ci + 1) * self.sp], self.cnts[p][ci * self.sc:(ci + 1) * self.sc]
+
+    def packed(self, ci):
+        if self.cuda:
+            self.events[ci] = self.streams[ci].record_event()
+
+    def exchange(self):
+        """Enqueue the all-gather of the current pack buffers; returns the parity (buffer index) it used."""
+        p = self.parity
+        if self.cuda:
+            with torch.cuda.stream(self.xstream):
+                for ev in self.events:
+                    if ev is not None:
+                        self.xstream.wait_event(ev)
+                self.works[p] = (self.dist.all_gather_into_tensor(self.gath_p[p], self.packs[p], async_op=True),
+                                 self.dist.all_gather_into_tensor(self.gath_c[p], self.cnts[p], async_op=True))
+        else:
+            self.dist.all_gather_into_tensor(self.gath_p[p], self.packs[p])
+            self.dist.all_gather_into_tensor(self.gath_c[p], self.cnts[p])
+        self.parity ^= 1
+        self.n_exchanges += 1
+        return p
+
+    def finish(self):
+        """Host-side wait for all outstanding collectives (end of the timed region / before reading a gathered buffer)."""
+        for ws in self.works:
+            if ws is not None:
+                for w in ws:
+                    w.wait()
+        if self.cuda:
+            self.xstream.synchronize()
+
+    def gathered(self, p):
+        """Views of buffer p: persons [world][n_ctx][slice_person_bytes] uint8, counts [world][n_ctx][slice_counts] int32."""
+        return self.gath_p[p].view(self.world, self.n_ctx, self.sp), self.gath_c[p].view(self.world, self.n_ctx, self.sc)
+
+    def verify(self, p):
+        """True iff the gathered buffer p equals, on THIS rank, the concatenation of every rank's pack buffer: every rank contributes
+        a checksum of what it sent (sum of counts, byte sum of the persons), the checksums are all-gathered and compared with the
+        same sums over the received slices.  Call after finish(); collective (every rank must call it)."""
+        self.finish()
+        mine = torch.stack([self.cnts[p].to(torch.int64).sum(), self.packs[p].to(torch.int64).sum()]).to(self.packs[p].device)
+        allsums = torch.empty(self.world * 2, dtype=torch.int64, device=mine.device)
+        self.dist.all_gather_into_tensor(allsums, mine)
+        gp, gc = self.gathered(p)
+        got = torch.stack([gc.reshape(self.world, -1).to(torch.int64).sum(1), gp.reshape(self.world, -1).to(torch.int64).sum(1)], 1).reshape(-1)
+        r = self.dist.get_rank()
+        own_ok = torch.equal(gp[r].reshape(-1), self.packs[p]) and torch.equal(gc[r].reshape(-1), self.cnts[p])
+        return bool(torch.equal(allsums.cpu(), got.cpu())) and own_ok

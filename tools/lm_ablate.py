@@ -7,7 +7,7 @@ os.environ["SE3D_WALK_LM"] = "solo"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from smartedgesensor3dhumanpose_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "smartedgesensor3dhumanpose_amd", "libse3d_hip_diag.so")
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "tmp", "libse3d_hip_diag.so")
 import numpy as np
 import bench
 w = bench.WORKLOADS["16cam6p"]

@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from smartedgesensor3dhumanpose_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "smartedgesensor3dhumanpose_amd", "libse3d_hip_diag.so")
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "tmp", "libse3d_hip_diag.so")
 import bench
 wl = sys.argv[1] if len(sys.argv) > 1 else "256cam128p"
 w = bench.WORKLOADS[wl]
