@@ -160,6 +160,19 @@ int se3d_sync(se3d_ctx *ctx);
 void *se3d_stream_handle(se3d_ctx *ctx);
 int se3d_fetch_stage1(se3d_ctx *ctx, int32_t n_frames, se3d_frame_out *outs);
 
+/* --- config 2 of the benchmark: batched DLT triangulation with the association GIVEN -----------------
+ * Rows N (S3D:312-333), T (:440-465), P (:425-438), O (:748-844) and U (:471-523) per hypothesis and joint, scattered into the
+ * 21-slot fusion layout (:849-857): what the reference's per-hypothesis loop does before its plausibility filters, with the
+ * greedy sweep replaced by the caller's table.  assoc: [n_frames][n_hyp][n_cam] index into that camera's persons[] of the frame or
+ * -1 (the layout of se3d_frame_out.hyp_assoc); persons_out: [n_frames][n_hyp]; a joint with < 2 usable views and a hypothesis with
+ * < 2 views are default-constructed (score 0).  No post-processing (X), no merge (D). */
+int se3d_triangulate_assoc(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in *frames, int32_t n_hyp, const int32_t *assoc,
+                           se3d_person3d *persons_out);
+/* resident form: se3d_stage_frames, then se3d_stage_assoc once; se3d_run_dlt is asynchronous on the context stream */
+int se3d_stage_assoc(se3d_ctx *ctx, int32_t n_hyp, const int32_t *assoc);
+int se3d_run_dlt(se3d_ctx *ctx);
+int se3d_fetch_dlt(se3d_ctx *ctx, int32_t n_frames, se3d_person3d *persons_out);
+
 /* --- stage 2: drop-in for the pose_prior skeletonCallback body (PP:505-921) ----------------------------
  * The context holds n_seq independent sequences (each the global state of one pose_prior node: g_tracks,
  * g_fb_delay_buffer, g_frame_nr, g_t_prev, g_next_id; PP:54-60,123).  Sequence s consumes, per call, frame
@@ -226,7 +239,8 @@ int se3d_pack_stage2_device(se3d_ctx *ctx, int32_t n_seq, void *d_persons, void 
 int se3d_profile_enable(se3d_ctx *ctx, int32_t on);
 int se3d_profile_reset(se3d_ctx *ctx);
 /* name in {"normalize","epipolar_pairs","sweep","triangulate","postprocess","track_assoc","lm_refine",
- *          "track_update"}; returns accumulated ms and launch count ("sweep" = all cost+assign launches of a run) */
+ *          "track_update","stage2_walk","dlt"}; returns accumulated ms and launch count ("sweep" = all cost+assign launches of a run,
+ *          "dlt" = one se3d_run_dlt pass) */
 int se3d_profile_get(se3d_ctx *ctx, const char *name, double *ms_total, int64_t *launches);
 
 #ifdef __cplusplus

@@ -15,15 +15,16 @@ extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status
 extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled);
 extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev);
 extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st);
+extern "C" void se3d_launch_dlt(const Se3dDev &D, const int32_t *d_assoc_orig, int nh, hipStream_t st, hipEvent_t *ev);
 extern "C" hipError_t se3d_stage1_init_device(void);
 extern "C" hipError_t se3d_stage2_init_device(void);
 
 #define SE3D_VERSION "se3d-hip 0.1.0 (gfx950)"
 
 namespace {
-enum ProfSlot { PS_NORMALIZE = 0, PS_PAIRS, PS_SWEEP, PS_TRI, PS_POST, PS_ASSOC2, PS_LM, PS_UPDATE2, PS_WALK, PS_COUNT };
+enum ProfSlot { PS_NORMALIZE = 0, PS_PAIRS, PS_SWEEP, PS_TRI, PS_POST, PS_ASSOC2, PS_LM, PS_UPDATE2, PS_WALK, PS_DLT, PS_COUNT };
 const int kStage1Slots = 5, kStage2Slots = 3;
-const char *kProfNames[PS_COUNT] = {"normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess", "track_assoc", "lm_refine", "track_update", "stage2_walk"};
+const char *kProfNames[PS_COUNT] = {"normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess", "track_assoc", "lm_refine", "track_update", "stage2_walk", "dlt"};
 }  // namespace
 
 struct se3d_ctx {
@@ -48,6 +49,10 @@ struct se3d_ctx {
   bool prof = false;
   static constexpr int kRing = 96;       // event sets in flight before the oldest are harvested
   hipEvent_t ev[kRing][6]{};             // stage-1 sets
+  bool ev_dlt[kRing]{};                  // set brackets one config-2 pass (events 0 and 1 only)
+  int32_t *d_assoc_in = nullptr;         // [B][H][N] caller's association table (config 2, se3d_stage_assoc)
+  int dlt_hyp = 0;                       // hypotheses per frame of the staged table (0: none staged)
+  bool ran_dlt = false;
   int ev_head = 0, ev_pending = 0;
   double prof_ms[PS_COUNT]{};
   int64_t prof_n[PS_COUNT]{};
@@ -106,6 +111,13 @@ bool dev_alloc(se3d_ctx *c, T **p, size_t n) {
 void collect_profile(se3d_ctx *c, bool all = true) {
   while (c->ev_pending > 0 && (all || c->ev_pending >= se3d_ctx::kRing)) {
     const int idx = (c->ev_head - c->ev_pending + 2 * se3d_ctx::kRing) % se3d_ctx::kRing;
+    if (c->ev_dlt[idx]) {
+      float ms = 0.f;
+      (void)hipEventSynchronize(c->ev[idx][1]);
+      if (hipEventElapsedTime(&ms, c->ev[idx][0], c->ev[idx][1]) == hipSuccess) { c->prof_ms[PS_DLT] += ms; c->prof_n[PS_DLT] += 1; }
+      --c->ev_pending;
+      continue;
+    }
     (void)hipEventSynchronize(c->ev[idx][5]);
     for (int i = 0; i < kStage1Slots; ++i) {
       float ms = 0.f;
@@ -131,6 +143,7 @@ hipEvent_t *next_ev1(se3d_ctx *c) {
   if (!c->prof) return nullptr;
   collect_profile(c, false);
   hipEvent_t *e = c->ev[c->ev_head];
+  c->ev_dlt[c->ev_head] = false;
   c->ev_head = (c->ev_head + 1) % se3d_ctx::kRing;
   ++c->ev_pending;
   return e;
@@ -269,7 +282,7 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
   int32_t *dnraw = nullptr;
   ok = ok && dev_alloc(c, &dRt, (size_t)N * 12) && dev_alloc(c, &dK, (size_t)N * 4) && dev_alloc(c, &dF, (size_t)np * 9);
   ok = ok && dev_alloc(c, &draw, (size_t)B * N * P) && dev_alloc(c, &dnraw, (size_t)B * N);
-  ok = ok && dev_alloc(c, &D.kp, (size_t)B * N * P * SE3D_NKP) && dev_alloc(c, &D.kcov, (size_t)B * N * P * SE3D_NKP);
+  ok = ok && dev_alloc(c, &D.kp, (size_t)B * N * P * SE3D_NKP) && dev_alloc(c, &c->d_assoc_in, (size_t)B * H * N);
   ok = ok && dev_alloc(c, &D.pscore, (size_t)B * N * P) && dev_alloc(c, &D.vmask_gt, (size_t)B * N * P) && dev_alloc(c, &D.vmask_ge, (size_t)B * N * P);
   ok = ok && dev_alloc(c, &D.nvalid, (size_t)B * N) && dev_alloc(c, &D.orig, (size_t)B * N * P);
   ok = ok && dev_alloc(c, &D.pair, (size_t)B * np * P * P);
@@ -410,6 +423,8 @@ int se3d_stage_frames(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->staged_frames = n_frames;
   c->ran = false;
+  c->ran_dlt = false;
+  c->dlt_hyp = 0;
   return SE3D_OK;
 }
 
@@ -478,6 +493,57 @@ int se3d_triangulate_batch(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *f
 }
 
 int se3d_triangulate(se3d_ctx *c, const se3d_frame_in *frame, se3d_frame_out *out) { return se3d_triangulate_batch(c, 1, frame, out); }
+
+// ---- config 2: batched DLT triangulation + UT covariance with the association given --------------------------------
+int se3d_stage_assoc(se3d_ctx *c, int32_t n_hyp, const int32_t *assoc) {
+  if (!c || !assoc || n_hyp < 1) return SE3D_ERR_ARG;
+  if (c->staged_frames < 1) { c->err = "se3d_stage_assoc: no frames staged"; return SE3D_ERR_STATE; }
+  if (n_hyp > c->D.d.H) { c->err = "se3d_stage_assoc: n_hyp exceeds limits.max_hyp"; return SE3D_ERR_CAPACITY; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)c->staged_frames * n_hyp * c->D.d.N;
+  memcpy(c->h_outassoc, assoc, sizeof(int32_t) * n);  // pinned staging ([B][H][N] ints, shared with se3d_fetch_stage1)
+  HIPCHK(c, hipMemcpyAsync(c->d_assoc_in, c->h_outassoc, sizeof(int32_t) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->dlt_hyp = n_hyp;
+  c->ran_dlt = false;
+  return SE3D_OK;
+}
+
+int se3d_run_dlt(se3d_ctx *c) {
+  if (!c) return SE3D_ERR_ARG;
+  if (c->staged_frames < 1 || c->dlt_hyp < 1) { c->err = "se3d_run_dlt needs se3d_stage_frames + se3d_stage_assoc"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  Se3dDev D = c->D;
+  D.d.B = c->staged_frames;
+  hipEvent_t *ev = next_ev1(c);
+  if (ev) c->ev_dlt[(c->ev_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = true;
+  se3d_launch_dlt(D, c->d_assoc_in, c->dlt_hyp, c->stream, ev);
+  HIPCHK(c, hipGetLastError());
+  c->ran_dlt = true;
+  c->ran = false;  // the association workspace now holds the caller's table, not a sweep result
+  return SE3D_OK;
+}
+
+int se3d_fetch_dlt(se3d_ctx *c, int32_t n_frames, se3d_person3d *persons_out) {
+  if (!c || !persons_out || n_frames < 1) return SE3D_ERR_ARG;
+  if (!c->ran_dlt || n_frames > c->staged_frames) { c->err = "se3d_fetch_dlt before se3d_run_dlt"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t H = c->D.d.H, nh = c->dlt_hyp;
+  HIPCHK(c, hipMemcpy2DAsync(c->h_out, sizeof(se3d_person3d) * nh, c->D.hypP, sizeof(se3d_person3d) * H, sizeof(se3d_person3d) * nh, (size_t)n_frames,
+                             hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  collect_profile(c);
+  memcpy(persons_out, c->h_out, sizeof(se3d_person3d) * nh * (size_t)n_frames);
+  return SE3D_OK;
+}
+
+int se3d_triangulate_assoc(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames, int32_t n_hyp, const int32_t *assoc, se3d_person3d *persons_out) {
+  int rc = se3d_stage_frames(c, n_frames, frames);
+  if (rc != SE3D_OK) return rc;
+  if ((rc = se3d_stage_assoc(c, n_hyp, assoc)) != SE3D_OK) return rc;
+  if ((rc = se3d_run_dlt(c)) != SE3D_OK) return rc;
+  return se3d_fetch_dlt(c, n_frames, persons_out);
+}
 
 int se3d_pack_stage1_device(se3d_ctx *c, void *d_persons, void *d_counts) {
   if (!c || !d_persons || !d_counts) return SE3D_ERR_ARG;

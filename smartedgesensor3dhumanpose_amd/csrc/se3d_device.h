@@ -2,8 +2,8 @@
 //
 // HBM layout (B = frames per batch, N = cameras, P = max detections per camera, H = max hypotheses):
 //   raw      [B][N][P] se3d_person2d      caller's Person2D payloads, dense-padded            (428 B each)
-//   kp       [B][N][P][17] float4         normalised (x, y, conf, 0); filtered slot order     (row N)
-//   kcov     [B][N][P][17] float4         normalised 2x2 covariance (a00, a01, a11, 0)
+//   kp       [B][N][P][17] float4         normalised (x, y, conf, 0); filtered slot order     (row N; stand-alone pair kernels only —
+//                                         small rigs keep the normalised points in LDS, the triangulation normalises in registers)
 //   vmask    [B][N][P] uint32 x2          bit j: conf > 0.30 (calcCost gate) / conf >= 0.30 (triangulation gate)
 //   pair     [B][N(N-1)/2][P][P] double   pairwise mean symmetric epipolar distance, -1 = no joint in common  (row E)
 //   assoc    [B][H][N] int32              filtered detection slot of hypothesis h in camera c, or -1           (row G)
@@ -37,8 +37,7 @@ struct Se3dDev {
   const se3d_person2d *raw;  // [B][N][P]
   const int32_t *nraw;       // [B][N]
   // normalised
-  float4 *kp;         // [B][N][P][17]
-  float4 *kcov;       // [B][N][P][17]
+  float4 *kp;         // [B][N][P][17] normalised (x, y, conf, 0): written only when a stand-alone pair kernel runs (large P, A/B switches)
   float *pscore;      // [B][N][P]
   uint32_t *vmask_gt; // [B][N][P]
   uint32_t *vmask_ge; // [B][N][P]

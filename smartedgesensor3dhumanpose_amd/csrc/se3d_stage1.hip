@@ -47,7 +47,10 @@ extern "C" void se3d_diag_s1_stamps(unsigned long long *out16, int reset) {
 // row N — normalize_keypoints (S3D:312-333) + ">= 9 valid keypoints" filter (S3D:579, 599) with order-preserving
 // compaction of the surviving detections.  One workgroup per (camera, frame).
 // =============================================================================================================
-__global__ __launch_bounds__(256) void se3d_k_normalize(Se3dDev D) {
+// The per-frame workspace reset covers assoc / nviews / nhyp / flags only: the triangulation kernels write every field of the hypothesis
+// slots they own (round 1 zero-filled hypP here: 166 MB of stores per 8192-frame launch at 16 cameras x 6 persons).
+// write_kp = 0: masks / slots only (config 2, where no pair kernel reads the normalised points).
+__global__ __launch_bounds__(256) void se3d_k_normalize(Se3dDev D, int write_kp) {
   const int c = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   const int N = D.d.N, P = D.d.P;
   __shared__ int cnt[SE3D_MUNKRES_MAX];
@@ -56,12 +59,9 @@ __global__ __launch_bounds__(256) void se3d_k_normalize(Se3dDev D) {
   __shared__ int s_nvalid;
   const int n = min(D.nraw[f * N + c], P);
   for (int r = tid; r < P; r += blockDim.x) { cnt[r] = 0; mgt[r] = 0; mge[r] = 0; }
-  {  // per-frame workspace reset (was five memsets per pass): the N workgroups of a frame share the work
+  {  // per-frame workspace reset: the N workgroups of a frame share the work
     const int H = D.d.H;
     for (int h = tid; h < H; h += blockDim.x) D.assoc[((size_t)f * H + h) * N + c] = -1;
-    const size_t words = (size_t)H * (sizeof(se3d_person3d) / 4);
-    uint32_t *hp = reinterpret_cast<uint32_t *>(D.hypP + (size_t)f * H);
-    for (size_t w = (size_t)c * blockDim.x + tid; w < words; w += (size_t)N * blockDim.x) hp[w] = 0u;
     if (c == 0) {
       for (int h = tid; h < H; h += blockDim.x) D.nviews[f * H + h] = 0;
       if (tid == 0) { D.nhyp[f] = 0; D.flags[f] = 0u; }
@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256) void se3d_k_normalize(Se3dDev D) {
   const se3d_person2d *raw = D.raw + ((size_t)(f * N + c)) * P;
   for (int idx = tid; idx < n * SE3D_NKP; idx += blockDim.x) {
     const int det = idx / SE3D_NKP, j = idx - det * SE3D_NKP;
-    if (raw[det].keypoints[j].score >= TRI_THRESH) atomicAdd(&cnt[det], 1);
+    const float sc = raw[det].keypoints[j].score;
+    if (sc >= TRI_THRESH) {
+      atomicAdd(&cnt[det], 1);
+      atomicOr(&mge[det], 1u << j);
+      if (sc > TRI_THRESH) atomicOr(&mgt[det], 1u << j);
+    }
   }
   __syncthreads();
   if (tid == 0) {
@@ -82,29 +87,22 @@ __global__ __launch_bounds__(256) void se3d_k_normalize(Se3dDev D) {
   __syncthreads();
   const float fx = D.K[c * 4 + 0], fy = D.K[c * 4 + 1], cx = D.K[c * 4 + 2], cy = D.K[c * 4 + 3];
   const size_t base = ((size_t)(f * N + c)) * P;
-  for (int idx = tid; idx < n * SE3D_NKP; idx += blockDim.x) {
+  for (int idx = tid; write_kp && idx < n * SE3D_NKP; idx += blockDim.x) {
     const int det = idx / SE3D_NKP, j = idx - det * SE3D_NKP;
     const int k = slot[det];
     if (k < 0) continue;
     const se3d_keypoint2d kp = raw[det].keypoints[j];
-    float4 o = make_float4(0.f, 0.f, -1.f, 0.f), oc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kp.score >= TRI_THRESH) {
-      o = make_float4((kp.x - cx) / fx, (kp.y - cy) / fy, kp.score, 0.f);
-      oc = make_float4(kp.cov[0] / (fx * fx), kp.cov[1] / (fx * fy), kp.cov[2] / (fy * fy), 0.f);
-      atomicOr(&mge[k], 1u << j);
-      if (kp.score > TRI_THRESH) atomicOr(&mgt[k], 1u << j);
-    }
+    float4 o = make_float4(0.f, 0.f, -1.f, 0.f);
+    if (kp.score >= TRI_THRESH) o = make_float4((kp.x - cx) / fx, (kp.y - cy) / fy, kp.score, 0.f);
     D.kp[(base + k) * SE3D_NKP + j] = o;
-    D.kcov[(base + k) * SE3D_NKP + j] = oc;
   }
-  __syncthreads();
   for (int det = tid; det < n; det += blockDim.x) {
     const int k = slot[det];
     if (k >= 0) {
       D.pscore[base + k] = raw[det].score;
       D.orig[base + k] = det;
-      D.vmask_gt[base + k] = mgt[k];
-      D.vmask_ge[base + k] = mge[k];
+      D.vmask_gt[base + k] = mgt[det];
+      D.vmask_ge[base + k] = mge[det];
     }
   }
   if (tid == 0) D.nvalid[f * N + c] = s_nvalid;
@@ -195,6 +193,133 @@ __global__ __launch_bounds__(256) void se3d_k_pairs_packed(Se3dDev D, const int2
     const size_t ia = ((size_t)(f * N + ab.x)) * P + p, ib = ((size_t)(f * N + ab.y)) * P + q;
     const unsigned m = D.vmask_gt[ia] & D.vmask_gt[ib];
     D.pair[(((size_t)f * np + pr) * P + p) * P + q] = se3d_pair_cost(D.F + 9 * (size_t)pr, D.kp + ia * SE3D_NKP, D.kp + ib * SE3D_NKP, m);
+  }
+}
+
+// Small rigs (N * P <= 256): normalisation and the packed pair-cost table in ONE workgroup per frame.  The normalised points of the
+// frame's detections live only in LDS (float2 x, y per (camera, slot, joint): 35 KB at most) — the kp / kcov copies of round 1 (two
+// float4 per joint: 428 MB of stores and 642 MB of loads per 8192-frame launch at 16 x 6) are gone; the triangulation kernels read the
+// caller's raw Person2D payload themselves.  Same float expressions as se3d_k_normalize / se3d_pair_cost -> identical table.
+#define NP_MAX_DETS 256
+__device__ __forceinline__ double se3d_pair_cost_lds(const float *__restrict__ F, const float2 *__restrict__ ka, const float2 *__restrict__ kb, unsigned m) {
+  double cost = 0.0;
+  int n = 0;
+  const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
+#pragma unroll
+  for (int k = 0; k < SE3D_NKP; ++k) {
+    if ((m >> k) & 1u) {
+      const float2 A = ka[k], Bq = kb[k];
+      const float p1x = A.x, p1y = A.y, p2x = Bq.x, p2y = Bq.y;
+      const float l1x = f0 * p1x + (f1 * p1y + f2);
+      const float l1y = f3 * p1x + (f4 * p1y + f5);
+      const float l1z = f6 * p1x + (f7 * p1y + f8);
+      const float l2x = f0 * p2x + (f3 * p2y + f6);
+      const float l2y = f1 * p2x + (f4 * p2y + f7);
+      const float l2z = f2 * p2x + (f5 * p2y + f8);
+      const float d1 = fabsf(p2x * l1x + (p2y * l1y + l1z)) / sqrtf(l1x * l1x + l1y * l1y);
+      const float d2 = fabsf(p1x * l2x + (p1y * l2y + l2z)) / sqrtf(l2x * l2x + l2y * l2y);
+      cost += (double)(d1 + d2);
+      ++n;
+    }
+  }
+  return n > 0 ? cost / n : -1.0;
+}
+
+__global__ __launch_bounds__(256) void se3d_k_normalize_pairs(Se3dDev D, const int2 *__restrict__ pair_ab) {
+  extern __shared__ __align__(16) unsigned char np_smem[];
+  const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float2 *skp = reinterpret_cast<float2 *>(np_smem);                       // [N * P][17] filtered slot order
+  unsigned *s_mgt = reinterpret_cast<unsigned *>(skp + (size_t)N * P * SE3D_NKP);  // [N * P] by filtered slot
+  int *s_slot = reinterpret_cast<int *>(s_mgt + N * P);                    // [N * P] by raw detection index: filtered slot or -1
+  int *s_nv = s_slot + N * P;                                              // [N]
+  int *s_cum = s_nv + N;                                                   // [np + 1]
+  __shared__ int s_part[4];
+  // ---- per-frame workspace reset (assoc, nviews, nhyp, flags) ----
+  for (int i = tid; i < H * N; i += 256) D.assoc[(size_t)f * H * N + i] = -1;
+  for (int h = tid; h < H; h += 256) D.nviews[f * H + h] = 0;
+  if (tid == 0) { D.nhyp[f] = 0; D.flags[f] = 0u; }
+  // ---- row N: valid-joint counts and masks, one thread per (camera, raw detection) ----
+  const int c = tid / P, det = tid - c * P;
+  const bool mine = tid < N * P && det < min(D.nraw[f * N + (c < N ? c : 0)], P);
+  unsigned mgt = 0u, mge = 0u;
+  const se3d_person2d *rp = D.raw + ((size_t)(f * N + (c < N ? c : 0))) * P + det;
+  if (mine) {
+#pragma unroll
+    for (int j = 0; j < SE3D_NKP; ++j) {
+      const float sc = rp->keypoints[j].score;
+      if (sc >= TRI_THRESH) { mge |= 1u << j; if (sc > TRI_THRESH) mgt |= 1u << j; }
+    }
+  }
+  const bool kept = mine && __popc(mge) > SE3D_NKP / 2;  // S3D:579, 599
+  if (tid < N * P) s_slot[tid] = kept ? 1 : 0;
+  __syncthreads();
+  int slot = -1;
+  if (kept) {  // order-preserving compaction within the camera
+    slot = 0;
+    for (int d2 = 0; d2 < det; ++d2) slot += s_slot[c * P + d2];
+  }
+  int nv = 0;
+  if (tid < N) for (int d2 = 0; d2 < P; ++d2) nv += s_slot[tid * P + d2];
+  __syncthreads();
+  if (tid < N * P) s_slot[tid] = slot;
+  if (tid < N) { s_nv[tid] = nv; D.nvalid[f * N + tid] = nv; }
+  if (kept) {
+    const size_t o = ((size_t)(f * N + c)) * P + slot;
+    D.pscore[o] = rp->score;
+    D.orig[o] = det;
+    D.vmask_gt[o] = mgt;
+    D.vmask_ge[o] = mge;
+    s_mgt[c * P + slot] = mgt;
+  }
+  __syncthreads();
+  // ---- normalised points of the kept detections into LDS ----
+  for (int idx = tid; idx < N * P * SE3D_NKP; idx += 256) {
+    const int cd = idx / SE3D_NKP, j = idx - cd * SE3D_NKP;
+    const int cc = cd / P, dd = cd - cc * P;
+    if (dd >= min(D.nraw[f * N + cc], P)) continue;
+    const int k = s_slot[cd];
+    if (k < 0) continue;
+    const se3d_keypoint2d *kp = &D.raw[((size_t)(f * N + cc)) * P + dd].keypoints[j];
+    const float sc = kp->score;
+    float2 o = make_float2(0.f, 0.f);
+    if (sc >= TRI_THRESH) {
+      const float fx = D.K[cc * 4 + 0], fy = D.K[cc * 4 + 1], cx = D.K[cc * 4 + 2], cy = D.K[cc * 4 + 3];
+      o = make_float2((kp->x - cx) / fx, (kp->y - cy) / fy);
+    }
+    skp[(size_t)(cc * P + k) * SE3D_NKP + j] = o;
+  }
+  // ---- exclusive prefix of n_a * n_b over the camera pairs ----
+  int carry = 0;
+  for (int base = 0; base < np; base += 256) {
+    const int pr = base + tid;
+    int v = 0;
+    if (pr < np) { const int2 ab = pair_ab[pr]; v = s_nv[ab.x] * s_nv[ab.y]; }
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_part[wave] = inc;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wave; ++w) off += s_part[w];
+    if (pr < np) s_cum[pr] = off + inc - v;
+    carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+  }
+  if (tid == 0) s_cum[np] = carry;
+  __syncthreads();
+  // ---- row E: the valid (det_a, det_b) entries of all camera pairs, densely over the threads ----
+  const int total = s_cum[np];
+  for (int e = tid; e < total; e += 256) {
+    int lo = 0, hi = np;  // largest pr with s_cum[pr] <= e
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cum[mid] <= e) lo = mid; else hi = mid; }
+    const int pr = lo;
+    const int2 ab = pair_ab[pr];
+    const int nb = s_nv[ab.y];
+    const int r = e - s_cum[pr];
+    const int p = r / nb, q = r - p * nb;
+    const int ia = ab.x * P + p, ib = ab.y * P + q;
+    const unsigned m = s_mgt[ia] & s_mgt[ib];
+    D.pair[(((size_t)f * np + pr) * P + p) * P + q] = se3d_pair_cost_lds(D.F + 9 * (size_t)pr, skp + (size_t)ia * SE3D_NKP, skp + (size_t)ib * SE3D_NKP, m);
   }
 }
 
@@ -800,6 +925,34 @@ __device__ __forceinline__ float se3d_reproj1(const float *__restrict__ M, float
   return sqrtf(dx * dx + dy * dy);
 }
 
+// Row N on the fly (S3D:312-333): keypoint j of the detection in FILTERED slot k of camera c, read from the caller's raw Person2D payload
+// and normalised in registers with the expressions of se3d_k_normalize (bit-identical values; no normalised copy in HBM).
+// Returns conf >= 0.30 (the triangulation gate, S3D:724-732); kp = (x, y, conf), kc = (a00, a01, a11) only when it does.
+__device__ __forceinline__ bool se3d_load_norm(const Se3dDev &D, int f, int c, int k, int j, float4 &kp, float4 &kc) {
+  const size_t base = ((size_t)(f * D.d.N + c)) * D.d.P;
+  const se3d_keypoint2d r = D.raw[base + D.orig[base + k]].keypoints[j];
+  kp = make_float4(0.f, 0.f, -1.f, 0.f);
+  kc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!(r.score >= TRI_THRESH)) return false;
+  const float fx = D.K[c * 4 + 0], fy = D.K[c * 4 + 1], cx = D.K[c * 4 + 2], cy = D.K[c * 4 + 3];
+  kp = make_float4((r.x - cx) / fx, (r.y - cy) / fy, r.score, 0.f);
+  kc = make_float4(r.cov[0] / (fx * fx), r.cov[1] / (fx * fy), r.cov[2] / (fy * fy), 0.f);
+  return true;
+}
+// The triangulation kernels write EVERY field of the hypothesis slots they own (no zero-fill pass before them).
+__device__ __forceinline__ void se3d_zero_kp_words(se3d_keypoint3d *kp, int lane, int nlanes) {
+  uint32_t *w = reinterpret_cast<uint32_t *>(kp);
+  for (int i = lane; i < (int)(sizeof(se3d_keypoint3d) / 4); i += nlanes) w[i] = 0u;
+}
+// header (id, score) and the fusion slots no input joint maps to (simple: Neck, MidHip, Head, Belly; h36m: eyes and ears)
+__device__ __forceinline__ void se3d_zero_unused_slots(se3d_person3d &p, int pm, int lane) {
+  uint32_t used = 0u;
+#pragma unroll
+  for (int j = 0; j < SE3D_NKP; ++j) used |= 1u << c_kp2fusion[pm][j];
+  if (lane == 0) { p.id = 0u; p.score = 0.f; }
+  for (uint32_t m = ~used & ((1u << SE3D_NFU) - 1u); m; m &= m - 1u) se3d_zero_kp_words(&p.keypoints[__ffs((int)m) - 1], lane, 64);
+}
+
 struct TriView {  // per-wave view list in LDS (structure of arrays, stride = N)
   float *x, *y, *cf, *ca, *cb, *cc;
   float *r0[4], *r1[4];
@@ -809,7 +962,7 @@ struct TriView {  // per-wave view list in LDS (structure of arrays, stride = N)
 // One (hypothesis, joint): rows T, P, O, U for a single joint by one wavefront.  `base`: 15 N floats of LDS owned by the wavefront,
 // `sRt`: the rig's camera matrices in LDS.
 __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int h, int j, int lane, float *base, const float *sRt) {
-  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  const int N = D.d.N, H = D.d.H;
   TriView T;
   T.x = base; T.y = base + N; T.cf = base + 2 * N; T.ca = base + 3 * N; T.cb = base + 4 * N; T.cc = base + 5 * N;
   for (int k = 0; k < 4; ++k) { T.r0[k] = base + (6 + k) * N; T.r1[k] = base + (10 + k) * N; }
@@ -824,12 +977,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
     float4 kp = make_float4(0, 0, -1, 0), kc = make_float4(0, 0, 0, 0);
     if (c < N) {
       const int k = arow[c];
-      if (k >= 0) {
-        const size_t idx = (((size_t)(f * N + c)) * P + k) * SE3D_NKP + j;
-        kp = D.kp[idx];
-        ok = kp.z >= TRI_THRESH;
-        if (ok) kc = D.kcov[idx];
-      }
+      if (k >= 0) ok = se3d_load_norm(D, f, c, k, j, kp, kc);
     }
     const unsigned long long bl = __ballot(ok);
     if (ok) {
@@ -845,7 +993,10 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
     n += __popcll(bl);
   }
   __builtin_amdgcn_wave_barrier();  // view list written by other lanes of this wave is read below
-  if (n < 2) return;  // cannot triangulate (S3D:734-736)
+  if (n < 2) {  // cannot triangulate (S3D:734-736): the slot is default-constructed (score 0)
+    se3d_zero_kp_words(&D.hypP[(size_t)f * H + h].keypoints[c_kp2fusion[D.d.pose_method][j]], lane, 64);
+    return;
+  }
 
   // ---- rows + Gram matrices: Gw (confidence weighted, S3D:450-453) and Gu (unweighted, used by the UT) ----
   double gw_[10], gu_[10];
@@ -1070,7 +1221,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   if (lane == 0) {
     se3d_keypoint3d *kp = &D.hypP[(size_t)f * H + h].keypoints[c_kp2fusion[D.d.pose_method][j]];
     kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
-    kp->score = avg_score;
+    kp->score = avg_score; kp->_pad = 0.f;
     kp->cov[0] = (double)(float)cv[0]; kp->cov[1] = (double)(float)cv[1]; kp->cov[2] = (double)(float)cv[2];
     kp->cov[3] = (double)(float)cv[3]; kp->cov[4] = (double)(float)cv[4]; kp->cov[5] = (double)(float)cv[5];
   }
@@ -1089,6 +1240,7 @@ __global__ __launch_bounds__(256, 3) void se3d_k_triangulate(Se3dDev D) {
   __syncthreads();
   if (h >= D.nhyp[f]) return;
   if (D.nviews[f * H + h] < 2) return;
+  if (j == 0) se3d_zero_unused_slots(D.hypP[(size_t)f * H + h], D.d.pose_method, lane);
   se3d_tri_joint_body(D, f, h, j, lane, reinterpret_cast<float *>(smem) + (size_t)wave * 15 * N, sRt);
 }
 
@@ -1125,7 +1277,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
   const int lane = threadIdx.x;
   const int f = blockIdx.y, h = blockIdx.x >> 1;
   const int jbase = (blockIdx.x & 1) * TH_JOINTS, JN = min(TH_JOINTS, SE3D_NKP - jbase);  // joints jbase .. jbase + JN - 1
-  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  const int N = D.d.N, H = D.d.H;
   if (h >= D.nhyp[f]) return;
   if (D.nviews[f * H + h] < 2) return;
   for (int i = lane; i < 12 * N; i += 64) sRt[i] = D.Rt[i];
@@ -1139,15 +1291,14 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
     if (k >= 0) { const int pos = __popcll(bl & ((1ull << lane) - 1ull)); S.cam[pos] = lane; S.det[pos] = k; }
   }
   __builtin_amdgcn_wave_barrier();
-  // ---- points: lanes over (joint, view) ----
+  if ((blockIdx.x & 1) == 0) se3d_zero_unused_slots(D.hypP[(size_t)f * H + h], D.d.pose_method, lane);
+  // ---- points: lanes over (joint, view); row N on the fly from the raw payload ----
   for (int idx = lane; idx < JN * nv; idx += 64) {
     const int j = idx / nv, v = idx - j * nv;
-    const size_t gi = (((size_t)(f * N + S.cam[v])) * P + S.det[v]) * SE3D_NKP + jbase + j;
-    const float4 kp = D.kp[gi];
-    const bool ok = kp.z >= TRI_THRESH;  // S3D:724-732
+    float4 kp, kc;
+    const bool ok = se3d_load_norm(D, f, S.cam[v], S.det[v], jbase + j, kp, kc);  // S3D:724-732
     S.x[j][v] = kp.x; S.y[j][v] = kp.y; S.cf[j][v] = ok ? kp.z : -1.f;
     if (ok) {
-      const float4 kc = D.kcov[gi];
       const float l11 = sqrtf(kc.x);       // lower Cholesky factor of the 2x2 keypoint covariance (S3D:476-480)
       const float l21 = kc.y / l11;
       S.ca[j][v] = l11; S.cb[j][v] = l21; S.cc[j][v] = sqrtf(kc.z - l21 * l21);
@@ -1292,10 +1443,16 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
       person.keypoints[c_kp2fusion[pm_][jbase + jj]].cov[e] = (double)(float)acc;
     }
   }
-  if (active && !slow) {
+  if (lane < JN && !slow) {  // slow joints are written (all fields) by se3d_k_triangulate_slow
     se3d_keypoint3d *kp = &person.keypoints[c_kp2fusion[pm_][jbase + lane]];
-    kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
-    kp->score = avg_score;
+    if (active) {
+      kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
+      kp->score = avg_score; kp->_pad = 0.f;
+    } else {  // < 2 usable views (S3D:734-736): default-constructed slot
+      kp->joint[0] = kp->joint[1] = kp->joint[2] = 0.0;
+      kp->score = 0.f; kp->_pad = 0.f;
+      for (int e = 0; e < 6; ++e) kp->cov[e] = 0.0;
+    }
   }
   // ---- joints that need outlier rejection are redone by se3d_k_triangulate_slow (per-joint routine) ----
   if (lane == 0) D.tri_slow[((size_t)f * H + h) * 2 + (blockIdx.x & 1)] = (uint32_t)slowmask << jbase;
@@ -1685,15 +1842,31 @@ extern "C" hipError_t se3d_stage1_init_device(void) {
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
+static void se3d_launch_triangulation(const Se3dDev &D, hipStream_t st) {
+  const int B = D.d.B, N = D.d.N, H = D.d.H;
+  const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
+  const char *e_tri = getenv("SE3D_TRI");  // A/B switch (read per launch): joint = always one wavefront per (hypothesis, joint)
+  if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) {
+    hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(2 * H, B), dim3(64), 0, st, D);
+    hipLaunchKernelGGL(se3d_k_triangulate_slow, dim3((B * H + 63) / 64), dim3(64), (size_t)27 * N * sizeof(float), st, D, B * H);
+  }
+  else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
+}
+
 extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, bool tiled) {
   const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H;
+  const char *e_pairs = getenv("SE3D_PAIRS");  // flat | packed | tiled: A/B switches that force the stand-alone pair kernels
+  const bool fused_np = !tiled && !e_pairs && N * P <= NP_MAX_DETS && D.d.npairs <= 2048;
   if (ev) (void)hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D);
+  if (!fused_np) hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D, 1);
   if (ev) (void)hipEventRecord(ev[1], st);
-  if (tiled) {
+  if (fused_np) {  // normalisation + packed pair table in one workgroup per frame, normalised points only in LDS
+    const size_t lds = (size_t)N * P * SE3D_NKP * sizeof(float2) + (size_t)N * P * 8 + (size_t)N * 4 + (size_t)(D.d.npairs + 1) * 4;
+    hipLaunchKernelGGL(se3d_k_normalize_pairs, dim3(B), dim3(256), lds, st, D, pair_ab);
+  } else if (tiled) {
     const int tiles = (P + PT - 1) / PT;
     hipLaunchKernelGGL(se3d_k_pairs_tiled, dim3(tiles * tiles, D.d.npairs, B), dim3(256), 0, st, D, pair_ab);
-  } else if (!(getenv("SE3D_PAIRS") && strcmp(getenv("SE3D_PAIRS"), "flat") == 0) && D.d.npairs < 12000) {  // SE3D_PAIRS=flat|tiled: A/B switch
+  } else if (!(e_pairs && strcmp(e_pairs, "flat") == 0) && D.d.npairs < 12000) {
     hipLaunchKernelGGL(se3d_k_pairs_packed, dim3(B), dim3(256), sizeof(int) * (D.d.npairs + 1), st, D, pair_ab);
   } else {
     const size_t total = (size_t)B * D.d.npairs * P * P;
@@ -1722,15 +1895,54 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     }
   }
   if (ev) (void)hipEventRecord(ev[3], st);
-  const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
-  const char *e_tri = getenv("SE3D_TRI");  // A/B switch (read per launch): joint = always one wavefront per (hypothesis, joint)
-  if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) {
-    hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(2 * H, B), dim3(64), 0, st, D);
-    hipLaunchKernelGGL(se3d_k_triangulate_slow, dim3((B * H + 63) / 64), dim3(64), (size_t)27 * N * sizeof(float), st, D, B * H);
-  }
-  else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
+  se3d_launch_triangulation(D, st);
   if (ev) (void)hipEventRecord(ev[4], st);
   if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), 0, st, D);
   else hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
   if (ev) (void)hipEventRecord(ev[5], st);
+}
+
+// =============================================================================================================
+// Config 2 of SURVEY 8d — batched DLT with the association GIVEN (se3d_triangulate_assoc): rows N, T, P, O, U only.
+// The caller's table holds ORIGINAL detection indices ([frame][hypothesis][camera], the layout of se3d_frame_out.hyp_assoc); row N
+// still applies its ">= 9 valid keypoints" filter (S3D:579, 599), so a listed detection that the sweep could never have attached maps
+// to "no view".  One workgroup per frame.
+// =============================================================================================================
+__global__ __launch_bounds__(256) void se3d_k_assoc_given(Se3dDev D, const int32_t *__restrict__ assoc_orig, int nh) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  for (int i = tid; i < nh * N; i += 256) {
+    const int h = i / N, c = i - h * N;
+    const int o = assoc_orig[((size_t)f * nh + h) * N + c];
+    int slot = -1;
+    if (o >= 0) {
+      const size_t base = ((size_t)(f * N + c)) * P;
+      const int nv = D.nvalid[f * N + c];
+      for (int k = 0; k < nv; ++k)
+        if (D.orig[base + k] == o) slot = k;
+    }
+    D.assoc[((size_t)f * H + h) * N + c] = slot;
+  }
+  __syncthreads();
+  for (int h = tid; h < nh; h += 256) {
+    int n = 0;
+    for (int c = 0; c < N; ++c) n += D.assoc[((size_t)f * H + h) * N + c] >= 0 ? 1 : 0;
+    D.nviews[f * H + h] = n;
+  }
+  if (tid == 0) D.nhyp[f] = nh;
+  __syncthreads();
+  for (int h = 0; h < nh; ++h) {  // hypotheses the triangulation skips (< 2 views, S3D:652): default-constructed persons
+    if (D.nviews[f * H + h] >= 2) continue;
+    uint32_t *w = reinterpret_cast<uint32_t *>(&D.hypP[(size_t)f * H + h]);
+    for (int i = tid; i < (int)(sizeof(se3d_person3d) / 4); i += 256) w[i] = 0u;
+  }
+}
+
+extern "C" void se3d_launch_dlt(const Se3dDev &D, const int32_t *d_assoc_orig, int nh, hipStream_t st, hipEvent_t *ev /* [2] or null */) {
+  const int B = D.d.B, N = D.d.N;
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D, 0);
+  hipLaunchKernelGGL(se3d_k_assoc_given, dim3(B), dim3(256), 0, st, D, d_assoc_orig, nh);
+  se3d_launch_triangulation(D, st);
+  if (ev) (void)hipEventRecord(ev[1], st);
 }

@@ -59,6 +59,31 @@ class Skeleton3D:
             r.c = o
         return res
 
+    # -- config 2: batched DLT triangulation with the association given (rows N, T, P, O, U)
+    def triangulate_assoc(self, frames, assoc):
+        """assoc: [n_frames][n_hyp][n_cam] original detection indices or -1 -> person3d array [n_frames][n_hyp]."""
+        frames = list(frames)
+        assoc = np.ascontiguousarray(assoc, np.int32).reshape(len(frames), -1, self.rig.n_cam)
+        arr = (pm.FrameIn * len(frames))(*[f.as_c() for f in frames])
+        out = np.zeros((len(frames), assoc.shape[1]), pm.person3d_dt)
+        self._chk(self._L.se3d_triangulate_assoc(C.c_void_p(self._h), len(frames), arr, assoc.shape[1], pm.iptr(assoc), C.c_void_p(out.ctypes.data)),
+                  "se3d_triangulate_assoc")
+        return out
+
+    def stage_assoc(self, assoc):
+        assoc = np.ascontiguousarray(assoc, np.int32).reshape(self._staged, -1, self.rig.n_cam)
+        self._dlt_hyp = assoc.shape[1]
+        self._chk(self._L.se3d_stage_assoc(C.c_void_p(self._h), assoc.shape[1], pm.iptr(assoc)), "se3d_stage_assoc")
+
+    def run_dlt(self):
+        self._chk(self._L.se3d_run_dlt(C.c_void_p(self._h)), "se3d_run_dlt")
+
+    def fetch_dlt(self, n_frames=None):
+        n = n_frames or self._staged
+        out = np.zeros((n, self._dlt_hyp), pm.person3d_dt)
+        self._chk(self._L.se3d_fetch_dlt(C.c_void_p(self._h), n, C.c_void_p(out.ctypes.data)), "se3d_fetch_dlt")
+        return out
+
     # -- resident pipeline
     def stage(self, frames):
         frames = list(frames)

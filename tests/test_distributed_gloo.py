@@ -76,3 +76,83 @@ def test_rank_sequences_partition():
     for world in (1, 2, 4, 8):
         seen = sorted(sum((shard.rank_sequences(13, r, world) for r in range(world)), []))
         assert seen == list(range(13))
+
+
+# ---- bench.py's own exchange object (shard.SkeletonExchange: double-buffered, one all-gather pair per step) on two gloo ranks ----
+N_CTX, SLICE_P, SLICE_C, N_STEPS = 3, 1688 * 5, 5, 5
+
+
+def _pattern(rank, ci, step):
+    rng = np.random.default_rng(1000 * rank + 10 * ci + step)
+    return rng.integers(0, 256, SLICE_P, dtype=np.uint8), rng.integers(0, 7, SLICE_C, dtype=np.int32)
+
+
+def _xworker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from smartedgesensor3dhumanpose_amd import shard
+    ex = shard.SkeletonExchange(dist, N_CTX, SLICE_P, SLICE_C, torch.device("cpu"), streams=None)
+    ok = True
+    for step in range(N_STEPS):
+        for ci in range(N_CTX):
+            pk, cn = ex.pack_target(ci)
+            p, c = _pattern(rank, ci, step)
+            pk.copy_(torch.from_numpy(p))
+            cn.copy_(torch.from_numpy(c))
+            ex.packed(ci)
+        par = ex.exchange()
+        assert par == step % 2                      # double-buffered
+        ex.finish()
+        gp, gc = ex.gathered(par)
+        for r in range(world):                      # every rank's gathered buffer == concatenation of all ranks' packs of THIS step
+            for ci in range(N_CTX):
+                p, c = _pattern(r, ci, step)
+                ok = ok and np.array_equal(gp[r, ci].numpy(), p) and np.array_equal(gc[r, ci].numpy(), c)
+        ok = ok and ex.verify(par)
+    # a corrupted slice must be detected by verify() on every rank
+    ex.gath_p[par][-1] ^= 0xFF
+    bad = not ex.verify(par)
+    q.put((rank, ok, bad, ex.n_exchanges))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_skeleton_exchange_world2_gathers_all_packs():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_xworker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, bad, n in got:
+        assert ok, "rank %d: gathered buffer differs from the concatenation of the packs" % rank
+        assert bad, "rank %d: verify() did not notice a corrupted slice" % rank
+        assert n == N_STEPS
+
+
+def test_bench_launcher_builds_a_torchrun_command(monkeypatch):
+    """bench.py --gpus N without RANK starts N ranks itself: the launcher must be invoked before anything touches the GPU."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                   # the children's return code is forwarded
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert "torch.cuda" not in sys.modules or not sys.modules["torch"].cuda.is_initialized()

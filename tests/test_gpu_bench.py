@@ -1,0 +1,38 @@
+"""GPU (-m gpu): bench.py as the driver runs it — under the torch.distributed launcher with one rank (the RCCL exchange path with
+world_size 1: pack on the context streams, event-ordered all-gather, gathered buffer verified against the packs) and the config-2 line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_exchange_under_launcher_world1():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29631",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "16cam6p", "--seqs", "32", "--contexts", "2", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = _json_line(p.stdout)
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert "verified: True" in line["config"]["sharding"]
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["valu"]["achieved"] > 0
+
+
+def test_bench_config2_line():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--stage", "dlt", "--seqs", "256", "--steps", "3", "--warmup", "1"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = _json_line(p.stdout)
+    assert line["value"] > 0 and line["latency_B1"]["device_ms"] > 0 and "config 2" in line["config"]["workload"]
