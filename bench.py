@@ -372,14 +372,20 @@ def roofline_of(res, w, stage2, source):
 def valu_of(res, w, stage2, pmc):
     """Vector-ALU roofline (SURVEY 8d asks for both): algorithmic flops per skeleton x skeletons/s against the fp32 vector peak."""
     it = res.get("lm_iterations_mean") or 0.0
-    flop = w["flop_s1"] + (FLOP_S2_PER_LM_ITER * (it + 1.0) if stage2 else 0.0)
+    flop = w["flop_s1"]
     tf = flop * res["value_per_gpu"] / 1e12
-    out = {"algorithmic_flop_per_skeleton": round(flop), "stage1_flop": round(w["flop_s1"]), "stage2_flop_per_lm_iteration": FLOP_S2_PER_LM_ITER if stage2 else 0,
-           "lm_iterations_mean": round(it, 3), "achieved": round(tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 6),
-           "note": "minimal-work flops of SURVEY 8d (the kernels issue more: IEEE-exact divides, fp64 solves); fp64 work counted at face value against the fp32 vector peak"}
-    if pmc:
-        out["measured_valu_issue_utilisation"] = pmc.get("valu_issue_utilisation")
-        out["measured_source"] = pmc.get("source")
+    out = {"algorithmic_flop_per_skeleton": round(flop), "achieved": round(tf, 4), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 6),
+           "lm_iterations_mean": round(it, 3),
+           "stage2_dense_equivalent_flop_per_skeleton": round(FLOP_S2_PER_LM_ITER * (it + 1.0)) if stage2 else 0,
+           "note": "SURVEY 8d minimal-work flops of stage 1 (association + triangulation + UT covariance) x skeletons/s against the fp32 vector peak; the "
+                   "kernels issue more (IEEE-exact divides, fp64 null-vector solves).  Stage 2 is not in `achieved`: SURVEY counts it as dense 63x63 normal "
+                   "equations (0.74 MFLOP per LM iteration), which the forest elimination never forms (DESIGN 3.1)"}
+    if pmc:   # committed SQ counter pass (tools/profile_r2.sh, tools/pmc_sq.py): VALU wave-instructions x 2 issue cycles / (1024 SIMDs x kernel cycles)
+        ks = [k for k in pmc["kernels"].values() if "SQ_INSTS_VALU" in k["counters_per_launch"]]
+        cyc = sum(k["kernel_cycles"] * k["launches"] for k in ks)
+        if cyc > 0:
+            out["measured_valu_issue_utilisation"] = round(sum(k["counters_per_launch"]["SQ_INSTS_VALU"] * k["launches"] for k in ks) * 2.0 / (1024.0 * cyc), 4)
+            out["measured_source"] = "profiles/r2: " + pmc.get("note", "")
     return out
 
 
@@ -460,7 +466,8 @@ def main():
     serial = None
     if (args.serial or (default_run and not args.no_serial)) and rank == 0:
         all_seqs = [s for ctx_seqs in seqs_head for s in ctx_seqs]
-        serial = run_workload(headline, [all_seqs], rig, args, max(3, args.steps // 4), 1, None, local_rank, stage2)
+        serial = run_workload(headline, [all_seqs], rig, args, args.steps if args.serial else max(3, args.steps // 4), args.warmup if args.serial else 1,
+                              None, local_rank, stage2)
         serial["value_per_gpu"] = serial["value"]
     del seqs_head
     sec = None
@@ -481,7 +488,7 @@ def main():
         tr = load("pmc_traffic_%s_serial.json" % headline)   # committed PMC passes of `bench.py --serial` (tools/profile_bench.sh)
         if tr and serial and serial["S"] == tr.get("sequences"):
             roof["traffic"] = tr["kernels"].get(roof["kernel"], {}).get("hbm_bytes_per_launch_corrected")
-        roof["valu"] = valu_of(main_res, w, stage2, load("pmc_valu_%s.json" % headline))
+        roof["valu"] = valu_of(main_res, w, stage2, load("pmc_sq_%s_serial.json" % headline))
         line = {
             "metric": "3D skeletons/sec (triangulated + refined; parity vs the CPU oracle is asserted by tests/ and smoke(), not here)",
             "value": round(main_res["value"], 2), "unit": "skeletons/s", "n_gpus": world, "steps": main_res["steps"], "warmup": main_res["warmup"],
@@ -504,7 +511,7 @@ def main():
                               "sequences": serial["S"], "n_gpus": 1}
         if sec is not None:
             roof2 = roofline_of(sec, WORKLOADS["256cam128p"], True, "overlapped contexts (%d per GPU)" % sec["NC"])
-            roof2["valu"] = valu_of(sec, WORKLOADS["256cam128p"], True, load("pmc_valu_256cam128p.json"))
+            roof2["valu"] = valu_of(sec, WORKLOADS["256cam128p"], True, load("pmc_sq_256cam128p_1ctx.json"))
             line["secondary"] = {"workload": "256cam128p, stage 1+2, %d contexts x %d sequences x %d frames per GPU" % (sec["NC"], sec["S"], sec["T"]),
                                  "value": round(sec["value"], 2), "unit": "skeletons/s", "n_gpus": world, "value_per_gpu": round(sec["value_per_gpu"], 2),
                                  "ms_per_step": round(sec["ms_per_step"], 3), "steps": sec["steps"], "warmup": sec["warmup"],

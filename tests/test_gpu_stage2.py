@@ -317,7 +317,7 @@ def test_stage2_walk_at_bench_size(extr_rig, oracle, demo_params, monkeypatch):
     monkeypatch.delenv("SE3D_WALK_LM", raising=False)
     w = bench.WORKLOADS["16cam6p"]
     S_, T_, U = 256, 16, 32
-    seqs = bench.make_sequences(extr_rig, w, S_, seed0=4000, t_steps=T_)
+    seqs = bench.make_sequences(None, w, 1, S_, 4, T_)[0]   # one context: up to 32 distinct seeded sequences (4000 ...), repeated
     frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
     node = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"])
     node.stage(frames)
