@@ -357,7 +357,7 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     return nullptr;
   }
   c->tiled = P > 16;
-  if (const char *e = getenv("SE3D_PAIRS")) c->tiled = (strcmp(e, "tiled") == 0);
+  if (const char *e = getenv("SE3D_PAIRS")) c->tiled = (strcmp(e, "tiled") == 0 || strcmp(e, "rows") == 0);  // A/B: force a large-P pair kernel
   return c;
 }
 

@@ -506,6 +506,155 @@ __global__ __launch_bounds__(256, 3) void se3d_k_pairs_tiled(Se3dDev D, const in
 }
 
 // =============================================================================================================
+// row E, large P, second form ("rows"): one workgroup per (48-row tile of det_a, camera pair, frame), looping over 32-column tiles
+// of det_b.  A wavefront carries TWO det_a rows (lanes 0-31 / 32-63) x 32 det_b columns:
+//   * the det_b side (epipolar line F^T p2, its norm and shared reciprocal, the point, the validity weight: 8 floats per joint)
+//     stays in REGISTERS for a 9-joint half while the wavefront walks its 12 rows;
+//   * the det_a side is read from LDS with two (half-wave uniform) addresses per instruction — a broadcast read, no bank traffic
+//     to speak of — instead of the 16 distinct ds_read_b128 per joint of the 4x4-register-tile kernel;
+//   * 128 VGPRs and 36 KB of LDS: four workgroups (16 wavefronts) per CU instead of two to three.
+// PMC on the 4x4-tile kernel at 256 cam x 128 p (profiles/r2): VALU issue utilisation 40 %, 29 % of the wave time in s_waitcnt, 22 %
+// issue stalls at ~2 wavefronts per SIMD.  Same per-element float expressions in the same order (FAST: shared-reciprocal Markstein
+// divide under the block-uniform range guard, else IEEE divide) -> the table is bit-identical to every other pair kernel.
+// =============================================================================================================
+#define RB_ROWS 48
+#define RB_COLS 32
+#define RB_JH 9
+struct __align__(16) RowOp { float lx, ly, lz, nrm, x, y, rcp, w; };
+
+__device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float px, float py, bool valid, bool &unsafe) {
+  RowOp o;
+  o.lx = lx; o.ly = ly; o.lz = lz;
+  o.nrm = sqrtf(lx * lx + ly * ly);
+  o.x = px; o.y = py;
+  o.rcp = se3d_safe_rcp(o.nrm);
+  o.w = valid ? 1.f : 0.f;
+  unsafe |= valid && !(o.rcp != 0.f && se3d_in_safe_range(lx) && se3d_in_safe_range(ly) && se3d_in_safe_range(lz) && se3d_in_safe_range(px) && se3d_in_safe_range(py));
+  return o;
+}
+
+template <int JN>
+__device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS], const RowOp (&b)[RB_JH], int jbase, int row0, int nrows_left,
+                                                  double (&acc)[RB_ROWS / 8]) {
+  // Straight-line code over (row pair, joint).  The det_a operand of the NEXT item is fetched from LDS while the current item is
+  // computed (two RowOp in flight = 16 registers).  The memory-clobbering empty asm after every item is what keeps it that way: without
+  // it the det_a operands — which do not change from one column tile to the next — are lifted out of the column loop by loop-invariant
+  // code motion, and the independent LDS reads of the block are all issued first (102 reads = 816 registers, 2 KB of scratch per lane).
+  asm volatile("" ::: "memory");
+  RowOp a = A[jbase][row0];
+#pragma unroll
+  for (int r = 0; r < RB_ROWS / 8; ++r) {
+    if (2 * r >= nrows_left) break;  // wave-uniform (scalar): both rows of the pair lie beyond the last detection of camera a
+    const int row = row0 + 2 * r;
+#pragma unroll
+    for (int jj = 0; jj < JN; ++jj) {
+      const bool last_j = jj + 1 == JN, last_r = r + 1 == RB_ROWS / 8;
+      const RowOp an = A[last_j ? jbase : jbase + jj + 1][last_j ? (last_r ? row0 : row + 2) : row];
+      const float n1 = fabsf(b[jj].x * a.lx + (b[jj].y * a.ly + a.lz));
+      const float n2 = fabsf(a.x * b[jj].lx + (a.y * b[jj].ly + b[jj].lz));
+      const float d1 = se3d_div_markstein(n1, a.nrm, a.rcp), d2 = se3d_div_markstein(n2, b[jj].nrm, b[jj].rcp);
+      const float sacc = (d1 + d2) * (a.w * b[jj].w);
+      acc[r] += (double)sacc;
+      asm volatile("" : "+v"(acc[r]) : : "memory");  // the item is complete (accumulated) before the fence; the next item's LDS read comes after it
+      a = an;
+    }
+  }
+}
+// IEEE-divide form for blocks whose operands fail the range guard of the shared-reciprocal divide (practically never): compact loops, both
+// operands from LDS.
+__device__ __forceinline__ void se3d_rows_compute_slow(const RowOp (*A)[RB_ROWS], const RowOp (*Bc)[RB_COLS], int ql, int jbase, int jn, int row0,
+                                                       unsigned m2, const unsigned *M1, double (&acc)[RB_ROWS / 8]) {
+#pragma unroll
+  for (int r = 0; r < RB_ROWS / 8; ++r) {
+    const int row = row0 + 2 * r;
+    const unsigned mm = M1[row] & m2;
+#pragma unroll 1
+    for (int jj = 0; jj < jn; ++jj) {
+      const RowOp a = A[jbase + jj][row], bq = Bc[jj][ql];
+      const float n1 = fabsf(bq.x * a.lx + (bq.y * a.ly + a.lz));
+      const float n2 = fabsf(a.x * bq.lx + (a.y * bq.ly + bq.lz));
+      const float sacc = n1 / a.nrm + n2 / bq.nrm;
+      acc[r] += ((mm >> (jbase + jj)) & 1u) ? (double)sacc : 0.0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 4) void se3d_k_pairs_rows(Se3dDev D, const int2 *__restrict__ pair_ab) {
+  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
+  const int pr = blockIdx.y, f = blockIdx.z;
+  const int2 ab = pair_ab[pr];
+  const int na = D.nvalid[f * N + ab.x], nb = D.nvalid[f * N + ab.y];
+  const int p0 = blockIdx.x * RB_ROWS;
+  if (p0 >= na || nb == 0) return;
+  __shared__ RowOp A[SE3D_NKP][RB_ROWS];  // det_a side, all joints: staged once per workgroup (26 KB)
+  __shared__ RowOp Bc[RB_JH][RB_COLS];    // det_b side of the current column tile, one joint half (9 KB)
+  __shared__ unsigned M1[RB_ROWS], M2[RB_COLS];
+  __shared__ int s_unsafe_a;
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, ql = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it is a uniform branch, not an exec mask
+  const float *F = D.F + 9 * (size_t)pr;
+  const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
+  const size_t baseA = ((size_t)(f * N + ab.x)) * P, baseB = ((size_t)(f * N + ab.y)) * P;
+  if (tid == 0) s_unsafe_a = 0;
+  for (int d = tid; d < RB_ROWS; d += 256) M1[d] = (p0 + d < na) ? D.vmask_gt[baseA + p0 + d] : 0u;
+  __syncthreads();
+  {
+    bool unsafe = false;
+    for (int i = tid; i < RB_ROWS * SE3D_NKP; i += 256) {
+      const int d = i / SE3D_NKP, k = i - d * SE3D_NKP, p = p0 + d;
+      float4 a4 = make_float4(0.f, 0.f, -1.f, 0.f);
+      if (p < na) a4 = D.kp[(baseA + p) * SE3D_NKP + k];
+      A[k][d] = se3d_rowop(f0 * a4.x + (f1 * a4.y + f2), f3 * a4.x + (f4 * a4.y + f5), f6 * a4.x + (f7 * a4.y + f8), a4.x, a4.y,
+                           p < na && ((M1[d] >> k) & 1u), unsafe);
+    }
+    if (unsafe) s_unsafe_a = 1;
+  }
+  const int row0 = wave * (RB_ROWS / 4) + half;             // this lane's first row inside the tile; row pairs r: row0 + 2 r
+  const int nrows_left = na - p0 - wave * (RB_ROWS / 4);    // rows of this wavefront that exist (wave-uniform)
+  double *out = D.pair + ((size_t)f * np + pr) * P * P;
+  for (int q0 = 0; q0 < nb; q0 += RB_COLS) {
+    double acc[RB_ROWS / 8];
+#pragma unroll
+    for (int r = 0; r < RB_ROWS / 8; ++r) acc[r] = 0.0;
+    unsigned m2 = 0u;
+    for (int jbase = 0; jbase < SE3D_NKP; jbase += RB_JH) {
+      const int jn = min(RB_JH, SE3D_NKP - jbase);
+      __syncthreads();  // the previous phase has finished reading Bc / M2 (first trip: M1 is visible)
+      if (jbase == 0)
+        for (int d = tid; d < RB_COLS; d += 256) M2[d] = (q0 + d < nb) ? D.vmask_gt[baseB + q0 + d] : 0u;
+      bool unsafe = false;
+      for (int i = tid; i < RB_COLS * jn; i += 256) {
+        const int d = i / jn, jj = i - d * jn, k = jbase + jj, q = q0 + d;
+        float4 b4 = make_float4(0.f, 0.f, -1.f, 0.f);
+        unsigned mq = 0u;
+        if (q < nb) { b4 = D.kp[(baseB + q) * SE3D_NKP + k]; mq = D.vmask_gt[baseB + q]; }
+        Bc[jj][d] = se3d_rowop(f0 * b4.x + (f3 * b4.y + f6), f1 * b4.x + (f4 * b4.y + f7), f2 * b4.x + (f5 * b4.y + f8), b4.x, b4.y,
+                               q < nb && ((mq >> k) & 1u), unsafe);
+      }
+      const int any_unsafe = __syncthreads_or(unsafe ? 1 : 0) | s_unsafe_a;  // block-uniform: shared-reciprocal divide or IEEE divide
+      if (jbase == 0) m2 = M2[ql];
+      RowOp b[RB_JH];
+#pragma unroll
+      for (int jj = 0; jj < RB_JH; ++jj) b[jj] = Bc[jj < jn ? jj : 0][ql];
+      if (nrows_left > 0) {
+        if (any_unsafe) se3d_rows_compute_slow(A, Bc, ql, jbase, jn, row0, m2, M1, acc);
+        else if (jn == RB_JH) se3d_rows_compute<RB_JH>(A, b, jbase, row0, nrows_left, acc);
+        else se3d_rows_compute<SE3D_NKP - RB_JH>(A, b, jbase, row0, nrows_left, acc);
+      }
+    }
+    const int q = q0 + ql;
+#pragma unroll
+    for (int r = 0; r < RB_ROWS / 8; ++r) {
+      const int row = row0 + 2 * r, p = p0 + row;
+      if (p < na && q < nb) {
+        const int n = __popc(M1[row] & m2);
+        out[(size_t)p * P + q] = n > 0 ? acc[r] / n : -1.0;
+      }
+    }
+  }
+}
+
+// =============================================================================================================
 // row G (cost) — C(hyp, det) of calcCost for sweep step `b` (S3D:616-626 -> 335-390) gathered from the pair table in the
 // reference's accumulation order (ascending attached view).  One workgroup per (hypothesis, frame), lanes over dets.
 // =============================================================================================================
@@ -1863,7 +2012,9 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   if (fused_np) {  // normalisation + packed pair table in one workgroup per frame, normalised points only in LDS
     const size_t lds = (size_t)N * P * SE3D_NKP * sizeof(float2) + (size_t)N * P * 8 + (size_t)N * 4 + (size_t)(D.d.npairs + 1) * 4;
     hipLaunchKernelGGL(se3d_k_normalize_pairs, dim3(B), dim3(256), lds, st, D, pair_ab);
-  } else if (tiled) {
+  } else if (tiled && !(e_pairs && strcmp(e_pairs, "tiled") == 0)) {  // large P: two rows x 32 columns per wavefront (default)
+    hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((P + RB_ROWS - 1) / RB_ROWS, D.d.npairs, B), dim3(256), 0, st, D, pair_ab);
+  } else if (tiled) {                                                  // SE3D_PAIRS=tiled: the 4x4 register-tile kernel (A/B)
     const int tiles = (P + PT - 1) / PT;
     hipLaunchKernelGGL(se3d_k_pairs_tiled, dim3(tiles * tiles, D.d.npairs, B), dim3(256), 0, st, D, pair_ab);
   } else if (!(e_pairs && strcmp(e_pairs, "flat") == 0) && D.d.npairs < 12000) {

@@ -110,8 +110,11 @@ def test_packed_pair_kernel_equals_flat_kernel_bitwise(extr_rig, monkeypatch):
     on every valid entry, including frames with low-confidence joints and cameras without detections."""
     frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=7, n_frames=6, seed=31, low_score_frac=0.2, p_miss=0.15))
     tabs = {}
-    for mode in ("flat", "packed"):
-        monkeypatch.setenv("SE3D_PAIRS", mode)
+    for mode in ("flat", "packed", "fused"):   # fused (the default for small rigs): normalisation + packed pairs in one kernel, points in LDS
+        if mode == "fused":
+            monkeypatch.delenv("SE3D_PAIRS", raising=False)
+        else:
+            monkeypatch.setenv("SE3D_PAIRS", mode)
         node = _node(extr_rig, max_frames=6, max_det_per_cam=8, max_hyp=32)
         node.stage(frames)
         node.run_stage1()
@@ -119,9 +122,9 @@ def test_packed_pair_kernel_equals_flat_kernel_bitwise(extr_rig, monkeypatch):
         tabs[mode] = [_pair_costs(node, fi, a, b) for fi in range(6) for a in range(16) for b in range(a + 1, 16)]
         node.close()
     n = 0
-    for (tf, na, nb), (tt, na2, nb2) in zip(tabs["flat"], tabs["packed"]):
-        assert (na, nb) == (na2, nb2)
-        assert np.array_equal(tf[:na, :nb], tt[:na, :nb])
+    for (tf, na, nb), (tt, na2, nb2), (tu, na3, nb3) in zip(tabs["flat"], tabs["packed"], tabs["fused"]):
+        assert (na, nb) == (na2, nb2) == (na3, nb3)
+        assert np.array_equal(tf[:na, :nb], tt[:na, :nb]) and np.array_equal(tf[:na, :nb], tu[:na, :nb])
         n += na * nb
     assert n > 4000
 
@@ -177,9 +180,12 @@ def _pair_costs(node, frame_idx, a, b):
     return out, na.value, nb.value
 
 
-@pytest.mark.parametrize("tiled", [False, True])
-def test_pair_cost_table_is_bit_exact(extr_rig, oracle, demo_params, tiled, monkeypatch):
-    monkeypatch.setenv("SE3D_PAIRS", "tiled" if tiled else "flat")
+@pytest.mark.parametrize("mode", ["flat", "tiled", "rows", "fused"])
+def test_pair_cost_table_is_bit_exact(extr_rig, oracle, demo_params, mode, monkeypatch):
+    if mode == "fused":
+        monkeypatch.delenv("SE3D_PAIRS", raising=False)
+    else:
+        monkeypatch.setenv("SE3D_PAIRS", mode)
     node = _node(extr_rig, max_frames=2, max_det_per_cam=8, max_hyp=32)
     frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=2, seed=11, p_miss=0.1))
     node.stage(frames)
@@ -298,8 +304,12 @@ def test_tiled_pair_kernel_equals_flat_kernel_bitwise_large(oracle, monkeypatch)
     rig = R.elliptical_rig(24, seed=4)
     rig.set_tensors(*rig_tensors(rig))
     frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=40, n_frames=1, seed=9, min_coverage=6, spacing=0.8))
+    # one detection of camera 3 far outside the operand range of the shared-reciprocal divide: the blocks that touch it must take the
+    # IEEE-divide form (block-uniform range guard) and still agree bit for bit
+    kp3 = frames[0].persons[frames[0].det_offset[3] + 1]["keypoints"]
+    kp3["x"][:5] = 3.0e12
     tabs = {}
-    for mode in ("flat", "tiled"):
+    for mode in ("flat", "tiled", "rows"):
         monkeypatch.setenv("SE3D_PAIRS", mode)
         node = _node(rig, max_frames=1, max_det_per_cam=48, max_hyp=96)
         node.stage(frames)
@@ -308,8 +318,8 @@ def test_tiled_pair_kernel_equals_flat_kernel_bitwise_large(oracle, monkeypatch)
         tabs[mode] = [_pair_costs(node, 0, a, b) for a in range(0, 24, 3) for b in range(a + 1, 24, 2)]
         node.close()
     n = 0
-    for (tf, na, nb), (tt, na2, nb2) in zip(tabs["flat"], tabs["tiled"]):
-        assert (na, nb) == (na2, nb2)
-        assert np.array_equal(tf[:na, :nb], tt[:na, :nb])
+    for (tf, na, nb), (tt, na2, nb2), (tr, na3, nb3) in zip(tabs["flat"], tabs["tiled"], tabs["rows"]):
+        assert (na, nb) == (na2, nb2) == (na3, nb3)
+        assert np.array_equal(tf[:na, :nb], tt[:na, :nb]) and np.array_equal(tf[:na, :nb], tr[:na, :nb])
         n += na * nb
     assert n > 30000
