@@ -351,6 +351,66 @@ def bench_dlt(args):
     print(json.dumps(line), flush=True)
 
 
+def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank):
+    """PCIe-inclusive rate (never `value`): every step each context receives its batch of frames from HOST memory (se3d_stream_submit:
+    ragged payload into pinned memory, H2D on a copy stream, expansion on the device, stage 1, stage-2 walk, device compaction of the
+    published persons, D2H) and hands the published fused / predicted persons back in host memory (se3d_stream_collect); two batches per
+    context in flight, one host thread per context (the C calls release the GIL)."""
+    import threading
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
+    w = WORKLOADS[name]
+    NC, S_, T_ = len(seqs_per_ctx), len(seqs_per_ctx[0]), len(seqs_per_ctx[0][0])
+    B = S_ * T_
+    nodes, prepared = [], []
+    in_bytes = 0
+    for seqs in seqs_per_ctx:
+        frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
+        nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank)
+        nd_.refine_reset()
+        nodes.append(nd_)
+        prepared.append(nd_.stream_prepare(frames))
+        in_bytes += sum(int(f.det_offset[-1]) for f in frames) * 428
+    counts = [[0, 0] for _ in nodes]   # published persons, bytes out per context (timed region)
+    go, done = threading.Barrier(NC + 1), threading.Barrier(NC + 1)
+
+    def worker(ci):
+        nd_, t, cyc = nodes[ci], 100.0, 0
+
+        def submit():
+            nonlocal t, cyc
+            ks = list(range(T_)) if cyc % 2 == 0 else list(range(T_ - 1, -1, -1))
+            ts = t + (1.0 / 30.0) * np.arange(1, T_ + 1)
+            t, cyc = float(ts[-1]), cyc + 1
+            nd_.stream_submit(prepared[ci], np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
+        submit()
+        for _ in range(warmup):
+            submit()
+            nd_.stream_collect(copy=False)
+        go.wait()
+        for _ in range(steps):
+            submit()
+            off, fused, _pred = nd_.stream_collect(copy=False)
+            counts[ci][0] += int(off[-1])
+            counts[ci][1] += 2 * int(off[-1]) * 1688 + 4 * len(off)
+        nd_.stream_collect(copy=False)
+        done.wait()
+    threads = [threading.Thread(target=worker, args=(ci,)) for ci in range(NC)]
+    for th in threads:
+        th.start()
+    go.wait()
+    t0 = time.perf_counter()
+    done.wait()
+    dt = time.perf_counter() - t0
+    for th in threads:
+        th.join()
+    for nd_ in nodes:
+        nd_.close()
+    n_skel = sum(c[0] for c in counts)
+    return {"value": n_skel / dt, "ms_per_step": dt / steps * 1e3, "contexts": NC, "sequences_per_context": S_, "steps": steps,
+            "h2d_gb_per_s": in_bytes * steps / dt / 1e9, "d2h_gb_per_s": sum(c[1] for c in counts) / dt / 1e9,
+            "h2d_mb_per_step": in_bytes / 1e6, "skeletons_per_step": n_skel // steps}
+
+
 def roofline_of(res, w, stage2, source):
     """HBM roofline of the dominant kernel of a measurement: achieved = algorithmic bytes per skeleton x skeletons per launch / average
     launch duration (HIP events on the kernel's own stream)."""
@@ -407,6 +467,8 @@ def main():
                     "(the run rocprofv3 --kernel-trace --stats is pointed at for profiles/*/serial_*)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 256cam128p secondary measurement of a default run")
     ap.add_argument("--no-serial", action="store_true", help="skip the serial per-kernel pass of a default run")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the PCIe-inclusive streaming measurement (value_streaming) of a default run")
+    ap.add_argument("--stream-contexts", type=int, default=4, help="contexts of the streaming measurement (each pins two batches of host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -469,6 +531,9 @@ def main():
         serial = run_workload(headline, [all_seqs], rig, args, args.steps if args.serial else max(3, args.steps // 4), args.warmup if args.serial else 1,
                               None, local_rank, stage2)
         serial["value_per_gpu"] = serial["value"]
+    streaming = None
+    if default_run and not args.no_streaming and stage2 and rank == 0:
+        streaming = run_streaming(headline, seqs_head[: max(1, min(args.stream_contexts, NC))], rig, max(3, args.steps // 2), 2, local_rank)
     del seqs_head
     sec = None
     if want_secondary:
@@ -509,6 +574,15 @@ def main():
         if serial is not None and head is not None:
             line["serial"] = {"value": round(serial["value"], 2), "ms_per_step": round(serial["ms_per_step"], 4), "steps": serial["steps"],
                               "sequences": serial["S"], "n_gpus": 1}
+        if streaming is not None:
+            line["value_streaming"] = round(streaming["value"], 2)
+            line["streaming"] = {"value": round(streaming["value"], 2), "unit": "skeletons/s", "fraction_of_resident": round(streaming["value"] / main_res["value_per_gpu"], 4),
+                                 "ms_per_step": round(streaming["ms_per_step"], 3), "contexts": streaming["contexts"], "sequences_per_context": streaming["sequences_per_context"],
+                                 "h2d_GB_per_s": round(streaming["h2d_gb_per_s"], 2), "d2h_GB_per_s": round(streaming["d2h_gb_per_s"], 2),
+                                 "h2d_MB_per_step": round(streaming["h2d_mb_per_step"], 1), "n_gpus": 1,
+                                 "note": "PCIe-inclusive: every step's frames come from host memory (ragged, pinned, double-buffered) and the published "
+                                         "persons go back to host memory; never `value`.  At 16cam6p a frame is ~40 KB in and ~20 KB out: PCIe Gen5 x16 "
+                                         "bounds this rate, not the kernels (DESIGN 5)"}
         if sec is not None:
             roof2 = roofline_of(sec, WORKLOADS["256cam128p"], True, "overlapped contexts (%d per GPU)" % sec["NC"])
             roof2["valu"] = valu_of(sec, WORKLOADS["256cam128p"], True, load("pmc_sq_256cam128p_1ctx.json"))

@@ -200,6 +200,25 @@ int se3d_pack_stage2_walk_device(se3d_ctx *ctx, int32_t n_frames, void *d_person
 int se3d_pack_stage2_walk_device_slots(se3d_ctx *ctx, int32_t n_frames, int32_t slots, void *d_persons, void *d_counts);
 
 
+/* --- streaming ingest: frames arrive from the host every step (the reference's situation at S3D:1069) ---------------------------
+ * se3d_stream_submit takes one batch of frames ([time step k][sequence s] order, frame slot = k * n_seq + s as in the resident path),
+ * copies the callers' ragged Person2D payloads WITHOUT padding into pinned memory, and enqueues, without waiting: H2D on a copy stream,
+ * the expansion into the resident layout, stage 1, the stage-2 walk over n_steps time steps (arguments as se3d_run_stage2_walk), a
+ * device-side compaction of the PUBLISHED persons and their D2H on a third stream.  Two batches may be in flight: the copies of batch
+ * k + 1 and k - 1 overlap the kernels of batch k.  se3d_stream_collect waits for the OLDEST batch and hands out its results in pinned
+ * host memory owned by the context (valid until the next-but-one submit): persons of frame slot i are
+ * fused[person_offset[i] .. person_offset[i + 1]).  Do not mix with the resident calls (se3d_stage_frames ...) on one context. */
+typedef struct se3d_stream_result {
+  int32_t n_frames;
+  int32_t n_persons;               /* published persons in the batch = person_offset[n_frames] */
+  const int32_t *person_offset;    /* [n_frames + 1] */
+  const se3d_person3d *fused;      /* [n_persons] persons3d_fused payloads, frame-slot order */
+  const se3d_person3d *fused_pred; /* [n_persons] persons3d_fused_pred */
+} se3d_stream_result;
+int se3d_stream_submit(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in *frames, int32_t n_seq, int32_t n_steps, const int32_t *frame_slot0,
+                       const double *t);
+int se3d_stream_collect(se3d_ctx *ctx, se3d_stream_result *out);
+
 /* --- feedback reprojection: drop-in for fusedSkeletonCallback (pose_reprojection/src/skeleton_reproj_mult_node.cpp:139-235) --
  * Projects fused/predicted 3D skeletons and their covariances (7-sigma-point unscented transform, :62-75) into every camera and
  * returns one Person2DList payload per camera (topic <cam>/skel_pred).  Cameras in double precision as the node uses them:

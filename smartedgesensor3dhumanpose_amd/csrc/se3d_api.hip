@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "se3d_device.h"
@@ -16,6 +17,9 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
 extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev);
 extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st);
 extern "C" void se3d_launch_dlt(const Se3dDev &D, const int32_t *d_assoc_orig, int nh, hipStream_t st, hipEvent_t *ev);
+extern "C" void se3d_launch_stream_scatter(const Se3dDev &D, const se3d_person2d *rag, const int32_t *off, hipStream_t st);
+extern "C" void se3d_launch_stream_compact(const se3d_person3d *fused, const se3d_person3d *pred, const int32_t *n_out, int n_frames, int H, int32_t *out_off,
+                                           se3d_person3d *dense_fused, se3d_person3d *dense_pred, hipStream_t st);
 extern "C" hipError_t se3d_stage1_init_device(void);
 extern "C" hipError_t se3d_stage2_init_device(void);
 
@@ -79,6 +83,21 @@ struct se3d_ctx {
   bool ev2_walk[kRing]{};                // set brackets one fused multi-step launch (events 0 and 3 only)
   int ev2_head = 0, ev2_pending = 0;
   bool ran2 = false;
+  // streaming ingest (se3d_stream_submit / se3d_stream_collect): two batches in flight
+  struct StreamSlot {
+    se3d_person2d *h_rag = nullptr, *d_rag = nullptr;   // ragged input, pinned host / device
+    int32_t *h_off = nullptr, *d_off = nullptr;         // [B][N + 1] absolute person offsets
+    se3d_person3d *d_fused = nullptr, *d_pred = nullptr, *h_fused = nullptr, *h_pred = nullptr;  // dense published persons
+    int32_t *d_out_off = nullptr, *h_out_off = nullptr; // [B + 1]
+    float *h_fb = nullptr, *d_fb = nullptr;             // [B][N] fb_delay of the batch (per slot: batch k + 1 is copied while batch k walks)
+    hipEvent_t in_done = nullptr, compute_done = nullptr, off_done = nullptr;
+    int n_frames = 0;
+    bool busy = false;
+  } ss[2];
+  hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+  bool stream_ready = false;
+  int ss_head = 0, ss_tail = 0;  // next slot to submit into / oldest batch not yet collected
+  const float *d_fb_walk = nullptr;  // fb_delay rows the next se3d_run_stage2_walk reads (streaming: the slot's; else d_fb)
   // feedback reprojection
   Se3dReproj R{};
   se3d_person3d *d_rp_in = nullptr;
@@ -385,6 +404,19 @@ void se3d_destroy(se3d_ctx *c) {
   if (c->h_flags2) (void)hipHostFree(c->h_flags2);
   if (c->h_preddt) (void)hipHostFree(c->h_preddt);
   if (c->h_rp_off) (void)hipHostFree(c->h_rp_off);
+  for (auto &sl : c->ss) {
+    if (sl.h_rag) (void)hipHostFree(sl.h_rag);
+    if (sl.h_off) (void)hipHostFree(sl.h_off);
+    if (sl.h_fused) (void)hipHostFree(sl.h_fused);
+    if (sl.h_pred) (void)hipHostFree(sl.h_pred);
+    if (sl.h_out_off) (void)hipHostFree(sl.h_out_off);
+    if (sl.h_fb) (void)hipHostFree(sl.h_fb);
+    if (sl.in_done) (void)hipEventDestroy(sl.in_done);
+    if (sl.compute_done) (void)hipEventDestroy(sl.compute_done);
+    if (sl.off_done) (void)hipEventDestroy(sl.off_done);
+  }
+  if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
+  if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
   for (auto &set : c->ev2)
     for (auto &e : set)
       if (e) (void)hipEventDestroy(e);
@@ -697,7 +729,7 @@ int se3d_run_stage2_walk(se3d_ctx *c, int32_t n_seq, int32_t n_steps, const int3
   Wk.n_steps = n_steps;
   for (int k = 0; k < n_steps; ++k) Wk.slot0[k] = frame_slot0[k];
   Wk.t = c->d_t; Wk.t_stride = n_seq;
-  Wk.outP = c->D.outP; Wk.out_count = c->D.out_count; Wk.fb = c->d_fb;
+  Wk.outP = c->D.outP; Wk.out_count = c->D.out_count; Wk.fb = c->d_fb_walk ? c->d_fb_walk : c->d_fb;
   Wk.Wf = Q0.fused; Wk.Wp = Q0.pred; Wk.Wit = Q0.iters; Wk.Wn = Q0.n_out; Wk.Wdt = Q0.pred_dt;
   hipEvent_t *ev = next_ev2(c);
   if (ev) { c->ev2_walk[(c->ev2_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = true; (void)hipEventRecord(ev[0], c->stream); }
@@ -747,6 +779,119 @@ int se3d_pack_stage2_walk_device_slots(se3d_ctx *c, int32_t n_frames, int32_t sl
   HIPCHK(c, hipMemcpy2DAsync(d_persons, sizeof(se3d_person3d) * (size_t)slots, Q.fused, sizeof(se3d_person3d) * (size_t)Q.H,
                              sizeof(se3d_person3d) * (size_t)slots, (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_counts, Q.n_out, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
+  return SE3D_OK;
+}
+
+// ---- streaming ingest: ragged pinned H2D -> device expansion -> stage 1 -> walk -> device compaction -> D2H of the published persons ----
+static int stream_init(se3d_ctx *c) {
+  if (c->stream_ready) return SE3D_OK;
+  const size_t B = c->D.d.B, N = c->D.d.N, P = c->D.d.P, H = c->D.d.H;
+  HIPCHK(c, hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
+  HIPCHK(c, hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+  for (auto &sl : c->ss) {
+    HIPCHK(c, hipHostMalloc((void **)&sl.h_rag, sizeof(se3d_person2d) * B * N * P, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&sl.h_off, sizeof(int32_t) * B * (N + 1), hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&sl.h_fused, sizeof(se3d_person3d) * B * H, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&sl.h_pred, sizeof(se3d_person3d) * B * H, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&sl.h_out_off, sizeof(int32_t) * (B + 1), hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&sl.h_fb, sizeof(float) * B * N, hipHostMallocDefault));
+    if (!dev_alloc(c, &sl.d_fb, B * N)) return SE3D_ERR_DEVICE;
+    if (!dev_alloc(c, &sl.d_rag, B * N * P) || !dev_alloc(c, &sl.d_off, B * (N + 1)) || !dev_alloc(c, &sl.d_fused, B * H) || !dev_alloc(c, &sl.d_pred, B * H) ||
+        !dev_alloc(c, &sl.d_out_off, B + 1))
+      return SE3D_ERR_DEVICE;
+    HIPCHK(c, hipEventCreateWithFlags(&sl.in_done, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.compute_done, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&sl.off_done, hipEventDisableTiming));
+  }
+  c->stream_ready = true;
+  return SE3D_OK;
+}
+
+int se3d_stream_submit(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames, int32_t n_seq, int32_t n_steps, const int32_t *frame_slot0, const double *t) {
+  if (!c || !frames || !t || !frame_slot0 || n_frames < 1 || n_seq < 1 || n_steps < 1 || n_steps > SE3D_WALK_MAX_STEPS) return SE3D_ERR_ARG;
+  const int B = c->D.d.B, N = c->D.d.N, P = c->D.d.P;
+  if (n_frames > B || (size_t)n_seq * n_steps > (size_t)n_frames) { c->err = "se3d_stream_submit: batch exceeds limits.max_frames / n_seq * n_steps exceeds the batch"; return SE3D_ERR_CAPACITY; }
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = stream_init(c);
+  if (rc != SE3D_OK) return rc;
+  se3d_ctx::StreamSlot &sl = c->ss[c->ss_head];
+  if (sl.busy) { c->err = "se3d_stream_submit: two batches are already in flight (collect one first)"; return SE3D_ERR_STATE; }
+  // ---- host: offsets, then the persons of every frame as ONE block into pinned memory (worker threads over frame ranges) ----
+  int32_t total = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    const se3d_frame_in &fr = frames[f];
+    if (fr.n_cam != N || !fr.det_offset || (fr.det_offset[N] > 0 && !fr.persons)) { c->err = "bad frame"; return SE3D_ERR_ARG; }
+    for (int cam = 0; cam <= N; ++cam) sl.h_off[(size_t)f * (N + 1) + cam] = total + fr.det_offset[cam];
+    for (int cam = 0; cam < N; ++cam) {
+      const int n = fr.det_offset[cam + 1] - fr.det_offset[cam];
+      if (n < 0) { c->err = "det_offset not monotone"; return SE3D_ERR_ARG; }
+      if (n > P) { c->err = "detections per camera exceed limits.max_det_per_cam"; return SE3D_ERR_CAPACITY; }
+      sl.h_fb[(size_t)f * N + cam] = fr.fb_delay ? fr.fb_delay[cam] : -1.0f;
+    }
+    total += fr.det_offset[N];
+  }
+  {
+    const int nthr = std::max(1, std::min<int>(8, std::min<int>((int)std::thread::hardware_concurrency(), n_frames / 256 + 1)));
+    auto work = [&](int f0, int f1) {
+      for (int f = f0; f < f1; ++f) {
+        const int n = frames[f].det_offset[N];
+        if (n) memcpy(sl.h_rag + sl.h_off[(size_t)f * (N + 1)], frames[f].persons, sizeof(se3d_person2d) * (size_t)n);
+      }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < nthr; ++k) th.emplace_back(work, (int)((int64_t)n_frames * k / nthr), (int)((int64_t)n_frames * (k + 1) / nthr));
+    work(0, n_frames / nthr);
+    for (auto &x : th) x.join();
+  }
+  // ---- H2D on the copy stream (no padding crosses PCIe), ordered after the previous use of this slot's device buffers ----
+  HIPCHK(c, hipMemcpyAsync(sl.d_rag, sl.h_rag, sizeof(se3d_person2d) * (size_t)total, hipMemcpyHostToDevice, c->s_h2d));
+  HIPCHK(c, hipMemcpyAsync(sl.d_off, sl.h_off, sizeof(int32_t) * (size_t)n_frames * (N + 1), hipMemcpyHostToDevice, c->s_h2d));
+  HIPCHK(c, hipMemcpyAsync(sl.d_fb, sl.h_fb, sizeof(float) * (size_t)n_frames * N, hipMemcpyHostToDevice, c->s_h2d));
+  HIPCHK(c, hipEventRecord(sl.in_done, c->s_h2d));
+  // ---- compute stream: expand, stage 1, walk, compact ----
+  HIPCHK(c, hipStreamWaitEvent(c->stream, sl.in_done, 0));
+  Se3dDev D = c->D;
+  D.d.B = n_frames;
+  se3d_launch_stream_scatter(D, sl.d_rag, sl.d_off, c->stream);
+  c->staged_frames = n_frames;
+  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled);
+  c->ran = true;
+  c->d_fb_walk = sl.d_fb;
+  rc = se3d_run_stage2_walk(c, n_seq, n_steps, frame_slot0, t);
+  c->d_fb_walk = nullptr;
+  if (rc != SE3D_OK) return rc;
+  se3d_launch_stream_compact(c->Q.fused, c->Q.pred, c->Q.n_out, n_frames, c->Q.H, sl.d_out_off, sl.d_fused, sl.d_pred, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(sl.compute_done, c->stream));
+  // ---- D2H stream: the offsets first (the host needs the total before it can size the copy of the persons) ----
+  HIPCHK(c, hipStreamWaitEvent(c->s_d2h, sl.compute_done, 0));
+  HIPCHK(c, hipMemcpyAsync(sl.h_out_off, sl.d_out_off, sizeof(int32_t) * (size_t)(n_frames + 1), hipMemcpyDeviceToHost, c->s_d2h));
+  HIPCHK(c, hipEventRecord(sl.off_done, c->s_d2h));
+  sl.n_frames = n_frames;
+  sl.busy = true;
+  c->ss_head ^= 1;
+  return SE3D_OK;
+}
+
+int se3d_stream_collect(se3d_ctx *c, se3d_stream_result *out) {
+  if (!c || !out) return SE3D_ERR_ARG;
+  se3d_ctx::StreamSlot &sl = c->ss[c->ss_tail];
+  if (!c->stream_ready || !sl.busy) { c->err = "se3d_stream_collect: no batch in flight"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventSynchronize(sl.off_done));
+  const int total = sl.h_out_off[sl.n_frames];
+  if (total > 0) {
+    HIPCHK(c, hipMemcpyAsync(sl.h_fused, sl.d_fused, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, c->s_d2h));
+    HIPCHK(c, hipMemcpyAsync(sl.h_pred, sl.d_pred, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, c->s_d2h));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->s_d2h));
+  out->n_frames = sl.n_frames;
+  out->n_persons = total;
+  out->person_offset = sl.h_out_off;
+  out->fused = sl.h_fused;
+  out->fused_pred = sl.h_pred;
+  sl.busy = false;
+  c->ss_tail ^= 1;
   return SE3D_OK;
 }
 

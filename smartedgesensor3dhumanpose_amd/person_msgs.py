@@ -62,6 +62,10 @@ class ReprojOut(C.Structure):
     _fields_ = [("capacity", C.c_int32), ("det_offset", C.POINTER(C.c_int32)), ("persons", C.c_void_p), ("person_index", C.POINTER(C.c_int32))]
 
 
+class StreamResult(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_persons", C.c_int32), ("person_offset", C.POINTER(C.c_int32)), ("fused", C.c_void_p), ("fused_pred", C.c_void_p)]
+
+
 def fptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 

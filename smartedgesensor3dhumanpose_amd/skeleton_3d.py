@@ -84,6 +84,33 @@ class Skeleton3D:
         self._chk(self._L.se3d_fetch_dlt(C.c_void_p(self._h), n, C.c_void_p(out.ctypes.data)), "se3d_fetch_dlt")
         return out
 
+    # -- streaming ingest: a batch of frames from the host every step, two batches in flight
+    def stream_prepare(self, frames):
+        """ctypes array of the frames (kept alive by the caller): building it is host bookkeeping of the caller, not part of the path."""
+        frames = list(frames)
+        return (pm.FrameIn * len(frames))(*[f.as_c() for f in frames]), frames
+
+    def stream_submit(self, prepared, t, frame_slot0):
+        arr, frames = prepared
+        t = np.ascontiguousarray(t, np.float64)
+        slots = np.ascontiguousarray(frame_slot0, np.int32)
+        assert t.ndim == 2 and len(slots) == t.shape[0]
+        self._chk(self._L.se3d_stream_submit(C.c_void_p(self._h), len(frames), arr, t.shape[1], t.shape[0], pm.iptr(slots),
+                                             t.ctypes.data_as(C.POINTER(C.c_double))), "se3d_stream_submit")
+
+    def stream_collect(self, copy=True):
+        """Oldest batch in flight -> (person_offset [n_frames + 1], fused [n], fused_pred [n]); views into the context's pinned memory
+        unless copy."""
+        r = pm.StreamResult()
+        self._chk(self._L.se3d_stream_collect(C.c_void_p(self._h), C.byref(r)), "se3d_stream_collect")
+        off = np.ctypeslib.as_array(r.person_offset, shape=(r.n_frames + 1,))
+        n = int(r.n_persons)
+        if n == 0:
+            return off.copy(), np.zeros(0, pm.person3d_dt), np.zeros(0, pm.person3d_dt)
+        fused = np.frombuffer((C.c_char * (n * pm.person3d_dt.itemsize)).from_address(r.fused), dtype=pm.person3d_dt)
+        pred = np.frombuffer((C.c_char * (n * pm.person3d_dt.itemsize)).from_address(r.fused_pred), dtype=pm.person3d_dt)
+        return (off.copy(), fused.copy(), pred.copy()) if copy else (off, fused, pred)
+
     # -- resident pipeline
     def stage(self, frames):
         frames = list(frames)
