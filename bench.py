@@ -411,6 +411,72 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank):
             "h2d_mb_per_step": in_bytes / 1e6, "skeletons_per_step": n_skel // steps}
 
 
+def run_hypothesis_shard(name, seq, rig, steps, dist, local_rank):
+    """north_star config 5 as a latency mode: ONE stream of frames, every rank holds the same frames, association and track lifecycle
+    replicated, triangulation and LM refinement split by index % world, RCCL all-gathers of the hypothesis / detection blocks
+    (shard.HypothesisShard).  Verified live: the sharded results of a whole walk equal the un-sharded results of the same context bit
+    for bit on every rank.  Only rows T/P/O/U and F/R/Z shard, so the speed-up over one GPU is bounded by their share of the step."""
+    import torch
+    from smartedgesensor3dhumanpose_amd import shard
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
+    w = WORKLOADS[name]
+    T_ = len(seq)
+    nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=T_, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank)
+    nd_.stage(seq)   # frame slot k = time step k of the one sequence
+    ts = 100.0 + (1.0 / 30.0) * np.arange(1, T_ + 1)
+
+    def walk(hs):
+        out = []
+        if hs is None:
+            nd_.run_stage1()
+        else:
+            hs.run_stage1()
+        for k in range(T_):
+            if hs is None:
+                nd_.run_stage2(ts[k:k + 1], frame_slot0=k)
+            else:
+                hs.run_stage2(ts[k:k + 1], k)
+            r = nd_.fetch_stage2(1)[0]
+            out.append((r.n_persons, r.c.n_tracks, r.fused[: r.n_persons].tobytes(), r.fused_pred[: r.n_persons].tobytes()))
+        return out, [r.published().tobytes() for r in nd_.fetch_stage1(T_)]
+    nd_.refine_reset()
+    ref = walk(None)
+    hs = shard.HypothesisShard(dist, nd_, T_, 1, torch.device("cuda", local_rank))
+    nd_.refine_reset()
+    got = walk(hs)
+    ok = torch.tensor([1 if got == ref else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    n_pub = sum(g[0] for g in got[0])
+    # timed: steady-state walks (tracks persist; forward only, stamps advance)
+    t_off = [float(ts[-1])]
+
+    def step():
+        hs.run_stage1()
+        tt = t_off[0] + (1.0 / 30.0) * np.arange(1, T_ + 1)
+        t_off[0] = float(tt[-1])
+        for k in range(T_):
+            hs.run_stage2(tt[k:k + 1], k)
+    step()
+    nd_.sync()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    nd_.sync()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    n_last = sum(r.n_persons for r in [nd_.fetch_stage2(1)[0]]) * T_   # persons of the last step x steps (steady state: constant per frame)
+    nd_.set_shard(0, 1)
+    nd_.close()
+    return {"verified_equal_to_single_rank": bool(ok.item()), "ms_per_frame": float(tmax.item()) / steps / T_ * 1e3, "frames_per_step": T_,
+            "skeletons_per_s": n_last * steps / float(tmax.item()), "published_in_verification_walk": n_pub,
+            "allgather_bytes_per_step": hs.bytes_per_step}
+
+
 def roofline_of(res, w, stage2, source):
     """HBM roofline of the dominant kernel of a measurement: achieved = algorithmic bytes per skeleton x skeletons per launch / average
     launch duration (HIP events on the kernel's own stream)."""
@@ -468,7 +534,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the 256cam128p secondary measurement of a default run")
     ap.add_argument("--no-serial", action="store_true", help="skip the serial per-kernel pass of a default run")
     ap.add_argument("--no-streaming", action="store_true", help="skip the PCIe-inclusive streaming measurement (value_streaming) of a default run")
-    ap.add_argument("--stream-contexts", type=int, default=4, help="contexts of the streaming measurement (each pins two batches of host memory)")
+    ap.add_argument("--stream-contexts", type=int, default=8, help="contexts of the streaming measurement (each pins two batches of host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -540,6 +606,9 @@ def main():
         sec = run_workload("256cam128p", seqs_sec, rig2, args, max(3, args.steps // 4), 1, dist, local_rank, True)
         sec["value_per_gpu"] = sec["value"] / world
 
+    hyp = None
+    if want_secondary and dist is not None:   # one 256cam128p stream, hypotheses sharded over the ranks (north_star config 5)
+        hyp = run_hypothesis_shard("256cam128p", _gen_one((256, 128, T_, 0)), rig2, 2, dist, local_rank)
     if rank == 0:
         main_res = head or serial
         pmc_dir = os.path.join(ROOT, "profiles", "r2")
@@ -592,6 +661,13 @@ def main():
                                  "skeletons_per_step_per_gpu": sec["n_skel_local"], "max_hypotheses_per_frame": sec["max_hyp_per_frame"],
                                  "target": "north_star: >= 1e5 skeletons/s on 8 GPUs = 12 500 per GPU", "exchange_verified": sec["exchange_verified"],
                                  "roofline": roof2}
+        if hyp is not None:
+            line["hypothesis_shard"] = {"workload": "ONE 256cam128p stream, %d-frame walks, every rank holds the same frames; hypotheses / detections "
+                                                    "split by index %% %d, association + lifecycle replicated" % (hyp["frames_per_step"], world),
+                                        "n_gpus": world, "ms_per_frame": round(hyp["ms_per_frame"], 3), "skeletons_per_s": round(hyp["skeletons_per_s"], 1),
+                                        "verified_equal_to_single_rank": hyp["verified_equal_to_single_rank"],
+                                        "allgather_bytes_per_step": hyp["allgather_bytes_per_step"],
+                                        "note": "latency mode of north_star config 5; throughput runs shard sequences (the headline / secondary values)"}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(rig, _gen_one((w["n_cam"], w["n_persons"], T_, 1000 * seed_rank)), main_res["params"], stage2)
         else:

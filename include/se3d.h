@@ -254,6 +254,24 @@ int se3d_get_pair_costs(se3d_ctx *ctx, int32_t frame, int32_t cam_a, int32_t cam
 int se3d_pack_stage1_device(se3d_ctx *ctx, void *d_persons, void *d_counts);
 int se3d_pack_stage2_device(se3d_ctx *ctx, int32_t n_seq, void *d_persons, void *d_counts);
 
+/* --- hypothesis shard of ONE stream over the ranks of a node (the reference's axes are its OpenMP loops over hypotheses,
+ * S3D:676-681, and over detections, PP:582-587).  Every rank stages the same frames; the association (rows N, E, G, M) and the track
+ * association / lifecycle (rows A2, L) run on every rank and give identical tables; rank r triangulates the hypotheses h with
+ * h % world == r and refines the detections i with i % world == r.  Two exchanges, done by the caller (RCCL all-gather in
+ * smartedgesensor3dhumanpose_amd/shard.py) on buffers in device memory:
+ *   stage 1: _pre writes [staged frames][ceil(max_hyp / world)] se3d_person3d (own hypotheses; se3d_shard_bytes(ctx, 1, frames));
+ *            _post takes the gathered [world][frames][ceil(max_hyp / world)] blocks and runs post-processing + duplicate merge;
+ *   stage 2: _pre writes [n_seq][ceil(max_hyp / world)] records (fused + predicted person and the updated track state;
+ *            se3d_shard_bytes(ctx, 2, n_seq)); _post applies the gathered [world][n_seq][...] records and runs the lifecycle.
+ * All four calls are asynchronous on the context stream; results are fetched with se3d_fetch_stage1 / se3d_fetch_stage2 and equal
+ * the single-rank results bit for bit.  se3d_set_shard(ctx, 0, 1) switches sharding off. */
+int se3d_set_shard(se3d_ctx *ctx, int32_t rank, int32_t world);
+int64_t se3d_shard_bytes(se3d_ctx *ctx, int32_t stage, int32_t n);
+int se3d_run_stage1_shard_pre(se3d_ctx *ctx, void *d_pack);
+int se3d_run_stage1_shard_post(se3d_ctx *ctx, const void *d_gathered);
+int se3d_run_stage2_shard_pre(se3d_ctx *ctx, int32_t n_seq, int32_t frame_slot0, const double *t, void *d_pack);
+int se3d_run_stage2_shard_post(se3d_ctx *ctx, int32_t n_seq, const void *d_gathered);
+
 /* --- measurement: HIP-event timing of the kernels on the context stream -------------------------------- */
 int se3d_profile_enable(se3d_ctx *ctx, int32_t on);
 int se3d_profile_reset(se3d_ctx *ctx);

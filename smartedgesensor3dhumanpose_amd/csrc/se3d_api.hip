@@ -13,8 +13,12 @@
 #include "se3d_device.h"
 
 extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st, int variant);
-extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled);
-extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev);
+extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled, int phases);
+extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev, int phases);
+extern "C" void se3d_launch_shard_pack_hyp(const Se3dDev &D, se3d_person3d *out, hipStream_t st);
+extern "C" void se3d_launch_shard_unpack_hyp(const Se3dDev &D, const se3d_person3d *gathered, hipStream_t st);
+extern "C" void se3d_launch_shard_pack_lm(const Se3dStage2 &Q, int nseq, Se3dShardRec *out, hipStream_t st);
+extern "C" void se3d_launch_shard_unpack_lm(const Se3dStage2 &Q, int nseq, const Se3dShardRec *gathered, hipStream_t st);
 extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st);
 extern "C" void se3d_launch_dlt(const Se3dDev &D, const int32_t *d_assoc_orig, int nh, hipStream_t st, hipEvent_t *ev);
 extern "C" void se3d_launch_stream_scatter(const Se3dDev &D, const se3d_person2d *rag, const int32_t *off, hipStream_t st);
@@ -97,6 +101,7 @@ struct se3d_ctx {
   hipStream_t s_h2d = nullptr, s_d2h = nullptr;
   bool stream_ready = false;
   int ss_head = 0, ss_tail = 0;  // next slot to submit into / oldest batch not yet collected
+  Se3dStage2 Q_shard{};   // views of the se3d_run_stage2_shard_pre call, reused by its _post half
   const float *d_fb_walk = nullptr;  // fb_delay rows the next se3d_run_stage2_walk reads (streaming: the slot's; else d_fb)
   // feedback reprojection
   Se3dReproj R{};
@@ -294,7 +299,7 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     for (auto &e : set) (void)hipEventCreate(&e);
   Se3dDev &D = c->D;
   const int np = N * (N - 1) / 2;
-  D.d = Se3dDims{B, N, P, H, np, params->pose_method, params->norm_height, params->max_epi_dist};
+  D.d = Se3dDims{B, N, P, H, np, params->pose_method, params->norm_height, params->max_epi_dist, 0, 1};
   bool ok = true;
   float *dRt = nullptr, *dK = nullptr, *dF = nullptr;
   se3d_person2d *draw = nullptr;
@@ -318,6 +323,7 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     Se3dStage2 &Q = c->Q;
     const size_t S = B;
     Q.S = B; Q.T = T; Q.H = H; Q.N = N; Q.pose_method = params->pose_method; Q.norm_height = params->norm_height; Q.seq0 = 0;
+    Q.shard_rank = 0; Q.shard_world = 1;
     ok = ok && dev_alloc(c, &Q.fb_buf, S * 3) && dev_alloc(c, &Q.t_prev, S) && dev_alloc(c, &Q.next_id, S) && dev_alloc(c, &Q.frame_nr, S);
     ok = ok && dev_alloc(c, &Q.n_tracks, S) && dev_alloc(c, &Q.order, S * T) && dev_alloc(c, &Q.pred_dt, S);
     ok = ok && dev_alloc(c, &Q.used, S * T) && dev_alloc(c, &Q.id, S * T) && dev_alloc(c, &Q.num_obs, S * T) && dev_alloc(c, &Q.has, S * T);
@@ -467,7 +473,7 @@ int se3d_run_stage1(se3d_ctx *c) {
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;  // grids cover the staged frames only (array strides do not depend on B)
   // the per-frame workspace (assoc, nviews, nhyp, flags, hypP) is reset by se3d_k_normalize, the first kernel of the pass
-  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled);
+  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 7);
   HIPCHK(c, hipGetLastError());
   c->ran = true;
   return SE3D_OK;
@@ -687,7 +693,7 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
   c->t_head = (c->t_head + 1) % se3d_ctx::kRing;
   HIPCHK(c, hipStreamSynchronize(c->stream));  // nd is a stack variable
   Q.dets = c->d_in2; Q.n_det = c->d_ndet2; Q.fb_delay = c->d_fb_ref; Q.t = c->d_t;
-  se3d_launch_stage2(Q, seq, 1, c->stream, next_ev2(c));
+  se3d_launch_stage2(Q, seq, 1, c->stream, next_ev2(c), 3);
   HIPCHK(c, hipGetLastError());
   c->ran2 = true;
   return fetch_stage2_range(c, seq, 1, out);
@@ -705,7 +711,7 @@ int se3d_run_stage2(se3d_ctx *c, int32_t n_seq, int32_t frame_slot0, const doubl
   HIPCHK(c, hipEventRecord(c->t_done[c->t_head], c->stream));
   c->t_head = (c->t_head + 1) % se3d_ctx::kRing;
   Q.dets = c->D.outP + (size_t)frame_slot0 * Q.H; Q.n_det = c->D.out_count + frame_slot0; Q.fb_delay = c->d_fb + (size_t)frame_slot0 * Q.N; Q.t = c->d_t;
-  se3d_launch_stage2(Q, 0, n_seq, c->stream, next_ev2(c));
+  se3d_launch_stage2(Q, 0, n_seq, c->stream, next_ev2(c), 3);
   HIPCHK(c, hipGetLastError());
   c->ran2 = true;
   return SE3D_OK;
@@ -739,7 +745,7 @@ int se3d_run_stage2_walk(se3d_ctx *c, int32_t n_seq, int32_t n_steps, const int3
       Se3dStage2 Q = Q0;
       Q.dets = Wk.outP + f0 * Q.H; Q.n_det = Wk.out_count + f0; Q.fb_delay = Wk.fb + f0 * Q.N; Q.t = c->d_t + (size_t)k * n_seq;
       Q.fused = Q0.fused + f0 * Q.H; Q.pred = Q0.pred + f0 * Q.H; Q.iters = Q0.iters + f0 * Q.H; Q.n_out = Q0.n_out + f0; Q.pred_dt = Q0.pred_dt + f0;
-      se3d_launch_stage2(Q, 0, n_seq, c->stream, nullptr);
+      se3d_launch_stage2(Q, 0, n_seq, c->stream, nullptr, 3);
     }
   }
   if (ev) (void)hipEventRecord(ev[3], c->stream);
@@ -779,6 +785,69 @@ int se3d_pack_stage2_walk_device_slots(se3d_ctx *c, int32_t n_frames, int32_t sl
   HIPCHK(c, hipMemcpy2DAsync(d_persons, sizeof(se3d_person3d) * (size_t)slots, Q.fused, sizeof(se3d_person3d) * (size_t)Q.H,
                              sizeof(se3d_person3d) * (size_t)slots, (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_counts, Q.n_out, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
+  return SE3D_OK;
+}
+
+// ---- hypothesis shard (SURVEY 8e / north_star config 5): replicated association, hypotheses and detections split over the ranks ----
+int se3d_set_shard(se3d_ctx *c, int32_t rank, int32_t world) {
+  if (!c || world < 1 || rank < 0 || rank >= world) return SE3D_ERR_ARG;
+  c->D.d.shard_rank = rank; c->D.d.shard_world = world;
+  c->Q.shard_rank = rank; c->Q.shard_world = world;
+  return SE3D_OK;
+}
+int64_t se3d_shard_bytes(se3d_ctx *c, int32_t stage, int32_t n) {
+  if (!c || n < 0) return 0;
+  const int64_t Hs = (c->D.d.H + c->D.d.shard_world - 1) / c->D.d.shard_world;
+  return (int64_t)n * Hs * (int64_t)(stage == 1 ? sizeof(se3d_person3d) : sizeof(Se3dShardRec));
+}
+int se3d_run_stage1_shard_pre(se3d_ctx *c, void *d_pack) {
+  if (!c || !d_pack) return SE3D_ERR_ARG;
+  if (c->staged_frames < 1) { c->err = "no frames staged"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  Se3dDev D = c->D;
+  D.d.B = c->staged_frames;
+  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 3);   // association on every rank, triangulation of the own hypotheses
+  se3d_launch_shard_pack_hyp(D, static_cast<se3d_person3d *>(d_pack), c->stream);
+  HIPCHK(c, hipGetLastError());
+  return SE3D_OK;
+}
+int se3d_run_stage1_shard_post(se3d_ctx *c, const void *d_gathered) {
+  if (!c || !d_gathered) return SE3D_ERR_ARG;
+  if (c->staged_frames < 1) return SE3D_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  Se3dDev D = c->D;
+  D.d.B = c->staged_frames;
+  se3d_launch_shard_unpack_hyp(D, static_cast<const se3d_person3d *>(d_gathered), c->stream);
+  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 4);   // post-processing + duplicate merge on every rank
+  HIPCHK(c, hipGetLastError());
+  c->ran = true;
+  return SE3D_OK;
+}
+int se3d_run_stage2_shard_pre(se3d_ctx *c, int32_t n_seq, int32_t frame_slot0, const double *t, void *d_pack) {
+  if (!c || !t || !d_pack || n_seq < 1 || frame_slot0 < 0) return SE3D_ERR_ARG;
+  if (!c->ran || frame_slot0 + n_seq > c->staged_frames) { c->err = "se3d_run_stage2_shard_pre needs a completed stage 1 over >= n_seq frames"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  Se3dStage2 Q = c->Q;
+  double *ht = c->h_t + (size_t)c->t_head * Q.S;
+  (void)hipEventSynchronize(c->t_done[c->t_head]);
+  memcpy(ht, t, sizeof(double) * (size_t)n_seq);
+  HIPCHK(c, hipMemcpyAsync(c->d_t, ht, sizeof(double) * (size_t)n_seq, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->t_done[c->t_head], c->stream));
+  c->t_head = (c->t_head + 1) % se3d_ctx::kRing;
+  Q.dets = c->D.outP + (size_t)frame_slot0 * Q.H; Q.n_det = c->D.out_count + frame_slot0; Q.fb_delay = c->d_fb + (size_t)frame_slot0 * Q.N; Q.t = c->d_t;
+  c->Q_shard = Q;
+  se3d_launch_stage2(Q, 0, n_seq, c->stream, nullptr, 1);   // track association on every rank, LM of the own detections
+  se3d_launch_shard_pack_lm(Q, n_seq, static_cast<Se3dShardRec *>(d_pack), c->stream);
+  HIPCHK(c, hipGetLastError());
+  return SE3D_OK;
+}
+int se3d_run_stage2_shard_post(se3d_ctx *c, int32_t n_seq, const void *d_gathered) {
+  if (!c || !d_gathered || n_seq < 1) return SE3D_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  se3d_launch_shard_unpack_lm(c->Q_shard, n_seq, static_cast<const Se3dShardRec *>(d_gathered), c->stream);
+  se3d_launch_stage2(c->Q_shard, 0, n_seq, c->stream, nullptr, 2);   // merge-distance matrix, publish, lifecycle on every rank
+  HIPCHK(c, hipGetLastError());
+  c->ran2 = true;
   return SE3D_OK;
 }
 
@@ -854,7 +923,7 @@ int se3d_stream_submit(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frame
   D.d.B = n_frames;
   se3d_launch_stream_scatter(D, sl.d_rag, sl.d_off, c->stream);
   c->staged_frames = n_frames;
-  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled);
+  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 7);
   c->ran = true;
   c->d_fb_walk = sl.d_fb;
   rc = se3d_run_stage2_walk(c, n_seq, n_steps, frame_slot0, t);

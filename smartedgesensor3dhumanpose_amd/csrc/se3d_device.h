@@ -25,6 +25,7 @@ struct Se3dDims {
   int B, N, P, H, npairs;
   int pose_method, norm_height;
   double max_epi;
+  int shard_rank, shard_world;  // hypothesis shard (se3d_set_shard): this context triangulates hypotheses h with h % world == rank
 };
 
 struct Se3dDev {
@@ -129,6 +130,17 @@ struct Se3dStage2 {
   int32_t *n_out;         // [S]
   uint32_t *flags2;       // [S]
   double *lm_scratch;     // [S][4][1865] HBM Schur workspace of the fused walk's non-forest LM fallback
+  int shard_rank, shard_world;  // hypothesis shard: the per-step LM kernel refines detections i with i % world == rank only
+};
+
+// One refined detection as it crosses the hypothesis-shard all-gather after the LM step: the two published payloads and the state of
+// the track the detection updated (what the owner's se3d_k_lm_refine wrote), so that every rank ends the step with identical state.
+struct Se3dShardRec {
+  se3d_person3d fused, pred;
+  double prev[SE3D_NFU * 3], vel[SE3D_NFU * 9], root[3], t_prev, height;
+  int32_t iters, num_obs;
+  uint32_t has;
+  uint8_t pub, pad[3];
 };
 
 // Multi-step stage-2 walk (se3d_run_stage2_walk): step k consumes the stage-1 output of frame slots slot0[k] .. slot0[k]+S-1 and

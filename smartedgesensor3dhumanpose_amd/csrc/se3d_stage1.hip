@@ -1389,6 +1389,7 @@ __global__ __launch_bounds__(256, 3) void se3d_k_triangulate(Se3dDev D) {
   __syncthreads();
   if (h >= D.nhyp[f]) return;
   if (D.nviews[f * H + h] < 2) return;
+  if (D.d.shard_world > 1 && h % D.d.shard_world != D.d.shard_rank) return;  // hypothesis shard: another rank's hypothesis
   if (j == 0) se3d_zero_unused_slots(D.hypP[(size_t)f * H + h], D.d.pose_method, lane);
   se3d_tri_joint_body(D, f, h, j, lane, reinterpret_cast<float *>(smem) + (size_t)wave * 15 * N, sRt);
 }
@@ -1429,6 +1430,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
   const int N = D.d.N, H = D.d.H;
   if (h >= D.nhyp[f]) return;
   if (D.nviews[f * H + h] < 2) return;
+  if (D.d.shard_world > 1 && h % D.d.shard_world != D.d.shard_rank) return;  // hypothesis shard: another rank's hypothesis
   for (int i = lane; i < 12 * N; i += 64) sRt[i] = D.Rt[i];
   __syncthreads();
   // ---- attached cameras of the hypothesis, ascending ----
@@ -1619,7 +1621,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_slow(Se3dDev D, int n_e
   uint32_t mymask = 0u;
   if (e < n_entries) {
     const int f = e / H, h = e - f * H;
-    if (h < D.nhyp[f] && D.nviews[e] >= 2) mymask = D.tri_slow[(size_t)e * 2] | D.tri_slow[(size_t)e * 2 + 1];
+    if (h < D.nhyp[f] && D.nviews[e] >= 2 && (D.d.shard_world <= 1 || h % D.d.shard_world == D.d.shard_rank)) mymask = D.tri_slow[(size_t)e * 2] | D.tri_slow[(size_t)e * 2 + 1];
   }
   unsigned long long todo = __ballot(mymask != 0u);
   if (!todo) return;
@@ -2002,8 +2004,11 @@ static void se3d_launch_triangulation(const Se3dDev &D, hipStream_t st) {
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
 }
 
-extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, bool tiled) {
+// phases: 1 = association (normalise, pair costs, camera sweep), 2 = triangulation, 4 = post-processing + duplicate merge
+extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, bool tiled, int phases) {
   const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H;
+  if (!(phases & 1)) goto after_association;
+  {
   const char *e_pairs = getenv("SE3D_PAIRS");  // flat | packed | tiled: A/B switches that force the stand-alone pair kernels
   const bool fused_np = !tiled && !e_pairs && N * P <= NP_MAX_DETS && D.d.npairs <= 2048;
   if (ev) (void)hipEventRecord(ev[0], st);
@@ -2045,12 +2050,49 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
       hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), (size_t)dynW, st, D, b, dynW);
     }
   }
+  }
+after_association:
   if (ev) (void)hipEventRecord(ev[3], st);
-  se3d_launch_triangulation(D, st);
+  if (phases & 2) se3d_launch_triangulation(D, st);
   if (ev) (void)hipEventRecord(ev[4], st);
-  if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), 0, st, D);
-  else hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
+  if (phases & 4) {
+    if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), 0, st, D);
+    else hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
+  }
   if (ev) (void)hipEventRecord(ev[5], st);
+}
+
+// =============================================================================================================
+// Hypothesis shard (north_star config 5): the association is replicated on every rank, rank r triangulates the hypotheses
+// h with h % world == r, the ranks all-gather their [frame][ceil(H / world)] blocks of hypothesis persons and every rank scatters all
+// blocks back into its hypothesis slots before the (replicated) post-processing and duplicate merge.
+// =============================================================================================================
+__global__ __launch_bounds__(64) void se3d_k_shard_pack_hyp(Se3dDev D, se3d_person3d *__restrict__ out) {
+  const int j = blockIdx.x, f = blockIdx.y, W = D.d.shard_world, Hs = gridDim.x, h = j * W + D.d.shard_rank;
+  constexpr int NW = (int)(sizeof(se3d_person3d) / 4);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)f * Hs + j);
+  if (h < D.d.H) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(D.hypP + (size_t)f * D.d.H + h);
+    for (int i = threadIdx.x; i < NW; i += 64) dst[i] = src[i];
+  } else {
+    for (int i = threadIdx.x; i < NW; i += 64) dst[i] = 0u;
+  }
+}
+__global__ __launch_bounds__(64) void se3d_k_shard_unpack_hyp(Se3dDev D, const se3d_person3d *__restrict__ gathered, int Hs) {
+  const int W = D.d.shard_world, r = blockIdx.x / Hs, j = blockIdx.x - r * Hs, f = blockIdx.y, h = j * W + r;
+  if (h >= D.d.H || r == D.d.shard_rank) return;   // own hypotheses are already in place
+  constexpr int NW = (int)(sizeof(se3d_person3d) / 4);
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(gathered + ((size_t)r * D.d.B + f) * Hs + j);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(D.hypP + (size_t)f * D.d.H + h);
+  for (int i = threadIdx.x; i < NW; i += 64) dst[i] = src[i];
+}
+extern "C" void se3d_launch_shard_pack_hyp(const Se3dDev &D, se3d_person3d *out, hipStream_t st) {
+  const int Hs = (D.d.H + D.d.shard_world - 1) / D.d.shard_world;
+  hipLaunchKernelGGL(se3d_k_shard_pack_hyp, dim3(Hs, D.d.B), dim3(64), 0, st, D, out);
+}
+extern "C" void se3d_launch_shard_unpack_hyp(const Se3dDev &D, const se3d_person3d *gathered, hipStream_t st) {
+  const int Hs = (D.d.H + D.d.shard_world - 1) / D.d.shard_world;
+  hipLaunchKernelGGL(se3d_k_shard_unpack_hyp, dim3(Hs * D.d.shard_world, D.d.B), dim3(64), 0, st, D, gathered, Hs);
 }
 
 // =============================================================================================================

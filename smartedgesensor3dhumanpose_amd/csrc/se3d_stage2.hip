@@ -1260,6 +1260,7 @@ template <int MODE>
 __global__ __launch_bounds__(64) void se3d_k_lm_refine(Se3dStage2 Q) {
   extern __shared__ __align__(16) unsigned char s2_smem[];
   using LdsT = typename std::conditional<MODE != 0, LmSchurLds, LmLds>::type;
+  if (Q.shard_world > 1 && (int)blockIdx.x % Q.shard_world != Q.shard_rank) return;  // hypothesis shard: another rank's detection
   s2_lm_body<MODE>(Q, blockIdx.x, blockIdx.y + Q.seq0, threadIdx.x, *reinterpret_cast<LdsT *>(s2_smem));
 }
 
@@ -2433,22 +2434,76 @@ extern "C" hipError_t se3d_stage2_init_device(void) {
   return hipSuccess;
 }
 
-extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev) {
+// Hypothesis shard, stage 2: after the (sharded) LM step every rank packs its detections' records (i % world == rank -> slot i / world),
+// the ranks all-gather them and every rank applies the other ranks' records: outputs per detection and the state of the updated track.
+__global__ __launch_bounds__(64) void se3d_k_shard_pack_lm(Se3dStage2 Q, Se3dShardRec *__restrict__ out) {
+  const int j = blockIdx.x, s = blockIdx.y + Q.seq0, Hs = gridDim.x, i = j * Q.shard_world + Q.shard_rank, lane = threadIdx.x;
+  Se3dShardRec *rec = out + (size_t)blockIdx.y * Hs + j;
+  if (i >= min(Q.n_det[s], Q.H)) return;
+  const size_t di = (size_t)s * Q.H + i;
+  constexpr int NW = (int)(sizeof(se3d_person3d) / 4);
+  const uint32_t *sf = reinterpret_cast<const uint32_t *>(Q.fused_det + di), *sp = reinterpret_cast<const uint32_t *>(Q.pred_det + di);
+  uint32_t *df = reinterpret_cast<uint32_t *>(&rec->fused), *dp = reinterpret_cast<uint32_t *>(&rec->pred);
+  for (int k = lane; k < NW; k += 64) { df[k] = sf[k]; dp[k] = sp[k]; }
+  const int slot = Q.det_slot[di];
+  if (lane == 0) { rec->iters = Q.iters_det[di]; rec->pub = Q.pub[di]; }
+  if (slot < 0) return;
+  const size_t sl = (size_t)s * Q.T + slot;
+  for (int k = lane; k < SE3D_NFU * 3; k += 64) rec->prev[k] = Q.prev[sl * SE3D_NFU * 3 + k];
+  for (int k = lane; k < SE3D_NFU * 9; k += 64) rec->vel[k] = Q.vel[sl * SE3D_NFU * 9 + k];
+  if (lane < 3) rec->root[lane] = Q.root_prev[sl * 3 + lane];
+  if (lane == 0) { rec->t_prev = Q.trk_t_prev[sl]; rec->height = Q.height_prev[sl]; rec->num_obs = Q.num_obs[sl]; rec->has = Q.has[sl]; }
+}
+__global__ __launch_bounds__(64) void se3d_k_shard_unpack_lm(Se3dStage2 Q, const Se3dShardRec *__restrict__ gathered, int Hs, int nseq) {
+  const int r = blockIdx.x / Hs, j = blockIdx.x - r * Hs, s = blockIdx.y + Q.seq0, i = j * Q.shard_world + r, lane = threadIdx.x;
+  if (r == Q.shard_rank || i >= min(Q.n_det[s], Q.H)) return;
+  const Se3dShardRec *rec = gathered + ((size_t)r * nseq + blockIdx.y) * Hs + j;
+  const size_t di = (size_t)s * Q.H + i;
+  constexpr int NW = (int)(sizeof(se3d_person3d) / 4);
+  const uint32_t *sf = reinterpret_cast<const uint32_t *>(&rec->fused), *sp = reinterpret_cast<const uint32_t *>(&rec->pred);
+  uint32_t *df = reinterpret_cast<uint32_t *>(Q.fused_det + di), *dp = reinterpret_cast<uint32_t *>(Q.pred_det + di);
+  for (int k = lane; k < NW; k += 64) { df[k] = sf[k]; dp[k] = sp[k]; }
+  const int slot = Q.det_slot[di];
+  if (lane == 0) { Q.iters_det[di] = rec->iters; Q.pub[di] = rec->pub; }
+  if (slot < 0) return;
+  const size_t sl = (size_t)s * Q.T + slot;
+  for (int k = lane; k < SE3D_NFU * 3; k += 64) Q.prev[sl * SE3D_NFU * 3 + k] = rec->prev[k];
+  for (int k = lane; k < SE3D_NFU * 9; k += 64) Q.vel[sl * SE3D_NFU * 9 + k] = rec->vel[k];
+  if (lane < 3) Q.root_prev[sl * 3 + lane] = rec->root[lane];
+  if (lane == 0) { Q.trk_t_prev[sl] = rec->t_prev; Q.height_prev[sl] = rec->height; Q.num_obs[sl] = rec->num_obs; Q.has[sl] = rec->has; }
+}
+extern "C" void se3d_launch_shard_pack_lm(const Se3dStage2 &Q, int nseq, Se3dShardRec *out, hipStream_t st) {
+  const int Hs = (Q.H + Q.shard_world - 1) / Q.shard_world;
+  hipLaunchKernelGGL(se3d_k_shard_pack_lm, dim3(Hs, nseq), dim3(64), 0, st, Q, out);
+}
+extern "C" void se3d_launch_shard_unpack_lm(const Se3dStage2 &Q, int nseq, const Se3dShardRec *gathered, hipStream_t st) {
+  const int Hs = (Q.H + Q.shard_world - 1) / Q.shard_world;
+  hipLaunchKernelGGL(se3d_k_shard_unpack_lm, dim3(Hs * Q.shard_world, nseq), dim3(64), 0, st, Q, gathered, Hs, nseq);
+}
+
+// phases: 1 = track costs + association + LM refinement, 2 = merge-distance matrix + publish / lifecycle
+extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev, int phases) {
   Se3dStage2 q = Q;
   q.seq0 = seq0;
   const int lm_mode = s2_lm_mode();
   if (ev) (void)hipEventRecord(ev[0], st);
   int dynW = (int)((size_t)q.H * q.T * sizeof(double));
   if (dynW > 128 * 1024) dynW = 128 * 1024;
-  hipLaunchKernelGGL(se3d_k_track_cost, dim3(q.T, nseq), dim3(128), 0, st, q);
-  hipLaunchKernelGGL(se3d_k_track_assoc, dim3(nseq), dim3(256), (size_t)dynW, st, q, dynW);
+  if (phases & 1) {
+    hipLaunchKernelGGL(se3d_k_track_cost, dim3(q.T, nseq), dim3(128), 0, st, q);
+    hipLaunchKernelGGL(se3d_k_track_assoc, dim3(nseq), dim3(256), (size_t)dynW, st, q, dynW);
+  }
   if (ev) (void)hipEventRecord(ev[1], st);
-  if (lm_mode == 0) hipLaunchKernelGGL(se3d_k_lm_refine<0>, dim3(q.H, nseq), dim3(64), sizeof(LmLds), st, q);
-  else if (lm_mode == 1) hipLaunchKernelGGL(se3d_k_lm_refine<1>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
-  else if (lm_mode == 2) hipLaunchKernelGGL(se3d_k_lm_refine<2>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
-  else hipLaunchKernelGGL(se3d_k_lm_refine<3>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
+  if (phases & 1) {
+    if (lm_mode == 0) hipLaunchKernelGGL(se3d_k_lm_refine<0>, dim3(q.H, nseq), dim3(64), sizeof(LmLds), st, q);
+    else if (lm_mode == 1) hipLaunchKernelGGL(se3d_k_lm_refine<1>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
+    else if (lm_mode == 2) hipLaunchKernelGGL(se3d_k_lm_refine<2>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
+    else hipLaunchKernelGGL(se3d_k_lm_refine<3>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
+  }
   if (ev) (void)hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL(se3d_k_track_near, dim3(q.T, nseq), dim3(64), 0, st, q);
-  hipLaunchKernelGGL(se3d_k_track_update, dim3(nseq), dim3(256), 0, st, q);
+  if (phases & 2) {
+    hipLaunchKernelGGL(se3d_k_track_near, dim3(q.T, nseq), dim3(64), 0, st, q);
+    hipLaunchKernelGGL(se3d_k_track_update, dim3(nseq), dim3(256), 0, st, q);
+  }
   if (ev) (void)hipEventRecord(ev[3], st);
 }

@@ -134,3 +134,63 @@ class SkeletonExchange:
         r = self.dist.get_rank()
         own_ok = torch.equal(gp[r].reshape(-1), self.packs[p]) and torch.equal(gc[r].reshape(-1), self.cnts[p])
         return bool(torch.equal(allsums.cpu(), got.cpu())) and own_ok
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Hypothesis shard of ONE stream (north_star config 5): replicated association, rank r owns the hypotheses / detections
+# with index % world == r, one all-gather of [frames][ceil(max_hyp / world)] blocks per stage-1 pass and per stage-2 step.
+# The device side is se3d_run_stage{1,2}_shard_{pre,post} (include/se3d.h); these helpers are the layout on the host and the collective.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def shard_slots(max_hyp, world):
+    return (max_hyp + world - 1) // world
+
+
+def pack_own(items, rank, world):
+    """items [n][max_hyp] (any dtype) -> this rank's block [n][ceil(max_hyp / world)]: slot j holds index j * world + rank (zero where
+    that index does not exist).  Same layout as se3d_k_shard_pack_hyp writes on the device."""
+    items = np.asarray(items)
+    n, H = items.shape[:2]
+    out = np.zeros((n, shard_slots(H, world)) + items.shape[2:], items.dtype)
+    own = items[:, rank::world]
+    out[:, : own.shape[1]] = own
+    return out
+
+
+def unpack_all(gathered, max_hyp):
+    """gathered [world][n][ceil(max_hyp / world)] (= all-gather of the ranks' pack_own blocks) -> [n][max_hyp]."""
+    gathered = np.asarray(gathered)
+    world, n = gathered.shape[:2]
+    out = np.zeros((n, max_hyp) + gathered.shape[3:], gathered.dtype)
+    for r in range(world):
+        m = len(range(r, max_hyp, world))
+        out[:, r::world] = gathered[r, :, :m]
+    return out
+
+
+class HypothesisShard:
+    """One context per rank working on the SAME frames: association and track lifecycle replicated, triangulation and LM refinement split
+    by index % world, results exchanged by RCCL all-gathers ordered on the context's stream (no host synchronisation)."""
+
+    def __init__(self, dist, node, n_frames, n_seq, device):
+        self.dist, self.node, self.n_frames, self.n_seq = dist, node, int(n_frames), int(n_seq)
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        node.set_shard(self.rank, self.world)
+        self.stream = torch.cuda.ExternalStream(node.stream_handle())
+        b1, b2 = node.shard_bytes(1, n_frames), node.shard_bytes(2, n_seq)
+        self.p1 = torch.zeros(b1, dtype=torch.uint8, device=device)
+        self.g1 = torch.zeros(b1 * self.world, dtype=torch.uint8, device=device)
+        self.p2 = torch.zeros(b2, dtype=torch.uint8, device=device)
+        self.g2 = torch.zeros(b2 * self.world, dtype=torch.uint8, device=device)
+        self.bytes_per_step = (b1 + n_frames // max(n_seq, 1) * b2) * self.world
+
+    def run_stage1(self):
+        self.node.run_stage1_shard_pre(self.p1.data_ptr())
+        with torch.cuda.stream(self.stream):   # the collective is ordered after the pack on the context's stream
+            self.dist.all_gather_into_tensor(self.g1, self.p1)
+        self.node.run_stage1_shard_post(self.g1.data_ptr())
+
+    def run_stage2(self, t, frame_slot0):
+        self.node.run_stage2_shard_pre(t, frame_slot0, self.p2.data_ptr())
+        with torch.cuda.stream(self.stream):
+            self.dist.all_gather_into_tensor(self.g2, self.p2)
+        self.node.run_stage2_shard_post(len(t), self.g2.data_ptr())

@@ -84,6 +84,27 @@ class Skeleton3D:
         self._chk(self._L.se3d_fetch_dlt(C.c_void_p(self._h), n, C.c_void_p(out.ctypes.data)), "se3d_fetch_dlt")
         return out
 
+    # -- hypothesis shard of one stream over the ranks: replicated association, hypotheses / detections split by index % world
+    def set_shard(self, rank, world):
+        self._chk(self._L.se3d_set_shard(C.c_void_p(self._h), int(rank), int(world)), "se3d_set_shard")
+
+    def shard_bytes(self, stage, n):
+        return int(self._L.se3d_shard_bytes(C.c_void_p(self._h), int(stage), int(n)))
+
+    def run_stage1_shard_pre(self, pack_ptr):
+        self._chk(self._L.se3d_run_stage1_shard_pre(C.c_void_p(self._h), C.c_void_p(pack_ptr)), "se3d_run_stage1_shard_pre")
+
+    def run_stage1_shard_post(self, gathered_ptr):
+        self._chk(self._L.se3d_run_stage1_shard_post(C.c_void_p(self._h), C.c_void_p(gathered_ptr)), "se3d_run_stage1_shard_post")
+
+    def run_stage2_shard_pre(self, t, frame_slot0, pack_ptr):
+        t = np.ascontiguousarray(t, np.float64)
+        self._chk(self._L.se3d_run_stage2_shard_pre(C.c_void_p(self._h), len(t), int(frame_slot0), t.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(pack_ptr)),
+                  "se3d_run_stage2_shard_pre")
+
+    def run_stage2_shard_post(self, n_seq, gathered_ptr):
+        self._chk(self._L.se3d_run_stage2_shard_post(C.c_void_p(self._h), int(n_seq), C.c_void_p(gathered_ptr)), "se3d_run_stage2_shard_post")
+
     # -- streaming ingest: a batch of frames from the host every step, two batches in flight
     def stream_prepare(self, frames):
         """ctypes array of the frames (kept alive by the caller): building it is host bookkeeping of the caller, not part of the path."""

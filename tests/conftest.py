@@ -42,7 +42,10 @@ class DeviceBuffer:
         from smartedgesensor3dhumanpose_amd import _lib
         _lib.lib()
         self._C, self.nbytes = C, int(nbytes)
-        self._hip = C.CDLL("libamdhip64.so")
+        # the HIP runtime the product library is already running on (torch's bundled copy when torch is installed): open THAT file —
+        # dlopen("libamdhip64.so") could pick another copy of the runtime (system ROCm) that does not match the loaded HSA runtime
+        loaded = [ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln]
+        self._hip = C.CDLL(loaded[0] if loaded else "libamdhip64.so")
         p = C.c_void_p()
         assert self._hip.hipMalloc(C.byref(p), C.c_size_t(self.nbytes)) == 0
         self.ptr = p.value
@@ -56,6 +59,12 @@ class DeviceBuffer:
         out = np.zeros(self.nbytes, np.uint8)
         assert self._hip.hipMemcpy(out.ctypes.data_as(self._C.c_void_p), self._C.c_void_p(self.ptr), self._C.c_size_t(self.nbytes), 2) == 0  # D2H
         return out.view(dtype)
+
+    def upload(self, arr):
+        import numpy as np
+        a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        assert a.nbytes <= self.nbytes
+        assert self._hip.hipMemcpy(self._C.c_void_p(self.ptr), a.ctypes.data_as(self._C.c_void_p), self._C.c_size_t(a.nbytes), 1) == 0  # H2D
 
     def free(self):
         if self.ptr:

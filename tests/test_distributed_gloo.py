@@ -156,3 +156,72 @@ def test_bench_launcher_builds_a_torchrun_command(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert "torch.cuda" not in sys.modules or not sys.modules["torch"].cuda.is_initialized()
+
+
+# ---- hypothesis shard of one stream (north_star config 5): layout + collective on two gloo ranks, compute = the oracle ----
+def _hworker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from smartedgesensor3dhumanpose_amd import person_msgs as pm, shard
+    from oracle import oracle_py as O
+    params = pm.Params(pm.POSE_SIMPLE, 0, 0.045)
+    frames = [_scene(s)[1] for s in range(3)]
+    rig = _scene(0)[0]
+    H = 10   # not a multiple of the world size: the last block is short
+    blocks = np.zeros((len(frames), H), pm.person3d_dt)
+    for k, fr in enumerate(frames):
+        a = O.triangulate(rig, params, fr, capacity=H, hyp_capacity=H).assoc()      # the association is replicated: every rank computes it
+        table = np.full((H, rig.n_cam), -1, np.int32)
+        table[: len(a)] = a
+        own = table.copy()
+        own[[h for h in range(H) if h % world != rank]] = -1                         # ... and triangulates only its own hypotheses
+        blocks[k] = O.triangulate_assoc(rig, params, fr, own)
+    mine = shard.pack_own(blocks, rank, world)
+    flat = torch.from_numpy(mine.view(np.uint8).reshape(-1).copy())
+    gath = torch.empty(world * flat.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(gath, flat)
+    allh = shard.unpack_all(gath.numpy().view(pm.person3d_dt).reshape(world, len(frames), shard.shard_slots(H, world)), H)
+    q.put((rank, allh.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hypothesis_shard_layout_world2_equals_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_hworker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from smartedgesensor3dhumanpose_amd import person_msgs as pm
+    from oracle import oracle_py as O
+    params = pm.Params(pm.POSE_SIMPLE, 0, 0.045)
+    rig = _scene(0)[0]
+    ref = np.zeros((3, 10), pm.person3d_dt)
+    for k in range(3):
+        fr = _scene(k)[1]
+        a = O.triangulate(rig, params, fr, capacity=10, hyp_capacity=10).assoc()
+        table = np.full((10, rig.n_cam), -1, np.int32)
+        table[: len(a)] = a
+        ref[k] = O.triangulate_assoc(rig, params, fr, table)
+    assert (ref["keypoints"]["score"] > 0).any()
+    for rank, blob in got:
+        assert blob == ref.tobytes(), "rank %d: gathered hypotheses differ from the single-rank result" % rank
+
+
+def test_shard_pack_unpack_roundtrip():
+    from smartedgesensor3dhumanpose_amd import shard
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 8):
+        for H in (1, 7, 8, 12):
+            x = rng.integers(0, 1000, (5, H, 3))
+            g = np.stack([shard.pack_own(x, r, world) for r in range(world)])
+            assert g.shape[2] == shard.shard_slots(H, world)
+            assert np.array_equal(shard.unpack_all(g, H), x)
