@@ -42,7 +42,7 @@ WORKLOADS = {
     # the marginals).
     "16cam6p": dict(n_cam=16, n_persons=6, seqs=512, contexts=12, max_det=8, max_hyp=12, bytes_s1=8972, bytes_s2=8900, flop_s1=0.12e6 + 1.86e6),
     "64cam32p": dict(n_cam=64, n_persons=32, seqs=32, contexts=3, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900, flop_s1=11.0e6 + 7.28e6),
-    "256cam128p": dict(n_cam=256, n_persons=128, seqs=1, contexts=3, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900, flop_s1=0.71e9 + 29.0e6),
+    "256cam128p": dict(n_cam=256, n_persons=128, seqs=1, contexts=4, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900, flop_s1=0.71e9 + 29.0e6),
 }
 FLOP_S2_PER_LM_ITER = 0.74e6
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -163,8 +163,26 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
     max_pub = [0]   # most skeletons any frame published (accounting pass): the exchange carries n_persons + 2 slots per frame
     lm_iters = []
 
+    # Large association problems (256 cameras): the pair-cost kernel is VALU-bound and fills the GPU, the camera sweep and the stage-2
+    # steps behind it are chains of small latency-bound launches.  With all contexts in the same phase the GPU alternates between
+    # saturated and nearly idle; chaining the pair kernels of the contexts by events (one at a time, round robin) staggers the contexts so
+    # that the latency-bound chains of two contexts run under the pair kernel of the third.
+    chain = w["n_cam"] >= 128 and NC > 1 and not os.environ.get("SE3D_BENCH_NO_CHAIN")
+    if chain:
+        tstreams = [torch.cuda.ExternalStream(nd_.stream_handle()) for nd_ in nodes] if ex is None else streams
+        pair_done = [None] * NC
+
     def issue_stage1(wk):
-        wk["node"].run_stage1()
+        if chain:
+            ci = wk["ci"]
+            prev = pair_done[(ci - 1) % NC]
+            if prev is not None:
+                tstreams[ci].wait_event(prev)
+            wk["node"].run_stage1_phases(1)
+            pair_done[ci] = tstreams[ci].record_event()
+            wk["node"].run_stage1_phases(8 | 2 | 4)
+        else:
+            wk["node"].run_stage1()
         if not stage2 and ex is not None:
             pk, cn = ex.pack_target(wk["ci"])
             wk["node"].pack_stage1_device(pk.data_ptr(), cn.data_ptr())

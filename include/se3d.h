@@ -154,6 +154,11 @@ int se3d_triangulate_batch(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in 
 /* resident pipeline for throughput: stage (H2D) once, run many times with inputs in HBM, fetch (D2H) */
 int se3d_stage_frames(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in *frames);
 int se3d_run_stage1(se3d_ctx *ctx); /* asynchronous on the context stream */
+/* The same pass in parts, for callers that schedule several contexts on one GPU (bench.py: at 256 cameras the VALU-bound pair-cost
+ * kernels of the contexts are chained by events so that one runs at a time while the latency-bound camera sweeps and stage-2 steps of
+ * the other contexts fill the gaps).  phases = bit mask, executed in this order: 1 normalisation + pair-cost table (rows N, E),
+ * 8 camera sweep (rows G, M), 2 triangulation (rows T, P, O, U), 4 post-processing + duplicate merge (rows X, D); 15 = se3d_run_stage1. */
+int se3d_run_stage1_phases(se3d_ctx *ctx, int32_t phases);
 int se3d_sync(se3d_ctx *ctx);
 /* The context's HIP stream (hipStream_t) so that a host framework can order its own work (e.g. an RCCL collective on the packed
  * skeletons) after the asynchronous calls of this context without a host-side synchronisation. */

@@ -13,7 +13,8 @@
 #include "se3d_device.h"
 
 extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st, int variant);
-extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled, int phases);
+extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled, int phases, hipStream_t st_hi,
+                                   hipEvent_t *ev_hi);
 extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev, int phases);
 extern "C" void se3d_launch_shard_pack_hyp(const Se3dDev &D, se3d_person3d *out, hipStream_t st);
 extern "C" void se3d_launch_shard_unpack_hyp(const Se3dDev &D, const se3d_person3d *gathered, hipStream_t st);
@@ -41,6 +42,9 @@ struct se3d_ctx {
   se3d_limits limits{};
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream_hi = nullptr;   // high-priority stream for the latency-bound chains of large problems (per-camera sweep, per-step stage 2)
+  hipEvent_t ev_hi[4]{};
+  hipEvent_t *cur_ev1 = nullptr;
   std::string err;
   std::vector<void *> allocs;
   int2 *pair_ab = nullptr;
@@ -287,7 +291,29 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
   c->limits = *limits;
   c->device = device_id;
   if (!hip_ok(c, hipSetDevice(device_id), "hipSetDevice")) { fprintf(stderr, "%s\n", c->err.c_str()); delete c; return nullptr; }
-  if (!hip_ok(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return nullptr; }
+  {
+    // Large rigs (>= 128 cameras): the bulk stream of the context (pair-cost kernel: millions of workgroups, 36 KB of LDS each) is kept off
+    // 32 CUs — one XCD — so that the small latency-bound launches of the camera sweep and the per-step stage 2 (high-priority stream, all
+    // CUs; a sweep workgroup wants ~100 KB of LDS for its Munkres matrix) always find a CU with room.  Measured at 256 cam x 128 p, four
+    // contexts: 21.0 k -> 22.5 k skeletons/s; 24 reserved CUs lose (20.6 k).  SE3D_RESERVE_CUS=R overrides (0 = off).
+    const char *er = getenv("SE3D_RESERVE_CUS");
+    const int reserve = er ? (limits->max_hyp > 64 ? atoi(er) : 0) : (N >= 128 ? 32 : 0);
+    hipDeviceProp_t prop;
+    bool ok_stream = false;
+    if (reserve > 0 && hipGetDeviceProperties(&prop, device_id) == hipSuccess && reserve < prop.multiProcessorCount) {
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int i = 0; i < ncu - reserve; ++i) mask[i / 32] |= 1u << (i % 32);
+      ok_stream = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+    }
+    if (!ok_stream && !hip_ok(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return nullptr; }
+  }
+  if (limits->max_hyp > 64 && !getenv("SE3D_NO_HI_STREAM")) {  // large association problems: their launch chains get a high-priority queue
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, hi) != hipSuccess) c->stream_hi = nullptr;
+    for (auto &e : c->ev_hi) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  }
   // dynamic-LDS limits of the large-LDS kernels: a per-device attribute, so it is set for every context's device
   if (!hip_ok(c, se3d_stage1_init_device(), "hipFuncSetAttribute (stage 1)") || !hip_ok(c, se3d_stage2_init_device(), "hipFuncSetAttribute (stage 2)")) {
     fprintf(stderr, "se3d_create: %s\n", c->err.c_str());
@@ -431,6 +457,9 @@ void se3d_destroy(se3d_ctx *c) {
   for (auto &set : c->ev)
     for (auto &e : set)
       if (e) (void)hipEventDestroy(e);
+  if (c->stream_hi) { (void)hipStreamSynchronize(c->stream_hi); (void)hipStreamDestroy(c->stream_hi); }
+  for (auto &e : c->ev_hi)
+    if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -473,9 +502,22 @@ int se3d_run_stage1(se3d_ctx *c) {
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;  // grids cover the staged frames only (array strides do not depend on B)
   // the per-frame workspace (assoc, nviews, nhyp, flags, hypP) is reset by se3d_k_normalize, the first kernel of the pass
-  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 7);
+  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi);
   HIPCHK(c, hipGetLastError());
   c->ran = true;
+  return SE3D_OK;
+}
+
+int se3d_run_stage1_phases(se3d_ctx *c, int32_t phases) {
+  if (!c || (phases & ~15) || !phases) return SE3D_ERR_ARG;
+  if (c->staged_frames < 1) { c->err = "no frames staged"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  Se3dDev D = c->D;
+  D.d.B = c->staged_frames;
+  if (phases & 1) c->cur_ev1 = next_ev1(c);   // one event set per pass, begun by the part that holds phase 1 and completed by the part with phase 4
+  se3d_launch_stage1(D, c->pair_ab, c->stream, c->cur_ev1, c->tiled, phases, c->stream_hi, c->ev_hi);
+  HIPCHK(c, hipGetLastError());
+  if (phases & 4) c->ran = true;
   return SE3D_OK;
 }
 
@@ -740,12 +782,22 @@ int se3d_run_stage2_walk(se3d_ctx *c, int32_t n_seq, int32_t n_steps, const int3
   hipEvent_t *ev = next_ev2(c);
   if (ev) { c->ev2_walk[(c->ev2_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = true; (void)hipEventRecord(ev[0], c->stream); }
   if (!se3d_launch_stage2_walk(Q0, Wk, n_seq, c->stream)) {
+    hipStream_t s2 = c->stream;
+    if (c->stream_hi) {  // the chain of 5 x n_steps small launches on the high-priority stream
+      (void)hipEventRecord(c->ev_hi[2], c->stream);
+      (void)hipStreamWaitEvent(c->stream_hi, c->ev_hi[2], 0);
+      s2 = c->stream_hi;
+    }
     for (int k = 0; k < n_steps; ++k) {  // per-step kernels with the same per-step views (large association problems)
       const size_t f0 = (size_t)frame_slot0[k];
       Se3dStage2 Q = Q0;
       Q.dets = Wk.outP + f0 * Q.H; Q.n_det = Wk.out_count + f0; Q.fb_delay = Wk.fb + f0 * Q.N; Q.t = c->d_t + (size_t)k * n_seq;
       Q.fused = Q0.fused + f0 * Q.H; Q.pred = Q0.pred + f0 * Q.H; Q.iters = Q0.iters + f0 * Q.H; Q.n_out = Q0.n_out + f0; Q.pred_dt = Q0.pred_dt + f0;
-      se3d_launch_stage2(Q, 0, n_seq, c->stream, nullptr, 3);
+      se3d_launch_stage2(Q, 0, n_seq, s2, nullptr, 3);
+    }
+    if (s2 != c->stream) {
+      (void)hipEventRecord(c->ev_hi[3], s2);
+      (void)hipStreamWaitEvent(c->stream, c->ev_hi[3], 0);
     }
   }
   if (ev) (void)hipEventRecord(ev[3], c->stream);
@@ -806,7 +858,7 @@ int se3d_run_stage1_shard_pre(se3d_ctx *c, void *d_pack) {
   HIPCHK(c, hipSetDevice(c->device));
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;
-  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 3);   // association on every rank, triangulation of the own hypotheses
+  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 11, c->stream_hi, c->ev_hi);   // association on every rank, triangulation of the own hypotheses
   se3d_launch_shard_pack_hyp(D, static_cast<se3d_person3d *>(d_pack), c->stream);
   HIPCHK(c, hipGetLastError());
   return SE3D_OK;
@@ -818,7 +870,7 @@ int se3d_run_stage1_shard_post(se3d_ctx *c, const void *d_gathered) {
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;
   se3d_launch_shard_unpack_hyp(D, static_cast<const se3d_person3d *>(d_gathered), c->stream);
-  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 4);   // post-processing + duplicate merge on every rank
+  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 4, c->stream_hi, c->ev_hi);   // post-processing + duplicate merge on every rank
   HIPCHK(c, hipGetLastError());
   c->ran = true;
   return SE3D_OK;
@@ -923,7 +975,7 @@ int se3d_stream_submit(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frame
   D.d.B = n_frames;
   se3d_launch_stream_scatter(D, sl.d_rag, sl.d_off, c->stream);
   c->staged_frames = n_frames;
-  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 7);
+  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi);
   c->ran = true;
   c->d_fb_walk = sl.d_fb;
   rc = se3d_run_stage2_walk(c, n_seq, n_steps, frame_slot0, t);

@@ -1710,21 +1710,22 @@ __device__ __forceinline__ int se3d_post_filter(se3d_person3d &p, int pm) {
 // per-person filters, the duplicate merge and the ordered compaction run at LDS instead of L2/HBM latency, without workgroup barriers.
 #define SE3D_POST_SMALL_H 16
 __global__ __launch_bounds__(64) void se3d_k_postprocess_wave(Se3dDev D) {
-  __shared__ se3d_person3d sp[SE3D_POST_SMALL_H];
+  extern __shared__ __align__(16) unsigned char post_smem[];   // H persons (not SE3D_POST_SMALL_H): 20 KB at H = 12 -> 7 wavefronts per CU
+  se3d_person3d *sp = reinterpret_cast<se3d_person3d *>(post_smem);
   const int f = blockIdx.x, lane = threadIdx.x;
   const int N = D.d.N, P = D.d.P, H = D.d.H;
   const int pm = D.d.pose_method;
   const int nh = D.nhyp[f];
   const se3d_person3d *persons = D.hypP + (size_t)f * H;
-  constexpr int words = (int)(sizeof(se3d_person3d) / 4);
+  constexpr int words2 = (int)(sizeof(se3d_person3d) / 8);   // a person is 211 8-byte words: half the copy instructions of a dword copy
   int ncam = 0;
   for (int c = lane; c < N; c += 64) ncam += (D.nraw[f * N + c] > 0) ? 1 : 0;
   for (int o = 32; o > 0; o >>= 1) ncam += __shfl_xor(ncam, o);
   const bool few = ncam < 2;  // S3D:557-560
   {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(persons);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(sp);
-    for (int w = lane; w < nh * words; w += 64) dst[w] = src[w];
+    const uint2 *src = reinterpret_cast<const uint2 *>(persons);
+    uint2 *dst = reinterpret_cast<uint2 *>(sp);
+    for (int w = lane; w < nh * words2; w += 64) dst[w] = src[w];
   }
   __syncthreads();
   bool al = false;
@@ -1775,9 +1776,9 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave(Se3dDev D) {
   int pos = 0;
   for (unsigned long long m = alive; m; m &= m - 1ull, ++pos) {
     const int h = __ffsll((long long)m) - 1;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&sp[h]);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(&D.outP[(size_t)f * H + pos]);
-    for (int w = lane; w < words; w += 64) dst[w] = src[w];
+    const uint2 *src = reinterpret_cast<const uint2 *>(&sp[h]);
+    uint2 *dst = reinterpret_cast<uint2 *>(&D.outP[(size_t)f * H + pos]);
+    for (int w = lane; w < words2; w += 64) dst[w] = src[w];
     if (lane == 0) D.out_hyp[(size_t)f * H + pos] = h;
   }
   if (lane == 0) {
@@ -2004,14 +2005,16 @@ static void se3d_launch_triangulation(const Se3dDev &D, hipStream_t st) {
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
 }
 
-// phases: 1 = association (normalise, pair costs, camera sweep), 2 = triangulation, 4 = post-processing + duplicate merge
-extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, bool tiled, int phases) {
+// phases (bit mask): 1 = normalise + pair-cost table, 8 = camera sweep, 2 = triangulation, 4 = post-processing + duplicate merge
+// st_hi / ev_hi: optional high-priority stream (+ two events) for the per-camera sweep launches of large problems: 2 x N tiny dependent
+// launches that otherwise queue behind the millions of workgroups of other contexts' pair kernels.
+extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, bool tiled, int phases,
+                                   hipStream_t st_hi, hipEvent_t *ev_hi) {
   const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H;
-  if (!(phases & 1)) goto after_association;
-  {
+  if (phases & 1) {
   const char *e_pairs = getenv("SE3D_PAIRS");  // flat | packed | tiled: A/B switches that force the stand-alone pair kernels
   const bool fused_np = !tiled && !e_pairs && N * P <= NP_MAX_DETS && D.d.npairs <= 2048;
-  if (ev) (void)hipEventRecord(ev[0], st);
+  if (ev && (phases & 1)) (void)hipEventRecord(ev[0], st);
   if (!fused_np) hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D, 1);
   if (ev) (void)hipEventRecord(ev[1], st);
   if (fused_np) {  // normalisation + packed pair table in one workgroup per frame, normalised points only in LDS
@@ -2030,6 +2033,8 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     hipLaunchKernelGGL(se3d_k_pairs_flat, dim3(blocks), dim3(256), 0, st, D, pair_ab);
   }
   if (ev) (void)hipEventRecord(ev[2], st);
+  }
+  if (phases & 8) {
   // Munkres working matrix in LDS when H*P doubles fit next to the static LDS of the kernel (<= 128 KB)
   int dynW = (int)((size_t)H * P * sizeof(double));
   if (dynW > 128 * 1024) dynW = 128 * 1024;
@@ -2045,21 +2050,30 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   } else if (H * P <= fused_limit && dynW <= 64 * 1024) {
     hipLaunchKernelGGL(se3d_k_sweep_fused, dim3(B), dim3(256), (size_t)dynW, st, D, dynW);
   } else {
+    hipStream_t sw = st;
+    if (st_hi && ev_hi) {  // pair table complete -> the sweep chain runs on the high-priority stream -> triangulation waits for it
+      (void)hipEventRecord(ev_hi[0], st);
+      (void)hipStreamWaitEvent(st_hi, ev_hi[0], 0);
+      sw = st_hi;
+    }
     for (int b = 0; b < N; ++b) {
-      if (b > 0) hipLaunchKernelGGL(se3d_k_sweep_cost, dim3(H, B), dim3(128), 0, st, D, b);
-      hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), (size_t)dynW, st, D, b, dynW);
+      if (b > 0) hipLaunchKernelGGL(se3d_k_sweep_cost, dim3(H, B), dim3(128), 0, sw, D, b);
+      hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), (size_t)dynW, sw, D, b, dynW);
+    }
+    if (sw != st) {
+      (void)hipEventRecord(ev_hi[1], sw);
+      (void)hipStreamWaitEvent(st, ev_hi[1], 0);
     }
   }
   }
-after_association:
-  if (ev) (void)hipEventRecord(ev[3], st);
+  if (ev && (phases & 8)) (void)hipEventRecord(ev[3], st);
   if (phases & 2) se3d_launch_triangulation(D, st);
-  if (ev) (void)hipEventRecord(ev[4], st);
+  if (ev && (phases & 2)) (void)hipEventRecord(ev[4], st);
   if (phases & 4) {
-    if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), 0, st, D);
+    if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), sizeof(se3d_person3d) * (size_t)H, st, D);
     else hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
   }
-  if (ev) (void)hipEventRecord(ev[5], st);
+  if (ev && (phases & 4)) (void)hipEventRecord(ev[5], st);
 }
 
 // =============================================================================================================

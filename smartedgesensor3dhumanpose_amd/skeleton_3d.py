@@ -142,6 +142,10 @@ class Skeleton3D:
     def run_stage1(self):
         self._chk(self._L.se3d_run_stage1(C.c_void_p(self._h)), "se3d_run_stage1")
 
+    def run_stage1_phases(self, phases):
+        """1 normalise + pair table, 8 camera sweep, 2 triangulation, 4 post-processing (bit mask, executed in that order)."""
+        self._chk(self._L.se3d_run_stage1_phases(C.c_void_p(self._h), int(phases)), "se3d_run_stage1_phases")
+
     def stream_handle(self):
         """hipStream_t of this context as an integer (e.g. for torch.cuda.ExternalStream)."""
         return int(self._L.se3d_stream_handle(C.c_void_p(self._h)) or 0)
