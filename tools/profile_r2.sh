@@ -22,11 +22,11 @@ serial)
   python3 tools/pmc_traffic2.py $OUT/serial_fetch $OUT/serial_write $OUT/pmc_traffic_16cam6p_serial.json 6144 "bench.py --serial --steps 2 --warmup 1"
   ;;
 c256)
-  rm -rf $OUT/c256_stats1 $OUT/c256_stats3 $OUT/c256_sq
+  rm -rf $OUT/c256_stats1 $OUT/c256_stats3 $OUT/c256_sq $OUT/c256_fetch $OUT/c256_write
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c256_stats1 -- python3 bench.py --workload 256cam128p --contexts 1 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/c256_bench_1ctx.log 2>&1
   python3 tools/kernel_stats.py $OUT/c256_stats1 $OUT/c256_1ctx_kernel_stats.csv
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c256_stats3 -- python3 bench.py --workload 256cam128p --steps 3 --warmup 1 --no-cpu-baseline > $OUT/c256_bench_3ctx.log 2>&1
-  python3 tools/kernel_stats.py $OUT/c256_stats3 $OUT/c256_3ctx_kernel_stats.csv
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c256_stats3 -- python3 bench.py --workload 256cam128p --steps 3 --warmup 2 --no-cpu-baseline > $OUT/c256_bench_4ctx.log 2>&1
+  python3 tools/kernel_stats.py $OUT/c256_stats3 $OUT/c256_4ctx_kernel_stats.csv
   timeout 900 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/c256_sq -- python3 bench.py --workload 256cam128p --contexts 1 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/c256_bench_sq.log 2>&1
   python3 tools/pmc_sq.py $OUT/c256_sq $OUT/pmc_sq_256cam128p_1ctx.json "bench.py --workload 256cam128p --contexts 1 --steps 1 --warmup 1"
   ;;
