@@ -5,7 +5,7 @@ from smartedgesensor3dhumanpose_amd import person_msgs as pm
 
 POS_TOL_M = 1e-3        # north_star: per-joint error < 1 mm vs the CPU reference path (max, not mean)
 SCORE_RTOL = 2e-5       # float32 mean-of-confidences; GPU sums in a different order
-COV_REL_FRO = 5e-3      # float32 unscented transform in the reference: sample differences are quantised at ~1e-6 m
+COV_REL_FRO = 1e-3      # covariances relative Frobenius <= 1e-3 (measured maxima are printed by the tests)
 
 
 def normalized_detections(rig, frame):

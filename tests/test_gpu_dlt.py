@@ -123,3 +123,78 @@ def test_dlt_thin_hypotheses_and_errors(extr_rig, oracle, demo_params):
     with pytest.raises(Se3dError):
         node.run_dlt()                                                                  # no table staged
     node.close()
+
+
+def _exact_ut_cov(Rt, pts, cov2, centre):
+    """The reference's unscented transform (S3D:471-523) evaluated in float64: sigma points as the reference forms them (float32 inputs,
+    kappa = 0.5, offsets along the Cholesky factor of each view's 2x2 covariance), every sample triangulated by an exact SVD, deviations from
+    the given (float32) centre, equal weights 1 / (2 (2n + kappa)) (2 kappa == 1)."""
+    n = len(Rt)
+    P = Rt.astype(np.float64).reshape(n, 3, 4)
+
+    def tri(xy):
+        rows = []
+        for c in range(n):
+            for r in (xy[c, 0] * P[c, 2] - P[c, 0], xy[c, 1] * P[c, 2] - P[c, 1]):
+                rows.append(r / np.linalg.norm(r))
+        v = np.linalg.svd(np.array(rows))[2][-1]
+        return v[:3] / v[3]
+    b = np.float32(np.sqrt(np.float32(2 * n) + np.float32(0.5)))
+    samples = [pts[:, :2].astype(np.float64)]
+    for c in range(n):
+        l11 = np.sqrt(cov2[c, 0]); l21 = cov2[c, 1] / l11; l22 = np.sqrt(cov2[c, 2] - l21 * l21)      # float32 like the reference
+        for dx, dy in ((-l11 * b, -l21 * b), (np.float32(0), -l22 * b), (l11 * b, l21 * b), (np.float32(0), l22 * b)):
+            s = pts[:, :2].copy()
+            s[c, 0] += dx; s[c, 1] += dy
+            samples.append(s.astype(np.float64))
+    w = 1.0 / (2.0 * (2 * n + 0.5))
+    dev = np.array([tri(s) - centre.astype(np.float64) for s in samples])
+    return w * dev.T @ dev
+
+
+def test_ut_covariance_error_budget(extr_rig, oracle, demo_params):
+    """Why the GPU-vs-oracle covariance tolerance is 5e-3 and not SURVEY 8c's 1e-3: against the EXACT (float64) evaluation of the reference's
+    unscented transform the HIP kernels are within 1e-3 (they solve every sample in fp64 and round to float32 like the reference), the
+    float32 oracle — i.e. the reference's own arithmetic — is the noisier side."""
+    frames = sum((S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=1, seed=seed))[0] for seed in (0, 1, 2)), [])
+    assoc = _assoc_tables(oracle, extr_rig, demo_params, frames, 12)
+    node = _node(extr_rig, max_frames=len(frames), max_det_per_cam=8, max_hyp=12)
+    got = node.triangulate_assoc(frames, assoc)
+    node.close()
+    w6 = np.array([1, 2, 2, 1, 2, 1.0])
+    K = extr_rig.K
+    worst_gpu, worst_ora, n = 0.0, 0.0, 0
+    for k, fr in enumerate(frames):
+        ora = oracle.triangulate_assoc(extr_rig, demo_params, fr, assoc[k])
+        for h in range(6):
+            for j in (0, 5, 9, 12, 16):   # nose, shoulder, wrist, hip, ankle
+                fu = pm.KP2FUSION_SIMPLE[j]
+                if not ora[h]["keypoints"]["score"][fu] > 0:
+                    continue
+                cams, pts, cov2 = [], [], []
+                for c in range(extr_rig.n_cam):
+                    d = assoc[k, h, c]
+                    if d < 0:
+                        continue
+                    kp = fr.persons[fr.det_offset[c] + d]["keypoints"][j]
+                    if kp["score"] < np.float32(0.30):
+                        continue
+                    fx, fy, cx, cy = [np.float32(v) for v in K[c]]
+                    cams.append(c)
+                    pts.append([(kp["x"] - cx) / fx, (kp["y"] - cy) / fy, kp["score"]])
+                    cov2.append([kp["cov"][0] / (fx * fx), kp["cov"][1] / (fx * fy), kp["cov"][2] / (fy * fy)])
+                pts, cov2 = np.array(pts, np.float32), np.array(cov2, np.float32)
+                for name, arr in (("gpu", got[k, h]), ("ora", ora[h])):   # each side against the exact evaluation about ITS OWN float32 centre
+                    centre = arr["keypoints"]["joint"][fu].astype(np.float32)
+                    Cx = _exact_ut_cov(extr_rig.Rt[cams], pts, cov2, centre)
+                    exact6 = Cx[[0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]]
+                    rel = np.sqrt((((arr["keypoints"]["cov"][fu] - exact6) ** 2) * w6).sum()) / np.sqrt(((exact6 ** 2) * w6).sum())
+                    if name == "gpu":
+                        worst_gpu = max(worst_gpu, rel)
+                    else:
+                        worst_ora = max(worst_ora, rel)
+                n += 1
+    print("UT covariance, relative Frobenius error against the exact float64 evaluation over %d joints: HIP %.2e, float32 oracle %.2e" % (n, worst_gpu, worst_ora))
+    assert n >= 60
+    assert worst_gpu < 1e-3, worst_gpu          # SURVEY 8c's bar, met against the exact arithmetic
+    assert worst_gpu <= worst_ora               # the oracle's float32 SVD is the noisier side
