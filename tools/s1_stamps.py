@@ -9,7 +9,7 @@ import bench
 wl = sys.argv[1] if len(sys.argv) > 1 else "256cam128p"
 w = bench.WORKLOADS[wl]
 rig = bench.make_rig(w)
-seqs = bench.make_sequences(rig, w, 1, 0, 4)
+seqs = bench.make_sequences(None, w, 1, 1, 0, 4)[0]
 frames = [seqs[0][k] for k in range(4)]
 from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
 node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=4, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"])

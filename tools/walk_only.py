@@ -9,7 +9,7 @@ rig = Bn.make_rig(w)
 S_, T_, NC = (int(sys.argv[2]) if len(sys.argv) > 2 else 128), 16, int(sys.argv[1])
 nodes = []
 for ci in range(NC):
-    seqs = Bn.make_sequences(rig, w, S_, seed0=100 * ci, t_steps=T_)
+    seqs = Bn.make_sequences(None, w, 1, S_, ci, T_)[0]
     frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
     nd = Skeleton3D(rig, max_epi_dist=0.045, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12)
     nd.stage(frames); nd.run_stage1(); nd.refine_reset(); nodes.append(nd)
