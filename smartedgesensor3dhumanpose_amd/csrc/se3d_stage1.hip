@@ -1054,6 +1054,39 @@ __device__ __forceinline__ void se3d_gram_add(double g[10], const float r[4]) {
   g[9] = __builtin_fma(sd, d, g[9]);
 }
 
+// ---- sigma samples of the unscented transform (S3D:471-523) --------------------------------------------------------------------
+// A view contributes four samples: (-dx1, -dy1), (0, -dy2), (+dx1, +dy1), (0, +dy2).  Row r0 = normalize(x P2 - P0) of the DLT system
+// depends on x only and r1 = normalize(y P2 - P1) on y only, so the two "y-only" samples leave r0 untouched: class A (centre + the
+// 2n diagonal samples) rebuilds both rows, class B (the 2n y-only samples) rebuilds r1 alone.  Sample rows are normalised with the
+// hardware reciprocal square root (1 ulp): the samples feed a covariance that is compared at 1e-3, not the association or the point (the
+// weighted solve keeps the exact row build of se3d_dlt_rows).
+__device__ __forceinline__ void se3d_dlt_row_fast(const float *__restrict__ M, int which, float coord, float r[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[k] = coord * M[8 + k] - M[4 * which + k];
+  const float z = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+  if (z > 0.f) { const float inv = __builtin_amdgcn_rsqf(z);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = r[k] * inv; }
+}
+// Gram matrix of sample (view c, kind): kind 0 centre (unchanged), 1 / 2 class A with sign -1 / +1, 3 / 4 class B with sign -1 / +1.
+__device__ __forceinline__ void se3d_sigma_gram(double g[10], const float *__restrict__ M, float x, float y, float l11, float l21, float l22, float bsc,
+                                                const float o0[4], const float o1[4], int kind) {
+  if (kind == 0) return;
+  const float sgn = (kind & 1) ? -1.f : 1.f;
+  float n1[4];
+  if (kind <= 2) {
+    float n0[4];
+    se3d_dlt_row_fast(M, 0, x + sgn * (l11 * bsc), n0);
+    se3d_dlt_row_fast(M, 1, y + sgn * (l21 * bsc), n1);
+    se3d_gram_add<true>(g, o0); se3d_gram_add<true>(g, o1);
+    se3d_gram_add(g, n0); se3d_gram_add(g, n1);
+  } else {
+    se3d_dlt_row_fast(M, 1, y + sgn * (l22 * bsc), n1);
+    se3d_gram_add<true>(g, o1);
+    se3d_gram_add(g, n1);
+  }
+}
+
 __device__ __forceinline__ double se3d_readlane_f64(double v, int l) {  // l uniform
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
@@ -1335,6 +1368,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
     const double hn = 1.0 / sqrt((double)X * X + (double)Y * Y + (double)Z * Z + 1.0);
     vstart[0] = X * hn; vstart[1] = Y * hn; vstart[2] = Z * hn; vstart[3] = hn;
   }
+  // samples 0 .. 2n: centre + class A (both rows rebuilt); 2n + 1 .. 4n: class B (y-only samples, r1 alone) — see se3d_sigma_gram
   for (int s0 = 0; s0 < nsamp; s0 += 64) {
     const int s = s0 + lane;
     if (s < nsamp) {
@@ -1342,20 +1376,12 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
 #pragma unroll
       for (int k = 0; k < 10; ++k) g[k] = gu_[k];
       if (s > 0) {
-        const int c = (s - 1) >> 2, t = (s - 1) & 3;
-        const float l11 = T.ca[c], l21 = T.cb[c], l22 = T.cc[c];
-        const float dx1 = l11 * bsc, dy1 = l21 * bsc, dy2 = l22 * bsc;
-        float px = T.x[c], py = T.y[c];
-        if (t == 0) { px -= dx1; py -= dy1; }
-        else if (t == 1) { py -= dy2; }
-        else if (t == 2) { px += dx1; py += dy1; }
-        else { py += dy2; }
-        float o0[4], o1[4], n0[4], n1[4];
+        const bool clsB = s > 2 * n;
+        const int q = clsB ? s - 2 * n - 1 : s - 1, c = q >> 1;
+        float o0[4], o1[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o0[k] = T.r0[k][c]; o1[k] = T.r1[k][c]; }
-        se3d_dlt_rows(sRt + 12 * T.cam[c], px, py, n0, n1);
-        se3d_gram_add<true>(g, o0); se3d_gram_add<true>(g, o1);
-        se3d_gram_add(g, n0); se3d_gram_add(g, n1);
+        se3d_sigma_gram(g, sRt + 12 * T.cam[c], T.x[c], T.y[c], T.ca[c], T.cb[c], T.cc[c], bsc, o0, o1, (clsB ? 3 : 1) + (q & 1));
       }
       double e4[4];
       if (!se3d_null_invit(g, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(g, e4);
@@ -1551,33 +1577,29 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
     double gj[10], cv[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 10; ++k) gj[k] = S.G[j][k];
-    for (int s = s0; s < cntj; s += LPJ) {
-      double gq[10];
+    // class A (centre + 2n diagonal samples: both rows rebuilt) first, then class B (2n y-only samples: r1 alone); the lanes of all
+    // joints are in the same class except around the switch
+    const int cntA = cntj > 0 ? 2 * n + 1 : 0, cntB = cntj > 0 ? 2 * n : 0;
+    for (int cls = 0; cls < 2; ++cls) {
+      for (int s = s0; s < (cls == 0 ? cntA : cntB); s += LPJ) {
+        double gq[10];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) gq[k] = gj[k];
-      if (s > 0) {
-        const int c = (s - 1) >> 2, t = (s - 1) & 3;
-        const int v = S.vidx[j][c];
-        const float l11 = S.ca[j][v], l21 = S.cb[j][v], l22 = S.cc[j][v];
-        const float dx1 = l11 * bsc, dy1 = l21 * bsc, dy2 = l22 * bsc;
-        float px = S.x[j][v], py = S.y[j][v];
-        if (t == 0) { px -= dx1; py -= dy1; }
-        else if (t == 1) { py -= dy2; }
-        else if (t == 2) { px += dx1; py += dy1; }
-        else { py += dy2; }
-        float o0[4], o1[4], n0[4], n1[4];
+        for (int k = 0; k < 10; ++k) gq[k] = gj[k];
+        const int q = cls == 0 ? s - 1 : s;            // class A: s = 0 is the centre
+        if (q >= 0) {
+          const int c = q >> 1, v = S.vidx[j][c];
+          float o0[4], o1[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { o0[k] = S.rows[j][v][k]; o1[k] = S.rows[j][v][4 + k]; }
-        se3d_dlt_rows(sRt + 12 * S.cam[v], px, py, n0, n1);
-        se3d_gram_add<true>(gq, o0); se3d_gram_add<true>(gq, o1);
-        se3d_gram_add(gq, n0); se3d_gram_add(gq, n1);
+          for (int k = 0; k < 4; ++k) { o0[k] = S.rows[j][v][k]; o1[k] = S.rows[j][v][4 + k]; }
+          se3d_sigma_gram(gq, sRt + 12 * S.cam[v], S.x[j][v], S.y[j][v], S.ca[j][v], S.cb[j][v], S.cc[j][v], bsc, o0, o1, (cls == 0 ? 1 : 3) + (q & 1));
+        }
+        double e4[4];
+        if (!se3d_null_invit(gq, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(gq, e4);
+        const double iw = se3d_rcp64(e4[3]);
+        const float sx = (float)(e4[0] * iw) - Xj, sy = (float)(e4[1] * iw) - Yj, sz = (float)(e4[2] * iw) - Zj;
+        const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
+        cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
       }
-      double e4[4];
-      if (!se3d_null_invit(gq, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(gq, e4);
-      const double iw = se3d_rcp64(e4[3]);
-      const float sx = (float)(e4[0] * iw) - Xj, sy = (float)(e4[1] * iw) - Yj, sz = (float)(e4[2] * iw) - Zj;
-      const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
-      cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
     }
     __builtin_amdgcn_wave_barrier();   // all samples done: the rows are dead, their LDS takes the partial sums
     static_assert(sizeof(S.rows) >= 64 * 6 * sizeof(double) && offsetof(TriHypLds, rows) % 8 == 0, "partial sums alias the rows");
