@@ -270,8 +270,9 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
     # untimed accounting pass: published skeletons of one (steady-state) step
     s1 = [r for nd_ in nodes for r in nd_.fetch_stage1(B)]
     n_s1 = sum(r.n_persons for r in s1)
-    assert not any(r.flags & pm.FLAG_HYP_OVERFLOW for r in s1), "hypothesis capacity (max_hyp) exceeded: results truncated"
-    assert not any(r.flags & pm.FLAG_ASSIGNMENT_FAILED for r in s1), "the sweep's Hungarian hit its iteration guard"
+    if not os.environ.get("SE3D_BENCH_ABLATION"):   # ablation: kernel-timing builds that write wrong tables on purpose (tools/tmp)
+        assert not any(r.flags & pm.FLAG_HYP_OVERFLOW for r in s1), "hypothesis capacity (max_hyp) exceeded: results truncated"
+        assert not any(r.flags & pm.FLAG_ASSIGNMENT_FAILED for r in s1), "the sweep's Hungarian hit its iteration guard"
     if stage2:
         per_call = []
         step(collect=per_call)

@@ -6,6 +6,7 @@
 //
 // Compile with -ffp-contract=off: the float32 geometry that decides association indices must round exactly like the
 // reference's SSE2 build (no FMA); fp64 kernels that want FMA call __builtin_fma explicitly.
+#include <type_traits>
 #include "se3d_device.h"
 #include "se3d_munkres.h"
 
@@ -519,7 +520,10 @@ __global__ __launch_bounds__(256, 3) void se3d_k_pairs_tiled(Se3dDev D, const in
 // =============================================================================================================
 #define RB_ROWS 48
 #define RB_COLS 32
-#define RB_JH 9
+#ifndef RB_JH
+#define RB_JH 6
+#endif
+#define RB_JLAST (SE3D_NKP % RB_JH ? SE3D_NKP % RB_JH : RB_JH)   // joints of the last phase
 struct __align__(16) RowOp { float lx, ly, lz, nrm, x, y, rcp, w; };
 
 __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float px, float py, bool valid, bool &unsafe) {
@@ -531,6 +535,16 @@ __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float 
   o.w = valid ? 1.f : 0.f;
   unsafe |= valid && !(o.rcp != 0.f && se3d_in_safe_range(lx) && se3d_in_safe_range(ly) && se3d_in_safe_range(lz) && se3d_in_safe_range(px) && se3d_in_safe_range(py));
   return o;
+}
+
+// acc / n for the joint count n = 1..17 of a pair entry, correctly rounded (= the IEEE quotient of calcCost's `cost / n`) in three fp64
+// operations instead of the ~15-instruction IEEE division sequence: with y = RN(1 / n), q0 = RN(acc y), r = acc - n q0 (exact in an FMA)
+// the corrected q0 + r y rounds to RN(acc / n) for every divisor whose significand is not all ones (Markstein 1990, Thm. 8.5 in Muller et al.,
+// "Handbook of Floating-Point Arithmetic"); tools/tmp-free check: tests/test_markstein64.py runs 17 x 2e6 random accumulators on the CPU.
+__device__ __forceinline__ double se3d_div_count(double acc, int n, double inv_n) {
+  const double q0 = acc * inv_n;
+  const double r = __fma_rn(-(double)n, q0, acc);
+  return __fma_rn(r, inv_n, q0);
 }
 
 template <int JN>
@@ -579,7 +593,13 @@ __device__ __forceinline__ void se3d_rows_compute_slow(const RowOp (*A)[RB_ROWS]
   }
 }
 
-__global__ __launch_bounds__(256, 4) void se3d_k_pairs_rows(Se3dDev D, const int2 *__restrict__ pair_ab) {
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).
+__device__ __forceinline__ void se3d_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifndef RB_WPE
+#define RB_WPE 4
+#endif
+__global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, const int2 *__restrict__ pair_ab) {
   const int N = D.d.N, P = D.d.P, np = D.d.npairs;
   const int pr = blockIdx.y, f = blockIdx.z;
   const int2 ab = pair_ab[pr];
@@ -589,49 +609,94 @@ __global__ __launch_bounds__(256, 4) void se3d_k_pairs_rows(Se3dDev D, const int
   __shared__ RowOp A[SE3D_NKP][RB_ROWS];  // det_a side, all joints: staged once per workgroup (26 KB)
   __shared__ RowOp Bc[RB_JH][RB_COLS];    // det_b side of the current column tile, one joint half (9 KB)
   __shared__ unsigned M1[RB_ROWS], M2[RB_COLS];
-  __shared__ int s_unsafe_a;
+  __shared__ int s_unsafe_a, s_unsafe_b[2];   // range-guard flags: det_a side, det_b side of the phase (ping-pong by phase parity)
+  __shared__ double INV[SE3D_NKP + 1];     // RN(1 / n) for the joint count of an entry
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, ql = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it is a uniform branch, not an exec mask
   const float *F = D.F + 9 * (size_t)pr;
   const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
   const size_t baseA = ((size_t)(f * N + ab.x)) * P, baseB = ((size_t)(f * N + ab.y)) * P;
-  if (tid == 0) s_unsafe_a = 0;
+  if (tid == 0) { s_unsafe_a = 0; s_unsafe_b[0] = 0; s_unsafe_b[1] = 0; }
+  if (tid <= SE3D_NKP) INV[tid] = tid ? 1.0 / (double)tid : 0.0;
+  constexpr int NA_ROUNDS = (RB_ROWS * SE3D_NKP + 255) / 256;
+  float4 a4[NA_ROUNDS];   // all global loads of the det_a side first (in flight across the barrier): one memory latency, not five in a row
+#pragma unroll
+  for (int u = 0; u < NA_ROUNDS; ++u) {
+    const int i = tid + 256 * u, d = i / SE3D_NKP, k = i - d * SE3D_NKP, p = p0 + d;
+    a4[u] = make_float4(0.f, 0.f, -1.f, 0.f);
+    if (i < RB_ROWS * SE3D_NKP && p < na) a4[u] = D.kp[(baseA + p) * SE3D_NKP + k];
+  }
   for (int d = tid; d < RB_ROWS; d += 256) M1[d] = (p0 + d < na) ? D.vmask_gt[baseA + p0 + d] : 0u;
   __syncthreads();
   {
     bool unsafe = false;
-    for (int i = tid; i < RB_ROWS * SE3D_NKP; i += 256) {
-      const int d = i / SE3D_NKP, k = i - d * SE3D_NKP, p = p0 + d;
-      float4 a4 = make_float4(0.f, 0.f, -1.f, 0.f);
-      if (p < na) a4 = D.kp[(baseA + p) * SE3D_NKP + k];
-      A[k][d] = se3d_rowop(f0 * a4.x + (f1 * a4.y + f2), f3 * a4.x + (f4 * a4.y + f5), f6 * a4.x + (f7 * a4.y + f8), a4.x, a4.y,
-                           p < na && ((M1[d] >> k) & 1u), unsafe);
+#pragma unroll
+    for (int u = 0; u < NA_ROUNDS; ++u) {
+      const int i = tid + 256 * u, d = i / SE3D_NKP, k = i - d * SE3D_NKP, p = p0 + d;
+      if (i < RB_ROWS * SE3D_NKP)
+        A[k][d] = se3d_rowop(f0 * a4[u].x + (f1 * a4[u].y + f2), f3 * a4[u].x + (f4 * a4[u].y + f5), f6 * a4[u].x + (f7 * a4[u].y + f8),
+                             a4[u].x, a4[u].y, p < na && ((M1[d] >> k) & 1u), unsafe);
     }
     if (unsafe) s_unsafe_a = 1;
   }
   const int row0 = wave * (RB_ROWS / 4) + half;             // this lane's first row inside the tile; row pairs r: row0 + 2 r
   const int nrows_left = na - p0 - wave * (RB_ROWS / 4);    // rows of this wavefront that exist (wave-uniform)
   double *out = D.pair + ((size_t)f * np + pr) * P * P;
-  for (int q0 = 0; q0 < nb; q0 += RB_COLS) {
-    double acc[RB_ROWS / 8];
+  double acc[RB_ROWS / 8];
+  unsigned m2 = 0u;
+  // One (detection, joint) operand of the det_b side per thread and phase (RB_COLS x RB_JH <= 256).  Its global loads are issued a whole
+  // phase ahead (before the barrier and the compute of the current phase), and the entries of a finished column tile are stored one
+  // phase late, after those loads have been consumed: loads and stores retire through one in-order counter (vmcnt), so a load issued
+  // behind the epilogue's stores would also wait for their round trip to L2.
+  static_assert(RB_COLS * RB_JH <= 256, "one staging item per thread");
+  float4 pre4 = make_float4(0.f, 0.f, -1.f, 0.f);
+  unsigned premq = 0u;
+  auto prefetch = [&](int q0, int jbase, int jn) {
+    const int d = tid / jn, jj = tid - d * jn, q = q0 + d;   // jn in {RB_JH, RB_JLAST}: two constant divisions selected by a uniform branch
+    pre4 = make_float4(0.f, 0.f, -1.f, 0.f);
+    premq = 0u;
+    if (tid < RB_COLS * jn && q < nb) { pre4 = D.kp[(baseB + q) * SE3D_NKP + jbase + jj]; premq = D.vmask_gt[baseB + q]; }
+  };
+  auto flush = [&](int q0_done) {
+    const int q = q0_done + ql;
 #pragma unroll
-    for (int r = 0; r < RB_ROWS / 8; ++r) acc[r] = 0.0;
-    unsigned m2 = 0u;
-    for (int jbase = 0; jbase < SE3D_NKP; jbase += RB_JH) {
-      const int jn = min(RB_JH, SE3D_NKP - jbase);
-      __syncthreads();  // the previous phase has finished reading Bc / M2 (first trip: M1 is visible)
-      if (jbase == 0)
-        for (int d = tid; d < RB_COLS; d += 256) M2[d] = (q0 + d < nb) ? D.vmask_gt[baseB + q0 + d] : 0u;
-      bool unsafe = false;
-      for (int i = tid; i < RB_COLS * jn; i += 256) {
-        const int d = i / jn, jj = i - d * jn, k = jbase + jj, q = q0 + d;
-        float4 b4 = make_float4(0.f, 0.f, -1.f, 0.f);
-        unsigned mq = 0u;
-        if (q < nb) { b4 = D.kp[(baseB + q) * SE3D_NKP + k]; mq = D.vmask_gt[baseB + q]; }
-        Bc[jj][d] = se3d_rowop(f0 * b4.x + (f3 * b4.y + f6), f1 * b4.x + (f4 * b4.y + f7), f2 * b4.x + (f5 * b4.y + f8), b4.x, b4.y,
-                               q < nb && ((mq >> k) & 1u), unsafe);
+    for (int r = 0; r < RB_ROWS / 8; ++r) {
+      const int row = row0 + 2 * r, p = p0 + row;
+      if (p < na && q < nb) {
+        const int n = __popc(M1[row] & m2);
+        out[(size_t)p * P + q] = n > 0 ? se3d_div_count(acc[r], n, INV[n]) : -1.0;
       }
-      const int any_unsafe = __syncthreads_or(unsafe ? 1 : 0) | s_unsafe_a;  // block-uniform: shared-reciprocal divide or IEEE divide
+    }
+  };
+  prefetch(0, 0, RB_JH);
+  int ph = 0;
+  for (int q0 = 0; q0 < nb; q0 += RB_COLS) {
+    for (int jbase = 0; jbase < SE3D_NKP; jbase += RB_JH, ++ph) {
+      const int jn = min(RB_JH, SE3D_NKP - jbase);
+      // LDS-only barriers inside the loop: __syncthreads() would also wait for every outstanding global access (s_waitcnt vmcnt(0))
+      se3d_lds_barrier();  // the previous phase has finished reading Bc / M2 / its flag (first trip: M1, A's flag are visible)
+      if (tid == 0) s_unsafe_b[(ph + 1) & 1] = 0;
+      bool unsafe = false;
+      {
+        const int d = jn == RB_JH ? tid / RB_JH : tid / RB_JLAST, jj = tid - d * jn, k = jbase + jj, q = q0 + d;
+        if (tid < RB_COLS * jn) {
+          Bc[jj][d] = se3d_rowop(f0 * pre4.x + (f3 * pre4.y + f6), f1 * pre4.x + (f4 * pre4.y + f7), f2 * pre4.x + (f5 * pre4.y + f8),
+                                 pre4.x, pre4.y, q < nb && ((premq >> k) & 1u), unsafe);
+          if (jj == 0 && jbase == 0) M2[d] = premq;
+        }
+      }
+      if (unsafe) s_unsafe_b[ph & 1] = 1;
+      if (jbase == 0) {
+        if (q0 > 0) flush(q0 - RB_COLS);
+#pragma unroll
+        for (int r = 0; r < RB_ROWS / 8; ++r) acc[r] = 0.0;
+      }
+      {  // the next phase's operand
+        const int jb2 = jbase + RB_JH < SE3D_NKP ? jbase + RB_JH : 0, q2 = jb2 ? q0 : q0 + RB_COLS;
+        if (q2 < nb) { if (min(RB_JH, SE3D_NKP - jb2) == RB_JH) prefetch(q2, jb2, RB_JH); else prefetch(q2, jb2, RB_JLAST); }
+      }
+      se3d_lds_barrier();
+      const int any_unsafe = s_unsafe_b[ph & 1] | s_unsafe_a;  // block-uniform: shared-reciprocal divide or IEEE divide
       if (jbase == 0) m2 = M2[ql];
       RowOp b[RB_JH];
 #pragma unroll
@@ -639,19 +704,11 @@ __global__ __launch_bounds__(256, 4) void se3d_k_pairs_rows(Se3dDev D, const int
       if (nrows_left > 0) {
         if (any_unsafe) se3d_rows_compute_slow(A, Bc, ql, jbase, jn, row0, m2, M1, acc);
         else if (jn == RB_JH) se3d_rows_compute<RB_JH>(A, b, jbase, row0, nrows_left, acc);
-        else se3d_rows_compute<SE3D_NKP - RB_JH>(A, b, jbase, row0, nrows_left, acc);
-      }
-    }
-    const int q = q0 + ql;
-#pragma unroll
-    for (int r = 0; r < RB_ROWS / 8; ++r) {
-      const int row = row0 + 2 * r, p = p0 + row;
-      if (p < na && q < nb) {
-        const int n = __popc(M1[row] & m2);
-        out[(size_t)p * P + q] = n > 0 ? acc[r] / n : -1.0;
+        else se3d_rows_compute<RB_JLAST>(A, b, jbase, row0, nrows_left, acc);
       }
     }
   }
+  flush(((nb - 1) / RB_COLS) * RB_COLS);
 }
 
 // =============================================================================================================
