@@ -510,13 +510,17 @@ __global__ __launch_bounds__(256, 3) void se3d_k_pairs_tiled(Se3dDev D, const in
 // row E, large P, second form ("rows"): one workgroup per (48-row tile of det_a, camera pair, frame), looping over 32-column tiles
 // of det_b.  A wavefront carries TWO det_a rows (lanes 0-31 / 32-63) x 32 det_b columns:
 //   * the det_b side (epipolar line F^T p2, its norm and shared reciprocal, the point, the validity weight: 8 floats per joint)
-//     stays in REGISTERS for a 9-joint half while the wavefront walks its 12 rows;
-//   * the det_a side is read from LDS with two (half-wave uniform) addresses per instruction — a broadcast read, no bank traffic
-//     to speak of — instead of the 16 distinct ds_read_b128 per joint of the 4x4-register-tile kernel;
-//   * 128 VGPRs and 36 KB of LDS: four workgroups (16 wavefronts) per CU instead of two to three.
-// PMC on the 4x4-tile kernel at 256 cam x 128 p (profiles/r2): VALU issue utilisation 40 %, 29 % of the wave time in s_waitcnt, 22 %
-// issue stalls at ~2 wavefronts per SIMD.  Same per-element float expressions in the same order (FAST: shared-reciprocal Markstein
-// divide under the block-uniform range guard, else IEEE divide) -> the table is bit-identical to every other pair kernel.
+//     stays in REGISTERS for a group of 6 joints while the wavefront walks its 12 rows;
+//   * the det_a side is read from LDS with two (half-wave uniform) addresses per instruction instead of the 16 distinct ds_read_b128
+//     per joint of the 4x4-register-tile kernel;
+//   * 124 VGPRs, no scratch, 38 KB of LDS: four workgroups (16 wavefronts) per CU instead of two to three.
+// Phases (column tile, joint group 6 / 6 / 5) are software-pipelined: the operands of phase k + 1 are written to the other half of a
+// double-buffered LDS tile before phase k computes, the global loads of phase k + 2 are in flight meanwhile, the table entries of a
+// finished column tile are stored one phase late, and the one barrier per phase orders LDS only.  Measured at 256 cam x 128 p per 16
+// frames (profiles/r2): 4x4 tiles 85.8 ms; rows with 9 / 8 joint groups and __syncthreads() 67.0 ms (of which, by doubling the item loop:
+// 39 ms items at the microbenchmarked issue floor, 28 ms everything else); this form 59.6 ms.
+// Same per-element float expressions in the same order (FAST: shared-reciprocal Markstein divide under the block-uniform range guard,
+// else IEEE divide) -> the table is bit-identical to every other pair kernel.
 // =============================================================================================================
 #define RB_ROWS 48
 #define RB_COLS 32
@@ -540,7 +544,7 @@ __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float 
 // acc / n for the joint count n = 1..17 of a pair entry, correctly rounded (= the IEEE quotient of calcCost's `cost / n`) in three fp64
 // operations instead of the ~15-instruction IEEE division sequence: with y = RN(1 / n), q0 = RN(acc y), r = acc - n q0 (exact in an FMA)
 // the corrected q0 + r y rounds to RN(acc / n) for every divisor whose significand is not all ones (Markstein 1990, Thm. 8.5 in Muller et al.,
-// "Handbook of Floating-Point Arithmetic"); tools/tmp-free check: tests/test_markstein64.py runs 17 x 2e6 random accumulators on the CPU.
+// "Handbook of Floating-Point Arithmetic"); tests/test_markstein64.py checks 17 x 2e4 accumulators against IEEE division on the CPU.
 __device__ __forceinline__ double se3d_div_count(double acc, int n, double inv_n) {
   const double q0 = acc * inv_n;
   const double r = __fma_rn(-(double)n, q0, acc);
@@ -607,16 +611,16 @@ __global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, cons
   const int p0 = blockIdx.x * RB_ROWS;
   if (p0 >= na || nb == 0) return;
   __shared__ RowOp A[SE3D_NKP][RB_ROWS];  // det_a side, all joints: staged once per workgroup (26 KB)
-  __shared__ RowOp Bc[RB_JH][RB_COLS];    // det_b side of the current column tile, one joint half (9 KB)
-  __shared__ unsigned M1[RB_ROWS], M2[RB_COLS];
-  __shared__ int s_unsafe_a, s_unsafe_b[2];   // range-guard flags: det_a side, det_b side of the phase (ping-pong by phase parity)
+  __shared__ RowOp Bc[2][RB_JH][RB_COLS];  // det_b side of a (column tile, joint group) phase, double-buffered (2 x 6 KB)
+  __shared__ unsigned M1[RB_ROWS], M2[2][RB_COLS];
+  __shared__ int s_unsafe_a, s_unsafe_b[3];   // range-guard flags: det_a side; det_b side of phase ph in [ph % 3]
   __shared__ double INV[SE3D_NKP + 1];     // RN(1 / n) for the joint count of an entry
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, ql = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it is a uniform branch, not an exec mask
   const float *F = D.F + 9 * (size_t)pr;
   const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
   const size_t baseA = ((size_t)(f * N + ab.x)) * P, baseB = ((size_t)(f * N + ab.y)) * P;
-  if (tid == 0) { s_unsafe_a = 0; s_unsafe_b[0] = 0; s_unsafe_b[1] = 0; }
+  if (tid == 0) { s_unsafe_a = 0; s_unsafe_b[0] = 0; s_unsafe_b[1] = 0; s_unsafe_b[2] = 0; }
   if (tid <= SE3D_NKP) INV[tid] = tid ? 1.0 / (double)tid : 0.0;
   constexpr int NA_ROUNDS = (RB_ROWS * SE3D_NKP + 255) / 256;
   float4 a4[NA_ROUNDS];   // all global loads of the det_a side first (in flight across the barrier): one memory latency, not five in a row
@@ -668,45 +672,53 @@ __global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, cons
       }
     }
   };
-  prefetch(0, 0, RB_JH);
-  int ph = 0;
-  for (int q0 = 0; q0 < nb; q0 += RB_COLS) {
-    for (int jbase = 0; jbase < SE3D_NKP; jbase += RB_JH, ++ph) {
-      const int jn = min(RB_JH, SE3D_NKP - jbase);
-      // LDS-only barriers inside the loop: __syncthreads() would also wait for every outstanding global access (s_waitcnt vmcnt(0))
-      se3d_lds_barrier();  // the previous phase has finished reading Bc / M2 / its flag (first trip: M1, A's flag are visible)
-      if (tid == 0) s_unsafe_b[(ph + 1) & 1] = 0;
-      bool unsafe = false;
-      {
-        const int d = jn == RB_JH ? tid / RB_JH : tid / RB_JLAST, jj = tid - d * jn, k = jbase + jj, q = q0 + d;
-        if (tid < RB_COLS * jn) {
-          Bc[jj][d] = se3d_rowop(f0 * pre4.x + (f3 * pre4.y + f6), f1 * pre4.x + (f4 * pre4.y + f7), f2 * pre4.x + (f5 * pre4.y + f8),
-                                 pre4.x, pre4.y, q < nb && ((premq >> k) & 1u), unsafe);
-          if (jj == 0 && jbase == 0) M2[d] = premq;
-        }
-      }
-      if (unsafe) s_unsafe_b[ph & 1] = 1;
-      if (jbase == 0) {
-        if (q0 > 0) flush(q0 - RB_COLS);
-#pragma unroll
-        for (int r = 0; r < RB_ROWS / 8; ++r) acc[r] = 0.0;
-      }
-      {  // the next phase's operand
-        const int jb2 = jbase + RB_JH < SE3D_NKP ? jbase + RB_JH : 0, q2 = jb2 ? q0 : q0 + RB_COLS;
-        if (q2 < nb) { if (min(RB_JH, SE3D_NKP - jb2) == RB_JH) prefetch(q2, jb2, RB_JH); else prefetch(q2, jb2, RB_JLAST); }
-      }
-      se3d_lds_barrier();
-      const int any_unsafe = s_unsafe_b[ph & 1] | s_unsafe_a;  // block-uniform: shared-reciprocal divide or IEEE divide
-      if (jbase == 0) m2 = M2[ql];
-      RowOp b[RB_JH];
-#pragma unroll
-      for (int jj = 0; jj < RB_JH; ++jj) b[jj] = Bc[jj < jn ? jj : 0][ql];
-      if (nrows_left > 0) {
-        if (any_unsafe) se3d_rows_compute_slow(A, Bc, ql, jbase, jn, row0, m2, M1, acc);
-        else if (jn == RB_JH) se3d_rows_compute<RB_JH>(A, b, jbase, row0, nrows_left, acc);
-        else se3d_rows_compute<RB_JLAST>(A, b, jbase, row0, nrows_left, acc);
-      }
+  // Phase ph = (column tile ph / NPH, joint group ph % NPH).  While a phase computes from registers, the operands of the NEXT phase are
+  // already in the other half of Bc (written before the compute from the prefetched registers) and the loads of the phase after that are
+  // in flight: ONE barrier per phase.
+  constexpr int NPH = (SE3D_NKP + RB_JH - 1) / RB_JH;
+  const int nph = NPH * ((nb + RB_COLS - 1) / RB_COLS);
+  auto jn_of = [](int ph_) { return min(RB_JH, SE3D_NKP - (ph_ % NPH) * RB_JH); };
+  auto stage = [&](int ph_) {   // pre4 / premq (operand of phase ph_) -> Bc[ph_ & 1], M2[(ph_ / NPH) & 1], flag[ph_ % 3]
+    const int jn = jn_of(ph_), jbase = (ph_ % NPH) * RB_JH, q0 = (ph_ / NPH) * RB_COLS;
+    const int d = jn == RB_JH ? tid / RB_JH : tid / RB_JLAST, jj = tid - d * jn, k = jbase + jj, q = q0 + d;
+    bool unsafe = false;
+    if (tid < RB_COLS * jn) {
+      Bc[ph_ & 1][jj][d] = se3d_rowop(f0 * pre4.x + (f3 * pre4.y + f6), f1 * pre4.x + (f4 * pre4.y + f7), f2 * pre4.x + (f5 * pre4.y + f8),
+                                      pre4.x, pre4.y, q < nb && ((premq >> k) & 1u), unsafe);
+      if (jj == 0 && jbase == 0) M2[(ph_ / NPH) & 1][d] = premq;
     }
+    if (unsafe) s_unsafe_b[ph_ % 3] = 1;
+  };
+  auto prefetch_ph = [&](int ph_) {
+    if (ph_ >= nph) return;
+    const int jbase = (ph_ % NPH) * RB_JH, q0 = (ph_ / NPH) * RB_COLS;
+    if (jn_of(ph_) == RB_JH) prefetch(q0, jbase, RB_JH); else prefetch(q0, jbase, RB_JLAST);
+  };
+  prefetch_ph(0);
+  stage(0);
+  prefetch_ph(1);
+  se3d_lds_barrier();   // A, M1, the flags and phase 0 of Bc are visible
+  for (int ph = 0; ph < nph; ++ph) {
+    const int jn = jn_of(ph), jbase = (ph % NPH) * RB_JH, q0 = (ph / NPH) * RB_COLS;
+    const int any_unsafe = s_unsafe_b[ph % 3] | s_unsafe_a;  // block-uniform: shared-reciprocal divide or IEEE divide
+    if (tid == 0) s_unsafe_b[(ph + 2) % 3] = 0;              // last read in phase ph - 1, next written in phase ph + 1
+    if (ph + 1 < nph) stage(ph + 1);   // consumes the prefetched registers before any store of this phase is issued
+    if (jbase == 0) {
+      if (ph > 0) flush(q0 - RB_COLS);
+#pragma unroll
+      for (int r = 0; r < RB_ROWS / 8; ++r) acc[r] = 0.0;
+      m2 = M2[(ph / NPH) & 1][ql];
+    }
+    prefetch_ph(ph + 2);
+    RowOp b[RB_JH];
+#pragma unroll
+    for (int jj = 0; jj < RB_JH; ++jj) b[jj] = Bc[ph & 1][jj < jn ? jj : 0][ql];
+    if (nrows_left > 0) {
+      if (any_unsafe) se3d_rows_compute_slow(A, Bc[ph & 1], ql, jbase, jn, row0, m2, M1, acc);
+      else if (jn == RB_JH) se3d_rows_compute<RB_JH>(A, b, jbase, row0, nrows_left, acc);
+      else se3d_rows_compute<RB_JLAST>(A, b, jbase, row0, nrows_left, acc);
+    }
+    se3d_lds_barrier();   // phase ph + 1 is staged; nobody reads Bc[ph & 1] any more (its next writer is the staging of phase ph + 2)
   }
   flush(((nb - 1) / RB_COLS) * RB_COLS);
 }
