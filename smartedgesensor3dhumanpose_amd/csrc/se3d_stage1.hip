@@ -1039,45 +1039,52 @@ __device__ __forceinline__ void se3d_eig4_smallest(const double g[10], double v[
 // vector of a nearby matrix (the sigma points of the unscented transform perturb two rows of the base system, so the
 // start error is ~1e-3 and the contraction per step is lambda_4 / lambda_3 << 1).  Returns false when 8 steps do not
 // reach a 1e-13 update (caller falls back to the Jacobi solver): same eigenvector, ~15x fewer fp64 operations.
-// 1/x and 1/sqrt(x) to ~1 ulp from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) and two Newton steps; the inverse
+// 1/x and 1/sqrt(x) to ~1 ulp from the hardware seeds (v_rcp_f64 / v_rsq_f64) and two Newton steps; the inverse
 // iteration below only needs them as scale factors, not correctly rounded.
+template <int NEWTON = 2>
 __device__ __forceinline__ double se3d_rcp64(double x) {
   double y = __builtin_amdgcn_rcp(x);
-  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-  y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+#pragma unroll
+  for (int k = 0; k < NEWTON; ++k) y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
   return y;
 }
+template <int NEWTON = 2>
 __device__ __forceinline__ double se3d_rsq64(double x) {
   double y = __builtin_amdgcn_rsq(x);
-  y = __builtin_fma(__builtin_fma(-x * y, y, 1.0), 0.5 * y, y);
-  y = __builtin_fma(__builtin_fma(-x * y, y, 1.0), 0.5 * y, y);
+#pragma unroll
+  for (int k = 0; k < NEWTON; ++k) y = __builtin_fma(__builtin_fma(-x * y, y, 1.0), 0.5 * y, y);
   return y;
 }
 
 // tol: exit once two successive unit iterates differ by less than tol (L1).  The main solves use 1e-13.  The unscented-transform
-// samples (SIGMA_TOL) are rounded to float32 and differenced against the float32 centre: the iterate returned is one contraction
-// (typically 1e-4 .. 1e-6) more accurate than the test, far below float32 resolution, and one iteration per sample is saved.
-#define SE3D_SIGMA_TOL 1e-9
+// samples start from the centre's solution (distance ~1e-3, the size of the sigma offsets) and are rounded to float32 and differenced
+// against the float32 centre.  Their first step cannot pass any useful test, so it is taken untested (SKIP = 1); the second step's update
+// is ~1e-3 x contraction (lambda_4 / lambda_3, typically 1e-4 .. 1e-6) and the iterate it returns is one further contraction more accurate
+// than that update: with SIGMA_TOL = 1e-6 the sample is good to <= 1e-10, far below float32 resolution, in two steps instead of the three
+// that a 1e-9 test took (tests/test_gpu_dlt.py::test_ut_covariance_error_budget prints the resulting error against the exact evaluation).
+#define SE3D_SIGMA_TOL 1e-6
+template <int SKIP = 0>
 __device__ __forceinline__ bool se3d_null_invit(const double g[10], const double v0[4], double v[4], const double tol = 1e-13) {
+  constexpr int NW = SKIP ? 1 : 2;   // sample solves: one Newton step on the ~2^-23 hardware seeds (2^-46) is ample for a float32 result
   const double tr = g[0] + g[4] + g[7] + g[9];
   const double tiny = 1e-30 * tr;
   double d0 = g[0];
   if (!(d0 > tiny)) return false;
-  const double i0 = se3d_rcp64(d0);
+  const double i0 = se3d_rcp64<NW>(d0);
   const double l10 = g[1] * i0, l20 = g[2] * i0, l30 = g[3] * i0;
   double d1 = __builtin_fma(-l10, g[1], g[4]);
   if (!(d1 > tiny)) return false;
-  const double i1 = se3d_rcp64(d1);
+  const double i1 = se3d_rcp64<NW>(d1);
   const double t21 = __builtin_fma(-l20, g[1], g[5]), t31 = __builtin_fma(-l30, g[1], g[6]);
   const double l21 = t21 * i1, l31 = t31 * i1;
   double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, g[2], g[7]));
   if (!(d2 > tiny)) return false;
-  const double i2 = se3d_rcp64(d2);
+  const double i2 = se3d_rcp64<NW>(d2);
   const double t32 = __builtin_fma(-l31, t21, __builtin_fma(-l30, g[2], g[8]));
   const double l32 = t32 * i2;
   double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, t31, __builtin_fma(-l30, g[3], g[9])));
   if (!(d3 > tiny)) d3 = tiny;  // numerically singular: the solve still returns the null direction
-  const double i3 = se3d_rcp64(d3);
+  const double i3 = se3d_rcp64<NW>(d3);
   double x0 = v0[0], x1 = v0[1], x2 = v0[2], x3 = v0[3];
   bool conv = false;
   for (int it = 0; it < 8; ++it) {
@@ -1086,9 +1093,10 @@ __device__ __forceinline__ bool se3d_null_invit(const double g[10], const double
                  y3 = __builtin_fma(-l32, y2, __builtin_fma(-l31, y1, __builtin_fma(-l30, y0, x3)));
     const double w3 = y3 * i3, w2 = __builtin_fma(-l32, w3, y2 * i2), w1 = __builtin_fma(-l31, w3, __builtin_fma(-l21, w2, y1 * i1)),
                  w0 = __builtin_fma(-l30, w3, __builtin_fma(-l20, w2, __builtin_fma(-l10, w1, y0 * i0)));
-    const double nn = se3d_rsq64(__builtin_fma(w3, w3, __builtin_fma(w2, w2, __builtin_fma(w1, w1, w0 * w0))));
+    const double nn = se3d_rsq64<NW>(__builtin_fma(w3, w3, __builtin_fma(w2, w2, __builtin_fma(w1, w1, w0 * w0))));
     const double sgn = __builtin_fma(w3, x3, __builtin_fma(w2, x2, __builtin_fma(w1, x1, w0 * x0))) < 0.0 ? -nn : nn;
     const double n0 = w0 * sgn, n1 = w1 * sgn, n2 = w2 * sgn, n3 = w3 * sgn;
+    if (it < SKIP) { x0 = n0; x1 = n1; x2 = n2; x3 = n3; continue; }
     const double e = fabs(n0 - x0) + fabs(n1 - x1) + fabs(n2 - x2) + fabs(n3 - x3);
     x0 = n0; x1 = n1; x2 = n2; x3 = n3;
     if (e < tol) { conv = true; break; }
@@ -1453,8 +1461,8 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
         se3d_sigma_gram(g, sRt + 12 * T.cam[c], T.x[c], T.y[c], T.ca[c], T.cb[c], T.cc[c], bsc, o0, o1, (clsB ? 3 : 1) + (q & 1));
       }
       double e4[4];
-      if (!se3d_null_invit(g, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(g, e4);
-      const double iw = se3d_rcp64(e4[3]);
+      if (!se3d_null_invit<1>(g, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(g, e4);
+      const double iw = se3d_rcp64<1>(e4[3]);
       const float sx = (float)(e4[0] * iw) - X, sy = (float)(e4[1] * iw) - Y, sz = (float)(e4[2] * iw) - Z;
       const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
       cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
@@ -1663,8 +1671,8 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
           se3d_sigma_gram(gq, sRt + 12 * S.cam[v], S.x[j][v], S.y[j][v], S.ca[j][v], S.cb[j][v], S.cc[j][v], bsc, o0, o1, (cls == 0 ? 1 : 3) + (q & 1));
         }
         double e4[4];
-        if (!se3d_null_invit(gq, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(gq, e4);
-        const double iw = se3d_rcp64(e4[3]);
+        if (!se3d_null_invit<1>(gq, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(gq, e4);
+        const double iw = se3d_rcp64<1>(e4[3]);
         const float sx = (float)(e4[0] * iw) - Xj, sy = (float)(e4[1] * iw) - Yj, sz = (float)(e4[2] * iw) - Zj;
         const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
         cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
