@@ -131,6 +131,8 @@ struct Se3dStage2 {
   uint32_t *flags2;       // [S]
   double *lm_scratch;     // [S][4][1865] HBM Schur workspace of the fused walk's non-forest LM fallback
   int shard_rank, shard_world;  // hypothesis shard: the per-step LM kernel refines detections i with i % world == rank only
+  int direct_out;       // fused walk: the association phase numbers the detections that will be published (pub = 1 + output slot) and the LM
+                        // writes a published person straight into fused / pred / iters; nothing is written for an unpublished one
 };
 
 // One refined detection as it crosses the hypothesis-shard all-gather after the LM step: the two published payloads and the state of

@@ -1192,8 +1192,10 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
 
   LM_STAMP(5)  // marginals
   // ---- outputs + track-state update: lane k <-> fusion joint k (PP:769-843) ----
-  se3d_person3d &pf = Q.fused_det[(size_t)s * H + i];
-  se3d_person3d &pp = Q.pred_det[(size_t)s * H + i];
+  // direct_out (fused walk): a detection that will be published carries pub = 1 + its output slot since the association phase
+  const int pubv = Q.direct_out ? (int)Q.pub[(size_t)s * H + i] : 0;
+  se3d_person3d &pf = pubv ? Q.fused[(size_t)s * H + pubv - 1] : Q.fused_det[(size_t)s * H + i];
+  se3d_person3d &pp = pubv ? Q.pred[(size_t)s * H + pubv - 1] : Q.pred_det[(size_t)s * H + i];
   {  // zero both persons cooperatively, then fill the measured joints
     uint32_t *w0 = reinterpret_cast<uint32_t *>(&pf), *w1 = reinterpret_cast<uint32_t *>(&pp);
     for (int w = lane; w < (int)(sizeof(se3d_person3d) / 4); w += 64) { w0[w] = 0u; w1[w] = 0u; }
@@ -1248,8 +1250,8 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
     for (int a = 0; a < 3; ++a) Q.root_prev[sl * 3 + a] = root[a];
     const int no = Q.num_obs[sl] + 1;
     Q.num_obs[sl] = no;
-    Q.pub[(size_t)s * H + i] = (no > 10) ? 1 : 0;  // g_min_num_obs_track (PP:845-848)
-    Q.iters_det[(size_t)s * H + i] = iterations;
+    Q.pub[(size_t)s * H + i] = (no > 10) ? (Q.direct_out ? (uint8_t)pubv : 1) : 0;  // g_min_num_obs_track (PP:845-848)
+    if (pubv) Q.iters[(size_t)s * H + pubv - 1] = iterations; else Q.iters_det[(size_t)s * H + i] = iterations;
   }
   LM_STAMP(6)  // outputs
 #ifdef SE3D_LM_STAMPS
@@ -1838,10 +1840,12 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
   LM_STAMP(5)  // marginals
   // ---- outputs + track-state update (PP:769-843): every lane writes the whole keypoint of its joint in both persons ----
   if (valid) {
-    se3d_person3d &pf = Q.fused_det[(size_t)s * H + i];
-    se3d_person3d &pp = Q.pred_det[(size_t)s * H + i];
+    const int pubv = Q.direct_out ? (int)Q.pub[(size_t)s * H + i] : 0;   // fused walk: 1 + output slot of a person that will be published
+    const bool wr = !Q.direct_out || pubv != 0;                          // an unpublished person's payload is never read: not written
+    se3d_person3d &pf = pubv ? Q.fused[(size_t)s * H + pubv - 1] : Q.fused_det[(size_t)s * H + i];
+    se3d_person3d &pp = pubv ? Q.pred[(size_t)s * H + pubv - 1] : Q.pred_det[(size_t)s * H + i];
     const int track_id = Q.id[sl];
-    if (j == 0) { pf.id = (uint32_t)track_id; pf.score = 0.f; pp.id = (uint32_t)track_id; pp.score = 0.f; }
+    if (j == 0 && wr) { pf.id = (uint32_t)track_id; pf.score = 0.f; pp.id = (uint32_t)track_id; pp.score = 0.f; }
     const double pred_dt = Q.pred_dt[s];
     const int fslot = Q.frame_nr[s] % 3;
     const double gtprev = Q.t_prev[s];
@@ -1880,8 +1884,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
     } else if ((hasprev >> j) & 1u) {
       for (int a = 0; a < 9; ++a) velk[a] = 0.0;  // joint vanished: reset its velocity buffer (PP:490-493)
     }
-    pf.keypoints[j] = kf;
-    pp.keypoints[j] = kpred;
+    if (wr) { pf.keypoints[j] = kf; pp.keypoints[j] = kpred; }
     if (j == 0) {
       Q.has[sl] = measmask;
       Q.trk_t_prev[sl] = t;
@@ -1889,8 +1892,8 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
       for (int a = 0; a < 3; ++a) Q.root_prev[sl * 3 + a] = root[a];
       const int no = Q.num_obs[sl] + 1;
       Q.num_obs[sl] = no;
-      Q.pub[(size_t)s * H + i] = (no > 10) ? 1 : 0;  // g_min_num_obs_track (PP:845-848)
-      Q.iters_det[(size_t)s * H + i] = iterations;
+      Q.pub[(size_t)s * H + i] = (no > 10) ? (Q.direct_out ? (uint8_t)pubv : 1) : 0;  // g_min_num_obs_track (PP:845-848)
+      if (pubv) Q.iters[(size_t)s * H + pubv - 1] = iterations; else Q.iters_det[(size_t)s * H + i] = iterations;
     }
   }
   LM_STAMP(6)  // outputs
@@ -1987,6 +1990,19 @@ __device__ __forceinline__ void s2_track_assoc_wave(const Se3dStage2 &Q, int s, 
     Q.n_tracks[s] = nt + created;
     Q.next_id[s] = next_id + total_new;
   }
+  if (Q.direct_out) {
+    // Which detections will be published is known here: the LM raises the observation count of the detection's track by one and publishes
+    // above g_min_num_obs_track (PP:845-848).  Number them in detection order (= the order s2_track_update_wave publishes in), so that the
+    // LM can write each published person once, in place, instead of per detection with a second copy at publishing time (6.7 KB of the
+    // 10 KB a published person used to move).
+    bool pubd = false;
+    if (lane < nd) {
+      const int slot = Q.det_slot[(size_t)s * H + lane];
+      pubd = slot >= 0 && Q.num_obs[(size_t)s * T + slot] + 1 > 10;
+    }
+    const unsigned long long pm_ = __ballot(pubd);
+    if (lane < nd) Q.pub[(size_t)s * H + lane] = pubd ? (uint8_t)(1 + __popcll(pm_ & ((1ull << lane) - 1ull))) : 0;
+  }
 }
 
 // row L + publishing (PP:845-852, 867-903, 909-910) by one wavefront
@@ -2001,6 +2017,7 @@ __device__ __forceinline__ void s2_track_update_wave(const Se3dStage2 &Q, int s,
   static_assert(sizeof(se3d_person3d) % 8 == 0 && sizeof(se3d_person3d) / 8 <= 4 * 64, "person copy below: four 8-byte words per lane");
   constexpr int words = (int)(sizeof(se3d_person3d) / 8);
   int p = 0;
+  if (!Q.direct_out)   // (fused walk: the LM has written the published persons in place)
   for (unsigned long long m = pbm; m; m &= m - 1ull, ++p) {  // publish in detection order
     const int srcd = __ffsll((long long)m) - 1;
     const size_t src = (size_t)s * H + srcd, dst = (size_t)s * H + p;
@@ -2259,6 +2276,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
     q.iters = Wk.Wit + f0 * H;
     q.n_out = Wk.Wn + f0;
     q.pred_dt = Wk.Wdt + f0;
+    q.direct_out = 1;
     int nd[SQ];
 #pragma unroll
     for (int s = 0; s < SQ; ++s) nd[s] = (s < ns) ? min(q.n_det[s], H) : 0;
