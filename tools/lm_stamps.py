@@ -9,7 +9,7 @@ import numpy as np
 import bench
 w = bench.WORKLOADS["16cam6p"]
 rig = bench.make_rig(w)
-S_, T_ = 128, 16
+S_, T_ = int(os.environ.get("STAMP_SEQS", "128")), 16
 seqs = bench.make_sequences(None, w, 1, S_, 0, T_)[0]
 frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
 from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
