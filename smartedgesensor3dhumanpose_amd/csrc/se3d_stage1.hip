@@ -538,6 +538,10 @@ __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float 
   o.rcp = se3d_safe_rcp(o.nrm);
   o.w = valid ? 1.f : 0.f;
   unsafe |= valid && !(o.rcp != 0.f && se3d_in_safe_range(lx) && se3d_in_safe_range(ly) && se3d_in_safe_range(lz) && se3d_in_safe_range(px) && se3d_in_safe_range(py));
+  // An unusable (detection, joint) is all zeros with a unit norm: every distance it is the LINE or the POINT of comes out as exactly 0, so the
+  // item needs the other side's weight only: d1 * w_b + d2 * w_a (one FMA) instead of (d1 + d2) * (w_a * w_b).  The IEEE-divide path
+  // (se3d_rows_compute_slow) selects by the validity masks and never divides by this norm for a masked joint's contribution.
+  if (!valid) { o.lx = 0.f; o.ly = 0.f; o.lz = 0.f; o.x = 0.f; o.y = 0.f; o.nrm = 1.f; o.rcp = 1.f; }
   return o;
 }
 
@@ -571,7 +575,7 @@ __device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS], con
       const float n1 = fabsf(b[jj].x * a.lx + (b[jj].y * a.ly + a.lz));
       const float n2 = fabsf(a.x * b[jj].lx + (a.y * b[jj].ly + b[jj].lz));
       const float d1 = se3d_div_markstein(n1, a.nrm, a.rcp), d2 = se3d_div_markstein(n2, b[jj].nrm, b[jj].rcp);
-      const float sacc = (d1 + d2) * (a.w * b[jj].w);
+      const float sacc = __builtin_fmaf(d1, b[jj].w, d2 * a.w);   // = d1 + d2 for a joint both sides have, exactly 0 otherwise (se3d_rowop)
       acc[r] += (double)sacc;
       asm volatile("" : "+v"(acc[r]) : : "memory");  // the item is complete (accumulated) before the fence; the next item's LDS read comes after it
       a = an;
