@@ -524,6 +524,11 @@ __global__ __launch_bounds__(256, 3) void se3d_k_pairs_tiled(Se3dDev D, const in
 // =============================================================================================================
 #define RB_ROWS 48
 #define RB_COLS 32
+// LDS rows are padded by one operand (32 B = 8 banks): the staging threads of a wavefront write the SAME detection slot of consecutive
+// joints, and an unpadded joint stride (48 or 32 operands) is a multiple of 128 B — every lane on the same four banks (17-way / 6-way
+// conflicts, 29 % of the LDS busy cycles in profiles/r2/pmc_lds_256cam128p_rows.json before the padding)
+#define RB_ROWS_P (RB_ROWS + 1)
+#define RB_COLS_P (RB_COLS + 1)
 #ifndef RB_JH
 #define RB_JH 6
 #endif
@@ -556,7 +561,7 @@ __device__ __forceinline__ double se3d_div_count(double acc, int n, double inv_n
 }
 
 template <int JN>
-__device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS], const RowOp (&b)[RB_JH], int jbase, int row0, int nrows_left,
+__device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS_P], const RowOp (&b)[RB_JH], int jbase, int row0, int nrows_left,
                                                   double (&acc)[RB_ROWS / 8]) {
   // Straight-line code over (row pair, joint).  The det_a operand of the NEXT item is fetched from LDS while the current item is
   // computed (two RowOp in flight = 16 registers).  The memory-clobbering empty asm after every item is what keeps it that way: without
@@ -584,7 +589,7 @@ __device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS], con
 }
 // IEEE-divide form for blocks whose operands fail the range guard of the shared-reciprocal divide (practically never): compact loops, both
 // operands from LDS.
-__device__ __forceinline__ void se3d_rows_compute_slow(const RowOp (*A)[RB_ROWS], const RowOp (*Bc)[RB_COLS], int ql, int jbase, int jn, int row0,
+__device__ __forceinline__ void se3d_rows_compute_slow(const RowOp (*A)[RB_ROWS_P], const RowOp (*Bc)[RB_COLS_P], int ql, int jbase, int jn, int row0,
                                                        unsigned m2, const unsigned *M1, double (&acc)[RB_ROWS / 8]) {
 #pragma unroll
   for (int r = 0; r < RB_ROWS / 8; ++r) {
@@ -614,8 +619,8 @@ __global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, cons
   const int na = D.nvalid[f * N + ab.x], nb = D.nvalid[f * N + ab.y];
   const int p0 = blockIdx.x * RB_ROWS;
   if (p0 >= na || nb == 0) return;
-  __shared__ RowOp A[SE3D_NKP][RB_ROWS];  // det_a side, all joints: staged once per workgroup (26 KB)
-  __shared__ RowOp Bc[2][RB_JH][RB_COLS];  // det_b side of a (column tile, joint group) phase, double-buffered (2 x 6 KB)
+  __shared__ RowOp A[SE3D_NKP][RB_ROWS_P];  // det_a side, all joints: staged once per workgroup (26 KB)
+  __shared__ RowOp Bc[2][RB_JH][RB_COLS_P];  // det_b side of a (column tile, joint group) phase, double-buffered (2 x 6 KB)
   __shared__ unsigned M1[RB_ROWS], M2[2][RB_COLS];
   __shared__ int s_unsafe_a, s_unsafe_b[3];   // range-guard flags: det_a side; det_b side of phase ph in [ph % 3]
   __shared__ double INV[SE3D_NKP + 1];     // RN(1 / n) for the joint count of an entry
