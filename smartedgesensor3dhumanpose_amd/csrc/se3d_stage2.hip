@@ -1930,13 +1930,21 @@ __device__ __forceinline__ void s2_track_assoc_wave(const Se3dStage2 &Q, int s, 
   const double t = Q.t[s];
   const int nd = min(Q.n_det[s], H);
   const int nt = Q.n_tracks[s];
-  if (lane == 0) {  // feedback-delay moving average -> pred_delta_t (PP:513-526)
-    double acc = 0.0;
-    int nv = 0;
-    for (int i = 0; i < N; ++i) {
-      const float d = Q.fb_delay ? Q.fb_delay[(size_t)s * N + i] : -1.0f;
-      if (d > 0.0f) { acc += (double)d; ++nv; }
+  // feedback-delay moving average -> pred_delta_t (PP:513-526): the N delays are fetched by N lanes in one memory round trip (a loop of
+  // loads on lane 0 was N round trips) and summed in camera order from the lanes' registers
+  double fb_acc = 0.0;
+  int fb_nv = 0;
+  for (int base = 0; base < N; base += 64) {
+    const float dl = (Q.fb_delay && base + lane < N) ? Q.fb_delay[(size_t)s * N + base + lane] : -1.0f;
+    const int cnt = min(64, N - base);
+    for (int i = 0; i < cnt; ++i) {
+      const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dl), i));
+      if (d > 0.0f) { fb_acc += (double)d; ++fb_nv; }
     }
+  }
+  if (lane == 0) {
+    const double acc = fb_acc;
+    const int nv = fb_nv;
     const double cur = nv > 0 ? acc / nv : 0.10;
     Q.fb_buf[s * 3 + (Q.frame_nr[s] % 3)] = cur;
     Q.pred_dt[s] = (0.0 + Q.fb_buf[s * 3 + 0] + Q.fb_buf[s * 3 + 1] + Q.fb_buf[s * 3 + 2]) / 3;
@@ -1965,11 +1973,14 @@ __device__ __forceinline__ void s2_track_assoc_wave(const Se3dStage2 &Q, int s, 
   const unsigned long long frb = __ballot((lane < T) && !Q.used[(size_t)s * T + lane]);
   const int total_free = __popcll(frb);
   const int next_id = Q.next_id[s];
+  int my_slot = -1;   // track slot of this lane's detection (what it writes to det_slot)
   if (lane < nd) {
     if (!isnew) {
-      Q.det_slot[(size_t)s * H + lane] = order[assign];
+      my_slot = order[assign];
+      Q.det_slot[(size_t)s * H + lane] = my_slot;
     } else if (nt + p < T && p < total_free) {
       const int slot = s2_nth_set_bit(frb, p);
+      my_slot = slot;
       const size_t sl = (size_t)s * T + slot;
       Q.used[sl] = 1;
       Q.id[sl] = next_id + p;
@@ -1995,11 +2006,7 @@ __device__ __forceinline__ void s2_track_assoc_wave(const Se3dStage2 &Q, int s, 
     // above g_min_num_obs_track (PP:845-848).  Number them in detection order (= the order s2_track_update_wave publishes in), so that the
     // LM can write each published person once, in place, instead of per detection with a second copy at publishing time (6.7 KB of the
     // 10 KB a published person used to move).
-    bool pubd = false;
-    if (lane < nd) {
-      const int slot = Q.det_slot[(size_t)s * H + lane];
-      pubd = slot >= 0 && Q.num_obs[(size_t)s * T + slot] + 1 > 10;
-    }
+    const bool pubd = my_slot >= 0 && Q.num_obs[(size_t)s * T + my_slot] + 1 > 10;
     const unsigned long long pm_ = __ballot(pubd);
     if (lane < nd) Q.pub[(size_t)s * H + lane] = pubd ? (uint8_t)(1 + __popcll(pm_ & ((1ull << lane) - 1ull))) : 0;
   }
@@ -2043,14 +2050,18 @@ __device__ __forceinline__ void s2_track_update_wave(const Se3dStage2 &Q, int s,
   int *order = Q.order + (size_t)s * T;
   const int slotv = (lane < nt) ? order[lane] : 0;
   unsigned long long alive = nt >= 64 ? ~0ull : ((1ull << nt) - 1ull);
+  // lane i holds the merge-distance row of track i (T <= 64: one word): one memory round trip instead of one per track in the loop below
+  const unsigned long long my_near = (lane < nt) ? Q.near[((size_t)s * T + slotv) * 4] : 0ull;
   for (int i = 0; i < nt; ++i) {
     if (!((alive >> i) & 1ull)) continue;
     const int slot_i = __builtin_amdgcn_readlane(slotv, i);
     const size_t si = (size_t)s * T + slot_i;
+    const unsigned long long row_i = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(my_near >> 32), i) << 32) |
+                                     (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(my_near & 0xFFFFFFFFull), i);
     bool kill = false;
     if (lane > i && lane < nt && ((alive >> lane) & 1ull)) {
       const size_t sj = (size_t)s * T + slotv;
-      if ((Q.near[si * 4 + (slotv >> 6)] >> (slotv & 63)) & 1ull) {  // se3d_k_track_near: closer than g_merge_dist_thresh
+      if ((row_i >> (slotv & 63)) & 1ull) {  // se3d_k_track_near: closer than g_merge_dist_thresh
         kill = true;
         Q.used[sj] = 0;
         const uint32_t idj = (uint32_t)Q.id[sj], idi = (uint32_t)Q.id[si];
