@@ -2071,6 +2071,139 @@ __global__ __launch_bounds__(64) void se3d_k_sweep_fused_wave(Se3dDev D) {
 }
 
 // stand-alone Munkres (se3d_hungarian): one workgroup, dist column-major with ld = nR
+// The one-wavefront sweep with its working set in LDS (round 2).  se3d_k_sweep_fused_wave keeps the association table, the view counts,
+// the cost matrix and the veto mask of the frame in global memory: every camera step is a chain of ~6 dependent L2 round trips (assoc ->
+// pair table -> C / mask stores -> loads by other lanes -> attach / spawn stores -> next step), ~100 per frame, and the kernel sat at 78 %
+// s_waitcnt with 17 % VALU issue utilisation.  Here only the pair-table reads (8 in flight per (hypothesis, detection) item) go to
+// memory; assoc / nviews / nhyp are written back once at the end.  Same decisions in the same order as se3d_sweep_cost_small +
+// se3d_sweep_assign_wave (S3D:538-673): the association tables of the three launch structures are compared bytewise in
+// tests/test_gpu_stage1.py.
+__global__ __launch_bounds__(64) void se3d_k_sweep_wave_lds(Se3dDev D) {
+  extern __shared__ __align__(16) double s_sw[];
+  const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
+  const int f = blockIdx.x, lane = threadIdx.x;
+  double *W = s_sw;                                   // [H * P] Munkres working matrix
+  double *C = W + (size_t)H * P;                      // [H * P] cost, hypothesis-major like D.C
+  float *psc = reinterpret_cast<float *>(C + (size_t)H * P);     // [N * P] detection scores of the frame
+  int32_t *assoc = reinterpret_cast<int32_t *>(psc + (size_t)N * P);  // [H * N]
+  int *nviews = assoc + (size_t)H * N;                // [H]
+  int *nraw = nviews + H, *nvalid = nraw + N;         // [N] each
+  uint8_t *mask = reinterpret_cast<uint8_t *>(nvalid + N);       // [H * P]
+  for (int i = lane; i < N * P; i += 64) psc[i] = D.pscore[(size_t)f * N * P + i];
+  for (int i = lane; i < H * N; i += 64) assoc[i] = -1;
+  for (int i = lane; i < H; i += 64) nviews[i] = 0;
+  for (int i = lane; i < N; i += 64) { nraw[i] = D.nraw[f * N + i]; nvalid[i] = D.nvalid[f * N + i]; }
+  __syncthreads();
+  const double max_epi = D.d.max_epi;
+  const double *tab = D.pair + (size_t)f * np * P * P;
+  int nh = 0;   // hypotheses so far: every lane derives the same value from the ballots
+  for (int b = 0; b < N; ++b) {
+    if (nraw[b] == 0) continue;  // S3D:538-555
+    const int nd = nvalid[b];
+    if (nh == 0) {  // seeding (S3D:565-586)
+      if (lane < nd && lane < H) { assoc[(size_t)lane * N + b] = lane; nviews[lane] = 1; }
+      nh = min(nd, H);
+      __syncthreads();
+      continue;
+    }
+    if (nd == 0) continue;
+    // ---- cost and veto mask of (hypothesis, detection of camera b): se3d_sweep_cost_small ----
+    for (int idx = lane; idx < nh * nd; idx += 64) {
+      const int h = idx % nh, q = idx / nh;
+      const int32_t *arow = assoc + (size_t)h * N;
+      const int n_obs = nviews[h];
+      const double tolerance = 1.0 - 1.0 / (2 * n_obs), veto_delta = 1.0 / n_obs;
+      double total = 0.0;
+      int nused = 0, cnt = 0;
+      for (int a0 = 0; a0 < b; a0 += 8) {  // 8 independent pair-table loads in flight, ordered accumulation
+        int k[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) k[u] = (a0 + u < b) ? arow[a0 + u] : -1;
+        double c[8];
+        float sc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          c[u] = -1.0; sc[u] = 0.f;
+          if (k[u] >= 0) {
+            c[u] = tab[((size_t)se3d_pair_index(a0 + u, b, N) * P + k[u]) * P + q];
+            sc[u] = psc[(size_t)(a0 + u) * P + k[u]];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (c[u] >= 0.0) {
+            total += c[u];
+            ++nused;
+            if (c[u] > max_epi && (sc[u] > 0.5f || n_obs == 1)) ++cnt;
+          }
+        }
+      }
+      bool veto = false;
+      if (cnt > 0) {
+        double tmp = 0.0;
+        for (int i = 0; i < cnt; ++i) tmp += veto_delta;
+        veto = tmp > tolerance;
+      }
+      double Cv;
+      if (nused > 0) Cv = total / nused;
+      else { Cv = MAX_COSTS; veto = true; }
+      C[h + (size_t)H * q] = Cv;
+      mask[h + (size_t)H * q] = (!veto && Cv < max_epi) ? 1 : 0;
+    }
+    __syncthreads();
+    // ---- assignment, attach / spawn: se3d_sweep_assign_wave ----
+    int cnt = 0, assign = -1;
+    if (lane < nh)
+      for (int q = 0; q < nd; ++q)
+        if (mask[lane + (size_t)H * q]) { ++cnt; assign = q; }   // S3D:620-623
+    int ccnt = 0;
+    if (lane < nd)
+      for (int h = 0; h < nh; ++h) ccnt += mask[h + (size_t)H * lane];
+    if (__ballot(cnt > 1 || ccnt > 1)) {  // S3D:628-634
+      if (lane < nh)
+        for (int q = 0; q < nd; ++q) W[lane + nh * q] = C[lane + (size_t)H * q];
+      const int rc = se3d_munkres_wave(W, nh, nh, nd, lane, assign);
+      if (rc != 0 && lane == 0) atomicOr(&D.flags[f], SE3D_FLAG_ASSIGNMENT_FAILED);
+    }
+    bool sp = false;
+    const int det = (lane < nh) ? assign : -1;
+    if (det >= 0) {
+      if (mask[lane + (size_t)H * det]) {
+        assoc[(size_t)lane * N + b] = det;
+        nviews[lane] += 1;
+      } else {
+        sp = true;
+      }
+    }
+    bool handled = false;
+    for (int h = 0; h < nh; ++h) handled |= (__builtin_amdgcn_readlane(det, h) == lane);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long spb = __ballot(sp);
+    const int tot1 = __popcll(spb);
+    if (sp) {
+      const int nhh = nh + __popcll(spb & lt);
+      if (nhh < H) { assoc[(size_t)nhh * N + b] = det; nviews[nhh] = 1; }
+    }
+    const bool un = (lane < nd) && !handled;  // S3D:662-673
+    const unsigned long long unb = __ballot(un);
+    const int tot2 = __popcll(unb);
+    if (un) {
+      const int nhh = nh + tot1 + __popcll(unb & lt);
+      if (nhh < H) { assoc[(size_t)nhh * N + b] = lane; nviews[nhh] = 1; }
+    }
+    const int nn = nh + tot1 + tot2;
+    if (nn > H && lane == 0) atomicOr(&D.flags[f], SE3D_FLAG_HYP_OVERFLOW);
+    nh = min(nn, H);
+    __syncthreads();
+  }
+  for (int i = lane; i < H * N; i += 64) D.assoc[(size_t)f * H * N + i] = assoc[i];
+  for (int i = lane; i < H; i += 64) D.nviews[f * H + i] = nviews[i];
+  if (lane == 0) D.nhyp[f] = nh;
+}
+static size_t se3d_sweep_wave_lds_bytes(int N, int P, int H) {
+  return (size_t)H * P * 16 + (size_t)N * P * 4 + (size_t)H * N * 4 + (size_t)H * 4 + (size_t)N * 8 + (((size_t)H * P + 15) & ~(size_t)15);
+}
+
 __global__ __launch_bounds__(256) void se3d_k_munkres(double *dist, int *assign, int *status, int nR, int nC) {
   __shared__ MunkresShared S;
   __shared__ int a[SE3D_MUNKRES_MAX];
@@ -2149,11 +2282,14 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   // (the dynamic-LDS limits of se3d_k_sweep_assign / se3d_k_sweep_fused are raised per device by se3d_stage1_init_device)
   // A/B switches (read per launch so that the parity tests can compare the variants in one process):
   //   SE3D_SWEEP_FUSED_MAX = H*P up to which the one-launch 256-thread sweep is used (0 = never), SE3D_SWEEP_WAVE=0 disables the
-  //   one-wavefront sweep
+  //   one-wavefront sweeps, 2 = the global-memory form of it
   const char *e_fused = getenv("SE3D_SWEEP_FUSED_MAX"), *e_wave = getenv("SE3D_SWEEP_WAVE");
   const int fused_limit = e_fused ? atoi(e_fused) : 256;
   const int sweep_wave = e_wave ? atoi(e_wave) : 1;
-  if (sweep_wave && H <= 64 && P <= 64 && H * P <= 2048) {  // larger problems: one wavefront per frame is too little parallelism
+  if (sweep_wave == 1 && H <= 64 && P <= 64 && D.d.N <= 64 && se3d_sweep_wave_lds_bytes(D.d.N, P, H) <= 16 * 1024) {
+    // small rigs: the frame's association state in LDS (SE3D_SWEEP_WAVE=2 selects the global-memory form below)
+    hipLaunchKernelGGL(se3d_k_sweep_wave_lds, dim3(B), dim3(64), se3d_sweep_wave_lds_bytes(D.d.N, P, H), st, D);
+  } else if (sweep_wave && H <= 64 && P <= 64 && H * P <= 2048) {  // larger problems: one wavefront per frame is too little parallelism
     hipLaunchKernelGGL(se3d_k_sweep_fused_wave, dim3(B), dim3(64), (size_t)dynW, st, D);
   } else if (H * P <= fused_limit && dynW <= 64 * 1024) {
     hipLaunchKernelGGL(se3d_k_sweep_fused, dim3(B), dim3(256), (size_t)dynW, st, D, dynW);

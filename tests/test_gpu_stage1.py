@@ -78,8 +78,9 @@ def test_device_hungarian_fuzz_vs_oracle(node16, oracle):
 
 @pytest.mark.parametrize("rig_name,persons,max_det,max_hyp", [("extr16", 6, 8, 8), ("extr16", 12, 16, 32), ("ell24", 20, 24, 48)])
 def test_sweep_variants_agree_exactly(monkeypatch, rig_name, persons, max_det, max_hyp):
-    """The three launch structures of the camera sweep — per-step kernels, one 256-thread launch, one wavefront per frame — must give
-    the same hypotheses, association tables and persons (crowded, noisy frames so that the Hungarian branch runs)."""
+    """The launch structures of the camera sweep — per-step kernels, one 256-thread launch, one wavefront per frame with its working set in
+    LDS (default for small rigs) or in global memory — must give the same hypotheses, association tables and persons (crowded, noisy frames
+    so that the Hungarian branch runs)."""
     from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
     rig = R.extr_rig_16cam() if rig_name == "extr16" else R.elliptical_rig(24, seed=4)
     rig.set_tensors(*rig_tensors(rig))
@@ -87,7 +88,7 @@ def test_sweep_variants_agree_exactly(monkeypatch, rig_name, persons, max_det, m
                                                        spacing=0.7, min_coverage=4 if rig_name == "extr16" else 6))
     res = {}
     for name, env in (("steps", {"SE3D_SWEEP_FUSED_MAX": "0", "SE3D_SWEEP_WAVE": "0"}), ("fused256", {"SE3D_SWEEP_FUSED_MAX": "100000", "SE3D_SWEEP_WAVE": "0"}),
-                      ("wave", {"SE3D_SWEEP_WAVE": "1"})):
+                      ("wave", {"SE3D_SWEEP_WAVE": "1"}), ("wave_global", {"SE3D_SWEEP_WAVE": "2"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         node = _node(rig, max_frames=8, max_det_per_cam=max_det, max_hyp=max_hyp)
@@ -96,8 +97,8 @@ def test_sweep_variants_agree_exactly(monkeypatch, rig_name, persons, max_det, m
         for k in env:
             monkeypatch.delenv(k)
     n_hyp = 0
-    for a, b, c in zip(res["steps"], res["fused256"], res["wave"]):
-        for other in (b, c):
+    for a, b, c, d in zip(res["steps"], res["fused256"], res["wave"], res["wave_global"]):
+        for other in (b, c, d):
             assert a.n_hyp == other.n_hyp and a.n_persons == other.n_persons and a.flags == other.flags
             assert np.array_equal(a.assoc(), other.assoc())
             assert a.published().tobytes() == other.published().tobytes()
