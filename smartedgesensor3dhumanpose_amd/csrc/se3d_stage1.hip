@@ -1903,6 +1903,183 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave(Se3dDev D) {
   }
 }
 
+// Lane-parallel form of se3d_k_postprocess_wave (round 2): the plausibility filter and the duplicate-merge distances run over
+// (person, joint) items instead of one lane per person walking its 17 + 21 joints (6 of 64 lanes busy, 4.7 k instructions per frame at
+// 17 % VALU issue utilisation).  Everything whose ORDER matters stays in the reference's order: a keypoint's covariance gets its own
+// limb-length term before the right-shoulder special case adds to the left shoulder (S3D:875-881), and the mean joint distance of a
+// pair of persons is summed joint by joint in ascending order by one lane — only the square roots under the sum are computed in
+// parallel.  Same results as se3d_post_filter / the sequential merge loop bit for bit (tests/test_gpu_stage1.py compares the two forms).
+__global__ __launch_bounds__(64) void se3d_k_postprocess_wave2(Se3dDev D) {
+  extern __shared__ __align__(16) unsigned char post_smem[];
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  const int pm = D.d.pose_method;
+  se3d_person3d *sp = reinterpret_cast<se3d_person3d *>(post_smem);                 // [H] persons
+  double *term = reinterpret_cast<double *>(sp + H);                                  // [H][21] joint distances of (i, j) for the current i; < 0: joint not in both
+  int *cnt0 = reinterpret_cast<int *>(term + (size_t)H * SE3D_NFU), *dec = cnt0 + H;  // [H] valid input keypoints / removed fusion slots
+  const int nh = D.nhyp[f];
+  const se3d_person3d *persons = D.hypP + (size_t)f * H;
+  constexpr int words2 = (int)(sizeof(se3d_person3d) / 8);
+  int ncam = 0;
+  for (int c = lane; c < N; c += 64) ncam += (D.nraw[f * N + c] > 0) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) ncam += __shfl_xor(ncam, o);
+  const bool few = ncam < 2;  // S3D:557-560
+  {
+    const uint2 *src = reinterpret_cast<const uint2 *>(persons);
+    uint2 *dst = reinterpret_cast<uint2 *>(sp);
+    for (int w = lane; w < nh * words2; w += 64) dst[w] = src[w];
+  }
+  const int nv_l = (lane < nh) ? D.nviews[f * H + lane] : 0;
+  if (lane < H) { cnt0[lane] = 0; dec[lane] = 0; }
+  __syncthreads();
+  // ---- limb-length covariance inflation (S3D:861-883), own keypoint: items (person, input keypoint) ----
+  double s56 = 0.0;   // the right shoulder's term for the left shoulder (special case), applied after every own term
+  bool add56 = false;
+  int h56 = 0;
+  for (int it = lane; it < nh * SE3D_NKP; it += 64) {
+    const int h = it / SE3D_NKP, k = it - h * SE3D_NKP;
+    se3d_person3d &p = sp[h];
+    se3d_keypoint3d &kp = p.keypoints[c_kp2fusion[pm][k]];
+    if (kp.score <= 0.f) continue;
+    atomicAdd(&cnt0[h], 1);
+    const int parent = c_kpParent[pm][k];
+    if (parent < 0) continue;
+    const se3d_keypoint3d &pk = p.keypoints[c_kp2fusion[pm][parent]];
+    if (pk.score > 0.f && c_limbLength[pm][k] > 0) {
+      const double jd = se3d_jdist(kp.joint, pk.joint);
+      se3d_addcov(kp, 0.075 * (jd - c_limbLength[pm][k]) / c_limbLSigma[pm][k]);
+    } else if (pm == SE3D_POSE_SIMPLE && k == 6) {  // RShoulder special case (S3D:875-881)
+      const se3d_keypoint3d &ls = p.keypoints[c_kp2fusion[pm][5]];
+      if (ls.score > 0.f) {
+        const double jd = se3d_jdist(kp.joint, ls.joint);
+        s56 = 0.075 * (jd - 0.35) / 0.15;
+        se3d_addcov(kp, s56);
+        add56 = true;
+        h56 = h;
+      }
+    }
+  }
+  __syncthreads();
+  if (add56) se3d_addcov(sp[h56].keypoints[c_kp2fusion[pm][5]], s56);   // after the left shoulder's own term (k = 5 precedes k = 6)
+  __syncthreads();
+  // ---- distance to the root (S3D:937-953): items (person, fusion slot) ----
+  for (int it = lane; it < nh * SE3D_NFU; it += 64) {
+    const int h = it / SE3D_NFU, k = it - h * SE3D_NFU;
+    se3d_person3d &p = sp[h];
+    double root[3] = {0, 0, 0};
+    float root_score = 0.f;
+    if (p.keypoints[FU_MidHip].score > 0.f) {
+      for (int a = 0; a < 3; ++a) root[a] = p.keypoints[FU_MidHip].joint[a];
+      root_score = p.keypoints[FU_MidHip].score;
+    } else if (p.keypoints[FU_LHip].score > 0.f && p.keypoints[FU_RHip].score > 0.f) {
+      for (int a = 0; a < 3; ++a) root[a] = (p.keypoints[FU_LHip].joint[a] + p.keypoints[FU_RHip].joint[a]) / 2.;
+      root_score = (p.keypoints[FU_LHip].score + p.keypoints[FU_RHip].score) / 2.f;
+    }
+    // the reference takes a copy of the root before it starts removing keypoints (a hip farther than 2 m from the hips' midpoint is removed
+    // too): every lane reads the root here, the removals come after the barrier below
+    bool rm = false;
+    if (root_score > 0.f) {
+      se3d_keypoint3d &kp = p.keypoints[k];
+      rm = !(kp.score > 0.f) || se3d_jdist(root, kp.joint) > 2.0;
+    }
+    term[it] = rm ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int it = lane; it < nh * SE3D_NFU; it += 64)
+    if (term[it] != 0.0) {
+      const int h = it / SE3D_NFU, k = it - h * SE3D_NFU;
+      se3d_zero_kp(sp[h].keypoints[k]);
+      atomicAdd(&dec[h], 1);
+    }
+  __syncthreads();
+  bool al = false;
+  if (lane < nh && !few && nv_l >= 2) {
+    const se3d_person3d &p = sp[lane];
+    int num_valid = cnt0[lane] - dec[lane];
+    double feet = 0.0;  // S3D:955-966
+    if (p.keypoints[FU_LAnkle].score > 0.f && p.keypoints[FU_RAnkle].score > 0.f)
+      feet = (p.keypoints[FU_LAnkle].joint[2] + p.keypoints[FU_RAnkle].joint[2]) / 2.0;
+    else if (p.keypoints[FU_LAnkle].score > 0.f) feet = p.keypoints[FU_LAnkle].joint[2];
+    else if (p.keypoints[FU_RAnkle].score > 0.f) feet = p.keypoints[FU_RAnkle].joint[2];
+    if (fabs(feet) > 0.50) num_valid = 0;
+    al = num_valid > 9;
+  }
+  unsigned long long alive = __ballot(al);
+  // ---- duplicate merge (S3D:984-996): sequential in i; joint distances of (i, every later alive j) over the lanes, summed in joint order ----
+  for (int i = 0; i < nh; ++i) {
+    if (!((alive >> i) & 1ull)) continue;
+    int from = i + 1;
+    for (;;) {
+      if (!(alive >> from)) break;   // nobody left behind i (from < 64 here: from <= nh <= H <= 16)
+      const int nj = nh - from;
+      for (int it = lane; it < nj * SE3D_NFU; it += 64) {
+        const int jo = it / SE3D_NFU, k = it - jo * SE3D_NFU, jj = from + jo;
+        double t = -1.0;
+        if ((alive >> jj) & 1ull) {
+          const se3d_keypoint3d &a = sp[i].keypoints[k], &bb = sp[jj].keypoints[k];
+          if (a.score > 0.f && bb.score > 0.f) {
+            const double dx = a.joint[0] - bb.joint[0], dy = a.joint[1] - bb.joint[1], dz = a.joint[2] - bb.joint[2];
+            t = sqrt(dx * dx + dy * dy + dz * dz);
+          }
+        }
+        term[it] = t;
+      }
+      __syncthreads();
+      bool hit = false;
+      if (lane < nj && ((alive >> (from + lane)) & 1ull)) {
+        int nu = 0;
+        double dist = 0.0;
+        for (int k = 0; k < SE3D_NFU; ++k) {
+          const double t = term[lane * SE3D_NFU + k];
+          if (t >= 0.0) { dist += t; ++nu; }
+        }
+        hit = (nu > 0 ? dist / nu : MAX_COSTS) < 0.20;
+      }
+      const unsigned long long hb = __ballot(hit);
+      if (!hb) break;
+      const int jm = from + __ffsll((long long)hb) - 1;
+      __syncthreads();
+      if (lane < SE3D_NFU) {  // merge_persons (S3D:410-423), one joint per lane
+        se3d_keypoint3d &k1 = sp[i].keypoints[lane];
+        const se3d_keypoint3d &k2 = sp[jm].keypoints[lane];
+        const double total = (double)(k1.score + k2.score);
+        if (total > 0.0) {
+          for (int a = 0; a < 3; ++a) k1.joint[a] = ((double)k1.score * k1.joint[a] + (double)k2.score * k2.joint[a]) / total;
+          k1.score = fmaxf(k1.score, k2.score);
+          for (int a = 0; a < 6; ++a) k1.cov[a] = (k1.cov[a] + k2.cov[a]) / 2.0;
+        }
+      }
+      __syncthreads();
+      alive &= ~(1ull << jm);
+      from = jm + 1;
+      if (from >= nh) break;
+    }
+  }
+  // ---- compaction in ascending hypothesis order + association table in original detection indices ----
+  const int total = __popcll(alive);
+  int pos = 0;
+  for (unsigned long long m = alive; m; m &= m - 1ull, ++pos) {
+    const int h = __ffsll((long long)m) - 1;
+    const uint2 *src = reinterpret_cast<const uint2 *>(&sp[h]);
+    uint2 *dst = reinterpret_cast<uint2 *>(&D.outP[(size_t)f * H + pos]);
+    for (int w = lane; w < words2; w += 64) dst[w] = src[w];
+    if (lane == 0) D.out_hyp[(size_t)f * H + pos] = h;
+  }
+  if (lane == 0) {
+    D.out_count[f] = total;
+    if (few) {  // the reference returns before building any hypothesis (S3D:557-560)
+      atomicOr(&D.flags[f], SE3D_FLAG_FEW_CAMERAS);
+      D.nhyp[f] = 0;
+    }
+  }
+  for (int i = lane; i < nh * N; i += 64) {
+    const int h = i / N, c = i - h * N;
+    const int k = D.assoc[((size_t)f * H + h) * N + c];
+    D.out_assoc[((size_t)f * H + h) * N + c] = (k >= 0) ? D.orig[((size_t)(f * N + c)) * P + k] : -1;
+  }
+}
+static size_t se3d_post_wave2_lds_bytes(int H) { return sizeof(se3d_person3d) * (size_t)H + (size_t)H * SE3D_NFU * 8 + (size_t)H * 8; }
+
 __global__ __launch_bounds__(256) void se3d_k_postprocess(Se3dDev D) {
   const int f = blockIdx.x, tid = threadIdx.x;
   const int N = D.d.N, P = D.d.P, H = D.d.H;
@@ -2314,7 +2491,10 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   if (phases & 2) se3d_launch_triangulation(D, st);
   if (ev && (phases & 2)) (void)hipEventRecord(ev[4], st);
   if (phases & 4) {
-    if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), sizeof(se3d_person3d) * (size_t)H, st, D);
+    const char *e_post = getenv("SE3D_POST_WAVE");   // A/B switch read per launch: 1 = one lane per person (round 1), default = lane-parallel
+    if (H <= SE3D_POST_SMALL_H && e_post && atoi(e_post) == 1)
+      hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), sizeof(se3d_person3d) * (size_t)H, st, D);
+    else if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave2, dim3(B), dim3(64), se3d_post_wave2_lds_bytes(H), st, D);
     else hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
   }
   if (ev && (phases & 4)) (void)hipEventRecord(ev[5], st);
