@@ -2092,6 +2092,67 @@ __device__ __forceinline__ void s2_fill_track_pos(const Se3dStage2 &Q, int s, in
     tpos[idx] = Q.used[sl] ? Q.prev[sl * SE3D_NFU * 3 + r] * Q.height_prev[sl] + Q.root_prev[sl * 3 + a] : 0.0;
   }
 }
+// One-wavefront forms over the ACTIVE tracks only (order[0 .. n_tracks)): the position table and the merge-distance matrix of the fused walk.
+// s2_fill_track_pos / s2_track_near_flat sweep all T slots (16 rounds of 64 entries / T x T pairs in windows of 64) although a sequence
+// has ~6 live tracks; every consumer (track cost, merge distances, the merge loop of s2_track_update_wave) only looks at slots in order[].
+__device__ __forceinline__ void s2_fill_track_pos_wave(const Se3dStage2 &Q, int s, int lane, double *tpos) {
+  const int T = Q.T;
+  const int nt = Q.n_tracks[s];
+  const int my_slot = (lane < nt) ? Q.order[(size_t)s * T + lane] : 0;
+  for (int base = 0; base < nt * SE3D_NFU * 3; base += 64) {   // uniform trip count: the shuffle below needs its source lanes active
+    const int idx = base + lane;
+    const int a_ = min(idx / (SE3D_NFU * 3), nt - 1), r = idx - a_ * (SE3D_NFU * 3), a = r % 3;
+    const int slot = __shfl(my_slot, a_);
+    if (idx < nt * SE3D_NFU * 3) {
+      const size_t sl = (size_t)s * T + slot;
+      tpos[(size_t)slot * SE3D_NFU * 3 + r] = Q.used[sl] ? Q.prev[sl * SE3D_NFU * 3 + r] * Q.height_prev[sl] + Q.root_prev[sl * 3 + a] : 0.0;
+    }
+  }
+}
+__device__ __forceinline__ void s2_track_near_wave(const Se3dStage2 &Q, int s, int lane, const double *tpos) {
+  const int T = Q.T;   // <= 64: a row of the bit matrix is one word
+  const size_t s0 = (size_t)s * T;
+  const int nt = Q.n_tracks[s];
+  const int my_slot = (lane < nt) ? Q.order[s0 + lane] : 0;
+  unsigned long long cm = 0ull;   // lane a: hits of track a against track b (compact indices)
+  for (int p0 = 0; p0 < nt * nt; p0 += 64) {
+    const int idx = p0 + lane;
+    bool nr = false;
+    const int a_ = min(idx / nt, nt - 1), b_ = idx - (idx / nt) * nt;
+    const int si = __shfl(my_slot, a_), j = __shfl(my_slot, b_);   // outside the bounds test: the source lanes must be active
+    if (idx < nt * nt) {
+      if (a_ != b_ && Q.used[s0 + si] && Q.used[s0 + j]) {
+        const uint32_t both = Q.has[s0 + si] & Q.has[s0 + j];
+        const double *pi = tpos + (size_t)si * SE3D_NFU * 3, *pj = tpos + (size_t)j * SE3D_NFU * 3;
+        int nj = 0;
+        double dist = 0.0;
+        for (int k = 0; k < SE3D_NFU; ++k)
+          if ((both >> k) & 1u) {
+            const double dx = pi[3 * k] - pj[3 * k], dy = pi[3 * k + 1] - pj[3 * k + 1], dz = pi[3 * k + 2] - pj[3 * k + 2];
+            dist += sqrt(dx * dx + dy * dy + dz * dz);
+            ++nj;
+          }
+        nr = (nj > 0 ? dist / nj : 1e6) < 0.20;
+      }
+    }
+    const unsigned long long b = __ballot(nr);   // bit l <-> pair p0 + l
+    const int lo = max(lane * nt, p0), hi = min(lane * nt + nt, p0 + 64);  // this lane's row within the window
+    if (lane < nt && lo < hi) {
+      const int w = hi - lo;
+      const unsigned long long m = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+      cm |= ((b >> (lo - p0)) & m) << (lo - lane * nt);
+    }
+  }
+  unsigned long long rowbits = 0ull;   // compact column index -> slot bit
+  for (int b_ = 0; b_ < nt; ++b_) {
+    const int slot_b = __builtin_amdgcn_readlane(my_slot, b_);
+    rowbits |= ((cm >> b_) & 1ull) << slot_b;
+  }
+  if (lane < nt) {
+    unsigned long long *row = Q.near + (s0 + my_slot) * 4;
+    row[0] = rowbits; row[1] = 0ull; row[2] = 0ull; row[3] = 0ull;
+  }
+}
 __device__ __forceinline__ void s2_track_cost_lds(const Se3dStage2 &Q, int s, int tid, int nthr, const double *tpos) {
   const int T = Q.T, H = Q.H;
   const int nd = min(Q.n_det[s], H), nt = Q.n_tracks[s];
@@ -2292,9 +2353,13 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
 #pragma unroll
     for (int s = 0; s < SQ; ++s) nd[s] = (s < ns) ? min(q.n_det[s], H) : 0;
     WK_STAMP_INIT
+    if constexpr (WV == 1) {
+      if (nd[0] > 0) s2_fill_track_pos_wave(q, 0, lane, tpos);
+    } else {
 #pragma unroll
-    for (int s = 0; s < SQ; ++s)
-      if (nd[s] > 0) s2_fill_track_pos(q, s, tid, NT, tpos + s * tpos_stride);
+      for (int s = 0; s < SQ; ++s)
+        if (nd[s] > 0) s2_fill_track_pos(q, s, tid, NT, tpos + s * tpos_stride);
+    }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < SQ; ++s)
@@ -2352,12 +2417,16 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
     }
     __syncthreads();
     WK_STAMP(12)  // LM
+    if constexpr (WV == 1) {
+      if (nd[0] > 0) s2_fill_track_pos_wave(q, 0, lane, tpos);  // the LM phase has updated the tracks
+    } else {
 #pragma unroll
-    for (int s = 0; s < SQ; ++s)
-      if (nd[s] > 0) s2_fill_track_pos(q, s, tid, NT, tpos + s * tpos_stride);  // the LM phase has updated the tracks
+      for (int s = 0; s < SQ; ++s)
+        if (nd[s] > 0) s2_fill_track_pos(q, s, tid, NT, tpos + s * tpos_stride);  // the LM phase has updated the tracks
+    }
     __syncthreads();
     if constexpr (WV == 1) {
-      if (nd[0] > 0) s2_track_near_flat(q, 0, lane, tpos);
+      if (nd[0] > 0) s2_track_near_wave(q, 0, lane, tpos);
     } else
     for (int it = wave; it < ns * T; it += WV) {
       const int s = it / T, si = it - s * T;
