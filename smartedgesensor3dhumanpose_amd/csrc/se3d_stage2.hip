@@ -2168,17 +2168,18 @@ __device__ __forceinline__ void s2_track_cost_lds(const Se3dStage2 &Q, int s, in
     const double *pp = tpos + (size_t)slot * SE3D_NFU * 3;
     int nj = 0;
     double dist = 0.0;
-    static_assert(SE3D_NFU % 7 == 0, "joints are fetched seven at a time");
-    for (int k0 = 0; k0 < SE3D_NFU; k0 += 7) {  // seven keypoints in flight per memory round trip (a load per joint behind its own test: 21 trips)
-      double jx[7], jy[7], jz[7];
-      float sc[7];
+    constexpr int CB = 21;   // keypoints in flight per memory round trip (7 when the walk was compiled for 168 VGPRs)
+    static_assert(SE3D_NFU % CB == 0, "joints are fetched CB at a time");
+    for (int k0 = 0; k0 < SE3D_NFU; k0 += CB) {  // (a load per joint behind its own test: 21 trips)
+      double jx[CB], jy[CB], jz[CB];
+      float sc[CB];
 #pragma unroll
-      for (int q = 0; q < 7; ++q) {
+      for (int q = 0; q < CB; ++q) {
         const se3d_keypoint3d &kp = dets[det].keypoints[k0 + q];
         jx[q] = kp.joint[0]; jy[q] = kp.joint[1]; jz[q] = kp.joint[2]; sc[q] = kp.score;
       }
 #pragma unroll
-      for (int q = 0; q < 7; ++q) {
+      for (int q = 0; q < CB; ++q) {
         const int k = k0 + q;
         if (sc[q] > 0.10f && ((has >> k) & 1u)) {
           const double dx = jx[q] - pp[3 * k], dy = jy[q] - pp[3 * k + 1], dz = jz[q] - pp[3 * k + 2];
