@@ -131,6 +131,8 @@ struct Se3dStage2 {
   uint32_t *flags2;       // [S]
   double *lm_scratch;     // [S][4][1865] HBM Schur workspace of the fused walk's non-forest LM fallback
   int shard_rank, shard_world;  // hypothesis shard: the per-step LM kernel refines detections i with i % world == rank only
+  int u_valid, u_fslot;          // fused walk, one sequence per workgroup: the step's per-sequence scalars, loaded once after the association
+  double u_pred_dt, u_t_prev;    // phase instead of by every LM wavefront pass at output time (pred_dt[s], frame_nr[s] % 3, t_prev[s])
   int direct_out;       // fused walk: the association phase numbers the detections that will be published (pub = 1 + output slot) and the LM
                         // writes a published person straight into fused / pred / iters; nothing is written for an unpublished one
 };

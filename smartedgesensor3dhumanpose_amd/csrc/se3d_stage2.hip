@@ -1433,6 +1433,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
   LmTrioGroup &L = W.g[g];
   have = have && g3 < 3;   // the caller hands out detections i < min(n_det, H) only
   const int slot = have ? Q.det_slot[(size_t)s * H + i] : -1;
+  const int pubv = (have && Q.direct_out) ? (int)Q.pub[(size_t)s * H + i] : 0;   // fused walk: 1 + output slot of a person that will be published
   have = have && slot >= 0;
   const size_t sl = have ? (size_t)s * T + slot : 0;
   const se3d_person3d &person = Q.dets[have ? (size_t)s * H + i : 0];
@@ -1840,15 +1841,14 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
   LM_STAMP(5)  // marginals
   // ---- outputs + track-state update (PP:769-843): every lane writes the whole keypoint of its joint in both persons ----
   if (valid) {
-    const int pubv = Q.direct_out ? (int)Q.pub[(size_t)s * H + i] : 0;   // fused walk: 1 + output slot of a person that will be published
     const bool wr = !Q.direct_out || pubv != 0;                          // an unpublished person's payload is never read: not written
     se3d_person3d &pf = pubv ? Q.fused[(size_t)s * H + pubv - 1] : Q.fused_det[(size_t)s * H + i];
     se3d_person3d &pp = pubv ? Q.pred[(size_t)s * H + pubv - 1] : Q.pred_det[(size_t)s * H + i];
     const int track_id = Q.id[sl];
     if (j == 0 && wr) { pf.id = (uint32_t)track_id; pf.score = 0.f; pp.id = (uint32_t)track_id; pp.score = 0.f; }
-    const double pred_dt = Q.pred_dt[s];
-    const int fslot = Q.frame_nr[s] % 3;
-    const double gtprev = Q.t_prev[s];
+    const double pred_dt = Q.u_valid ? Q.u_pred_dt : Q.pred_dt[s];
+    const int fslot = Q.u_valid ? Q.u_fslot : Q.frame_nr[s] % 3;
+    const double gtprev = Q.u_valid ? Q.u_t_prev : Q.t_prev[s];
     double *velk = Q.vel + (sl * SE3D_NFU + j) * 9;
     se3d_keypoint3d kf, kpred;
     for (int a = 0; a < 3; ++a) { kf.joint[a] = 0.0; kpred.joint[a] = 0.0; }
@@ -2374,6 +2374,12 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
     }
     if (tid == 0) s_next_person = 0;
     __syncthreads();
+    if constexpr (SQ == 1) {   // the step's per-sequence scalars once, not per LM pass
+      q.u_pred_dt = q.pred_dt[0];
+      q.u_fslot = q.frame_nr[0] % 3;
+      q.u_t_prev = q.t_prev[0];
+      q.u_valid = 1;
+    }
     WK_STAMP(11)  // association (Munkres)
     {
       int total = 0;
