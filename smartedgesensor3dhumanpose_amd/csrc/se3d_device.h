@@ -152,7 +152,8 @@ struct Se3dShardRec {
 #define SE3D_WALK_MAX_STEPS 64
 struct Se3dWalk {
   int n_steps;
-  int lds_state;               // set by the launcher: per-track state staged in LDS for the duration of the walk
+  int lds_state;               // set by the launcher: per-track state staged in LDS for the duration of the walk (bit 1: previous poses, bit 2: bookkeeping)
+  int book_offset;             // byte offset of the bookkeeping block in the dynamic LDS (lds_state & 4)
   int slot0[SE3D_WALK_MAX_STEPS];
   const double *t;             // [n_steps][t_stride] (device)
   int t_stride;

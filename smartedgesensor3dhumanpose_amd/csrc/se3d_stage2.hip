@@ -2328,13 +2328,45 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
     Qs.root_prev += g0 * 3; Qs.height_prev += g0; Qs.trk_t_prev += g0;
     Qs.has += g0; Qs.id += g0; Qs.num_obs += g0; Qs.used += g0;
   }
+  // (lds_state & 4, one-wavefront shape) the per-step bookkeeping too: cost matrix, merge-distance rows, track order, detection -> slot /
+  // publish tables and the per-sequence scalars.  In global memory each of them is a store -> fence -> load round trip to L2 between two
+  // phases of the same wavefront, a dozen per time step.
+  double *b_C = nullptr, *b_tprev = nullptr, *b_fb = nullptr;
+  unsigned long long *b_near = nullptr;
+  int32_t *b_order = nullptr, *b_detslot = nullptr, *b_ntr = nullptr, *b_nid = nullptr, *b_fnr = nullptr;
+  uint8_t *b_pub = nullptr;
+  if (Wk.lds_state & 4) {
+    unsigned char *base = s2_walk_smem + Wk.book_offset;
+    b_C = reinterpret_cast<double *>(base); base += (size_t)SQ * H * T * sizeof(double);
+    b_near = reinterpret_cast<unsigned long long *>(base); base += (size_t)TT * 4 * sizeof(unsigned long long);
+    b_tprev = reinterpret_cast<double *>(base); base += (size_t)SQ * sizeof(double);
+    b_fb = reinterpret_cast<double *>(base); base += (size_t)SQ * 3 * sizeof(double);
+    b_order = reinterpret_cast<int32_t *>(base); base += (size_t)TT * 4;
+    b_detslot = reinterpret_cast<int32_t *>(base); base += (size_t)SQ * H * 4;
+    b_ntr = reinterpret_cast<int32_t *>(base); base += (size_t)SQ * 4;
+    b_nid = reinterpret_cast<int32_t *>(base); base += (size_t)SQ * 4;
+    b_fnr = reinterpret_cast<int32_t *>(base); base += (size_t)SQ * 4;
+    b_pub = reinterpret_cast<uint8_t *>(base);
+    for (int i = tid; i < tn; i += NT) b_order[i] = Q.order[g0 + i];
+    for (int i = tid; i < ns; i += NT) {
+      b_ntr[i] = Q.n_tracks[sb + i]; b_nid[i] = Q.next_id[sb + i]; b_fnr[i] = Q.frame_nr[sb + i]; b_tprev[i] = Q.t_prev[sb + i];
+      for (int a = 0; a < 3; ++a) b_fb[i * 3 + a] = Q.fb_buf[(size_t)(sb + i) * 3 + a];
+    }
+    __syncthreads();
+  }
   // every per-sequence array is rebased to the first sequence of the workgroup: the phase bodies run with the local sequence index
   // the normalised previous pose (0.5 KB per track) and the velocity ring (1.5 KB), touched once per person and step, stay in HBM / L2;
   // the phases that compare against every track (cost, merge distance) read the de-normalised table `tpos` in LDS
   if (l_prev) Qs.prev = l_prev; else Qs.prev += g0 * SE3D_NFU * 3;
   Qs.vel += g0 * SE3D_NFU * 9;
-  Qs.fb_buf += (size_t)sb * 3; Qs.t_prev += sb; Qs.next_id += sb; Qs.frame_nr += sb; Qs.n_tracks += sb; Qs.order += g0;
-  Qs.C += (size_t)sb * H * T; Qs.W += (size_t)sb * H * T; Qs.near += g0 * 4; Qs.det_slot += (size_t)sb * H; Qs.pub += (size_t)sb * H;
+  if (Wk.lds_state & 4) {
+    Qs.fb_buf = b_fb; Qs.t_prev = b_tprev; Qs.next_id = b_nid; Qs.frame_nr = b_fnr; Qs.n_tracks = b_ntr; Qs.order = b_order;
+    Qs.C = b_C; Qs.near = b_near; Qs.det_slot = b_detslot; Qs.pub = b_pub;
+  } else {
+    Qs.fb_buf += (size_t)sb * 3; Qs.t_prev += sb; Qs.next_id += sb; Qs.frame_nr += sb; Qs.n_tracks += sb; Qs.order += g0;
+    Qs.C += (size_t)sb * H * T; Qs.near += g0 * 4; Qs.det_slot += (size_t)sb * H; Qs.pub += (size_t)sb * H;
+  }
+  Qs.W += (size_t)sb * H * T;
   Qs.fused_det += (size_t)sb * H; Qs.pred_det += (size_t)sb * H; Qs.iters_det += (size_t)sb * H; Qs.flags2 += sb;
   const bool par_assoc = WV > 1 && (size_t)H * T * sizeof(double) <= sizeof(WaveLds);  // each association wavefront has its own Munkres scratch
   for (int k = 0; k < Wk.n_steps; ++k) {
@@ -2453,6 +2485,14 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
     __syncthreads();
     WK_STAMP(14)  // publish + lifecycle
   }
+  if (Wk.lds_state & 4) {  // persistent bookkeeping back to global memory (C, near, det_slot, pub are per-step scratch)
+    __syncthreads();
+    for (int i = tid; i < tn; i += NT) Q.order[g0 + i] = b_order[i];
+    for (int i = tid; i < ns; i += NT) {
+      Q.n_tracks[sb + i] = b_ntr[i]; Q.next_id[sb + i] = b_nid[i]; Q.frame_nr[sb + i] = b_fnr[i]; Q.t_prev[sb + i] = b_tprev[i];
+      for (int a = 0; a < 3; ++a) Q.fb_buf[(size_t)(sb + i) * 3 + a] = b_fb[i * 3 + a];
+    }
+  }
   if (Wk.lds_state) {  // write the track state back
     if (l_prev)
       for (int i = tid; i < tn * SE3D_NFU * 3; i += NT) Q.prev[g0 * SE3D_NFU * 3 + i] = l_prev[i];
@@ -2480,7 +2520,16 @@ static bool s2_launch_walk_shape(const Se3dStage2 &q, const Se3dWalk &Wk, int ns
   // ... and the normalised previous poses (0.5 KB per track) when the one-wavefront shape still fits eight workgroups per CU with them
   const size_t prev_bytes = (size_t)SQ * q.T * SE3D_NFU * 3 * sizeof(double) + 8;
   if (WV == 1 && w.lds_state && work_bytes + state_bytes + prev_bytes <= 19 * 1024) w.lds_state |= 2;
-  const size_t dyn = work_bytes + (w.lds_state ? state_bytes : 0) + ((w.lds_state & 2) ? prev_bytes : 0);
+  size_t dyn = work_bytes + (w.lds_state ? state_bytes : 0) + ((w.lds_state & 2) ? prev_bytes : 0);
+  // ... and the per-step bookkeeping (cost matrix, merge rows, order, slot / publish tables, scalars) while eight workgroups still fit a CU
+  const size_t book_bytes = (size_t)SQ * q.H * q.T * 8 + (size_t)SQ * q.T * (32 + 4) + (size_t)SQ * (8 + 24 + 12) + (size_t)SQ * q.H * 5 + 32;
+  dyn = (dyn + 15) & ~(size_t)15;
+  const char *e_book = getenv("SE3D_WALK_BOOK");   // A/B switch (read per launch): 0 keeps the bookkeeping in global memory
+  if (WV == 1 && (w.lds_state & 2) && dyn + book_bytes <= 20 * 1024 && !(e_book && atoi(e_book) == 0)) {
+    w.lds_state |= 4;
+    w.book_offset = (int)dyn;
+    dyn += book_bytes;
+  }
   if (dyn > (size_t)lds_max) return false;
   hipLaunchKernelGGL((se3d_k_stage2_walk<TRIO, WV, SQ>), dim3((nseq + SQ - 1) / SQ), dim3(64 * WV), dyn, st, q, w, nseq);
   return true;
