@@ -610,7 +610,9 @@ def main():
 
     def run_secondary():
         nonlocal sec, hyp
-        sec = run_workload("256cam128p", seqs_sec, rig2, args, max(3, args.steps // 4), 2, dist, local_rank, True)
+        # steps: the four contexts take turns on the pair-cost kernel, so a timed region ends with a drain of ~100 ms (the last context's
+        # sweep / stage-2 chain) that K steps of ~260 ms have to carry: K = 10 by default
+        sec = run_workload("256cam128p", seqs_sec, rig2, args, max(5, args.steps // 2), 2, dist, local_rank, True)
         sec["value_per_gpu"] = sec["value"] / world
         if dist is not None:   # one 256cam128p stream, hypotheses sharded over the ranks (north_star config 5)
             hyp = run_hypothesis_shard("256cam128p", _gen_one((256, 128, T_, 0)), rig2, 2, dist, local_rank)
