@@ -308,6 +308,44 @@ def test_stage2_walk_is_deterministic_and_sequences_do_not_interact(extr_rig, mo
     assert sum(v[0] for v in outs[0].values()) > S_ * 3
 
 
+def test_stage2_walk_bookkeeping_in_lds_equals_global(extr_rig, monkeypatch):
+    """One-wavefront walk: the per-step bookkeeping (cost matrix, merge rows, order, slot / publish tables, per-sequence scalars) in LDS
+    (default when it fits) against the same tables in global memory (SE3D_WALK_BOOK=0): published persons, iteration counts, track counts and
+    flags byte for byte, over a ping-pong walk of sequences with appearing / vanishing persons; then the per-step kernels continue from the
+    state both left behind (order, n_tracks, next_id, frame_nr, t_prev, feedback buffer were written back)."""
+    monkeypatch.setenv("SE3D_WALK_SHAPE", "wave")
+    S_, T_ = 5, 12
+    seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=3 + (s % 4), n_frames=T_, seed=900 + s, p_miss=0.04 * (s % 3), low_score_frac=0.1))[0] for s in range(S_)]
+    frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
+    outs = []
+    for book in ("1", "0"):
+        monkeypatch.setenv("SE3D_WALK_BOOK", book)
+        node = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12)
+        node.stage(frames)
+        node.run_stage1()
+        node.refine_reset()
+        t = 100.0
+        res = []
+        for ks in (list(range(T_)), list(range(T_ - 1, -1, -1))):
+            ts = t + np.arange(1, T_ + 1) / 30.0
+            t = float(ts[-1])
+            node.run_stage2_walk(np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
+            for k in ks:
+                for r in node.fetch_stage2_walk(k * S_, S_):
+                    n = r.n_persons
+                    res.append((n, r.fused[:n].tobytes(), r.fused_pred[:n].tobytes(), r.lm_iterations[:n].tobytes(), r.c.n_tracks, r.c.flags))
+        monkeypatch.setenv("SE3D_WALK", "steps")   # continue with the per-step kernels from the written-back state
+        node.run_stage2(np.full(S_, t + 1 / 30.0), frame_slot0=0)
+        for r in node.fetch_stage2(S_):
+            n = r.n_persons
+            res.append((n, r.fused[:n].tobytes(), r.lm_iterations[:n].tobytes(), r.c.n_tracks))
+        monkeypatch.delenv("SE3D_WALK")
+        outs.append(res)
+        node.close()
+    assert outs[0] == outs[1]
+    assert sum(v[0] for v in outs[0]) > S_ * T_
+
+
 def test_stage2_walk_at_bench_size(extr_rig, oracle, demo_params, monkeypatch):
     """The bench.py shape of 16 cam x 6 persons: 256 sequences x 16 frames in one launch (the launcher picks the one-wavefront-per-sequence
     kernel from 256 sequences).  The distinct sequences are checked against the oracle step by step, every replica must be bitwise
