@@ -12,6 +12,7 @@ One "step" = one pass of the hot path over one batch of synthetic frames that ar
 
 The JSON line of a default run carries, next to the headline (16cam6p, the first configuration BASELINE.json's metric is quoted on):
   "secondary": the same measurement at 256cam128p (the second configuration of the metric),
+  "reprojection": the feedback reprojection of the serial pass's predicted skeletons: 16 384 frame slots per launch,
   "serial":    ONE context holding all sequences, kernels strictly one after the other on one stream — the per-kernel times that
                "roofline" is computed from (the kernels of the headline's contexts overlap by design; their durations are not
                per-kernel evidence),
@@ -121,7 +122,7 @@ def cpu_baseline(rig, seq, params, with_stage2, budget_s=12.0):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # one measurement: NC contexts x S sequences x T frames resident on this rank's GPU
 # ---------------------------------------------------------------------------------------------------------------------------------
-def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank, stage2, verify_exchange=True):
+def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank, stage2, verify_exchange=True, reproj=False):
     """seqs_per_ctx: list over contexts of lists of sequences.  Returns a dict (all ranks; `value` etc. are whole-job figures)."""
     import torch
     from smartedgesensor3dhumanpose_amd import person_msgs as pm
@@ -297,9 +298,51 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         "max_hyp_per_frame": int(max(r.n_hyp for r in s1)), "max_published_per_frame": int(max_pub[0]), "exchange_verified": exchange_ok,
         "lm_iterations_mean": float(np.mean(lm_iters)) if lm_iters else None, "params": node.params,
     }
+    if reproj and stage2 and fused_walk:
+        res["reprojection"] = bench_reprojection(node, rig, min(B, 16384))
     for nd_ in nodes:
         nd_.close()
     return res
+
+
+def bench_reprojection(node, rig, n_slots, launches=5):
+    """SURVEY 8f rank 1, measured: the feedback reprojection (pose_reprojection, REPROJ:139-235) of the predicted skeletons that the walk
+    left in HBM — n_slots frame slots per launch (se3d_reproject_resident_batch), every skeleton into every camera (7 sigma points per
+    joint, fp64), per-camera Person2D lists compacted on the device.  Throughput from `launches` back-to-back launches (host clock around
+    a stream synchronisation: the three kernels of a launch run for milliseconds); output volume from a sample of 64 slots; CPU: the
+    oracle's reprojection (kind 'port', single thread) of the same sample."""
+    from oracle import oracle_py as O
+    node.set_reprojection_cameras()
+    node.reproject_resident_batch(0, n_slots)   # allocates the batch buffers, warm-up
+    node.sync()
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        node.reproject_resident_batch(0, n_slots)
+    node.sync()
+    dt = (time.perf_counter() - t0) / launches
+    sample = list(range(0, n_slots, max(1, n_slots // 64)))[:64]
+    n_sk = n_out = 0
+    preds = []
+    for slot in sample:
+        r = node.fetch_stage2_walk(slot, 1)[0]
+        n_sk += r.n_persons
+        n_out += int(node.fetch_reprojection(slot).det_offset[-1])
+        preds.append(r.fused_pred[:r.n_persons].copy())
+    scale = n_slots / len(sample)
+    n_sk_launch, n_out_launch = n_sk * scale, n_out * scale
+    t1 = time.perf_counter()
+    for p in preds:
+        O.reproject(rig, "simple", p)
+    cpu_dt = time.perf_counter() - t1
+    from smartedgesensor3dhumanpose_amd import person_msgs as pm
+    bytes_launch = n_sk_launch * pm.person3d_dt.itemsize + n_out_launch * pm.person2d_dt.itemsize
+    return {"value": round(n_sk_launch / dt, 1), "unit": "skeletons/s reprojected into all %d cameras" % rig.n_cam, "ms_per_launch": round(dt * 1e3, 4),
+            "slots_per_launch": n_slots, "skeletons_per_launch": round(n_sk_launch), "projected_persons_per_launch": round(n_out_launch),
+            "roofline": {"bound": "hbm", "achieved": round(bytes_launch / dt / 1e9, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(bytes_launch / dt / 8e12, 5),
+                         "algorithmic_bytes": "1688 B per skeleton in + 428 B per (skeleton, camera that sees it) out",
+                         "flop_note": "fp64 VALU: ~0.5 kFLOP per (joint, camera); %.1f GFLOP/s" % (n_sk_launch * rig.n_cam * 17 * 500 / dt / 1e9)},
+            "cpu_baseline": {"value": round(n_sk / cpu_dt, 1) if cpu_dt > 0 else None, "unit": "skeletons/s", "cores": 1, "kind": "port",
+                             "sample": "%d skeletons of %d slots" % (n_sk, len(sample))}}
 
 
 def bench_dlt(args):
@@ -633,7 +676,7 @@ def main():
     if (args.serial or (default_run and not args.no_serial)) and rank == 0:
         all_seqs = [s for ctx_seqs in seqs_head for s in ctx_seqs]
         serial = run_workload(headline, [all_seqs], rig, args, args.steps if args.serial else max(3, args.steps // 4), args.warmup if args.serial else 1,
-                              None, local_rank, stage2)
+                              None, local_rank, stage2, reproj=True)
         serial["value_per_gpu"] = serial["value"]
     seqs_stream = seqs_head[: max(1, min(args.stream_contexts, NC))]
     del seqs_head
@@ -679,6 +722,8 @@ def main():
         if serial is not None and head is not None:
             line["serial"] = {"value": round(serial["value"], 2), "ms_per_step": round(serial["ms_per_step"], 4), "steps": serial["steps"],
                               "sequences": serial["S"], "n_gpus": 1}
+        if serial is not None and serial.get("reprojection"):
+            line["reprojection"] = serial["reprojection"]   # the stage after the path, on the serial pass's resident results
         if streaming is not None:
             line["value_streaming"] = round(streaming["value"], 2)
             line["streaming"] = {"value": round(streaming["value"], 2), "unit": "skeletons/s", "fraction_of_resident": round(streaming["value"] / main_res["value_per_gpu"], 4),

@@ -241,6 +241,11 @@ int se3d_reproject(se3d_ctx *ctx, int32_t n_persons, const se3d_person3d *person
  * reprojection.  `slot` selects the result: the sequence index after se3d_run_stage2 / se3d_refine, the FRAME slot (frame_slot0[k] + s)
  * after se3d_run_stage2_walk, whose results are kept per frame slot.  out == NULL: launch only (asynchronous). */
 int se3d_reproject_resident(se3d_ctx *ctx, int32_t slot, se3d_reproj_out *out);
+/* The reprojection of a replayed batch: result slots slot0 .. slot0 + n_slots - 1 (frame slots after se3d_run_stage2_walk) in ONE launch —
+ * n_slots x fusedSkeletonCallback (REPROJ:139-235).  Asynchronous; the per-camera lists stay on the device, se3d_fetch_reprojection copies
+ * the lists of one slot of the last batch out (same layout as se3d_reproject). */
+int se3d_reproject_resident_batch(se3d_ctx *ctx, int32_t slot0, int32_t n_slots);
+int se3d_fetch_reprojection(se3d_ctx *ctx, int32_t slot, se3d_reproj_out *out);
 
 /* --- row M as a stand-alone entry: drop-in for HungarianAlgorithm::assignmentoptimal (Hungarian.cpp:60) on the GPU.
  * dist is column-major [row + n_rows*col] (host memory), n_rows, n_cols <= 256; assignment[row] = col or -1. */

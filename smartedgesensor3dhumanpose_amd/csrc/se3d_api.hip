@@ -112,6 +112,8 @@ struct se3d_ctx {
   se3d_person3d *d_rp_in = nullptr;
   int32_t *h_rp_off = nullptr;
   bool rp_ready = false;
+  Se3dReproj RB{};          // batch buffers of se3d_reproject_resident_batch (one block of every output array per result slot)
+  int rpb_cap = 0, rpb_slot0 = 0, rpb_n = 0;
 };
 
 namespace {
@@ -436,6 +438,7 @@ void se3d_destroy(se3d_ctx *c) {
   if (c->h_flags2) (void)hipHostFree(c->h_flags2);
   if (c->h_preddt) (void)hipHostFree(c->h_preddt);
   if (c->h_rp_off) (void)hipHostFree(c->h_rp_off);
+  if (c->RB.dense) { (void)hipFree(c->RB.dense); (void)hipFree(c->RB.valid); (void)hipFree(c->RB.slot); (void)hipFree(c->RB.det_offset); (void)hipFree(c->RB.out); (void)hipFree(c->RB.out_src); }
   for (auto &sl : c->ss) {
     if (sl.h_rag) (void)hipHostFree(sl.h_rag);
     if (sl.h_off) (void)hipHostFree(sl.h_off);
@@ -1101,6 +1104,57 @@ int se3d_reproject_resident(se3d_ctx *c, int32_t slot, se3d_reproj_out *out) {
   if (!out) return SE3D_OK;  // asynchronous: result stays on the device (timing / chaining)
   if (!out->det_offset || (out->capacity > 0 && !out->persons)) return SE3D_ERR_ARG;
   return reproject_fetch(c, out);
+}
+
+// All result slots slot0 .. slot0 + n_slots - 1 of the resident stage-2 results in ONE launch (the reprojection of a replayed batch: one
+// list of predicted skeletons per frame slot -> N per-camera Person2D lists per slot).  Results stay on the device; se3d_fetch_reprojection
+// copies one slot's lists out.
+int se3d_reproject_resident_batch(se3d_ctx *c, int32_t slot0, int32_t n_slots) {
+  if (!c || slot0 < 0 || n_slots < 1 || slot0 + n_slots > c->Q.S) return SE3D_ERR_ARG;
+  if (!c->rp_ready) { c->err = "se3d_reproject_resident_batch: se3d_set_reprojection_cameras was not called"; return SE3D_ERR_STATE; }
+  if (!c->ran2) { c->err = "se3d_reproject_resident_batch: no stage-2 result"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nt = (size_t)c->R.N * c->R.T;
+  if (n_slots > c->rpb_cap) {   // batch buffers: one block of every output array per slot
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->RB.dense) { (void)hipFree(c->RB.dense); (void)hipFree(c->RB.valid); (void)hipFree(c->RB.slot); (void)hipFree(c->RB.det_offset); (void)hipFree(c->RB.out); (void)hipFree(c->RB.out_src); }
+    c->RB = c->R;
+    c->RB.dense = nullptr; c->rpb_cap = 0;
+    if (hipMalloc(reinterpret_cast<void **>(&c->RB.dense), sizeof(se3d_person2d) * nt * n_slots) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->RB.valid), nt * n_slots) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->RB.slot), sizeof(int32_t) * nt * n_slots) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->RB.det_offset), sizeof(int32_t) * (size_t)(c->R.N + 1) * n_slots) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->RB.out), sizeof(se3d_person2d) * nt * n_slots) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->RB.out_src), sizeof(int32_t) * nt * n_slots) != hipSuccess) {
+      c->err = "se3d_reproject_resident_batch: out of device memory";
+      return SE3D_ERR_DEVICE;
+    }
+    c->rpb_cap = n_slots;
+  }
+  Se3dReproj R = c->RB;
+  R.cam = c->R.cam; R.wh = c->R.wh; R.N = c->R.N; R.T = c->R.T; R.pose_method = c->R.pose_method;
+  R.in = c->Q.pred + (size_t)slot0 * c->Q.H; R.in_stride = c->Q.H; R.n = 0; R.n_dev = c->Q.n_out + slot0;
+  c->rpb_slot0 = slot0; c->rpb_n = n_slots;
+  HIPCHK(c, se3d_launch_reproject(R, c->Q.H, c->stream, n_slots));
+  return SE3D_OK;
+}
+
+int se3d_fetch_reprojection(se3d_ctx *c, int32_t slot, se3d_reproj_out *out) {
+  if (!c || !out || !out->det_offset || (out->capacity > 0 && !out->persons)) return SE3D_ERR_ARG;
+  if (c->rpb_n < 1 || slot < c->rpb_slot0 || slot >= c->rpb_slot0 + c->rpb_n) { c->err = "se3d_fetch_reprojection: slot not in the last batch"; return SE3D_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int N = c->R.N, b = slot - c->rpb_slot0;
+  const size_t nt = (size_t)N * c->R.T;
+  HIPCHK(c, hipMemcpyAsync(c->h_rp_off, c->RB.det_offset + (size_t)b * (N + 1), sizeof(int32_t) * (N + 1), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(out->det_offset, c->h_rp_off, sizeof(int32_t) * (N + 1));
+  const int tot = c->h_rp_off[N];
+  if (tot > out->capacity) { c->err = "se3d_fetch_reprojection: output capacity too small"; return SE3D_ERR_CAPACITY; }
+  if (tot > 0) {
+    HIPCHK(c, hipMemcpy(out->persons, c->RB.out + b * nt, sizeof(se3d_person2d) * (size_t)tot, hipMemcpyDeviceToHost));
+    if (out->person_index) HIPCHK(c, hipMemcpy(out->person_index, c->RB.out_src + b * nt, sizeof(int32_t) * (size_t)tot, hipMemcpyDeviceToHost));
+  }
+  return SE3D_OK;
 }
 
 int se3d_profile_enable(se3d_ctx *c, int32_t on) {

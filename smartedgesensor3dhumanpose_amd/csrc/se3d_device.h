@@ -171,6 +171,8 @@ struct Se3dWalk {
 // ---------------------------------------------------------------------------------------------------------------
 struct Se3dReproj {
   int N, T, n, pose_method;
+  int in_stride;              // batched launch (grid.z = result slot b): persons of slot b at in + b * in_stride, count n_dev[b]; every output
+                              // array below holds one block per slot (dense / valid / slot / out / out_src: N * T entries, det_offset: N + 1)
   const int32_t *n_dev;       // optional device-side person count (resident chaining after stage 2); overrides n
   const double *cam;          // [N][16]: rows of the 3x4 base->camera transform (12), then fx, fy, cx, cy
   const int32_t *wh;          // [N][2] image width, height
@@ -182,4 +184,4 @@ struct Se3dReproj {
   se3d_person2d *out;         // [N*T] compacted, camera-major, person order preserved (REPROJ:226-233)
   int32_t *out_src;           // [N*T] input person index of each output entry
 };
-hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t stream);
+hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t stream, int batch = 1);

@@ -11,20 +11,33 @@ namespace {
 
 constexpr int kCamsPerBlock = 8;  // 8 half-waves of 32 lanes
 
-__global__ __launch_bounds__(256) void se3d_k_reproject(Se3dReproj R) {
+// Result slot b = blockIdx.z of a batched launch (se3d_reproject_resident_batch: every frame slot of a resident walk in one launch): inputs and
+// outputs of slot b are the b-th blocks of the descriptor's arrays.  A single-list call is the batch of one.
+__device__ __forceinline__ Se3dReproj se3d_reproj_slot(Se3dReproj R, int b) {
+  const size_t nt = (size_t)R.N * R.T;
+  R.in += (size_t)b * R.in_stride;
+  if (R.n_dev) R.n_dev += b;
+  R.dense += b * nt; R.valid += b * nt; R.slot += b * nt; R.out += b * nt; R.out_src += b * nt;
+  R.det_offset += (size_t)b * (R.N + 1);
+  return R;
+}
+
+__global__ __launch_bounds__(256) void se3d_k_reproject(Se3dReproj Rb) {
+  const Se3dReproj R = se3d_reproj_slot(Rb, blockIdx.z);
   const int lane = threadIdx.x & 31;
   const int cam = blockIdx.x * kCamsPerBlock + (threadIdx.x >> 5);
   const int person = blockIdx.y;
   const int n = R.n_dev ? *R.n_dev : R.n;
-  if (person >= n || cam >= R.N) return;
-  const int W = R.wh[2 * cam], Hh = R.wh[2 * cam + 1];
-  bool valid = false;
-  double mx = 0., my = 0., cxx = 0., cxy = 0., cyy = 0.;
-  float score = 0.f;
-  if (lane < SE3D_NKP) {
-    const se3d_keypoint3d &kp = R.in[person].keypoints[c_kp2fusion[R.pose_method][lane]];
-    score = kp.score;
-    if (score > 0.f) {  // REPROJ:167-168
+  if (person >= n) return;   // block-uniform
+  // The sigma points of a joint depend on the person only (REPROJ:62-75: cov.llt(), +- sqrt(3 + kappa) L columns): the first half-wave draws them
+  // once per block into LDS and the eight (person, camera) half-waves of the block project them — round 1 redid the 3x3 Cholesky
+  // (3 square roots, 3 divisions in fp64) for every camera.
+  __shared__ double s_X[SE3D_NKP][7][3];
+  __shared__ float s_score[SE3D_NKP];
+  if (threadIdx.x < SE3D_NKP) {
+    const se3d_keypoint3d &kp = R.in[person].keypoints[c_kp2fusion[R.pose_method][threadIdx.x]];
+    s_score[threadIdx.x] = kp.score;
+    if (kp.score > 0.f) {  // REPROJ:167-168
       // cov.llt().matrixL() (REPROJ:70)
       const double c00 = kp.cov[0], c10 = kp.cov[1], c20 = kp.cov[2], c11 = kp.cov[3], c21 = kp.cov[4], c22 = kp.cov[5];
       const double l00 = sqrt(c00);
@@ -33,24 +46,33 @@ __global__ __launch_bounds__(256) void se3d_k_reproject(Se3dReproj R) {
       const double l21 = (c21 - l20 * l10) / l11;
       const double l22 = sqrt(c22 - l20 * l20 - l21 * l21);
       const double L[3][3] = {{l00, 0., 0.}, {l10, l11, 0.}, {l20, l21, l22}};
-      const double kappa = 0.5;
-      const double b = sqrt(3.0 + kappa);
-      const double w = 1.0 / (2.0 * (3.0 + kappa));  // weights(0) = 2 kappa / (2 (DIM + kappa)) equals the others for kappa = 0.5
+      const double b = sqrt(3.0 + 0.5);   // kappa = 0.5
+#pragma unroll
+      for (int s = 0; s < 7; ++s)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+          s_X[threadIdx.x][s][a] = s == 0 ? kp.joint[a] : (s < 4 ? L[a][s - 1] * (-b) + kp.joint[a] : L[a][s - 4] * b + kp.joint[a]);
+    }
+  }
+  __syncthreads();
+  if (cam >= R.N) return;
+  const int W = R.wh[2 * cam], Hh = R.wh[2 * cam + 1];
+  bool valid = false;
+  double mx = 0., my = 0., cxx = 0., cxy = 0., cyy = 0.;
+  float score = 0.f;
+  if (lane < SE3D_NKP) {
+    score = s_score[lane];
+    if (score > 0.f) {
+      const double w = 1.0 / (2.0 * (3.0 + 0.5));  // weights(0) = 2 kappa / (2 (DIM + kappa)) equals the others for kappa = 0.5
       const double *M = R.cam + 16 * (size_t)cam;
       const double fx = M[12], fy = M[13], pcx = M[14], pcy = M[15];
       double px[7], py[7];
 #pragma unroll
       for (int s = 0; s < 7; ++s) {
-        double X[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          if (s == 0) X[a] = kp.joint[a];
-          else if (s < 4) X[a] = L[a][s - 1] * (-b) + kp.joint[a];
-          else X[a] = L[a][s - 4] * b + kp.joint[a];
-        }
-        const double xc = (M[0] * X[0] + M[1] * X[1] + M[2] * X[2]) + M[3];
-        const double yc = (M[4] * X[0] + M[5] * X[1] + M[6] * X[2]) + M[7];
-        const double zc = (M[8] * X[0] + M[9] * X[1] + M[10] * X[2]) + M[11];
+        const double X0 = s_X[lane][s][0], X1 = s_X[lane][s][1], X2 = s_X[lane][s][2];
+        const double xc = (M[0] * X0 + M[1] * X1 + M[2] * X2) + M[3];
+        const double yc = (M[4] * X0 + M[5] * X1 + M[6] * X2) + M[7];
+        const double zc = (M[8] * X0 + M[9] * X1 + M[10] * X2) + M[11];
         px[s] = (fx * xc) / zc + pcx;  // project3dToPixel (REPROJ:186)
         py[s] = (fy * yc) / zc + pcy;
       }
@@ -93,7 +115,8 @@ __global__ __launch_bounds__(256) void se3d_k_reproject(Se3dReproj R) {
 }
 
 // one block, thread c = camera c: per-camera counts -> exclusive offsets -> output slot of every (person, camera)
-__global__ __launch_bounds__(256) void se3d_k_reproj_scan(Se3dReproj R) {
+__global__ __launch_bounds__(256) void se3d_k_reproj_scan(Se3dReproj Rb) {
+  const Se3dReproj R = se3d_reproj_slot(Rb, blockIdx.z);
   __shared__ int s_cnt[256];
   const int c = threadIdx.x;
   const int n = R.n_dev ? *R.n_dev : R.n;
@@ -121,7 +144,8 @@ __global__ __launch_bounds__(256) void se3d_k_reproj_scan(Se3dReproj R) {
 }
 
 // grid (ceil(N/2), n): 128 threads per (person, camera) copy the 107 dwords of a valid projected person to its list slot
-__global__ __launch_bounds__(256) void se3d_k_reproj_compact(Se3dReproj R) {
+__global__ __launch_bounds__(256) void se3d_k_reproj_compact(Se3dReproj Rb) {
+  const Se3dReproj R = se3d_reproj_slot(Rb, blockIdx.z);
   const int cam = blockIdx.x * 2 + (threadIdx.x >> 7);
   const int person = blockIdx.y;
   const int t = threadIdx.x & 127;
@@ -138,12 +162,12 @@ __global__ __launch_bounds__(256) void se3d_k_reproj_compact(Se3dReproj R) {
 
 }  // namespace
 
-hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t stream) {
-  if (n_grid <= 0) {
-    return hipMemsetAsync(R.det_offset, 0, sizeof(int32_t) * (R.N + 1), stream);
+hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t stream, int batch) {
+  if (n_grid <= 0 || batch <= 0) {
+    return hipMemsetAsync(R.det_offset, 0, sizeof(int32_t) * (R.N + 1) * (size_t)(batch > 0 ? batch : 1), stream);
   }
-  hipLaunchKernelGGL(se3d_k_reproject, dim3((R.N + kCamsPerBlock - 1) / kCamsPerBlock, n_grid), dim3(256), 0, stream, R);
-  hipLaunchKernelGGL(se3d_k_reproj_scan, dim3(1), dim3(256), 0, stream, R);
-  hipLaunchKernelGGL(se3d_k_reproj_compact, dim3((R.N + 1) / 2, n_grid), dim3(256), 0, stream, R);
+  hipLaunchKernelGGL(se3d_k_reproject, dim3((R.N + kCamsPerBlock - 1) / kCamsPerBlock, n_grid, batch), dim3(256), 0, stream, R);
+  hipLaunchKernelGGL(se3d_k_reproj_scan, dim3(1, 1, batch), dim3(256), 0, stream, R);
+  hipLaunchKernelGGL(se3d_k_reproj_compact, dim3((R.N + 1) / 2, n_grid, batch), dim3(256), 0, stream, R);
   return hipGetLastError();
 }

@@ -245,6 +245,15 @@ class Skeleton3D:
         self._chk(self._L.se3d_reproject_resident(C.c_void_p(self._h), int(seq), C.byref(res.c)), "se3d_reproject_resident")
         return res
 
+    def reproject_resident_batch(self, slot0, n_slots):
+        """All result slots of a resident walk in one launch (asynchronous); fetch_reprojection(slot) returns one slot's lists."""
+        self._chk(self._L.se3d_reproject_resident_batch(C.c_void_p(self._h), int(slot0), int(n_slots)), "se3d_reproject_resident_batch")
+
+    def fetch_reprojection(self, slot):
+        res = pm.ReprojResult(self.rig.n_cam, self.rig.n_cam * self.limits.max_hyp)
+        self._chk(self._L.se3d_fetch_reprojection(C.c_void_p(self._h), int(slot), C.byref(res.c)), "se3d_fetch_reprojection")
+        return res
+
     def profile(self, on=True):
         self._chk(self._L.se3d_profile_enable(C.c_void_p(self._h), int(on)), "se3d_profile_enable")
 

@@ -95,6 +95,44 @@ def test_reproject_resident_after_stage2(oracle):
     node.close()
 
 
+def test_reproject_resident_batch_after_walk(oracle):
+    """The reprojection of a replayed batch in ONE launch (se3d_reproject_resident_batch over every frame slot of a resident walk): every
+    slot's per-camera lists equal the single-slot entry byte for byte and the oracle's reprojection of the predicted skeletons of that
+    slot; slots without published persons give empty lists."""
+    rig = extr_rig_16cam()
+    S_, T_ = 3, 14
+    seqs = [generate_sequence(rig, SceneConfig(n_persons=3 + s, n_frames=T_, seed=40 + s))[0] for s in range(S_)]
+    frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
+    node = Skeleton3D(rig, pose_method="simple", max_epi_dist=0.045, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12)
+    node.set_reprojection_cameras()
+    node.stage(frames)
+    node.run_stage1()
+    node.refine_reset()
+    ts = [100.0 + (i + 1) / 30.0 for i in range(T_)]
+    node.run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in range(T_)])
+    node.reproject_resident_batch(0, S_ * T_)
+    n_checked = n_empty = 0
+    for slot in range(S_ * T_):
+        got = node.fetch_reprojection(slot)
+        fused = node.fetch_stage2_walk(slot, 1)[0]
+        pred = fused.fused_pred[:fused.n_persons]
+        ref = oracle.reproject(rig, "simple", pred)
+        if fused.n_persons == 0:
+            assert got.det_offset[-1] == 0
+            n_empty += 1
+            continue
+        n_checked += compare(got, ref, rig.n_cam)
+    assert n_checked > 200 and n_empty >= S_ * 10    # nothing is published before a track's 11th observation
+    for slot in (S_ * T_ - 1, S_ * (T_ - 2) + 1):    # single-slot entry: same bytes
+        one = node.reproject_resident(slot)
+        node.reproject_resident_batch(S_ * (T_ - 3), 3 * S_)   # a sub-range that contains the slot
+        got = node.fetch_reprojection(slot)
+        n = int(one.det_offset[-1])
+        assert np.array_equal(one.det_offset, got.det_offset) and n > 0
+        assert one.persons[:n].tobytes() == got.persons[:n].tobytes() and np.array_equal(one.person_index[:n], got.person_index[:n])
+    node.close()
+
+
 def test_reproject_large_rig(oracle):
     rig = elliptical_rig(64, seed=2)
     node = Skeleton3D(rig, max_det_per_cam=8, max_hyp=128)
