@@ -13,7 +13,7 @@ with open(out_csv, "w") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "percent"])
     for r in rows:
-        name = r["Name"].replace("void ", "").split("(")[0]
+        name = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         w.writerow([name, r["Calls"], round(float(r["TotalDurationNs"]) / 1e6, 3), round(float(r["AverageNs"]) / 1e3, 2),
                     round(float(r["MinNs"]) / 1e3, 2), round(float(r["MaxNs"]) / 1e3, 2), r["Percentage"]])
 print(open(out_csv).read())

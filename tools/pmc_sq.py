@@ -27,7 +27,7 @@ NAMES = {"se3d_k_normalize": "normalize", "se3d_k_normalize_pairs": "normalize_p
 
 
 def short(name):
-    n = name.replace("void ", "").split("(")[0].split("<")[0]
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
     return NAMES.get(n, n)
 
 
