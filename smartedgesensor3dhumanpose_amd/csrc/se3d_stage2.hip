@@ -1487,6 +1487,11 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
         height = sqrt(dx * dx + dy * dy + dz * dz);
       } else height = 0.60;
     }
+    // 1 / height and 1 / height^2 once: the branches below scale nine covariance entries and three coordinates each, and a wavefront runs
+    // all three branches (hip, neck, other lanes) — 42 fp64 IEEE divisions (~40 instructions each) per pass, a fifth of the walk's
+    // instructions, on the critical path of every LM set-up.  The products differ from the reference's quotients by <= 1 ulp of a double
+    // (exactly equal when heights are not normalised: height = 1); the trio LM is compared with the per-step kernels at 1e-9 m anyway.
+    const double ih = 1.0 / height, ih2 = 1.0 / (height * height);
     const bool first = hp_old < 0.0;  // PP:699-702
     hprev = first ? height : hp_old;
     for (int a = 0; a < 3; ++a) rprev[a] = first ? root[a] : rp_old[a];
@@ -1502,7 +1507,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
           s2_cov6_to_mat(cb6, cr);
           for (int q = 0; q < 9; ++q) cov[q] = (cl[q] + cr[q]) / 2.0;
         }
-        for (int q = 0; q < 9; ++q) cov[q] = cov[q] / (height * height) / (100.0 * 100.0);
+        for (int q = 0; q < 9; ++q) cov[q] = cov[q] * ih2 * (1.0 / (100.0 * 100.0));
         kscore = root_score;
       }
     } else if (neck_lane && neck_score > 0.10f) {
@@ -1510,15 +1515,15 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
       double cl[9], cr[9];
       s2_cov6_to_mat(ca6, cl);
       s2_cov6_to_mat(cb6, cr);
-      for (int q = 0; q < 9; ++q) cov[q] = (cl[q] + cr[q]) / 2.0 / (height * height);
-      for (int a = 0; a < 3; ++a) m[a] = (neck[a] - root[a]) / height;
+      for (int q = 0; q < 9; ++q) cov[q] = (cl[q] + cr[q]) / 2.0 * ih2;
+      for (int a = 0; a < 3; ++a) m[a] = (neck[a] - root[a]) * ih;
       kscore = neck_score;
     } else if (so > 0.10f) {
       measured = true;
       double c9[9];
       s2_cov6_to_mat(co6, c9);
-      for (int q = 0; q < 9; ++q) cov[q] = c9[q] / (height * height);
-      for (int a = 0; a < 3; ++a) m[a] = (jo[a] - root[a]) / height;
+      for (int q = 0; q < 9; ++q) cov[q] = c9[q] * ih2;
+      for (int a = 0; a < 3; ++a) m[a] = (jo[a] - root[a]) * ih;
       kscore = so;
     }
   }
@@ -1868,12 +1873,13 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
         const double pv[3] = {x0[0] * hprev + rprev[0], x0[1] * hprev + rprev[1], x0[2] * hprev + rprev[2]};
         double vk[9];
         for (int a = 0; a < 9; ++a) vk[a] = velk[a];
+        const double idt = 1.0 / (t - gtprev);   // one division for the three velocity components (<= 1 ulp from the three quotients)
         for (int a = 0; a < 3; ++a) {
-          const double vnew = (jf[a] - pv[a]) / (t - gtprev);
+          const double vnew = (jf[a] - pv[a]) * idt;
           velk[fslot * 3 + a] = vnew;
           vk[0 * 3 + a] = fslot == 0 ? vnew : vk[0 * 3 + a]; vk[1 * 3 + a] = fslot == 1 ? vnew : vk[1 * 3 + a]; vk[2 * 3 + a] = fslot == 2 ? vnew : vk[2 * 3 + a];
           const double acc = ((0.0 + vk[0 * 3 + a]) + vk[1 * 3 + a]) + vk[2 * 3 + a];
-          jp[a] += acc / 3.0 * pred_dt;
+          jp[a] += acc * (1.0 / 3.0) * pred_dt;
         }
       }
       for (int a = 0; a < 3; ++a) kpred.joint[a] = jp[a];
