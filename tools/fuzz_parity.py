@@ -48,13 +48,14 @@ for trial in range(trials):
     node.refine_reset()
     r1 = node.fetch_stage1(S_ * T_)
     for fi, fr in enumerate(frames):
-        g, o = r1[fi], O.triangulate(rig, params, fr, capacity=mh, hyp_capacity=mh)
+        g, o = r1[fi], O.triangulate(rig, params, fr, capacity=4 * mh, hyp_capacity=4 * mh)   # the oracle with room to spare
         tally["frames"] += 1
         # ---- index results: exact or abort ----
-        assert g.flags == o.flags, ("flags", trial, fi, g.flags, o.flags)
-        if g.flags & pm.FLAG_HYP_OVERFLOW:   # more hypotheses than max_hyp: truncated by contract on both sides (the oracle reports the uncapped count)
+        if g.flags & pm.FLAG_HYP_OVERFLOW:   # more hypotheses than max_hyp: the kernels truncate and say so; the oracle must indeed have needed more
+            assert o.n_hyp > mh, ("overflow flag without overflow", trial, fi, o.n_hyp)
             tally["frames_hyp_overflow"] += 1
             continue
+        assert g.flags == o.flags and o.n_hyp <= mh, ("flags", trial, fi, g.flags, o.flags, o.n_hyp)
         assert g.n_hyp == o.n_hyp, ("hypotheses", trial, fi, g.n_hyp, o.n_hyp)
         assert np.array_equal(g.assoc(), o.assoc()), ("association table", trial, fi)
         assert g.n_persons == o.n_persons and np.array_equal(g.person_hyp[:g.n_persons], o.person_hyp[:g.n_persons]), ("published persons", trial, fi)
@@ -108,6 +109,7 @@ for trial in range(trials):
                 msg = str(e)
                 if "mm" in msg or "cov" in msg or "marg" in msg or msg == "":
                     tally["stage2_numeric_failures"] += 1   # tolerance, not an index
+                    print("stage-2 numeric: trial", trial, "step", k, "seq", s, msg[:160], file=sys.stderr, flush=True)
                 else:
                     # An index differs.  The one case analysed so far (seed 4, trial 2): a person whose eye and ear were
                     # triangulated 400 m away (no hip pair -> no root-distance filter) and hang on the body by the ear-shoulder bone: the LM
