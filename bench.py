@@ -571,7 +571,7 @@ def valu_of(res, w, stage2, pmc):
                    "kernels issue more (IEEE-exact divides, fp64 null-vector solves).  Stage 2 is not in `achieved`: SURVEY counts it as dense 63x63 normal "
                    "equations (0.74 MFLOP per LM iteration), which the forest elimination never forms (DESIGN 3.1)"}
     if pmc:   # committed SQ counter pass (tools/profile_r2.sh, tools/pmc_sq.py): VALU wave-instructions x 2 issue cycles / (1024 SIMDs x kernel cycles)
-        ks = [k for k in pmc["kernels"].values() if "SQ_INSTS_VALU" in k["counters_per_launch"]]
+        ks = [k for n_, k in pmc["kernels"].items() if "SQ_INSTS_VALU" in k["counters_per_launch"] and "reproj" not in n_]   # the step: stage 1 + stage 2
         cyc = sum(k["kernel_cycles"] * k["launches"] for k in ks)
         if cyc > 0:
             out["measured_valu_issue_utilisation"] = round(sum(k["counters_per_launch"]["SQ_INSTS_VALU"] * k["launches"] for k in ks) * 2.0 / (1024.0 * cyc), 4)

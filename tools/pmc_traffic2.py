@@ -18,7 +18,7 @@ def short(name, _n={}):
     if not _n:
         src = open(spec.origin).read()
         _n.update(eval(src[src.index("NAMES = {") + 8: src.index("}", src.index("NAMES = {")) + 1]))
-    n = name.replace("void ", "").split("(")[0].split("<")[0]
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
     return _n.get(n, n)
 
 
@@ -46,7 +46,8 @@ for k in sorted(set(ft) | set(wt)):
     f = ft[k] / max(fc.get(k, 1), 1)
     w_ = wt[k] / max(wc.get(k, 1), 1)
     b = int((2 * f + w_) * 1024)
-    total += b
+    if "reproj" not in k:   # the feedback reprojection follows the path; `pipeline` = one step of stage 1 + stage 2
+        total += b
     res["kernels"][k] = {"fetch_size_kb_per_launch": round(f, 1), "write_size_kb_per_launch": round(w_, 1), "launches_sampled": int(fc.get(k, 0)),
                          "hbm_bytes_per_launch_corrected": b}
 res["pipeline_bytes_per_step_corrected"] = total
