@@ -256,6 +256,11 @@ int se3d_hungarian(se3d_ctx *ctx, int32_t *assignment, double *cost, const doubl
  * S3D:353-368) in FILTERED detection slots, -1 where no joint is shared; n_a/n_b receive the valid slot counts. */
 int se3d_get_pair_costs(se3d_ctx *ctx, int32_t frame, int32_t cam_a, int32_t cam_b, double *out, int32_t *n_a, int32_t *n_b);
 
+/* --- diagnostic self-test: the pair-cost kernels form sqrtf(x) and a / b of calcCost (S3D:358-361) with the arithmetic cores of the IEEE
+ * sequences (no operand scaling / fix-up) inside [2^-60, 2^60]; this runs both against the device's IEEE results — the square root on every
+ * float of the range, the quotient on n_div pseudo-random operand pairs — and returns the mismatch counts (expected: 0, 0). */
+int se3d_selftest_exact_math(se3d_ctx *ctx, uint64_t n_div, uint64_t *sqrt_mismatches, uint64_t *div_mismatches);
+
 /* --- device-side result access for multi-GPU exchange (RCCL all-gather of final skeletons) -------------
  * Enqueue, on the context stream, device-to-device copies of the results of the last run into caller-provided DEVICE
  * memory (e.g. torch tensors): persons as [n][max_hyp] se3d_person3d (valid entries first) and counts as [n] int32,

@@ -1157,6 +1157,23 @@ int se3d_fetch_reprojection(se3d_ctx *c, int32_t slot, se3d_reproj_out *out) {
   return SE3D_OK;
 }
 
+// Diagnostic: the instruction-level square root / quotient of the pair-cost kernels against the IEEE expressions, on this device.
+extern "C" hipError_t se3d_launch_selftest_exact_math(unsigned long long *d_out, unsigned long long n_div, hipStream_t st);
+int se3d_selftest_exact_math(se3d_ctx *c, uint64_t n_div, uint64_t *sqrt_mismatches, uint64_t *div_mismatches) {
+  if (!c || !sqrt_mismatches || !div_mismatches) return SE3D_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  unsigned long long *d = nullptr, h[2] = {0, 0};
+  HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d), sizeof(h)));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(h), c->stream);
+  if (e == hipSuccess) e = se3d_launch_selftest_exact_math(d, (unsigned long long)n_div, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  HIPCHK(c, e);
+  *sqrt_mismatches = h[0]; *div_mismatches = h[1];
+  return SE3D_OK;
+}
+
 int se3d_profile_enable(se3d_ctx *c, int32_t on) {
   if (!c) return SE3D_ERR_ARG;
   collect_profile(c);

@@ -109,6 +109,47 @@ __global__ __launch_bounds__(256) void se3d_k_normalize(Se3dDev D, int write_kp)
   if (tid == 0) D.nvalid[f * N + c] = s_nvalid;
 }
 
+// ---- correctly rounded float32 square root and quotient without the special-case scaffolding -------------------------------------------------
+// sqrtf(x) and a / b compile to the IEEE sequences of the AMDGPU back end: v_sqrt_f32 + a one-ulp correction from two FMA residuals, and
+// v_rcp_f32 + six FMA / multiply refinements — wrapped in operand scaling (v_div_scale_f32, x * 2^32), v_div_fmas / v_div_fixup and class
+// tests for denormal, huge, zero and infinite operands: 16 and ~14 instructions where the arithmetic core is 9 and 8.  The pair cost needs
+// two of each per (entry, joint) — 60 of its ~105 instructions.  The cores below are the SAME operation sequences, so inside the operand
+// range in which the scaffolding is the identity (se3d_pair_ops_in_range: everything within [2^-60, 2^60], numerators also zero) they return
+// the same bits; outside it the caller takes the IEEE expressions.  se3d_selftest_exact_math (C-ABI, tests/test_gpu_stage1.py) checks the
+// square root on EVERY float of the range and the quotient on 2^33 operand pairs against sqrtf / operator/ on the device.
+__device__ __forceinline__ float se3d_sqrt_core(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1), su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+  const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+  s = rd <= 0.f ? sd : s;
+  s = ru > 0.f ? su : s;
+  return s;
+}
+__device__ __forceinline__ float se3d_div_core(float a, float b) {
+  const float r0 = __builtin_amdgcn_rcpf(b);
+  const float e0 = __builtin_fmaf(-b, r0, 1.f);
+  const float r1 = __builtin_fmaf(e0, r0, r0);
+  const float q0 = a * r1;
+  const float e1 = __builtin_fmaf(-b, q0, a);
+  const float q1 = __builtin_fmaf(e1, r1, q0);
+  const float e2 = __builtin_fmaf(-b, q1, a);
+  return __builtin_fmaf(e2, r1, q1);
+}
+#define SE3D_EXACT_LO 0x21800000u   // 2^-60
+#define SE3D_EXACT_HI 0x5d800000u   // 2^60
+// s1, s2: arguments of the square roots (their roots, in [2^-30, 2^30], are the divisors); n1, n2 >= 0: the numerators.  Non-negative floats
+// order like their bit patterns; n - 1 wraps zero to the top, so a zero numerator passes and anything in (0, 2^-60) does not.
+__device__ __forceinline__ bool se3d_pair_ops_in_range(float s1, float s2, float n1, float n2) {
+  const unsigned a = __float_as_uint(s1), b = __float_as_uint(s2), c = __float_as_uint(n1), d = __float_as_uint(n2);
+  const unsigned hi = max(max(a, b), max(c, d)), lo_s = min(a, b), lo_n = min(c - 1u, d - 1u);
+  return hi <= SE3D_EXACT_HI && lo_s >= SE3D_EXACT_LO && lo_n >= SE3D_EXACT_LO - 1u;
+}
+// d1 + d2 of one joint of one (det_a, det_b) pair: the two point-to-epipolar-line distances (S3D:358-361)
+__device__ __forceinline__ float se3d_pair_joint_dist(float n1, float s1, float n2, float s2) {
+  if (se3d_pair_ops_in_range(s1, s2, n1, n2)) return se3d_div_core(n1, se3d_sqrt_core(s1)) + se3d_div_core(n2, se3d_sqrt_core(s2));
+  return n1 / sqrtf(s1) + n2 / sqrtf(s2);
+}
+
 // =============================================================================================================
 // row E (inner) — symmetric epipolar distance of one (view-a detection, view-b detection) pair, exactly the float
 // expression tree of calcCost (S3D:353-365) with Eigen's fixed-size evaluation order a0 + (a1 + a2).
@@ -129,9 +170,8 @@ __device__ __forceinline__ double se3d_pair_cost(const float *__restrict__ F, co
       const float l2x = f0 * p2x + (f3 * p2y + f6);
       const float l2y = f1 * p2x + (f4 * p2y + f7);
       const float l2z = f2 * p2x + (f5 * p2y + f8);
-      const float d1 = fabsf(p2x * l1x + (p2y * l1y + l1z)) / sqrtf(l1x * l1x + l1y * l1y);
-      const float d2 = fabsf(p1x * l2x + (p1y * l2y + l2z)) / sqrtf(l2x * l2x + l2y * l2y);
-      cost += (double)(d1 + d2);
+      cost += (double)se3d_pair_joint_dist(fabsf(p2x * l1x + (p2y * l1y + l1z)), l1x * l1x + l1y * l1y,
+                                           fabsf(p1x * l2x + (p1y * l2y + l2z)), l2x * l2x + l2y * l2y);
       ++n;
     }
   }
@@ -217,9 +257,8 @@ __device__ __forceinline__ double se3d_pair_cost_lds(const float *__restrict__ F
       const float l2x = f0 * p2x + (f3 * p2y + f6);
       const float l2y = f1 * p2x + (f4 * p2y + f7);
       const float l2z = f2 * p2x + (f5 * p2y + f8);
-      const float d1 = fabsf(p2x * l1x + (p2y * l1y + l1z)) / sqrtf(l1x * l1x + l1y * l1y);
-      const float d2 = fabsf(p1x * l2x + (p1y * l2y + l2z)) / sqrtf(l2x * l2x + l2y * l2y);
-      cost += (double)(d1 + d2);
+      cost += (double)se3d_pair_joint_dist(fabsf(p2x * l1x + (p2y * l1y + l1z)), l1x * l1x + l1y * l1y,
+                                           fabsf(p1x * l2x + (p1y * l2y + l2z)), l2x * l2x + l2y * l2y);
       ++n;
     }
   }
@@ -2379,6 +2418,35 @@ __global__ __launch_bounds__(64) void se3d_k_sweep_wave_lds(Se3dDev D) {
 }
 static size_t se3d_sweep_wave_lds_bytes(int N, int P, int H) {
   return (size_t)H * P * 16 + (size_t)N * P * 4 + (size_t)H * N * 4 + (size_t)H * 4 + (size_t)N * 8 + (((size_t)H * P + 15) & ~(size_t)15);
+}
+
+// Self-test of se3d_sqrt_core / se3d_div_core against the IEEE expressions on the device (se3d_selftest_exact_math).
+// out[0]: square-root mismatches over every float in [2^-60, 2^60]; out[1]: quotient mismatches over n_div pseudo-random operand pairs
+// (numerator zero every 64th pair, both operands anywhere in the range).
+__global__ __launch_bounds__(256) void se3d_k_selftest_exact_math(unsigned long long *out, unsigned long long n_div) {
+  const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x, nthr = (unsigned long long)gridDim.x * 256;
+  unsigned long long bad_s = 0, bad_d = 0;
+  for (unsigned long long u = SE3D_EXACT_LO + tid; u <= SE3D_EXACT_HI; u += nthr) {
+    const float x = __uint_as_float((unsigned)u);
+    bad_s += __float_as_uint(se3d_sqrt_core(x)) != __float_as_uint(sqrtf(x));
+  }
+  const unsigned span = SE3D_EXACT_HI - SE3D_EXACT_LO + 1u;
+  for (unsigned long long i = tid; i < n_div; i += nthr) {
+    unsigned long long z = (i + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;   // splitmix64
+    z ^= z >> 30; z *= 0x94D049BB133111EBull; z ^= z >> 27; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 31;
+    float a = __uint_as_float(SE3D_EXACT_LO + (unsigned)(z & 0xffffffffull) % span);
+    // divisors as the pair cost has them (roots: [2^-30, 2^30]) on odd i, anywhere in the range on even i
+    const unsigned bs = (unsigned)(z >> 32) % span;
+    float b = __uint_as_float(SE3D_EXACT_LO + ((i & 1ull) ? (0x30800000u - SE3D_EXACT_LO) + bs % (0x4e800000u - 0x30800000u + 1u) : bs));
+    if ((i & 63ull) == 63ull) a = 0.f;
+    bad_d += __float_as_uint(se3d_div_core(a, b)) != __float_as_uint(a / b);
+  }
+  if (bad_s) atomicAdd(&out[0], bad_s);
+  if (bad_d) atomicAdd(&out[1], bad_d);
+}
+extern "C" hipError_t se3d_launch_selftest_exact_math(unsigned long long *d_out, unsigned long long n_div, hipStream_t st) {
+  hipLaunchKernelGGL(se3d_k_selftest_exact_math, dim3(256 * 64), dim3(256), 0, st, d_out, n_div);
+  return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void se3d_k_munkres(double *dist, int *assign, int *status, int nR, int nC) {

@@ -254,6 +254,13 @@ class Skeleton3D:
         self._chk(self._L.se3d_fetch_reprojection(C.c_void_p(self._h), int(slot), C.byref(res.c)), "se3d_fetch_reprojection")
         return res
 
+    def selftest_exact_math(self, n_div=1 << 33):
+        """(square-root mismatches over every float in [2^-60, 2^60], quotient mismatches over n_div operand pairs) of the pair-cost kernels'
+        instruction-level sqrt / divide against the device's IEEE results."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.se3d_selftest_exact_math(C.c_void_p(self._h), C.c_uint64(int(n_div)), C.byref(a), C.byref(b)), "se3d_selftest_exact_math")
+        return int(a.value), int(b.value)
+
     def profile(self, on=True):
         self._chk(self._L.se3d_profile_enable(C.c_void_p(self._h), int(on)), "se3d_profile_enable")
 

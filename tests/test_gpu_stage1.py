@@ -349,3 +349,14 @@ def test_postprocess_forms_agree_bytewise(extr_rig, monkeypatch):
         assert a.published().tobytes() == b.published().tobytes()
         n += a.n_persons
     assert n >= 30
+
+
+
+def test_exact_sqrt_and_divide_cores_match_ieee_on_the_device(extr_rig):
+    """The pair-cost kernels take sqrtf and operator/ of calcCost (S3D:358-361) as the arithmetic cores of the IEEE sequences inside
+    [2^-60, 2^60] (csrc/se3d_stage1.hip: se3d_sqrt_core / se3d_div_core): exhaustive for the square root (1.0e9 floats), 2^33 operand
+    pairs for the quotient (every 64th numerator zero; divisors half in the roots' range, half anywhere) — bit for bit."""
+    node = _node(extr_rig, max_frames=1, max_det_per_cam=8, max_hyp=8)
+    bad_sqrt, bad_div = node.selftest_exact_math(1 << 33)
+    node.close()
+    assert bad_sqrt == 0 and bad_div == 0, (bad_sqrt, bad_div)
