@@ -1659,7 +1659,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
     const double iw0 = se3d_rcp64(ev[3]);
     X = (float)(ev[0] * iw0); Y = (float)(ev[1] * iw0); Z = (float)(ev[2] * iw0);
     S.X[lane] = X; S.Y[lane] = Y; S.Z[lane] = Z;
-    const double hn = 1.0 / sqrt((double)X * X + (double)Y * Y + (double)Z * Z + 1.0);
+    const double hn = se3d_rsq64((double)X * X + (double)Y * Y + (double)Z * Z + 1.0);   // scale of the samples' start vector: any accuracy will do
     S.vs[lane][0] = X * hn; S.vs[lane][1] = Y * hn; S.vs[lane][2] = Z * hn; S.vs[lane][3] = hn;
   }
   __builtin_amdgcn_wave_barrier();
@@ -1677,10 +1677,12 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
       se += (double)(cf * e);
       sc += (double)cf;
     }
-    const double err = se / sc;
-    avg_score = (float)(S.G[lane][20] / nj);
+    // quotients by reciprocal (hardware seed + two Newton steps, <= 1 ulp of fp64 from the IEEE quotient) instead of three fp64 division
+    // sequences on nine lanes: the error only meets thresholds, the score is published as float32
+    const double err = se * se3d_rcp64(sc);
+    avg_score = (float)(S.G[lane][20] * se3d_rcp64((double)nj));
     slow = err > REPROJ_MAX && nj >= 3;  // outlier rejection needed (S3D:748-838): per-joint routine below
-    if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX / err));  // S3D:840-841
+    if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX * se3d_rcp64(err)));  // S3D:840-841
   }
   const unsigned long long slowmask = __ballot(slow);
   // ---- sigma points (S3D:471-523): lanes are tied to joints (64 / JN lanes each) and stride over the joint's 4n + 1 samples, so the
