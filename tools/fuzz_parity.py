@@ -41,8 +41,12 @@ for trial in range(trials):
                  pixel_noise=float(rng.uniform(0.5, 4.0)), spacing=float(rng.uniform(0.5, 1.2)))
     seqs = [S.generate_sequence(rig, S.SceneConfig(n_persons=persons, n_frames=T_, seed=int(rng.integers(1 << 30)), **extra))[0] for _ in range(S_)]
     frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
-    node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=S_ * T_, max_det_per_cam=12, max_hyp=mh, device=0)
-    params = pm.Params(pm.POSE_SIMPLE, 0, 0.045)
+    # FUZZ_VARIANTS=1: also the h36m keypoint set and the height-normalised LM (drawn after the scene, so the scenes of a seed stay the same)
+    variants = bool(os.environ.get("FUZZ_VARIANTS"))
+    pose = "h36m" if variants and trial % 3 == 1 else "simple"
+    norm_h = variants and trial % 2 == 1
+    node = Skeleton3D(rig, pose_method=pose, norm_height=norm_h, max_epi_dist=0.045, max_frames=S_ * T_, max_det_per_cam=12, max_hyp=mh, device=0)
+    params = node.params
     node.stage(frames)
     node.run_stage1()
     node.refine_reset()
