@@ -256,6 +256,11 @@ int se3d_hungarian(se3d_ctx *ctx, int32_t *assignment, double *cost, const doubl
  * S3D:353-368) in FILTERED detection slots, -1 where no joint is shared; n_a/n_b receive the valid slot counts. */
 int se3d_get_pair_costs(se3d_ctx *ctx, int32_t frame, int32_t cam_a, int32_t cam_b, double *out, int32_t *n_a, int32_t *n_b);
 
+/* --- diagnostic accessor: the FUSION_BODY_PARTS constants compiled into the kernels (fusion_body_parts.h:3-24, 33): indices22 = the joint
+ * indices in the enum's declaration order, NUM_KEYPOINTS last (-1 for joints the kernels never name), vel_sigmas21 read back from the
+ * device's constant table. */
+int se3d_get_fusion_constants(se3d_ctx *ctx, int32_t *indices22, double *vel_sigmas21);
+
 /* --- diagnostic self-test: the pair-cost kernels form sqrtf(x) and a / b of calcCost (S3D:358-361) with the arithmetic cores of the IEEE
  * sequences (no operand scaling / fix-up) inside [2^-60, 2^60]; this runs both against the device's IEEE results — the square root on every
  * float of the range, the quotient on n_div pseudo-random operand pairs — and returns the mismatch counts (expected: 0, 0). */

@@ -39,6 +39,32 @@ def lib():
     return _lib
 
 
+_REF_FBP = os.path.join(_HERE, "_ref", "libfbp_ref.so")
+
+
+def ref_fbp_available():
+    return os.path.exists(_REF_FBP)
+
+
+def ref_fusion_constants():
+    """FUSION_BODY_PARTS indices (declaration order, NUM_KEYPOINTS last) and vel_sigmas from the REFERENCE's header compiled in place."""
+    L = C.CDLL(_REF_FBP)
+    idx = (C.c_int * 22)()
+    vel = (C.c_double * 21)()
+    L.fbp_ref_indices(idx)
+    L.fbp_ref_vel_sigmas(vel)
+    assert L.fbp_ref_num_keypoints() == 21
+    return list(idx), list(vel)
+
+
+def fusion_constants():
+    """The oracle's restated FUSION_BODY_PARTS constants in the same layout."""
+    idx = (C.c_int32 * 22)()
+    vel = (C.c_double * 21)()
+    lib().se3d_oracle_fusion_constants(idx, vel)
+    return list(idx), list(vel)
+
+
 def ref_hungarian_available():
     return os.path.exists(_REF)
 

@@ -1468,6 +1468,15 @@ void se3d_oracle_stats_get(int64_t *out) {
   for (int i = 0; i < SE3D_ORACLE_STAT_COUNT; ++i) out[i] = (int64_t)g_stat[i].load();
 }
 
+// The restated FUSION_BODY_PARTS constants (FBP:3-24, 33) as data, so that a test can compare them with the reference's header compiled
+// in place (oracle/_ref/libfbp_ref.so, tests/golden/fusion_body_parts.json).
+void se3d_oracle_fusion_constants(int32_t *indices22, double *vel_sigmas21) {
+  const int v[22] = {F_Nose, F_Neck, F_RShoulder, F_RElbow, F_RWrist, F_LShoulder, F_LElbow, F_LWrist, F_MidHip, F_RHip, F_RKnee, F_RAnkle,
+                     F_LHip, F_LKnee, F_LAnkle, F_REye, F_LEye, F_REar, F_LEar, F_Head, F_Belly, NFU};
+  for (int i = 0; i < 22; ++i) indices22[i] = v[i];
+  for (int i = 0; i < NFU; ++i) vel_sigmas21[i] = vel_sigmas[i];
+}
+
 se3d_oracle_pp *se3d_oracle_pp_create(const se3d_params *params) {
   if (!params) return nullptr;
   se3d_oracle_pp *pp = new se3d_oracle_pp();

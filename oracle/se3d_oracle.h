@@ -8,6 +8,9 @@
  * Pinning status:
  *   - Hungarian (row M): PINNED bit-exactly against the reference's own Hungarian.cpp compiled from
  *     /root/reference into oracle/_ref/ (tests/golden/hungarian_*.json were produced by that binary).
+ *   - Constants (row K, the part that lives in a stand-alone header): PINNED — FUSION_BODY_PARTS joint indices and vel_sigmas against the
+ *     reference's fusion_body_parts.h compiled in place (oracle/fbp_ref_shim.cpp -> oracle/_ref/libfbp_ref.so,
+ *     tests/golden/fusion_body_parts.json, tests/test_oracle_fbp_golden.py).  The pose-specific tables sit inside the ROS node sources.
  *   - Everything that goes through Eigen 3 JacobiSVD / GTSAM 4.0.3 (rows T, U, R): PARITY UNPINNED — those
  *     libraries are not in the reference tree and not in this image; the algorithms are restated from their
  *     published behaviour and checked against independent numpy/scipy solutions (tests/test_oracle_kat.py).
@@ -72,6 +75,8 @@ enum {
 };
 void se3d_oracle_stats_reset(void);
 void se3d_oracle_stats_get(int64_t *out /* [SE3D_ORACLE_STAT_COUNT] */);
+/* the restated FUSION_BODY_PARTS constants: joint indices in declaration order + NUM_KEYPOINTS, vel_sigmas (FBP:3-24, 33) */
+void se3d_oracle_fusion_constants(int32_t *indices22, double *vel_sigmas21);
 
 /* pose_prior node state + callback (PP:505-921). */
 typedef struct se3d_oracle_pp se3d_oracle_pp;

@@ -1157,6 +1157,14 @@ int se3d_fetch_reprojection(se3d_ctx *c, int32_t slot, se3d_reproj_out *out) {
   return SE3D_OK;
 }
 
+extern "C" hipError_t se3d_read_fusion_constants(int32_t *indices22, double *vel_sigmas21);
+int se3d_get_fusion_constants(se3d_ctx *c, int32_t *indices22, double *vel_sigmas21) {
+  if (!c || !indices22 || !vel_sigmas21) return SE3D_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, se3d_read_fusion_constants(indices22, vel_sigmas21));
+  return SE3D_OK;
+}
+
 // Diagnostic: the instruction-level square root / quotient of the pair-cost kernels against the IEEE expressions, on this device.
 extern "C" hipError_t se3d_launch_selftest_exact_math(unsigned long long *d_out, unsigned long long n_div, hipStream_t st);
 int se3d_selftest_exact_math(se3d_ctx *c, uint64_t n_div, uint64_t *sqrt_mismatches, uint64_t *div_mismatches) {

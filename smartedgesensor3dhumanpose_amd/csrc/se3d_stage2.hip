@@ -2575,6 +2575,15 @@ extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk,
               : s2_launch_walk_shape<false, S2_WALK_WAVES, S2_WALK_SEQS>(q, Wk, nseq, st);
 }
 
+// Diagnostic: the fusion-joint indices the kernels use by name (FU_*) and the device's vel_sigmas table, for the test that compares them
+// with the reference's fusion_body_parts.h (tests/golden/fusion_body_parts.json).  -1: an index the kernels never refer to by name.
+extern "C" hipError_t se3d_read_fusion_constants(int32_t *indices22, double *vel_sigmas21) {
+  for (int i = 0; i < 22; ++i) indices22[i] = -1;
+  indices22[0] = FU_Nose; indices22[1] = FU_Neck; indices22[2] = FU_RShoulder; indices22[5] = FU_LShoulder; indices22[8] = FU_MidHip;
+  indices22[9] = FU_RHip; indices22[11] = FU_RAnkle; indices22[12] = FU_LHip; indices22[14] = FU_LAnkle; indices22[20] = FU_Belly; indices22[21] = SE3D_NFU;
+  return hipMemcpyFromSymbol(vel_sigmas21, HIP_SYMBOL(c_vel_sigmas), sizeof(double) * SE3D_NFU);
+}
+
 // Kernel attributes are per DEVICE in HIP: called by se3d_create for the context's device (after hipSetDevice), not once per process.
 extern "C" hipError_t se3d_stage2_init_device(void) {
   const struct { const void *fn; int bytes; } attrs[] = {

@@ -254,6 +254,13 @@ class Skeleton3D:
         self._chk(self._L.se3d_fetch_reprojection(C.c_void_p(self._h), int(slot), C.byref(res.c)), "se3d_fetch_reprojection")
         return res
 
+    def fusion_constants(self):
+        """(indices22, vel_sigmas21) compiled into the kernels (diagnostic; compared with the reference's fusion_body_parts.h by the tests)."""
+        idx = (C.c_int32 * 22)()
+        vel = (C.c_double * 21)()
+        self._chk(self._L.se3d_get_fusion_constants(C.c_void_p(self._h), idx, vel), "se3d_get_fusion_constants")
+        return list(idx), list(vel)
+
     def selftest_exact_math(self, n_div=1 << 33):
         """(square-root mismatches over every float in [2^-60, 2^60], quotient mismatches over n_div operand pairs) of the pair-cost kernels'
         instruction-level sqrt / divide against the device's IEEE results."""

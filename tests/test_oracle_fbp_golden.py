@@ -1,0 +1,42 @@
+"""Row K (constants) pinned to the reference: tests/golden/fusion_body_parts.json holds the FUSION_BODY_PARTS joint indices and the
+vel_sigmas table read from the reference's own fusion_body_parts.h compiled in place (tests/golden/make_fbp_golden.py, oracle/_ref).
+CPU: the oracle's restated constants equal the golden values (and, in the build container, the freshly compiled reference header).
+GPU: so do the constants compiled into the HIP kernels."""
+import json
+import os
+
+import pytest
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fusion_body_parts.json")))
+NAMES = ["Nose", "Neck", "RShoulder", "RElbow", "RWrist", "LShoulder", "LElbow", "LWrist", "MidHip", "RHip", "RKnee", "RAnkle", "LHip", "LKnee",
+         "LAnkle", "REye", "LEye", "REar", "LEar", "Head", "Belly", "NUM_KEYPOINTS"]
+
+
+def test_oracle_fusion_constants_equal_the_reference_header(oracle):
+    idx, vel = oracle.fusion_constants()
+    assert idx == [GOLD["indices"][n] for n in NAMES]
+    assert vel == GOLD["vel_sigmas"]
+    if oracle.ref_fbp_available():   # build container: the golden file still matches the reference tree
+        ridx, rvel = oracle.ref_fusion_constants()
+        assert ridx == idx and rvel == vel
+
+
+def test_person_msgs_fusion_tables_use_the_reference_indices():
+    from smartedgesensor3dhumanpose_amd import person_msgs as pm
+    g = GOLD["indices"]
+    assert pm.NUM_FUSION_KEYPOINTS == g["NUM_KEYPOINTS"]
+    # the simple keypoint set maps onto the reference's named joints (S3D:139-142: Nose, LEye, REye, LEar, REar, LShoulder, RShoulder, ...)
+    want = [g[n] for n in ("Nose", "LEye", "REye", "LEar", "REar", "LShoulder", "RShoulder", "LElbow", "RElbow", "LWrist", "RWrist", "LHip", "RHip",
+                           "LKnee", "RKnee", "LAnkle", "RAnkle")]
+    assert list(pm.KP2FUSION_SIMPLE) == want
+
+
+@pytest.mark.gpu
+def test_kernel_fusion_constants_equal_the_reference_header(extr_rig):
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
+    node = Skeleton3D(extr_rig, max_frames=1, max_det_per_cam=8, max_hyp=8)
+    idx, vel = node.fusion_constants()
+    node.close()
+    want = [GOLD["indices"][n] for n in NAMES]
+    assert all(i == -1 or i == w for i, w in zip(idx, want)) and idx[21] == want[21] and sum(i >= 0 for i in idx) >= 10
+    assert vel == GOLD["vel_sigmas"]
