@@ -122,3 +122,15 @@ def test_bag_to_synchronised_frames(tmp_path):
             fr = frames[k]
             ref = fr.persons[fr.det_offset[c]:fr.det_offset[c + 1]]
             assert m.persons.tobytes() == ref.tobytes()
+
+
+def test_message_definitions_have_the_reference_md5_sums():
+    """tests/golden/person_msgs_md5.json holds the ROS md5 sums of the reference's own person_msgs/msg/*.msg files (make_msg_md5_golden.py,
+    genmsg rule).  An md5 pins field names, types and order: the definitions rosbag_io writes into its bags and parses messages by are the
+    reference's."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "person_msgs_md5.json")))["md5"]
+    assert set(rb.MSG_DEFS) <= set(gold) and len(rb.MSG_DEFS) == 6
+    for t in rb.MSG_DEFS:
+        assert rb.msg_md5(t) == gold[t], t
