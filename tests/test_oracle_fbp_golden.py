@@ -40,3 +40,13 @@ def test_kernel_fusion_constants_equal_the_reference_header(extr_rig):
     want = [GOLD["indices"][n] for n in NAMES]
     assert all(i == -1 or i == w for i, w in zip(idx, want)) and idx[21] == want[21] and sum(i >= 0 for i in idx) >= 10
     assert vel == GOLD["vel_sigmas"]
+
+
+def test_demo_configuration_is_the_reference_launch_file(demo_params, extr_rig):
+    """tests/golden/demo_params.json: arguments of the reference's pose_triangulate_demo.launch (make_demo_params_golden.py).  The
+    parameters every parity test and bench.py run with, and the 16-camera rig, are that configuration."""
+    from smartedgesensor3dhumanpose_amd import person_msgs as pm
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "demo_params.json")))
+    assert demo_params.max_epi_dist == gold["max_epi_dist"] and bool(demo_params.norm_height) == gold["norm_height"]
+    assert gold["pose_methods"] == ["simple"] and demo_params.pose_method == pm.POSE_SIMPLE
+    assert extr_rig.n_cam == gold["n_cameras"]
