@@ -65,6 +65,27 @@ def fusion_constants():
     return list(idx), list(vel)
 
 
+# (reference file, reference name) of every value se3d_oracle_node_constants returns, in order
+NODE_CONSTANT_NAMES = [("skeleton_3d", "g_min_num_valid_keypoints"), ("skeleton_3d", "g_triangulation_threshold"), ("skeleton_3d", "g_reproj_error_max_acceptable"),
+                       ("skeleton_3d", "g_max_joint_dist_to_root"), ("skeleton_3d", "g_merge_dist_thresh"), ("skeleton_3d", "g_limbLCovOffsetSigma"),
+                       ("pose_prior", "MAX_DIST"), ("pose_prior", "g_min_score"), ("pose_prior", "g_predNoiseSigma"), ("pose_prior", "g_defaultResSigma"),
+                       ("pose_prior", "g_root_sigma_factor"), ("pose_prior", "g_n_mov_avg"), ("pose_prior", "g_t_max_unobserved"), ("pose_prior", "g_dist_threshold"),
+                       ("pose_prior", "g_min_num_obs_track"), ("pose_prior", "g_avg_delay")]
+
+
+def node_constants():
+    v = (C.c_double * 16)()
+    lib().se3d_oracle_node_constants(v)
+    return list(v)
+
+
+def pose_tables(pose_method):
+    par, k2f = (C.c_int32 * 17)(), (C.c_int32 * 17)()
+    ln, sg, sh = (C.c_double * 17)(), (C.c_double * 17)(), (C.c_double * 2)()
+    lib().se3d_oracle_pose_tables(int(pose_method), par, ln, sg, k2f, sh)
+    return {"kpParent": list(par), "limbLength": list(ln), "limbLSigma": list(sg), "kp2fusion": list(k2f), "shoulderDist": sh[0], "shoulderSigma": sh[1]}
+
+
 def ref_hungarian_available():
     return os.path.exists(_REF)
 

@@ -41,6 +41,11 @@ constexpr double g_reproj_error_max_acceptable = 0.050;    // S3D:59
 constexpr double g_max_joint_dist_to_root = 2.0;           // S3D:61
 constexpr double g_merge_dist_thresh = 0.20;               // S3D:62, PP:64
 constexpr double g_limbLCovOffsetSigma = 0.075;            // S3D:149
+// pose_prior node constants (PP:46-66)
+constexpr float g_min_score = 0.10f;                       // PP:50
+constexpr double g_avg_delay = 0.10, g_root_sigma_factor = 100.0, g_predNoiseSigma = 0.12, g_defaultResSigma = 0.10;   // PP:51, 52, 47, 48
+constexpr int g_n_mov_avg = 3, g_min_num_obs_track = 10;  // PP:53, 66
+constexpr double g_t_max_unobserved = 1.0, g_dist_threshold = 5.0;   // PP:62, 63
 
 // FUSION_BODY_PARTS (FBP:3-24)
 enum Fusion {
@@ -1468,6 +1473,23 @@ void se3d_oracle_stats_get(int64_t *out) {
   for (int i = 0; i < SE3D_ORACLE_STAT_COUNT; ++i) out[i] = (int64_t)g_stat[i].load();
 }
 
+// The restated node constants and per-pose tables as data (tests/golden/pose_constants.json holds the reference's values by name).
+// scalars13: g_min_num_valid_keypoints, g_triangulation_threshold, g_reproj_error_max_acceptable, g_max_joint_dist_to_root, g_merge_dist_thresh,
+//            g_limbLCovOffsetSigma, MAX_COSTS | g_min_score, g_predNoiseSigma, g_defaultResSigma, g_root_sigma_factor, g_n_mov_avg,
+//            g_t_max_unobserved, g_dist_threshold, g_min_num_obs_track, g_avg_delay  (16 values)
+void se3d_oracle_node_constants(double *scalars16) {
+  const double v[16] = {(double)g_min_num_valid_keypoints, (double)g_triangulation_threshold, g_reproj_error_max_acceptable, g_max_joint_dist_to_root,
+                        g_merge_dist_thresh, g_limbLCovOffsetSigma, MAX_COSTS, (double)g_min_score, g_predNoiseSigma, g_defaultResSigma,
+                        g_root_sigma_factor, (double)g_n_mov_avg, g_t_max_unobserved, g_dist_threshold, (double)g_min_num_obs_track, g_avg_delay};
+  for (int i = 0; i < 16; ++i) scalars16[i] = v[i];
+}
+void se3d_oracle_pose_tables(int32_t pose_method, int32_t *kp_parent17, double *limb_length17, double *limb_sigma17, int32_t *kp2fusion17,
+                             double *shoulder2) {
+  const auto T = tables_for(pose_method);
+  for (int k = 0; k < NKP; ++k) { kp_parent17[k] = T.kpParent[k]; limb_length17[k] = T.limbLength[k]; limb_sigma17[k] = T.limbLSigma[k]; kp2fusion17[k] = T.kp2fusion[k]; }
+  shoulder2[0] = simple_shoulderDist; shoulder2[1] = simple_shoulderSigma;
+}
+
 // The restated FUSION_BODY_PARTS constants (FBP:3-24, 33) as data, so that a test can compare them with the reference's header compiled
 // in place (oracle/_ref/libfbp_ref.so, tests/golden/fusion_body_parts.json).
 void se3d_oracle_fusion_constants(int32_t *indices22, double *vel_sigmas21) {
@@ -1492,10 +1514,6 @@ void se3d_oracle_pp_destroy(se3d_oracle_pp *pp) { delete pp; }
 int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *dets, int32_t n_cam, const float *fb_delay_per_cam,
                         double t, se3d_fused_out *out, int32_t omp_threads) {
   if (!pp || !out || (n_det > 0 && !dets)) return SE3D_ERR_ARG;
-  const float g_min_score = 0.10f;
-  const double g_avg_delay = 0.10, g_root_sigma_factor = 100.0, g_predNoiseSigma = 0.12, g_defaultResSigma = 0.10;
-  const int g_n_mov_avg = 3, g_min_num_obs_track = 10;
-  const double g_t_max_unobserved = 1.0, g_dist_threshold = 5.0;
   const bool simple = pp->params.pose_method == SE3D_POSE_SIMPLE;
   const bool norm_height = pp->params.norm_height != 0;
   auto &g_tracks = pp->tracks;

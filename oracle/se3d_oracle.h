@@ -10,7 +10,8 @@
  *     /root/reference into oracle/_ref/ (tests/golden/hungarian_*.json were produced by that binary).
  *   - Constants (row K, the part that lives in a stand-alone header): PINNED — FUSION_BODY_PARTS joint indices and vel_sigmas against the
  *     reference's fusion_body_parts.h compiled in place (oracle/fbp_ref_shim.cpp -> oracle/_ref/libfbp_ref.so,
- *     tests/golden/fusion_body_parts.json, tests/test_oracle_fbp_golden.py).  The pose-specific tables sit inside the ROS node sources.
+ *     tests/golden/fusion_body_parts.json, tests/test_oracle_fbp_golden.py).  The named node constants and the pose-specific tables sit inside
+ *     the ROS node sources: read out BY NAME into tests/golden/pose_constants.json and compared with this library's values by the same test.
  *   - Everything that goes through Eigen 3 JacobiSVD / GTSAM 4.0.3 (rows T, U, R): PARITY UNPINNED — those
  *     libraries are not in the reference tree and not in this image; the algorithms are restated from their
  *     published behaviour and checked against independent numpy/scipy solutions (tests/test_oracle_kat.py).
@@ -77,6 +78,10 @@ void se3d_oracle_stats_reset(void);
 void se3d_oracle_stats_get(int64_t *out /* [SE3D_ORACLE_STAT_COUNT] */);
 /* the restated FUSION_BODY_PARTS constants: joint indices in declaration order + NUM_KEYPOINTS, vel_sigmas (FBP:3-24, 33) */
 void se3d_oracle_fusion_constants(int32_t *indices22, double *vel_sigmas21);
+/* the restated node constants (order documented in se3d_oracle.cpp / oracle_py.NODE_CONSTANT_NAMES) and per-pose-method tables */
+void se3d_oracle_node_constants(double *scalars16);
+void se3d_oracle_pose_tables(int32_t pose_method, int32_t *kp_parent17, double *limb_length17, double *limb_sigma17, int32_t *kp2fusion17,
+                             double *shoulder2);
 
 /* pose_prior node state + callback (PP:505-921). */
 typedef struct se3d_oracle_pp se3d_oracle_pp;
