@@ -86,6 +86,13 @@ def pose_tables(pose_method):
     return {"kpParent": list(par), "limbLength": list(ln), "limbLSigma": list(sg), "kp2fusion": list(k2f), "shoulderDist": sh[0], "shoulderSigma": sh[1]}
 
 
+def bone_table(norm_height):
+    k1, k2, nb = (C.c_int32 * 21)(), (C.c_int32 * 21)(), (C.c_int32 * 21)()
+    ln, sg = (C.c_double * 21)(), (C.c_double * 21)()
+    lib().se3d_oracle_bone_table(int(bool(norm_height)), k1, k2, ln, sg, nb)
+    return [[k1[i], k2[i], ln[i], sg[i], bool(nb[i])] for i in range(21)]
+
+
 def ref_hungarian_available():
     return os.path.exists(_REF)
 

@@ -1490,6 +1490,12 @@ void se3d_oracle_pose_tables(int32_t pose_method, int32_t *kp_parent17, double *
   shoulder2[0] = simple_shoulderDist; shoulder2[1] = simple_shoulderSigma;
 }
 
+// The 21 range factors of addBinaryFactors (PP:384-481) per branch: k1, k2, length, sigma coefficient, "only if the belly is NOT measured".
+void se3d_oracle_bone_table(int32_t norm_height, int32_t *k1, int32_t *k2, double *length, double *sigma, int32_t *not_belly) {
+  const BoneDef *bones = norm_height ? bones_norm : bones_abs;
+  for (int i = 0; i < 21; ++i) { k1[i] = bones[i].k1; k2[i] = bones[i].k2; length[i] = bones[i].L; sigma[i] = bones[i].sigma; not_belly[i] = bones[i].not_belly ? 1 : 0; }
+}
+
 // The restated FUSION_BODY_PARTS constants (FBP:3-24, 33) as data, so that a test can compare them with the reference's header compiled
 // in place (oracle/_ref/libfbp_ref.so, tests/golden/fusion_body_parts.json).
 void se3d_oracle_fusion_constants(int32_t *indices22, double *vel_sigmas21) {

@@ -80,6 +80,7 @@ void se3d_oracle_stats_get(int64_t *out /* [SE3D_ORACLE_STAT_COUNT] */);
 void se3d_oracle_fusion_constants(int32_t *indices22, double *vel_sigmas21);
 /* the restated node constants (order documented in se3d_oracle.cpp / oracle_py.NODE_CONSTANT_NAMES) and per-pose-method tables */
 void se3d_oracle_node_constants(double *scalars16);
+void se3d_oracle_bone_table(int32_t norm_height, int32_t *k1, int32_t *k2, double *length, double *sigma, int32_t *not_belly);   /* 21 entries each */
 void se3d_oracle_pose_tables(int32_t pose_method, int32_t *kp_parent17, double *limb_length17, double *limb_sigma17, int32_t *kp2fusion17,
                              double *shoulder2);
 

@@ -45,6 +45,27 @@ def kp2fusion(path, name):
 out = {"source": "named constants and tables parsed from skeleton_3d_triang_mult_node.cpp / pose_prior_mult_node.cpp of the reference",
        "skeleton_3d": scalars(S3D), "pose_prior": scalars(PP),
        "simple": struct_tables(S3D, "EdgeTPU_BodyParts_Simple"), "h36m": struct_tables(S3D, "EdgeTPU_BodyParts_H36M")}
+
+
+def bone_tables(path):
+    """addBinaryFactors (PP:384-481): per branch (heights normalised / absolute) the ordered list of range factors
+    [k1, k2, length, sigma coefficient, [joints that must be measured], [joints that must NOT be measured]]."""
+    src = open(path).read()
+    body = src[src.index("void addBinaryFactors("):]
+    body = body[:body.index("\n}\n")]
+    norm, absolute = body.split("else{", 1)
+    out = {}
+    for key, part in (("normalized", norm), ("absolute", absolute)):
+        rows = []
+        for m in re.finditer(r"if\(([^\n]*)\)\s*\n\s*graph\.emplace_shared<RangeFactor<Point3>>\(\s*(\d+)\s*,\s*(\d+)\s*,\s*(" + NUM + r")\s*,\s*noiseModel::Isotropic::Sigma\(1,\s*(" + NUM + ")", part):
+            need = [FBP[x] for x in re.findall(r"(?<!!)joints_measured\[FUSION_BODY_PARTS::(\w+)\]", m.group(1))]
+            deny = [FBP[x] for x in re.findall(r"!joints_measured\[FUSION_BODY_PARTS::(\w+)\]", m.group(1))]
+            rows.append([int(m.group(2)), int(m.group(3)), float(m.group(4)), float(m.group(5)), need, deny])
+        out[key] = rows
+    return out
+
+
+out["bones"] = bone_tables(PP)
 out["simple"]["kp2fusion"] = kp2fusion(S3D, "g_kp2kpFusion_idx_simple[17]")
 out["h36m"]["kp2fusion"] = kp2fusion(S3D, "g_kp2kpFusion_idx_h36m[17]")
 json.dump(out, open(os.path.join(os.path.dirname(__file__), "pose_constants.json"), "w"), indent=1)

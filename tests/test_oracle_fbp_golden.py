@@ -72,3 +72,17 @@ def test_oracle_node_constants_and_pose_tables_equal_the_reference_sources(oracl
     assert list(pm.KP2FUSION_SIMPLE) == gold["simple"]["kp2fusion"]
     if hasattr(pm, "KP2FUSION_H36M"):
         assert list(pm.KP2FUSION_H36M) == gold["h36m"]["kp2fusion"]
+
+
+
+def test_oracle_bone_tables_equal_the_reference_source(oracle):
+    """The 2 x 21 range factors of addBinaryFactors (PP:384-481) — joint pair, length, sigma coefficient, measured / not-measured conditions —
+    parsed out of the reference source in order (tests/golden/pose_constants.json["bones"]) against the oracle's tables."""
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pose_constants.json")))
+    belly = GOLD["indices"]["Belly"]
+    for norm, key in ((False, "absolute"), (True, "normalized")):
+        tab = oracle.bone_table(norm)
+        assert len(gold["bones"][key]) == 21
+        for (k1, k2, length, sigma, not_belly), (g1, g2, gl, gs, need, deny) in zip(tab, gold["bones"][key]):
+            assert (k1, k2, length, sigma) == (g1, g2, gl, gs)
+            assert sorted(need) == sorted([k1, k2]) and deny == ([belly] if not_belly else [])
