@@ -1556,8 +1556,15 @@ __global__ __launch_bounds__(256, 3) void se3d_k_triangulate(Se3dDev D) {
 // views, S3D:748-838) are rare and go through the per-joint routine afterwards.
 // =============================================================================================================
 #define TH_MAXV 16
-#define TH_JOINTS 9   // joints per workgroup: a hypothesis is split into two one-wavefront workgroups (9 + 8 joints) of 13 KB LDS each,
-                      // of ~7 KB LDS each
+// A hypothesis is split into TH_PARTS one-wavefront workgroups of 6 + 6 + 5 joints (round 1 / first half of round 2: two of 9 + 8).  Three
+// parts: 8 KB of LDS per wavefront instead of 11.6 KB, so that LDS no longer caps a CU at 13 wavefronts; with the kernel compiled for four
+// wavefronts per SIMD (128 VGPRs, 56 B of scratch outside the sample loop) 16 are resident instead of 12; and 10 / 12 lanes per joint
+// walk the 4n + 1 sigma samples of a 12-view joint in 3 + 3 trips instead of 4 + 4.  13.09 -> 12.38 (three parts) -> 11.50 ms per
+// 98 304 frames; with two parts the same compilation for 128 VGPRs was SLOWER (15.8 vs 14.8 ms at the time: spills without the occupancy).
+#ifndef TH_PARTS
+#define TH_PARTS 3
+#endif
+#define TH_JOINTS ((SE3D_NKP + TH_PARTS - 1) / TH_PARTS)   // joints per workgroup
 struct TriHypLds {
   float x[TH_JOINTS][TH_MAXV], y[TH_JOINTS][TH_MAXV], cf[TH_JOINTS][TH_MAXV];  // normalised point and confidence per (joint, attached view); cf < 0: unusable
   float ca[TH_JOINTS][TH_MAXV], cb[TH_JOINTS][TH_MAXV], cc[TH_JOINTS][TH_MAXV];  // Cholesky factor of the 2x2 keypoint covariance
@@ -1572,12 +1579,15 @@ struct TriHypLds {
   unsigned char vidx[TH_JOINTS][TH_MAXV];              // usable views of a joint in ascending camera order
 };
 
-__global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
-  __shared__ TriHypLds S;   // one wavefront per workgroup: 25 KB of LDS fit next to two resident stage-2 walk workgroups of another context
+#ifndef TH_WPE
+#define TH_WPE 4
+#endif
+__global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) {
+  __shared__ TriHypLds S;   // one wavefront per workgroup
   __shared__ float sRt[12 * TH_MAXV];
   const int lane = threadIdx.x;
-  const int f = blockIdx.y, h = blockIdx.x >> 1;
-  const int jbase = (blockIdx.x & 1) * TH_JOINTS, JN = min(TH_JOINTS, SE3D_NKP - jbase);  // joints jbase .. jbase + JN - 1
+  const int f = blockIdx.y, h = blockIdx.x / TH_PARTS, part_ = blockIdx.x - h * TH_PARTS;
+  const int jbase = part_ * TH_JOINTS, JN = min(TH_JOINTS, SE3D_NKP - jbase);  // joints jbase .. jbase + JN - 1
   const int N = D.d.N, H = D.d.H;
   if (h >= D.nhyp[f]) return;
   if (D.nviews[f * H + h] < 2) return;
@@ -1593,7 +1603,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
     if (k >= 0) { const int pos = __popcll(bl & ((1ull << lane) - 1ull)); S.cam[pos] = lane; S.det[pos] = k; }
   }
   __builtin_amdgcn_wave_barrier();
-  if ((blockIdx.x & 1) == 0) se3d_zero_unused_slots(D.hypP[(size_t)f * H + h], D.d.pose_method, lane);
+  if (part_ == 0) se3d_zero_unused_slots(D.hypP[(size_t)f * H + h], D.d.pose_method, lane);
   // ---- points: lanes over (joint, view); row N on the fly from the raw payload ----
   for (int idx = lane; idx < JN * nv; idx += 64) {
     const int j = idx / nv, v = idx - j * nv;
@@ -1693,7 +1703,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
   se3d_person3d &person = D.hypP[(size_t)f * H + h];
   const int pm_ = D.d.pose_method;
   {
-    const int LPJ = 64 / JN;                       // 7 lanes per joint (9 joints) or 8 (8 joints)
+    const int LPJ = 64 / JN;                       // 10 lanes per joint (6 joints) or 12 (5 joints)
     const int jl = lane / LPJ, j = min(jl, JN - 1), s0 = lane - LPJ * jl;
     const int cntj = jl < JN ? __shfl(cnt, j) : 0;
     const int n = S.n[j];
@@ -1755,7 +1765,8 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_hyp(Se3dDev D) {
     }
   }
   // ---- joints that need outlier rejection are redone by se3d_k_triangulate_slow (per-joint routine) ----
-  if (lane == 0) D.tri_slow[((size_t)f * H + h) * 2 + (blockIdx.x & 1)] = (uint32_t)slowmask << jbase;
+  if (lane == 0) D.tri_slow[((size_t)f * H + h) * 3 + part_] = (uint32_t)slowmask << jbase;
+  if (lane == 0 && TH_PARTS == 2 && part_ == 0) D.tri_slow[((size_t)f * H + h) * 3 + 2] = 0u;
 }
 
 // Outlier-rejection path of the hypothesis kernel: one wavefront per hypothesis redoes the flagged joints (usually none) with the
@@ -1770,7 +1781,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_slow(Se3dDev D, int n_e
   uint32_t mymask = 0u;
   if (e < n_entries) {
     const int f = e / H, h = e - f * H;
-    if (h < D.nhyp[f] && D.nviews[e] >= 2 && (D.d.shard_world <= 1 || h % D.d.shard_world == D.d.shard_rank)) mymask = D.tri_slow[(size_t)e * 2] | D.tri_slow[(size_t)e * 2 + 1];
+    if (h < D.nhyp[f] && D.nviews[e] >= 2 && (D.d.shard_world <= 1 || h % D.d.shard_world == D.d.shard_rank)) mymask = D.tri_slow[(size_t)e * 3] | D.tri_slow[(size_t)e * 3 + 1] | D.tri_slow[(size_t)e * 3 + 2];
   }
   unsigned long long todo = __ballot(mymask != 0u);
   if (!todo) return;
@@ -2487,7 +2498,7 @@ static void se3d_launch_triangulation(const Se3dDev &D, hipStream_t st) {
   const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
   const char *e_tri = getenv("SE3D_TRI");  // A/B switch (read per launch): joint = always one wavefront per (hypothesis, joint)
   if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) {
-    hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(2 * H, B), dim3(64), 0, st, D);
+    hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(TH_PARTS * H, B), dim3(64), 0, st, D);
     hipLaunchKernelGGL(se3d_k_triangulate_slow, dim3((B * H + 63) / 64), dim3(64), (size_t)27 * N * sizeof(float), st, D, B * H);
   }
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
