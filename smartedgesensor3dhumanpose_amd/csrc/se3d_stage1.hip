@@ -2130,6 +2130,192 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave2(Se3dDev D) {
     D.out_assoc[((size_t)f * H + h) * N + c] = (k >= 0) ? D.orig[((size_t)(f * N + c)) * P + k] : -1;
   }
 }
+// Third form (round 2, default for H <= 16): as se3d_k_postprocess_wave2, but the persons stay in GLOBAL memory (hypP, modified in place:
+// it is an intermediate between triangulation and this kernel) and LDS holds only what lanes read from EACH OTHER — joint position and score
+// per (person, joint): 32 B instead of the 80-B keypoint, 6.7 KB per wavefront at H = 8 instead of 14.9 KB, 23 wavefronts per CU instead
+// of 10 on a kernel that sits in s_waitcnt three quarters of the time.  Every modification goes to both copies: covariance inflation is a
+// read-modify-write of the owner lane (the left shoulder's two terms by ONE lane, in the reference's order), a removed keypoint is zeroed
+// in hypP and in LDS, a merge rewrites person i in both; the published persons are then a plain hypP -> outP copy behind a fence.
+struct PostKp { double joint[3]; float score; float _pad; };
+__global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
+  extern __shared__ __align__(16) unsigned char post_smem[];
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  const int pm = D.d.pose_method;
+  PostKp *sk = reinterpret_cast<PostKp *>(post_smem);                                 // [H][21]
+  double *term = reinterpret_cast<double *>(sk + (size_t)H * SE3D_NFU);               // [H][21]
+  int *cnt0 = reinterpret_cast<int *>(term + (size_t)H * SE3D_NFU), *dec = cnt0 + H;  // [H] valid input keypoints / removed fusion slots
+  const int nh = D.nhyp[f];
+  se3d_person3d *persons = D.hypP + (size_t)f * H;
+  constexpr int words2 = (int)(sizeof(se3d_person3d) / 8);
+  int ncam = 0;
+  for (int c = lane; c < N; c += 64) ncam += (D.nraw[f * N + c] > 0) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) ncam += __shfl_xor(ncam, o);
+  const bool few = ncam < 2;  // S3D:557-560
+  for (int it = lane; it < nh * SE3D_NFU; it += 64) {
+    const int h = it / SE3D_NFU, k = it - h * SE3D_NFU;
+    const se3d_keypoint3d &g = persons[h].keypoints[k];
+    PostKp c;
+    c.joint[0] = g.joint[0]; c.joint[1] = g.joint[1]; c.joint[2] = g.joint[2]; c.score = g.score; c._pad = 0.f;
+    sk[it] = c;
+  }
+  const int nv_l = (lane < nh) ? D.nviews[f * H + lane] : 0;
+  if (lane < H) { cnt0[lane] = 0; dec[lane] = 0; }
+  __syncthreads();
+  // ---- limb-length covariance inflation (S3D:861-883): items (person, input keypoint); the owner lane adds every term of its keypoint ----
+  for (int it = lane; it < nh * SE3D_NKP; it += 64) {
+    const int h = it / SE3D_NKP, k = it - h * SE3D_NKP;
+    const PostKp *pk_ = sk + (size_t)h * SE3D_NFU;
+    const int fu = c_kp2fusion[pm][k];
+    const PostKp &kp = pk_[fu];
+    if (kp.score <= 0.f) continue;
+    atomicAdd(&cnt0[h], 1);
+    double s_own = 0.0, s_56 = 0.0;   // sigma of the keypoint's own limb term / of the right shoulder's term for the LEFT shoulder
+    bool has_own = false, has_56 = false;
+    const int parent = c_kpParent[pm][k];
+    if (parent >= 0) {
+      const PostKp &pk = pk_[c_kp2fusion[pm][parent]];
+      if (pk.score > 0.f && c_limbLength[pm][k] > 0) {
+        s_own = 0.075 * (se3d_jdist(kp.joint, pk.joint) - c_limbLength[pm][k]) / c_limbLSigma[pm][k];
+        has_own = true;
+      } else if (pm == SE3D_POSE_SIMPLE && k == 6) {  // RShoulder special case (S3D:875-881): its own share
+        const PostKp &ls = pk_[c_kp2fusion[pm][5]];
+        if (ls.score > 0.f) { s_own = 0.075 * (se3d_jdist(kp.joint, ls.joint) - 0.35) / 0.15; has_own = true; }
+      }
+    }
+    if (pm == SE3D_POSE_SIMPLE && k == 5) {  // ... and the left shoulder's share of it, added after its own term (k = 5 precedes k = 6)
+      const PostKp &rs = pk_[c_kp2fusion[pm][6]];
+      const int par6 = c_kpParent[pm][6];
+      const bool rs_case1 = par6 >= 0 && pk_[c_kp2fusion[pm][par6]].score > 0.f && c_limbLength[pm][6] > 0;
+      if (rs.score > 0.f && par6 >= 0 && !rs_case1) { s_56 = 0.075 * (se3d_jdist(rs.joint, kp.joint) - 0.35) / 0.15; has_56 = true; }
+    }
+    if (has_own || has_56) {
+      se3d_keypoint3d &g = persons[h].keypoints[fu];
+      double c0 = g.cov[0], c3 = g.cov[3], c5 = g.cov[5];
+      if (has_own) { c0 += s_own * s_own; c3 += s_own * s_own; c5 += s_own * s_own; }
+      if (has_56) { c0 += s_56 * s_56; c3 += s_56 * s_56; c5 += s_56 * s_56; }
+      g.cov[0] = c0; g.cov[3] = c3; g.cov[5] = c5;
+    }
+  }
+  // ---- distance to the root (S3D:937-953): items (person, fusion slot); every lane reads the root before anything is removed ----
+  for (int it = lane; it < nh * SE3D_NFU; it += 64) {
+    const int h = it / SE3D_NFU, k = it - h * SE3D_NFU;
+    const PostKp *p = sk + (size_t)h * SE3D_NFU;
+    double root[3] = {0, 0, 0};
+    float root_score = 0.f;
+    if (p[FU_MidHip].score > 0.f) {
+      for (int a = 0; a < 3; ++a) root[a] = p[FU_MidHip].joint[a];
+      root_score = p[FU_MidHip].score;
+    } else if (p[FU_LHip].score > 0.f && p[FU_RHip].score > 0.f) {
+      for (int a = 0; a < 3; ++a) root[a] = (p[FU_LHip].joint[a] + p[FU_RHip].joint[a]) / 2.;
+      root_score = (p[FU_LHip].score + p[FU_RHip].score) / 2.f;
+    }
+    bool rm = false;
+    if (root_score > 0.f) rm = !(p[k].score > 0.f) || se3d_jdist(root, p[k].joint) > 2.0;
+    term[it] = rm ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int it = lane; it < nh * SE3D_NFU; it += 64)
+    if (term[it] != 0.0) {
+      const int h = it / SE3D_NFU, k = it - h * SE3D_NFU;
+      se3d_zero_kp(persons[h].keypoints[k]);
+      PostKp z; z.joint[0] = z.joint[1] = z.joint[2] = 0.0; z.score = 0.f; z._pad = 0.f;
+      sk[it] = z;
+      atomicAdd(&dec[h], 1);
+    }
+  __syncthreads();
+  bool al = false;
+  if (lane < nh && !few && nv_l >= 2) {
+    const PostKp *p = sk + (size_t)lane * SE3D_NFU;
+    int num_valid = cnt0[lane] - dec[lane];
+    double feet = 0.0;  // S3D:955-966
+    if (p[FU_LAnkle].score > 0.f && p[FU_RAnkle].score > 0.f) feet = (p[FU_LAnkle].joint[2] + p[FU_RAnkle].joint[2]) / 2.0;
+    else if (p[FU_LAnkle].score > 0.f) feet = p[FU_LAnkle].joint[2];
+    else if (p[FU_RAnkle].score > 0.f) feet = p[FU_RAnkle].joint[2];
+    if (fabs(feet) > 0.50) num_valid = 0;
+    al = num_valid > 9;
+  }
+  unsigned long long alive = __ballot(al);
+  // ---- duplicate merge (S3D:984-996): as in se3d_k_postprocess_wave2, distances from the LDS copy ----
+  for (int i = 0; i < nh; ++i) {
+    if (!((alive >> i) & 1ull)) continue;
+    int from = i + 1;
+    for (;;) {
+      if (!(alive >> from)) break;
+      const int nj = nh - from;
+      for (int it = lane; it < nj * SE3D_NFU; it += 64) {
+        const int jo = it / SE3D_NFU, k = it - jo * SE3D_NFU, jj = from + jo;
+        double t = -1.0;
+        if ((alive >> jj) & 1ull) {
+          const PostKp &a = sk[(size_t)i * SE3D_NFU + k], &bb = sk[(size_t)jj * SE3D_NFU + k];
+          if (a.score > 0.f && bb.score > 0.f) {
+            const double dx = a.joint[0] - bb.joint[0], dy = a.joint[1] - bb.joint[1], dz = a.joint[2] - bb.joint[2];
+            t = sqrt(dx * dx + dy * dy + dz * dz);
+          }
+        }
+        term[it] = t;
+      }
+      __syncthreads();
+      bool hit = false;
+      if (lane < nj && ((alive >> (from + lane)) & 1ull)) {
+        int nu = 0;
+        double dist = 0.0;
+        for (int k = 0; k < SE3D_NFU; ++k) {
+          const double t = term[lane * SE3D_NFU + k];
+          if (t >= 0.0) { dist += t; ++nu; }
+        }
+        hit = (nu > 0 ? dist / nu : MAX_COSTS) < 0.20;
+      }
+      const unsigned long long hb = __ballot(hit);
+      if (!hb) break;
+      const int jm = from + __ffsll((long long)hb) - 1;
+      __syncthreads();
+      if (lane < SE3D_NFU) {  // merge_persons (S3D:410-423), one joint per lane: hypP (all fields) and the LDS copy (position, score)
+        se3d_keypoint3d &k1 = persons[i].keypoints[lane];
+        const se3d_keypoint3d &k2 = persons[jm].keypoints[lane];
+        PostKp &c1 = sk[(size_t)i * SE3D_NFU + lane];
+        const PostKp &c2 = sk[(size_t)jm * SE3D_NFU + lane];
+        const double total = (double)(c1.score + c2.score);
+        if (total > 0.0) {
+          for (int a = 0; a < 3; ++a) { c1.joint[a] = ((double)c1.score * c1.joint[a] + (double)c2.score * c2.joint[a]) / total; k1.joint[a] = c1.joint[a]; }
+          c1.score = fmaxf(c1.score, c2.score);
+          k1.score = c1.score;
+          for (int a = 0; a < 6; ++a) k1.cov[a] = (k1.cov[a] + k2.cov[a]) / 2.0;
+        }
+      }
+      __threadfence_block();   // the merged covariances were formed from values other lanes wrote to hypP (inflation, removals) ...
+      __syncthreads();
+      alive &= ~(1ull << jm);
+      from = jm + 1;
+      if (from >= nh) break;
+    }
+  }
+  // ---- compaction in ascending hypothesis order + association table in original detection indices ----
+  __threadfence_block();   // ... and so is the copy below: hypP holds the modifications of every lane of this wavefront
+  __syncthreads();
+  const int total = __popcll(alive);
+  int pos = 0;
+  for (unsigned long long m = alive; m; m &= m - 1ull, ++pos) {
+    const int h = __ffsll((long long)m) - 1;
+    const uint2 *src = reinterpret_cast<const uint2 *>(&persons[h]);
+    uint2 *dst = reinterpret_cast<uint2 *>(&D.outP[(size_t)f * H + pos]);
+    for (int w = lane; w < words2; w += 64) dst[w] = src[w];
+    if (lane == 0) D.out_hyp[(size_t)f * H + pos] = h;
+  }
+  if (lane == 0) {
+    D.out_count[f] = total;
+    if (few) {  // the reference returns before building any hypothesis (S3D:557-560)
+      atomicOr(&D.flags[f], SE3D_FLAG_FEW_CAMERAS);
+      D.nhyp[f] = 0;
+    }
+  }
+  for (int i = lane; i < nh * N; i += 64) {
+    const int h = i / N, c = i - h * N;
+    const int k = D.assoc[((size_t)f * H + h) * N + c];
+    D.out_assoc[((size_t)f * H + h) * N + c] = (k >= 0) ? D.orig[((size_t)(f * N + c)) * P + k] : -1;
+  }
+}
+static size_t se3d_post_wave3_lds_bytes(int H) { return (size_t)H * SE3D_NFU * (sizeof(PostKp) + 8) + (size_t)H * 8; }
 static size_t se3d_post_wave2_lds_bytes(int H) { return sizeof(se3d_person3d) * (size_t)H + (size_t)H * SE3D_NFU * 8 + (size_t)H * 8; }
 
 __global__ __launch_bounds__(256) void se3d_k_postprocess(Se3dDev D) {
@@ -2572,10 +2758,12 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   if (phases & 2) se3d_launch_triangulation(D, st);
   if (ev && (phases & 2)) (void)hipEventRecord(ev[4], st);
   if (phases & 4) {
-    const char *e_post = getenv("SE3D_POST_WAVE");   // A/B switch read per launch: 1 = one lane per person (round 1), default = lane-parallel
+    const char *e_post = getenv("SE3D_POST_WAVE");   // A/B switch read per launch: 1 = one lane per person (round 1), 2 = lane-parallel with the persons in LDS, default = persons in place
     if (H <= SE3D_POST_SMALL_H && e_post && atoi(e_post) == 1)
       hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), sizeof(se3d_person3d) * (size_t)H, st, D);
-    else if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave2, dim3(B), dim3(64), se3d_post_wave2_lds_bytes(H), st, D);
+    else if (H <= SE3D_POST_SMALL_H && e_post && atoi(e_post) == 2)
+      hipLaunchKernelGGL(se3d_k_postprocess_wave2, dim3(B), dim3(64), se3d_post_wave2_lds_bytes(H), st, D);
+    else if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave3, dim3(B), dim3(64), se3d_post_wave3_lds_bytes(H), st, D);
     else hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
   }
   if (ev && (phases & 4)) (void)hipEventRecord(ev[5], st);
