@@ -1559,8 +1559,10 @@ __global__ __launch_bounds__(256, 3) void se3d_k_triangulate(Se3dDev D) {
 // A hypothesis is split into TH_PARTS one-wavefront workgroups of 6 + 6 + 5 joints (round 1 / first half of round 2: two of 9 + 8).  Three
 // parts: 8 KB of LDS per wavefront instead of 11.6 KB, so that LDS no longer caps a CU at 13 wavefronts; with the kernel compiled for four
 // wavefronts per SIMD (128 VGPRs, 56 B of scratch outside the sample loop) 16 are resident instead of 12; and 10 / 12 lanes per joint
-// walk the 4n + 1 sigma samples of a 12-view joint in 3 + 3 trips instead of 4 + 4.  13.09 -> 12.38 (three parts) -> 11.50 ms per
-// 98 304 frames; with two parts the same compilation for 128 VGPRs was SLOWER (15.8 vs 14.8 ms at the time: spills without the occupancy).
+// walk the 4n + 1 sigma samples of a 12-view joint in 3 + 3 trips instead of 4 + 4.  13.09 -> 12.38 (three parts) -> 11.50 (128 VGPRs, 56 B of
+// scratch per lane: 5.5 GB of HBM traffic per launch) -> 11.17 ms per 98 304 frames with position / score written before the sample loop and
+// the sample counts in LDS (12 B of scratch left); with two parts the same compilation for 128 VGPRs was SLOWER (15.8 vs 14.8 ms at the
+// time: spills without the occupancy).
 #ifndef TH_PARTS
 #define TH_PARTS 3
 #endif
@@ -1575,6 +1577,7 @@ struct TriHypLds {
   float X[TH_JOINTS], Y[TH_JOINTS], Z[TH_JOINTS];
   int cam[TH_MAXV], det[TH_MAXV];
   int n[TH_JOINTS];
+  int cnt[TH_JOINTS];                                  // sigma samples of the joint (0: no covariance from this kernel)
   int bad[TH_JOINTS];                                  // a usable view's 2x2 covariance is not SPD: the joint's 3-D covariance is NaN
   unsigned char vidx[TH_JOINTS][TH_MAXV];              // usable views of a joint in ascending camera order
 };
@@ -1695,17 +1698,37 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
     if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX * se3d_rcp64(err)));  // S3D:840-841
   }
   const unsigned long long slowmask = __ballot(slow);
+  // Position, score and the default-constructed slots are written HERE, before the sample loop: nothing below needs X, Y, Z, the score or the
+  // flags in registers any more (the loop re-reads the centre from LDS), which is what lets the kernel fit 128 VGPRs without spilling them
+  // across the loop (56 B of scratch per lane otherwise: 5.5 GB of HBM traffic per 98 304-frame launch in the PMC passes).
+  {
+    se3d_person3d &person0 = D.hypP[(size_t)f * H + h];
+    const int pm_ = D.d.pose_method;
+  if (lane < JN && !slow) {  // slow joints are written (all fields) by se3d_k_triangulate_slow
+    se3d_keypoint3d *kp = &person0.keypoints[c_kp2fusion[pm_][jbase + lane]];
+    if (active) {
+      kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
+      kp->score = avg_score; kp->_pad = 0.f;
+    } else {  // < 2 usable views (S3D:734-736): default-constructed slot
+      kp->joint[0] = kp->joint[1] = kp->joint[2] = 0.0;
+      kp->score = 0.f; kp->_pad = 0.f;
+      for (int e = 0; e < 6; ++e) kp->cov[e] = 0.0;
+    }
+  }
+  // ---- joints that need outlier rejection are redone by se3d_k_triangulate_slow (per-joint routine) ----
+  if (lane == 0) D.tri_slow[((size_t)f * H + h) * 3 + part_] = (uint32_t)slowmask << jbase;
+  if (lane == 0 && TH_PARTS == 2 && part_ == 0) D.tri_slow[((size_t)f * H + h) * 3 + 2] = 0u;
+  }
   // ---- sigma points (S3D:471-523): lanes are tied to joints (64 / JN lanes each) and stride over the joint's 4n + 1 samples, so the
   // joint's Gram matrix, start vector and centre stay in registers and the weighted outer products of the deviations are
   // accumulated in registers as the samples are solved (no sample buffer: 7 KB of LDS less, the DLT rows of the views stay
   // resident instead of being rebuilt for every sample); the partial sums of a joint's lanes are added in lane order.
-  const int cnt = (active && !slow) ? 4 * nj + 1 : 0;
-  se3d_person3d &person = D.hypP[(size_t)f * H + h];
-  const int pm_ = D.d.pose_method;
+  if (lane < JN) S.cnt[lane] = (active && !slow) ? 4 * nj + 1 : 0;
+  __builtin_amdgcn_wave_barrier();
   {
     const int LPJ = 64 / JN;                       // 10 lanes per joint (6 joints) or 12 (5 joints)
     const int jl = lane / LPJ, j = min(jl, JN - 1), s0 = lane - LPJ * jl;
-    const int cntj = jl < JN ? __shfl(cnt, j) : 0;
+    const int cntj = jl < JN ? S.cnt[j] : 0;
     const int n = S.n[j];
     const float Xj = S.X[j], Yj = S.Y[j], Zj = S.Z[j];
     const float bsc = sqrtf((float)(2 * n) + 0.5f);
@@ -1746,27 +1769,13 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
     __builtin_amdgcn_wave_barrier();
     for (int it = lane; it < JN * 6; it += 64) {
       const int jj = it / 6, e = it - jj * 6;
-      if (__shfl(cnt, jj) == 0) continue;
+      if (S.cnt[jj] == 0) continue;
       double acc = 0.0;
       for (int q = 0; q < LPJ; ++q) acc += part[jj * LPJ + q][e];
       if (S.bad[jj]) acc = (double)__builtin_nanf("");
-      person.keypoints[c_kp2fusion[pm_][jbase + jj]].cov[e] = (double)(float)acc;
+      D.hypP[(size_t)blockIdx.y * D.d.H + blockIdx.x / TH_PARTS].keypoints[c_kp2fusion[D.d.pose_method][jbase + jj]].cov[e] = (double)(float)acc;   // (address re-formed here: not carried across the loop)
     }
   }
-  if (lane < JN && !slow) {  // slow joints are written (all fields) by se3d_k_triangulate_slow
-    se3d_keypoint3d *kp = &person.keypoints[c_kp2fusion[pm_][jbase + lane]];
-    if (active) {
-      kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
-      kp->score = avg_score; kp->_pad = 0.f;
-    } else {  // < 2 usable views (S3D:734-736): default-constructed slot
-      kp->joint[0] = kp->joint[1] = kp->joint[2] = 0.0;
-      kp->score = 0.f; kp->_pad = 0.f;
-      for (int e = 0; e < 6; ++e) kp->cov[e] = 0.0;
-    }
-  }
-  // ---- joints that need outlier rejection are redone by se3d_k_triangulate_slow (per-joint routine) ----
-  if (lane == 0) D.tri_slow[((size_t)f * H + h) * 3 + part_] = (uint32_t)slowmask << jbase;
-  if (lane == 0 && TH_PARTS == 2 && part_ == 0) D.tri_slow[((size_t)f * H + h) * 3 + 2] = 0u;
 }
 
 // Outlier-rejection path of the hypothesis kernel: one wavefront per hypothesis redoes the flagged joints (usually none) with the
