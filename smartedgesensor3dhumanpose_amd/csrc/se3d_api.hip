@@ -341,7 +341,7 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
   ok = ok && dev_alloc(c, &D.assoc, (size_t)B * H * N) && dev_alloc(c, &D.nviews, (size_t)B * H) && dev_alloc(c, &D.nhyp, (size_t)B);
   ok = ok && dev_alloc(c, &D.C, (size_t)B * H * P) && dev_alloc(c, &D.mask, (size_t)B * H * P) && dev_alloc(c, &D.mwork, (size_t)B * H * P);
   ok = ok && dev_alloc(c, &D.flags, (size_t)B);
-  ok = ok && dev_alloc(c, &D.tri_slow, (size_t)B * H * 3);
+  ok = ok && dev_alloc(c, &D.tri_slow, (size_t)B * H * 4);
   ok = ok && dev_alloc(c, &D.hypP, (size_t)B * H) && dev_alloc(c, &D.keep, (size_t)B * H) && dev_alloc(c, &D.outP, (size_t)B * H);
   ok = ok && dev_alloc(c, &D.out_count, (size_t)B) && dev_alloc(c, &D.out_hyp, (size_t)B * H) && dev_alloc(c, &D.out_assoc, (size_t)B * H * N);
   ok = ok && dev_alloc(c, &c->pair_ab, (size_t)np);

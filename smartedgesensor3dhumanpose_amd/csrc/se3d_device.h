@@ -56,7 +56,7 @@ struct Se3dDev {
   // triangulation + output
   se3d_person3d *hypP;   // [B][H]
   uint8_t *keep;         // [B][H]
-  uint32_t *tri_slow;    // [B][H][3] joints of a hypothesis (per workgroup of the hypothesis kernel: 2 or 3 parts) that need the outlier-rejection path
+  uint32_t *tri_slow;    // [B][H][4] joints of a hypothesis (per workgroup of the hypothesis kernel: up to 4 parts) that need the outlier-rejection path
   se3d_person3d *outP;   // [B][H]
   int32_t *out_count;    // [B]
   int32_t *out_hyp;      // [B][H]

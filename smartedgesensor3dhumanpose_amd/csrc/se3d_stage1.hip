@@ -1716,8 +1716,9 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
     }
   }
   // ---- joints that need outlier rejection are redone by se3d_k_triangulate_slow (per-joint routine) ----
-  if (lane == 0) D.tri_slow[((size_t)f * H + h) * 3 + part_] = (uint32_t)slowmask << jbase;
-  if (lane == 0 && TH_PARTS == 2 && part_ == 0) D.tri_slow[((size_t)f * H + h) * 3 + 2] = 0u;
+  if (lane == 0) D.tri_slow[((size_t)f * H + h) * 4 + part_] = (uint32_t)slowmask << jbase;
+  if (lane == 0 && part_ == 0)
+    for (int q = TH_PARTS; q < 4; ++q) D.tri_slow[((size_t)f * H + h) * 4 + q] = 0u;
   }
   // ---- sigma points (S3D:471-523): lanes are tied to joints (64 / JN lanes each) and stride over the joint's 4n + 1 samples, so the
   // joint's Gram matrix, start vector and centre stay in registers and the weighted outer products of the deviations are
@@ -1762,7 +1763,8 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
       }
     }
     __builtin_amdgcn_wave_barrier();   // all samples done: the rows are dead, their LDS takes the partial sums
-    static_assert(sizeof(S.rows) >= 64 * 6 * sizeof(double) && offsetof(TriHypLds, rows) % 8 == 0, "partial sums alias the rows");
+    // (rows, and behind them re / vs / G, are all dead once the samples are done)
+    static_assert(offsetof(TriHypLds, X) - offsetof(TriHypLds, rows) >= 64 * 6 * sizeof(double) && offsetof(TriHypLds, rows) % 8 == 0, "partial sums alias the rows");
     double (*part)[6] = reinterpret_cast<double (*)[6]>(&S.rows[0][0][0]);
 #pragma unroll
     for (int e = 0; e < 6; ++e) part[lane][e] = cv[e];
@@ -1790,7 +1792,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_slow(Se3dDev D, int n_e
   uint32_t mymask = 0u;
   if (e < n_entries) {
     const int f = e / H, h = e - f * H;
-    if (h < D.nhyp[f] && D.nviews[e] >= 2 && (D.d.shard_world <= 1 || h % D.d.shard_world == D.d.shard_rank)) mymask = D.tri_slow[(size_t)e * 3] | D.tri_slow[(size_t)e * 3 + 1] | D.tri_slow[(size_t)e * 3 + 2];
+    if (h < D.nhyp[f] && D.nviews[e] >= 2 && (D.d.shard_world <= 1 || h % D.d.shard_world == D.d.shard_rank)) mymask = D.tri_slow[(size_t)e * 4] | D.tri_slow[(size_t)e * 4 + 1] | D.tri_slow[(size_t)e * 4 + 2] | D.tri_slow[(size_t)e * 4 + 3];
   }
   unsigned long long todo = __ballot(mymask != 0u);
   if (!todo) return;
