@@ -27,7 +27,7 @@ __device__ unsigned long long g_lm_stamps[16];
 #define LM_STAMP(idx)                                                                 \
   {                                                                                   \
     const unsigned long long now_ = __builtin_readcyclecounter();                     \
-    if (threadIdx.x == 0) atomicAdd(&g_lm_stamps[idx], now_ - stamp_prev_);           \
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicAdd(&g_lm_stamps[idx], now_ - stamp_prev_);   /* one workgroup in 64: the counters are one cache line */ \
     stamp_prev_ = __builtin_readcyclecounter();                                       \
   }
 #define LM_STAMP_INIT unsigned long long stamp_prev_ = __builtin_readcyclecounter();
@@ -1255,7 +1255,7 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
   }
   LM_STAMP(6)  // outputs
 #ifdef SE3D_LM_STAMPS
-  if (threadIdx.x == 0) { atomicAdd(&g_lm_stamps[8], 1ull); atomicAdd(&g_lm_stamps[9], (unsigned long long)iterations); }
+  if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&g_lm_stamps[8], 1ull); atomicAdd(&g_lm_stamps[9], (unsigned long long)iterations); }
 #endif
 }
 template <int MODE>
@@ -1786,7 +1786,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
     pending = accepted;
     __builtin_amdgcn_wave_barrier();
 #ifdef SE3D_LM_STAMPS
-    if (threadIdx.x == 0) atomicAdd(&g_lm_stamps[9], 1ull);
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicAdd(&g_lm_stamps[9], 1ull);
 #endif
   }
   if (valid && !wh_ok && measured) { x[0] = m[0]; x[1] = m[1]; x[2] = m[2]; }  // optimisation failed: output the measurements (PP:751-758)
@@ -1904,7 +1904,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
   }
   LM_STAMP(6)  // outputs
 #ifdef SE3D_LM_STAMPS
-  if (threadIdx.x == 0) atomicAdd(&g_lm_stamps[8], 1ull);
+  if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicAdd(&g_lm_stamps[8], 1ull);
 #endif
 }
 
@@ -2268,7 +2268,7 @@ __device__ __forceinline__ void s2_track_near_flat(const Se3dStage2 &Q, int s, i
 #endif
 #ifdef SE3D_LM_STAMPS
 #define WK_STAMP_INIT unsigned long long wk_prev_ = __builtin_readcyclecounter();
-#define WK_STAMP(idx) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_lm_stamps[idx], now_ - wk_prev_); wk_prev_ = now_; }
+#define WK_STAMP(idx) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) atomicAdd(&g_lm_stamps[idx], now_ - wk_prev_); wk_prev_ = now_; }
 #else
 #define WK_STAMP_INIT
 #define WK_STAMP(idx)
