@@ -1153,6 +1153,68 @@ __device__ __forceinline__ bool se3d_null_invit(const double g[10], const double
   return conv && (x0 == x0);
 }
 
+// Sample solves of the unscented transform: the same LDL^T inverse iteration, carried WITHOUT normalising the iterate.  What a sample
+// contributes is the dehomogenised point w[0..2] / w[3], which is scale-free, so the unit-length iterate, its sign fix and the L1 test on
+// unit vectors of se3d_null_invit (18 of its 42 instructions per step) are replaced by the point itself: p_k = w_k / w_k[3] after every
+// step, exit when two successive points agree to tol x (1 + |p|_1).  |w| grows by ~1 / lambda_4 per step (<= 1e30 / trace with the pivot
+// floor below); from the third step on the iterate is rescaled by the last pivot, so eight steps stay far inside the fp64 range.
+// Returns false (caller: Jacobi fallback) when the steps do not settle or the point is not finite (w[3] = 0: point at infinity).
+// NW: Newton steps on the hardware reciprocal seeds (1: ~2^-46, ample for a float32 sample; 2: ~1 ulp, the main solves).
+#define SE3D_SIGMA_PTOL 5e-7   // samples: |dp|_1 < 5e-7 (1 + |p|_1), at least as strict as the former 1e-6 on unit homogeneous vectors
+#define SE3D_MAIN_PTOL 1e-13   // main solves: converged to fp64 (the point is published as float32)
+template <int NW = 1>
+__device__ __forceinline__ bool se3d_null_invit_point(const double g[10], const double v0[4], double p[3], const double tol = SE3D_SIGMA_PTOL) {
+  const double tr = g[0] + g[4] + g[7] + g[9];
+  const double tiny = 1e-30 * tr;
+  double d0 = g[0];
+  if (!(d0 > tiny)) return false;
+  const double i0 = se3d_rcp64<NW>(d0);
+  const double l10 = g[1] * i0, l20 = g[2] * i0, l30 = g[3] * i0;
+  double d1 = __builtin_fma(-l10, g[1], g[4]);
+  if (!(d1 > tiny)) return false;
+  const double i1 = se3d_rcp64<NW>(d1);
+  const double t21 = __builtin_fma(-l20, g[1], g[5]), t31 = __builtin_fma(-l30, g[1], g[6]);
+  const double l21 = t21 * i1, l31 = t31 * i1;
+  double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, g[2], g[7]));
+  if (!(d2 > tiny)) return false;
+  const double i2 = se3d_rcp64<NW>(d2);
+  const double t32 = __builtin_fma(-l31, t21, __builtin_fma(-l30, g[2], g[8]));
+  const double l32 = t32 * i2;
+  double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, t31, __builtin_fma(-l30, g[3], g[9])));
+  if (!(d3 > tiny)) d3 = tiny;  // numerically singular: the solve still returns the null direction
+  const double i3 = se3d_rcp64<NW>(d3);
+  double x0 = v0[0], x1 = v0[1], x2 = v0[2], x3 = v0[3];
+  double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+  bool conv = false;
+  for (int it = 0; it < 8; ++it) {
+    const double y0 = x0, y1 = __builtin_fma(-l10, y0, x1), y2 = __builtin_fma(-l21, y1, __builtin_fma(-l20, y0, x2)),
+                 y3 = __builtin_fma(-l32, y2, __builtin_fma(-l31, y1, __builtin_fma(-l30, y0, x3)));
+    const double w3 = y3 * i3, w2 = __builtin_fma(-l32, w3, y2 * i2), w1 = __builtin_fma(-l31, w3, __builtin_fma(-l21, w2, y1 * i1)),
+                 w0 = __builtin_fma(-l30, w3, __builtin_fma(-l20, w2, __builtin_fma(-l10, w1, y0 * i0)));
+    const double iw = se3d_rcp64<NW>(w3);
+    const double p0 = w0 * iw, p1 = w1 * iw, p2 = w2 * iw;
+    if (it >= 1) {
+      const double e = fabs(p0 - q0) + fabs(p1 - q1) + fabs(p2 - q2);
+      if (e < tol * (1.0 + fabs(p0) + fabs(p1) + fabs(p2))) { q0 = p0; q1 = p1; q2 = p2; conv = true; break; }
+    }
+    q0 = p0; q1 = p1; q2 = p2;
+    const double sc = it >= 1 ? d3 : 1.0;
+    x0 = w0 * sc; x1 = w1 * sc; x2 = w2 * sc; x3 = w3 * sc;
+  }
+  p[0] = q0; p[1] = q1; p[2] = q2;
+  return conv;
+}
+
+// Dehomogenised null vector of g: the inverse iteration above, the Jacobi solver when it does not settle.
+template <int NW = 1>
+__device__ __forceinline__ void se3d_solve_point(const double g[10], const double v0[4], double p[3], const double tol = SE3D_SIGMA_PTOL) {
+  if (se3d_null_invit_point<NW>(g, v0, p, tol)) return;
+  double e4[4];
+  se3d_eig4_smallest(g, e4);
+  const double iw = se3d_rcp64<NW>(e4[3]);
+  p[0] = e4[0] * iw; p[1] = e4[1] * iw; p[2] = e4[2] * iw;
+}
+
 // rows of the DLT system for one view: r0 = normalize(x*P2 - P0), r1 = normalize(y*P2 - P1)  (float, S3D:446-449)
 __device__ __forceinline__ void se3d_dlt_rows(const float *__restrict__ M, float x, float y, float r0[4], float r1[4]) {
 #pragma unroll
@@ -1232,6 +1294,18 @@ __device__ __forceinline__ float se3d_reproj1(const float *__restrict__ M, float
   return sqrtf(dx * dx + dy * dy);
 }
 
+// The 2x2 keypoint covariance in normalised image coordinates and its lower Cholesky factor (S3D:476-480).  They feed only the sigma offsets
+// of the unscented transform, whose covariance is compared at 1e-3: hardware reciprocal / square root (1 ulp each) instead of four IEEE
+// division and two IEEE square-root sequences per (joint, view).  A factor that is not finite (non-SPD input) stays not finite.
+__device__ __forceinline__ void se3d_norm_cov2(const float cov[3], float fx, float fy, float &k00, float &k01, float &k11) {
+  const float ifx = __builtin_amdgcn_rcpf(fx), ify = __builtin_amdgcn_rcpf(fy);
+  k00 = cov[0] * (ifx * ifx); k01 = cov[1] * (ifx * ify); k11 = cov[2] * (ify * ify);
+}
+__device__ __forceinline__ void se3d_chol2(float k00, float k01, float k11, float &l11, float &l21, float &l22) {
+  l11 = __builtin_amdgcn_sqrtf(k00);
+  l21 = k01 * __builtin_amdgcn_rcpf(l11);
+  l22 = __builtin_amdgcn_sqrtf(k11 - l21 * l21);
+}
 // Row N on the fly (S3D:312-333): keypoint j of the detection in FILTERED slot k of camera c, read from the caller's raw Person2D payload
 // and normalised in registers with the expressions of se3d_k_normalize (bit-identical values; no normalised copy in HBM).
 // Returns conf >= 0.30 (the triangulation gate, S3D:724-732); kp = (x, y, conf), kc = (a00, a01, a11) only when it does.
@@ -1243,7 +1317,7 @@ __device__ __forceinline__ bool se3d_load_norm(const Se3dDev &D, int f, int c, i
   if (!(r.score >= TRI_THRESH)) return false;
   const float fx = D.K[c * 4 + 0], fy = D.K[c * 4 + 1], cx = D.K[c * 4 + 2], cy = D.K[c * 4 + 3];
   kp = make_float4((r.x - cx) / fx, (r.y - cy) / fy, r.score, 0.f);
-  kc = make_float4(r.cov[0] / (fx * fx), r.cov[1] / (fx * fy), r.cov[2] / (fy * fy), 0.f);
+  se3d_norm_cov2(r.cov, fx, fy, kc.x, kc.y, kc.z);
   return true;
 }
 // The triangulation kernels write EVERY field of the hypothesis slots they own (no zero-fill pass before them).
@@ -1291,9 +1365,9 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
       const int pos = n + __popcll(bl & ((1ull << lane) - 1ull));
       T.x[pos] = kp.x; T.y[pos] = kp.y; T.cf[pos] = kp.z;
       {  // lower Cholesky factor of the view's 2x2 keypoint covariance (S3D:476-480), shared by the view's four sigma points
-        const float l11 = sqrtf(kc.x);
-        const float l21 = kc.y / l11;
-        T.ca[pos] = l11; T.cb[pos] = l21; T.cc[pos] = sqrtf(kc.z - l21 * l21);
+        float l11, l21, l22;
+        se3d_chol2(kc.x, kc.y, kc.z, l11, l21, l22);
+        T.ca[pos] = l11; T.cb[pos] = l21; T.cc[pos] = l22;
       }
       T.cam[pos] = c;
     }
@@ -1380,11 +1454,10 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   };
 
   build(n);
-  double ev[4];
+  double pw[3];
   const double e4start[4] = {0.0, 0.0, 0.0, 1.0};  // the null vector (X, Y, Z, 1)/|.| of a finite point always has a w component
-  if (!se3d_null_invit(gw_, e4start, ev)) se3d_eig4_smallest(gw_, ev);
-  const double iw0 = se3d_rcp64(ev[3]);
-  float X = (float)(ev[0] * iw0), Y = (float)(ev[1] * iw0), Z = (float)(ev[2] * iw0);
+  se3d_solve_point<2>(gw_, e4start, pw, SE3D_MAIN_PTOL);
+  float X = (float)pw[0], Y = (float)pw[1], Z = (float)pw[2];
   double err = reproj(n, X, Y, Z);
   float avg_score = (float)(sconf / n);
 
@@ -1414,8 +1487,8 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
       remove_view(n, bestIndex);
       n = 2;
       build(n);
-      if (!se3d_null_invit(gw_, e4start, ev)) se3d_eig4_smallest(gw_, ev);
-      { const double iw = se3d_rcp64(ev[3]); X = (float)(ev[0] * iw); Y = (float)(ev[1] * iw); Z = (float)(ev[2] * iw); }
+      se3d_solve_point<2>(gw_, e4start, pw, SE3D_MAIN_PTOL);
+      X = (float)pw[0]; Y = (float)pw[1]; Z = (float)pw[2];
       err = reproj(n, X, Y, Z);
       avg_score = (T.cf[0] + T.cf[1]) / 2.0f;
     }
@@ -1436,9 +1509,10 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
 #pragma unroll
         for (int k = 0; k < 4; ++k) { w0[k] = T.r0[k][i] * cf; w1[k] = T.r1[k][i] * cf; }
         se3d_gram_add<true>(g, w0); se3d_gram_add<true>(g, w1);
-        double e4[4];
-        if (!se3d_null_invit(g, ev, e4)) se3d_eig4_smallest(g, e4);
-        { const double iw = se3d_rcp64(e4[3]); cx_ = (float)(e4[0] * iw); cy_ = (float)(e4[1] * iw); cz_ = (float)(e4[2] * iw); }
+        double pc[3];
+        const double wstart[4] = {pw[0], pw[1], pw[2], 1.0};   // warm start: the solution with all views
+        se3d_solve_point<2>(g, wstart, pc, SE3D_MAIN_PTOL);
+        cx_ = (float)pc[0]; cy_ = (float)pc[1]; cz_ = (float)pc[2];
         double se = 0.0, sc = 0.0;
         for (int v = 0; v < n; ++v) {
           if (v == i) continue;
@@ -1488,11 +1562,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   const float wgt = 1.0f / (2.0f * ((float)dim + 0.5f));  // all weights equal because 2*kappa == 1
   double cv[6] = {0, 0, 0, 0, 0, 0};
   const int nsamp = 4 * n + 1;
-  double vstart[4];  // warm start of the sigma-point solves: the (weighted) solution in normalised homogeneous form
-  {
-    const double hn = 1.0 / sqrt((double)X * X + (double)Y * Y + (double)Z * Z + 1.0);
-    vstart[0] = X * hn; vstart[1] = Y * hn; vstart[2] = Z * hn; vstart[3] = hn;
-  }
+  const double vstart[4] = {(double)X, (double)Y, (double)Z, 1.0};  // warm start of the sigma-point solves: the published point (the iteration is scale-free)
   // samples 0 .. 2n: centre + class A (both rows rebuilt); 2n + 1 .. 4n: class B (y-only samples, r1 alone) — see se3d_sigma_gram
   for (int s0 = 0; s0 < nsamp; s0 += 64) {
     const int s = s0 + lane;
@@ -1508,10 +1578,9 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
         for (int k = 0; k < 4; ++k) { o0[k] = T.r0[k][c]; o1[k] = T.r1[k][c]; }
         se3d_sigma_gram(g, sRt + 12 * T.cam[c], T.x[c], T.y[c], T.ca[c], T.cb[c], T.cc[c], bsc, o0, o1, (clsB ? 3 : 1) + (q & 1));
       }
-      double e4[4];
-      if (!se3d_null_invit<1>(g, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(g, e4);
-      const double iw = se3d_rcp64<1>(e4[3]);
-      const float sx = (float)(e4[0] * iw) - X, sy = (float)(e4[1] * iw) - Y, sz = (float)(e4[2] * iw) - Z;
+      double pt[3];
+      se3d_solve_point(g, vstart, pt);
+      const float sx = (float)pt[0] - X, sy = (float)pt[1] - Y, sz = (float)pt[2] - Z;
       const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
       cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
     }
@@ -1572,8 +1641,7 @@ struct TriHypLds {
   float ca[TH_JOINTS][TH_MAXV], cb[TH_JOINTS][TH_MAXV], cc[TH_JOINTS][TH_MAXV];  // Cholesky factor of the 2x2 keypoint covariance
   float rows[TH_JOINTS][TH_MAXV][8];                   // DLT rows r0, r1 of every (joint, view); at the very end: 64 x 6 partial covariance sums
   float re[TH_JOINTS][TH_MAXV];                        // reprojection error of the weighted solution per (joint, view)
-  double vs[TH_JOINTS][4];                             // unit homogeneous start vector of the sigma-point solves
-  double G[TH_JOINTS][21];                             // unweighted Gram (10), weighted Gram (10), sum of confidences
+  double G[TH_JOINTS][20];                             // unweighted Gram (10), weighted Gram (10)
   float X[TH_JOINTS], Y[TH_JOINTS], Z[TH_JOINTS];
   int cam[TH_MAXV], det[TH_MAXV];
   int n[TH_JOINTS];
@@ -1585,119 +1653,168 @@ struct TriHypLds {
 #ifndef TH_WPE
 #define TH_WPE 4
 #endif
+#ifdef SE3D_LM_STAMPS
+__device__ unsigned long long g_th_stamps[16];
+#define TH_STAMP_INIT unsigned long long th_prev_ = __builtin_readcyclecounter();
+#define TH_STAMP(idx) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && ((blockIdx.x + 7 * blockIdx.y) & 63) == 0) atomicAdd(&g_th_stamps[idx], now_ - th_prev_); th_prev_ = now_; }
+extern "C" void se3d_diag_th_stamps(unsigned long long *out16, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_th_stamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_th_stamps), z, sizeof(z)); }
+}
+#else
+#define TH_STAMP_INIT
+#define TH_STAMP(idx)
+#endif
 __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) {
   __shared__ TriHypLds S;   // one wavefront per workgroup
   __shared__ float sRt[12 * TH_MAXV];
+  __shared__ float sK[4 * TH_MAXV];
   const int lane = threadIdx.x;
   const int f = blockIdx.y, h = blockIdx.x / TH_PARTS, part_ = blockIdx.x - h * TH_PARTS;
   const int jbase = part_ * TH_JOINTS, JN = min(TH_JOINTS, SE3D_NKP - jbase);  // joints jbase .. jbase + JN - 1
   const int N = D.d.N, H = D.d.H;
-  if (h >= D.nhyp[f]) return;
-  if (D.nviews[f * H + h] < 2) return;
+  TH_STAMP_INIT
+  // Everything whose address is known at entry is requested at once (hypothesis count, view count, association row, camera matrices): one
+  // memory round trip, then the exits.  (h < H: the association row of an unused slot is readable.)
+  const int nh_ = D.nhyp[f], nvw_ = D.nviews[f * H + h];
+  const int ka = (lane < N) ? D.assoc[((size_t)f * H + h) * N + lane] : -1;
+  float rt_[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) rt_[q] = (lane + 64 * q < 12 * N) ? D.Rt[lane + 64 * q] : 0.f;
+  const float kin_ = (lane < 4 * N) ? D.K[lane] : 0.f;   // N <= 16: one intrinsic per lane
+  if (h >= nh_) return;
+  if (nvw_ < 2) return;
   if (D.d.shard_world > 1 && h % D.d.shard_world != D.d.shard_rank) return;  // hypothesis shard: another rank's hypothesis
-  for (int i = lane; i < 12 * N; i += 64) sRt[i] = D.Rt[i];
-  __syncthreads();
-  // ---- attached cameras of the hypothesis, ascending ----
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (lane + 64 * q < 12 * N) sRt[lane + 64 * q] = rt_[q];
+  sK[lane] = kin_;
+  TH_STAMP(0)  // entry loads
+  // ---- attached cameras of the hypothesis, ascending; the camera's lane resolves the filtered slot to the raw detection index once ----
   int nv;
   {
-    const int k = (lane < N) ? D.assoc[((size_t)f * H + h) * N + lane] : -1;
-    const unsigned long long bl = __ballot(k >= 0);
+    const unsigned long long bl = __ballot(ka >= 0);
     nv = __popcll(bl);
-    if (k >= 0) { const int pos = __popcll(bl & ((1ull << lane) - 1ull)); S.cam[pos] = lane; S.det[pos] = k; }
+    if (ka >= 0) {
+      const size_t cbase = ((size_t)(f * N + lane)) * D.d.P;
+      const int pos = __popcll(bl & ((1ull << lane) - 1ull));
+      S.cam[pos] = lane; S.det[pos] = (int)D.orig[cbase + ka];
+    }
   }
   __builtin_amdgcn_wave_barrier();
   if (part_ == 0) se3d_zero_unused_slots(D.hypP[(size_t)f * H + h], D.d.pose_method, lane);
-  // ---- points: lanes over (joint, view); row N on the fly from the raw payload ----
-  for (int idx = lane; idx < JN * nv; idx += 64) {
-    const int j = idx / nv, v = idx - j * nv;
-    float4 kp, kc;
-    const bool ok = se3d_load_norm(D, f, S.cam[v], S.det[v], jbase + j, kp, kc);  // S3D:724-732
-    S.x[j][v] = kp.x; S.y[j][v] = kp.y; S.cf[j][v] = ok ? kp.z : -1.f;
-    if (ok) {
-      const float l11 = sqrtf(kc.x);       // lower Cholesky factor of the 2x2 keypoint covariance (S3D:476-480)
-      const float l21 = kc.y / l11;
-      S.ca[j][v] = l11; S.cb[j][v] = l21; S.cc[j][v] = sqrtf(kc.z - l21 * l21);
-      float r0[4], r1[4];
-      se3d_dlt_rows(sRt + 12 * S.cam[v], kp.x, kp.y, r0, r1);
+  TH_STAMP(1)  // association row, unused slots
+  // ---- points: lane <-> (joint, view slot), 16 view slots per joint and four joints per trip, so that a joint's views sit in one 16-lane
+  // group: the list of usable views (ascending), their number and the bad-covariance flag come from two ballots instead of a serial
+  // scan of the views by one lane per joint.  Row N on the fly from the raw payload (expressions of se3d_load_norm). ----
+  static_assert(TH_MAXV == 16 && TH_JOINTS <= 8, "lane <-> (joint, view slot) mapping, two trips");
+  const int vslot = lane & 15, cslot = vslot < nv ? S.cam[vslot] : 0;
+  se3d_keypoint2d raw2[2];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { S.rows[j][v][k] = r0[k]; S.rows[j][v][4 + k] = r1[k]; }
+  for (int t = 0; t < 2; ++t) {   // the payload of both trips is requested before either is worked on
+    const int j = 4 * t + (lane >> 4);
+    raw2[t].x = raw2[t].y = 0.f; raw2[t].score = -1.f; raw2[t].cov[0] = raw2[t].cov[1] = raw2[t].cov[2] = 0.f;
+    if (j < JN && vslot < nv) raw2[t] = D.raw[((size_t)(f * N + cslot)) * D.d.P + S.det[vslot]].keypoints[jbase + j];
+  }
+  const float fx = sK[cslot * 4 + 0], fy = sK[cslot * 4 + 1], cx = sK[cslot * 4 + 2], cy = sK[cslot * 4 + 3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int j = 4 * t + (lane >> 4), v = vslot;
+    const bool in = j < JN && v < nv;
+    const se3d_keypoint2d r = raw2[t];
+    bool ok = false, badv = false;
+    if (in) {
+      float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
+      float px = 0.f, py = 0.f;
+      ok = r.score >= TRI_THRESH;   // S3D:724-732
+      if (ok) {
+        px = (r.x - cx) / fx; py = (r.y - cy) / fy;
+        float k00, k01, k11, l11, l21, l22;
+        se3d_norm_cov2(r.cov, fx, fy, k00, k01, k11);
+        se3d_chol2(k00, k01, k11, l11, l21, l22);
+        S.ca[j][v] = l11; S.cb[j][v] = l21; S.cc[j][v] = l22;
+        badv = !(isfinite(l11) && isfinite(l21) && isfinite(l22));
+        se3d_dlt_rows(sRt + 12 * cslot, px, py, r0, r1);
+      }
+      S.x[j][v] = px; S.y[j][v] = py; S.cf[j][v] = ok ? r.score : -1.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { S.rows[j][v][k] = r0[k]; S.rows[j][v][4 + k] = r1[k]; }   // zero rows for an unusable view: the Gram loop adds them
+    }
+    const unsigned seg = (unsigned)(__ballot(ok) >> (lane & 48)) & 0xFFFFu, segbad = (unsigned)(__ballot(badv) >> (lane & 48)) & 0xFFFFu;
+    if (ok) S.vidx[j][__popc(seg & ((1u << v) - 1u))] = (unsigned char)v;
+    if (in && v == 0) { S.n[j] = __popc(seg); S.bad[j] = segbad ? 1 : 0; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  TH_STAMP(2)  // points + rows + view lists
+  // ---- Gram matrices: lane <-> (joint, entry), unweighted and weighted entry together; accumulation over the view slots in ascending order
+  // like the per-joint kernel (an unusable view's rows are zero: adding them changes nothing).  The sum of confidences is formed by the score
+  // loop below (same terms, same order). ----
+  {
+    const int j = lane / 10, e = lane - 10 * j;
+    if (j < JN) {
+      double au = 0.0, aw = 0.0;
+      if (S.n[j] >= 2) {
+        const int gi = (int)((0x3221110000ull >> (4 * e)) & 0xFull), gj = (int)((0x3323213210ull >> (4 * e)) & 0xFull);
+#pragma unroll 4
+        for (int v = 0; v < nv; ++v) {
+          const float cf = S.cf[j][v];
+          const float a0 = S.rows[j][v][gi], b0 = S.rows[j][v][gj], a1 = S.rows[j][v][4 + gi], b1 = S.rows[j][v][4 + gj];
+          au = __builtin_fma((double)a0, (double)b0, au);
+          au = __builtin_fma((double)a1, (double)b1, au);
+          const float wa0 = a0 * cf, wb0 = b0 * cf, wa1 = a1 * cf, wb1 = b1 * cf;
+          aw = __builtin_fma((double)wa0, (double)wb0, aw);
+          aw = __builtin_fma((double)wa1, (double)wb1, aw);
+        }
+      }
+      S.G[j][e] = au; S.G[j][10 + e] = aw;
     }
   }
   __builtin_amdgcn_wave_barrier();
-  if (lane < JN) {
-    int n = 0;
-    bool bad = false;
-    for (int v = 0; v < nv; ++v)
-      if (S.cf[lane][v] >= 0.f) {
-        S.vidx[lane][n++] = (unsigned char)v;
-        bad |= !(isfinite(S.ca[lane][v]) && isfinite(S.cb[lane][v]) && isfinite(S.cc[lane][v]));
-      }
-    S.n[lane] = n;
-    S.bad[lane] = bad ? 1 : 0;
-  }
-  __builtin_amdgcn_wave_barrier();
-  // ---- Gram matrices: lanes over (joint, entry); accumulation over the views in list order like the per-joint kernel ----
-  for (int it = lane; it < JN * 21; it += 64) {
-    const int j = it / 21, e = it - j * 21;
-    const int nn = S.n[j];
-    double acc = 0.0;
-    if (nn >= 2) {
-      const int ge = e < 10 ? e : (e < 20 ? e - 10 : 0);
-      const int gi = (int)((0x3221110000ull >> (4 * ge)) & 0xFull), gj = (int)((0x3323213210ull >> (4 * ge)) & 0xFull);
-      const bool weighted = e >= 10;
-      for (int k = 0; k < nn; ++k) {
-        const int v = S.vidx[j][k];
-        const float cf = S.cf[j][v];
-        if (e == 20) { acc += (double)cf; continue; }
-        float a0 = S.rows[j][v][gi], b0 = S.rows[j][v][gj], a1 = S.rows[j][v][4 + gi], b1 = S.rows[j][v][4 + gj];
-        if (weighted) { a0 = a0 * cf; b0 = b0 * cf; a1 = a1 * cf; b1 = b1 * cf; }
-        acc = __builtin_fma((double)a0, (double)b0, acc);
-        acc = __builtin_fma((double)a1, (double)b1, acc);
-      }
-    }
-    S.G[j][e] = acc;
-  }
-  __builtin_amdgcn_wave_barrier();
+  TH_STAMP(4)  // Gram
   // ---- weighted solve, reprojection error and score: lane <-> joint ----
   const int nj = (lane < JN) ? S.n[lane] : 0;
   const bool active = nj >= 2;
   bool slow = false;
   float X = 0.f, Y = 0.f, Z = 0.f, avg_score = 0.f;
   if (active) {
-    double gw_[10], ev[4];
+    double gw_[10], pw[3];
 #pragma unroll
     for (int k = 0; k < 10; ++k) gw_[k] = S.G[lane][10 + k];
     const double e4start[4] = {0.0, 0.0, 0.0, 1.0};
-    if (!se3d_null_invit(gw_, e4start, ev)) se3d_eig4_smallest(gw_, ev);
-    const double iw0 = se3d_rcp64(ev[3]);
-    X = (float)(ev[0] * iw0); Y = (float)(ev[1] * iw0); Z = (float)(ev[2] * iw0);
-    S.X[lane] = X; S.Y[lane] = Y; S.Z[lane] = Z;
-    const double hn = se3d_rsq64((double)X * X + (double)Y * Y + (double)Z * Z + 1.0);   // scale of the samples' start vector: any accuracy will do
-    S.vs[lane][0] = X * hn; S.vs[lane][1] = Y * hn; S.vs[lane][2] = Z * hn; S.vs[lane][3] = hn;
+    se3d_solve_point<2>(gw_, e4start, pw, SE3D_MAIN_PTOL);
+    X = (float)pw[0]; Y = (float)pw[1]; Z = (float)pw[2];
+    S.X[lane] = X; S.Y[lane] = Y; S.Z[lane] = Z;   // also the start (X, Y, Z, 1) of the samples' solves
   }
   __builtin_amdgcn_wave_barrier();
-  for (int idx = lane; idx < JN * nv; idx += 64) {  // reprojection errors: lanes over (joint, view)
-    const int j = idx / nv, v = idx - j * nv;
-    if (S.n[j] >= 2 && S.cf[j][v] >= 0.f) S.re[j][v] = se3d_reproj1(sRt + 12 * S.cam[v], S.X[j], S.Y[j], S.Z[j], S.x[j][v], S.y[j][v]);
+  TH_STAMP(5)  // weighted solve
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {  // confidence-weighted reprojection errors: lane <-> (joint, view slot); 0 for a view that is not usable
+    const int j = 4 * t + (lane >> 4), v = vslot;
+    if (j < JN && v < nv) {
+      const float cf = S.cf[j][v];
+      float ce = 0.f;
+      if (S.n[j] >= 2 && cf >= 0.f) ce = cf * se3d_reproj1(sRt + 12 * cslot, S.X[j], S.Y[j], S.Z[j], S.x[j][v], S.y[j][v]);
+      S.re[j][v] = ce;
+    }
   }
   __builtin_amdgcn_wave_barrier();
   if (active) {
     double se = 0.0, sc = 0.0;
-    for (int k = 0; k < nj; ++k) {  // summed in view order like the per-joint kernel
-      const int v = S.vidx[lane][k];
-      const float cf = S.cf[lane][v];
-      const float e = S.re[lane][v];
-      se += (double)(cf * e);
-      sc += (double)cf;
+#pragma unroll 4
+    for (int v = 0; v < nv; ++v) {  // summed in view order like the per-joint kernel (the terms of the views that are not usable are zero)
+      se += (double)S.re[lane][v];
+      sc += (double)fmaxf(S.cf[lane][v], 0.f);
     }
     // quotients by reciprocal (hardware seed + two Newton steps, <= 1 ulp of fp64 from the IEEE quotient) instead of three fp64 division
     // sequences on nine lanes: the error only meets thresholds, the score is published as float32
     const double err = se * se3d_rcp64(sc);
-    avg_score = (float)(S.G[lane][20] * se3d_rcp64((double)nj));
+    avg_score = (float)(sc * se3d_rcp64((double)nj));   // sc: the confidences summed in view order (what G[.][20] used to hold)
     slow = err > REPROJ_MAX && nj >= 3;  // outlier rejection needed (S3D:748-838): per-joint routine below
     if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX * se3d_rcp64(err)));  // S3D:840-841
   }
   const unsigned long long slowmask = __ballot(slow);
+  TH_STAMP(6)  // reprojection errors + score
   // Position, score and the default-constructed slots are written HERE, before the sample loop: nothing below needs X, Y, Z, the score or the
   // flags in registers any more (the loop re-reads the centre from LDS), which is what lets the kernel fit 128 VGPRs without spilling them
   // across the loop (56 B of scratch per lane otherwise: 5.5 GB of HBM traffic per 98 304-frame launch in the PMC passes).
@@ -1725,6 +1842,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
   // accumulated in registers as the samples are solved (no sample buffer: 7 KB of LDS less, the DLT rows of the views stay
   // resident instead of being rebuilt for every sample); the partial sums of a joint's lanes are added in lane order.
   if (lane < JN) S.cnt[lane] = (active && !slow) ? 4 * nj + 1 : 0;
+  TH_STAMP(7)  // position / score writes
   __builtin_amdgcn_wave_barrier();
   {
     const int LPJ = 64 / JN;                       // 10 lanes per joint (6 joints) or 12 (5 joints)
@@ -1734,7 +1852,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
     const float Xj = S.X[j], Yj = S.Y[j], Zj = S.Z[j];
     const float bsc = sqrtf((float)(2 * n) + 0.5f);
     const float wgt = 1.0f / (2.0f * ((float)(2 * n) + 0.5f));  // all weights equal because 2*kappa == 1
-    const double vstart[4] = {S.vs[j][0], S.vs[j][1], S.vs[j][2], S.vs[j][3]};
+    const double vstart[4] = {(double)Xj, (double)Yj, (double)Zj, 1.0};   // the iteration is scale-free: the published point is its start
     double gj[10], cv[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 10; ++k) gj[k] = S.G[j][k];
@@ -1754,14 +1872,14 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
           for (int k = 0; k < 4; ++k) { o0[k] = S.rows[j][v][k]; o1[k] = S.rows[j][v][4 + k]; }
           se3d_sigma_gram(gq, sRt + 12 * S.cam[v], S.x[j][v], S.y[j][v], S.ca[j][v], S.cb[j][v], S.cc[j][v], bsc, o0, o1, (cls == 0 ? 1 : 3) + (q & 1));
         }
-        double e4[4];
-        if (!se3d_null_invit<1>(gq, vstart, e4, SE3D_SIGMA_TOL)) se3d_eig4_smallest(gq, e4);
-        const double iw = se3d_rcp64<1>(e4[3]);
-        const float sx = (float)(e4[0] * iw) - Xj, sy = (float)(e4[1] * iw) - Yj, sz = (float)(e4[2] * iw) - Zj;
+        double pt[3];
+        se3d_solve_point(gq, vstart, pt);
+        const float sx = (float)pt[0] - Xj, sy = (float)pt[1] - Yj, sz = (float)pt[2] - Zj;
         const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
         cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
       }
     }
+    TH_STAMP(8)  // sigma samples
     __builtin_amdgcn_wave_barrier();   // all samples done: the rows are dead, their LDS takes the partial sums
     // (rows, and behind them re / vs / G, are all dead once the samples are done)
     static_assert(offsetof(TriHypLds, X) - offsetof(TriHypLds, rows) >= 64 * 6 * sizeof(double) && offsetof(TriHypLds, rows) % 8 == 0, "partial sums alias the rows");
@@ -1777,6 +1895,10 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
       if (S.bad[jj]) acc = (double)__builtin_nanf("");
       D.hypP[(size_t)blockIdx.y * D.d.H + blockIdx.x / TH_PARTS].keypoints[c_kp2fusion[D.d.pose_method][jbase + jj]].cov[e] = (double)(float)acc;   // (address re-formed here: not carried across the loop)
     }
+    TH_STAMP(9)  // covariance sums + writes
+#ifdef SE3D_LM_STAMPS
+    if (threadIdx.x == 0 && ((blockIdx.x + 7 * blockIdx.y) & 63) == 0) atomicAdd(&g_th_stamps[15], 1ull);
+#endif
   }
 }
 
