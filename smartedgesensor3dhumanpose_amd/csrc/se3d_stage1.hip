@@ -1160,7 +1160,8 @@ __device__ __forceinline__ bool se3d_null_invit(const double g[10], const double
 // floor below); from the third step on the iterate is rescaled by the last pivot, so eight steps stay far inside the fp64 range.
 // Returns false (caller: Jacobi fallback) when the steps do not settle or the point is not finite (w[3] = 0: point at infinity).
 // NW: Newton steps on the hardware reciprocal seeds (1: ~2^-46, ample for a float32 sample; 2: ~1 ulp, the main solves).
-#define SE3D_SIGMA_PTOL 5e-7   // samples: |dp|_1 < 5e-7 (1 + |p|_1), at least as strict as the former 1e-6 on unit homogeneous vectors
+#define SE3D_SIGMA_PTOL 5e-6   // samples: |dp|_1 < 5e-6 (1 + |p|_1), i.e. an update below ~2.5e-5 m; the accepted iterate is one contraction (<= 1.5e-2) better: < 4e-7 m.
+                               // (5e-7: same covariances to all printed digits, 2 % slower; 3e-5: the outlier scenes' covariance error grows from 7e-5 to 5e-4)
 #define SE3D_MAIN_PTOL 1e-13   // main solves: converged to fp64 (the point is published as float32)
 template <int NW = 1>
 __device__ __forceinline__ bool se3d_null_invit_point(const double g[10], const double v0[4], double p[3], const double tol = SE3D_SIGMA_PTOL) {
