@@ -1162,7 +1162,8 @@ __device__ __forceinline__ bool se3d_null_invit(const double g[10], const double
 // NW: Newton steps on the hardware reciprocal seeds (1: ~2^-46, ample for a float32 sample; 2: ~1 ulp, the main solves).
 #define SE3D_SIGMA_PTOL 5e-6   // samples: |dp|_1 < 5e-6 (1 + |p|_1), i.e. an update below ~2.5e-5 m; the accepted iterate is one contraction (<= 1.5e-2) better: < 4e-7 m.
                                // (5e-7: same covariances to all printed digits, 2 % slower; 3e-5: the outlier scenes' covariance error grows from 7e-5 to 5e-4)
-#define SE3D_MAIN_PTOL 1e-13   // main solves: converged to fp64 (the point is published as float32)
+#define SE3D_MAIN_PTOL 1e-10   // main solves: update below 1e-10 (1 + |p|_1); the accepted iterate is one contraction (lambda_4 / lambda_3 <= ~1e-2) better, i.e.
+                               // <= 1e-12 and typically 1e-14 .. 1e-16: converged for a point that is published as float32 (1e-13 cost one more step for nothing)
 template <int NW = 1>
 __device__ __forceinline__ bool se3d_null_invit_point(const double g[10], const double v0[4], double p[3], const double tol = SE3D_SIGMA_PTOL) {
   const double tr = g[0] + g[4] + g[7] + g[9];
