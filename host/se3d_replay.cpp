@@ -10,6 +10,7 @@
 #include <fstream>
 #include <iostream>
 
+#include "se3d_markers.hpp"
 #include "se3d_nodes.hpp"
 
 template <typename T> static T rd(std::ifstream& f) { T v; f.read(reinterpret_cast<char*>(&v), sizeof(T)); return v; }
@@ -65,6 +66,8 @@ int main(int argc, char** argv) {
       wr<int32_t>(rout, n_cam);
     }
     int n_tuples = 0;
+    se3d::FusedMarkerState marker_state;   // the nodes' MarkerArray publications (S3D:1172-1174, PP:945): built per frame, totals reported below
+    size_t n_markers3d = 0, n_markers_fused = 0, n_markers_deleted = 0;
     auto handle_tuple = [&](const std::vector<person_msgs::Person2DList>& people) {
       ++n_tuples;
       person_msgs::PersonCovList persons3d, fused, pred;
@@ -75,6 +78,14 @@ int main(int argc, char** argv) {
       write_list(out, persons3d);
       write_list(out, fused);
       write_list(out, pred);
+      {
+        visualization_msgs::MarkerArray skel3d_msg, vis_markers;
+        se3d::skeleton_markers(persons3d, prm.pose_method, skel3d_msg);
+        se3d::fused_markers(fused, vis_markers);
+        const size_t n_add = vis_markers.markers.size();
+        marker_state.update(fused, vis_markers);
+        n_markers3d += skel3d_msg.markers.size(); n_markers_fused += n_add; n_markers_deleted += vis_markers.markers.size() - n_add;
+      }
       if (reproj) {
         pred.header.frame_id = "base";
         std::vector<person_msgs::Person2DList> per_cam;
@@ -120,6 +131,7 @@ int main(int argc, char** argv) {
     }
     out.seekp(0);
     wr<int32_t>(out, n_tuples);  // tuples actually handled (with the synchroniser in front the last frames may still be held back)
+    std::cout << "Markers: " << n_markers3d << " skeleton_3d, " << n_markers_fused << " fused, " << n_markers_deleted << " deleted" << std::endl;
     for (size_t i = 0; i < skel.timings_ms().size(); ++i)  // S3D:1234-1241
       if (skel.timing_counts()[i] > 0) {
         std::cout << "Triangulation: ";
