@@ -27,8 +27,12 @@ def test_cpp_replay_matches_oracle(tmp_path, oracle, extr_rig, demo_params):
         m.fb_delay = 0.08                       # feedback delay measured on the sensors
     scene, out = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")
     Hn.write_replay_scene(scene, extr_rig, demo_params, stream)
-    subprocess.check_call([os.path.join(ROOT, "host", "se3d_replay"), scene, out])
+    log = subprocess.run([os.path.join(ROOT, "host", "se3d_replay"), scene, out], check=True, capture_output=True, text=True).stdout
     got = Hn.read_replay_output(out)
+    # the MarkerArray publications of the two nodes (host/se3d_markers.hpp): a line list and a sphere list per published person
+    marker_line = [ln for ln in log.split("\n") if ln.startswith("Markers:")][0].replace(",", "").split()
+    assert int(marker_line[1]) == 2 * sum(len(g[0].persons) for g in got if g is not None)
+    assert int(marker_line[3]) == 2 * sum(len(g[1].persons) for g in got if g is not None)
 
     pp = oracle.PosePrior(demo_params)
     h1 = Hn.Skeleton3DHarness(16, lambda fr: oracle.triangulate(extr_rig, demo_params, fr, capacity=64, hyp_capacity=64))
