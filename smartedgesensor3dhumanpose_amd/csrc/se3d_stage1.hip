@@ -1710,18 +1710,19 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
   // ---- points: lane <-> (joint, view slot), 16 view slots per joint and four joints per trip, so that a joint's views sit in one 16-lane
   // group: the list of usable views (ascending), their number and the bad-covariance flag come from two ballots instead of a serial
   // scan of the views by one lane per joint.  Row N on the fly from the raw payload (expressions of se3d_load_norm). ----
-  static_assert(TH_MAXV == 16 && TH_JOINTS <= 8, "lane <-> (joint, view slot) mapping, two trips");
+  static_assert(TH_MAXV == 16, "lane <-> (joint, view slot) mapping");
+  constexpr int TH_TRIPS = (TH_JOINTS + 3) / 4;   // four joints per trip
   const int vslot = lane & 15, cslot = vslot < nv ? S.cam[vslot] : 0;
-  se3d_keypoint2d raw2[2];
+  se3d_keypoint2d raw2[TH_TRIPS];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {   // the payload of both trips is requested before either is worked on
+  for (int t = 0; t < TH_TRIPS; ++t) {   // the payload of all trips is requested before any is worked on
     const int j = 4 * t + (lane >> 4);
     raw2[t].x = raw2[t].y = 0.f; raw2[t].score = -1.f; raw2[t].cov[0] = raw2[t].cov[1] = raw2[t].cov[2] = 0.f;
     if (j < JN && vslot < nv) raw2[t] = D.raw[((size_t)(f * N + cslot)) * D.d.P + S.det[vslot]].keypoints[jbase + j];
   }
   const float fx = sK[cslot * 4 + 0], fy = sK[cslot * 4 + 1], cx = sK[cslot * 4 + 2], cy = sK[cslot * 4 + 3];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < TH_TRIPS; ++t) {
     const int j = 4 * t + (lane >> 4), v = vslot;
     const bool in = j < JN && v < nv;
     const se3d_keypoint2d r = raw2[t];
@@ -1752,9 +1753,9 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
   // ---- Gram matrices: lane <-> (joint, entry), unweighted and weighted entry together; accumulation over the view slots in ascending order
   // like the per-joint kernel (an unusable view's rows are zero: adding them changes nothing).  The sum of confidences is formed by the score
   // loop below (same terms, same order). ----
-  {
-    const int j = lane / 10, e = lane - 10 * j;
-    if (j < JN) {
+  for (int it = lane; it < JN * 10; it += 64) {   // one trip for up to six joints
+    const int j = it / 10, e = it - 10 * j;
+    {
       double au = 0.0, aw = 0.0;
       if (S.n[j] >= 2) {
         const int gi = (int)((0x3221110000ull >> (4 * e)) & 0xFull), gj = (int)((0x3323213210ull >> (4 * e)) & 0xFull);
@@ -1791,7 +1792,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
   __builtin_amdgcn_wave_barrier();
   TH_STAMP(5)  // weighted solve
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {  // confidence-weighted reprojection errors: lane <-> (joint, view slot); 0 for a view that is not usable
+  for (int t = 0; t < TH_TRIPS; ++t) {  // confidence-weighted reprojection errors: lane <-> (joint, view slot); 0 for a view that is not usable
     const int j = 4 * t + (lane >> 4), v = vslot;
     if (j < JN && v < nv) {
       const float cf = S.cf[j][v];
