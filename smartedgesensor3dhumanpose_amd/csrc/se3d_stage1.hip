@@ -1083,12 +1083,8 @@ __device__ __forceinline__ void se3d_eig4_smallest(const double g[10], double v[
   v[3] = (m == 0) ? V[3][0] : (m == 1) ? V[3][1] : (m == 2) ? V[3][2] : V[3][3];
 }
 
-// Null vector of a 4x4 SPD Gram matrix by inverse iteration on its LDL^T factorisation, warm-started from the null
-// vector of a nearby matrix (the sigma points of the unscented transform perturb two rows of the base system, so the
-// start error is ~1e-3 and the contraction per step is lambda_4 / lambda_3 << 1).  Returns false when 8 steps do not
-// reach a 1e-13 update (caller falls back to the Jacobi solver): same eigenvector, ~15x fewer fp64 operations.
-// 1/x and 1/sqrt(x) to ~1 ulp from the hardware seeds (v_rcp_f64 / v_rsq_f64) and two Newton steps; the inverse
-// iteration below only needs them as scale factors, not correctly rounded.
+// 1/x to ~1 ulp (two Newton steps) or ~2^-46 (one) from the hardware seed v_rcp_f64; the inverse iteration below only needs scale factors,
+// not correctly rounded quotients.
 template <int NEWTON = 2>
 __device__ __forceinline__ double se3d_rcp64(double x) {
   double y = __builtin_amdgcn_rcp(x);
@@ -1096,70 +1092,18 @@ __device__ __forceinline__ double se3d_rcp64(double x) {
   for (int k = 0; k < NEWTON; ++k) y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
   return y;
 }
-template <int NEWTON = 2>
-__device__ __forceinline__ double se3d_rsq64(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-#pragma unroll
-  for (int k = 0; k < NEWTON; ++k) y = __builtin_fma(__builtin_fma(-x * y, y, 1.0), 0.5 * y, y);
-  return y;
-}
 
-// tol: exit once two successive unit iterates differ by less than tol (L1).  The main solves use 1e-13.  The unscented-transform
-// samples start from the centre's solution (distance ~1e-3, the size of the sigma offsets) and are rounded to float32 and differenced
-// against the float32 centre.  Their first step cannot pass any useful test, so it is taken untested (SKIP = 1); the second step's update
-// is ~1e-3 x contraction (lambda_4 / lambda_3, typically 1e-4 .. 1e-6) and the iterate it returns is one further contraction more accurate
-// than that update: with SIGMA_TOL = 1e-6 the sample is good to <= 1e-10, far below float32 resolution, in two steps instead of the three
-// that a 1e-9 test took (tests/test_gpu_dlt.py::test_ut_covariance_error_budget prints the resulting error against the exact evaluation).
-#define SE3D_SIGMA_TOL 1e-6
-template <int SKIP = 0>
-__device__ __forceinline__ bool se3d_null_invit(const double g[10], const double v0[4], double v[4], const double tol = 1e-13) {
-  constexpr int NW = SKIP ? 1 : 2;   // sample solves: one Newton step on the ~2^-23 hardware seeds (2^-46) is ample for a float32 result
-  const double tr = g[0] + g[4] + g[7] + g[9];
-  const double tiny = 1e-30 * tr;
-  double d0 = g[0];
-  if (!(d0 > tiny)) return false;
-  const double i0 = se3d_rcp64<NW>(d0);
-  const double l10 = g[1] * i0, l20 = g[2] * i0, l30 = g[3] * i0;
-  double d1 = __builtin_fma(-l10, g[1], g[4]);
-  if (!(d1 > tiny)) return false;
-  const double i1 = se3d_rcp64<NW>(d1);
-  const double t21 = __builtin_fma(-l20, g[1], g[5]), t31 = __builtin_fma(-l30, g[1], g[6]);
-  const double l21 = t21 * i1, l31 = t31 * i1;
-  double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, g[2], g[7]));
-  if (!(d2 > tiny)) return false;
-  const double i2 = se3d_rcp64<NW>(d2);
-  const double t32 = __builtin_fma(-l31, t21, __builtin_fma(-l30, g[2], g[8]));
-  const double l32 = t32 * i2;
-  double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, t31, __builtin_fma(-l30, g[3], g[9])));
-  if (!(d3 > tiny)) d3 = tiny;  // numerically singular: the solve still returns the null direction
-  const double i3 = se3d_rcp64<NW>(d3);
-  double x0 = v0[0], x1 = v0[1], x2 = v0[2], x3 = v0[3];
-  bool conv = false;
-  for (int it = 0; it < 8; ++it) {
-    // L y = x ; z = D^-1 y ; L^T w = z
-    const double y0 = x0, y1 = __builtin_fma(-l10, y0, x1), y2 = __builtin_fma(-l21, y1, __builtin_fma(-l20, y0, x2)),
-                 y3 = __builtin_fma(-l32, y2, __builtin_fma(-l31, y1, __builtin_fma(-l30, y0, x3)));
-    const double w3 = y3 * i3, w2 = __builtin_fma(-l32, w3, y2 * i2), w1 = __builtin_fma(-l31, w3, __builtin_fma(-l21, w2, y1 * i1)),
-                 w0 = __builtin_fma(-l30, w3, __builtin_fma(-l20, w2, __builtin_fma(-l10, w1, y0 * i0)));
-    const double nn = se3d_rsq64<NW>(__builtin_fma(w3, w3, __builtin_fma(w2, w2, __builtin_fma(w1, w1, w0 * w0))));
-    const double sgn = __builtin_fma(w3, x3, __builtin_fma(w2, x2, __builtin_fma(w1, x1, w0 * x0))) < 0.0 ? -nn : nn;
-    const double n0 = w0 * sgn, n1 = w1 * sgn, n2 = w2 * sgn, n3 = w3 * sgn;
-    if (it < SKIP) { x0 = n0; x1 = n1; x2 = n2; x3 = n3; continue; }
-    const double e = fabs(n0 - x0) + fabs(n1 - x1) + fabs(n2 - x2) + fabs(n3 - x3);
-    x0 = n0; x1 = n1; x2 = n2; x3 = n3;
-    if (e < tol) { conv = true; break; }
-  }
-  v[0] = x0; v[1] = x1; v[2] = x2; v[3] = x3;
-  return conv && (x0 == x0);
-}
-
-// Sample solves of the unscented transform: the same LDL^T inverse iteration, carried WITHOUT normalising the iterate.  What a sample
-// contributes is the dehomogenised point w[0..2] / w[3], which is scale-free, so the unit-length iterate, its sign fix and the L1 test on
-// unit vectors of se3d_null_invit (18 of its 42 instructions per step) are replaced by the point itself: p_k = w_k / w_k[3] after every
-// step, exit when two successive points agree to tol x (1 + |p|_1).  |w| grows by ~1 / lambda_4 per step (<= 1e30 / trace with the pivot
-// floor below); from the third step on the iterate is rescaled by the last pivot, so eight steps stay far inside the fp64 range.
+// Dehomogenised null vector of a 4x4 SPD Gram matrix by inverse iteration on its LDL^T factorisation (same eigenvector as the Jacobi solver
+// above, ~15x fewer fp64 operations; the main solves start from (0, 0, 0, 1), the sigma points of the unscented transform — which perturb
+// one or two rows of the base system — from the centre's solution, ~1e-3 away; the contraction per step is lambda_4 / lambda_3 << 1).
+// The iterate is carried WITHOUT normalising it.  What every caller uses is the dehomogenised point w[0..2] / w[3], which is scale-free, so
+// the unit-length iterate, its sign fix and an L1 test on unit vectors (18 of 42 instructions per step in the first half of round 2) are
+// replaced by the point itself: p_k = w_k / w_k[3] after every step, exit when two successive points agree to tol x (1 + |p|_1).  The first
+// step can pass no useful test and is taken untested.  |w| grows by ~1 / lambda_4 per step (<= 1e30 / trace with the pivot floor below);
+// from the third step on the iterate is rescaled by the last pivot, so eight steps stay far inside the fp64 range.
 // Returns false (caller: Jacobi fallback) when the steps do not settle or the point is not finite (w[3] = 0: point at infinity).
 // NW: Newton steps on the hardware reciprocal seeds (1: ~2^-46, ample for a float32 sample; 2: ~1 ulp, the main solves).
+// (tests/test_gpu_dlt.py::test_ut_covariance_error_budget prints the samples' resulting error against the exact evaluation.)
 #define SE3D_SIGMA_PTOL 5e-6   // samples: |dp|_1 < 5e-6 (1 + |p|_1), i.e. an update below ~2.5e-5 m; the accepted iterate is one contraction (<= 1.5e-2) better: < 4e-7 m.
                                // (5e-7: same covariances to all printed digits, 2 % slower; 3e-5: the outlier scenes' covariance error grows from 7e-5 to 5e-4)
 #define SE3D_MAIN_PTOL 1e-10   // main solves: update below 1e-10 (1 + |p|_1); the accepted iterate is one contraction (lambda_4 / lambda_3 <= ~1e-2) better, i.e.
