@@ -261,6 +261,27 @@ def test_stage1_h36m_pose_method(extr_rig, oracle):
     node.close()
 
 
+@pytest.mark.parametrize("n_cam,persons,max_det,max_hyp", [(3, 2, 4, 8), (5, 3, 4, 8), (8, 4, 6, 16), (12, 5, 8, 16), (16, 7, 16, 32)])
+@pytest.mark.parametrize("tri", ["hyp", "joint"])
+def test_stage1_parity_small_rigs(oracle, demo_params, monkeypatch, n_cam, persons, max_det, max_hyp, tri):
+    """Rigs of 3 .. 16 cameras (the one-wavefront-per-hypothesis triangulation: view slots, ballots and lane groups at every width),
+    ragged views and low-confidence joints, several detection capacities; both triangulation kernels."""
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
+    if tri == "joint":
+        monkeypatch.setenv("SE3D_TRI", "joint")
+    rig = R.elliptical_rig(n_cam, seed=3, a=5.0, b=4.0)
+    rig.set_tensors(*rig_tensors(rig))
+    frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=persons, n_frames=6, seed=40 + n_cam, p_miss=0.15, low_score_frac=0.15,
+                                                       min_coverage=min(3, n_cam), spacing=0.9))
+    node = _node(rig, max_frames=6, max_det_per_cam=max_det, max_hyp=max_hyp)
+    n_pub = 0
+    for fr, g in zip(frames, node.triangulate_persons(frames)):
+        compare_stage1(g, oracle.triangulate(rig, demo_params, fr, capacity=max_hyp, hyp_capacity=max_hyp))
+        n_pub += g.n_persons
+    node.close()
+    assert n_pub >= persons   # the scenes do publish persons
+
+
 def test_stage1_parity_ellipse_24cam_20p_tiled(oracle, demo_params):
     """Larger P: tiled pair kernel + Hungarian in crowded early sweep steps."""
     from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
