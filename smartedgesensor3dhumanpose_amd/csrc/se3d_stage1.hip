@@ -2217,6 +2217,11 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave2(Se3dDev D) {
 // read-modify-write of the owner lane (the left shoulder's two terms by ONE lane, in the reference's order), a removed keypoint is zeroed
 // in hypP and in LDS, a merge rewrites person i in both; the published persons are then a plain hypP -> outP copy behind a fence.
 struct PostKp { double joint[3]; float score; float _pad; };
+// DEFER (default): the limb-length covariance inflation — which touches three words of nearly every keypoint — is not written back into hypP:
+// its terms wait in LDS (one double per (person, joint) plus the left shoulder's second term per person) and are added, in the reference's
+// order, where a covariance is consumed: by a merge, or by the copy into outP.  hypP is then written only by the rare removals and merges
+// instead of having every line dirtied (~1 GB of write-back per 98 304-frame launch).  DEFER = false: the read-modify-write form (A/B).
+template <bool DEFER>
 __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
   extern __shared__ __align__(16) unsigned char post_smem[];
   const int f = blockIdx.x, lane = threadIdx.x;
@@ -2225,6 +2230,8 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
   PostKp *sk = reinterpret_cast<PostKp *>(post_smem);                                 // [H][21]
   double *term = reinterpret_cast<double *>(sk + (size_t)H * SE3D_NFU);               // [H][21]
   int *cnt0 = reinterpret_cast<int *>(term + (size_t)H * SE3D_NFU), *dec = cnt0 + H;  // [H] valid input keypoints / removed fusion slots
+  double *infl = reinterpret_cast<double *>(dec + H);                                 // DEFER: [H][21] own limb term^2, then [H] the left shoulder's second term^2
+  double *infl2 = infl + (size_t)H * SE3D_NFU;
   const int nh = D.nhyp[f];
   se3d_person3d *persons = D.hypP + (size_t)f * H;
   constexpr int words2 = (int)(sizeof(se3d_person3d) / 8);
@@ -2238,9 +2245,10 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
     PostKp c;
     c.joint[0] = g.joint[0]; c.joint[1] = g.joint[1]; c.joint[2] = g.joint[2]; c.score = g.score; c._pad = 0.f;
     sk[it] = c;
+    if (DEFER) infl[it] = 0.0;
   }
   const int nv_l = (lane < nh) ? D.nviews[f * H + lane] : 0;
-  if (lane < H) { cnt0[lane] = 0; dec[lane] = 0; }
+  if (lane < H) { cnt0[lane] = 0; dec[lane] = 0; if (DEFER) infl2[lane] = 0.0; }
   __syncthreads();
   // ---- limb-length covariance inflation (S3D:861-883): items (person, input keypoint); the owner lane adds every term of its keypoint ----
   for (int it = lane; it < nh * SE3D_NKP; it += 64) {
@@ -2269,7 +2277,10 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
       const bool rs_case1 = par6 >= 0 && pk_[c_kp2fusion[pm][par6]].score > 0.f && c_limbLength[pm][6] > 0;
       if (rs.score > 0.f && par6 >= 0 && !rs_case1) { s_56 = 0.075 * (se3d_jdist(rs.joint, kp.joint) - 0.35) / 0.15; has_56 = true; }
     }
-    if (has_own || has_56) {
+    if (DEFER) {
+      if (has_own) infl[(size_t)h * SE3D_NFU + fu] = s_own * s_own;
+      if (has_56) infl2[h] = s_56 * s_56;     // only the left shoulder (fusion slot 5) has a second term
+    } else if (has_own || has_56) {
       se3d_keypoint3d &g = persons[h].keypoints[fu];
       double c0 = g.cov[0], c3 = g.cov[3], c5 = g.cov[5];
       if (has_own) { c0 += s_own * s_own; c3 += s_own * s_own; c5 += s_own * s_own; }
@@ -2301,6 +2312,7 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
       se3d_zero_kp(persons[h].keypoints[k]);
       PostKp z; z.joint[0] = z.joint[1] = z.joint[2] = 0.0; z.score = 0.f; z._pad = 0.f;
       sk[it] = z;
+      if (DEFER) { infl[it] = 0.0; if (k == FU_LShoulder) infl2[h] = 0.0; }   // the zeroed keypoint carries no inflation
       atomicAdd(&dec[h], 1);
     }
   __syncthreads();
@@ -2360,7 +2372,17 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
           for (int a = 0; a < 3; ++a) { c1.joint[a] = ((double)c1.score * c1.joint[a] + (double)c2.score * c2.joint[a]) / total; k1.joint[a] = c1.joint[a]; }
           c1.score = fmaxf(c1.score, c2.score);
           k1.score = c1.score;
-          for (int a = 0; a < 6; ++a) k1.cov[a] = (k1.cov[a] + k2.cov[a]) / 2.0;
+          double v1[6], v2[6];
+          for (int a = 0; a < 6; ++a) { v1[a] = k1.cov[a]; v2[a] = k2.cov[a]; }
+          if (DEFER) {   // the pending inflation of both keypoints, in the reference's order (own term, then the left shoulder's second one)
+            const double o1 = infl[(size_t)i * SE3D_NFU + lane], o2 = infl[(size_t)jm * SE3D_NFU + lane];
+            const double s1 = lane == FU_LShoulder ? infl2[i] : 0.0, s2 = lane == FU_LShoulder ? infl2[jm] : 0.0;
+            v1[0] = (v1[0] + o1) + s1; v1[3] = (v1[3] + o1) + s1; v1[5] = (v1[5] + o1) + s1;
+            v2[0] = (v2[0] + o2) + s2; v2[3] = (v2[3] + o2) + s2; v2[5] = (v2[5] + o2) + s2;
+            infl[(size_t)i * SE3D_NFU + lane] = 0.0;
+            if (lane == FU_LShoulder) infl2[i] = 0.0;
+          }
+          for (int a = 0; a < 6; ++a) k1.cov[a] = (v1[a] + v2[a]) / 2.0;
         }
       }
       __threadfence_block();   // the merged covariances were formed from values other lanes wrote to hypP (inflation, removals) ...
@@ -2379,7 +2401,18 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
     const int h = __ffsll((long long)m) - 1;
     const uint2 *src = reinterpret_cast<const uint2 *>(&persons[h]);
     uint2 *dst = reinterpret_cast<uint2 *>(&D.outP[(size_t)f * H + pos]);
-    for (int w = lane; w < words2; w += 64) dst[w] = src[w];
+    for (int w = lane; w < words2; w += 64) {
+      uint2 v = src[w];
+      if (DEFER && w >= 1) {   // word 0: id, score; keypoint kk: words 1 + 10 kk .. 10 + 10 kk = joint[3], (score, pad), cov[6]
+        const int kk = (w - 1) / 10, r = (w - 1) - 10 * kk;
+        if (r == 4 || r == 7 || r == 9) {   // cov[0], cov[3], cov[5]
+          double c = __builtin_bit_cast(double, v);
+          c = (c + infl[(size_t)h * SE3D_NFU + kk]) + (kk == FU_LShoulder ? infl2[h] : 0.0);
+          v = __builtin_bit_cast(uint2, c);
+        }
+      }
+      dst[w] = v;
+    }
     if (lane == 0) D.out_hyp[(size_t)f * H + pos] = h;
   }
   if (lane == 0) {
@@ -2395,7 +2428,7 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
     D.out_assoc[((size_t)f * H + h) * N + c] = (k >= 0) ? D.orig[((size_t)(f * N + c)) * P + k] : -1;
   }
 }
-static size_t se3d_post_wave3_lds_bytes(int H) { return (size_t)H * SE3D_NFU * (sizeof(PostKp) + 8) + (size_t)H * 8; }
+static size_t se3d_post_wave3_lds_bytes(int H, bool defer) { return (size_t)H * SE3D_NFU * (sizeof(PostKp) + 8) + (size_t)H * 8 + (defer ? (size_t)H * SE3D_NFU * 8 + (size_t)H * 8 : 0); }
 static size_t se3d_post_wave2_lds_bytes(int H) { return sizeof(se3d_person3d) * (size_t)H + (size_t)H * SE3D_NFU * 8 + (size_t)H * 8; }
 
 __global__ __launch_bounds__(256) void se3d_k_postprocess(Se3dDev D) {
@@ -2838,12 +2871,14 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   if (phases & 2) se3d_launch_triangulation(D, st);
   if (ev && (phases & 2)) (void)hipEventRecord(ev[4], st);
   if (phases & 4) {
-    const char *e_post = getenv("SE3D_POST_WAVE");   // A/B switch read per launch: 1 = one lane per person (round 1), 2 = lane-parallel with the persons in LDS, default = persons in place
+    const char *e_post = getenv("SE3D_POST_WAVE");   // A/B switch read per launch: 1 = one lane per person (round 1), 2 = lane-parallel with the persons in LDS, 3 = persons in place with the inflation written back, default = in place, inflation deferred
     if (H <= SE3D_POST_SMALL_H && e_post && atoi(e_post) == 1)
       hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), sizeof(se3d_person3d) * (size_t)H, st, D);
     else if (H <= SE3D_POST_SMALL_H && e_post && atoi(e_post) == 2)
       hipLaunchKernelGGL(se3d_k_postprocess_wave2, dim3(B), dim3(64), se3d_post_wave2_lds_bytes(H), st, D);
-    else if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave3, dim3(B), dim3(64), se3d_post_wave3_lds_bytes(H), st, D);
+    else if (H <= SE3D_POST_SMALL_H && e_post && atoi(e_post) == 3)
+      hipLaunchKernelGGL(se3d_k_postprocess_wave3<false>, dim3(B), dim3(64), se3d_post_wave3_lds_bytes(H, false), st, D);
+    else if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave3<true>, dim3(B), dim3(64), se3d_post_wave3_lds_bytes(H, true), st, D);
     else hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
   }
   if (ev && (phases & 4)) (void)hipEventRecord(ev[5], st);

@@ -348,15 +348,16 @@ def test_tiled_pair_kernel_equals_flat_kernel_bitwise_large(oracle, monkeypatch)
 
 
 def test_postprocess_forms_agree_bytewise(extr_rig, monkeypatch):
-    """The lane-parallel post-processing kernels (persons modified in place in hypP with a compact LDS copy: default for H <= 16; persons
-    staged in LDS: SE3D_POST_WAVE=2) against the one-lane-per-person form of round 1: plausibility filter,
+    """The lane-parallel post-processing kernels (persons in place in hypP with a compact LDS copy and the covariance inflation deferred to the
+    output copy: default for H <= 16; the same with the inflation written back: SE3D_POST_WAVE=3; persons staged in LDS: SE3D_POST_WAVE=2)
+    against the one-lane-per-person form of round 1: plausibility filter,
     limb-length covariance inflation (incl. the right-shoulder special case), duplicate merges — published persons byte for byte, on frames
     with clones (merges), a person far from its root and low-confidence joints."""
     import branch_scenes as BS
     frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=6, seed=5, pixel_noise=3.0, low_score_frac=0.2, p_miss=0.1))
     frames = frames + BS.duplicate_merge(extr_rig) + BS.root_distance_reset(extr_rig) + BS.feet_height_reject(extr_rig) + BS.outliers(extr_rig)
     res = {}
-    for name, env in (("lanes", None), ("person", "1"), ("lanes_lds", "2")):
+    for name, env in (("lanes", None), ("person", "1"), ("lanes_lds", "2"), ("lanes_rmw", "3")):
         if env:
             monkeypatch.setenv("SE3D_POST_WAVE", env)
         node = _node(extr_rig, max_frames=len(frames), max_det_per_cam=8, max_hyp=12)
@@ -365,8 +366,8 @@ def test_postprocess_forms_agree_bytewise(extr_rig, monkeypatch):
         if env:
             monkeypatch.delenv("SE3D_POST_WAVE")
     n = 0
-    for a, b, c in zip(res["lanes"], res["person"], res["lanes_lds"]):
-        for o in (b, c):
+    for a, b, c, d in zip(res["lanes"], res["person"], res["lanes_lds"], res["lanes_rmw"]):
+        for o in (b, c, d):
             assert a.n_hyp == o.n_hyp and a.n_persons == o.n_persons and a.flags == o.flags
             assert np.array_equal(a.assoc(), o.assoc())
             assert a.published().tobytes() == o.published().tobytes()
