@@ -1654,21 +1654,31 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
   // ---- points: lane <-> (joint, view slot), 16 view slots per joint and four joints per trip, so that a joint's views sit in one 16-lane
   // group: the list of usable views (ascending), their number and the bad-covariance flag come from two ballots instead of a serial
   // scan of the views by one lane per joint.  Row N on the fly from the raw payload (expressions of se3d_load_norm). ----
-  static_assert(TH_MAXV == 16, "lane <-> (joint, view slot) mapping");
-  constexpr int TH_TRIPS = (TH_JOINTS + 3) / 4;   // four joints per trip
-  const int vslot = lane & 15, cslot = vslot < nv ? S.cam[vslot] : 0;
-  se3d_keypoint2d raw2[TH_TRIPS];
+  // (joint, view) pairs packed densely over the lanes: item = lane + 64 trip, joint = item / nv, view = item % nv — one trip for up to
+  // 64 / JN views per joint (10 or 12), two for more.  The usable-view lists come from the trips' ballots, read as one 128-bit mask:
+  // the rank of a view among its joint's usable ones is a population count below its bit, wherever the joint's bits lie.
+  static_assert(TH_MAXV == 16 && TH_JOINTS * TH_MAXV <= 128, "two trips of 64 (joint, view) items at most");
+  const int nitems = JN * nv, ntrips = nitems > 64 ? 2 : 1;
+  int ij[2], iv[2], ic[2];
+  se3d_keypoint2d raw2[2];
 #pragma unroll
-  for (int t = 0; t < TH_TRIPS; ++t) {   // the payload of all trips is requested before any is worked on
-    const int j = 4 * t + (lane >> 4);
+  for (int t = 0; t < 2; ++t) {   // the payload of both trips is requested before either is worked on
+    const int item = lane + 64 * t;
+    ij[t] = item / nv; iv[t] = item - ij[t] * nv;
     raw2[t].x = raw2[t].y = 0.f; raw2[t].score = -1.f; raw2[t].cov[0] = raw2[t].cov[1] = raw2[t].cov[2] = 0.f;
-    if (j < JN && vslot < nv) raw2[t] = D.raw[((size_t)(f * N + cslot)) * D.d.P + S.det[vslot]].keypoints[jbase + j];
+    ic[t] = 0;
+    if (item < nitems) {
+      ic[t] = S.cam[iv[t]];
+      raw2[t] = D.raw[((size_t)(f * N + ic[t])) * D.d.P + S.det[iv[t]]].keypoints[jbase + ij[t]];
+    }
   }
-  const float fx = sK[cslot * 4 + 0], fy = sK[cslot * 4 + 1], cx = sK[cslot * 4 + 2], cy = sK[cslot * 4 + 3];
+  unsigned long long okm[2] = {0ull, 0ull}, badm[2] = {0ull, 0ull};
+  bool okl[2] = {false, false};
 #pragma unroll
-  for (int t = 0; t < TH_TRIPS; ++t) {
-    const int j = 4 * t + (lane >> 4), v = vslot;
-    const bool in = j < JN && v < nv;
+  for (int t = 0; t < 2; ++t) {
+    if (t >= ntrips) break;   // uniform
+    const int j = ij[t], v = iv[t], c = ic[t];
+    const bool in = lane + 64 * t < nitems;
     const se3d_keypoint2d r = raw2[t];
     bool ok = false, badv = false;
     if (in) {
@@ -1676,21 +1686,38 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
       float px = 0.f, py = 0.f;
       ok = r.score >= TRI_THRESH;   // S3D:724-732
       if (ok) {
+        const float fx = sK[c * 4 + 0], fy = sK[c * 4 + 1], cx = sK[c * 4 + 2], cy = sK[c * 4 + 3];
         px = (r.x - cx) / fx; py = (r.y - cy) / fy;
         float k00, k01, k11, l11, l21, l22;
         se3d_norm_cov2(r.cov, fx, fy, k00, k01, k11);
         se3d_chol2(k00, k01, k11, l11, l21, l22);
         S.ca[j][v] = l11; S.cb[j][v] = l21; S.cc[j][v] = l22;
         badv = !(isfinite(l11) && isfinite(l21) && isfinite(l22));
-        se3d_dlt_rows(sRt + 12 * cslot, px, py, r0, r1);
+        se3d_dlt_rows(sRt + 12 * c, px, py, r0, r1);
       }
       S.x[j][v] = px; S.y[j][v] = py; S.cf[j][v] = ok ? r.score : -1.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) { S.rows[j][v][k] = r0[k]; S.rows[j][v][4 + k] = r1[k]; }   // zero rows for an unusable view: the Gram loop adds them
     }
-    const unsigned seg = (unsigned)(__ballot(ok) >> (lane & 48)) & 0xFFFFu, segbad = (unsigned)(__ballot(badv) >> (lane & 48)) & 0xFFFFu;
-    if (ok) S.vidx[j][__popc(seg & ((1u << v) - 1u))] = (unsigned char)v;
-    if (in && v == 0) { S.n[j] = __popc(seg); S.bad[j] = segbad ? 1 : 0; }
+    okm[t] = __ballot(ok); badm[t] = __ballot(badv);
+    okl[t] = ok;
+  }
+  {
+    // bits [b, b + nv) of the 128-bit mask (m1 : m0), nv <= 16
+    auto seg = [&](unsigned long long m0, unsigned long long m1, int b2) -> unsigned {
+      const unsigned long long x = b2 < 64 ? ((m0 >> b2) | (b2 ? (m1 << (64 - b2)) : 0ull)) : (m1 >> (b2 - 64));
+      return (unsigned)x & ((1u << nv) - 1u);
+    };
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t >= ntrips) break;
+      const int j = ij[t], v = iv[t];
+      if (lane + 64 * t < nitems) {
+        const unsigned su = seg(okm[0], okm[1], j * nv);
+        if (okl[t]) S.vidx[j][__popc(su & ((1u << v) - 1u))] = (unsigned char)v;
+        if (v == 0) { S.n[j] = __popc(su); S.bad[j] = seg(badm[0], badm[1], j * nv) ? 1 : 0; }
+      }
+    }
   }
   __builtin_amdgcn_wave_barrier();
   TH_STAMP(2)  // points + rows + view lists
@@ -1736,12 +1763,13 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
   __builtin_amdgcn_wave_barrier();
   TH_STAMP(5)  // weighted solve
 #pragma unroll
-  for (int t = 0; t < TH_TRIPS; ++t) {  // confidence-weighted reprojection errors: lane <-> (joint, view slot); 0 for a view that is not usable
-    const int j = 4 * t + (lane >> 4), v = vslot;
-    if (j < JN && v < nv) {
+  for (int t = 0; t < 2; ++t) {  // confidence-weighted reprojection errors on the same (joint, view) lanes; 0 for a view that is not usable
+    if (t >= ntrips) break;
+    const int j = ij[t], v = iv[t];
+    if (lane + 64 * t < nitems) {
       const float cf = S.cf[j][v];
       float ce = 0.f;
-      if (S.n[j] >= 2 && cf >= 0.f) ce = cf * se3d_reproj1(sRt + 12 * cslot, S.X[j], S.Y[j], S.Z[j], S.x[j][v], S.y[j][v]);
+      if (S.n[j] >= 2 && cf >= 0.f) ce = cf * se3d_reproj1(sRt + 12 * ic[t], S.X[j], S.Y[j], S.Z[j], S.x[j][v], S.y[j][v]);
       S.re[j][v] = ce;
     }
   }
