@@ -154,8 +154,10 @@ void pseudo_inv34d(const double P[12], double Pinv[12]) {
 }
 
 // Null vector of a (rows x 4) float matrix: restatement of Eigen 3.3 JacobiSVD<Matrix<float,-1,4>>(ComputeThinV)
-// .matrixV().col(3) as called at S3D:456 — ColPivHouseholderQR preconditioner to a 4x4 upper-triangular R, two-sided
-// Jacobi sweeps on R (real_2x2_jacobi_svd), descending sort of the singular values, last column of V.
+// .matrixV().col(3) as called at S3D:456 — for rows != 4 the ColPivHouseholderQR preconditioner to a 4x4 upper-triangular R
+// (JacobiSVD::compute step 1, `if (m_rows != m_cols)`); for rows == 4 (a joint seen by exactly TWO views) Eigen skips the
+// preconditioner: the work matrix is the scaled input itself and V starts as the identity; then two-sided
+// Jacobi sweeps on the work matrix (real_2x2_jacobi_svd), descending sort of the singular values, last column of V.
 // All arithmetic in float like the reference.  Inner products are plain sequential sums (Eigen's vectorised
 // summation order is not reproduced: "parity unpinned", see header).
 struct JacobiRot { float c, s; };
@@ -173,6 +175,78 @@ inline bool make_jacobi(float x, float y, float z, JacobiRot &r) {  // JacobiRot
   return true;
 }
 
+// JacobiSVD::compute steps 2-4 on the 4x4 work matrix W with the accumulated right factor V; v_out = V.col(3) after the descending sort.
+void jacobi_null_vector_4x4(float W[4][4], float V[4][4], float v_out[4]) {
+  // --- two-sided Jacobi on W (JacobiSVD::compute step 2) ---
+  const float precision = 2.0f * std::numeric_limits<float>::epsilon();
+  const float considerAsZero = std::numeric_limits<float>::min();
+  float maxDiag = 0.f;
+  for (int i = 0; i < 4; ++i) maxDiag = std::max(maxDiag, std::fabs(W[i][i]));
+  bool finished = false;
+  int guard = 0;
+  while (!finished && guard++ < 200) {
+    finished = true;
+    for (int p = 1; p < 4; ++p)
+      for (int q = 0; q < p; ++q) {
+        float threshold = std::max(considerAsZero, precision * maxDiag);
+        if (std::fabs(W[p][q]) > threshold || std::fabs(W[q][p]) > threshold) {
+          finished = false;
+          // real_2x2_jacobi_svd
+          float m00 = W[p][p], m01 = W[p][q], m10 = W[q][p], m11 = W[q][q];
+          JacobiRot rot1;
+          float t = m00 + m11, d = m10 - m01;
+          if (std::fabs(d) < std::numeric_limits<float>::min()) {
+            rot1.s = 0.f; rot1.c = 1.f;
+          } else {
+            float u = t / d;
+            float tm = std::sqrt(1.0f + u * u);
+            rot1.s = 1.0f / tm;
+            rot1.c = u / tm;
+          }
+          // m.applyOnTheLeft(0,1,rot1): x' = c x + s y ; y' = -s x + c y  (rows)
+          float n00 = rot1.c * m00 + rot1.s * m10, n01 = rot1.c * m01 + rot1.s * m11;
+          float n10 = -rot1.s * m00 + rot1.c * m10, n11 = -rot1.s * m01 + rot1.c * m11;
+          (void)n10;
+          JacobiRot jr;
+          make_jacobi(n00, n01, n11, jr);
+          // j_left = rot1 * j_right.transpose();  transpose = (c, -s);  product (c1*c2 - s1*s2, c1*s2 + s1*c2)
+          JacobiRot jrt{jr.c, -jr.s};
+          JacobiRot jl{rot1.c * jrt.c - rot1.s * jrt.s, rot1.c * jrt.s + rot1.s * jrt.c};
+          // W.applyOnTheLeft(p,q,jl)
+          for (int j = 0; j < 4; ++j) {
+            float x = W[p][j], y = W[q][j];
+            W[p][j] = jl.c * x + jl.s * y;
+            W[q][j] = -jl.s * x + jl.c * y;
+          }
+          // W.applyOnTheRight(p,q,jr): x' = c x - s y ; y' = s x + c y (columns)
+          for (int i = 0; i < 4; ++i) {
+            float x = W[i][p], y = W[i][q];
+            W[i][p] = jr.c * x - jr.s * y;
+            W[i][q] = jr.s * x + jr.c * y;
+          }
+          for (int i = 0; i < 4; ++i) {
+            float x = V[i][p], y = V[i][q];
+            V[i][p] = jr.c * x - jr.s * y;
+            V[i][q] = jr.s * x + jr.c * y;
+          }
+          maxDiag = std::max(maxDiag, std::max(std::fabs(W[p][p]), std::fabs(W[q][q])));
+        }
+      }
+  }
+  // singular values, descending selection sort with column swaps (step 4) — only the smallest matters
+  float sv[4];
+  int idx[4] = {0, 1, 2, 3};
+  for (int i = 0; i < 4; ++i) sv[i] = std::fabs(W[i][i]);
+  for (int i = 0; i < 4; ++i) {
+    int pos = i;
+    for (int j = i + 1; j < 4; ++j)
+      if (sv[j] > sv[pos]) pos = j;
+    if (sv[pos] == 0.f) break;
+    if (pos != i) { std::swap(sv[i], sv[pos]); std::swap(idx[i], idx[pos]); }
+  }
+  for (int i = 0; i < 4; ++i) v_out[i] = V[i][idx[3]];
+}
+
 void null_vector_f32(int rows, std::vector<float> &A /*col-major rows x 4*/, float v_out[4]) {
   const int cols = 4;
   // scale (JacobiSVD::compute)
@@ -180,6 +254,17 @@ void null_vector_f32(int rows, std::vector<float> &A /*col-major rows x 4*/, flo
   for (float x : A) scale = std::max(scale, std::fabs(x));
   if (scale == 0.f) scale = 1.f;
   for (float &x : A) x = x / scale;
+  float W[4][4], V[4][4];
+  if (rows == cols) {
+    // square input: no QR step (Eigen 3.3 JacobiSVD::compute: m_workMatrix = matrix / scale, m_matrixV.setIdentity())
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        W[i][j] = A[i + rows * j];
+        V[i][j] = (i == j) ? 1.f : 0.f;
+      }
+    jacobi_null_vector_4x4(W, V, v_out);
+    return;
+  }
   // --- ColPivHouseholderQR ---
   int perm[4] = {0, 1, 2, 3};
   float normsUpdated[4], normsDirect[4];
@@ -253,81 +338,13 @@ void null_vector_f32(int rows, std::vector<float> &A /*col-major rows x 4*/, flo
     }
   }
   // work matrix W = R (4x4 upper triangular), V = column permutation
-  float W[4][4], V[4][4];
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
       W[i][j] = (j >= i && i < rows) ? A[i + rows * j] : 0.f;
       V[i][j] = 0.f;
     }
   for (int j = 0; j < 4; ++j) V[perm[j]][j] = 1.f;
-  // --- two-sided Jacobi on W (JacobiSVD::compute step 2) ---
-  const float precision = 2.0f * std::numeric_limits<float>::epsilon();
-  const float considerAsZero = std::numeric_limits<float>::min();
-  float maxDiag = 0.f;
-  for (int i = 0; i < 4; ++i) maxDiag = std::max(maxDiag, std::fabs(W[i][i]));
-  bool finished = false;
-  int guard = 0;
-  while (!finished && guard++ < 200) {
-    finished = true;
-    for (int p = 1; p < 4; ++p)
-      for (int q = 0; q < p; ++q) {
-        float threshold = std::max(considerAsZero, precision * maxDiag);
-        if (std::fabs(W[p][q]) > threshold || std::fabs(W[q][p]) > threshold) {
-          finished = false;
-          // real_2x2_jacobi_svd
-          float m00 = W[p][p], m01 = W[p][q], m10 = W[q][p], m11 = W[q][q];
-          JacobiRot rot1;
-          float t = m00 + m11, d = m10 - m01;
-          if (std::fabs(d) < std::numeric_limits<float>::min()) {
-            rot1.s = 0.f; rot1.c = 1.f;
-          } else {
-            float u = t / d;
-            float tm = std::sqrt(1.0f + u * u);
-            rot1.s = 1.0f / tm;
-            rot1.c = u / tm;
-          }
-          // m.applyOnTheLeft(0,1,rot1): x' = c x + s y ; y' = -s x + c y  (rows)
-          float n00 = rot1.c * m00 + rot1.s * m10, n01 = rot1.c * m01 + rot1.s * m11;
-          float n10 = -rot1.s * m00 + rot1.c * m10, n11 = -rot1.s * m01 + rot1.c * m11;
-          (void)n10;
-          JacobiRot jr;
-          make_jacobi(n00, n01, n11, jr);
-          // j_left = rot1 * j_right.transpose();  transpose = (c, -s);  product (c1*c2 - s1*s2, c1*s2 + s1*c2)
-          JacobiRot jrt{jr.c, -jr.s};
-          JacobiRot jl{rot1.c * jrt.c - rot1.s * jrt.s, rot1.c * jrt.s + rot1.s * jrt.c};
-          // W.applyOnTheLeft(p,q,jl)
-          for (int j = 0; j < 4; ++j) {
-            float x = W[p][j], y = W[q][j];
-            W[p][j] = jl.c * x + jl.s * y;
-            W[q][j] = -jl.s * x + jl.c * y;
-          }
-          // W.applyOnTheRight(p,q,jr): x' = c x - s y ; y' = s x + c y (columns)
-          for (int i = 0; i < 4; ++i) {
-            float x = W[i][p], y = W[i][q];
-            W[i][p] = jr.c * x - jr.s * y;
-            W[i][q] = jr.s * x + jr.c * y;
-          }
-          for (int i = 0; i < 4; ++i) {
-            float x = V[i][p], y = V[i][q];
-            V[i][p] = jr.c * x - jr.s * y;
-            V[i][q] = jr.s * x + jr.c * y;
-          }
-          maxDiag = std::max(maxDiag, std::max(std::fabs(W[p][p]), std::fabs(W[q][q])));
-        }
-      }
-  }
-  // singular values, descending selection sort with column swaps (step 4) — only the smallest matters
-  float sv[4];
-  int idx[4] = {0, 1, 2, 3};
-  for (int i = 0; i < 4; ++i) sv[i] = std::fabs(W[i][i]);
-  for (int i = 0; i < 4; ++i) {
-    int pos = i;
-    for (int j = i + 1; j < 4; ++j)
-      if (sv[j] > sv[pos]) pos = j;
-    if (sv[pos] == 0.f) break;
-    if (pos != i) { std::swap(sv[i], sv[pos]); std::swap(idx[i], idx[pos]); }
-  }
-  for (int i = 0; i < 4; ++i) v_out[i] = V[i][idx[3]];
+  jacobi_null_vector_4x4(W, V, v_out);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1197,17 +1214,18 @@ int se3d_oracle_rig_from_transforms(int32_t n_cam, const double *T, float *Rt_ou
         const double ex[9] = {0, -e[2], e[1], e[2], 0, -e[0], -e[1], e[0], 0};  // cross_prod_matrix (S3D:230-234)
         double Pinv[12];
         pseudo_inv34d(Ps[i].data(), Pinv);
-        double PjPinv[9];
+        // (e_ij_cross * Ps[j] * Pinv).cast<float>() (S3D:1201): operator* associates to the left -> (e_x P_j) P_i^+
+        double exPj[12];
         for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b) {
+          for (int b = 0; b < 4; ++b) {
             double s = 0;
-            for (int k = 0; k < 4; ++k) s += Ps[j][a * 4 + k] * Pinv[k * 3 + b];
-            PjPinv[a * 3 + b] = s;
+            for (int k = 0; k < 3; ++k) s += ex[a * 3 + k] * Ps[j][k * 4 + b];
+            exPj[a * 4 + b] = s;
           }
         for (int a = 0; a < 3; ++a)
           for (int b = 0; b < 3; ++b) {
             double s = 0;
-            for (int k = 0; k < 3; ++k) s += ex[a * 3 + k] * PjPinv[k * 3 + b];
+            for (int k = 0; k < 4; ++k) s += exPj[a * 4 + k] * Pinv[k * 3 + b];
             F_out[9 * idx + a * 3 + b] = static_cast<float>(s);
           }
       }

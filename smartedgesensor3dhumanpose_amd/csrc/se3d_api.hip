@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <thread>
 #include <vector>
@@ -205,25 +206,58 @@ int stage2_reset(se3d_ctx *c) {
   return SE3D_OK;
 }
 
-// 3x4 pseudo-inverse of a full-row-rank P: P^+ = P^T (P P^T)^-1  (host, fp64)
+// 3x4 pseudo-inverse the way the reference forms it (pseudo_inv34d, S3D:236-240): P = U S V^T by a Jacobi SVD, singular values below
+// eps * max(rows, cols) * s_max dropped, P^+ = V S^+ U^T.  Host, fp64.  The SVD is a one-sided (Hestenes) Jacobi iteration on the 4x3
+// matrix B = P^T: column pairs are rotated until they are mutually orthogonal (B -> U' S, rotations accumulated in V'), so that
+// P^T = U' S V'^T and P^+ = U' S^+ V'^T.  Every operation is spelled out in a fixed order and the file is compiled with
+// -ffp-contract=off: the test oracle forms its matrices by the same sequence and the two F tables are compared bit for bit
+// (tests/test_abi.py) — F feeds a strict `<` against max_epi_dist (S3D:620), so "close" is not good enough for index parity.
 void pinv34(const double P[12], double out[12]) {
-  double G[9];
-  for (int i = 0; i < 3; ++i)
+  double B[4][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int r = 0; r < 4; ++r)
+    for (int k = 0; k < 3; ++k) B[r][k] = P[k * 4 + r];
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double worst = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double pp = 0, qq = 0, pq = 0;
+        for (int r = 0; r < 4; ++r) {
+          pp += B[r][p] * B[r][p];
+          qq += B[r][q] * B[r][q];
+          pq += B[r][p] * B[r][q];
+        }
+        if (pq == 0.0) continue;
+        worst = std::max(worst, std::fabs(pq) / std::sqrt(pp * qq));
+        const double zeta = (qq - pp) / (2.0 * pq);
+        const double tn = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / std::sqrt(1.0 + tn * tn), sn = cs * tn;
+        for (int r = 0; r < 4; ++r) {
+          const double x = B[r][p], y = B[r][q];
+          B[r][p] = cs * x - sn * y;
+          B[r][q] = sn * x + cs * y;
+        }
+        for (int r = 0; r < 3; ++r) {
+          const double x = V[r][p], y = V[r][q];
+          V[r][p] = cs * x - sn * y;
+          V[r][q] = sn * x + cs * y;
+        }
+      }
+    if (worst < 1e-16) break;
+  }
+  double sv[3];
+  for (int k = 0; k < 3; ++k) {
+    double nn = 0;
+    for (int r = 0; r < 4; ++r) nn += B[r][k] * B[r][k];
+    sv[k] = std::sqrt(nn);
+    if (sv[k] > 0)
+      for (int r = 0; r < 4; ++r) B[r][k] /= sv[k];
+  }
+  const double tol = std::numeric_limits<double>::epsilon() * 4.0 * std::max(sv[0], std::max(sv[1], sv[2]));
+  for (int r = 0; r < 4; ++r)
     for (int j = 0; j < 3; ++j) {
-      double s = 0;
-      for (int k = 0; k < 4; ++k) s += P[i * 4 + k] * P[j * 4 + k];
-      G[i * 3 + j] = s;
-    }
-  const double a = G[0], b = G[1], cc = G[2], d = G[3], e = G[4], f = G[5], g = G[6], h = G[7], i9 = G[8];
-  const double c00 = e * i9 - f * h, c01 = -(d * i9 - f * g), c02 = d * h - e * g;
-  const double det = a * c00 + b * c01 + cc * c02, id = 1.0 / det;
-  const double Gi[9] = {c00 * id, -(b * i9 - cc * h) * id, (b * f - cc * e) * id, c01 * id, (a * i9 - cc * g) * id,
-                        -(a * f - cc * d) * id, c02 * id, -(a * h - b * g) * id, (a * e - b * d) * id};
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 3; ++j) {
-      double s = 0;
-      for (int k = 0; k < 3; ++k) s += P[k * 4 + i] * Gi[k * 3 + j];
-      out[i * 3 + j] = s;
+      double acc = 0;
+      for (int k = 0; k < 3; ++k) acc += B[r][k] * ((std::fabs(sv[k]) > tol) ? 1.0 / sv[k] : 0.0) * V[j][k];
+      out[r * 3 + j] = acc;
     }
 }
 
@@ -256,17 +290,18 @@ int se3d_rig_from_transforms(int32_t n_cam, const double *T, float *Rt_out, floa
           for (int k = 0; k < 4; ++k) e[a] += Pj[a * 4 + k] * Ci[k];
         }
         const double ex[9] = {0, -e[2], e[1], e[2], 0, -e[0], -e[1], e[0], 0};
-        double M[9];
+        // `e_ij_cross * Ps[j] * Pinv` (S3D:1201) associates to the left: (e_x P_j) P_i^+
+        double M[12];
         for (int a = 0; a < 3; ++a)
-          for (int b = 0; b < 3; ++b) {
+          for (int b = 0; b < 4; ++b) {
             double s = 0;
-            for (int k = 0; k < 4; ++k) s += Pj[a * 4 + k] * Pinv[k * 3 + b];
-            M[a * 3 + b] = s;
+            for (int k = 0; k < 3; ++k) s += ex[a * 3 + k] * Pj[k * 4 + b];
+            M[a * 4 + b] = s;
           }
         for (int a = 0; a < 3; ++a)
           for (int b = 0; b < 3; ++b) {
             double s = 0;
-            for (int k = 0; k < 3; ++k) s += ex[a * 3 + k] * M[k * 3 + b];
+            for (int k = 0; k < 4; ++k) s += M[a * 4 + k] * Pinv[k * 3 + b];
             F_out[9 * idx + a * 3 + b] = (float)s;
           }
       }

@@ -21,9 +21,16 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def extr_rig(oracle):
+    """The reference's 16-camera rig (EXTR) with the PRODUCT's tensors (se3d_rig_from_transforms, host code): what bench.py and a node built
+    on the library run with.  tests/test_abi.py asserts that they equal the oracle's restatement of S3D:1187-1211 bit for bit."""
+    import numpy as np
     from smartedgesensor3dhumanpose_amd import rig as R
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
     r = R.extr_rig_16cam()
-    r.set_tensors(*oracle.rig_tensors(r))
+    Rt, F = rig_tensors(r)
+    Rt_o, F_o = oracle.rig_tensors(r)
+    assert np.array_equal(Rt, Rt_o) and np.array_equal(F.view(np.uint32), F_o.view(np.uint32))
+    r.set_tensors(Rt, F)
     return r
 
 

@@ -7,6 +7,7 @@ import pytest
 
 from smartedgesensor3dhumanpose_amd import rig as R
 from smartedgesensor3dhumanpose_amd import scene as S
+from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +36,7 @@ def test_hypothesis_shard_equals_single_rank(extr_rig, oracle, device_buffer, wo
         rig = extr_rig
     else:
         rig = R.elliptical_rig(24, seed=3)
-        rig.set_tensors(*oracle.rig_tensors(rig))
+        rig.set_tensors(*rig_tensors(rig))   # product tensors (bit-equal to the oracle's: tests/test_abi.py)
     S_, T_ = 3, 14
     extra = dict(p_miss=0.1, low_score_frac=0.1, outlier_frac=0.02)
     seqs = [S.generate_sequence(rig, S.SceneConfig(n_persons=persons - s, n_frames=T_, seed=500 + s, min_coverage=4 if rig.n_cam == 16 else 6, **extra))[0] for s in range(S_)]
