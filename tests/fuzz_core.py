@@ -1,0 +1,138 @@
+"""Randomised parity sweep, shared by tests/test_gpu_fuzz_parity.py (asserts) and tools/fuzz_parity.py (prints): the default HIP kernels
+through the C-ABI against the CPU oracle on the scenes of tests/fuzz_scenes.py — stage 1 per frame, the resident stage-2 walk per sequence.
+
+What must hold, and where the line is drawn (criteria computed from the inputs, tests/parity.py):
+  * stage-1 index results (flags, hypothesis counts, association tables, published persons, sets of valid joints): identical in every frame
+    (frames on which the library raised FLAG_HYP_OVERFLOW are counted; the oracle, run with room to spare, must have needed more);
+  * stage-1 positions < 1 mm, scores rtol 2e-5, covariances relative Frobenius < 1e-3 for every joint whose DLT systems have
+    kappa < DLT_KAPPA_MAX; joints above it are the exclusion set (counted, worst deviation recorded);
+  * stage-2 ids / counts / LM iteration counts identical, refined joints < 1 mm, marginal covariances rtol 1e-4 on every sequence-step of a
+    sequence that has not yet seen a garbage person (a joint > GARBAGE_JOINT_DIST_M from its person's median joint); from the first such
+    person on the sequence is in the exclusion set (counted), because its LM problem is solver-dependent and the difference lives on in the
+    track state."""
+import os
+
+import numpy as np
+
+from smartedgesensor3dhumanpose_amd import person_msgs as pm
+from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
+from fuzz_scenes import MAX_HYP, N_SEQ, T_STEPS, draw_trial
+from parity import COV_REL_FRO, DLT_KAPPA_MAX, POS_TOL_M, SCORE_RTOL, compare_stage2, garbage_persons, published_joint_condition
+
+W6 = np.array([1, 2, 2, 1, 2, 1.0])
+
+
+def new_report(seed):
+    return dict(seed=seed, trials=0, frames=0, frames_hyp_overflow=0, persons=0, joints=0, joints_excluded=0,
+                joints_over_1mm=0, pos_max_mm=0.0, scores_over_rtol=0, cov_over_tol=0, cov_rel_max=0.0, cov_nan=0,
+                excluded_over_1mm=0, excluded_pos_max_mm=0.0, excluded_cov_over_tol=0, excluded_cov_rel_max=0.0,
+                seq_steps=0, seq_steps_track_overflow=0, seq_steps_excluded=0, stage2_numeric_failures=0, stage2_index_divergences=0,
+                excluded_stage2_mismatches=0, violations=[])
+
+
+def run_trials(O, seed, trials, walk_mode="wave"):
+    """O: the oracle module (tests' fixture / oracle_py).  Index mismatches of stage 1 raise at once; everything else is tallied."""
+    rng = np.random.default_rng(seed)
+    rep = new_report(seed)
+    k2f = np.array(pm.KP2FUSION_SIMPLE)
+    for trial in range(trials):
+        rig, persons, seqs, extra = draw_trial(rng)
+        frames = [seqs[s][k] for k in range(T_STEPS) for s in range(N_SEQ)]
+        node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=N_SEQ * T_STEPS, max_det_per_cam=12, max_hyp=MAX_HYP, device=0)
+        params = node.params
+        node.stage(frames)
+        node.run_stage1()
+        node.refine_reset()
+        r1 = node.fetch_stage1(N_SEQ * T_STEPS)
+        for fi, fr in enumerate(frames):
+            g, o = r1[fi], O.triangulate(rig, params, fr, capacity=4 * MAX_HYP, hyp_capacity=4 * MAX_HYP)   # the oracle with room to spare
+            rep["frames"] += 1
+            if g.flags & pm.FLAG_HYP_OVERFLOW:
+                assert o.n_hyp > MAX_HYP, ("overflow flag without overflow", seed, trial, fi, o.n_hyp)
+                rep["frames_hyp_overflow"] += 1
+                continue
+            assert g.flags == o.flags and o.n_hyp <= MAX_HYP, ("flags", seed, trial, fi, g.flags, o.flags, o.n_hyp)
+            assert g.n_hyp == o.n_hyp, ("hypotheses", seed, trial, fi, g.n_hyp, o.n_hyp)
+            assert np.array_equal(g.assoc(), o.assoc()), ("association table", seed, trial, fi)
+            assert g.n_persons == o.n_persons and np.array_equal(g.person_hyp[:g.n_persons], o.person_hyp[:g.n_persons]), ("published persons", seed, trial, fi)
+            n = g.n_persons
+            if n == 0:
+                continue
+            gk, ok = g.published()["keypoints"][:, k2f], o.published()["keypoints"][:, k2f]     # the 17 triangulated joints, input order
+            v = ok["score"] > 0
+            assert np.array_equal(gk["score"] > 0, v), ("valid joints", seed, trial, fi)
+            kappa = published_joint_condition(rig, fr, g)
+            assert not np.isnan(kappa[v]).any(), ("published joint with fewer than two usable views", seed, trial, fi)
+            inside = v & (kappa < DLT_KAPPA_MAX)
+            outside = v & ~inside
+            d = np.linalg.norm(gk["joint"] - ok["joint"], axis=-1)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                rs = np.abs(gk["score"] - ok["score"]) / ok["score"]
+                cg, co = gk["cov"], ok["cov"]
+                rel = np.sqrt(((cg - co) ** 2 * W6).sum(-1)) / np.sqrt((co ** 2 * W6).sum(-1))
+            nan_o, nan_g = np.isnan(co).any(-1) & v, np.isnan(cg).any(-1) & v
+            assert np.array_equal(nan_g, nan_o), ("NaN covariances", seed, trial, fi)
+            rep["cov_nan"] += int(nan_o.sum())
+            relv = np.where(nan_o, 0.0, rel)
+            rep["persons"] += n
+            rep["joints"] += int(v.sum())
+            rep["joints_excluded"] += int(outside.sum())
+            if inside.any():
+                rep["joints_over_1mm"] += int((d[inside] >= POS_TOL_M).sum())
+                rep["pos_max_mm"] = max(rep["pos_max_mm"], float(d[inside].max() * 1e3))
+                rep["scores_over_rtol"] += int((rs[inside] > SCORE_RTOL).sum())
+                rep["cov_over_tol"] += int((relv[inside] >= COV_REL_FRO).sum())
+                rep["cov_rel_max"] = max(rep["cov_rel_max"], float(relv[inside].max()))
+                for p, k in zip(*np.nonzero(inside & ((d >= POS_TOL_M) | (relv >= COV_REL_FRO) | (rs > SCORE_RTOL)))):
+                    rep["violations"].append(dict(trial=trial, frame=fi, person=int(p), joint=int(k), kappa=float(kappa[p, k]), d_mm=float(d[p, k] * 1e3),
+                                                  cov_rel=float(relv[p, k]), score_rel=float(rs[p, k])))
+            if outside.any():
+                rep["excluded_over_1mm"] += int((d[outside] >= POS_TOL_M).sum())
+                rep["excluded_pos_max_mm"] = max(rep["excluded_pos_max_mm"], float(d[outside].max() * 1e3))
+                rep["excluded_cov_over_tol"] += int((relv[outside] >= COV_REL_FRO).sum())
+                rep["excluded_cov_rel_max"] = max(rep["excluded_cov_rel_max"], float(relv[outside].max()))
+        # ---- stage 2: the resident walk; ids / counts / iteration counts exact inside compare_stage2 ----
+        if walk_mode in ("wave", "wg"):
+            os.environ["SE3D_WALK_SHAPE"] = walk_mode
+        else:
+            os.environ["SE3D_WALK"] = "steps"
+        try:
+            ts = [100.0 + (i + 1) / 30.0 for i in range(T_STEPS)]
+            node.run_stage2_walk(np.repeat(np.array(ts)[:, None], N_SEQ, 1), [k * N_SEQ for k in range(T_STEPS)])
+            node.sync()
+        finally:
+            os.environ.pop("SE3D_WALK_SHAPE", None)
+            os.environ.pop("SE3D_WALK", None)
+        oras = [O.PosePrior(params) for _ in range(N_SEQ)]
+        dead, tainted = [False] * N_SEQ, [False] * N_SEQ
+        for k, t in enumerate(ts):
+            ra = node.fetch_stage2_walk(k * N_SEQ, N_SEQ)
+            for s in range(N_SEQ):
+                if dead[s]:
+                    continue
+                rep["seq_steps"] += 1
+                if ra[s].c.flags & pm.S2FLAG_TRACK_OVERFLOW:   # track capacity exceeded: truncated by contract, the oracle has no capacity
+                    rep["seq_steps_track_overflow"] += 1
+                    dead[s] = True
+                    continue
+                dets = r1[k * N_SEQ + s].published()
+                tainted[s] = tainted[s] or bool(garbage_persons(dets).any())
+                o2 = oras[s].step(dets, rig.n_cam, t, seqs[s][k].fb_delay, capacity=MAX_HYP)
+                if tainted[s]:
+                    rep["seq_steps_excluded"] += 1
+                try:
+                    compare_stage2(ra[s], o2, check_tracks=(k == T_STEPS - 1))
+                except AssertionError as e:
+                    msg = str(e)
+                    numeric = "mm" in msg or "cov" in msg or "marg" in msg
+                    if tainted[s]:
+                        rep["excluded_stage2_mismatches"] += 1
+                        dead[s] = dead[s] or not numeric
+                        continue
+                    rep["stage2_numeric_failures" if numeric else "stage2_index_divergences"] += 1
+                    rep["violations"].append(dict(trial=trial, step=k, seq=s, stage2=msg[:200]))
+                    dead[s] = dead[s] or not numeric
+        node.close()
+        rep["trials"] += 1
+    rep["tolerances"] = {"POS_TOL_M": POS_TOL_M, "SCORE_RTOL": SCORE_RTOL, "COV_REL_FRO": COV_REL_FRO, "DLT_KAPPA_MAX": DLT_KAPPA_MAX}
+    return rep

@@ -94,3 +94,135 @@ def compare_stage2(gpu, ora, check_iters=True, check_tracks=True):
     if check_iters:
         assert np.array_equal(gpu.lm_iterations[:n], ora.lm_iterations[:n]), (gpu.lm_iterations[:n], ora.lm_iterations[:n])
     return stats
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Ill-conditioning criteria of the randomised sweep (tests/test_gpu_fuzz_parity.py), computed FROM THE INPUTS in float64.
+#
+# Rows T/U: the reference takes the DLT null vector from a float32 JacobiSVD (S3D:456), the kernels from an fp64 solve of the same
+# float32 rows.  A float32 perturbation of relative size eps = 2^-24 of the rows turns the null vector by ~ eps * s1 / (s3 - s4)
+# (singular values of the 2n x 4 system) and dehomogenising v -> v[:3] / v[3] multiplies that by ~ (1 + |X|^2): a joint whose system has
+#     kappa = (1 + |X|^2) * s1 / (s3 - s4)
+# can come out of the two solvers up to ~ c * eps * kappa metres apart (measured c <= 5 over 3e5 joints, tools: profiles/r3/README.md).
+# kappa >= DLT_KAPPA_MAX is the exclusion set of the < 1 mm / 1e-3 assertions: such joints are triangulated far outside the hall from
+# nearly parallel or inconsistent rays (gross 2-D outliers, wrong associations) and the reference's own answer there is rounding noise.
+# ---------------------------------------------------------------------------------------------------------------------------------
+DLT_KAPPA_MAX = 2.0e3     # c * eps * kappa = 5 * 6e-8 * 2e3 = 0.6 mm: below it the two solvers must agree to POS_TOL_M
+GARBAGE_JOINT_DIST_M = 10.0   # stage 2: a measured joint further than this from the median joint of its person (no body spans 10 m)
+
+
+def _dlt_rows(rig, frame, assoc_rows):
+    """float32 DLT rows of every (person, joint, camera) exactly as S3D:446-453 builds them, + usable-view mask and confidences."""
+    f = np.float32
+    n, N = len(assoc_rows), rig.n_cam
+    K = rig.K.astype(f)
+    P = rig.Rt.reshape(N, 3, 4).astype(f)
+    x = np.zeros((n, pm.NUM_KEYPOINTS, N), f)
+    y = np.zeros_like(x)
+    cf = np.full_like(x, -1.0)
+    for c in range(N):
+        idx = assoc_rows[:, c]
+        m = idx >= 0
+        if not m.any():
+            continue
+        kp = frame.persons[frame.det_offset[c] + idx[m]]["keypoints"]
+        ok = kp["score"] >= f(0.30)                      # normalize_keypoints gate (S3D:321) == triangulation gate (S3D:725)
+        x[m, :, c] = np.where(ok, (kp["x"] - K[c, 2]) / K[c, 0], f(0))
+        y[m, :, c] = np.where(ok, (kp["y"] - K[c, 3]) / K[c, 1], f(0))
+        cf[m, :, c] = np.where(ok, kp["score"], f(-1))
+    use = cf >= f(0.30)
+    r0 = (x[..., None] * P[None, None, :, 2, :] - P[None, None, :, 0, :]).astype(f)
+    r1 = (y[..., None] * P[None, None, :, 2, :] - P[None, None, :, 1, :]).astype(f)
+    r0 = (r0 / np.sqrt((r0 * r0).sum(-1, dtype=f), dtype=f)[..., None]).astype(f)
+    r1 = (r1 / np.sqrt((r1 * r1).sum(-1, dtype=f), dtype=f)[..., None]).astype(f)
+    return r0, r1, use, np.where(use, cf, f(0)), x, y
+
+
+def _kappa_from_gram(G):
+    """G [..., 4, 4] fp64 Gram matrix A^T A -> (kappa, X [..., 3])."""
+    lam, vec = np.linalg.eigh(G)
+    s = np.sqrt(np.maximum(lam, 0.0))
+    v = vec[..., :, 0]
+    w = np.where(np.abs(v[..., 3:4]) > 1e-150, v[..., 3:4], 1e-150)
+    X = v[..., :3] / w
+    gap = np.maximum(s[..., 1] - s[..., 0], 1e-150)
+    with np.errstate(over="ignore", invalid="ignore"):
+        kappa = (1.0 + (X * X).sum(-1)) * s[..., 3] / gap
+    return np.where(np.isfinite(kappa), kappa, np.inf), X
+
+
+def dlt_condition(rig, frame, assoc_rows, want_points=False):
+    """kappa [n][17] of the DLT systems behind each (hypothesis, joint) of a frame (nan: fewer than two usable views), the maximum over the
+    confidence-weighted system of the main solve (S3D:746), the unweighted system of the sigma points (S3D:518) and — where the fp64
+    reprojection error comes near g_reproj_error_max_acceptable, so that the outlier rejection (S3D:748-838) may have removed a view —
+    their leave-one-view-out subsets.  assoc_rows: [n][n_cam] original detection indices or -1 (rows of the result's association table).
+    want_points: also the fp64 solution of the weighted system [n][17][3]."""
+    assoc_rows = np.asarray(assoc_rows, np.int32).reshape(-1, rig.n_cam)
+    r0, r1, use, cf, x, y = _dlt_rows(rig, frame, assoc_rows)
+    a0, a1 = r0.astype(np.float64), r1.astype(np.float64)
+    outer = a0[..., :, None] * a0[..., None, :] + a1[..., :, None] * a1[..., None, :]          # [n,17,N,4,4]
+    u = use.astype(np.float64)
+    w2 = (cf.astype(np.float64)) ** 2
+    Gu = (outer * u[..., None, None]).sum(2)
+    Gw = (outer * w2[..., None, None]).sum(2)
+    nv = use.sum(-1)
+    ku, _ = _kappa_from_gram(Gu)
+    kw, X = _kappa_from_gram(Gw)
+    kappa = np.maximum(ku, kw)
+    # reprojection error of the weighted solution (S3D:425-438) in fp64
+    P = rig.Rt.reshape(rig.n_cam, 3, 4).astype(np.float64)
+    Xh = np.concatenate([X, np.ones(X.shape[:-1] + (1,))], -1)
+    pr = np.einsum("cij,pkj->pkci", P, Xh)
+    z = np.where(np.abs(pr[..., 2]) > 1e-150, pr[..., 2], 1e-150)
+    with np.errstate(over="ignore", invalid="ignore"):
+        e = np.hypot(pr[..., 0] / z - x, pr[..., 1] / z - y)
+        cfd = cf.astype(np.float64)
+        err = (cfd * np.where(use, e, 0.0)).sum(-1) / np.maximum(cfd.sum(-1), 1e-150)
+    for p, k in zip(*np.nonzero(~(err <= 0.8 * 0.05) & (nv >= 3))):
+        for c in np.nonzero(use[p, k])[0]:
+            kk_u, _ = _kappa_from_gram(Gu[p, k] - outer[p, k, c])
+            kk_w, _ = _kappa_from_gram(Gw[p, k] - outer[p, k, c] * w2[p, k, c])
+            kappa[p, k] = max(kappa[p, k], kk_u, kk_w)
+    kappa = np.where(nv >= 2, kappa, np.nan)
+    return (kappa, X) if want_points else kappa
+
+
+def published_joint_condition(rig, frame, result):
+    """kappa [n_persons][17] for the PUBLISHED persons of a stage-1 result (keypoint order of the input, not the fusion layout).  A published
+    person is its own hypothesis or, after the duplicate merge (S3D:984-996: the later of two persons closer than 0.20 m is averaged into
+    the earlier one and erased, joints only one of them has are taken over), a blend: every unpublished later hypothesis whose fp64 joints
+    lie within 0.5 m (median over the joints both have; the reference's test runs after its plausibility filters, which this criterion
+    does not redo) or that has one joint within 2 cm (a joint taken over unchanged) counts as a possible merge partner and contributes the maximum of its kappa."""
+    n = result.n_persons
+    hyp = result.person_hyp[:n]
+    kap, X = dlt_condition(rig, frame, result.assoc(), want_points=True)
+    out = kap[hyp].copy()
+    pub = np.zeros(len(kap), bool)
+    pub[hyp] = True
+    k2f = np.array(pm.KP2FUSION_SIMPLE)
+    kp = result.published()["keypoints"][:, k2f]
+    for h2 in np.nonzero(~pub)[0]:
+        have2 = ~np.isnan(kap[h2])
+        for i in range(n):
+            if hyp[i] > h2:
+                break
+            both = have2 & (kp["score"][i] > 0)
+            if not both.any():
+                continue
+            dist = np.linalg.norm(X[h2][both] - kp["joint"][i][both], axis=-1)
+            if np.median(dist) < 0.5 or dist.min() < 0.02:     # close as a whole, or a joint that was taken over as it is
+                out[i] = np.where(have2, np.fmax(out[i], kap[h2]), out[i])
+    return out
+
+
+def garbage_persons(persons3d):
+    """bool [n]: stage-1 persons with a valid joint more than GARBAGE_JOINT_DIST_M from the median of their valid joints — a joint
+    triangulated from an inconsistent pair of rays on a person without a root (no root-distance filter, S3D:937-953).  Its LM problem
+    (PP:690-746) is flat along that ray and badly scaled; algebraically equivalent solvers take different accept / reject paths."""
+    out = np.zeros(len(persons3d), bool)
+    for i, p in enumerate(persons3d):
+        v = p["keypoints"]["score"] > 0
+        if v.sum() >= 2:
+            J = p["keypoints"]["joint"][v]
+            out[i] = np.linalg.norm(J - np.median(J, 0), axis=-1).max() > GARBAGE_JOINT_DIST_M
+    return out

@@ -1,0 +1,32 @@
+"""Randomised GPU-vs-oracle parity sweep inside the suite (round 2 ran it as a tool that only tallied): fixed seeds — among them 4, 15, 37,
+whose scenes made the default stage-2 path diverge from the oracle in round 2, and 1, 3, 39 with joints more than 1 mm off — and the
+assertion that NOTHING outside an input-derived exclusion set deviates: tests/fuzz_core.py states what is compared and where the exclusion
+criteria (tests/parity.py: DLT_KAPPA_MAX, GARBAGE_JOINT_DIST_M) draw the line; the size of the exclusion set is asserted too."""
+import json
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fuzz_core import run_trials  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = [4, 15, 37, 39, 0, 1, 2, 3]
+TRIALS = 40   # 40 scenes x 3 sequences x 12 frames per seed: ~1 440 frames, ~110 k joints, ~1 430 sequence-steps
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_scenes_match_the_oracle_outside_the_ill_conditioned_set(oracle, seed):
+    rep = run_trials(oracle, seed, TRIALS)
+    viol = rep.pop("violations")
+    print(json.dumps(rep))
+    assert rep["frames"] == TRIALS * 36 and rep["joints"] > 50_000
+    # stage 1, everything outside the exclusion set
+    assert rep["joints_over_1mm"] == 0 and rep["scores_over_rtol"] == 0 and rep["cov_over_tol"] == 0, viol[:5]
+    # stage 2, every sequence-step outside the exclusion set
+    assert rep["stage2_index_divergences"] == 0 and rep["stage2_numeric_failures"] == 0, viol[:5]
+    # the exclusion sets stay small: joints whose DLT system is ill-conditioned, sequence-steps after a garbage person
+    assert rep["joints_excluded"] <= 0.01 * rep["joints"], rep
+    assert rep["seq_steps_excluded"] <= 0.15 * rep["seq_steps"], rep
