@@ -95,28 +95,160 @@ def make_sequences(pool, w, n_ctx, n_seq, seed_rank, t_steps):
 
 
 def cpu_baseline(rig, seq, params, with_stage2, budget_s=12.0):
-    """Oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores on a bounded sample."""
+    """Oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores on a bounded sample.  Next to the rate: the
+    per-stage wall-clock averages bucketed by the number of published persons, as the reference's own timers report them at node exit
+    (g_timings[0] = all frames, g_timings[n] = frames with n persons, n < 10: S3D:1076-1084, 1234-1241; PP:912-920, 952-959)."""
     from oracle import oracle_py as O
     ncores = os.cpu_count() or 1
-    out = {}
+    out, buckets = {}, {}
     for label, thr in (("1t", 1), ("omp", ncores)):
         pp = O.PosePrior(params) if with_stage2 else None
         t0 = time.perf_counter()
         n_sk, n_fr = 0, 0
+        bk = {}
         while time.perf_counter() - t0 < budget_s / 2:
             fr = seq[n_fr % len(seq)]
+            ta = time.perf_counter()
             r = O.triangulate(rig, params, fr, capacity=512, hyp_capacity=512, omp_threads=thr)
+            tb = time.perf_counter()
+            n2 = 0
             if pp is not None:
-                pp.step(r.published(), rig.n_cam, 100.0 + n_fr / 30.0, fr.fb_delay, capacity=512, omp_threads=thr)
+                r2 = pp.step(r.published(), rig.n_cam, 100.0 + n_fr / 30.0, fr.fb_delay, capacity=512, omp_threads=thr)
+                n2 = r2.n_persons
+            tc = time.perf_counter()
+            for key, n_, dt_ in (("stage1", r.n_persons, tb - ta), ("stage2", n2, tc - tb)):
+                for b in ("all", str(n_) if n_ < 10 else ">=10"):
+                    e = bk.setdefault(key, {}).setdefault(b, [0, 0.0])
+                    e[0] += 1
+                    e[1] += dt_
             n_sk += r.n_persons
             n_fr += 1
         dt = time.perf_counter() - t0
         out[label] = (n_sk / dt, n_fr, dt)
+        buckets[label] = {k: {b: {"frames": e[0], "avg_ms": round(e[1] / e[0] * 1e3, 4)} for b, e in sorted(v.items())} for k, v in bk.items()}
     best = "omp" if out["omp"][0] > out["1t"][0] else "1t"
     return {"value": round(out[best][0], 2), "unit": "skeletons/s", "cores": ncores if best == "omp" else 1, "kind": "port",
             "sample": "%d frames of one sequence of the same workload, stage %s; single thread %.1f skel/s (%d frames), OpenMP x%d over "
                       "hypotheses/persons as in S3D:676 / PP:582: %.1f skel/s (%d frames)"
-                      % (out[best][1], "1+2" if with_stage2 else "1", out["1t"][0], out["1t"][1], ncores, out["omp"][0], out["omp"][1])}
+                      % (out[best][1], "1+2" if with_stage2 else "1", out["1t"][0], out["1t"][1], ncores, out["omp"][0], out["omp"][1]),
+            "per_stage_ms": {"note": "wall-clock ms per frame of the oracle, bucketed by the number of persons the stage published (the reference's "
+                                     "g_timings buckets, S3D:1076-1084 / PP:912-920); stage1 = triangulate_persons, stage2 = pose_prior skeletonCallback",
+                             "single_thread": buckets["1t"], "openmp_x%d" % ncores: buckets["omp"]}}
+
+
+def bench_parity(name, rig, seqs, n_seq=4, device=0):
+    """The second half of the metric (BASELINE.json: "3D skeletons/sec + mm MPJPE vs CPU ref"; SURVEY 8d: max and mean per-joint error, association
+    exact-match rate), untimed: the HIP path against the CPU oracle on the bench's OWN scenes through a context of the same limits — stage 1 per
+    frame (n_seq sequences x T frames), then the resident stage-2 walk against the oracle's pose_prior fed with the same stage-1 persons."""
+    from oracle import oracle_py as O
+    from smartedgesensor3dhumanpose_amd import person_msgs as pm
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
+    w = WORKLOADS[name]
+    seqs = seqs[:n_seq]
+    S_, T_ = len(seqs), len(seqs[0])
+    frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
+    node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=S_ * T_, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=device)
+    node.stage(frames)
+    node.run_stage1()
+    node.refine_reset()
+    r1 = node.fetch_stage1(S_ * T_)
+    t0 = time.perf_counter()
+    exact, d_all, n_skel = 0, [], 0
+    for fr, g in zip(frames, r1):
+        o = O.triangulate(rig, node.params, fr, capacity=2 * w["max_hyp"], hyp_capacity=2 * w["max_hyp"])
+        same = (g.flags == o.flags and g.n_hyp == o.n_hyp and g.n_persons == o.n_persons and np.array_equal(g.assoc(), o.assoc())
+                and np.array_equal(g.person_hyp[:g.n_persons], o.person_hyp[:g.n_persons]))
+        exact += int(same)
+        if same and g.n_persons:
+            gk, ok = g.published()["keypoints"], o.published()["keypoints"]
+            v = ok["score"] > 0
+            same_valid = np.array_equal(gk["score"] > 0, v)
+            exact -= int(not same_valid)
+            if same_valid:
+                d_all.append(np.linalg.norm(gk["joint"] - ok["joint"], axis=-1)[v])
+                n_skel += g.n_persons
+    out = {"workload": name, "frames": len(frames), "skeletons": n_skel, "assoc_exact_rate": exact / len(frames)}
+    if d_all:
+        d = np.concatenate(d_all)
+        out.update(mpjpe_max_mm=round(float(d.max() * 1e3), 6), mpjpe_mean_mm=round(float(d.mean() * 1e3), 6), joints=int(len(d)))
+    # stage 2: the resident walk (the bench's default path) vs the oracle's pose_prior on the same stage-1 persons
+    ts = [100.0 + (i + 1) / 30.0 for i in range(T_)]
+    if w["max_hyp"] <= 16:   # the kernel form the headline runs (one wavefront per sequence, three persons per LM wavefront); few sequences would default to the workgroup form
+        os.environ["SE3D_WALK_SHAPE"] = "wave"
+    try:
+        node.run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in range(T_)])
+        node.sync()
+    finally:
+        os.environ.pop("SE3D_WALK_SHAPE", None)
+    oras = [O.PosePrior(node.params) for _ in range(S_)]
+    d2, ids_ok, it_ok, steps2, n_ref = [], 0, 0, 0, 0
+    for k, t in enumerate(ts):
+        ra = node.fetch_stage2_walk(k * S_, S_)
+        for s_ in range(S_):
+            o2 = oras[s_].step(r1[k * S_ + s_].published(), rig.n_cam, t, seqs[s_][k].fb_delay, capacity=2 * w["max_hyp"])
+            g2 = ra[s_]
+            steps2 += 1
+            n = g2.n_persons
+            ok_ids = n == o2.n_persons and np.array_equal(g2.fused["id"][:n], o2.fused["id"][:n])
+            ids_ok += int(ok_ids)
+            if ok_ids and n:
+                it_ok += int(np.array_equal(g2.lm_iterations[:n], o2.lm_iterations[:n]))
+                for nm in ("fused", "fused_pred"):
+                    gk, ok = getattr(g2, nm)[:n]["keypoints"], getattr(o2, nm)[:n]["keypoints"]
+                    v = ok["score"] > 0
+                    if np.array_equal(gk["score"] > 0, v):
+                        d2.append(np.linalg.norm(gk["joint"] - ok["joint"], axis=-1)[v])
+                n_ref += n
+            elif ok_ids:
+                it_ok += 1
+    out.update(stage2_steps=steps2, refined_skeletons=n_ref, track_ids_exact_rate=ids_ok / max(steps2, 1), lm_iterations_equal_rate=it_ok / max(steps2, 1))
+    if d2:
+        d = np.concatenate(d2)
+        out.update(refined_max_mm=round(float(d.max() * 1e3), 6), refined_mean_mm=round(float(d.mean() * 1e3), 6))
+    out["oracle_seconds"] = round(time.perf_counter() - t0, 2)
+    node.close()
+    return out
+
+
+def bench_latency_b1(rig, seq, name, device=0, frames_timed=200):
+    """The reference's operating point: ONE synchronised frame per callback (S3D:1069, PP:505).  se3d_triangulate + se3d_refine of one 16cam6p
+    frame through the synchronous host calls (pageable host buffers in, results out) and the device time of the kernels in between
+    (HIP events on the context's stream); frames of a sequence in order, so tracks persist and every person is refined."""
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
+    w = WORKLOADS[name]
+    node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=1, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=device)
+    node.refine_reset()
+    T_ = len(seq)
+    order = list(range(T_)) + list(range(T_ - 2, 0, -1))    # forward and back: continuous motion
+
+    def run(n, t_start):
+        t1 = t2 = 0.0
+        n_ref = 0
+        for i in range(n):
+            fr = seq[order[i % len(order)]]
+            a = time.perf_counter()
+            r = node.triangulate_persons([fr])[0]
+            b = time.perf_counter()
+            f = node.refine(0, r.published(), t_start + (i + 1) / 30.0, fr.fb_delay)
+            c = time.perf_counter()
+            t1 += b - a
+            t2 += c - b
+            n_ref += f.n_persons
+        return t1 / n, t2 / n, n_ref / n
+    run(40, 100.0)
+    node.profile(True)
+    node.profile_reset()
+    h1, h2, n_ref = run(frames_timed, 100.0 + 41 / 30.0)
+    node.profile(False)
+    dev = {k: node.profile_get(k) for k in STAGE1_KERNELS + STAGE2_KERNELS}
+    d1 = sum(dev[k][0] for k in STAGE1_KERNELS) / frames_timed
+    d2 = sum(dev[k][0] for k in STAGE2_KERNELS) / frames_timed
+    node.close()
+    return {"workload": "%s, one frame per call (B = 1)" % name, "frames_timed": frames_timed, "refined_skeletons_per_frame": round(n_ref, 2),
+            "host_call_ms": {"se3d_triangulate": round(h1 * 1e3, 4), "se3d_refine": round(h2 * 1e3, 4), "frame": round((h1 + h2) * 1e3, 4)},
+            "device_ms": {"stage1": round(d1, 4), "stage2": round(d2, 4), "frame": round(d1 + d2, 4)},
+            "note": "host: synchronous C-ABI calls incl. H2D / D2H of pageable buffers; device: HIP events around the kernel groups of the call "
+                    "(reference call sites S3D:1069, PP:505); the oracle's ms per frame: cpu_baseline.per_stage_ms"}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -575,7 +707,7 @@ def valu_of(res, w, stage2, pmc):
         cyc = sum(k["kernel_cycles"] * k["launches"] for k in ks)
         if cyc > 0:
             out["measured_valu_issue_utilisation"] = round(sum(k["counters_per_launch"]["SQ_INSTS_VALU"] * k["launches"] for k in ks) * 2.0 / (1024.0 * cyc), 4)
-            out["measured_source"] = "profiles/r2: " + pmc.get("note", "")
+            out["measured_source"] = pmc.get("_file", "profiles") + ": " + pmc.get("note", "")
     return out
 
 
@@ -600,6 +732,7 @@ def main():
     ap.add_argument("--no-streaming", action="store_true", help="skip the PCIe-inclusive streaming measurement (value_streaming) of a default run")
     ap.add_argument("--stream-contexts", type=int, default=8, help="contexts of the streaming measurement (each pins two batches of host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity / latency blocks of a default run")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -633,6 +766,10 @@ def main():
         w2 = WORKLOADS["256cam128p"]
         rig2 = make_rig(w2)
         seqs_sec = make_sequences(pool, w2, w2["contexts"], w2["seqs"], seed_rank, T_)
+    want_parity = default_run and stage2 and rank == 0 and not args.no_parity
+    if want_parity:   # the parity block's 64cam32p scene (two frames of one sequence)
+        rig64 = make_rig(WORKLOADS["64cam32p"])
+        seq64 = (pool.apply(_gen_one, ((64, 32, 2, 77),)) if pool is not None else _gen_one((64, 32, 2, 77)))
     if pool is not None:
         pool.close()
         pool.join()
@@ -649,14 +786,18 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
 
-    sec, hyp = None, None
+    sec, hyp, sec_serial = None, None, None
 
     def run_secondary():
-        nonlocal sec, hyp
+        nonlocal sec, hyp, sec_serial
         # steps: the four contexts take turns on the pair-cost kernel, so a timed region ends with a drain of ~100 ms (the last context's
         # sweep / stage-2 chain) that K steps of ~260 ms have to carry: K = 10 by default
         sec = run_workload("256cam128p", seqs_sec, rig2, args, max(5, args.steps // 2), 2, dist, local_rank, True)
         sec["value_per_gpu"] = sec["value"] / world
+        if rank == 0 and not args.no_serial:
+            # serial pass of the secondary configuration: ONE context, one stream, nothing else on the GPU -> per-kernel durations
+            sec_serial = run_workload("256cam128p", [seqs_sec[0]], rig2, args, 3, 1, None, local_rank, True)
+            sec_serial["value_per_gpu"] = sec_serial["value"]
         if dist is not None:   # one 256cam128p stream, hypotheses sharded over the ranks (north_star config 5)
             hyp = run_hypothesis_shard("256cam128p", _gen_one((256, 128, T_, 0)), rig2, 2, dist, local_rank)
 
@@ -679,6 +820,7 @@ def main():
                               None, local_rank, stage2, reproj=True)
         serial["value_per_gpu"] = serial["value"]
     seqs_stream = seqs_head[: max(1, min(args.stream_contexts, NC))]
+    seqs_par = seqs_head[0][:4]
     del seqs_head
     if os.environ.get("SE3D_BENCH_DEBUG_MEM"):
         free, total = torch.cuda.mem_get_info()
@@ -690,11 +832,14 @@ def main():
         streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps // 2), 2, local_rank)
     if rank == 0:
         main_res = head or serial
-        pmc_dir = os.path.join(ROOT, "profiles", "r2")
-
-        def load(fn):
-            p = os.path.join(pmc_dir, fn)
-            return json.load(open(p)) if os.path.exists(p) else None
+        def load(fn):   # committed counter summaries: this round's when present, else the previous round's
+            for rd in ("r3", "r2"):
+                p = os.path.join(ROOT, "profiles", rd, fn)
+                if os.path.exists(p):
+                    d = json.load(open(p))
+                    d["_file"] = "profiles/%s/%s" % (rd, fn)
+                    return d
+            return None
         roof_src = serial or head
         roof = roofline_of(roof_src, w, stage2, "serial pass: one context, one stream, %d sequences x %d frames (%.0f skeletons/s alone)"
                            % (roof_src["S"], roof_src["T"], roof_src["value"]) if serial else "overlapped contexts (no serial pass in this run)")
@@ -703,7 +848,7 @@ def main():
             roof["traffic"] = tr["kernels"].get(roof["kernel"], {}).get("hbm_bytes_per_launch_corrected")
         roof["valu"] = valu_of(main_res, w, stage2, load("pmc_sq_%s_serial.json" % headline))
         line = {
-            "metric": "3D skeletons/sec (triangulated + refined; parity vs the CPU oracle is asserted by tests/ and smoke(), not here)",
+            "metric": "3D skeletons/sec (triangulated + refined) + mm MPJPE vs the CPU oracle (`parity`), 16cam/6p (`value`) and 256cam/128p (`secondary`)",
             "value": round(main_res["value"], 2), "unit": "skeletons/s", "n_gpus": world, "steps": main_res["steps"], "warmup": main_res["warmup"],
             "ms_per_step": round(main_res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 geometry, f64 accumulation/eigen/LM", "data": "synthetic",
@@ -734,7 +879,15 @@ def main():
                                          "persons go back to host memory; never `value`.  At 16cam6p a frame is ~40 KB in and ~20 KB out: PCIe Gen5 x16 "
                                          "bounds this rate, not the kernels (DESIGN 5)"}
         if sec is not None:
-            roof2 = roofline_of(sec, WORKLOADS["256cam128p"], True, "overlapped contexts (%d per GPU)" % sec["NC"])
+            if sec_serial is not None:
+                roof2 = roofline_of(sec_serial, WORKLOADS["256cam128p"], True, "serial pass: one context, one stream, %d sequence x %d frames (%.0f skeletons/s alone)"
+                                    % (sec_serial["S"], sec_serial["T"], sec_serial["value"]))
+                tr2 = load("pmc_traffic_256cam128p_1ctx.json")   # committed PMC passes of `bench.py --workload 256cam128p --contexts 1`
+                if tr2:
+                    roof2["traffic"] = tr2["kernels"].get(roof2["kernel"], {}).get("hbm_bytes_per_launch_corrected")
+                    roof2["traffic_source"] = tr2["_file"]
+            else:
+                roof2 = roofline_of(sec, WORKLOADS["256cam128p"], True, "overlapped contexts (%d per GPU)" % sec["NC"])
             roof2["valu"] = valu_of(sec, WORKLOADS["256cam128p"], True, load("pmc_sq_256cam128p_1ctx.json"))
             line["secondary"] = {"workload": "256cam128p, stage 1+2, %d contexts x %d sequences x %d frames per GPU" % (sec["NC"], sec["S"], sec["T"]),
                                  "value": round(sec["value"], 2), "unit": "skeletons/s", "n_gpus": world, "value_per_gpu": round(sec["value_per_gpu"], 2),
@@ -749,6 +902,15 @@ def main():
                                         "verified_equal_to_single_rank": hyp["verified_equal_to_single_rank"],
                                         "allgather_bytes_per_step": hyp["allgather_bytes_per_step"],
                                         "note": "latency mode of north_star config 5; throughput runs shard sequences (the headline / secondary values)"}
+        if sec_serial is not None:
+            line["secondary"]["serial"] = {"value": round(sec_serial["value"], 2), "ms_per_step": round(sec_serial["ms_per_step"], 3), "steps": sec_serial["steps"],
+                                           "contexts": 1, "frames_per_step": sec_serial["B"]}
+        if want_parity:
+            line["parity"] = {"16cam6p": bench_parity(headline, rig, seqs_par, 4, local_rank), "64cam32p": bench_parity("64cam32p", rig64, [seq64], 1, local_rank),
+                              "note": "HIP path vs the CPU oracle (restatement of the reference, DESIGN 4) on the bench's own scenes, untimed: stage-1 joints "
+                                      "(mpjpe_*), association / hypothesis / person tables identical per frame (assoc_exact_rate), refined + predicted joints "
+                                      "of the resident stage-2 walk (refined_*), track ids and LM iteration counts per sequence-step; tolerance of the tests: 1 mm"}
+            line["latency_B1"] = bench_latency_b1(rig, seqs_par[0], headline, local_rank)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(rig, _gen_one((w["n_cam"], w["n_persons"], T_, 1000 * seed_rank)), main_res["params"], stage2)
         else:

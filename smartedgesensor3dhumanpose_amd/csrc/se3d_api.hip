@@ -100,10 +100,11 @@ struct se3d_ctx {
     int32_t *d_out_off = nullptr, *h_out_off = nullptr; // [B + 1]
     float *h_fb = nullptr, *d_fb = nullptr;             // [B][N] fb_delay of the batch (per slot: batch k + 1 is copied while batch k walks)
     hipEvent_t in_done = nullptr, compute_done = nullptr, off_done = nullptr;
+    hipStream_t s_out = nullptr;                        // the slot's OWN D2H stream: collect(k) never queues behind compute_done(k + 1)
     int n_frames = 0;
     bool busy = false;
   } ss[2];
-  hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+  hipStream_t s_h2d = nullptr;
   bool stream_ready = false;
   int ss_head = 0, ss_tail = 0;  // next slot to submit into / oldest batch not yet collected
   Se3dStage2 Q_shard{};   // views of the se3d_run_stage2_shard_pre call, reused by its _post half
@@ -486,7 +487,8 @@ void se3d_destroy(se3d_ctx *c) {
     if (sl.off_done) (void)hipEventDestroy(sl.off_done);
   }
   if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
-  if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
+  for (auto &sl : c->ss)
+    if (sl.s_out) (void)hipStreamDestroy(sl.s_out);
   for (auto &set : c->ev2)
     for (auto &e : set)
       if (e) (void)hipEventDestroy(e);
@@ -946,8 +948,8 @@ static int stream_init(se3d_ctx *c) {
   if (c->stream_ready) return SE3D_OK;
   const size_t B = c->D.d.B, N = c->D.d.N, P = c->D.d.P, H = c->D.d.H;
   HIPCHK(c, hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
-  HIPCHK(c, hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
   for (auto &sl : c->ss) {
+    HIPCHK(c, hipStreamCreateWithFlags(&sl.s_out, hipStreamNonBlocking));
     HIPCHK(c, hipHostMalloc((void **)&sl.h_rag, sizeof(se3d_person2d) * B * N * P, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void **)&sl.h_off, sizeof(int32_t) * B * (N + 1), hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void **)&sl.h_fused, sizeof(se3d_person3d) * B * H, hipHostMallocDefault));
@@ -969,7 +971,9 @@ static int stream_init(se3d_ctx *c) {
 int se3d_stream_submit(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames, int32_t n_seq, int32_t n_steps, const int32_t *frame_slot0, const double *t) {
   if (!c || !frames || !t || !frame_slot0 || n_frames < 1 || n_seq < 1 || n_steps < 1 || n_steps > SE3D_WALK_MAX_STEPS) return SE3D_ERR_ARG;
   const int B = c->D.d.B, N = c->D.d.N, P = c->D.d.P;
-  if (n_frames > B || (size_t)n_seq * n_steps > (size_t)n_frames) { c->err = "se3d_stream_submit: batch exceeds limits.max_frames / n_seq * n_steps exceeds the batch"; return SE3D_ERR_CAPACITY; }
+  if (n_frames > B) { c->err = "se3d_stream_submit: batch exceeds limits.max_frames"; return SE3D_ERR_CAPACITY; }
+  // every frame slot of the batch must be visited by the walk: a slot it skips would publish the results of an EARLIER batch
+  if ((size_t)n_seq * n_steps != (size_t)n_frames) { c->err = "se3d_stream_submit: n_seq * n_steps must equal n_frames"; return SE3D_ERR_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc = stream_init(c);
   if (rc != SE3D_OK) return rc;
@@ -1023,9 +1027,9 @@ int se3d_stream_submit(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frame
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(sl.compute_done, c->stream));
   // ---- D2H stream: the offsets first (the host needs the total before it can size the copy of the persons) ----
-  HIPCHK(c, hipStreamWaitEvent(c->s_d2h, sl.compute_done, 0));
-  HIPCHK(c, hipMemcpyAsync(sl.h_out_off, sl.d_out_off, sizeof(int32_t) * (size_t)(n_frames + 1), hipMemcpyDeviceToHost, c->s_d2h));
-  HIPCHK(c, hipEventRecord(sl.off_done, c->s_d2h));
+  HIPCHK(c, hipStreamWaitEvent(sl.s_out, sl.compute_done, 0));
+  HIPCHK(c, hipMemcpyAsync(sl.h_out_off, sl.d_out_off, sizeof(int32_t) * (size_t)(n_frames + 1), hipMemcpyDeviceToHost, sl.s_out));
+  HIPCHK(c, hipEventRecord(sl.off_done, sl.s_out));
   sl.n_frames = n_frames;
   sl.busy = true;
   c->ss_head ^= 1;
@@ -1040,10 +1044,10 @@ int se3d_stream_collect(se3d_ctx *c, se3d_stream_result *out) {
   HIPCHK(c, hipEventSynchronize(sl.off_done));
   const int total = sl.h_out_off[sl.n_frames];
   if (total > 0) {
-    HIPCHK(c, hipMemcpyAsync(sl.h_fused, sl.d_fused, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, c->s_d2h));
-    HIPCHK(c, hipMemcpyAsync(sl.h_pred, sl.d_pred, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, c->s_d2h));
+    HIPCHK(c, hipMemcpyAsync(sl.h_fused, sl.d_fused, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, sl.s_out));
+    HIPCHK(c, hipMemcpyAsync(sl.h_pred, sl.d_pred, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, sl.s_out));
   }
-  HIPCHK(c, hipStreamSynchronize(c->s_d2h));
+  HIPCHK(c, hipStreamSynchronize(sl.s_out));
   out->n_frames = sl.n_frames;
   out->n_persons = total;
   out->person_offset = sl.h_out_off;

@@ -226,3 +226,31 @@ def garbage_persons(persons3d):
             J = p["keypoints"]["joint"][v]
             out[i] = np.linalg.norm(J - np.median(J, 0), axis=-1).max() > GARBAGE_JOINT_DIST_M
     return out
+
+
+def inflation_allowance(tables, joints, valid, d):
+    """Absolute Frobenius allowance [n][17] for the comparison of stage-1 covariances that comes from the POSITION difference d [n][17] (m)
+    between the two sides: the limb-length term added to the diagonal (S3D:861-883), t = (g_limbLCovOffsetSigma (dist - L) / sigma_L)^2, is
+    a function of the joint positions — a difference of nearly equal numbers when the limb has its model length — so two results whose
+    joints differ by d (inside the 1 mm tolerance) differ in t by |dt| <= 2 c^2 |dist - L| D + c^2 D^2 with D <= d_joint + d_parent,
+    c = 0.075 / sigma_L, on each of the three diagonal entries.  joints / valid: one side's positions and validity in keypoint order;
+    tables: oracle.pose_tables(pose_method)."""
+    par, L, sg = tables["kpParent"], tables["limbLength"], tables["limbLSigma"]
+    out = np.zeros(valid.shape)
+
+    def term(j, k, length, sigma, targets):
+        both = valid[:, j] & valid[:, k]
+        dist = np.linalg.norm(joints[:, j] - joints[:, k], axis=-1)
+        D = d[:, j] + d[:, k]
+        c2 = (0.075 / sigma) ** 2
+        a = np.sqrt(3.0) * (2.0 * c2 * np.abs(dist - length) * D + c2 * D * D)
+        for t_ in targets:
+            out[:, t_] += np.where(both, a, 0.0)
+    for j in range(pm.NUM_KEYPOINTS):
+        if par[j] >= 0 and L[j] > 0:
+            term(j, par[j], L[j], sg[j], [j])
+    if tables.get("shoulderDist", 0) > 0:   # "simple": the right shoulder's term goes to both shoulders (S3D:875-881); keypoints 6 / 5
+        rs, ls = 6, 5
+        if par[rs] >= 0 and not (L[rs] > 0):
+            term(rs, ls, tables["shoulderDist"], tables["shoulderSigma"], [rs, ls])
+    return out
