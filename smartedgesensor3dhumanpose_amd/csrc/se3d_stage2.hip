@@ -1448,7 +1448,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
   double root[3] = {0, 0, 0}, neck[3] = {0, 0, 0};
   float root_score = 0.f, neck_score = 0.f;
   double height = 1.0, hprev = 1.0, rprev[3] = {0, 0, 0};
-  bool has_root = false, measured = false;
+  bool has_root = false, measured = false, first_obs = false;
   double m[3] = {0, 0, 0}, cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, xprev[3] = {0, 0, 0};
   float kscore = 0.f;
   if (have) {
@@ -1493,6 +1493,7 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
     // (exactly equal when heights are not normalised: height = 1); the trio LM is compared with the per-step kernels at 1e-9 m anyway.
     const double ih = 1.0 / height, ih2 = 1.0 / (height * height);
     const bool first = hp_old < 0.0;  // PP:699-702
+    first_obs = first;
     hprev = first ? height : hp_old;
     for (int a = 0; a < 3; ++a) rprev[a] = first ? root[a] : rp_old[a];
     if (first && j == 0) { Q.height_prev[sl] = height; for (int a = 0; a < 3; ++a) Q.root_prev[sl * 3 + a] = root[a]; }
@@ -1846,6 +1847,47 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
   LM_STAMP(5)  // marginals
   // ---- outputs + track-state update (PP:769-843): every lane writes the whole keypoint of its joint in both persons ----
   if (valid) {
+#ifndef SE3D_TRIO_CARRY
+    // What only this phase needs — root, height, the previous root / height, the initial value, the score, the stamp — is derived AGAIN
+    // from memory here (the detection and the track slot are unchanged, L2 / LDS hits) instead of being carried across the trial loop:
+    // 13 doubles per lane that the loop never touches were spilled to scratch before every pass and reloaded after it.
+    asm volatile("" ::: "memory");
+    {
+      const int ia = simple ? FU_LHip : FU_MidHip, ib = simple ? FU_RHip : FU_MidHip, ic = simple ? FU_LShoulder : FU_Neck, id = simple ? FU_RShoulder : FU_Neck;
+      const se3d_keypoint3d &ka = person.keypoints[ia], &kb = person.keypoints[ib], &kc = person.keypoints[ic], &kd = person.keypoints[id];
+      const float sa = ka.score, sb = kb.score, sc = kc.score, sd = kd.score, so = person.keypoints[j].score;
+      double nk[3] = {0, 0, 0};
+      float rs = 0.f, ns = 0.f;
+      root[0] = root[1] = root[2] = 0.0;
+      if (!simple) {
+        for (int a = 0; a < 3; ++a) { root[a] = ka.joint[a]; nk[a] = kc.joint[a]; }
+        rs = sa; ns = sc;
+      } else {
+        if (sa > 0.0f && sb > 0.0f) {
+          for (int a = 0; a < 3; ++a) root[a] = (ka.joint[a] + kb.joint[a]) / 2.0;
+          rs = (sa + sb) / 2.0f;
+        }
+        if (sc > 0.0f && sd > 0.0f) {
+          for (int a = 0; a < 3; ++a) nk[a] = (kc.joint[a] + kd.joint[a]) / 2.0;
+          ns = (sc + sd) / 2.0f;
+        }
+      }
+      height = 1.0;
+      if (rs > 0.10f && Q.norm_height) {
+        if (ns > 0.10f) {
+          const double dx = nk[0] - root[0], dy = nk[1] - root[1], dz = nk[2] - root[2];
+          height = sqrt(dx * dx + dy * dy + dz * dz);
+        } else height = 0.60;
+      }
+      kscore = j == FU_MidHip ? rs : ((simple && j == FU_Neck) ? ns : so);
+      // a first observation stored height / root into the slot before the loop: reading them back gives `first ? height : old` either way
+      hprev = first_obs ? height : Q.height_prev[sl];
+      for (int a = 0; a < 3; ++a) {
+        rprev[a] = first_obs ? root[a] : Q.root_prev[sl * 3 + a];
+        x0[a] = use_vel ? Q.prev[(sl * SE3D_NFU + j) * 3 + a] : m[a];
+      }
+    }
+#endif
     const bool wr = !Q.direct_out || pubv != 0;                          // an unpublished person's payload is never read: not written
     se3d_person3d &pf = pubv ? Q.fused[(size_t)s * H + pubv - 1] : Q.fused_det[(size_t)s * H + i];
     se3d_person3d &pp = pubv ? Q.pred[(size_t)s * H + pubv - 1] : Q.pred_det[(size_t)s * H + i];
@@ -2263,6 +2305,9 @@ __device__ __forceinline__ void s2_track_near_flat(const Se3dStage2 &Q, int s, i
   }
 }
 
+#ifndef S2_TRIO_WAVES
+#define S2_TRIO_WAVES 2   // wavefronts per SIMD the trio walk is compiled for (256 VGPRs)
+#endif
 #ifndef S2_WALK_WAVES
 #define S2_WALK_WAVES 4
 #endif
@@ -2286,7 +2331,7 @@ __device__ __forceinline__ void s2_track_near_flat(const Se3dStage2 &Q, int s, i
 // for launches of many sequences.  Its LM workspace, Munkres scratch and track-position table share one LDS region (the phases of
 // a single wavefront are sequential).
 template <bool TRIO, int WV, int SQ>
-__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 2 : 3, TRIO ? 2 : 3))) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int nseq) {
+__global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? S2_TRIO_WAVES : 3, TRIO ? S2_TRIO_WAVES : 3))) void se3d_k_stage2_walk(Se3dStage2 Q, Se3dWalk Wk, int nseq) {
   using WaveLds = typename std::conditional<TRIO, LmTrioLds, LmTreeLds>::type;
   extern __shared__ __align__(16) unsigned char s2_walk_smem[];
   __shared__ int s_next_person;
