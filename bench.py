@@ -254,6 +254,27 @@ def bench_latency_b1(rig, seq, name, device=0, frames_timed=200):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # one measurement: NC contexts x S sequences x T frames resident on this rank's GPU
 # ---------------------------------------------------------------------------------------------------------------------------------
+def memory_plan(name, n_ctx, n_frames, exchange=False, free_bytes=None):
+    """Device memory one rank's GPU needs for `n_ctx` contexts of `n_frames` resident frames each (se3d_device_bytes: the library's own
+    allocation list, host arithmetic) + the exchange's pack / gather buffers; raises SystemExit with the figures when it exceeds what is
+    free, instead of a hipMalloc error half-way through the context creation."""
+    from smartedgesensor3dhumanpose_amd import person_msgs as pm
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import device_bytes
+    w = WORKLOADS[name]
+    per_ctx = device_bytes(w["n_cam"], n_frames, w["max_det"], w["max_hyp"])
+    ex = 0
+    if exchange:   # SkeletonExchange: 2 pack + 2 gather buffers of [n_ctx][n_frames][max_hyp] persons (+ counts), gather x world
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        ex = 2 * (1 + world) * n_ctx * n_frames * (w["max_hyp"] * pm.person3d_dt.itemsize + 4)
+    plan = {"workload": name, "contexts": n_ctx, "frames_per_context": n_frames, "bytes_per_context": per_ctx, "exchange_bytes": ex,
+            "total_bytes": n_ctx * per_ctx + ex}
+    if free_bytes is not None and plan["total_bytes"] > free_bytes:
+        raise SystemExit("bench.py: %s with %d contexts x %d frames needs %.1f GB of device memory per GPU (%.2f GB per context%s), %.1f GB are free: "
+                         "lower --contexts / --seqs" % (name, n_ctx, n_frames, plan["total_bytes"] / 1e9, per_ctx / 1e9,
+                                                        ", %.2f GB exchange buffers" % (ex / 1e9) if ex else "", free_bytes / 1e9))
+    return plan
+
+
 def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank, stage2, verify_exchange=True, reproj=False):
     """seqs_per_ctx: list over contexts of lists of sequences.  Returns a dict (all ranks; `value` etc. are whole-job figures)."""
     import torch
@@ -264,6 +285,7 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
     NC, S_, T_ = len(seqs_per_ctx), len(seqs_per_ctx[0]), len(seqs_per_ctx[0][0])
     B = S_ * T_
     world = dist.get_world_size() if dist is not None else 1
+    memory_plan(name, NC, B, exchange=dist is not None, free_bytes=torch.cuda.mem_get_info(local_rank)[0])   # fails fast, with the figures
     nodes = []
     for seqs in seqs_per_ctx:   # every rank (and every context) owns its own sequences: weak scaling, no data-path collective
         frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s

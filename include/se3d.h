@@ -142,7 +142,13 @@ int se3d_rig_from_transforms(int32_t n_cam, const double *T_base_to_cam, float *
 /* --- context ------------------------------------------------------------------------------------------- */
 se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d_limits *limits, int32_t device_id);
 void se3d_destroy(se3d_ctx *ctx);
+/* ctx != NULL: message of the context's last failed call.  ctx == NULL: why the last se3d_create of the calling thread returned NULL
+ * (unsupported sizes, no device, out of device memory — with the bytes the context needs and the bytes free). */
 const char *se3d_last_error(const se3d_ctx *ctx);
+/* Device memory in bytes that se3d_create allocates for a rig of n_cam cameras under `limits` (host arithmetic only, no device call; the
+ * streaming, reprojection and hypothesis-shard buffers of later calls are not included); -1 for sizes se3d_create rejects.  bench.py's
+ * memory plan (N contexts per GPU) and a node's start-up check use it to fail with a message instead of a hipMalloc error. */
+int64_t se3d_device_bytes(int32_t n_cam, const se3d_limits *limits);
 const char *se3d_version(void);
 
 /* --- stage 1: drop-in for triangulate_persons (S3D:525-997) ------------------------------------------- */

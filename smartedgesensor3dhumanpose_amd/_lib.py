@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("SE3D_LIB_OVERRIDE") or os.path.join(_HERE, "libse3d_h
 
 # every entry point declared in include/se3d.h (checked against the header in tests/test_abi.py)
 EXPORTS = [
-    "se3d_rig_from_transforms", "se3d_create", "se3d_destroy", "se3d_last_error", "se3d_version",
+    "se3d_rig_from_transforms", "se3d_create", "se3d_destroy", "se3d_last_error", "se3d_device_bytes", "se3d_version",
     "se3d_triangulate", "se3d_triangulate_batch", "se3d_stage_frames", "se3d_run_stage1", "se3d_sync", "se3d_fetch_stage1",
     "se3d_refine_reset", "se3d_refine", "se3d_run_stage2", "se3d_fetch_stage2",
     "se3d_hungarian", "se3d_get_pair_costs", "se3d_selftest_exact_math", "se3d_get_fusion_constants", "se3d_pack_stage1_device", "se3d_pack_stage2_device",
@@ -80,5 +80,6 @@ def lib():
                      "se3d_run_stage1_phases", "se3d_set_shard", "se3d_run_stage1_shard_pre", "se3d_run_stage1_shard_post", "se3d_run_stage2_shard_pre", "se3d_run_stage2_shard_post"):
             getattr(L, name).restype = C.c_int
         L.se3d_shard_bytes.restype = C.c_int64
+        L.se3d_device_bytes.restype = C.c_int64
         _lib = L
     return _lib

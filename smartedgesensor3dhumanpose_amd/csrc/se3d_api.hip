@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -105,6 +106,8 @@ struct se3d_ctx {
     bool busy = false;
   } ss[2];
   hipStream_t s_h2d = nullptr;
+  bool dry = false;          // dev_alloc only counts (se3d_device_bytes)
+  size_t dry_bytes = 0;
   bool stream_ready = false;
   int ss_head = 0, ss_tail = 0;  // next slot to submit into / oldest batch not yet collected
   Se3dStage2 Q_shard{};   // views of the se3d_run_stage2_shard_pre call, reused by its _post half
@@ -132,6 +135,11 @@ bool hip_ok(se3d_ctx *c, hipError_t e, const char *what) {
 
 template <typename T>
 bool dev_alloc(se3d_ctx *c, T **p, size_t n) {
+  if (c->dry) {   // se3d_device_bytes: the allocation list of se3d_create is walked without touching a device
+    c->dry_bytes += (n * sizeof(T) + 255) & ~(size_t)255;
+    *p = nullptr;
+    return true;
+  }
   void *q = nullptr;
   if (!hip_ok(c, hipMalloc(&q, n * sizeof(T)), "hipMalloc")) return false;
   c->allocs.push_back(q);
@@ -262,6 +270,65 @@ void pinv34(const double P[12], double out[12]) {
     }
 }
 
+// Why the last se3d_create of this thread returned NULL: kept for se3d_last_error(NULL) (a NULL context has no error slot of its own)
+// and printed to stderr as before.
+static thread_local std::string t_create_err;
+static void create_error(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  t_create_err = buf;
+  fprintf(stderr, "%s\n", buf);
+}
+
+// Every device buffer a context owns from its creation on (the streaming slots, the reprojection lists and the hypothesis-shard blocks are
+// allocated by the first call that needs them).  One list for se3d_create and for se3d_device_bytes (dry run: c->dry).
+struct RigDev { float *Rt = nullptr, *K = nullptr, *F = nullptr; se3d_person2d *raw = nullptr; int32_t *nraw = nullptr; };
+static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, const se3d_limits *limits, RigDev &r) {
+  const int B = limits->max_frames, P = limits->max_det_per_cam, H = limits->max_hyp;
+  Se3dDev &D = c->D;
+  const int np = N * (N - 1) / 2;
+  D.d = Se3dDims{B, N, P, H, np, params->pose_method, params->norm_height, params->max_epi_dist, 0, 1};
+  bool ok = true;
+  ok = ok && dev_alloc(c, &r.Rt, (size_t)N * 12) && dev_alloc(c, &r.K, (size_t)N * 4) && dev_alloc(c, &r.F, (size_t)np * 9);
+  ok = ok && dev_alloc(c, &r.raw, (size_t)B * N * P) && dev_alloc(c, &r.nraw, (size_t)B * N);
+  ok = ok && dev_alloc(c, &D.kp, (size_t)B * N * P * SE3D_NKP) && dev_alloc(c, &c->d_assoc_in, (size_t)B * H * N);
+  ok = ok && dev_alloc(c, &D.pscore, (size_t)B * N * P) && dev_alloc(c, &D.vmask_gt, (size_t)B * N * P) && dev_alloc(c, &D.vmask_ge, (size_t)B * N * P);
+  ok = ok && dev_alloc(c, &D.nvalid, (size_t)B * N) && dev_alloc(c, &D.orig, (size_t)B * N * P);
+  ok = ok && dev_alloc(c, &D.pair, (size_t)B * np * P * P);
+  ok = ok && dev_alloc(c, &D.assoc, (size_t)B * H * N) && dev_alloc(c, &D.nviews, (size_t)B * H) && dev_alloc(c, &D.nhyp, (size_t)B);
+  ok = ok && dev_alloc(c, &D.C, (size_t)B * H * P) && dev_alloc(c, &D.mask, (size_t)B * H * P) && dev_alloc(c, &D.mwork, (size_t)B * H * P);
+  ok = ok && dev_alloc(c, &D.flags, (size_t)B);
+  ok = ok && dev_alloc(c, &D.tri_slow, (size_t)B * H * 4);
+  ok = ok && dev_alloc(c, &D.hypP, (size_t)B * H) && dev_alloc(c, &D.keep, (size_t)B * H) && dev_alloc(c, &D.outP, (size_t)B * H);
+  ok = ok && dev_alloc(c, &D.out_count, (size_t)B) && dev_alloc(c, &D.out_hyp, (size_t)B * H) && dev_alloc(c, &D.out_assoc, (size_t)B * H * N);
+  ok = ok && dev_alloc(c, &c->pair_ab, (size_t)np);
+  {  // stage 2 state: S = B sequences, T = max_tracks
+    const int T = limits->max_tracks > 0 ? limits->max_tracks : H;
+    Se3dStage2 &Q = c->Q;
+    const size_t S = B;
+    Q.S = B; Q.T = T; Q.H = H; Q.N = N; Q.pose_method = params->pose_method; Q.norm_height = params->norm_height; Q.seq0 = 0;
+    Q.shard_rank = 0; Q.shard_world = 1;
+    ok = ok && dev_alloc(c, &Q.fb_buf, S * 3) && dev_alloc(c, &Q.t_prev, S) && dev_alloc(c, &Q.next_id, S) && dev_alloc(c, &Q.frame_nr, S);
+    ok = ok && dev_alloc(c, &Q.n_tracks, S) && dev_alloc(c, &Q.order, S * T) && dev_alloc(c, &Q.pred_dt, S);
+    ok = ok && dev_alloc(c, &Q.used, S * T) && dev_alloc(c, &Q.id, S * T) && dev_alloc(c, &Q.num_obs, S * T) && dev_alloc(c, &Q.has, S * T);
+    ok = ok && dev_alloc(c, &Q.trk_t_prev, S * T) && dev_alloc(c, &Q.height_prev, S * T) && dev_alloc(c, &Q.root_prev, S * T * 3);
+    ok = ok && dev_alloc(c, &Q.prev, S * T * SE3D_NFU * 3) && dev_alloc(c, &Q.vel, S * T * SE3D_NFU * 9);
+    ok = ok && dev_alloc(c, &Q.near, S * T * 4);
+    ok = ok && dev_alloc(c, &Q.C, S * H * T) && dev_alloc(c, &Q.W, S * H * T) && dev_alloc(c, &Q.det_slot, S * H) && dev_alloc(c, &Q.pub, S * H);
+    ok = ok && dev_alloc(c, &Q.fused_det, S * H) && dev_alloc(c, &Q.pred_det, S * H) && dev_alloc(c, &Q.iters_det, S * H);
+    ok = ok && dev_alloc(c, &Q.lm_scratch, S * 4 * 1865);  // [S][4 wavefronts][S2_SCHUR_SCRATCH_DOUBLES] (se3d_stage2.hip)
+    ok = ok && dev_alloc(c, &Q.fused, S * H) && dev_alloc(c, &Q.pred, S * H) && dev_alloc(c, &Q.iters, S * H) && dev_alloc(c, &Q.n_out, S);
+    ok = ok && dev_alloc(c, &Q.flags2, S);
+    ok = ok && dev_alloc(c, &c->d_in2, S * H) && dev_alloc(c, &c->d_ndet2, S) && dev_alloc(c, &c->d_fb, S * N) && dev_alloc(c, &c->d_t, S);
+    ok = ok && dev_alloc(c, &c->d_fb_ref, S * N) && dev_alloc(c, &c->d_hung, (size_t)SE3D_MUNKRES_MAX * SE3D_MUNKRES_MAX) &&
+         dev_alloc(c, &c->d_hung_assign, (size_t)SE3D_MUNKRES_MAX + 1);
+  }
+  return ok;
+}
+
 }  // namespace
 
 extern "C" {
@@ -315,20 +382,20 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
   if (!rig || !params || !limits || !rig->Rt || !rig->K || !rig->F) return nullptr;
   const int N = rig->n_cam, B = limits->max_frames, P = limits->max_det_per_cam, H = limits->max_hyp;
   if (N < 2 || N > SE3D_MAX_CAMS || B < 1 || P < 1 || P > SE3D_MUNKRES_MAX || H < P || H > SE3D_MUNKRES_MAX) {
-    fprintf(stderr, "se3d_create: unsupported sizes (n_cam %d [2..%d], det/cam %d [1..%d], hyp %d [det..%d])\n", N, SE3D_MAX_CAMS, P,
-            SE3D_MUNKRES_MAX, H, SE3D_MUNKRES_MAX);
+    create_error("se3d_create: unsupported sizes (n_cam %d [2..%d], det/cam %d [1..%d], hyp %d [det..%d])", N, SE3D_MAX_CAMS, P,
+                 SE3D_MUNKRES_MAX, H, SE3D_MUNKRES_MAX);
     return nullptr;
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) {
-    fprintf(stderr, "se3d_create: no usable HIP device (count=%d, requested=%d); there is no CPU fallback\n", ndev, device_id);
+    create_error("se3d_create: no usable HIP device (count=%d, requested=%d); there is no CPU fallback", ndev, device_id);
     return nullptr;
   }
   se3d_ctx *c = new se3d_ctx();
   c->params = *params;
   c->limits = *limits;
   c->device = device_id;
-  if (!hip_ok(c, hipSetDevice(device_id), "hipSetDevice")) { fprintf(stderr, "%s\n", c->err.c_str()); delete c; return nullptr; }
+  if (!hip_ok(c, hipSetDevice(device_id), "hipSetDevice")) { create_error("se3d_create: %s", c->err.c_str()); delete c; return nullptr; }
   {
     // Large rigs (>= 128 cameras): the bulk stream of the context (pair-cost kernel: millions of workgroups, 36 KB of LDS each) is kept off
     // 32 CUs — one XCD — so that the small latency-bound launches of the camera sweep and the per-step stage 2 (high-priority stream, all
@@ -354,54 +421,27 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
   }
   // dynamic-LDS limits of the large-LDS kernels: a per-device attribute, so it is set for every context's device
   if (!hip_ok(c, se3d_stage1_init_device(), "hipFuncSetAttribute (stage 1)") || !hip_ok(c, se3d_stage2_init_device(), "hipFuncSetAttribute (stage 2)")) {
-    fprintf(stderr, "se3d_create: %s\n", c->err.c_str());
+    create_error("se3d_create: %s", c->err.c_str());
     (void)hipStreamDestroy(c->stream);
+    if (c->stream_hi) (void)hipStreamDestroy(c->stream_hi);
+    for (auto &e : c->ev_hi)
+      if (e) (void)hipEventDestroy(e);
     delete c;
     return nullptr;
   }
   for (auto &set : c->ev)
     for (auto &e : set) (void)hipEventCreate(&e);
+  const int T_chk = limits->max_tracks > 0 ? limits->max_tracks : H;
+  if (T_chk > SE3D_MUNKRES_MAX) { create_error("se3d_create: max_tracks %d > %d", T_chk, SE3D_MUNKRES_MAX); se3d_destroy(c); return nullptr; }
   Se3dDev &D = c->D;
   const int np = N * (N - 1) / 2;
-  D.d = Se3dDims{B, N, P, H, np, params->pose_method, params->norm_height, params->max_epi_dist, 0, 1};
-  bool ok = true;
-  float *dRt = nullptr, *dK = nullptr, *dF = nullptr;
-  se3d_person2d *draw = nullptr;
-  int32_t *dnraw = nullptr;
-  ok = ok && dev_alloc(c, &dRt, (size_t)N * 12) && dev_alloc(c, &dK, (size_t)N * 4) && dev_alloc(c, &dF, (size_t)np * 9);
-  ok = ok && dev_alloc(c, &draw, (size_t)B * N * P) && dev_alloc(c, &dnraw, (size_t)B * N);
-  ok = ok && dev_alloc(c, &D.kp, (size_t)B * N * P * SE3D_NKP) && dev_alloc(c, &c->d_assoc_in, (size_t)B * H * N);
-  ok = ok && dev_alloc(c, &D.pscore, (size_t)B * N * P) && dev_alloc(c, &D.vmask_gt, (size_t)B * N * P) && dev_alloc(c, &D.vmask_ge, (size_t)B * N * P);
-  ok = ok && dev_alloc(c, &D.nvalid, (size_t)B * N) && dev_alloc(c, &D.orig, (size_t)B * N * P);
-  ok = ok && dev_alloc(c, &D.pair, (size_t)B * np * P * P);
-  ok = ok && dev_alloc(c, &D.assoc, (size_t)B * H * N) && dev_alloc(c, &D.nviews, (size_t)B * H) && dev_alloc(c, &D.nhyp, (size_t)B);
-  ok = ok && dev_alloc(c, &D.C, (size_t)B * H * P) && dev_alloc(c, &D.mask, (size_t)B * H * P) && dev_alloc(c, &D.mwork, (size_t)B * H * P);
-  ok = ok && dev_alloc(c, &D.flags, (size_t)B);
-  ok = ok && dev_alloc(c, &D.tri_slow, (size_t)B * H * 4);
-  ok = ok && dev_alloc(c, &D.hypP, (size_t)B * H) && dev_alloc(c, &D.keep, (size_t)B * H) && dev_alloc(c, &D.outP, (size_t)B * H);
-  ok = ok && dev_alloc(c, &D.out_count, (size_t)B) && dev_alloc(c, &D.out_hyp, (size_t)B * H) && dev_alloc(c, &D.out_assoc, (size_t)B * H * N);
-  ok = ok && dev_alloc(c, &c->pair_ab, (size_t)np);
-  {  // stage 2 state: S = B sequences, T = max_tracks
-    const int T = limits->max_tracks > 0 ? limits->max_tracks : H;
-    if (T > SE3D_MUNKRES_MAX) { fprintf(stderr, "se3d_create: max_tracks %d > %d\n", T, SE3D_MUNKRES_MAX); se3d_destroy(c); return nullptr; }
-    Se3dStage2 &Q = c->Q;
+  RigDev rd;
+  bool ok = alloc_device_state(c, N, params, limits, rd);
+  float *dRt = rd.Rt, *dK = rd.K, *dF = rd.F;
+  se3d_person2d *draw = rd.raw;
+  int32_t *dnraw = rd.nraw;
+  {
     const size_t S = B;
-    Q.S = B; Q.T = T; Q.H = H; Q.N = N; Q.pose_method = params->pose_method; Q.norm_height = params->norm_height; Q.seq0 = 0;
-    Q.shard_rank = 0; Q.shard_world = 1;
-    ok = ok && dev_alloc(c, &Q.fb_buf, S * 3) && dev_alloc(c, &Q.t_prev, S) && dev_alloc(c, &Q.next_id, S) && dev_alloc(c, &Q.frame_nr, S);
-    ok = ok && dev_alloc(c, &Q.n_tracks, S) && dev_alloc(c, &Q.order, S * T) && dev_alloc(c, &Q.pred_dt, S);
-    ok = ok && dev_alloc(c, &Q.used, S * T) && dev_alloc(c, &Q.id, S * T) && dev_alloc(c, &Q.num_obs, S * T) && dev_alloc(c, &Q.has, S * T);
-    ok = ok && dev_alloc(c, &Q.trk_t_prev, S * T) && dev_alloc(c, &Q.height_prev, S * T) && dev_alloc(c, &Q.root_prev, S * T * 3);
-    ok = ok && dev_alloc(c, &Q.prev, S * T * SE3D_NFU * 3) && dev_alloc(c, &Q.vel, S * T * SE3D_NFU * 9);
-    ok = ok && dev_alloc(c, &Q.near, S * T * 4);
-    ok = ok && dev_alloc(c, &Q.C, S * H * T) && dev_alloc(c, &Q.W, S * H * T) && dev_alloc(c, &Q.det_slot, S * H) && dev_alloc(c, &Q.pub, S * H);
-    ok = ok && dev_alloc(c, &Q.fused_det, S * H) && dev_alloc(c, &Q.pred_det, S * H) && dev_alloc(c, &Q.iters_det, S * H);
-    ok = ok && dev_alloc(c, &Q.lm_scratch, S * 4 * 1865);  // [S][4 wavefronts][S2_SCHUR_SCRATCH_DOUBLES] (se3d_stage2.hip)
-    ok = ok && dev_alloc(c, &Q.fused, S * H) && dev_alloc(c, &Q.pred, S * H) && dev_alloc(c, &Q.iters, S * H) && dev_alloc(c, &Q.n_out, S);
-    ok = ok && dev_alloc(c, &Q.flags2, S);
-    ok = ok && dev_alloc(c, &c->d_in2, S * H) && dev_alloc(c, &c->d_ndet2, S) && dev_alloc(c, &c->d_fb, S * N) && dev_alloc(c, &c->d_t, S);
-    ok = ok && dev_alloc(c, &c->d_fb_ref, S * N) && dev_alloc(c, &c->d_hung, (size_t)SE3D_MUNKRES_MAX * SE3D_MUNKRES_MAX) &&
-         dev_alloc(c, &c->d_hung_assign, (size_t)SE3D_MUNKRES_MAX + 1);
     for (auto &set : c->ev2)
       for (auto &e : set) (void)hipEventCreate(&e);
     if (ok) {
@@ -441,7 +481,12 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_outassoc, sizeof(int32_t) * (size_t)B * H * N, hipHostMallocDefault), "hipHostMalloc");
   }
   if (!ok) {
-    fprintf(stderr, "se3d_create failed: %s\n", c->err.c_str());
+    {
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      create_error("se3d_create failed: %s (the context needs %.2f GB of device memory, %.2f of %.2f GB are free)", c->err.c_str(),
+                   (double)se3d_device_bytes(N, limits) / 1e9, free_b / 1e9, total_b / 1e9);
+    }
     se3d_destroy(c);
     return nullptr;
   }
@@ -504,7 +549,23 @@ void se3d_destroy(se3d_ctx *c) {
   delete c;
 }
 
-const char *se3d_last_error(const se3d_ctx *c) { return c ? c->err.c_str() : "null context"; }
+const char *se3d_last_error(const se3d_ctx *c) { return c ? c->err.c_str() : t_create_err.c_str(); }
+
+// Device memory se3d_create(rig with n_cam cameras, limits) allocates, in bytes (host arithmetic only; no device is touched): the
+// allocation list of se3d_create walked with a counting allocator.  -1 for sizes se3d_create rejects.
+int64_t se3d_device_bytes(int32_t n_cam, const se3d_limits *limits) {
+  if (!limits) return -1;
+  const int N = n_cam, B = limits->max_frames, P = limits->max_det_per_cam, H = limits->max_hyp;
+  const int T = limits->max_tracks > 0 ? limits->max_tracks : H;
+  if (N < 2 || N > SE3D_MAX_CAMS || B < 1 || P < 1 || P > SE3D_MUNKRES_MAX || H < P || H > SE3D_MUNKRES_MAX || T > SE3D_MUNKRES_MAX) return -1;
+  se3d_ctx c;
+  c.dry = true;
+  c.limits = *limits;
+  se3d_params prm{};
+  RigDev rd;
+  (void)alloc_device_state(&c, N, &prm, limits, rd);
+  return (int64_t)c.dry_bytes;
+}
 
 int se3d_stage_frames(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames) {
   if (!c || !frames || n_frames < 1) return SE3D_ERR_ARG;
@@ -537,6 +598,7 @@ int se3d_stage_frames(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames
 
 int se3d_run_stage1(se3d_ctx *c) {
   if (!c) return SE3D_ERR_ARG;
+  if (c->D.d.shard_world > 1) { c->err = "a hypothesis shard is set (se3d_set_shard, world > 1): use the se3d_run_stage*_shard_pre / _post pairs, the plain run calls would skip the other ranks' hypotheses"; return SE3D_ERR_STATE; }
   if (c->staged_frames < 1) { c->err = "no frames staged"; return SE3D_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   Se3dDev D = c->D;
@@ -550,6 +612,7 @@ int se3d_run_stage1(se3d_ctx *c) {
 
 int se3d_run_stage1_phases(se3d_ctx *c, int32_t phases) {
   if (!c || (phases & ~15) || !phases) return SE3D_ERR_ARG;
+  if (c->D.d.shard_world > 1) { c->err = "a hypothesis shard is set (se3d_set_shard, world > 1): use the se3d_run_stage*_shard_pre / _post pairs, the plain run calls would skip the other ranks' hypotheses"; return SE3D_ERR_STATE; }
   if (c->staged_frames < 1) { c->err = "no frames staged"; return SE3D_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   Se3dDev D = c->D;
@@ -783,6 +846,7 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
 
 int se3d_run_stage2(se3d_ctx *c, int32_t n_seq, int32_t frame_slot0, const double *t) {
   if (!c || !t || n_seq < 1 || frame_slot0 < 0) return SE3D_ERR_ARG;
+  if (c->D.d.shard_world > 1) { c->err = "a hypothesis shard is set (se3d_set_shard, world > 1): use the se3d_run_stage*_shard_pre / _post pairs, the plain run calls would skip the other ranks' hypotheses"; return SE3D_ERR_STATE; }
   if (!c->ran || frame_slot0 + n_seq > c->staged_frames) { c->err = "se3d_run_stage2 needs a preceding se3d_run_stage1 over >= n_seq frames"; return SE3D_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   Se3dStage2 Q = c->Q;
@@ -801,6 +865,7 @@ int se3d_run_stage2(se3d_ctx *c, int32_t n_seq, int32_t frame_slot0, const doubl
 
 int se3d_run_stage2_walk(se3d_ctx *c, int32_t n_seq, int32_t n_steps, const int32_t *frame_slot0, const double *t) {
   if (!c || !t || !frame_slot0 || n_seq < 1 || n_steps < 1 || n_steps > SE3D_WALK_MAX_STEPS) return SE3D_ERR_ARG;
+  if (c->D.d.shard_world > 1) { c->err = "a hypothesis shard is set (se3d_set_shard, world > 1): use the se3d_run_stage*_shard_pre / _post pairs, the plain run calls would skip the other ranks' hypotheses"; return SE3D_ERR_STATE; }
   if (!c->ran) { c->err = "se3d_run_stage2_walk needs a preceding se3d_run_stage1"; return SE3D_ERR_STATE; }
   if ((size_t)n_steps * n_seq > (size_t)c->Q.S) { c->err = "se3d_run_stage2_walk: n_steps * n_seq exceeds limits.max_frames"; return SE3D_ERR_CAPACITY; }
   for (int k = 0; k < n_steps; ++k)

@@ -184,12 +184,15 @@ class HypothesisShard:
         self.bytes_per_step = (b1 + n_frames // max(n_seq, 1) * b2) * self.world
 
     def run_stage1(self):
+        # the unpack kernels index rank r's block at r * staged_frames * ceil(H / world): the gather buffers were sized for n_frames
+        assert self.node._staged == self.n_frames, "HypothesisShard was built for %d staged frames, the context holds %d" % (self.n_frames, self.node._staged)
         self.node.run_stage1_shard_pre(self.p1.data_ptr())
         with torch.cuda.stream(self.stream):   # the collective is ordered after the pack on the context's stream
             self.dist.all_gather_into_tensor(self.g1, self.p1)
         self.node.run_stage1_shard_post(self.g1.data_ptr())
 
     def run_stage2(self, t, frame_slot0):
+        assert len(t) == self.n_seq, "HypothesisShard was built for %d sequences per step, got %d" % (self.n_seq, len(t))
         self.node.run_stage2_shard_pre(t, frame_slot0, self.p2.data_ptr())
         with torch.cuda.stream(self.stream):
             self.dist.all_gather_into_tensor(self.g2, self.p2)

@@ -25,6 +25,15 @@ def rig_tensors(rig):
     return Rt, F
 
 
+def device_bytes(n_cam, max_frames, max_det_per_cam, max_hyp, max_tracks=None):
+    """Device memory a context of these limits allocates at creation (se3d_device_bytes: host arithmetic, no GPU call)."""
+    lim = pm.Limits(int(max_frames), int(max_det_per_cam), int(max_hyp), int(max_tracks or max_hyp))
+    n = _lib.lib().se3d_device_bytes(int(n_cam), C.byref(lim))
+    if n < 0:
+        raise Se3dError("se3d_device_bytes: unsupported sizes")
+    return int(n)
+
+
 class Skeleton3D:
     """One skeleton_3d node instance bound to one GPU."""
 
@@ -40,7 +49,8 @@ class Skeleton3D:
         self._L = _lib.lib()
         self._h = self._L.se3d_create(C.byref(self._rig_c), C.byref(self.params), C.byref(self.limits), int(device))
         if not self._h:
-            raise Se3dError("se3d_create failed (no GPU, unsupported sizes or out of memory); there is no CPU fallback")
+            why = self._L.se3d_last_error(None)
+            raise Se3dError("se3d_create failed: %s; there is no CPU fallback" % (why.decode() if why else "no GPU, unsupported sizes or out of memory"))
         self._staged = 0
 
     # -- error helper

@@ -96,3 +96,39 @@ def test_product_rig_tensors_match_oracle(product_lib, oracle):
             r = np.einsum("ni,ij,nj->n", x[j], Fk, x[i])
             assert np.abs(r).max() < 1e-6 * np.linalg.norm(Fk), (i, j, np.abs(r).max())
             k += 1
+
+
+def test_device_bytes_and_bench_memory_plan(product_lib):
+    """se3d_device_bytes walks se3d_create's allocation list on the host: the 256cam128p pair table (16 frames x 32 640 camera pairs x 128^2
+    doubles = 68.5 GB) dominates a context; bench.py's plan fails fast with the figures when the contexts do not fit the GPU."""
+    import bench
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Se3dError, device_bytes
+    b = device_bytes(256, 16, 128, 256)
+    pair = 16 * (256 * 255 // 2) * 128 * 128 * 8
+    assert pair < b < pair + 2e9
+    assert device_bytes(16, 2, 8, 12) < device_bytes(16, 4, 8, 12) < 10e6
+    with pytest.raises(Se3dError):
+        device_bytes(1, 1, 8, 12)          # fewer than two cameras: se3d_create rejects it, so does the plan
+    plan = bench.memory_plan("256cam128p", 4, 16, exchange=True)
+    assert plan["total_bytes"] == 4 * b + plan["exchange_bytes"] and plan["total_bytes"] < 288e9
+    with pytest.raises(SystemExit) as e:
+        bench.memory_plan("256cam128p", 5, 16, free_bytes=int(288e9))
+    assert "needs" in str(e.value) and "GB" in str(e.value) and "--contexts" in str(e.value)
+
+
+def test_create_failure_reason_is_retrievable(product_lib):
+    """se3d_last_error(NULL): why the calling thread's last se3d_create returned NULL (round 2 only printed it)."""
+    import ctypes as C
+    from smartedgesensor3dhumanpose_amd import person_msgs as pm, rig as R
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
+    L = product_lib.lib()
+    rig = R.extr_rig_16cam()
+    rig.set_tensors(*rig_tensors(rig))
+    rc = pm.Rig(rig.n_cam, pm.fptr(rig.Rt), pm.fptr(rig.K), pm.fptr(rig.F))
+    prm = pm.Params(pm.POSE_SIMPLE, 0, 0.045)
+    lim = pm.Limits(1, 8, 4, 4)       # max_hyp < max_det_per_cam: rejected before any device call
+    L.se3d_create.restype = C.c_void_p
+    L.se3d_last_error.restype = C.c_char_p
+    L.se3d_last_error.argtypes = [C.c_void_p]
+    assert not L.se3d_create(C.byref(rc), C.byref(prm), C.byref(lim), 0)
+    assert b"unsupported sizes" in L.se3d_last_error(None)

@@ -52,14 +52,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sequence_sharding_and_allgather_world2():
+@pytest.mark.parametrize("world", [2, 4])
+def test_sequence_sharding_and_allgather(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + 7 * world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in procs]
+    got = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -119,14 +120,16 @@ def _xworker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_skeleton_exchange_world2_gathers_all_packs():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_skeleton_exchange_gathers_all_packs(world):
+    """world 4 and 8 (round 3): the layout [world][n_ctx][slice] with N_CTX = 3 contexts per rank, every rank checks every other rank's slices."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_xworker, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + (os.getpid() % 2000) + 7 * world
+    procs = [ctx.Process(target=_xworker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in procs]
+    got = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -188,14 +191,16 @@ def _hworker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_hypothesis_shard_layout_world2_equals_single_rank():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_hypothesis_shard_layout_equals_single_rank(world):
+    """H = 10 hypotheses over 2, 4 and 8 ranks: H % world != 0 for 4 and 8 (short last blocks, ranks 2.. of world 8 own one hypothesis or none)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_hworker, args=(r, 2, port, q)) for r in range(2)]
+    port = 33500 + (os.getpid() % 2000) + 7 * world
+    procs = [ctx.Process(target=_hworker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in procs]
+    got = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
