@@ -12,7 +12,10 @@ static const char* BASE_FRAME = "base";       // S3D:45
 
 Context::Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam, int max_hyp, int device) {
   n_cam_ = (int)cams.size();
-  max_hyp_ = max_hyp;
+  max_hyp_ = std::max(max_hyp, max_det_per_cam);   // the library wants max_hyp >= max_det_per_cam (the first camera seeds one hypothesis per detection)
+  max_det_ = max_det_per_cam;
+  device_ = device;
+  prm_ = prm;
   cams_ = cams;
   if (n_cam_ < 2) throw std::runtime_error("Need at least 2 cameras for triangulation");  // S3D:1133-1136
   std::vector<double> T(16 * (size_t)n_cam_);
@@ -24,11 +27,54 @@ Context::Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, in
     K_[4 * i + 0] = (float)cams[i].fx; K_[4 * i + 1] = (float)cams[i].fy; K_[4 * i + 2] = (float)cams[i].cx; K_[4 * i + 3] = (float)cams[i].cy;
   }
   if (se3d_rig_from_transforms(n_cam_, T.data(), Rt_.data(), F_.data()) != SE3D_OK) throw std::runtime_error("se3d_rig_from_transforms failed");
-  se3d_rig rig{n_cam_, Rt_.data(), K_.data(), F_.data()};
-  se3d_params p{prm.pose_method == "h36m" ? SE3D_POSE_H36M : SE3D_POSE_SIMPLE, prm.norm_height ? 1 : 0, prm.max_epi_dist};
-  se3d_limits lim{1, max_det_per_cam, max_hyp, max_hyp};
-  ctx_ = se3d_create(&rig, &p, &lim, device);
-  if (!ctx_) throw std::runtime_error("se3d_create failed: no HIP device or unsupported sizes (there is no CPU fallback)");
+  ctx_ = create(max_det_, max_hyp_);
+}
+
+se3d_ctx* Context::create(int max_det, int max_hyp) const {
+  se3d_rig rig{n_cam_, const_cast<float*>(Rt_.data()), const_cast<float*>(K_.data()), const_cast<float*>(F_.data())};
+  se3d_params p{prm_.pose_method == "h36m" ? SE3D_POSE_H36M : SE3D_POSE_SIMPLE, prm_.norm_height ? 1 : 0, prm_.max_epi_dist};
+  se3d_limits lim{1, max_det, max_hyp, max_hyp};
+  se3d_ctx* c = se3d_create(&rig, &p, &lim, device_);
+  if (!c) throw std::runtime_error(std::string("se3d_create failed: ") + se3d_last_error(nullptr) + " (there is no CPU fallback)");
+  return c;
+}
+
+void Context::grow(int min_det_per_cam, int min_hyp, const char* why) {
+  if (min_det_per_cam > kCapacityMax || min_hyp > kCapacityMax)
+    throw std::runtime_error(std::string(why) + ": needs " + std::to_string(std::max(min_det_per_cam, min_hyp)) +
+                             " slots, the library's capacity is " + std::to_string(kCapacityMax) + " detections per camera / hypotheses / tracks");
+  int det = max_det_, hyp = max_hyp_;
+  while (det < min_det_per_cam) det = std::min(2 * det, kCapacityMax);
+  while (hyp < std::max(min_hyp, det)) hyp = std::min(2 * hyp, kCapacityMax);
+  if (det == max_det_ && hyp == max_hyp_) return;
+  // the running pose_prior instance moves over: its tracks in vector order and the node globals
+  std::vector<unsigned char> blob((size_t)se3d_refine_state_bytes(ctx_));
+  int64_t n = 0;
+  if (se3d_refine_save(ctx_, 0, blob.data(), (int64_t)blob.size(), &n) != SE3D_OK) throw std::runtime_error(std::string("se3d_refine_save: ") + se3d_last_error(ctx_));
+  se3d_ctx* bigger = create(det, hyp);
+  if (se3d_refine_load(bigger, 0, blob.data(), n) != SE3D_OK) {
+    const std::string msg = std::string("se3d_refine_load: ") + se3d_last_error(bigger);
+    se3d_destroy(bigger);
+    throw std::runtime_error(msg);
+  }
+  if (!rp_T_.empty() && se3d_set_reprojection_cameras(bigger, rp_T_.data(), rp_P_.data(), rp_wh_.data()) != SE3D_OK) {
+    const std::string msg = std::string("se3d_set_reprojection_cameras: ") + se3d_last_error(bigger);
+    se3d_destroy(bigger);
+    throw std::runtime_error(msg);
+  }
+  se3d_destroy(ctx_);
+  ctx_ = bigger;
+  std::cout << "se3d: " << why << ": limits raised to " << det << " detections per camera, " << hyp << " hypotheses / tracks (were " << max_det_ << ", "
+            << max_hyp_ << ")" << std::endl;
+  max_det_ = det;
+  max_hyp_ = hyp;
+  ++n_grown_;
+}
+
+void Context::set_reprojection_cameras(const std::vector<double>& T, const std::vector<double>& P, const std::vector<int32_t>& wh) {
+  if (se3d_set_reprojection_cameras(ctx_, T.data(), P.data(), wh.data()) != SE3D_OK)
+    throw std::runtime_error(std::string("se3d_set_reprojection_cameras: ") + se3d_last_error(ctx_));
+  rp_T_ = T; rp_P_ = P; rp_wh_ = wh;
 }
 Context::~Context() { se3d_destroy(ctx_); }
 
@@ -77,13 +123,26 @@ void Skeleton3DNode::triangulate_persons(const std::vector<person_msgs::Person2D
     off[i + 1] = (int32_t)flat.size();
     fb[i] = people[i].fb_delay;
   }
-  const int H = ctx_->max_hyp();
-  std::vector<se3d_person3d> out(H);
-  std::vector<int32_t> hyp(H), asc((size_t)H * N, -1);
+  int max_per_cam = 0;
+  for (int i = 0; i < N; ++i) max_per_cam = std::max(max_per_cam, off[i + 1] - off[i]);
+  if (max_per_cam > ctx_->max_det_per_cam()) ctx_->grow(max_per_cam, 0, "more detections in one camera than limits.max_det_per_cam");
+  std::vector<se3d_person3d> out;
+  std::vector<int32_t> hyp, asc;
   se3d_frame_in in{N, off.data(), flat.empty() ? nullptr : flat.data(), fb.data(), persons3d_msg.header.stamp};
-  se3d_frame_out res{H, H, 0, 0, 0u, out.data(), hyp.data(), asc.data()};
-  const int rc = se3d_triangulate(ctx_->get(), &in, &res);
-  if (rc != SE3D_OK) throw std::runtime_error(std::string("se3d_triangulate: ") + se3d_last_error(ctx_->get()));
+  se3d_frame_out res{};
+  for (;;) {
+    const int H = ctx_->max_hyp();
+    out.assign(H, se3d_person3d{});
+    hyp.assign(H, 0);
+    asc.assign((size_t)H * N, -1);
+    res = se3d_frame_out{H, H, 0, 0, 0u, out.data(), hyp.data(), asc.data()};
+    const int rc = se3d_triangulate(ctx_->get(), &in, &res);
+    if (rc != SE3D_OK) throw std::runtime_error(std::string("se3d_triangulate: ") + se3d_last_error(ctx_->get()));
+    if (!(res.flags & SE3D_FLAG_HYP_OVERFLOW)) break;
+    // the sweep spawned more hypotheses than limits.max_hyp and truncated (the reference appends, S3D:636-673): raise the limit, run the frame again
+    ctx_->grow(0, 2 * H, "SE3D_FLAG_HYP_OVERFLOW (more hypotheses than limits.max_hyp)");
+  }
+  if (res.flags & SE3D_FLAG_ASSIGNMENT_FAILED) throw std::runtime_error("se3d_triangulate: SE3D_FLAG_ASSIGNMENT_FAILED (non-finite association costs)");
   persons3d_msg.persons.clear();  // < 2 cameras with detections: the empty list is still published (S3D:557-560, 1071)
   for (int p = 0; p < res.n_persons; ++p) { persons3d_msg.persons.emplace_back(); from_pod(out[p], persons3d_msg.persons.back()); }
   if (assoc) assoc->assign(asc.begin(), asc.begin() + (size_t)res.n_hyp * N);
@@ -132,19 +191,27 @@ bool Skeleton3DNode::skeletonThreadStep(std::vector<person_msgs::Person2DList> p
   return true;
 }
 
-void PosePriorNode::reset() { se3d_refine_reset(ctx_->get()); }
+void PosePriorNode::reset() { se3d_refine_reset(ctx_->get()); n_tracks_ = 0; }
 
 void PosePriorNode::skeletonCallback(const person_msgs::PersonCovList& persons, person_msgs::PersonCovList& persons_fused,
                                      person_msgs::PersonCovList& persons_fused_pred) {
-  const int H = ctx_->max_hyp();
   std::vector<se3d_person3d> dets(persons.persons.size());
   for (size_t i = 0; i < dets.size(); ++i) to_pod3(persons.persons[i], dets[i]);
+  // g_tracks.push_back (PP:570-580) never fails in the reference.  A callback adds at most one track per detection, so the live tracks
+  // after it are at most n_tracks_ + n_det: raise the limits BEFORE the call when that bound does not fit (a truncated step could not
+  // be undone: it has already changed the track state).
+  const int need = std::max((int)dets.size(), n_tracks_ + (int)dets.size());
+  if (need > ctx_->max_hyp()) ctx_->grow(0, need, "more detections + live tracks than limits.max_hyp / max_tracks");
+  const int H = ctx_->max_hyp();
   std::vector<se3d_person3d> fused(H), pred(H);
   std::vector<int32_t> iters(H);
   se3d_fused_out fo{H, 0, 0, 0.f, fused.data(), pred.data(), iters.data(), 0u};
   const int rc = se3d_refine(ctx_->get(), seq_, (int32_t)dets.size(), dets.empty() ? nullptr : dets.data(), (int32_t)persons.fb_delay_per_cam.size(),
                              persons.fb_delay_per_cam.empty() ? nullptr : persons.fb_delay_per_cam.data(), persons.header.stamp, &fo);
   if (rc != SE3D_OK) throw std::runtime_error(std::string("se3d_refine: ") + se3d_last_error(ctx_->get()));
+  if (fo.flags & SE3D_S2FLAG_TRACK_OVERFLOW) throw std::runtime_error("se3d_refine: SE3D_S2FLAG_TRACK_OVERFLOW although the limits were raised beforehand");
+  if (fo.flags & SE3D_S2FLAG_ASSIGNMENT_FAILED) throw std::runtime_error("se3d_refine: SE3D_S2FLAG_ASSIGNMENT_FAILED (non-finite track association costs)");
+  n_tracks_ = fo.n_tracks;
   persons_fused = person_msgs::PersonCovList();
   persons_fused.header = persons.header;  // PP:528-532
   persons_fused.ts_per_cam = persons.ts_per_cam;
@@ -165,8 +232,7 @@ ReprojectionNode::ReprojectionNode(std::shared_ptr<Context> ctx) : ctx_(std::mov
     P[4 * i] = cams[i].fx; P[4 * i + 1] = cams[i].fy; P[4 * i + 2] = cams[i].cx; P[4 * i + 3] = cams[i].cy;
     wh[2 * i] = cams[i].width; wh[2 * i + 1] = cams[i].height;
   }
-  if (se3d_set_reprojection_cameras(ctx_->get(), T.data(), P.data(), wh.data()) != SE3D_OK)
-    throw std::runtime_error(std::string("se3d_set_reprojection_cameras: ") + se3d_last_error(ctx_->get()));
+  ctx_->set_reprojection_cameras(T, P, wh);   // kept by the context: re-applied when its limits are raised
 }
 
 bool ReprojectionNode::fusedSkeletonCallback(const person_msgs::PersonCovList& humans, std::vector<person_msgs::Person2DList>& humans_in_cam) {

@@ -34,23 +34,41 @@ struct CameraCalib {
   int width = 640, height = 480;         // CameraInfo width / height (REPROJ:161-162)
 };
 
-class Context {                      // owns one se3d_ctx (one GPU stream, stage-1 workspace, stage-2 track state)
+// Owns one se3d_ctx (one GPU stream, stage-1 workspace, stage-2 track state).  The library works inside fixed limits (detections per
+// camera, hypotheses per frame, live tracks) and reports when a frame exceeds them (SE3D_ERR_CAPACITY, SE3D_FLAG_HYP_OVERFLOW,
+// SE3D_S2FLAG_TRACK_OVERFLOW); the reference has no such limits — its vectors grow (S3D:636-673 H.push_back, PP:570-580
+// g_tracks.push_back).  The nodes below therefore never publish a truncated result: they call grow(), which creates a context with
+// larger limits, moves the pose_prior state over (se3d_refine_save / _load) and re-applies the reprojection cameras, and run the frame
+// again.  The only hard bound left is the library's SE3D capacity of 256 detections / hypotheses / tracks (kCapacityMax): beyond it the
+// node throws and names the limit.
+class Context {
  public:
+  static constexpr int kCapacityMax = 256;   // SE3D_MUNKRES_MAX of the library: rows / columns of the device Munkres
   Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam = 16, int max_hyp = 64, int device = 0);
   ~Context();
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
   se3d_ctx* get() const { return ctx_; }
   int n_cam() const { return n_cam_; }
-  int max_hyp() const { return max_hyp_; }
+  int max_hyp() const { return max_hyp_; }            // = limits.max_hyp = limits.max_tracks
+  int max_det_per_cam() const { return max_det_; }
+  int n_grown() const { return n_grown_; }            // how often the limits were raised (diagnostic)
   const std::vector<float>& fundamental() const { return F_; }
   const std::vector<CameraCalib>& cameras() const { return cams_; }
+  // Raise the limits to at least (min_det_per_cam, min_hyp) — doubling, so that a growing scene costs O(log) re-creations — keeping the
+  // pose_prior state.  Throws std::runtime_error naming the limit when kCapacityMax is not enough.
+  void grow(int min_det_per_cam, int min_hyp, const char* why);
+  void set_reprojection_cameras(const std::vector<double>& T, const std::vector<double>& P, const std::vector<int32_t>& wh);
 
  private:
+  se3d_ctx* create(int max_det, int max_hyp) const;
   se3d_ctx* ctx_ = nullptr;
-  int n_cam_ = 0, max_hyp_ = 0;
+  int n_cam_ = 0, max_hyp_ = 0, max_det_ = 0, device_ = 0, n_grown_ = 0;
+  NodeParams prm_;
   std::vector<float> Rt_, K_, F_;
   std::vector<CameraCalib> cams_;
+  std::vector<double> rp_T_, rp_P_;      // reprojection cameras, re-applied after grow()
+  std::vector<int32_t> rp_wh_;
 };
 
 class Skeleton3DNode {
@@ -104,6 +122,7 @@ class PosePriorNode {
  private:
   std::shared_ptr<Context> ctx_;
   int seq_;
+  int n_tracks_ = 0;   // live tracks after the last callback: a step adds at most one track per detection, so n_tracks_ + n_det is a bound
 };
 
 class ReprojectionNode {

@@ -52,7 +52,10 @@ int main(int argc, char** argv) {
   prm.max_epi_dist = rd<double>(in);
   const int n_frames = rd<int32_t>(in);
   try {
-    auto ctx = std::make_shared<se3d::Context>(cams, prm, 16, 64, 0);
+    // initial limits (SE3D_REPLAY_MAX_DET / SE3D_REPLAY_MAX_HYP: tests start far below what the scene needs; the nodes raise them)
+    const int det0 = std::getenv("SE3D_REPLAY_MAX_DET") ? std::atoi(std::getenv("SE3D_REPLAY_MAX_DET")) : 16;
+    const int hyp0 = std::getenv("SE3D_REPLAY_MAX_HYP") ? std::atoi(std::getenv("SE3D_REPLAY_MAX_HYP")) : 64;
+    auto ctx = std::make_shared<se3d::Context>(cams, prm, det0, hyp0, 0);
     se3d::Skeleton3DNode skel(ctx);
     se3d::PosePriorNode prior(ctx);
     std::ofstream out(argv[2], std::ios::binary);
@@ -131,6 +134,7 @@ int main(int argc, char** argv) {
     }
     out.seekp(0);
     wr<int32_t>(out, n_tuples);  // tuples actually handled (with the synchroniser in front the last frames may still be held back)
+    std::cout << "Limits: raised " << ctx->n_grown() << " times, now " << ctx->max_det_per_cam() << " detections per camera, " << ctx->max_hyp() << " hypotheses / tracks" << std::endl;
     std::cout << "Markers: " << n_markers3d << " skeleton_3d, " << n_markers_fused << " fused, " << n_markers_deleted << " deleted" << std::endl;
     for (size_t i = 0; i < skel.timings_ms().size(); ++i)  // S3D:1234-1241
       if (skel.timing_counts()[i] > 0) {

@@ -189,6 +189,14 @@ int se3d_fetch_dlt(se3d_ctx *ctx, int32_t n_frames, se3d_person3d *persons_out);
  * g_fb_delay_buffer, g_frame_nr, g_t_prev, g_next_id; PP:54-60,123).  Sequence s consumes, per call, frame
  * slot s of the most recent stage-1 run (resident path) or host measurements (se3d_refine). */
 int se3d_refine_reset(se3d_ctx *ctx);
+/* The state of one pose_prior instance (its g_tracks in vector order and the node globals) as a host blob that does not depend on the
+ * context's limits: se3d_refine_save from one context, se3d_refine_load into another (e.g. one created with larger limits — the
+ * reference's g_tracks grows without bound, PP:570-580; host/se3d_nodes.cpp grows its context this way instead of truncating).
+ * se3d_refine_state_bytes: upper bound of a blob of this context.  Loading re-numbers the track slots (track k of the vector -> slot k);
+ * results do not depend on the slot numbering.  Synchronous. */
+int64_t se3d_refine_state_bytes(const se3d_ctx *ctx);
+int se3d_refine_save(se3d_ctx *ctx, int32_t seq, void *blob, int64_t capacity_bytes, int64_t *bytes);
+int se3d_refine_load(se3d_ctx *ctx, int32_t seq, const void *blob, int64_t bytes);
 /* one PersonCovList in, fused lists out; seq selects the pose_prior instance */
 int se3d_refine(se3d_ctx *ctx, int32_t seq, int32_t n_det, const se3d_person3d *dets, int32_t n_cam,
                 const float *fb_delay_per_cam, double t, se3d_fused_out *out);

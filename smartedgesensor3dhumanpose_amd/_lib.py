@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("SE3D_LIB_OVERRIDE") or os.path.join(_HERE, "libse3d_h
 EXPORTS = [
     "se3d_rig_from_transforms", "se3d_create", "se3d_destroy", "se3d_last_error", "se3d_device_bytes", "se3d_version",
     "se3d_triangulate", "se3d_triangulate_batch", "se3d_stage_frames", "se3d_run_stage1", "se3d_sync", "se3d_fetch_stage1",
-    "se3d_refine_reset", "se3d_refine", "se3d_run_stage2", "se3d_fetch_stage2",
+    "se3d_refine_reset", "se3d_refine_state_bytes", "se3d_refine_save", "se3d_refine_load", "se3d_refine", "se3d_run_stage2", "se3d_fetch_stage2",
     "se3d_hungarian", "se3d_get_pair_costs", "se3d_selftest_exact_math", "se3d_get_fusion_constants", "se3d_pack_stage1_device", "se3d_pack_stage2_device",
     "se3d_profile_enable", "se3d_profile_reset", "se3d_profile_get",
     "se3d_set_reprojection_cameras", "se3d_reproject", "se3d_reproject_resident", "se3d_reproject_resident_batch", "se3d_fetch_reprojection",
@@ -72,7 +72,7 @@ def lib():
         L.se3d_stream_handle.restype = C.c_void_p
         L.se3d_stream_handle.argtypes = [C.c_void_p]
         for name in ("se3d_triangulate", "se3d_triangulate_batch", "se3d_stage_frames", "se3d_run_stage1", "se3d_sync", "se3d_fetch_stage1",
-                     "se3d_refine_reset", "se3d_refine", "se3d_run_stage2", "se3d_fetch_stage2", "se3d_pack_stage1_device",
+                     "se3d_refine_reset", "se3d_refine_state_bytes", "se3d_refine_save", "se3d_refine_load", "se3d_refine", "se3d_run_stage2", "se3d_fetch_stage2", "se3d_pack_stage1_device",
                      "se3d_pack_stage2_device", "se3d_hungarian", "se3d_get_pair_costs", "se3d_selftest_exact_math", "se3d_get_fusion_constants", "se3d_profile_enable", "se3d_profile_reset", "se3d_profile_get",
                      "se3d_set_reprojection_cameras", "se3d_reproject", "se3d_reproject_resident", "se3d_reproject_resident_batch", "se3d_fetch_reprojection",
                      "se3d_run_stage2_walk", "se3d_fetch_stage2_walk", "se3d_pack_stage2_walk_device", "se3d_pack_stage2_walk_device_slots",
@@ -81,5 +81,9 @@ def lib():
             getattr(L, name).restype = C.c_int
         L.se3d_shard_bytes.restype = C.c_int64
         L.se3d_device_bytes.restype = C.c_int64
+        L.se3d_refine_state_bytes.restype = C.c_int64
+        L.se3d_refine_state_bytes.argtypes = [C.c_void_p]
+        L.se3d_refine_save.restype = C.c_int
+        L.se3d_refine_load.restype = C.c_int
         _lib = L
     return _lib

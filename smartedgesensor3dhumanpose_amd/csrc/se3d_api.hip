@@ -844,6 +844,98 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
   return fetch_stage2_range(c, seq, 1, out);
 }
 
+// ---- sequence state of pose_prior (g_tracks and the node globals, PP:54-60, 68-76, 123) out of / into a context: a host blob that does
+// not depend on the context's capacity, so that a host layer can move a running sequence into a context with larger limits (the
+// reference's vectors grow without bound, PP:570-580: g_tracks.push_back) ----
+extern "C++" {
+namespace {
+struct SeqStateHeader { uint32_t magic; int32_t n_tracks, next_id, frame_nr; double t_prev, fb_buf[3]; uint32_t flags2, pad; };
+struct SeqStateTrack {
+  int32_t id, num_obs; uint32_t has, pad; double t_prev, height_prev, root_prev[3], prev[SE3D_NFU * 3], vel[SE3D_NFU * 9];
+};
+constexpr uint32_t kSeqMagic = 0x53325354u;  // "S2ST"
+template <typename T> bool d2h(se3d_ctx *c, T *dst, const T *src, size_t n) { return hip_ok(c, hipMemcpy(dst, src, n * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+template <typename T> bool h2d(se3d_ctx *c, T *dst, const T *src, size_t n) { return hip_ok(c, hipMemcpy(dst, src, n * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D"); }
+}  // namespace
+}  // extern "C++"
+
+int64_t se3d_refine_state_bytes(const se3d_ctx *c) {
+  return c ? (int64_t)(sizeof(SeqStateHeader) + (size_t)c->Q.T * sizeof(SeqStateTrack)) : 0;
+}
+
+int se3d_refine_save(se3d_ctx *c, int32_t seq, void *blob, int64_t capacity_bytes, int64_t *bytes) {
+  if (!c || !blob || !bytes) return SE3D_ERR_ARG;
+  const Se3dStage2 &Q = c->Q;
+  if (seq < 0 || seq >= Q.S) { c->err = "sequence index out of range"; return SE3D_ERR_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t T = Q.T, s0 = (size_t)seq * T;
+  SeqStateHeader h{};
+  h.magic = kSeqMagic;
+  if (!d2h(c, &h.n_tracks, Q.n_tracks + seq, 1) || !d2h(c, &h.next_id, Q.next_id + seq, 1) || !d2h(c, &h.frame_nr, Q.frame_nr + seq, 1) ||
+      !d2h(c, &h.t_prev, Q.t_prev + seq, 1) || !d2h(c, h.fb_buf, Q.fb_buf + (size_t)seq * 3, 3) || !d2h(c, &h.flags2, Q.flags2 + seq, 1))
+    return SE3D_ERR_DEVICE;
+  if (h.n_tracks < 0 || (size_t)h.n_tracks > T) { c->err = "se3d_refine_save: corrupt track count"; return SE3D_ERR_STATE; }
+  const int64_t need = (int64_t)(sizeof(SeqStateHeader) + (size_t)h.n_tracks * sizeof(SeqStateTrack));
+  *bytes = need;
+  if (capacity_bytes < need) { c->err = "se3d_refine_save: blob too small (se3d_refine_state_bytes)"; return SE3D_ERR_CAPACITY; }
+  std::vector<int32_t> order(T), id(T), nobs(T);
+  std::vector<uint32_t> has(T);
+  std::vector<double> tp(T), hp(T), rp(T * 3), prev(T * SE3D_NFU * 3), vel(T * SE3D_NFU * 9);
+  if (!d2h(c, order.data(), Q.order + s0, T) || !d2h(c, id.data(), Q.id + s0, T) || !d2h(c, nobs.data(), Q.num_obs + s0, T) || !d2h(c, has.data(), Q.has + s0, T) ||
+      !d2h(c, tp.data(), Q.trk_t_prev + s0, T) || !d2h(c, hp.data(), Q.height_prev + s0, T) || !d2h(c, rp.data(), Q.root_prev + s0 * 3, T * 3) ||
+      !d2h(c, prev.data(), Q.prev + s0 * SE3D_NFU * 3, T * SE3D_NFU * 3) || !d2h(c, vel.data(), Q.vel + s0 * SE3D_NFU * 9, T * SE3D_NFU * 9))
+    return SE3D_ERR_DEVICE;
+  unsigned char *out = static_cast<unsigned char *>(blob);
+  memcpy(out, &h, sizeof h);
+  for (int k = 0; k < h.n_tracks; ++k) {   // g_tracks vector order
+    const size_t sl = (size_t)order[k];
+    if (sl >= T) { c->err = "se3d_refine_save: corrupt track order"; return SE3D_ERR_STATE; }
+    SeqStateTrack t{};
+    t.id = id[sl]; t.num_obs = nobs[sl]; t.has = has[sl]; t.t_prev = tp[sl]; t.height_prev = hp[sl];
+    memcpy(t.root_prev, &rp[sl * 3], sizeof t.root_prev);
+    memcpy(t.prev, &prev[sl * SE3D_NFU * 3], sizeof t.prev);
+    memcpy(t.vel, &vel[sl * SE3D_NFU * 9], sizeof t.vel);
+    memcpy(out + sizeof h + (size_t)k * sizeof t, &t, sizeof t);
+  }
+  return SE3D_OK;
+}
+
+int se3d_refine_load(se3d_ctx *c, int32_t seq, const void *blob, int64_t bytes) {
+  if (!c || !blob || bytes < (int64_t)sizeof(SeqStateHeader)) return SE3D_ERR_ARG;
+  const Se3dStage2 &Q = c->Q;
+  if (seq < 0 || seq >= Q.S) { c->err = "sequence index out of range"; return SE3D_ERR_ARG; }
+  SeqStateHeader h;
+  memcpy(&h, blob, sizeof h);
+  if (h.magic != kSeqMagic || h.n_tracks < 0 || bytes < (int64_t)(sizeof h + (size_t)h.n_tracks * sizeof(SeqStateTrack))) { c->err = "se3d_refine_load: not a sequence state"; return SE3D_ERR_ARG; }
+  const size_t T = Q.T, s0 = (size_t)seq * T;
+  if ((size_t)h.n_tracks > T) { c->err = "se3d_refine_load: more tracks than limits.max_tracks"; return SE3D_ERR_CAPACITY; }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<int32_t> order(T, 0), id(T, 0), nobs(T, 0);
+  std::vector<uint32_t> has(T, 0u);
+  std::vector<uint8_t> used(T, 0);
+  std::vector<double> tp(T, 0.0), hp(T, 0.0), rp(T * 3, 0.0), prev(T * SE3D_NFU * 3, 0.0), vel(T * SE3D_NFU * 9, 0.0);
+  const unsigned char *in = static_cast<const unsigned char *>(blob) + sizeof h;
+  for (int k = 0; k < h.n_tracks; ++k) {   // track k of the vector goes to slot k
+    SeqStateTrack t;
+    memcpy(&t, in + (size_t)k * sizeof t, sizeof t);
+    order[k] = k; used[k] = 1; id[k] = t.id; nobs[k] = t.num_obs; has[k] = t.has; tp[k] = t.t_prev; hp[k] = t.height_prev;
+    memcpy(&rp[(size_t)k * 3], t.root_prev, sizeof t.root_prev);
+    memcpy(&prev[(size_t)k * SE3D_NFU * 3], t.prev, sizeof t.prev);
+    memcpy(&vel[(size_t)k * SE3D_NFU * 9], t.vel, sizeof t.vel);
+  }
+  const uint32_t fl = h.flags2 & ~SE3D_S2FLAG_TRACK_OVERFLOW;   // the overflow flag is a statement about the context the state came from
+  if (!h2d(c, Q.n_tracks + seq, &h.n_tracks, 1) || !h2d(c, Q.next_id + seq, &h.next_id, 1) || !h2d(c, Q.frame_nr + seq, &h.frame_nr, 1) ||
+      !h2d(c, Q.t_prev + seq, &h.t_prev, 1) || !h2d(c, Q.fb_buf + (size_t)seq * 3, h.fb_buf, 3) || !h2d(c, Q.flags2 + seq, &fl, 1) ||
+      !h2d(c, Q.order + s0, order.data(), T) || !h2d(c, Q.used + s0, used.data(), T) || !h2d(c, Q.id + s0, id.data(), T) ||
+      !h2d(c, Q.num_obs + s0, nobs.data(), T) || !h2d(c, Q.has + s0, has.data(), T) || !h2d(c, Q.trk_t_prev + s0, tp.data(), T) ||
+      !h2d(c, Q.height_prev + s0, hp.data(), T) || !h2d(c, Q.root_prev + s0 * 3, rp.data(), T * 3) ||
+      !h2d(c, Q.prev + s0 * SE3D_NFU * 3, prev.data(), T * SE3D_NFU * 3) || !h2d(c, Q.vel + s0 * SE3D_NFU * 9, vel.data(), T * SE3D_NFU * 9))
+    return SE3D_ERR_DEVICE;
+  return SE3D_OK;
+}
+
 int se3d_run_stage2(se3d_ctx *c, int32_t n_seq, int32_t frame_slot0, const double *t) {
   if (!c || !t || n_seq < 1 || frame_slot0 < 0) return SE3D_ERR_ARG;
   if (c->D.d.shard_world > 1) { c->err = "a hypothesis shard is set (se3d_set_shard, world > 1): use the se3d_run_stage*_shard_pre / _post pairs, the plain run calls would skip the other ranks' hypotheses"; return SE3D_ERR_STATE; }

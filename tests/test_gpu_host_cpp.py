@@ -118,3 +118,44 @@ def test_cpp_replay_through_time_synchroniser(tmp_path, extr_rig, demo_params):
         for la, lb in zip(ra, rb):
             assert la.stamp == lb.stamp and la.ts_per_cam == lb.ts_per_cam
             assert la.persons.tobytes() == lb.persons.tobytes()
+
+
+def test_cpp_replay_grows_its_limits_instead_of_truncating(tmp_path, oracle, extr_rig, demo_params):
+    """The reference never truncates (S3D:636-673 appends hypotheses, PP:570-580 appends tracks); the library works inside limits and flags
+    when a frame exceeds them.  The C++ nodes act on the flags: a scene with 9 persons (9 detections per camera, up to 19 hypotheses with the
+    spurious ones that gross outliers and missed views spawn, 10 tracks) is replayed through contexts that start with room for 3 — a third of what
+    the scene needs — and must publish exactly what a replay with ample limits publishes, and what the oracle publishes."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")], stdout=subprocess.DEVNULL)
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=9, n_frames=16, seed=31, spacing=0.9, outlier_frac=0.01, p_miss=0.05))
+    stream = Hn.stream_from_frames(frames)
+    scene, out_small, out_big = str(tmp_path / "scene.bin"), str(tmp_path / "small.bin"), str(tmp_path / "big.bin")
+    Hn.write_replay_scene(scene, extr_rig, demo_params, stream)
+    exe = os.path.join(ROOT, "host", "se3d_replay")
+    small = subprocess.run([exe, scene, out_small], check=True, capture_output=True, text=True, env=dict(os.environ, SE3D_REPLAY_MAX_DET="3", SE3D_REPLAY_MAX_HYP="3"))
+    big = subprocess.run([exe, scene, out_big], check=True, capture_output=True, text=True, env=dict(os.environ, SE3D_REPLAY_MAX_DET="32", SE3D_REPLAY_MAX_HYP="128"))
+    lim_small = [ln for ln in small.stdout.split("\n") if ln.startswith("Limits:")][0]
+    lim_big = [ln for ln in big.stdout.split("\n") if ln.startswith("Limits:")][0]
+    assert int(lim_small.split()[2]) >= 2 and int(lim_big.split()[2]) == 0, (lim_small, lim_big)
+    a, b = Hn.read_replay_output(out_small), Hn.read_replay_output(out_big)
+    assert len(a) == len(b) == len(stream)
+    n_pub = 0
+    for ra, rb in zip(a, b):
+        assert ra is not None and rb is not None
+        for la, lb in zip(ra, rb):     # persons_3d, persons3d_fused, persons3d_fused_pred: byte-equal, whatever the limits the run started with
+            assert la.persons.tobytes() == lb.persons.tobytes()
+        n_pub += len(ra[1].persons)
+    assert max(len(r[0].persons) for r in a) >= 9 and n_pub > 0
+    # ... and equal to the oracle (which has no limits)
+    pp = oracle.PosePrior(demo_params)
+    h1 = Hn.Skeleton3DHarness(16, lambda fr: oracle.triangulate(extr_rig, demo_params, fr, capacity=256, hyp_capacity=256))
+    h2 = Hn.PosePriorHarness(lambda persons, n_cam, t, fb: pp.step(persons, n_cam, t, fb, capacity=256))
+    for k, msgs in enumerate(stream):
+        p3d = h1.step(msgs)
+        g3d, gfused, _ = a[k]
+        assert len(g3d.persons) == len(p3d.persons)
+        v = p3d.persons["keypoints"]["score"] > 0
+        assert np.array_equal(g3d.persons["keypoints"]["score"] > 0, v)
+        ofused, _ = h2.callback(p3d)
+        assert len(gfused.persons) == len(ofused.persons)
+        if len(ofused.persons):
+            assert np.array_equal(gfused.persons["id"], ofused.persons["id"])
