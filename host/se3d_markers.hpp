@@ -6,9 +6,13 @@
 // Deviations from the reference, all confined to the picture in rviz (documented in INTEGRATION.md):
 //   * the stage-1 markers are built from the PUBLISHED persons; the reference builds them inside the hypothesis loop, before the
 //     root-distance reset (S3D:936-951), so a joint that filter removed is still drawn there, and it numbers them by hypothesis index
-//     (here: index in the published list); `vis_cov` ellipsoids (off by default, S3D:77) are not produced;
+//     (here: index in the published list); the `vis_cov` ellipsoids (off by default, S3D:77; covariance_markers below) are drawn from the
+//     PUBLISHED covariances: stage 1 after the limb-length inflation (the reference draws before S3D:861-883 inflates), stage 2 with the
+//     mid hip's x 100^2 rescale undone as the reference draws before it (PP:795-814); eigenvector signs are free, so a quaternion may
+//     differ from Eigen's by a half turn about an axis of the same ellipsoid;
 //   * DELETE markers are derived from the published ids (an id not seen for t_max_unobserved), the reference emits them from its track list.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <map>
@@ -21,7 +25,7 @@ namespace visualization_msgs {
 
 struct ColorRGBA { float r = 0, g = 0, b = 0, a = 0; };
 struct Marker {  // visualization_msgs/Marker
-  enum : int32_t { LINE_LIST = 5, SPHERE_LIST = 7, ADD = 0, DELETE = 2 };
+  enum : int32_t { SPHERE = 2, LINE_LIST = 5, SPHERE_LIST = 7, ADD = 0, DELETE = 2 };
   person_msgs::Header header;
   std::string ns;
   int32_t id = 0, type = 0, action = ADD;
@@ -144,6 +148,118 @@ inline void fused_markers(const person_msgs::PersonCovList& fused, visualization
     out.markers.push_back(std::move(joints));
     out.markers.push_back(std::move(skel));
   }
+}
+
+// ---- `vis_cov`: one SPHERE marker per joint drawn as the 95 % ellipsoid of its 3x3 covariance (setMarkerPose, S3D:279-309 = PP:237-254) ----
+// Eigen-decomposition of a symmetric 3x3 matrix by cyclic Jacobi rotations: eigenvalues ascending (the order of Eigen's
+// SelfAdjointEigenSolver, which the reference reads as scale x, y, z), eigenvectors in the columns of V.
+inline void sym3_eigen(const double c6[6], double eval[3], double V[3][3]) {
+  double A[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 50; ++sweep) {
+    const double off = std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]);
+    const double diag = std::fabs(A[0][0]) + std::fabs(A[1][1]) + std::fabs(A[2][2]);
+    if (off <= 1e-18 * diag || off == 0.0) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (A[p][q] == 0.0) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s_ = t * c;
+        for (int k = 0; k < 3; ++k) { const double x = A[k][p], y = A[k][q]; A[k][p] = c * x - s_ * y; A[k][q] = s_ * x + c * y; }
+        for (int k = 0; k < 3; ++k) { const double x = A[p][k], y = A[q][k]; A[p][k] = c * x - s_ * y; A[q][k] = s_ * x + c * y; }
+        for (int k = 0; k < 3; ++k) { const double x = V[k][p], y = V[k][q]; V[k][p] = c * x - s_ * y; V[k][q] = s_ * x + c * y; }
+      }
+  }
+  int idx[3] = {0, 1, 2};
+  for (int i = 0; i < 2; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (A[idx[j]][idx[j]] < A[idx[i]][idx[i]]) std::swap(idx[i], idx[j]);
+  double Vs[3][3];
+  for (int k = 0; k < 3; ++k) { eval[k] = A[idx[k]][idx[k]]; for (int r = 0; r < 3; ++r) Vs[r][k] = V[r][idx[k]]; }
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) V[r][k] = Vs[r][k];
+}
+
+// pose (position, orientation of the principal axes, a proper rotation) and scale (2 x 2.7955 sigma per axis: 2.7955 = sqrt(chi2inv(0.95, 3)))
+inline void set_marker_pose(visualization_msgs::Marker& m, const person_msgs::Point& joint, const double c6[6], double eval_out[3] = nullptr) {
+  double ev[3], V[3][3];
+  sym3_eigen(c6, ev, V);
+  const double det = V[0][0] * (V[1][1] * V[2][2] - V[1][2] * V[2][1]) - V[0][1] * (V[1][0] * V[2][2] - V[1][2] * V[2][0]) + V[0][2] * (V[1][0] * V[2][1] - V[1][1] * V[2][0]);
+  if (!(det > 0.0))   // "Determinant must be +1!" (S3D:289-292)
+    for (auto& row : V) for (double& v : row) v = -v;
+  // rotation matrix -> quaternion (the trace method Eigen::Quaterniond(Matrix3d) uses)
+  double q[4];  // w, x, y, z
+  const double tr = V[0][0] + V[1][1] + V[2][2];
+  if (tr > 0.0) {
+    double t = std::sqrt(tr + 1.0);
+    q[0] = 0.5 * t; t = 0.5 / t;
+    q[1] = (V[2][1] - V[1][2]) * t; q[2] = (V[0][2] - V[2][0]) * t; q[3] = (V[1][0] - V[0][1]) * t;
+  } else {
+    int i = 0;
+    if (V[1][1] > V[0][0]) i = 1;
+    if (V[2][2] > V[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = std::sqrt(V[i][i] - V[j][j] - V[k][k] + 1.0);
+    q[1 + i] = 0.5 * t; t = 0.5 / t;
+    q[0] = (V[k][j] - V[j][k]) * t; q[1 + j] = (V[j][i] + V[i][j]) * t; q[1 + k] = (V[k][i] + V[i][k]) * t;
+  }
+  m.position = joint;
+  m.orientation = {{q[1], q[2], q[3], q[0]}};
+  for (int a = 0; a < 3; ++a) m.scale[a] = 2.0 * 2.7955 * std::sqrt(ev[a]);
+  if (eval_out) for (int a = 0; a < 3; ++a) eval_out[a] = ev[a];
+}
+
+// running minimum / maximum of the covariance eigenvalues, printed as "Sigmas 3D [mm]" when the node exits (S3D:303-309, 1243-1247)
+struct SigmaRange {
+  double min_ev[3] = {1e30, 1e30, 1e30}, max_ev[3] = {0, 0, 0};
+  void add(const double ev[3]) { for (int a = 0; a < 3; ++a) { min_ev[a] = std::min(min_ev[a], ev[a]); max_ev[a] = std::max(max_ev[a], ev[a]); } }
+  double min_mm(int a) const { return std::sqrt(min_ev[a]) * 1000.0; }
+  double max_mm(int a) const { return std::sqrt(max_ev[a]) * 1000.0; }
+};
+
+// Stage 1, vis_cov = true: "joint_cov_3d" SPHERE markers, lifetime 5 s, id = 21 * person + input keypoint index, for the keypoints whose fusion
+// part is below 15 (no eyes / ears / head / belly), colour of the joint at alpha 0.5 (S3D:887-898).
+inline void covariance_markers_3d(const person_msgs::PersonCovList& persons3d, const std::string& pose_method, visualization_msgs::MarkerArray& out,
+                                  SigmaRange* range = nullptr) {
+  static const int fusion_simple[17] = {FU_Nose, FU_LEye, FU_REye, FU_LEar, FU_REar, FU_LShoulder, FU_RShoulder, FU_LElbow, FU_RElbow, FU_LWrist, FU_RWrist,
+                                        FU_LHip, FU_RHip, FU_LKnee, FU_RKnee, FU_LAnkle, FU_RAnkle};
+  static const int fusion_h36m[17] = {FU_Nose, FU_Head, FU_Neck, FU_Belly, FU_MidHip, FU_LShoulder, FU_RShoulder, FU_LElbow, FU_RElbow, FU_LWrist, FU_RWrist,
+                                      FU_LHip, FU_RHip, FU_LKnee, FU_RKnee, FU_LAnkle, FU_RAnkle};
+  const int* fusion = pose_method == "h36m" ? fusion_h36m : fusion_simple;
+  for (size_t p = 0; p < persons3d.persons.size(); ++p)
+    for (int k = 0; k < 17; ++k) {
+      const int f = fusion[k];
+      if (f >= 15 || (int)persons3d.persons[p].keypoints.size() <= f) continue;
+      const auto& kp = persons3d.persons[p].keypoints[f];
+      if (kp.score <= 0) continue;
+      visualization_msgs::Marker m;
+      m.header = persons3d.header; m.lifetime = 5.0; m.type = visualization_msgs::Marker::SPHERE; m.ns = "joint_cov_3d";
+      m.id = (int32_t)(FU_NUM * p + k);
+      m.color = joint_color(f); m.color.a = 0.50f;
+      double ev[3];
+      set_marker_pose(m, kp.joint, kp.cov.data(), ev);
+      if (range) range->add(ev);
+      out.markers.push_back(std::move(m));
+    }
+}
+
+// Stage 2, vis_cov = true: "joint_cov_fused" SPHERE markers, lifetime g_t_max_unobserved, id = 21 * person + fusion part, parts below 15
+// (PP:795-807).  The reference draws the mid hip's marginal before it is rescaled by g_root_sigma_factor^2 (PP:813-814): undone here.
+inline void covariance_markers_fused(const person_msgs::PersonCovList& fused, visualization_msgs::MarkerArray& out, double t_max_unobserved = 1.0) {
+  for (size_t p = 0; p < fused.persons.size(); ++p)
+    for (int k = 0; k < 15 && k < (int)fused.persons[p].keypoints.size(); ++k) {
+      const auto& kp = fused.persons[p].keypoints[k];
+      if (kp.score <= 0) continue;
+      double c6[6];
+      for (int a = 0; a < 6; ++a) c6[a] = k == FU_MidHip ? kp.cov[a] / (100.0 * 100.0) : kp.cov[a];
+      visualization_msgs::Marker m;
+      m.header = fused.header; m.lifetime = t_max_unobserved; m.type = visualization_msgs::Marker::SPHERE; m.ns = "joint_cov_fused";
+      m.id = (int32_t)(FU_NUM * p + k);
+      m.color = joint_color(k); m.color.a = 0.50f;
+      set_marker_pose(m, kp.joint, c6);
+      out.markers.push_back(std::move(m));
+    }
 }
 
 // DELETE markers for tracks that are gone (PP:191-209; after a merge PP:878-891): an id that was published and has not been seen for

@@ -71,6 +71,8 @@ int main(int argc, char** argv) {
     int n_tuples = 0;
     se3d::FusedMarkerState marker_state;   // the nodes' MarkerArray publications (S3D:1172-1174, PP:945): built per frame, totals reported below
     size_t n_markers3d = 0, n_markers_fused = 0, n_markers_deleted = 0;
+    const bool vis_cov = std::getenv("SE3D_REPLAY_VIS_COV") != nullptr;
+    se3d::SigmaRange sigma_range;
     auto handle_tuple = [&](const std::vector<person_msgs::Person2DList>& people) {
       ++n_tuples;
       person_msgs::PersonCovList persons3d, fused, pred;
@@ -85,6 +87,10 @@ int main(int argc, char** argv) {
         visualization_msgs::MarkerArray skel3d_msg, vis_markers;
         se3d::skeleton_markers(persons3d, prm.pose_method, skel3d_msg);
         se3d::fused_markers(fused, vis_markers);
+        if (vis_cov) {   // ROS parameter `vis_cov` of both nodes (S3D:1096, PP:932): covariance ellipsoids next to the skeletons
+          se3d::covariance_markers_3d(persons3d, prm.pose_method, skel3d_msg, &sigma_range);
+          se3d::covariance_markers_fused(fused, vis_markers);
+        }
         const size_t n_add = vis_markers.markers.size();
         marker_state.update(fused, vis_markers);
         n_markers3d += skel3d_msg.markers.size(); n_markers_fused += n_add; n_markers_deleted += vis_markers.markers.size() - n_add;
@@ -136,6 +142,11 @@ int main(int argc, char** argv) {
     wr<int32_t>(out, n_tuples);  // tuples actually handled (with the synchroniser in front the last frames may still be held back)
     std::cout << "Limits: raised " << ctx->n_grown() << " times, now " << ctx->max_det_per_cam() << " detections per camera, " << ctx->max_hyp() << " hypotheses / tracks" << std::endl;
     std::cout << "Markers: " << n_markers3d << " skeleton_3d, " << n_markers_fused << " fused, " << n_markers_deleted << " deleted" << std::endl;
+    if (vis_cov && sigma_range.max_ev[0] > 0) {   // S3D:1243-1247
+      std::cout << "Sigmas 3D [mm]:" << std::endl;
+      std::cout << "min: x: " << sigma_range.min_mm(0) << "mm, y: " << sigma_range.min_mm(1) << "mm, z: " << sigma_range.min_mm(2) << "mm." << std::endl;
+      std::cout << "max: x: " << sigma_range.max_mm(0) << "mm, y: " << sigma_range.max_mm(1) << "mm, z: " << sigma_range.max_mm(2) << "mm." << std::endl;
+    }
     for (size_t i = 0; i < skel.timings_ms().size(); ++i)  // S3D:1234-1241
       if (skel.timing_counts()[i] > 0) {
         std::cout << "Triangulation: ";

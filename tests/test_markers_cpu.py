@@ -76,3 +76,54 @@ def test_delete_markers_after_the_track_timeout(driver):
     assert len(g[0]) == 2 and g[1] == []
     assert [(m["ns"], m["id"], m["action"]) for m in g[2]] == [("skeleton_fused", 3, DELETE), ("joints_fused", 3, DELETE)]   # unseen for > 1.0 s (PP:62, 191-209)
     assert g[3] == []                                                      # once
+
+
+def test_vis_cov_ellipsoid_markers(driver):
+    """`vis_cov` (S3D:279-309, 887-898; PP:237-254, 795-807): a SPHERE marker per joint whose pose / scale are the principal axes of the joint's
+    covariance: R(q) diag((scale / (2 * 2.7955))^2) R(q)^T must give the covariance back, R a proper rotation, scales ascending (Eigen's
+    SelfAdjointEigenSolver order), eyes / ears / head / belly (fusion part >= 15) not drawn, the mid hip's x 100^2 undone for the fused marker."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+
+    def quat_to_R(q):   # x, y, z, w
+        x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def call(stage, part, C):
+        c6 = [C[0, 0], C[0, 1], C[0, 2], C[1, 1], C[1, 2], C[2, 2]]
+        out = subprocess.run([driver], input="cov %s %d %s\n" % (stage, part, " ".join("%.17g" % v for v in c6)), capture_output=True, text=True, check=True).stdout
+        return [ln for ln in out.strip().split("\n") if ln != "--"]
+
+    for trial in range(20):
+        A = rng.normal(size=(3, 3)) * rng.uniform(0.001, 0.3)
+        C = A @ A.T + 1e-8 * np.eye(3)
+        if trial == 0:
+            C = np.diag([4e-4, 1e-4, 9e-4])            # axis-aligned: eigenvalues out of order
+        if trial == 1:
+            C = 2.5e-3 * np.eye(3)                      # isotropic: any rotation is right
+        for stage, part in (("s1", 4), ("s2", 8), ("s2", 3)):   # RWrist (simple keypoint 10), MidHip (rescale), RElbow
+            lines = call(stage, part, C)
+            head, pos, quat, scale = [x.split() for x in lines[0].split("|")]
+            ns, mid, typ, life, alpha = head
+            assert typ == "2" and float(alpha) == 0.5
+            if stage == "s1":
+                assert ns == "joint_cov_3d" and int(mid) == 21 * 1 + 10 and float(life) == 5.0
+            else:
+                assert ns == "joint_cov_fused" and int(mid) == 21 * 1 + part and float(life) == 1.0
+            assert [float(v) for v in pos] == [1.0, 2.0, 3.0]
+            q = np.array([float(v) for v in quat])
+            s = np.array([float(v) for v in scale])
+            R = quat_to_R(q)
+            assert abs(np.linalg.norm(q) - 1) < 1e-12 and abs(np.linalg.det(R) - 1) < 1e-9
+            assert s[0] <= s[1] * (1 + 1e-12) and s[1] <= s[2] * (1 + 1e-12)
+            want = C / 1e4 if (stage, part) == ("s2", 8) else C
+            got = R @ np.diag((s / (2 * 2.7955)) ** 2) @ R.T
+            assert np.allclose(got, want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
+            if stage == "s1":
+                ev = np.linalg.eigvalsh(C)
+                rng_mm = [float(v) for v in lines[1].split()[1:]]
+                assert np.allclose(rng_mm[:3], np.sqrt(ev) * 1e3, rtol=1e-6) and np.allclose(rng_mm[3:], np.sqrt(ev) * 1e3, rtol=1e-6)
+    assert call("s1", 16, np.eye(3) * 1e-3) == []     # LEye (fusion part 16): not drawn
+    assert call("s2", 17, np.eye(3) * 1e-3) == []
