@@ -43,7 +43,9 @@ WORKLOADS = {
     # the marginals).
     "16cam6p": dict(n_cam=16, n_persons=6, seqs=512, contexts=12, max_det=8, max_hyp=12, bytes_s1=8972, bytes_s2=8900, flop_s1=0.12e6 + 1.86e6),
     "64cam32p": dict(n_cam=64, n_persons=32, seqs=32, contexts=3, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900, flop_s1=11.0e6 + 7.28e6),
-    "256cam128p": dict(n_cam=256, n_persons=128, seqs=1, contexts=4, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900, flop_s1=0.71e9 + 29.0e6),
+    # 256cam128p: 4 contexts x 4 sequences x 16 frames; the pair table is kept as two camera-column chunks per frame (Se3dPairPlan):
+    # 9.4 GB per 16 frames instead of 68.9 GB, 4 x 37.6 GB per GPU
+    "256cam128p": dict(n_cam=256, n_persons=128, seqs=4, contexts=4, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900, flop_s1=0.71e9 + 29.0e6),
 }
 FLOP_S2_PER_LM_ITER = 0.74e6
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec

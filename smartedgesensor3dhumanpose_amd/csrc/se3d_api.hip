@@ -16,7 +16,8 @@
 
 extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st, int variant);
 extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled, int phases, hipStream_t st_hi,
-                                   hipEvent_t *ev_hi);
+                                   hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk);
+extern "C" void se3d_launch_pair_block(const Se3dDev &D, const int2 *d_ab_one, int frame, hipStream_t st);
 extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev, int phases);
 extern "C" void se3d_launch_shard_pack_hyp(const Se3dDev &D, se3d_person3d *out, hipStream_t st);
 extern "C" void se3d_launch_shard_unpack_hyp(const Se3dDev &D, const se3d_person3d *gathered, hipStream_t st);
@@ -46,6 +47,8 @@ struct se3d_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream_hi = nullptr;   // high-priority stream for the latency-bound chains of large problems (per-camera sweep, per-step stage 2)
   hipEvent_t ev_hi[4]{};
+  Se3dPairPlan plan{};               // camera-column chunks of the pair table (large rigs; plan.m == 0: whole table)
+  hipEvent_t ev_chunk[2 * SE3D_PAIR_CHUNKS_MAX]{};   // [j]: pair chunk j written, [MAX + j]: sweep of chunk j done (buffer j % 2 free again)
   hipEvent_t *cur_ev1 = nullptr;
   std::string err;
   std::vector<void *> allocs;
@@ -297,7 +300,15 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
   ok = ok && dev_alloc(c, &D.kp, (size_t)B * N * P * SE3D_NKP) && dev_alloc(c, &c->d_assoc_in, (size_t)B * H * N);
   ok = ok && dev_alloc(c, &D.pscore, (size_t)B * N * P) && dev_alloc(c, &D.vmask_gt, (size_t)B * N * P) && dev_alloc(c, &D.vmask_ge, (size_t)B * N * P);
   ok = ok && dev_alloc(c, &D.nvalid, (size_t)B * N) && dev_alloc(c, &D.orig, (size_t)B * N * P);
-  ok = ok && dev_alloc(c, &D.pair, (size_t)B * np * P * P);
+  {
+    const char *ec = getenv("SE3D_PAIR_CHUNKS");
+    const int m = (getenv("SE3D_PAIRS") || getenv("SE3D_SWEEP_WAVE") || getenv("SE3D_SWEEP_FUSED_MAX")) ? 0   // A/B switches of the kernels that need the whole table
+                  : (ec ? atoi(ec) : se3d_pair_chunks_default(N, P, H));
+    c->plan = se3d_pair_plan(N, se3d_pair_chunks_default(N, P, H) > 0 ? m : 0);   // chunks only where the sweep is the per-camera launch chain
+    D.d.pair_chunks = c->plan.m;
+    D.d.pair_stride = c->plan.m ? 2 * c->plan.cap : np;
+  }
+  ok = ok && dev_alloc(c, &D.pair, (size_t)B * D.d.pair_stride * P * P);
   ok = ok && dev_alloc(c, &D.assoc, (size_t)B * H * N) && dev_alloc(c, &D.nviews, (size_t)B * H) && dev_alloc(c, &D.nhyp, (size_t)B);
   ok = ok && dev_alloc(c, &D.C, (size_t)B * H * P) && dev_alloc(c, &D.mask, (size_t)B * H * P) && dev_alloc(c, &D.mwork, (size_t)B * H * P);
   ok = ok && dev_alloc(c, &D.flags, (size_t)B);
@@ -463,8 +474,15 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
   if (ok) {
     D.Rt = dRt; D.K = dK; D.F = dF; D.raw = draw; D.nraw = dnraw;
     std::vector<int2> ab(np);
-    for (int i = 0, idx = 0; i < N; ++i)
-      for (int j = i + 1; j < N; ++j, ++idx) ab[idx] = make_int2(i, j);
+    if (c->plan.m) {   // column-major: the pairs of a camera-column chunk are contiguous
+      for (int j = 1, idx = 0; j < N; ++j)
+        for (int i = 0; i < j; ++i, ++idx) ab[idx] = make_int2(i, j);
+    } else {
+      for (int i = 0, idx = 0; i < N; ++i)
+        for (int j = i + 1; j < N; ++j, ++idx) ab[idx] = make_int2(i, j);
+    }
+    if (c->plan.m)
+      for (auto &e : c->ev_chunk) ok = ok && hip_ok(c, hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     ok = ok && hip_ok(c, hipMemcpy(dRt, rig->Rt, sizeof(float) * N * 12, hipMemcpyHostToDevice), "copy Rt");
     ok = ok && hip_ok(c, hipMemcpy(dK, rig->K, sizeof(float) * N * 4, hipMemcpyHostToDevice), "copy K");
     ok = ok && hip_ok(c, hipMemcpy(dF, rig->F, sizeof(float) * np * 9, hipMemcpyHostToDevice), "copy F");
@@ -543,6 +561,8 @@ void se3d_destroy(se3d_ctx *c) {
     for (auto &e : set)
       if (e) (void)hipEventDestroy(e);
   if (c->stream_hi) { (void)hipStreamSynchronize(c->stream_hi); (void)hipStreamDestroy(c->stream_hi); }
+  for (auto &e : c->ev_chunk)
+    if (e) (void)hipEventDestroy(e);
   for (auto &e : c->ev_hi)
     if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -604,7 +624,7 @@ int se3d_run_stage1(se3d_ctx *c) {
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;  // grids cover the staged frames only (array strides do not depend on B)
   // the per-frame workspace (assoc, nviews, nhyp, flags, hypP) is reset by se3d_k_normalize, the first kernel of the pass
-  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi);
+  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);
   HIPCHK(c, hipGetLastError());
   c->ran = true;
   return SE3D_OK;
@@ -618,7 +638,7 @@ int se3d_run_stage1_phases(se3d_ctx *c, int32_t phases) {
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;
   if (phases & 1) c->cur_ev1 = next_ev1(c);   // one event set per pass, begun by the part that holds phase 1 and completed by the part with phase 4
-  se3d_launch_stage1(D, c->pair_ab, c->stream, c->cur_ev1, c->tiled, phases, c->stream_hi, c->ev_hi);
+  se3d_launch_stage1(D, c->pair_ab, c->stream, c->cur_ev1, c->tiled, phases, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);
   HIPCHK(c, hipGetLastError());
   if (phases & 4) c->ran = true;
   return SE3D_OK;
@@ -768,7 +788,18 @@ int se3d_get_pair_costs(se3d_ctx *c, int32_t frame, int32_t cam_a, int32_t cam_b
   if (cam_a < 0 || cam_b <= cam_a || cam_b >= D.d.N) return SE3D_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   const int P = D.d.P;
-  const size_t off = ((size_t)frame * D.d.npairs + se3d_pair_index(cam_a, cam_b, D.d.N)) * P * P;
+  size_t off = ((size_t)frame * D.d.npairs + se3d_pair_index(cam_a, cam_b, D.d.N)) * P * P;
+  if (D.d.pair_chunks) {
+    // column chunks: the table of the pass is gone (every chunk buffer has been overwritten since); the block is computed again by the
+    // pair kernel of the pass into slot 0 of the frame (one-entry pair list in the first element of C, free between passes)
+    const int2 one = make_int2(cam_a, cam_b);
+    HIPCHK(c, hipMemcpyAsync(D.C, &one, sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    Se3dDev D1 = D;
+    D1.d.B = 1;
+    se3d_launch_pair_block(D1, reinterpret_cast<const int2 *>(D.C), frame, c->stream);
+    HIPCHK(c, hipGetLastError());
+    off = (size_t)frame * D.d.pair_stride * P * P;
+  }
   int32_t nv[2];
   HIPCHK(c, hipMemcpyAsync(out, D.pair + off, sizeof(double) * (size_t)P * P, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&nv[0], D.nvalid + frame * D.d.N + cam_a, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1055,7 +1086,7 @@ int se3d_run_stage1_shard_pre(se3d_ctx *c, void *d_pack) {
   HIPCHK(c, hipSetDevice(c->device));
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;
-  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 11, c->stream_hi, c->ev_hi);   // association on every rank, triangulation of the own hypotheses
+  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 11, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);   // association on every rank, triangulation of the own hypotheses
   se3d_launch_shard_pack_hyp(D, static_cast<se3d_person3d *>(d_pack), c->stream);
   HIPCHK(c, hipGetLastError());
   return SE3D_OK;
@@ -1067,7 +1098,7 @@ int se3d_run_stage1_shard_post(se3d_ctx *c, const void *d_gathered) {
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;
   se3d_launch_shard_unpack_hyp(D, static_cast<const se3d_person3d *>(d_gathered), c->stream);
-  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 4, c->stream_hi, c->ev_hi);   // post-processing + duplicate merge on every rank
+  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 4, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);   // post-processing + duplicate merge on every rank
   HIPCHK(c, hipGetLastError());
   c->ran = true;
   return SE3D_OK;
@@ -1174,7 +1205,7 @@ int se3d_stream_submit(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frame
   D.d.B = n_frames;
   se3d_launch_stream_scatter(D, sl.d_rag, sl.d_off, c->stream);
   c->staged_frames = n_frames;
-  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi);
+  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);
   c->ran = true;
   c->d_fb_walk = sl.d_fb;
   rc = se3d_run_stage2_walk(c, n_seq, n_steps, frame_slot0, t);

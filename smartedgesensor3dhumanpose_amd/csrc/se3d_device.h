@@ -5,7 +5,8 @@
 //   kp       [B][N][P][17] float4         normalised (x, y, conf, 0); filtered slot order     (row N; stand-alone pair kernels only —
 //                                         small rigs keep the normalised points in LDS, the triangulation normalises in registers)
 //   vmask    [B][N][P] uint32 x2          bit j: conf > 0.30 (calcCost gate) / conf >= 0.30 (triangulation gate)
-//   pair     [B][N(N-1)/2][P][P] double   pairwise mean symmetric epipolar distance, -1 = no joint in common  (row E)
+//   pair     [B][N(N-1)/2][P][P] double   pairwise mean symmetric epipolar distance, -1 = no joint in common  (row E); large rigs keep
+//                                         two camera-column chunks of it per frame instead of the whole table (Se3dPairPlan)
 //   assoc    [B][H][N] int32              filtered detection slot of hypothesis h in camera c, or -1           (row G)
 //   C, mask  [B][H*P] double / uint8      per-step cost matrix, column-major with leading dimension H
 //   hypP     [B][H] se3d_person3d         per-hypothesis triangulated person                                  (rows T,U,X)
@@ -26,7 +27,49 @@ struct Se3dDims {
   int pose_method, norm_height;
   double max_epi;
   int shard_rank, shard_world;  // hypothesis shard (se3d_set_shard): this context triangulates hypotheses h with h % world == rank
+  int pair_stride;              // pair slots per frame of `pair`: npairs (whole table) or 2 x the largest column chunk (se3d_pair_plan)
+  int pair_chunks;              // 0: the whole pair table is materialised; m >= 2: camera-column chunks (large rigs), see Se3dPairPlan
 };
+
+// Column chunks of the pair table (large rigs, round 3).  Camera step b of the sweep (S3D:588-674) reads only the blocks (a, b), a < b —
+// column b of the upper-triangular table — so the table never has to exist as a whole: the columns 1 .. N-1 are cut into m chunks of about
+// equal pair count, the pair kernel fills chunk j (buffer j % 2) while the sweep walks the columns of chunk j - 1, and a frame keeps
+// 2 x cap pair slots instead of N (N - 1) / 2 (256 cameras, m = 16: 4 592 instead of 32 640 — 0.6 instead of 4.3 GB per frame at P = 128).
+// Pairs are enumerated column-major inside the plan: list index of (a, b) = b (b - 1) / 2 + a.
+#define SE3D_PAIR_CHUNKS_MAX 32
+struct Se3dPairPlan {
+  int m = 0;                                  // chunks (0: whole table)
+  int col0[SE3D_PAIR_CHUNKS_MAX + 1] = {};    // chunk j covers the columns col0[j] .. col0[j + 1] - 1; col0[0] = 1, col0[m] = N
+  int list0[SE3D_PAIR_CHUNKS_MAX + 1] = {};   // column-major list index of its first pair: col0[j] (col0[j] - 1) / 2
+  int cap = 0;                                // largest chunk, in pairs
+};
+__host__ __device__ inline int se3d_pair_col_index(int a, int b) { return b * (b - 1) / 2 + a; }   // a < b
+inline Se3dPairPlan se3d_pair_plan(int N, int m) {
+  Se3dPairPlan pl;
+  if (m < 2) return pl;
+  if (m > SE3D_PAIR_CHUNKS_MAX) m = SE3D_PAIR_CHUNKS_MAX;
+  if (m > N - 1) m = N - 1;
+  const long long np = (long long)N * (N - 1) / 2;
+  pl.m = m;
+  int b = 1;
+  for (int j = 0; j < m; ++j) {
+    while (b < N && (long long)b * (b - 1) / 2 < np * j / m) ++b;
+    if (j > 0 && b <= pl.col0[j - 1]) b = pl.col0[j - 1] + 1;   // every chunk holds at least one column
+    pl.col0[j] = b;
+  }
+  pl.col0[0] = 1;
+  pl.col0[m] = N;
+  for (int j = 0; j <= m; ++j) pl.list0[j] = pl.col0[j] * (pl.col0[j] - 1) / 2;
+  for (int j = 0; j < m; ++j) pl.cap = pl.list0[j + 1] - pl.list0[j] > pl.cap ? pl.list0[j + 1] - pl.list0[j] : pl.cap;
+  return pl;
+}
+// Which rigs run in chunks: those whose sweep is the chain of per-camera launches anyway (se3d_launch_stage1: neither the one-wavefront nor
+// the one-workgroup sweep applies) and whose table is big enough to matter.  SE3D_PAIR_CHUNKS=m overrides (0 / 1: whole table).
+inline int se3d_pair_chunks_default(int N, int P, int H) {
+  const bool wave_sweep = H <= 64 && P <= 64 && H * P <= 2048;
+  if (P <= 16 || N < 32 || wave_sweep || H * P <= 256) return 0;
+  return N >= 128 ? 16 : 8;
+}
 
 struct Se3dDev {
   Se3dDims d;
@@ -45,7 +88,7 @@ struct Se3dDev {
   int32_t *nvalid;    // [B][N]
   int32_t *orig;      // [B][N][P]
   // association
-  double *pair;       // [B][npairs][P][P]
+  double *pair;       // [B][pair_stride][P][P]
   int32_t *assoc;     // [B][H][N]
   int32_t *nviews;    // [B][H]
   int32_t *nhyp;      // [B]

@@ -651,10 +651,13 @@ __device__ __forceinline__ void se3d_lds_barrier() { asm volatile("s_waitcnt lgk
 #ifndef RB_WPE
 #define RB_WPE 4
 #endif
-__global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, const int2 *__restrict__ pair_ab) {
-  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
-  const int pr = blockIdx.y, f = blockIdx.z;
-  const int2 ab = pair_ab[pr];
+// list0 / slot0 / fbase: the workgroups of grid row y work on pair list0 + y of `pair_ab` and write slot slot0 + y of the frame's pair slots;
+// frame = fbase + blockIdx.z.  Whole table: list0 = slot0 = 0 over all pairs; column chunks (Se3dPairPlan): one launch per chunk.
+__global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, const int2 *__restrict__ pair_ab, int list0, int slot0, int fbase) {
+  const int N = D.d.N, P = D.d.P, np = D.d.pair_stride;
+  const int f = fbase + blockIdx.z;
+  const int2 ab = pair_ab[list0 + blockIdx.y];
+  const int pr = slot0 + blockIdx.y;
   const int na = D.nvalid[f * N + ab.x], nb = D.nvalid[f * N + ab.y];
   const int p0 = blockIdx.x * RB_ROWS;
   if (p0 >= na || nb == 0) return;
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, cons
   __shared__ double INV[SE3D_NKP + 1];     // RN(1 / n) for the joint count of an entry
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, ql = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it is a uniform branch, not an exec mask
-  const float *F = D.F + 9 * (size_t)pr;
+  const float *F = D.F + 9 * (size_t)se3d_pair_index(ab.x, ab.y, N);   // F is stored in the reference's pair order (get_fundamental_idx)
   const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
   const size_t baseA = ((size_t)(f * N + ab.x)) * P, baseB = ((size_t)(f * N + ab.y)) * P;
   if (tid == 0) { s_unsafe_a = 0; s_unsafe_b[0] = 0; s_unsafe_b[1] = 0; s_unsafe_b[2] = 0; }
@@ -775,9 +778,10 @@ __global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, cons
 // row G (cost) — C(hyp, det) of calcCost for sweep step `b` (S3D:616-626 -> 335-390) gathered from the pair table in the
 // reference's accumulation order (ascending attached view).  One workgroup per (hypothesis, frame), lanes over dets.
 // =============================================================================================================
-__global__ __launch_bounds__(128) void se3d_k_sweep_cost(Se3dDev D, int b) {
+// slot_shift: column chunks (D.d.pair_chunks): pair (a, b) sits in slot se3d_pair_col_index(a, b) + slot_shift of the frame's pair slots
+__global__ __launch_bounds__(128) void se3d_k_sweep_cost(Se3dDev D, int b, int slot_shift) {
   const int h = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
-  const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
+  const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.pair_stride;
   if (D.nraw[f * N + b] == 0) return;
   const int nh = D.nhyp[f];
   if (nh == 0 || h >= nh) return;
@@ -796,7 +800,8 @@ __global__ __launch_bounds__(128) void se3d_k_sweep_cost(Se3dDev D, int b) {
       const unsigned long long bl = __ballot(k >= 0);
       if (k >= 0) {
         const int pos = m + __popcll(bl & ((1ull << tid) - 1ull));
-        s_off[pos] = ((unsigned long long)se3d_pair_index(a, b, N) * P + k) * P;
+        const int slot = D.d.pair_chunks ? se3d_pair_col_index(a, b) + slot_shift : se3d_pair_index(a, b, N);
+        s_off[pos] = ((unsigned long long)slot * P + k) * P;
         s_scored[pos] = D.pscore[((size_t)(f * N + a)) * P + k] > 0.5f ? 1 : 0;
       }
       m += __popcll(bl);
@@ -2834,10 +2839,19 @@ static void se3d_launch_triangulation(const Se3dDev &D, hipStream_t st) {
 // phases (bit mask): 1 = normalise + pair-cost table, 8 = camera sweep, 2 = triangulation, 4 = post-processing + duplicate merge
 // st_hi / ev_hi: optional high-priority stream (+ two events) for the per-camera sweep launches of large problems: 2 x N tiny dependent
 // launches that otherwise queue behind the millions of workgroups of other contexts' pair kernels.
+extern "C" void se3d_launch_pair_block(const Se3dDev &D, const int2 *d_ab_one, int frame, hipStream_t st) {   // se3d_get_pair_costs under column chunks
+  hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((D.d.P + RB_ROWS - 1) / RB_ROWS, 1, 1), dim3(256), 0, st, D, d_ab_one, 0, 0, frame);
+}
+
 extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, bool tiled, int phases,
-                                   hipStream_t st_hi, hipEvent_t *ev_hi) {
+                                   hipStream_t st_hi, hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk) {
   const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H;
-  if (phases & 1) {
+  const bool chunked = D.d.pair_chunks > 0 && plan && plan->m == D.d.pair_chunks;
+  if ((phases & 1) && chunked) {   // column chunks: phase 1 is the normalisation only, the pair kernel runs chunk by chunk inside phase 8
+    if (ev) (void)hipEventRecord(ev[0], st);
+    hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D, 1);
+    if (ev) (void)hipEventRecord(ev[1], st);
+  } else if (phases & 1) {
   const char *e_pairs = getenv("SE3D_PAIRS");  // flat | packed | tiled: A/B switches that force the stand-alone pair kernels
   const bool fused_np = !tiled && !e_pairs && N * P <= NP_MAX_DETS && D.d.npairs <= 2048;
   if (ev && (phases & 1)) (void)hipEventRecord(ev[0], st);
@@ -2847,7 +2861,7 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     const size_t lds = (size_t)N * P * SE3D_NKP * sizeof(float2) + (size_t)N * P * 8 + (size_t)N * 4 + (size_t)(D.d.npairs + 1) * 4;
     hipLaunchKernelGGL(se3d_k_normalize_pairs, dim3(B), dim3(256), lds, st, D, pair_ab);
   } else if (tiled && !(e_pairs && strcmp(e_pairs, "tiled") == 0)) {  // large P: two rows x 32 columns per wavefront (default)
-    hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((P + RB_ROWS - 1) / RB_ROWS, D.d.npairs, B), dim3(256), 0, st, D, pair_ab);
+    hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((P + RB_ROWS - 1) / RB_ROWS, D.d.npairs, B), dim3(256), 0, st, D, pair_ab, 0, 0, 0);
   } else if (tiled) {                                                  // SE3D_PAIRS=tiled: the 4x4 register-tile kernel (A/B)
     const int tiles = (P + PT - 1) / PT;
     hipLaunchKernelGGL(se3d_k_pairs_tiled, dim3(tiles * tiles, D.d.npairs, B), dim3(256), 0, st, D, pair_ab);
@@ -2860,7 +2874,34 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   }
   if (ev) (void)hipEventRecord(ev[2], st);
   }
-  if (phases & 8) {
+  if ((phases & 8) && chunked) {
+    // Pair kernel and camera sweep interleaved, chunk by chunk: chunk j of the pair table (columns col0[j] .. col0[j + 1] - 1) goes to
+    // buffer j % 2 of the frame's pair slots on the bulk stream while the sweep of chunk j - 1 reads the other buffer on the
+    // (high-priority) sweep stream; chunk j + 2 waits until the sweep has left buffer j % 2.
+    int dynW = (int)((size_t)H * P * sizeof(double));
+    if (dynW > 128 * 1024) dynW = 128 * 1024;
+    if (const char *e = getenv("SE3D_SWEEP_LDS_KB")) dynW = std::min(dynW, atoi(e) * 1024);   // A/B: Munkres matrix in LDS (blocks a CU's LDS for the pair kernel) or in L2
+    hipStream_t sw = (st_hi && ev_chunk) ? st_hi : st;
+    const int m = plan->m, cap = plan->cap;
+    hipEvent_t *ev_p = ev_chunk, *ev_s = ev_chunk ? ev_chunk + SE3D_PAIR_CHUNKS_MAX : nullptr;
+    for (int j = 0; j < m; ++j) {
+      const int n_pairs = plan->list0[j + 1] - plan->list0[j], slot0 = (j & 1) * cap;
+      if (sw != st && j >= 2) (void)hipStreamWaitEvent(st, ev_s[j - 2], 0);
+      hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((P + RB_ROWS - 1) / RB_ROWS, n_pairs, B), dim3(256), 0, st, D, pair_ab, plan->list0[j], slot0, 0);
+      if (sw != st) {
+        (void)hipEventRecord(ev_p[j], st);
+        (void)hipStreamWaitEvent(sw, ev_p[j], 0);
+      }
+      if (j == 0) hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), (size_t)dynW, sw, D, 0, dynW);   // camera 0 seeds the hypotheses
+      for (int b = plan->col0[j]; b < plan->col0[j + 1]; ++b) {
+        hipLaunchKernelGGL(se3d_k_sweep_cost, dim3(H, B), dim3(128), 0, sw, D, b, slot0 - plan->list0[j]);
+        hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), (size_t)dynW, sw, D, b, dynW);
+      }
+      if (sw != st) (void)hipEventRecord(ev_s[j], sw);
+    }
+    if (ev) (void)hipEventRecord(ev[2], st);   // "pairs": the bulk stream up to its last chunk (waits for free buffers included)
+    if (sw != st) (void)hipStreamWaitEvent(st, ev_s[m - 1], 0);
+  } else if (phases & 8) {
   // Munkres working matrix in LDS when H*P doubles fit next to the static LDS of the kernel (<= 128 KB)
   int dynW = (int)((size_t)H * P * sizeof(double));
   if (dynW > 128 * 1024) dynW = 128 * 1024;
@@ -2886,7 +2927,7 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
       sw = st_hi;
     }
     for (int b = 0; b < N; ++b) {
-      if (b > 0) hipLaunchKernelGGL(se3d_k_sweep_cost, dim3(H, B), dim3(128), 0, sw, D, b);
+      if (b > 0) hipLaunchKernelGGL(se3d_k_sweep_cost, dim3(H, B), dim3(128), 0, sw, D, b, 0);
       hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), (size_t)dynW, sw, D, b, dynW);
     }
     if (sw != st) {

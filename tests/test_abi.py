@@ -99,20 +99,26 @@ def test_product_rig_tensors_match_oracle(product_lib, oracle):
 
 
 def test_device_bytes_and_bench_memory_plan(product_lib):
-    """se3d_device_bytes walks se3d_create's allocation list on the host: the 256cam128p pair table (16 frames x 32 640 camera pairs x 128^2
-    doubles = 68.5 GB) dominates a context; bench.py's plan fails fast with the figures when the contexts do not fit the GPU."""
+    """se3d_device_bytes walks se3d_create's allocation list on the host: the pair slots dominate a 256cam128p context (the whole table would
+    be 16 frames x 32 640 camera pairs x 128^2 doubles = 68.5 GB); bench.py's plan fails fast with the figures when the contexts do not fit."""
     import bench
     from smartedgesensor3dhumanpose_amd.skeleton_3d import Se3dError, device_bytes
     b = device_bytes(256, 16, 128, 256)
-    pair = 16 * (256 * 255 // 2) * 128 * 128 * 8
-    assert pair < b < pair + 2e9
+    # round 3: large rigs keep two camera-column chunks of the pair table per frame (16 chunks at 256 cameras: 2 x 2 296 of the 32 640 pairs)
+    whole = 16 * (256 * 255 // 2) * 128 * 128 * 8
+    assert whole / 16 < b < whole / 5      # two chunks of ~1 / 16 of the pairs each, plus everything else
+    os.environ["SE3D_PAIR_CHUNKS"] = "0"   # the whole table (A/B switch)
+    try:
+        assert whole < device_bytes(256, 16, 128, 256) < whole + 2e9
+    finally:
+        del os.environ["SE3D_PAIR_CHUNKS"]
     assert device_bytes(16, 2, 8, 12) < device_bytes(16, 4, 8, 12) < 10e6
     with pytest.raises(Se3dError):
         device_bytes(1, 1, 8, 12)          # fewer than two cameras: se3d_create rejects it, so does the plan
     plan = bench.memory_plan("256cam128p", 4, 16, exchange=True)
     assert plan["total_bytes"] == 4 * b + plan["exchange_bytes"] and plan["total_bytes"] < 288e9
     with pytest.raises(SystemExit) as e:
-        bench.memory_plan("256cam128p", 5, 16, free_bytes=int(288e9))
+        bench.memory_plan("256cam128p", 4, 512, free_bytes=int(288e9))
     assert "needs" in str(e.value) and "GB" in str(e.value) and "--contexts" in str(e.value)
 
 
