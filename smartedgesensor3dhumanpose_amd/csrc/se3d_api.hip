@@ -413,7 +413,10 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     // CUs; a sweep workgroup wants ~100 KB of LDS for its Munkres matrix) always find a CU with room.  Measured at 256 cam x 128 p, four
     // contexts: 21.0 k -> 22.5 k skeletons/s; 24 reserved CUs lose (20.6 k).  SE3D_RESERVE_CUS=R overrides (0 = off).
     const char *er = getenv("SE3D_RESERVE_CUS");
-    const int reserve = er ? (limits->max_hyp > 64 ? atoi(er) : 0) : (N >= 128 ? 32 : 0);
+    // (column chunks of the pair table, round 3: pair kernel and sweep alternate in short launches and the Munkres matrix sits in L2 — no CUs reserved)
+    const bool chunks = !getenv("SE3D_PAIR_CHUNKS") ? se3d_pair_chunks_default(N, P, H) > 0 && !getenv("SE3D_PAIRS") && !getenv("SE3D_SWEEP_WAVE") && !getenv("SE3D_SWEEP_FUSED_MAX")
+                                                    : atoi(getenv("SE3D_PAIR_CHUNKS")) >= 2;
+    const int reserve = er ? (limits->max_hyp > 64 ? atoi(er) : 0) : (N >= 128 && !chunks ? 32 : 0);
     hipDeviceProp_t prop;
     bool ok_stream = false;
     if (reserve > 0 && hipGetDeviceProperties(&prop, device_id) == hipSuccess && reserve < prop.multiProcessorCount) {

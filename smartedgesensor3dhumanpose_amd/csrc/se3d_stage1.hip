@@ -2878,9 +2878,11 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     // Pair kernel and camera sweep interleaved, chunk by chunk: chunk j of the pair table (columns col0[j] .. col0[j + 1] - 1) goes to
     // buffer j % 2 of the frame's pair slots on the bulk stream while the sweep of chunk j - 1 reads the other buffer on the
     // (high-priority) sweep stream; chunk j + 2 waits until the sweep has left buffer j % 2.
-    int dynW = (int)((size_t)H * P * sizeof(double));
-    if (dynW > 128 * 1024) dynW = 128 * 1024;
-    if (const char *e = getenv("SE3D_SWEEP_LDS_KB")) dynW = std::min(dynW, atoi(e) * 1024);   // A/B: Munkres matrix in LDS (blocks a CU's LDS for the pair kernel) or in L2
+    // Munkres working matrix: in L2 here (dynW = 0).  In LDS (up to 128 KB per frame's workgroup, SE3D_SWEEP_LDS_KB=128) a resident sweep
+    // workgroup leaves room for one pair-kernel workgroup on its CU instead of four; with 64 frames per context in flight that cost more
+    // than the faster Munkres gave back (26.6 k vs 27.6 k skeletons/s at 256cam128p, profiles/r3/README.md).
+    int dynW = 0;
+    if (const char *e = getenv("SE3D_SWEEP_LDS_KB")) dynW = std::min((int)std::min((size_t)H * P * sizeof(double), (size_t)128 * 1024), atoi(e) * 1024);
     hipStream_t sw = (st_hi && ev_chunk) ? st_hi : st;
     const int m = plan->m, cap = plan->cap;
     hipEvent_t *ev_p = ev_chunk, *ev_s = ev_chunk ? ev_chunk + SE3D_PAIR_CHUNKS_MAX : nullptr;
