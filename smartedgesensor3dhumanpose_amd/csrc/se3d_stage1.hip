@@ -265,16 +265,10 @@ __device__ __forceinline__ double se3d_pair_cost_lds(const float *__restrict__ F
   return n > 0 ? cost / n : -1.0;
 }
 
-__global__ __launch_bounds__(256) void se3d_k_normalize_pairs(Se3dDev D, const int2 *__restrict__ pair_ab) {
-  extern __shared__ __align__(16) unsigned char np_smem[];
-  const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float2 *skp = reinterpret_cast<float2 *>(np_smem);                       // [N * P][17] filtered slot order
-  unsigned *s_mgt = reinterpret_cast<unsigned *>(skp + (size_t)N * P * SE3D_NKP);  // [N * P] by filtered slot
-  int *s_slot = reinterpret_cast<int *>(s_mgt + N * P);                    // [N * P] by raw detection index: filtered slot or -1
-  int *s_nv = s_slot + N * P;                                              // [N]
-  int *s_cum = s_nv + N;                                                   // [np + 1]
-  __shared__ int s_part[4];
+// Rows N of a frame for the small-rig kernels below: per-frame workspace reset, valid-joint masks, order-preserving slot compaction, the
+// normalised points of the kept detections into LDS.  256 threads; ends with the points visible to the whole workgroup.
+__device__ __forceinline__ void se3d_np_prologue(const Se3dDev &D, int f, int tid, float2 *skp, unsigned *s_mgt, int *s_slot, int *s_nv) {
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
   // ---- per-frame workspace reset (assoc, nviews, nhyp, flags) ----
   for (int i = tid; i < H * N; i += 256) D.assoc[(size_t)f * H * N + i] = -1;
   for (int h = tid; h < H; h += 256) D.nviews[f * H + h] = 0;
@@ -329,6 +323,20 @@ __global__ __launch_bounds__(256) void se3d_k_normalize_pairs(Se3dDev D, const i
     }
     skp[(size_t)(cc * P + k) * SE3D_NKP + j] = o;
   }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void se3d_k_normalize_pairs(Se3dDev D, const int2 *__restrict__ pair_ab) {
+  extern __shared__ __align__(16) unsigned char np_smem[];
+  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float2 *skp = reinterpret_cast<float2 *>(np_smem);                       // [N * P][17] filtered slot order
+  unsigned *s_mgt = reinterpret_cast<unsigned *>(skp + (size_t)N * P * SE3D_NKP);  // [N * P] by filtered slot
+  int *s_slot = reinterpret_cast<int *>(s_mgt + N * P);                    // [N * P] by raw detection index: filtered slot or -1
+  int *s_nv = s_slot + N * P;                                              // [N]
+  int *s_cum = s_nv + N;                                                   // [np + 1]
+  __shared__ int s_part[4];
+  se3d_np_prologue(D, f, tid, skp, s_mgt, s_slot, s_nv);
   // ---- exclusive prefix of n_a * n_b over the camera pairs ----
   int carry = 0;
   for (int base = 0; base < np; base += 256) {
@@ -360,6 +368,186 @@ __global__ __launch_bounds__(256) void se3d_k_normalize_pairs(Se3dDev D, const i
     const int ia = ab.x * P + p, ib = ab.y * P + q;
     const unsigned m = s_mgt[ia] & s_mgt[ib];
     D.pair[(((size_t)f * np + pr) * P + p) * P + q] = se3d_pair_cost_lds(D.F + 9 * (size_t)pr, skp + (size_t)ia * SE3D_NKP, skp + (size_t)ib * SE3D_NKP, m);
+  }
+}
+
+// ---- the same table with the epipolar LINES hoisted (round 3; P <= 8; an A/B variant that lost: see the launcher) --------------------------
+// se3d_k_normalize_pairs evaluates an entry (det_a p, det_b q) on one lane and rebuilds, per joint, both epipolar lines F p1 and F^T p2, the
+// square roots of their norms and the two divisions: ~85 instructions per (entry, joint), although a line belongs to a (camera pair, detection,
+// joint) and serves n_b (n_a) entries.  Here a wavefront takes a run of camera pairs ("round": at most 64 det_b lanes and NPL_ROWS det_a rows);
+// a lane is one (pair, det_b q) and walks the det_a rows of its pair.  Per chunk of NPL_J joints: the lanes together build the det_a side's
+// operands of the round — line, sqrt(norm), the refined reciprocal of it, the point — once per (pair, p, joint) into the wavefront's own LDS
+// region (no workgroup barrier after the prologue), every lane builds the operands of its own det_b once per joint in registers, and an entry
+// costs two dot products, two five-operation quotients on the shared reciprocals, the range test and the fp64 add: ~26 instructions + two
+// 16-byte LDS reads.  The float operations are those of se3d_pair_cost_lds in the same order — the shared reciprocal is the first three
+// operations of se3d_div_core, the remaining five are applied per entry — so the table is bit-identical (tests/test_gpu_stage1.py).
+#define NPL_J 2        // joints per chunk
+#define NPL_ROWS 96    // det_a rows (pair, p) a round can stage; a round with more computes its det_a operands per entry
+#define NPL_PMAX 8     // P limit of this kernel (accumulators in registers); larger P takes se3d_k_normalize_pairs
+#define NPL_NPMAX 256  // camera pairs (one scan pass, pair list and F staged in LDS)
+struct __align__(16) NplRec { float lx, ly, lz, r, inv, px, py, pad; };
+__device__ __forceinline__ bool se3d_num_in_range(float n) {   // n >= 0: zero or inside [2^-60, 2^60]
+  const unsigned c = __float_as_uint(n);
+  return (c - 1u >= SE3D_EXACT_LO - 1u) && c <= SE3D_EXACT_HI;
+}
+// operands of one side of one joint: r = sqrt(lx^2 + ly^2) and the refined reciprocal of r (both 0: norm outside the exact range)
+__device__ __forceinline__ void se3d_line_ops(float lx, float ly, float &r, float &inv) {
+  const float s = lx * lx + ly * ly;
+  const unsigned b = __float_as_uint(s);
+  if (b >= SE3D_EXACT_LO && b <= SE3D_EXACT_HI) {
+    r = se3d_sqrt_core(s);
+    const float r0 = __builtin_amdgcn_rcpf(r);
+    const float e0 = __builtin_fmaf(-r, r0, 1.f);
+    inv = __builtin_fmaf(e0, r0, r0);
+  } else { r = 0.f; inv = 0.f; }
+}
+// n / r on the shared reciprocal (the last five operations of se3d_div_core) or, outside the exact range, the IEEE expressions on the norm
+__device__ __forceinline__ float se3d_line_dist(float n, float lx, float ly, float r, float inv) {
+  if (inv != 0.f && se3d_num_in_range(n)) {
+    const float q0 = n * inv;
+    const float e1 = __builtin_fmaf(-r, q0, n);
+    const float q1 = __builtin_fmaf(e1, inv, q0);
+    const float e2 = __builtin_fmaf(-r, q1, n);
+    return __builtin_fmaf(e2, inv, q1);
+  }
+  return n / sqrtf(lx * lx + ly * ly);
+}
+__device__ __forceinline__ NplRec se3d_npl_arec(const float *F, float2 pt) {
+  NplRec rc;
+  rc.lx = F[0] * pt.x + (F[1] * pt.y + F[2]);
+  rc.ly = F[3] * pt.x + (F[4] * pt.y + F[5]);
+  rc.lz = F[6] * pt.x + (F[7] * pt.y + F[8]);
+  se3d_line_ops(rc.lx, rc.ly, rc.r, rc.inv);
+  rc.px = pt.x; rc.py = pt.y; rc.pad = 0.f;
+  return rc;
+}
+__global__ __launch_bounds__(256) void se3d_k_normalize_pairs_lines(Se3dDev D, const int2 *__restrict__ pair_ab) {
+  extern __shared__ __align__(16) unsigned char np_smem[];
+  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  NplRec *arec = reinterpret_cast<NplRec *>(np_smem) + (size_t)wave * NPL_ROWS * NPL_J;   // [4 waves][NPL_ROWS][NPL_J], 16-byte aligned at the front
+  float2 *skp = reinterpret_cast<float2 *>(np_smem + (size_t)4 * NPL_ROWS * NPL_J * sizeof(NplRec));   // [N * P][17] filtered slot order
+  unsigned *s_mgt = reinterpret_cast<unsigned *>(skp + (size_t)N * P * SE3D_NKP);  // [N * P] by filtered slot
+  int *s_slot = reinterpret_cast<int *>(s_mgt + N * P);                    // [N * P]
+  int *s_nv = s_slot + N * P;                                              // [N]
+  int *s_cumA = s_nv + N;                                                  // [np + 1] det_a rows before pair pr
+  int *s_cumB = s_cumA + np + 1;                                           // [np + 1] det_b lanes before pair pr
+  int2 *s_ab = reinterpret_cast<int2 *>(s_cumB + np + 1 + ((np + 1) & 1)); // [np] the pair list (8-byte aligned)
+  float *s_F = reinterpret_cast<float *>(s_ab + np);                       // [np][9]
+  short2 *s_row = reinterpret_cast<short2 *>(s_F + (size_t)np * 9) + (size_t)wave * NPL_ROWS;   // [4 waves][NPL_ROWS]: (pair, det_a index ia) of a staged row
+  __shared__ int s_part[2][4];
+  // the pair list and the fundamental matrices of the rig into LDS (read many times below); overlaps the prologue's loads
+  for (int i = tid; i < np; i += 256) s_ab[i] = pair_ab[i];
+  for (int i = tid; i < np * 9; i += 256) s_F[i] = D.F[i];
+  se3d_np_prologue(D, f, tid, skp, s_mgt, s_slot, s_nv);
+  // ---- exclusive prefixes over the pairs of det_a rows and det_b lanes; a pair without detections on one side contributes nothing ----
+  {
+    int na = 0, nb = 0;
+    if (tid < np) { const int2 ab = s_ab[tid]; na = s_nv[ab.x]; nb = s_nv[ab.y]; if (na == 0 || nb == 0) { na = 0; nb = 0; } }
+    int ia = na, ib = nb;
+    for (int o = 1; o < 64; o <<= 1) { const int ta = __shfl_up(ia, o), tb = __shfl_up(ib, o); if (lane >= o) { ia += ta; ib += tb; } }
+    if (lane == 63) { s_part[0][wave] = ia; s_part[1][wave] = ib; }
+    __syncthreads();
+    int offa = 0, offb = 0;
+    for (int w = 0; w < wave; ++w) { offa += s_part[0][w]; offb += s_part[1][w]; }
+    if (tid < np) { s_cumA[tid] = offa + ia - na; s_cumB[tid] = offb + ib - nb; }
+    if (tid == np - 1) { s_cumA[np] = offa + ia; s_cumB[np] = offb + ib; }
+    __syncthreads();
+  }
+  const int totalB = s_cumB[np];
+  const int nrounds = (totalB + 63) >> 6;
+  for (int rd = wave; rd < nrounds; rd += 4) {   // a round: 64 consecutive (pair, det_b) lanes; from here on a wavefront works on its own
+    const int key = (rd << 6) + lane;
+    const bool have = key < totalB;
+    int pr;
+    {
+      const int k = have ? key : totalB - 1;
+      int lo = 0, hi = np;   // largest pr with s_cumB[pr] <= k (ties: the last one, which is the pair that owns lanes)
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cumB[mid] <= k) lo = mid; else hi = mid; }
+      pr = lo;
+    }
+    const int pr0 = __builtin_amdgcn_readfirstlane(pr);
+    const int pr1 = __builtin_amdgcn_readlane(pr, 63);   // lanes past the end were given the last lane's pair
+    const int rows0 = s_cumA[pr0], nrows = s_cumA[pr1 + 1] - rows0;
+    const bool staged = nrows <= NPL_ROWS;               // wave-uniform
+    const int2 ab = s_ab[pr];
+    const int q = (have ? key : totalB - 1) - s_cumB[pr];
+    const int na = have ? s_nv[ab.x] : 0;
+    const int rowbase = s_cumA[pr] - rows0;
+    const int ib = ab.y * P + q;
+    const unsigned mB = have ? s_mgt[ib] : 0u;
+    float Fv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Fv[k] = s_F[pr * 9 + k];
+    unsigned mA[NPL_PMAX];
+#pragma unroll
+    for (int p_ = 0; p_ < NPL_PMAX; ++p_) mA[p_] = (p_ < na) ? (s_mgt[ab.x * P + p_] & mB) : 0u;
+    double acc[NPL_PMAX];
+#pragma unroll
+    for (int p_ = 0; p_ < NPL_PMAX; ++p_) acc[p_] = 0.0;
+    if (staged) {   // which (pair, detection) a staged row is: once per round
+      for (int row = lane; row < nrows; row += 64) {
+        const int k = rows0 + row;
+        int lo = pr0, hi = pr1 + 1;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cumA[mid] <= k) lo = mid; else hi = mid; }
+        s_row[row] = make_short2((short)lo, (short)(s_ab[lo].x * P + (k - s_cumA[lo])));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    for (int jc = 0; jc < SE3D_NKP; jc += NPL_J) {
+      const int jn = min(NPL_J, SE3D_NKP - jc);
+      if (staged) {   // ---- det_a side of the round: one (row, joint) item per lane and trip ----
+        for (int it = lane; it < nrows * NPL_J; it += 64) {
+          const int row = it / NPL_J, jj = it - row * NPL_J;
+          if (jj >= jn) continue;
+          const short2 ri = s_row[row];
+          arec[row * NPL_J + jj] = se3d_npl_arec(s_F + 9 * (int)ri.x, skp[(size_t)ri.y * SE3D_NKP + jc + jj]);
+        }
+      }
+      // ---- det_b side: this lane's own detection, in registers ----
+      float bx[NPL_J], by[NPL_J], l2x[NPL_J], l2y[NPL_J], l2z[NPL_J], r2[NPL_J], inv2[NPL_J];
+#pragma unroll
+      for (int jj = 0; jj < NPL_J; ++jj) {
+        const float2 pt = (have && jj < jn) ? skp[(size_t)ib * SE3D_NKP + jc + jj] : make_float2(0.f, 0.f);
+        bx[jj] = pt.x; by[jj] = pt.y;
+        l2x[jj] = Fv[0] * pt.x + (Fv[3] * pt.y + Fv[6]);
+        l2y[jj] = Fv[1] * pt.x + (Fv[4] * pt.y + Fv[7]);
+        l2z[jj] = Fv[2] * pt.x + (Fv[5] * pt.y + Fv[8]);
+        se3d_line_ops(l2x[jj], l2y[jj], r2[jj], inv2[jj]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      // ---- entries: rows of this lane's pair ----
+#pragma unroll
+      for (int p_ = 0; p_ < NPL_PMAX; ++p_) {
+        if (p_ < na) {
+          const unsigned m = mA[p_] >> jc;
+#pragma unroll
+          for (int jj = 0; jj < NPL_J; ++jj) {
+            if (jj < jn && ((m >> jj) & 1u)) {
+              const NplRec a = staged ? arec[(rowbase + p_) * NPL_J + jj] : se3d_npl_arec(Fv, skp[(size_t)(ab.x * P + p_) * SE3D_NKP + jc + jj]);
+              const float n1 = fabsf(bx[jj] * a.lx + (by[jj] * a.ly + a.lz));
+              const float n2 = fabsf(a.px * l2x[jj] + (a.py * l2y[jj] + l2z[jj]));
+              const float d = se3d_line_dist(n1, a.lx, a.ly, a.r, a.inv) + se3d_line_dist(n2, l2x[jj], l2y[jj], r2[jj], inv2[jj]);
+              acc[p_] += (double)d;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();   // the records of this chunk are dead: the next chunk overwrites them
+    }
+    if (have) {
+#pragma unroll
+      for (int p_ = 0; p_ < NPL_PMAX; ++p_) {
+        if (p_ < na) {
+          const int n = __popc(mA[p_]);
+          D.pair[(((size_t)f * np + pr) * P + p_) * P + q] = n > 0 ? acc[p_] / n : -1.0;
+        }
+      }
+    }
   }
 }
 
@@ -2857,7 +3045,15 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   if (ev && (phases & 1)) (void)hipEventRecord(ev[0], st);
   if (!fused_np) hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D, 1);
   if (ev) (void)hipEventRecord(ev[1], st);
-  if (fused_np) {  // normalisation + packed pair table in one workgroup per frame, normalised points only in LDS
+  // SE3D_NP_LINES=1: the line-hoisted form (round 3).  NOT the default: measured 9.55 ms per 98 304 frames against 4.86 ms of the per-entry kernel —
+  // 1.8 x fewer instructions, but 51 KB of LDS per workgroup (3 workgroups per CU instead of 8) and, per two-joint chunk, a chain of dependent LDS
+  // round trips (row descriptor -> F -> point -> record -> barrier -> entry reads) that twelve wavefronts per CU do not hide (profiles/r3/README.md)
+  const char *e_lines = getenv("SE3D_NP_LINES");
+  if (fused_np && P <= NPL_PMAX && D.d.npairs <= NPL_NPMAX && e_lines && atoi(e_lines) == 1) {
+    const size_t lds = (size_t)4 * NPL_ROWS * NPL_J * sizeof(NplRec) + (size_t)N * P * SE3D_NKP * sizeof(float2) + (size_t)N * P * 8 + (size_t)N * 4 +
+                       (size_t)(D.d.npairs + 2) * 8 + (size_t)D.d.npairs * (8 + 36) + (size_t)4 * NPL_ROWS * 4 + 16;
+    hipLaunchKernelGGL(se3d_k_normalize_pairs_lines, dim3(B), dim3(256), lds, st, D, pair_ab);
+  } else if (fused_np) {  // normalisation + packed pair table in one workgroup per frame, normalised points only in LDS
     const size_t lds = (size_t)N * P * SE3D_NKP * sizeof(float2) + (size_t)N * P * 8 + (size_t)N * 4 + (size_t)(D.d.npairs + 1) * 4;
     hipLaunchKernelGGL(se3d_k_normalize_pairs, dim3(B), dim3(256), lds, st, D, pair_ab);
   } else if (tiled && !(e_pairs && strcmp(e_pairs, "tiled") == 0)) {  // large P: two rows x 32 columns per wavefront (default)
