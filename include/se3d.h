@@ -140,6 +140,10 @@ typedef struct se3d_ctx se3d_ctx;
 int se3d_rig_from_transforms(int32_t n_cam, const double *T_base_to_cam, float *Rt_out, float *F_out);
 
 /* --- context ------------------------------------------------------------------------------------------- */
+/* Stream semantics: a context works on its own non-blocking HIP stream (se3d_stream_handle).  One exception: with SE3D_RESERVE_CUS > 0 (or
+ * a rig of >= 128 cameras run with SE3D_PAIR_CHUNKS=0) the stream is created by hipExtStreamCreateWithCUMask, which yields a BLOCKING stream:
+ * work on the legacy null stream (plain hipMemcpy, a torch op on the default stream) then synchronises with it — keep such work out of
+ * timed regions. */
 se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d_limits *limits, int32_t device_id);
 void se3d_destroy(se3d_ctx *ctx);
 /* ctx != NULL: message of the context's last failed call.  ctx == NULL: why the last se3d_create of the calling thread returned NULL

@@ -408,8 +408,9 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
   c->device = device_id;
   if (!hip_ok(c, hipSetDevice(device_id), "hipSetDevice")) { create_error("se3d_create: %s", c->err.c_str()); delete c; return nullptr; }
   {
-    // Large rigs (>= 128 cameras): the bulk stream of the context (pair-cost kernel: millions of workgroups, 36 KB of LDS each) is kept off
-    // 32 CUs — one XCD — so that the small latency-bound launches of the camera sweep and the per-step stage 2 (high-priority stream, all
+    // Large rigs (>= 128 cameras) with the WHOLE pair table (SE3D_PAIR_CHUNKS=0; the default since round 3 is column chunks without a
+    // reservation): the bulk stream of the context (pair-cost kernel: millions of workgroups, 36 KB of LDS each) is kept off 32 CUs — the
+    // mask's bits are spread round-robin over the eight XCDs, so that is ~4 CUs of every XCD, not one XCD — so that the small latency-bound launches of the camera sweep and the per-step stage 2 (high-priority stream, all
     // CUs; a sweep workgroup wants ~100 KB of LDS for its Munkres matrix) always find a CU with room.  Measured at 256 cam x 128 p, four
     // contexts: 21.0 k -> 22.5 k skeletons/s; 24 reserved CUs lose (20.6 k).  SE3D_RESERVE_CUS=R overrides (0 = off).
     const char *er = getenv("SE3D_RESERVE_CUS");
@@ -540,7 +541,7 @@ void se3d_destroy(se3d_ctx *c) {
   if (c->h_flags2) (void)hipHostFree(c->h_flags2);
   if (c->h_preddt) (void)hipHostFree(c->h_preddt);
   if (c->h_rp_off) (void)hipHostFree(c->h_rp_off);
-  if (c->RB.dense) { (void)hipFree(c->RB.dense); (void)hipFree(c->RB.valid); (void)hipFree(c->RB.slot); (void)hipFree(c->RB.det_offset); (void)hipFree(c->RB.out); (void)hipFree(c->RB.out_src); }
+  if (c->rpb_cap > 0) { (void)hipFree(c->RB.dense); (void)hipFree(c->RB.valid); (void)hipFree(c->RB.slot); (void)hipFree(c->RB.det_offset); (void)hipFree(c->RB.out); (void)hipFree(c->RB.out_src); }   // rpb_cap > 0 <=> RB owns all six
   for (auto &sl : c->ss) {
     if (sl.h_rag) (void)hipHostFree(sl.h_rag);
     if (sl.h_off) (void)hipHostFree(sl.h_off);
@@ -1347,15 +1348,30 @@ int se3d_reproject_resident_batch(se3d_ctx *c, int32_t slot0, int32_t n_slots) {
   const size_t nt = (size_t)c->R.N * c->R.T;
   if (n_slots > c->rpb_cap) {   // batch buffers: one block of every output array per slot
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->RB.dense) { (void)hipFree(c->RB.dense); (void)hipFree(c->RB.valid); (void)hipFree(c->RB.slot); (void)hipFree(c->RB.det_offset); (void)hipFree(c->RB.out); (void)hipFree(c->RB.out_src); }
-    c->RB = c->R;
-    c->RB.dense = nullptr; c->rpb_cap = 0;
+    // the batch buffers are OWNED by RB (never aliases of the single-list buffers of c->R): free what exists, member by member
+    auto free_rb = [&]() {
+      if (c->rpb_cap > 0 || c->RB.dense) {
+        if (c->RB.dense) (void)hipFree(c->RB.dense);
+        if (c->RB.valid) (void)hipFree(c->RB.valid);
+        if (c->RB.slot) (void)hipFree(c->RB.slot);
+        if (c->RB.det_offset) (void)hipFree(c->RB.det_offset);
+        if (c->RB.out) (void)hipFree(c->RB.out);
+        if (c->RB.out_src) (void)hipFree(c->RB.out_src);
+      }
+      c->RB.dense = nullptr; c->RB.valid = nullptr; c->RB.slot = nullptr; c->RB.det_offset = nullptr; c->RB.out = nullptr; c->RB.out_src = nullptr;
+      c->rpb_cap = 0;
+    };
+    free_rb();
+    c->RB = c->R;   // cameras, sizes, pose method ...
+    c->RB.dense = nullptr; c->RB.valid = nullptr; c->RB.slot = nullptr; c->RB.det_offset = nullptr; c->RB.out = nullptr; c->RB.out_src = nullptr;   // ... but none of its buffers
     if (hipMalloc(reinterpret_cast<void **>(&c->RB.dense), sizeof(se3d_person2d) * nt * n_slots) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->RB.valid), nt * n_slots) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->RB.slot), sizeof(int32_t) * nt * n_slots) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->RB.det_offset), sizeof(int32_t) * (size_t)(c->R.N + 1) * n_slots) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->RB.out), sizeof(se3d_person2d) * nt * n_slots) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->RB.out_src), sizeof(int32_t) * nt * n_slots) != hipSuccess) {
+      (void)hipGetLastError();
+      free_rb();   // nothing half-allocated stays behind, nothing of c->R is touched
       c->err = "se3d_reproject_resident_batch: out of device memory";
       return SE3D_ERR_DEVICE;
     }

@@ -50,13 +50,16 @@ inline Se3dPairPlan se3d_pair_plan(int N, int m) {
   if (m > SE3D_PAIR_CHUNKS_MAX) m = SE3D_PAIR_CHUNKS_MAX;
   if (m > N - 1) m = N - 1;
   const long long np = (long long)N * (N - 1) / 2;
-  pl.m = m;
-  int b = 1;
+  int b = 1, cnt = 0;
   for (int j = 0; j < m; ++j) {
     while (b < N && (long long)b * (b - 1) / 2 < np * j / m) ++b;
-    if (j > 0 && b <= pl.col0[j - 1]) b = pl.col0[j - 1] + 1;   // every chunk holds at least one column
-    pl.col0[j] = b;
+    if (cnt > 0 && b <= pl.col0[cnt - 1]) b = pl.col0[cnt - 1] + 1;   // every chunk holds at least one column
+    if (b >= N) break;                                                 // no column left: fewer chunks than asked for
+    pl.col0[cnt++] = b;
   }
+  if (cnt < 2) return Se3dPairPlan();
+  m = cnt;
+  pl.m = m;
   pl.col0[0] = 1;
   pl.col0[m] = N;
   for (int j = 0; j <= m; ++j) pl.list0[j] = pl.col0[j] * (pl.col0[j] - 1) / 2;

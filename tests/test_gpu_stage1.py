@@ -386,3 +386,38 @@ def test_exact_sqrt_and_divide_cores_match_ieee_on_the_device(extr_rig):
     bad_sqrt, bad_div = node.selftest_exact_math(1 << 33)
     node.close()
     assert bad_sqrt == 0 and bad_div == 0, (bad_sqrt, bad_div)
+
+
+def test_pair_table_column_chunks_equal_the_whole_table(monkeypatch, oracle, demo_params):
+    """Large rigs keep the pair table as camera-column chunks (Se3dPairPlan): the pair kernel fills chunk j while the sweep walks chunk j - 1.
+    A 48-camera, 24-person scene (per-camera sweep launches, 8 chunks by default) through the whole table (SE3D_PAIR_CHUNKS=0), the default,
+    3 and 32 chunks and with the Munkres matrix in LDS: hypotheses, association tables and published persons byte-equal, and equal to the
+    oracle; a pair-table block fetched in chunk mode (recomputed on demand) equals the whole-table block bit for bit."""
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
+    rig = R.elliptical_rig(48, seed=6)
+    rig.set_tensors(*rig_tensors(rig))
+    frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=24, n_frames=3, seed=19, pixel_noise=3.0, p_miss=0.08, spacing=0.8, min_coverage=6))
+    res, blocks = {}, {}
+    for name, env in (("whole", {"SE3D_PAIR_CHUNKS": "0"}), ("default", {}), ("c3", {"SE3D_PAIR_CHUNKS": "3"}), ("c32", {"SE3D_PAIR_CHUNKS": "32"}),
+                      ("lds", {"SE3D_SWEEP_LDS_KB": "128"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        node = _node(rig, max_frames=3, max_det_per_cam=32, max_hyp=80)
+        res[name] = node.triangulate_persons(frames)
+        if name in ("whole", "default"):
+            blocks[name] = [_pair_costs(node, 1, a, b) for (a, b) in ((0, 1), (3, 40), (46, 47), (10, 11))]
+        node.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    for (ta, na, nb), (tb, na2, nb2) in zip(blocks["whole"], blocks["default"]):
+        assert (na, nb) == (na2, nb2) and na > 0 and nb > 0
+        assert np.array_equal(ta[:na, :nb], tb[:na, :nb])
+    for fi, a in enumerate(res["whole"]):
+        assert a.n_hyp > 24 * 0.8
+        for name in ("default", "c3", "c32", "lds"):
+            b = res[name][fi]
+            assert a.n_hyp == b.n_hyp and a.n_persons == b.n_persons and a.flags == b.flags, name
+            assert np.array_equal(a.assoc(), b.assoc()), name
+            assert a.published().tobytes() == b.published().tobytes(), name
+        o = oracle.triangulate(rig, demo_params, frames[fi], capacity=80, hyp_capacity=80)
+        compare_stage1(res["default"][fi], o)
