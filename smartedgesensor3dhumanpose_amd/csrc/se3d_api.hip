@@ -122,6 +122,7 @@ struct se3d_ctx {
   bool rp_ready = false;
   Se3dReproj RB{};          // batch buffers of se3d_reproject_resident_batch (one block of every output array per result slot)
   int rpb_cap = 0, rpb_slot0 = 0, rpb_n = 0;
+  bool rpb_lists = false;   // the batch buffers were sized for the one-kernel form (no dense intermediate)
 };
 
 namespace {
@@ -1346,7 +1347,8 @@ int se3d_reproject_resident_batch(se3d_ctx *c, int32_t slot0, int32_t n_slots) {
   if (!c->ran2) { c->err = "se3d_reproject_resident_batch: no stage-2 result"; return SE3D_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nt = (size_t)c->R.N * c->R.T;
-  if (n_slots > c->rpb_cap) {   // batch buffers: one block of every output array per slot
+  const bool want_lists = se3d_reproj_lists_lds(c->R.N, c->R.T) > 0;
+  if (n_slots > c->rpb_cap || want_lists != c->rpb_lists) {   // batch buffers: one block of every output array per slot
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // the batch buffers are OWNED by RB (never aliases of the single-list buffers of c->R): free what exists, member by member
     auto free_rb = [&]() {
@@ -1364,9 +1366,10 @@ int se3d_reproject_resident_batch(se3d_ctx *c, int32_t slot0, int32_t n_slots) {
     free_rb();
     c->RB = c->R;   // cameras, sizes, pose method ...
     c->RB.dense = nullptr; c->RB.valid = nullptr; c->RB.slot = nullptr; c->RB.det_offset = nullptr; c->RB.out = nullptr; c->RB.out_src = nullptr;   // ... but none of its buffers
-    if (hipMalloc(reinterpret_cast<void **>(&c->RB.dense), sizeof(se3d_person2d) * nt * n_slots) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&c->RB.valid), nt * n_slots) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&c->RB.slot), sizeof(int32_t) * nt * n_slots) != hipSuccess ||
+    const size_t ni = want_lists ? 1 : nt * n_slots;   // the one-kernel form has no dense intermediate (1.3 GB per 16 384 slots at 16 x 12)
+    if (hipMalloc(reinterpret_cast<void **>(&c->RB.dense), sizeof(se3d_person2d) * ni) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->RB.valid), ni) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->RB.slot), sizeof(int32_t) * ni) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->RB.det_offset), sizeof(int32_t) * (size_t)(c->R.N + 1) * n_slots) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->RB.out), sizeof(se3d_person2d) * nt * n_slots) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->RB.out_src), sizeof(int32_t) * nt * n_slots) != hipSuccess) {
@@ -1376,6 +1379,7 @@ int se3d_reproject_resident_batch(se3d_ctx *c, int32_t slot0, int32_t n_slots) {
       return SE3D_ERR_DEVICE;
     }
     c->rpb_cap = n_slots;
+    c->rpb_lists = want_lists;
   }
   Se3dReproj R = c->RB;
   R.cam = c->R.cam; R.wh = c->R.wh; R.N = c->R.N; R.T = c->R.T; R.pose_method = c->R.pose_method;

@@ -231,3 +231,4 @@ struct Se3dReproj {
   int32_t *out_src;           // [N*T] input person index of each output entry
 };
 hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t stream, int batch = 1);
+size_t se3d_reproj_lists_lds(int N, int T);   // > 0: small rig, the one-kernel form runs and dense / valid / slot are not touched

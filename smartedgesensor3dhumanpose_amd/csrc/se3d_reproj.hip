@@ -5,6 +5,8 @@
 // mean / 2x2 covariance (REPROJ:178-205).  Validity count and bounding box (REPROJ:207-223) are half-wave shuffle reductions.
 // The ordered per-camera person lists (REPROJ:226-233) are built by a flag scan (se3d_k_reproj_scan) and a 428-byte gather
 // (se3d_k_reproj_compact).  Everything is fp64 like the node; no FMA contraction (-ffp-contract=off).
+#include <cstdlib>
+
 #include "se3d_device.h"
 
 namespace {
@@ -17,45 +19,17 @@ __device__ __forceinline__ Se3dReproj se3d_reproj_slot(Se3dReproj R, int b) {
   const size_t nt = (size_t)R.N * R.T;
   R.in += (size_t)b * R.in_stride;
   if (R.n_dev) R.n_dev += b;
-  R.dense += b * nt; R.valid += b * nt; R.slot += b * nt; R.out += b * nt; R.out_src += b * nt;
+  if (R.dense) { R.dense += b * nt; R.valid += b * nt; R.slot += b * nt; }   // (the one-kernel form below has no dense intermediate)
+  R.out += b * nt; R.out_src += b * nt;
   R.det_offset += (size_t)b * (R.N + 1);
   return R;
 }
 
-__global__ __launch_bounds__(256) void se3d_k_reproject(Se3dReproj Rb) {
-  const Se3dReproj R = se3d_reproj_slot(Rb, blockIdx.z);
-  const int lane = threadIdx.x & 31;
-  const int cam = blockIdx.x * kCamsPerBlock + (threadIdx.x >> 5);
-  const int person = blockIdx.y;
-  const int n = R.n_dev ? *R.n_dev : R.n;
-  if (person >= n) return;   // block-uniform
-  // The sigma points of a joint depend on the person only (REPROJ:62-75: cov.llt(), +- sqrt(3 + kappa) L columns): the first half-wave draws them
-  // once per block into LDS and the eight (person, camera) half-waves of the block project them — round 1 redid the 3x3 Cholesky
-  // (3 square roots, 3 divisions in fp64) for every camera.
-  __shared__ double s_X[SE3D_NKP][7][3];
-  __shared__ float s_score[SE3D_NKP];
-  if (threadIdx.x < SE3D_NKP) {
-    const se3d_keypoint3d &kp = R.in[person].keypoints[c_kp2fusion[R.pose_method][threadIdx.x]];
-    s_score[threadIdx.x] = kp.score;
-    if (kp.score > 0.f) {  // REPROJ:167-168
-      // cov.llt().matrixL() (REPROJ:70)
-      const double c00 = kp.cov[0], c10 = kp.cov[1], c20 = kp.cov[2], c11 = kp.cov[3], c21 = kp.cov[4], c22 = kp.cov[5];
-      const double l00 = sqrt(c00);
-      const double l10 = c10 / l00, l20 = c20 / l00;
-      const double l11 = sqrt(c11 - l10 * l10);
-      const double l21 = (c21 - l20 * l10) / l11;
-      const double l22 = sqrt(c22 - l20 * l20 - l21 * l21);
-      const double L[3][3] = {{l00, 0., 0.}, {l10, l11, 0.}, {l20, l21, l22}};
-      const double b = sqrt(3.0 + 0.5);   // kappa = 0.5
-#pragma unroll
-      for (int s = 0; s < 7; ++s)
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-          s_X[threadIdx.x][s][a] = s == 0 ? kp.joint[a] : (s < 4 ? L[a][s - 1] * (-b) + kp.joint[a] : L[a][s - 4] * b + kp.joint[a]);
-    }
-  }
-  __syncthreads();
-  if (cam >= R.N) return;
+// One (person, camera) on a 32-lane half-wave: lane j < 17 projects the 7 sigma points of model joint j (s_X / s_score: drawn once per person),
+// weighted mean / 2x2 covariance, in-image gate; count and bounding box by half-wave shuffles.  Returns what lane j publishes for its joint
+// and (every lane) the person's count and box.
+struct ReprojLane { bool valid; double mx, my, cxx, cxy, cyy; float score; int cnt; double mnx, mny, mxx, mxy; };
+__device__ __forceinline__ ReprojLane se3d_reproj_person_cam(const Se3dReproj &R, int cam, int lane, const double (*s_X)[7][3], const float *s_score) {
   const int W = R.wh[2 * cam], Hh = R.wh[2 * cam + 1];
   bool valid = false;
   double mx = 0., my = 0., cxx = 0., cxy = 0., cyy = 0.;
@@ -103,20 +77,122 @@ __global__ __launch_bounds__(256) void se3d_k_reproject(Se3dReproj Rb) {
     mxx = fmax(mxx, __shfl_xor(mxx, o, 32));
     mxy = fmax(mxy, __shfl_xor(mxy, o, 32));
   }
-  se3d_person2d &o = R.dense[(size_t)cam * R.T + person];
+  ReprojLane out;
+  out.valid = valid; out.mx = mx; out.my = my; out.cxx = cxx; out.cxy = cxy; out.cyy = cyy; out.score = score; out.cnt = cnt;
+  out.mnx = mnx; out.mny = mny; out.mxx = mxx; out.mxy = mxy;
+  return out;
+}
+
+// the 7 sigma points of one joint (REPROJ:62-75: cov.llt(), +- sqrt(3 + kappa) L columns) and its score
+__device__ __forceinline__ void se3d_reproj_sigma(const se3d_keypoint3d &kp, double (*X)[3], float &score) {
+  score = kp.score;
+  if (kp.score > 0.f) {  // REPROJ:167-168
+    const double c00 = kp.cov[0], c10 = kp.cov[1], c20 = kp.cov[2], c11 = kp.cov[3], c21 = kp.cov[4], c22 = kp.cov[5];
+    const double l00 = sqrt(c00);
+    const double l10 = c10 / l00, l20 = c20 / l00;
+    const double l11 = sqrt(c11 - l10 * l10);
+    const double l21 = (c21 - l20 * l10) / l11;
+    const double l22 = sqrt(c22 - l20 * l20 - l21 * l21);
+    const double L[3][3] = {{l00, 0., 0.}, {l10, l11, 0.}, {l20, l21, l22}};
+    const double b = sqrt(3.0 + 0.5);   // kappa = 0.5
+#pragma unroll
+    for (int s_ = 0; s_ < 7; ++s_)
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        X[s_][a] = s_ == 0 ? kp.joint[a] : (s_ < 4 ? L[a][s_ - 1] * (-b) + kp.joint[a] : L[a][s_ - 4] * b + kp.joint[a]);
+  }
+}
+__device__ __forceinline__ void se3d_reproj_store(se3d_person2d &o, const ReprojLane &r, int lane) {
   if (lane < SE3D_NKP) {
     se3d_keypoint2d k;
-    if (valid) {
-      k.x = (float)mx; k.y = (float)my; k.score = score;
-      k.cov[0] = (float)cxx; k.cov[1] = (float)cxy; k.cov[2] = (float)cyy;
+    if (r.valid) {
+      k.x = (float)r.mx; k.y = (float)r.my; k.score = r.score;
+      k.cov[0] = (float)r.cxx; k.cov[1] = (float)r.cxy; k.cov[2] = (float)r.cyy;
     } else {
       k.x = k.y = k.score = 0.f; k.cov[0] = k.cov[1] = k.cov[2] = 0.f;
     }
     o.keypoints[lane] = k;
   } else if (lane == SE3D_NKP) {
     o.score = 1.0f;  // REPROJ:154
-    o.bbox[0] = (float)mnx; o.bbox[1] = (float)mny; o.bbox[2] = (float)mxx; o.bbox[3] = (float)mxy;
-    R.valid[(size_t)person * R.N + cam] = cnt > 0 ? 1 : 0;
+    o.bbox[0] = (float)r.mnx; o.bbox[1] = (float)r.mny; o.bbox[2] = (float)r.mxx; o.bbox[3] = (float)r.mxy;
+  }
+}
+
+__global__ __launch_bounds__(256) void se3d_k_reproject(Se3dReproj Rb) {
+  const Se3dReproj R = se3d_reproj_slot(Rb, blockIdx.z);
+  const int lane = threadIdx.x & 31;
+  const int cam = blockIdx.x * kCamsPerBlock + (threadIdx.x >> 5);
+  const int person = blockIdx.y;
+  const int n = R.n_dev ? *R.n_dev : R.n;
+  if (person >= n) return;   // block-uniform
+  // The sigma points of a joint depend on the person only: the first half-wave draws them once per block into LDS and the eight (person,
+  // camera) half-waves of the block project them — round 1 redid the 3x3 Cholesky (3 square roots, 3 divisions in fp64) for every camera.
+  __shared__ double s_X[SE3D_NKP][7][3];
+  __shared__ float s_score[SE3D_NKP];
+  if (threadIdx.x < SE3D_NKP) se3d_reproj_sigma(R.in[person].keypoints[c_kp2fusion[R.pose_method][threadIdx.x]], s_X[threadIdx.x], s_score[threadIdx.x]);
+  __syncthreads();
+  if (cam >= R.N) return;
+  const ReprojLane r = se3d_reproj_person_cam(R, cam, lane, s_X, s_score);
+  se3d_reproj_store(R.dense[(size_t)cam * R.T + person], r, lane);
+  if (lane == SE3D_NKP) R.valid[(size_t)person * R.N + cam] = r.cnt > 0 ? 1 : 0;
+}
+
+// Small rigs (round 3): ONE workgroup per result slot does everything — no dense [N][T] intermediate in HBM (707 MB written and 242 MB read
+// back per 16 384-slot launch at 16 cameras), no scan and compaction launches.  1024 threads = 32 half-waves = 32 / N persons x N cameras per
+// trip; the projected persons of the slot wait in LDS ([n][N] x 428 B) until all are done, then the per-camera counts are scanned by one
+// wavefront and a wavefront per (person, camera) pair copies the valid ones to their list slots (camera-major, person order: REPROJ:226-233).
+// Same arithmetic as se3d_k_reproject (shared device functions) -> identical lists.
+__global__ __launch_bounds__(1024) void se3d_k_reproject_lists(Se3dReproj Rb) {
+  const Se3dReproj R = se3d_reproj_slot(Rb, blockIdx.z);
+  extern __shared__ __align__(16) unsigned char rl_smem[];
+  const int N = R.N, T = R.T;
+  se3d_person2d *res = reinterpret_cast<se3d_person2d *>(rl_smem);                    // [T][N]
+  double (*s_X)[SE3D_NKP][7][3] = reinterpret_cast<double (*)[SE3D_NKP][7][3]>(rl_smem + ((sizeof(se3d_person2d) * (size_t)T * N + 15) & ~(size_t)15));   // [ppr][17][7][3]
+  const int ppr = 32 / N;                                                             // persons per trip
+  float (*s_score)[SE3D_NKP] = reinterpret_cast<float (*)[SE3D_NKP]>(reinterpret_cast<unsigned char *>(s_X) + sizeof(double) * (size_t)ppr * SE3D_NKP * 21);
+  unsigned char *s_valid = reinterpret_cast<unsigned char *>(s_score) + sizeof(float) * (size_t)ppr * SE3D_NKP;   // [T][N]
+  __shared__ int s_off[64];
+  const int tid = threadIdx.x, lane = tid & 31, hw = tid >> 5;
+  const int n = min(R.n_dev ? *R.n_dev : R.n, T);
+  const int pi = hw / N, cam = hw - pi * N;
+  for (int p0 = 0; p0 < n; p0 += ppr) {
+    if (tid < ppr * SE3D_NKP) {
+      const int pp = tid / SE3D_NKP, j = tid - pp * SE3D_NKP;
+      if (p0 + pp < n) se3d_reproj_sigma(R.in[p0 + pp].keypoints[c_kp2fusion[R.pose_method][j]], s_X[pp][j], s_score[pp][j]);
+    }
+    __syncthreads();
+    const int person = p0 + pi;
+    if (pi < ppr && person < n) {
+      const ReprojLane r = se3d_reproj_person_cam(R, cam, lane, s_X[pi], s_score[pi]);
+      se3d_reproj_store(res[(size_t)person * N + cam], r, lane);
+      if (lane == SE3D_NKP) s_valid[person * N + cam] = r.cnt > 0 ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (tid < 64) {   // per-camera counts -> exclusive offsets (N <= 32)
+    int cnt = 0;
+    if (tid < N)
+      for (int p = 0; p < n; ++p) cnt += s_valid[p * N + tid];
+    int inc = cnt;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (tid >= o) inc += t; }
+    s_off[tid] = inc - cnt;
+    if (tid < N) R.det_offset[tid + 1] = inc;
+    if (tid == 0) R.det_offset[0] = 0;
+  }
+  __syncthreads();
+  constexpr int kWords = sizeof(se3d_person2d) / 4;
+  const int l64 = tid & 63, wave = tid >> 6;
+  for (int pair = wave; pair < n * N; pair += 16) {
+    const int person = pair / N, c = pair - person * N;
+    if (!s_valid[pair]) continue;
+    int rank = 0;
+    for (int p = 0; p < person; ++p) rank += s_valid[p * N + c];
+    const int slot = s_off[c] + rank;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&res[pair]);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&R.out[slot]);
+    dst[l64] = src[l64];
+    if (l64 + 64 < kWords) dst[l64 + 64] = src[l64 + 64];
+    if (l64 == 0) R.out_src[slot] = person;
   }
 }
 
@@ -172,9 +248,28 @@ __global__ __launch_bounds__(256) void se3d_k_reproj_compact(Se3dReproj Rb) {
 
 }  // namespace
 
+// dynamic LDS of the one-kernel form for a rig of N cameras and T person slots, 0 when the three-kernel form is used
+size_t se3d_reproj_lists_lds(int N, int T) {
+  if (N > 32 || getenv("SE3D_REPROJ_DENSE")) return 0;
+  const size_t b = ((sizeof(se3d_person2d) * (size_t)T * N + 15) & ~(size_t)15) + (size_t)(32 / N) * SE3D_NKP * (21 * sizeof(double) + sizeof(float)) + (size_t)T * N + 16;
+  return b <= 96 * 1024 ? b : 0;
+}
+
 hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t stream, int batch) {
   if (n_grid <= 0 || batch <= 0) {
     return hipMemsetAsync(R.det_offset, 0, sizeof(int32_t) * (R.N + 1) * (size_t)(batch > 0 ? batch : 1), stream);
+  }
+  // small rigs: one workgroup per result slot, lists written directly (SE3D_REPROJ_DENSE=1: the three-kernel form, A/B)
+  const size_t lds_lists = se3d_reproj_lists_lds(R.N, R.T);
+  if (lds_lists > 0) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_reproject_lists), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(se3d_k_reproject_lists, dim3(1, 1, batch), dim3(1024), lds_lists, stream, R);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL(se3d_k_reproject, dim3((R.N + kCamsPerBlock - 1) / kCamsPerBlock, n_grid, batch), dim3(256), 0, stream, R);
   hipLaunchKernelGGL(se3d_k_reproj_scan, dim3(1, 1, batch), dim3(256), 0, stream, R);

@@ -7,7 +7,7 @@ import sys
 
 src, key = sys.argv[1], sys.argv[2]
 lines = open(src).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and l.rstrip().endswith(":") or (l.startswith("_Z") and key in l and ": " in l and l.split(":")[0].endswith("i") and not l.startswith("\t")))
+start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and key in l.split(":")[0])
 end = next(i for i in range(start, len(lines)) if lines[i].startswith("\t.end_amdhsa_kernel") or lines[i].startswith(".Lfunc_end"))
 body = lines[start:end]
 labels = {}
