@@ -36,3 +36,18 @@ def test_bench_config2_line():
     assert p.returncode == 0, p.stderr[-3000:]
     line = _json_line(p.stdout)
     assert line["value"] > 0 and line["latency_B1"]["device_ms"] > 0 and "config 2" in line["config"]["workload"]
+
+
+def test_bench_parity_and_latency_blocks():
+    """The untimed blocks of the default driver line (round 3): MPJPE / association exactness against the oracle on the bench's own scenes, and
+    the one-frame-per-call latency of se3d_triangulate + se3d_refine."""
+    sys.path.insert(0, ROOT)
+    import bench
+    w = bench.WORKLOADS["16cam6p"]
+    rig = bench.make_rig(w)
+    seqs = bench.make_sequences(None, w, 1, 2, 0, 16)[0]
+    p = bench.bench_parity("16cam6p", rig, seqs, 2)
+    assert p["frames"] == 32 and p["assoc_exact_rate"] == 1.0 and p["track_ids_exact_rate"] == 1.0 and p["lm_iterations_equal_rate"] == 1.0
+    assert p["mpjpe_max_mm"] < 1.0 and p["refined_max_mm"] < 1.0 and p["refined_skeletons"] > 0
+    lat = bench.bench_latency_b1(rig, seqs[0], "16cam6p", frames_timed=30)
+    assert 0 < lat["device_ms"]["frame"] < lat["host_call_ms"]["frame"] < 50 and lat["refined_skeletons_per_frame"] > 0
