@@ -31,16 +31,21 @@ def new_report(seed):
                 excluded_stage2_mismatches=0, violations=[])
 
 
-def run_trials(O, seed, trials, walk_mode="wave"):
-    """O: the oracle module (tests' fixture / oracle_py).  Index mismatches of stage 1 raise at once; everything else is tallied."""
+def run_trials(O, seed, trials, walk_mode="wave", pose_method="simple", norm_height=False):
+    """O: the oracle module (tests' fixture / oracle_py).  Index mismatches of stage 1 raise at once; everything else is tallied.
+    pose_method / norm_height: the nodes' ROS parameters (S3D:1095, PP:930-931) — "h36m" keypoint set, height-normalised LM."""
     rng = np.random.default_rng(seed)
     rep = new_report(seed)
-    k2f = np.array(pm.KP2FUSION_SIMPLE)
-    tables = O.pose_tables(pm.POSE_SIMPLE)
+    rep["pose_method"], rep["norm_height"] = pose_method, bool(norm_height)
+    tables = O.pose_tables(pm.POSE_H36M if pose_method == "h36m" else pm.POSE_SIMPLE)
+    k2f = np.array(tables["kp2fusion"])
+    if pose_method == "h36m":
+        tables = dict(tables, shoulderDist=0.0)   # the shoulder special case exists in the "simple" model only (S3D:875)
     for trial in range(trials):
         rig, persons, seqs, extra = draw_trial(rng)
         frames = [seqs[s][k] for k in range(T_STEPS) for s in range(N_SEQ)]
-        node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=N_SEQ * T_STEPS, max_det_per_cam=12, max_hyp=MAX_HYP, device=0)
+        node = Skeleton3D(rig, pose_method=pose_method, norm_height=norm_height, max_epi_dist=0.045, max_frames=N_SEQ * T_STEPS, max_det_per_cam=12,
+                          max_hyp=MAX_HYP, device=0)
         params = node.params
         node.stage(frames)
         node.run_stage1()
@@ -63,7 +68,7 @@ def run_trials(O, seed, trials, walk_mode="wave"):
             gk, ok = g.published()["keypoints"][:, k2f], o.published()["keypoints"][:, k2f]     # the 17 triangulated joints, input order
             v = ok["score"] > 0
             assert np.array_equal(gk["score"] > 0, v), ("valid joints", seed, trial, fi)
-            kappa = published_joint_condition(rig, fr, g)
+            kappa = published_joint_condition(rig, fr, g, k2f)
             assert not np.isnan(kappa[v]).any(), ("published joint with fewer than two usable views", seed, trial, fi)
             inside = v & (kappa < DLT_KAPPA_MAX)
             outside = v & ~inside

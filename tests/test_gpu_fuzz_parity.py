@@ -17,9 +17,12 @@ SEEDS = [4, 15, 37, 39, 0, 1, 2, 3]
 TRIALS = 40   # 40 scenes x 3 sequences x 12 frames per seed: ~1 440 frames, ~110 k joints, ~1 430 sequence-steps
 
 
-@pytest.mark.parametrize("seed", SEEDS)
-def test_random_scenes_match_the_oracle_outside_the_ill_conditioned_set(oracle, seed):
-    rep = run_trials(oracle, seed, TRIALS)
+VARIANTS = [(s, "simple", False) for s in SEEDS] + [(5, "h36m", False), (6, "simple", True), (7, "h36m", True)]   # the nodes' other configurations
+
+
+@pytest.mark.parametrize("seed,pose_method,norm_height", VARIANTS)
+def test_random_scenes_match_the_oracle_outside_the_ill_conditioned_set(oracle, seed, pose_method, norm_height):
+    rep = run_trials(oracle, seed, TRIALS, pose_method=pose_method, norm_height=norm_height)
     viol = rep.pop("violations")
     print(json.dumps(rep))
     assert rep["frames"] == TRIALS * 36 and rep["joints"] > 50_000
