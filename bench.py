@@ -908,8 +908,11 @@ def main():
                                     % (sec_serial["S"], sec_serial["T"], sec_serial["value"]))
                 tr2 = load("pmc_traffic_256cam128p_1ctx.json")   # committed PMC passes of `bench.py --workload 256cam128p --contexts 1`
                 if tr2:
-                    roof2["traffic"] = tr2["kernels"].get(roof2["kernel"], {}).get("hbm_bytes_per_launch_corrected")
-                    roof2["traffic_source"] = tr2["_file"]
+                    per_launch = tr2["kernels"].get(roof2["kernel"], {}).get("hbm_bytes_per_launch_corrected")
+                    # column chunks: the "launch" the HIP events bracket is the pass's whole pair phase = one kernel launch per chunk (16 from 128 cameras)
+                    n_launch = (16 if WORKLOADS["256cam128p"]["n_cam"] >= 128 else 8) if roof2["kernel"] == "epipolar_pairs" and not os.environ.get("SE3D_PAIR_CHUNKS") else 1
+                    roof2["traffic"] = per_launch * n_launch if per_launch is not None else None
+                    roof2["traffic_source"] = "%s: %s bytes per kernel launch x %d launches per pass" % (tr2["_file"], per_launch, n_launch)
             else:
                 roof2 = roofline_of(sec, WORKLOADS["256cam128p"], True, "overlapped contexts (%d per GPU)" % sec["NC"])
             roof2["valu"] = valu_of(sec, WORKLOADS["256cam128p"], True, load("pmc_sq_256cam128p_1ctx.json"))
