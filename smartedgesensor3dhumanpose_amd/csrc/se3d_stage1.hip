@@ -551,6 +551,109 @@ __global__ __launch_bounds__(256) void se3d_k_normalize_pairs_lines(Se3dDev D, c
   }
 }
 
+// ---- the same table with TR x TC register tiles of entries per lane (round 3) ---------------------------------------------------------------
+// The per-entry kernel rebuilds both epipolar lines, their norms' square roots and the reciprocals for every (entry, joint): ~54 of its ~81
+// instructions.  A lane that owns a TR x TC block of entries of one camera pair builds TR + TC lines per joint instead of 2 TR TC and needs no
+// LDS beyond the points: (TR + TC) / (TR TC) x 27 + 27 instructions per (entry, joint) — 54 at 2 x 2 — at the price of padding when n_a, n_b are
+// not multiples of the tile.  Same float operations in the same order as se3d_pair_cost_lds (the shared reciprocal is the first three operations
+// of se3d_div_core, see se3d_line_ops / se3d_line_dist) -> bit-identical table.
+template <int TR, int TC>
+__global__ __launch_bounds__(256) void se3d_k_normalize_pairs_tiles(Se3dDev D, const int2 *__restrict__ pair_ab) {
+  extern __shared__ __align__(16) unsigned char np_smem[];
+  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float2 *skp = reinterpret_cast<float2 *>(np_smem);                       // [N * P][17] filtered slot order
+  unsigned *s_mgt = reinterpret_cast<unsigned *>(skp + (size_t)N * P * SE3D_NKP);  // [N * P] by filtered slot
+  int *s_slot = reinterpret_cast<int *>(s_mgt + N * P);                    // [N * P]
+  int *s_nv = s_slot + N * P;                                              // [N]
+  int *s_cum = s_nv + N;                                                   // [np + 1] tiles before pair pr
+  __shared__ int s_part[4];
+  se3d_np_prologue(D, f, tid, skp, s_mgt, s_slot, s_nv);
+  int carry = 0;
+  for (int base = 0; base < np; base += 256) {   // exclusive prefix of ceil(n_a / TR) * ceil(n_b / TC) over the camera pairs
+    const int pr = base + tid;
+    int v = 0;
+    if (pr < np) { const int2 ab = pair_ab[pr]; v = ((s_nv[ab.x] + TR - 1) / TR) * ((s_nv[ab.y] + TC - 1) / TC); }
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_part[wave] = inc;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wave; ++w) off += s_part[w];
+    if (pr < np) s_cum[pr] = off + inc - v;
+    carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+  }
+  if (tid == 0) s_cum[np] = carry;
+  __syncthreads();
+  const int total = s_cum[np];
+  for (int e = tid; e < total; e += 256) {
+    int lo = 0, hi = np;  // largest pr with s_cum[pr] <= e
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cum[mid] <= e) lo = mid; else hi = mid; }
+    const int pr = lo;
+    const int2 ab = pair_ab[pr];
+    const int na = s_nv[ab.x], nb = s_nv[ab.y];
+    const int tcn = (nb + TC - 1) / TC;
+    const int r = e - s_cum[pr];
+    const int p0 = (r / tcn) * TR, q0 = (r - (r / tcn) * tcn) * TC;
+    const float *F = D.F + 9 * (size_t)pr;
+    const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
+    unsigned ma[TR], mb[TC], many = 0u;
+    const float2 *ka[TR], *kb[TC];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) { const int p = min(p0 + i, na - 1); ma[i] = (p0 + i < na) ? s_mgt[ab.x * P + p] : 0u; ka[i] = skp + (size_t)(ab.x * P + p) * SE3D_NKP; }
+#pragma unroll
+    for (int k = 0; k < TC; ++k) { const int q = min(q0 + k, nb - 1); mb[k] = (q0 + k < nb) ? s_mgt[ab.y * P + q] : 0u; kb[k] = skp + (size_t)(ab.y * P + q) * SE3D_NKP; }
+    double acc[TR][TC];
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int k = 0; k < TC; ++k) { acc[i][k] = 0.0; many |= ma[i] & mb[k]; }
+#pragma unroll
+    for (int j = 0; j < SE3D_NKP; ++j) {
+      if ((many >> j) & 1u) {
+        float ax[TR], ay[TR], l1x[TR], l1y[TR], l1z[TR], r1[TR], i1[TR];
+        float bx[TC], by[TC], l2x[TC], l2y[TC], l2z[TC], r2[TC], i2[TC];
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+          const float2 pt = ka[i][j];
+          ax[i] = pt.x; ay[i] = pt.y;
+          l1x[i] = f0 * pt.x + (f1 * pt.y + f2);
+          l1y[i] = f3 * pt.x + (f4 * pt.y + f5);
+          l1z[i] = f6 * pt.x + (f7 * pt.y + f8);
+          se3d_line_ops(l1x[i], l1y[i], r1[i], i1[i]);
+        }
+#pragma unroll
+        for (int k = 0; k < TC; ++k) {
+          const float2 pt = kb[k][j];
+          bx[k] = pt.x; by[k] = pt.y;
+          l2x[k] = f0 * pt.x + (f3 * pt.y + f6);
+          l2y[k] = f1 * pt.x + (f4 * pt.y + f7);
+          l2z[k] = f2 * pt.x + (f5 * pt.y + f8);
+          se3d_line_ops(l2x[k], l2y[k], r2[k], i2[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < TR; ++i)
+#pragma unroll
+          for (int k = 0; k < TC; ++k) {
+            const float n1 = fabsf(bx[k] * l1x[i] + (by[k] * l1y[i] + l1z[i]));
+            const float n2 = fabsf(ax[i] * l2x[k] + (ay[i] * l2y[k] + l2z[k]));
+            const float d = se3d_line_dist(n1, l1x[i], l1y[i], r1[i], i1[i]) + se3d_line_dist(n2, l2x[k], l2y[k], r2[k], i2[k]);
+            acc[i][k] += ((ma[i] & mb[k]) >> j) & 1u ? (double)d : 0.0;
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int k = 0; k < TC; ++k)
+        if (p0 + i < na && q0 + k < nb) {
+          const int n = __popc(ma[i] & mb[k]);
+          D.pair[(((size_t)f * np + pr) * P + p0 + i) * P + q0 + k] = n > 0 ? acc[i][k] / n : -1.0;
+        }
+  }
+}
+
 // tiled variant for large P: one workgroup per (64x64 tile of det_a x det_b, camera pair, frame).
 // The epipolar line of a point depends on one side only, so l1 = F p1 (+ its norm) is computed once per (det_a, joint)
 // and l2 = F^T p2 once per (det_b, joint) and staged in LDS; the inner loop is 2 dot products, 2 IEEE divides and one
@@ -3055,7 +3158,12 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     hipLaunchKernelGGL(se3d_k_normalize_pairs_lines, dim3(B), dim3(256), lds, st, D, pair_ab);
   } else if (fused_np) {  // normalisation + packed pair table in one workgroup per frame, normalised points only in LDS
     const size_t lds = (size_t)N * P * SE3D_NKP * sizeof(float2) + (size_t)N * P * 8 + (size_t)N * 4 + (size_t)(D.d.npairs + 1) * 4;
-    hipLaunchKernelGGL(se3d_k_normalize_pairs, dim3(B), dim3(256), lds, st, D, pair_ab);
+    // SE3D_NP_TILE=22: 2 x 2 entries per lane (register tile; A/B evidence).  Measured per 98 304 frames (bench scenes: ~4 detections per camera):
+    // 1 x 1 (this kernel's default) 4.83 ms, 1 x 2 4.93, 2 x 2 4.78, 2 x 3 5.25, 3 x 3 6.07 — padding of the ragged n_a x n_b blocks and the
+    // registers (72 / 90 / 127 VGPRs) eat what the shared lines save (profiles/r3/README.md)
+    const char *e_tile = getenv("SE3D_NP_TILE");
+    if (e_tile && atoi(e_tile) == 22) hipLaunchKernelGGL((se3d_k_normalize_pairs_tiles<2, 2>), dim3(B), dim3(256), lds, st, D, pair_ab);
+    else hipLaunchKernelGGL(se3d_k_normalize_pairs, dim3(B), dim3(256), lds, st, D, pair_ab);
   } else if (tiled && !(e_pairs && strcmp(e_pairs, "tiled") == 0)) {  // large P: two rows x 32 columns per wavefront (default)
     hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((P + RB_ROWS - 1) / RB_ROWS, D.d.npairs, B), dim3(256), 0, st, D, pair_ab, 0, 0, 0);
   } else if (tiled) {                                                  // SE3D_PAIRS=tiled: the 4x4 register-tile kernel (A/B)

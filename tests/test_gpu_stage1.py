@@ -181,12 +181,14 @@ def _pair_costs(node, frame_idx, a, b):
     return out, na.value, nb.value
 
 
-@pytest.mark.parametrize("mode", ["flat", "tiled", "rows", "fused", "lines"])
+@pytest.mark.parametrize("mode", ["flat", "tiled", "rows", "fused", "lines", "tile22"])
 def test_pair_cost_table_is_bit_exact(extr_rig, oracle, demo_params, mode, monkeypatch):
-    if mode in ("fused", "lines"):
+    if mode in ("fused", "lines") or mode.startswith("tile"):
         monkeypatch.delenv("SE3D_PAIRS", raising=False)
         if mode == "lines":
             monkeypatch.setenv("SE3D_NP_LINES", "1")   # the line-hoisted variant of the fused kernel (A/B evidence, not the default)
+        if mode.startswith("tile"):
+            monkeypatch.setenv("SE3D_NP_TILE", mode[4:])   # TR x TC entries per lane of the fused kernel
     else:
         monkeypatch.setenv("SE3D_PAIRS", mode)
     node = _node(extr_rig, max_frames=2, max_det_per_cam=8, max_hyp=32)
