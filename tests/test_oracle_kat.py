@@ -75,6 +75,39 @@ def test_dlt_matches_float64_svd_under_noise(oracle, extr_rig):
     assert worst < 5e-5  # float32 SVD vs float64 SVD: SURVEY probe says <= 0.0054 mm; allow 0.05 mm
 
 
+def test_dlt_two_view_systems_take_the_square_path(oracle, extr_rig):
+    """A joint seen by exactly two views gives a square 4 x 4 DLT system, for which Eigen 3.3 JacobiSVD::compute skips the QR
+    preconditioner (work matrix = A / scale, V = I); round 3 fixed the restatement to do the same.  Known answers, no reference needed:
+    noise-free pairs must come back to the point, noisy well-conditioned pairs must agree with LAPACK's float64 SVD like the n >= 3
+    systems do, and the result must not depend on the order of the two views beyond float32 rounding."""
+    rng = np.random.default_rng(5)
+    worst_clean = worst_noisy = worst_swap = 0.0
+    n_done = 0
+    while n_done < 150:
+        X, sel = _random_visible(extr_rig, rng, 2)
+        sel = np.sort(rng.choice(sel, 2, replace=False))
+        c0, c1 = [-(extr_rig.T[i][:3, :3].T @ extr_rig.T[i][:3, 3]) for i in sel]
+        d0, d1 = (X - c0) / np.linalg.norm(X - c0), (X - c1) / np.linalg.norm(X - c1)
+        if abs(d0 @ d1) > 0.94:   # rays less than ~20 degrees apart: ill-conditioned, not a known answer
+            continue
+        n_done += 1
+        pts = _project(extr_rig, X)[sel]
+        conf = rng.uniform(0.3, 1.0, (2, 1))
+        p3 = np.concatenate([pts, conf], 1).astype(np.float32)
+        Xo, err = oracle.dlt(extr_rig.Rt[sel], p3, True)
+        worst_clean = max(worst_clean, np.linalg.norm(Xo - X))
+        assert err < 1e-4
+        pn = p3.copy()
+        pn[:, :2] += rng.normal(0, 3e-3, (2, 2)).astype(np.float32)
+        Xo, _ = oracle.dlt(extr_rig.Rt[sel], pn, True)
+        Xr = _dlt_f64(extr_rig.Rt[sel], pn, True)
+        worst_noisy = max(worst_noisy, np.linalg.norm(Xo - Xr))
+        Xs, _ = oracle.dlt(extr_rig.Rt[sel[::-1]], pn[::-1], True)
+        worst_swap = max(worst_swap, np.linalg.norm(Xo - Xs))
+    print("two-view DLT: noise-free %.2e m, vs float64 SVD %.2e m, view order %.2e m" % (worst_clean, worst_noisy, worst_swap))
+    assert worst_clean < 1e-4 and worst_noisy < 1e-4 and worst_swap < 1e-4
+
+
 def test_epipolar_distance_zero_for_consistent_pairs(oracle, extr_rig):
     rng = np.random.default_rng(2)
     for _ in range(50):
