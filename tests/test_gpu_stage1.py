@@ -398,13 +398,23 @@ def test_pair_table_column_chunks_equal_the_whole_table(monkeypatch, oracle, dem
     from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
     rig = R.elliptical_rig(48, seed=6)
     rig.set_tensors(*rig_tensors(rig))
-    frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=24, n_frames=3, seed=19, pixel_noise=3.0, p_miss=0.08, spacing=0.8, min_coverage=6))
+    frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=24, n_frames=5, seed=19, pixel_noise=3.0, p_miss=0.08, spacing=0.8, min_coverage=6))
+
+    def without(fr, keep):   # the frame with the detections of the cameras in `keep` only
+        parts, off = [], np.zeros(rig.n_cam + 1, np.int32)
+        for c in range(rig.n_cam):
+            seg = fr.persons[fr.det_offset[c]:fr.det_offset[c + 1]] if c in keep else fr.persons[:0]
+            parts.append(seg)
+            off[c + 1] = off[c] + len(seg)
+        return pm.Frame(rig.n_cam, off, np.concatenate(parts), fr.fb_delay, fr.stamp)
+    frames[3] = without(frames[3], set(range(48)) - {0, 5, 6, 31, 47})   # cameras without detections, among them the first and the last
+    frames[4] = without(frames[4], {17})                                # one camera only: FLAG_FEW_CAMERAS, empty result
     res, blocks = {}, {}
     for name, env in (("whole", {"SE3D_PAIR_CHUNKS": "0"}), ("default", {}), ("c3", {"SE3D_PAIR_CHUNKS": "3"}), ("c32", {"SE3D_PAIR_CHUNKS": "32"}),
                       ("lds", {"SE3D_SWEEP_LDS_KB": "128"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        node = _node(rig, max_frames=3, max_det_per_cam=32, max_hyp=80)
+        node = _node(rig, max_frames=5, max_det_per_cam=32, max_hyp=80)
         res[name] = node.triangulate_persons(frames)
         if name in ("whole", "default"):
             blocks[name] = [_pair_costs(node, 1, a, b) for (a, b) in ((0, 1), (3, 40), (46, 47), (10, 11))]
@@ -414,8 +424,9 @@ def test_pair_table_column_chunks_equal_the_whole_table(monkeypatch, oracle, dem
     for (ta, na, nb), (tb, na2, nb2) in zip(blocks["whole"], blocks["default"]):
         assert (na, nb) == (na2, nb2) and na > 0 and nb > 0
         assert np.array_equal(ta[:na, :nb], tb[:na, :nb])
+    assert res["whole"][4].flags & pm.FLAG_FEW_CAMERAS and res["whole"][4].n_persons == 0
     for fi, a in enumerate(res["whole"]):
-        assert a.n_hyp > 24 * 0.8
+        assert a.n_hyp > 24 * 0.8 or fi == 4
         for name in ("default", "c3", "c32", "lds"):
             b = res[name][fi]
             assert a.n_hyp == b.n_hyp and a.n_persons == b.n_persons and a.flags == b.flags, name
