@@ -138,3 +138,15 @@ def test_create_failure_reason_is_retrievable(product_lib):
     L.se3d_last_error.argtypes = [C.c_void_p]
     assert not L.se3d_create(C.byref(rc), C.byref(prm), C.byref(lim), 0)
     assert b"unsupported sizes" in L.se3d_last_error(None)
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C-ABI: include/se3d.h must compile as C (not only as C++) without warnings, and the POD mirrors of person_msgs
+    must have the sizes the Python / C++ sides assume."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "se3d.h"\nint main(void) { return (sizeof(se3d_person3d) == 1688 && sizeof(se3d_person2d) == 428 && sizeof(se3d_keypoint3d) == 80) ? 0 : 1; }\n')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
