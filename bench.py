@@ -248,7 +248,8 @@ def bench_latency_b1(rig, seq, name, device=0, frames_timed=200):
     node.close()
     return {"workload": "%s, one frame per call (B = 1)" % name, "frames_timed": frames_timed, "refined_skeletons_per_frame": round(n_ref, 2),
             "host_call_ms": {"se3d_triangulate": round(h1 * 1e3, 4), "se3d_refine": round(h2 * 1e3, 4), "frame": round((h1 + h2) * 1e3, 4)},
-            "device_ms": {"stage1": round(d1, 4), "stage2": round(d2, 4), "frame": round(d1 + d2, 4)},
+            "device_ms": {"stage1": round(d1, 4), "stage2": round(d2, 4), "frame": round(d1 + d2, 4),
+                          "by_kernel_group": {k: round(dev[k][0] / frames_timed, 4) for k in STAGE1_KERNELS + STAGE2_KERNELS}},
             "note": "host: synchronous C-ABI calls incl. H2D / D2H of pageable buffers; device: HIP events around the kernel groups of the call "
                     "(reference call sites S3D:1069, PP:505); the oracle's ms per frame: cpu_baseline.per_stage_ms"}
 
@@ -756,6 +757,7 @@ def main():
     ap.add_argument("--no-streaming", action="store_true", help="skip the PCIe-inclusive streaming measurement (value_streaming) of a default run")
     ap.add_argument("--stream-contexts", type=int, default=8, help="contexts of the streaming measurement (each pins two batches of host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-only", action="store_true", help="only the B = 1 latency block (one 16cam6p frame per call), printed as its own JSON line")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity / latency blocks of a default run")
     args = ap.parse_args()
 
@@ -770,6 +772,10 @@ def main():
     if args.stage == "dlt":
         return bench_dlt(args)
 
+    if args.latency_only:   # A/B of the synchronous single-frame calls: same scene and block as the default run's latency_B1
+        w = WORKLOADS["16cam6p"]
+        print(json.dumps({"latency_B1": bench_latency_b1(make_rig(w), _gen_one((w["n_cam"], w["n_persons"], args.tsteps, 0)), "16cam6p", local_rank)}), flush=True)
+        return 0
     default_run = args.workload is None and not args.serial
     headline = args.workload or "16cam6p"
     stage2 = args.stage == "12"

@@ -53,7 +53,13 @@ struct se3d_ctx {
   std::string err;
   std::vector<void *> allocs;
   int2 *pair_ab = nullptr;
-  // pinned host staging
+  // Slabs: the arrays that cross the bus together are carved from ONE device allocation and ONE pinned host allocation at the same
+  // offsets, so that the transfer of a whole batch (a single frame for max_frames = 1, the reference's operating point) is one copy
+  // instead of one per array: in1 = {nraw, fb, raw}, out1 = {out_count, nhyp, flags, outP, out_hyp, out_assoc},
+  // in2 = {n_det, t, fb_ref, dets}, out2 = {n_out, n_tracks, flags2, pred_dt, iters, fused, pred}.
+  struct Slab { char *d = nullptr, *h = nullptr; size_t bytes = 0; } sl_in1, sl_out1, sl_in2, sl_out2;
+  size_t off_raw = 0, off_in2 = 0;   // offsets of the variable-length tails of the two input slabs
+  // pinned host staging (views into the slabs)
   se3d_person2d *h_raw = nullptr;
   int32_t *h_nraw = nullptr;
   se3d_person3d *h_out = nullptr;
@@ -81,6 +87,9 @@ struct se3d_ctx {
   float *d_fb_ref = nullptr;       // [S][N] fb_delay rows of se3d_refine (host path): its own buffer, so mixing the two paths on one
                                    // context cannot overwrite the staged batch's values
   float *h_fb_ref = nullptr;
+  se3d_person3d *h_in2 = nullptr;  // pinned mirrors of d_in2 / d_ndet2 / d_t (in2 slab)
+  int32_t *h_ndet2 = nullptr;
+  double *h_t_ref = nullptr;
   double *d_hung = nullptr;        // se3d_hungarian scratch: 256 x 256 cost matrix + assignment + status
   int *d_hung_assign = nullptr;
   double *d_t = nullptr;           // [S]
@@ -148,6 +157,33 @@ bool dev_alloc(se3d_ctx *c, T **p, size_t n) {
   if (!hip_ok(c, hipMalloc(&q, n * sizeof(T)), "hipMalloc")) return false;
   c->allocs.push_back(q);
   *p = reinterpret_cast<T *>(q);
+  return true;
+}
+
+// Slab construction: `carve` names the arrays once; it runs with null bases to size the slab and again with the real bases.
+struct SlabCarver {
+  char *d, *h;
+  size_t off = 0;
+  template <typename T>
+  size_t take(T **dp, T **hp, size_t n) {
+    const size_t at = off;
+    if (dp) *dp = d ? reinterpret_cast<T *>(d + off) : nullptr;
+    if (hp) *hp = h ? reinterpret_cast<T *>(h + off) : nullptr;
+    off += (n * sizeof(T) + 255) & ~(size_t)255;
+    return at;
+  }
+};
+template <typename F>
+bool slab_build(se3d_ctx *c, se3d_ctx::Slab &s, F carve) {
+  SlabCarver sizing{nullptr, nullptr};
+  carve(sizing);
+  s.bytes = sizing.off;
+  if (!dev_alloc(c, &s.d, s.bytes)) return false;
+  if (c->dry) return true;
+  if (!hip_ok(c, hipHostMalloc((void **)&s.h, s.bytes, hipHostMallocDefault), "hipHostMalloc (slab)")) return false;
+  memset(s.h, 0, s.bytes);
+  SlabCarver real{s.d, s.h};
+  carve(real);
   return true;
 }
 
@@ -297,7 +333,11 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
   D.d = Se3dDims{B, N, P, H, np, params->pose_method, params->norm_height, params->max_epi_dist, 0, 1};
   bool ok = true;
   ok = ok && dev_alloc(c, &r.Rt, (size_t)N * 12) && dev_alloc(c, &r.K, (size_t)N * 4) && dev_alloc(c, &r.F, (size_t)np * 9);
-  ok = ok && dev_alloc(c, &r.raw, (size_t)B * N * P) && dev_alloc(c, &r.nraw, (size_t)B * N);
+  ok = ok && slab_build(c, c->sl_in1, [&](SlabCarver &m) {   // raw last: one copy covers the header and the staged frames
+    m.take(&r.nraw, &c->h_nraw, (size_t)B * N);
+    m.take(&c->d_fb, &c->h_fb, (size_t)B * N);
+    c->off_raw = m.take(&r.raw, &c->h_raw, (size_t)B * N * P);
+  });
   ok = ok && dev_alloc(c, &D.kp, (size_t)B * N * P * SE3D_NKP) && dev_alloc(c, &c->d_assoc_in, (size_t)B * H * N);
   ok = ok && dev_alloc(c, &D.pscore, (size_t)B * N * P) && dev_alloc(c, &D.vmask_gt, (size_t)B * N * P) && dev_alloc(c, &D.vmask_ge, (size_t)B * N * P);
   ok = ok && dev_alloc(c, &D.nvalid, (size_t)B * N) && dev_alloc(c, &D.orig, (size_t)B * N * P);
@@ -310,12 +350,18 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
     D.d.pair_stride = c->plan.m ? 2 * c->plan.cap : np;
   }
   ok = ok && dev_alloc(c, &D.pair, (size_t)B * D.d.pair_stride * P * P);
-  ok = ok && dev_alloc(c, &D.assoc, (size_t)B * H * N) && dev_alloc(c, &D.nviews, (size_t)B * H) && dev_alloc(c, &D.nhyp, (size_t)B);
+  ok = ok && dev_alloc(c, &D.assoc, (size_t)B * H * N) && dev_alloc(c, &D.nviews, (size_t)B * H);
   ok = ok && dev_alloc(c, &D.C, (size_t)B * H * P) && dev_alloc(c, &D.mask, (size_t)B * H * P) && dev_alloc(c, &D.mwork, (size_t)B * H * P);
-  ok = ok && dev_alloc(c, &D.flags, (size_t)B);
   ok = ok && dev_alloc(c, &D.tri_slow, (size_t)B * H * 4);
-  ok = ok && dev_alloc(c, &D.hypP, (size_t)B * H) && dev_alloc(c, &D.keep, (size_t)B * H) && dev_alloc(c, &D.outP, (size_t)B * H);
-  ok = ok && dev_alloc(c, &D.out_count, (size_t)B) && dev_alloc(c, &D.out_hyp, (size_t)B * H) && dev_alloc(c, &D.out_assoc, (size_t)B * H * N);
+  ok = ok && dev_alloc(c, &D.hypP, (size_t)B * H) && dev_alloc(c, &D.keep, (size_t)B * H);
+  ok = ok && slab_build(c, c->sl_out1, [&](SlabCarver &m) {
+    m.take(&D.out_count, &c->h_count, (size_t)B);
+    m.take(&D.nhyp, &c->h_nhyp, (size_t)B);
+    m.take(&D.flags, &c->h_flags, (size_t)B);
+    m.take(&D.outP, &c->h_out, (size_t)B * H);
+    m.take(&D.out_hyp, &c->h_outhyp, (size_t)B * H);
+    m.take(&D.out_assoc, &c->h_outassoc, (size_t)B * H * N);
+  });
   ok = ok && dev_alloc(c, &c->pair_ab, (size_t)np);
   {  // stage 2 state: S = B sequences, T = max_tracks
     const int T = limits->max_tracks > 0 ? limits->max_tracks : H;
@@ -324,7 +370,7 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
     Q.S = B; Q.T = T; Q.H = H; Q.N = N; Q.pose_method = params->pose_method; Q.norm_height = params->norm_height; Q.seq0 = 0;
     Q.shard_rank = 0; Q.shard_world = 1;
     ok = ok && dev_alloc(c, &Q.fb_buf, S * 3) && dev_alloc(c, &Q.t_prev, S) && dev_alloc(c, &Q.next_id, S) && dev_alloc(c, &Q.frame_nr, S);
-    ok = ok && dev_alloc(c, &Q.n_tracks, S) && dev_alloc(c, &Q.order, S * T) && dev_alloc(c, &Q.pred_dt, S);
+    ok = ok && dev_alloc(c, &Q.order, S * T);
     ok = ok && dev_alloc(c, &Q.used, S * T) && dev_alloc(c, &Q.id, S * T) && dev_alloc(c, &Q.num_obs, S * T) && dev_alloc(c, &Q.has, S * T);
     ok = ok && dev_alloc(c, &Q.trk_t_prev, S * T) && dev_alloc(c, &Q.height_prev, S * T) && dev_alloc(c, &Q.root_prev, S * T * 3);
     ok = ok && dev_alloc(c, &Q.prev, S * T * SE3D_NFU * 3) && dev_alloc(c, &Q.vel, S * T * SE3D_NFU * 9);
@@ -332,10 +378,22 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
     ok = ok && dev_alloc(c, &Q.C, S * H * T) && dev_alloc(c, &Q.W, S * H * T) && dev_alloc(c, &Q.det_slot, S * H) && dev_alloc(c, &Q.pub, S * H);
     ok = ok && dev_alloc(c, &Q.fused_det, S * H) && dev_alloc(c, &Q.pred_det, S * H) && dev_alloc(c, &Q.iters_det, S * H);
     ok = ok && dev_alloc(c, &Q.lm_scratch, S * 4 * 1865);  // [S][4 wavefronts][S2_SCHUR_SCRATCH_DOUBLES] (se3d_stage2.hip)
-    ok = ok && dev_alloc(c, &Q.fused, S * H) && dev_alloc(c, &Q.pred, S * H) && dev_alloc(c, &Q.iters, S * H) && dev_alloc(c, &Q.n_out, S);
-    ok = ok && dev_alloc(c, &Q.flags2, S);
-    ok = ok && dev_alloc(c, &c->d_in2, S * H) && dev_alloc(c, &c->d_ndet2, S) && dev_alloc(c, &c->d_fb, S * N) && dev_alloc(c, &c->d_t, S);
-    ok = ok && dev_alloc(c, &c->d_fb_ref, S * N) && dev_alloc(c, &c->d_hung, (size_t)SE3D_MUNKRES_MAX * SE3D_MUNKRES_MAX) &&
+    ok = ok && slab_build(c, c->sl_out2, [&](SlabCarver &m) {
+      m.take(&Q.n_out, &c->h_nout, S);
+      m.take(&Q.n_tracks, &c->h_ntracks, S);
+      m.take(&Q.flags2, &c->h_flags2, S);
+      m.take(&Q.pred_dt, &c->h_preddt, S);
+      m.take(&Q.iters, &c->h_iters, S * H);
+      m.take(&Q.fused, &c->h_fused, S * H);
+      m.take(&Q.pred, &c->h_pred, S * H);
+    });
+    ok = ok && slab_build(c, c->sl_in2, [&](SlabCarver &m) {   // measurements last: one copy covers the header and the n_det persons (S = 1)
+      m.take(&c->d_ndet2, &c->h_ndet2, S);
+      m.take(&c->d_t, &c->h_t_ref, S);
+      m.take(&c->d_fb_ref, &c->h_fb_ref, S * N);
+      c->off_in2 = m.take(&c->d_in2, &c->h_in2, S * H);
+    });
+    ok = ok && dev_alloc(c, &c->d_hung, (size_t)SE3D_MUNKRES_MAX * SE3D_MUNKRES_MAX) &&
          dev_alloc(c, &c->d_hung_assign, (size_t)SE3D_MUNKRES_MAX + 1);
   }
   return ok;
@@ -461,17 +519,8 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     for (auto &set : c->ev2)
       for (auto &e : set) (void)hipEventCreate(&e);
     if (ok) {
-      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_fb, sizeof(float) * S * N, hipHostMallocDefault), "hipHostMalloc");
-      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_fb_ref, sizeof(float) * S * N, hipHostMallocDefault), "hipHostMalloc");
       ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_t, sizeof(double) * S * se3d_ctx::kRing, hipHostMallocDefault), "hipHostMalloc");
       for (auto &e : c->t_done) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_fused, sizeof(se3d_person3d) * S * H, hipHostMallocDefault), "hipHostMalloc");
-      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_pred, sizeof(se3d_person3d) * S * H, hipHostMallocDefault), "hipHostMalloc");
-      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_iters, sizeof(int32_t) * S * H, hipHostMallocDefault), "hipHostMalloc");
-      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_nout, sizeof(int32_t) * S, hipHostMallocDefault), "hipHostMalloc");
-      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_ntracks, sizeof(int32_t) * S, hipHostMallocDefault), "hipHostMalloc");
-      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_flags2, sizeof(uint32_t) * S, hipHostMallocDefault), "hipHostMalloc");
-      ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_preddt, sizeof(double) * S, hipHostMallocDefault), "hipHostMalloc");
       ok = ok && hip_ok(c, hipMemset(c->d_fb, 0, sizeof(float) * S * N), "memset fb");
       ok = ok && (stage2_reset(c) == SE3D_OK);
     }
@@ -494,14 +543,6 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     ok = ok && hip_ok(c, hipMemcpy(c->pair_ab, ab.data(), sizeof(int2) * np, hipMemcpyHostToDevice), "copy pair_ab");
     ok = ok && hip_ok(c, hipMemset(draw, 0, sizeof(se3d_person2d) * (size_t)B * N * P), "memset raw");
     ok = ok && hip_ok(c, hipMemset(dnraw, 0, sizeof(int32_t) * (size_t)B * N), "memset nraw");
-    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_raw, sizeof(se3d_person2d) * (size_t)B * N * P, hipHostMallocDefault), "hipHostMalloc raw");
-    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_nraw, sizeof(int32_t) * (size_t)B * N, hipHostMallocDefault), "hipHostMalloc nraw");
-    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_out, sizeof(se3d_person3d) * (size_t)B * H, hipHostMallocDefault), "hipHostMalloc out");
-    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_count, sizeof(int32_t) * (size_t)B, hipHostMallocDefault), "hipHostMalloc");
-    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_nhyp, sizeof(int32_t) * (size_t)B, hipHostMallocDefault), "hipHostMalloc");
-    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_flags, sizeof(uint32_t) * (size_t)B, hipHostMallocDefault), "hipHostMalloc");
-    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_outhyp, sizeof(int32_t) * (size_t)B * H, hipHostMallocDefault), "hipHostMalloc");
-    ok = ok && hip_ok(c, hipHostMalloc((void **)&c->h_outassoc, sizeof(int32_t) * (size_t)B * H * N, hipHostMallocDefault), "hipHostMalloc");
   }
   if (!ok) {
     {
@@ -523,24 +564,9 @@ void se3d_destroy(se3d_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (void *p : c->allocs) (void)hipFree(p);
-  if (c->h_raw) (void)hipHostFree(c->h_raw);
-  if (c->h_nraw) (void)hipHostFree(c->h_nraw);
-  if (c->h_out) (void)hipHostFree(c->h_out);
-  if (c->h_count) (void)hipHostFree(c->h_count);
-  if (c->h_nhyp) (void)hipHostFree(c->h_nhyp);
-  if (c->h_flags) (void)hipHostFree(c->h_flags);
-  if (c->h_outhyp) (void)hipHostFree(c->h_outhyp);
-  if (c->h_outassoc) (void)hipHostFree(c->h_outassoc);
-  if (c->h_fb) (void)hipHostFree(c->h_fb);
-  if (c->h_fb_ref) (void)hipHostFree(c->h_fb_ref);
+  for (se3d_ctx::Slab *sl : {&c->sl_in1, &c->sl_out1, &c->sl_in2, &c->sl_out2})
+    if (sl->h) (void)hipHostFree(sl->h);
   if (c->h_t) (void)hipHostFree(c->h_t);
-  if (c->h_fused) (void)hipHostFree(c->h_fused);
-  if (c->h_pred) (void)hipHostFree(c->h_pred);
-  if (c->h_iters) (void)hipHostFree(c->h_iters);
-  if (c->h_nout) (void)hipHostFree(c->h_nout);
-  if (c->h_ntracks) (void)hipHostFree(c->h_ntracks);
-  if (c->h_flags2) (void)hipHostFree(c->h_flags2);
-  if (c->h_preddt) (void)hipHostFree(c->h_preddt);
   if (c->h_rp_off) (void)hipHostFree(c->h_rp_off);
   if (c->rpb_cap > 0) { (void)hipFree(c->RB.dense); (void)hipFree(c->RB.valid); (void)hipFree(c->RB.slot); (void)hipFree(c->RB.det_offset); (void)hipFree(c->RB.out); (void)hipFree(c->RB.out_src); }   // rpb_cap > 0 <=> RB owns all six
   for (auto &sl : c->ss) {
@@ -592,7 +618,7 @@ int64_t se3d_device_bytes(int32_t n_cam, const se3d_limits *limits) {
   return (int64_t)c.dry_bytes;
 }
 
-int se3d_stage_frames(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames) {
+static int stage_frames(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames, bool sync) {
   if (!c || !frames || n_frames < 1) return SE3D_ERR_ARG;
   const int B = c->D.d.B, N = c->D.d.N, P = c->D.d.P;
   if (n_frames > B) { c->err = "n_frames exceeds limits.max_frames"; return SE3D_ERR_CAPACITY; }
@@ -610,16 +636,17 @@ int se3d_stage_frames(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames
       if (n) memcpy(c->h_raw + ((size_t)(f * N + cam)) * P, fr.persons + fr.det_offset[cam], sizeof(se3d_person2d) * (size_t)n);
     }
   }
-  HIPCHK(c, hipMemcpyAsync((void *)c->D.raw, c->h_raw, sizeof(se3d_person2d) * (size_t)n_frames * N * P, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync((void *)c->D.nraw, c->h_nraw, sizeof(int32_t) * (size_t)B * N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_fb, c->h_fb, sizeof(float) * (size_t)n_frames * N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // one copy: {nraw, fb} header and the staged frames' detections (in1 slab, raw last)
+  HIPCHK(c, hipMemcpyAsync(c->sl_in1.d, c->sl_in1.h, c->off_raw + sizeof(se3d_person2d) * (size_t)n_frames * N * P, hipMemcpyHostToDevice, c->stream));
+  if (sync) HIPCHK(c, hipStreamSynchronize(c->stream));   // the pinned slab may be refilled as soon as this returns
   c->staged_frames = n_frames;
   c->ran = false;
   c->ran_dlt = false;
   c->dlt_hyp = 0;
   return SE3D_OK;
 }
+
+int se3d_stage_frames(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames) { return stage_frames(c, n_frames, frames, true); }
 
 int se3d_run_stage1(se3d_ctx *c) {
   if (!c) return SE3D_ERR_ARG;
@@ -665,12 +692,16 @@ int se3d_fetch_stage1(se3d_ctx *c, int32_t n_frames, se3d_frame_out *outs) {
   const Se3dDev &D = c->D;
   const int N = D.d.N, H = D.d.H;
   HIPCHK(c, hipSetDevice(c->device));
+  if (n_frames == D.d.B) {   // the whole batch: one copy of the out1 slab
+    HIPCHK(c, hipMemcpyAsync(c->sl_out1.h, c->sl_out1.d, c->sl_out1.bytes, hipMemcpyDeviceToHost, c->stream));
+  } else {
   HIPCHK(c, hipMemcpyAsync(c->h_out, D.outP, sizeof(se3d_person3d) * (size_t)n_frames * H, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_count, D.out_count, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_nhyp, D.nhyp, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_flags, D.flags, sizeof(uint32_t) * (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_outhyp, D.out_hyp, sizeof(int32_t) * (size_t)n_frames * H, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_outassoc, D.out_assoc, sizeof(int32_t) * (size_t)n_frames * H * N, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   collect_profile(c);
   int rc = SE3D_OK;
@@ -693,7 +724,7 @@ int se3d_fetch_stage1(se3d_ctx *c, int32_t n_frames, se3d_frame_out *outs) {
 }
 
 int se3d_triangulate_batch(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frames, se3d_frame_out *outs) {
-  int rc = se3d_stage_frames(c, n_frames, frames);
+  int rc = stage_frames(c, n_frames, frames, false);   // no wait after the upload: the fetch below synchronises the stream
   if (rc != SE3D_OK) return rc;
   rc = se3d_run_stage1(c);
   if (rc != SE3D_OK) return rc;
@@ -826,6 +857,9 @@ int se3d_refine_reset(se3d_ctx *c) {
 static int fetch_stage2_range(se3d_ctx *c, int seq0, int n_seq, se3d_fused_out *outs) {
   const Se3dStage2 &Q = c->Q;
   const size_t H = Q.H;
+  if (seq0 == 0 && n_seq == Q.S) {   // all sequences: one copy of the out2 slab
+    HIPCHK(c, hipMemcpyAsync(c->sl_out2.h, c->sl_out2.d, c->sl_out2.bytes, hipMemcpyDeviceToHost, c->stream));
+  } else {
   HIPCHK(c, hipMemcpyAsync(c->h_fused + seq0 * H, Q.fused + seq0 * H, sizeof(se3d_person3d) * n_seq * H, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_pred + seq0 * H, Q.pred + seq0 * H, sizeof(se3d_person3d) * n_seq * H, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_iters + seq0 * H, Q.iters + seq0 * H, sizeof(int32_t) * n_seq * H, hipMemcpyDeviceToHost, c->stream));
@@ -833,6 +867,7 @@ static int fetch_stage2_range(se3d_ctx *c, int seq0, int n_seq, se3d_fused_out *
   HIPCHK(c, hipMemcpyAsync(c->h_ntracks + seq0, Q.n_tracks + seq0, sizeof(int32_t) * n_seq, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_flags2 + seq0, Q.flags2 + seq0, sizeof(uint32_t) * n_seq, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_preddt + seq0, Q.pred_dt + seq0, sizeof(double) * n_seq, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   collect_profile(c);
   int rc = SE3D_OK;
@@ -861,18 +896,19 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
   HIPCHK(c, hipSetDevice(c->device));
   collect_profile(c);
   const size_t H = Q.H, N = Q.N;
+  // every return path of this call synchronises the stream, so the pinned in2 slab is free to refill here
   for (size_t i = 0; i < N; ++i) c->h_fb_ref[seq * N + i] = (fb_delay_per_cam && (int)i < n_cam) ? fb_delay_per_cam[i] : -1.0f;
-  double *ht = c->h_t + (size_t)c->t_head * Q.S;
-  (void)hipEventSynchronize(c->t_done[c->t_head]);
-  ht[0] = t;
-  int32_t nd = n_det;
-  if (n_det) HIPCHK(c, hipMemcpyAsync(c->d_in2 + seq * H, dets, sizeof(se3d_person3d) * (size_t)n_det, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_ndet2 + seq, &nd, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_fb_ref + seq * N, c->h_fb_ref + seq * N, sizeof(float) * N, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_t + seq, ht, sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipEventRecord(c->t_done[c->t_head], c->stream));
-  c->t_head = (c->t_head + 1) % se3d_ctx::kRing;
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // nd is a stack variable
+  c->h_t_ref[seq] = t;
+  c->h_ndet2[seq] = n_det;
+  if (n_det) memcpy(c->h_in2 + seq * H, dets, sizeof(se3d_person3d) * (size_t)n_det);
+  if (Q.S == 1) {   // one copy: {n_det, t, fb_delay} header and the n_det measurements (in2 slab, measurements last)
+    HIPCHK(c, hipMemcpyAsync(c->sl_in2.d, c->sl_in2.h, c->off_in2 + sizeof(se3d_person3d) * (size_t)n_det, hipMemcpyHostToDevice, c->stream));
+  } else {
+    if (n_det) HIPCHK(c, hipMemcpyAsync(c->d_in2 + seq * H, c->h_in2 + seq * H, sizeof(se3d_person3d) * (size_t)n_det, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ndet2 + seq, c->h_ndet2 + seq, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_fb_ref + seq * N, c->h_fb_ref + seq * N, sizeof(float) * N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_t + seq, c->h_t_ref + seq, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
   Q.dets = c->d_in2; Q.n_det = c->d_ndet2; Q.fb_delay = c->d_fb_ref; Q.t = c->d_t;
   se3d_launch_stage2(Q, seq, 1, c->stream, next_ev2(c), 3);
   HIPCHK(c, hipGetLastError());

@@ -3144,7 +3144,12 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     if (ev) (void)hipEventRecord(ev[1], st);
   } else if (phases & 1) {
   const char *e_pairs = getenv("SE3D_PAIRS");  // flat | packed | tiled: A/B switches that force the stand-alone pair kernels
-  const bool fused_np = !tiled && !e_pairs && N * P <= NP_MAX_DETS && D.d.npairs <= 2048;
+  // Small batches (a single frame per call is the reference's operating point, S3D:1069): the fused kernel is ONE workgroup per frame,
+  // which leaves the chip empty — the stand-alone normalisation + the flat pair kernel (one lane per table entry over the whole
+  // chip) write the same table (tests: packed == flat == fused bitwise) in 14 us instead of 47 us at B = 1 (16cam6p).  Up to 65 536 table
+  // entries per launch (8 frames of 16cam6p); SE3D_NO_SMALL_BATCH=1 keeps the fused kernel (tests of that kernel on small batches).
+  const bool small_batch = !tiled && !e_pairs && (size_t)B * D.d.npairs * P * P <= ((size_t)1 << 16) && !getenv("SE3D_NO_SMALL_BATCH");
+  const bool fused_np = !tiled && !e_pairs && !small_batch && N * P <= NP_MAX_DETS && D.d.npairs <= 2048;
   if (ev && (phases & 1)) (void)hipEventRecord(ev[0], st);
   if (!fused_np) hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D, 1);
   if (ev) (void)hipEventRecord(ev[1], st);
@@ -3169,7 +3174,7 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
   } else if (tiled) {                                                  // SE3D_PAIRS=tiled: the 4x4 register-tile kernel (A/B)
     const int tiles = (P + PT - 1) / PT;
     hipLaunchKernelGGL(se3d_k_pairs_tiled, dim3(tiles * tiles, D.d.npairs, B), dim3(256), 0, st, D, pair_ab);
-  } else if (!(e_pairs && strcmp(e_pairs, "flat") == 0) && D.d.npairs < 12000) {
+  } else if (!small_batch && !(e_pairs && strcmp(e_pairs, "flat") == 0) && D.d.npairs < 12000) {
     hipLaunchKernelGGL(se3d_k_pairs_packed, dim3(B), dim3(256), sizeof(int) * (D.d.npairs + 1), st, D, pair_ab);
   } else {
     const size_t total = (size_t)B * D.d.npairs * P * P;

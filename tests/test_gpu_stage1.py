@@ -111,6 +111,7 @@ def test_packed_pair_kernel_equals_flat_kernel_bitwise(extr_rig, monkeypatch):
     on every valid entry, including frames with low-confidence joints and cameras without detections."""
     frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=7, n_frames=6, seed=31, low_score_frac=0.2, p_miss=0.15))
     tabs = {}
+    monkeypatch.setenv("SE3D_NO_SMALL_BATCH", "1")   # 6 frames: the library would pick normalize + flat by itself
     for mode in ("flat", "packed", "fused"):   # fused (the default for small rigs): normalisation + packed pairs in one kernel, points in LDS
         if mode == "fused":
             monkeypatch.delenv("SE3D_PAIRS", raising=False)
@@ -181,10 +182,14 @@ def _pair_costs(node, frame_idx, a, b):
     return out, na.value, nb.value
 
 
-@pytest.mark.parametrize("mode", ["flat", "tiled", "rows", "fused", "lines", "tile22"])
+@pytest.mark.parametrize("mode", ["flat", "tiled", "rows", "fused", "lines", "tile22", "small_batch"])
 def test_pair_cost_table_is_bit_exact(extr_rig, oracle, demo_params, mode, monkeypatch):
-    if mode in ("fused", "lines") or mode.startswith("tile"):
+    if mode == "small_batch":    # the library's own choice for <= 65 536 table entries per launch: normalize + flat kernel
         monkeypatch.delenv("SE3D_PAIRS", raising=False)
+        monkeypatch.delenv("SE3D_NO_SMALL_BATCH", raising=False)
+    elif mode in ("fused", "lines") or mode.startswith("tile"):
+        monkeypatch.delenv("SE3D_PAIRS", raising=False)
+        monkeypatch.setenv("SE3D_NO_SMALL_BATCH", "1")
         if mode == "lines":
             monkeypatch.setenv("SE3D_NP_LINES", "1")   # the line-hoisted variant of the fused kernel (A/B evidence, not the default)
         if mode.startswith("tile"):
