@@ -3121,6 +3121,8 @@ static void se3d_launch_triangulation(const Se3dDev &D, hipStream_t st) {
   const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
   const char *e_tri = getenv("SE3D_TRI");  // A/B switch (read per launch): joint = always one wavefront per (hypothesis, joint)
   if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) {
+    // (the grid covers all H hypothesis slots; the workgroups of unused slots exit after one load — capping the grid at 12 / 16 / 24 slots
+    // changed the kernel's 7.6 - 7.7 ms per 98 304 frames by less than the run-to-run spread, profiles/r3/README.md)
     hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(TH_PARTS * H, B), dim3(64), 0, st, D);
     hipLaunchKernelGGL(se3d_k_triangulate_slow, dim3((B * H + 63) / 64), dim3(64), (size_t)27 * N * sizeof(float), st, D, B * H);
   }
