@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from smartedgesensor3dhumanpose_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "tools", "tmp", "libse3d_hip_diag.so")
+_lib.LIB_PATH = os.environ.get("STAMP_LIB") or os.path.join(ROOT, "tools", "tmp", "libse3d_hip_diag.so")
 import bench
 w = bench.WORKLOADS["16cam6p"]
 rig = bench.make_rig(w)
@@ -23,3 +23,8 @@ for rep in range(3):
     L.se3d_diag_th_stamps(out, 1)
     v = list(out); n = max(v[15], 1)
     print("rep", rep, "workgroups stamped", v[15], "| cycles per workgroup:", {nm: round(v[i] / n) for i, nm in enumerate(names)}, "total", round(sum(v[:10]) / n))
+
+import numpy as np
+res = node.triangulate_persons(frames[:256])
+nv = np.concatenate([(r.assoc() >= 0).sum(1) for r in res])
+print("views per hypothesis (256 frames): histogram", np.bincount(nv, minlength=17).tolist(), "mean", round(float(nv.mean()), 2))
