@@ -2,7 +2,8 @@
 """Summarise a rocprofv3 --kernel-trace --pmc SQ_* pass (counter_collection.csv + kernel_trace.csv) per kernel:
   python3 tools/pmc_sq.py <rocprof output dir> <out.json> [note]
 Per kernel (averages per launch): the raw counters, duration, and
-  valu_issue_utilisation = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles)   (a wave64 VALU op holds a SIMD's issue for 2 cycles;
+  valu_issue_utilisation = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles)   (a wave64 fp32 / int32 VALU op holds a SIMD's issue for 2 cycles, fp64 for 4:
+                                                                                     a LOWER bound for kernels with fp64 arithmetic, tools/valumix.py prices the mix;
                                                                                      kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs when collected,
                                                                                      else duration x 2.4 GHz)
   valu_busy   = 4 x SQ_ACTIVE_INST_VALU / (1024 x kernel cycles)    (SQ_* time counters tick in quad-cycles, MI355X_MICROARCH.md)

@@ -33,6 +33,14 @@ c256)
   timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/c256_write -- python3 bench.py --workload 256cam128p --contexts 1 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/c256_bench_write.log 2>&1
   python3 tools/pmc_traffic2.py $OUT/c256_fetch $OUT/c256_write $OUT/pmc_traffic_256cam128p_1ctx.json 4 "bench.py --workload 256cam128p --contexts 1 --steps 1 --warmup 1 (one context, 4 sequences x 16 frames)"
   ;;
+valumix)
+  # instruction mix of the vector ALU per kernel (two passes: the counters do not fit one)
+  rm -rf $OUT/serial_mix64 $OUT/serial_mix32
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE --output-format csv -d $OUT/serial_mix64 -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline > $OUT/serial_bench_mix64.log 2>&1
+  python3 tools/pmc_sq.py $OUT/serial_mix64 $OUT/pmc_valumix64_16cam6p_serial.json "bench.py --serial --steps 2 --warmup 1: fp64 VALU instruction counters"
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/serial_mix32 -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline > $OUT/serial_bench_mix32.log 2>&1
+  python3 tools/pmc_sq.py $OUT/serial_mix32 $OUT/pmc_valumix32_16cam6p_serial.json "bench.py --serial --steps 2 --warmup 1: fp32 / integer VALU instruction counters"
+  ;;
 lm)
   for mode in tree tree_mfma schur dense; do
     rm -rf $OUT/lm_$mode
