@@ -439,3 +439,28 @@ def test_pair_table_column_chunks_equal_the_whole_table(monkeypatch, oracle, dem
             assert a.published().tobytes() == b.published().tobytes(), name
         o = oracle.triangulate(rig, demo_params, frames[fi], capacity=80, hyp_capacity=80)
         compare_stage1(res["default"][fi], o)
+
+
+def test_partial_stage_and_fetch_equal_the_whole_batch(extr_rig):
+    """The transfers of a call are one copy of a slab when the whole batch moves (n_frames == max_frames) and per-array copies otherwise:
+    staging 5 of 8 frame slots and fetching 3 of them gives byte for byte what the whole batch gives for those frames (persons, hypothesis
+    table, association table, flags), and a second whole batch after the partial one is unaffected by it."""
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=5, n_frames=8, seed=73, p_miss=0.1, low_score_frac=0.1))
+    node = _node(extr_rig, max_frames=8, max_det_per_cam=8, max_hyp=16)
+    whole = node.triangulate_persons(frames)
+
+    def same(a, b):
+        assert (a.n_hyp, a.n_persons, a.flags) == (b.n_hyp, b.n_persons, b.flags)
+        assert np.array_equal(a.assoc(), b.assoc())
+        assert a.published().tobytes() == b.published().tobytes()
+        assert np.array_equal(a.person_hyp[: a.n_persons], b.person_hyp[: b.n_persons])
+    node.stage(frames[:5])
+    node.run_stage1()
+    part = node.fetch_stage1(3)
+    assert len(part) == 3
+    for a, b in zip(whole, part):
+        same(a, b)
+    again = node.triangulate_persons(frames)
+    for a, b in zip(whole, again):
+        same(a, b)
+    node.close()
