@@ -632,6 +632,24 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank):
             "h2d_mb_per_step": in_bytes / 1e6, "skeletons_per_step": n_skel // steps}
 
 
+def guarded(fn, seconds, what):
+    """Run `fn` on a worker thread with a deadline: (result, error text or None, True if it is still running)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn()
+        except BaseException as e:   # noqa: BLE001 — reported in the JSON line
+            box["e"] = "%s: %s" % (type(e).__name__, e)
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return None, "%s did not finish within %.0f s" % (what, seconds), True
+    return box.get("r"), box.get("e"), False
+
+
 def run_hypothesis_shard(name, seq, rig, steps, dist, local_rank):
     """north_star config 5 as a latency mode: ONE stream of frames, every rank holds the same frames, association and track lifecycle
     replicated, triangulation and LM refinement split by index % world, RCCL all-gathers of the hypothesis / detection blocks
@@ -828,8 +846,6 @@ def main():
             # serial pass of the secondary configuration: ONE context, one stream, nothing else on the GPU -> per-kernel durations
             sec_serial = run_workload("256cam128p", [seqs_sec[0]], rig2, args, 3, 1, None, local_rank, True)
             sec_serial["value_per_gpu"] = sec_serial["value"]
-        if dist is not None:   # one 256cam128p stream, hypotheses sharded over the ranks (north_star config 5)
-            hyp = run_hypothesis_shard("256cam128p", _gen_one((256, 128, T_, 0)), rig2, 2, dist, local_rank)
 
     # Order of a default run: the 256cam128p measurement FIRST, on the fresh device (its four contexts take 272 of the 288 GB; behind the
     # headline's twelve contexts the same measurement came out ~8 % lower, behind the streaming contexts at half speed — measured, cause
@@ -860,6 +876,16 @@ def main():
     streaming = None
     if default_run and not args.no_streaming and stage2 and rank == 0:
         streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps // 2), 2, local_rank)
+    # ---- latency mode of north_star config 5, LAST and guarded: one 256cam128p stream with its hypotheses sharded over the ranks.  Every
+    # measurement of the line above is already taken; an exception here is reported in the block, and a collective that does not return
+    # within the deadline (ranks != 0 wait in it while rank 0 runs its serial / streaming passes: minutes at most) ends the run with the
+    # line printed instead of hanging the launcher.
+    hyp_error, hyp_hung = None, False
+    if want_secondary and dist is not None:
+        def hyp_run():
+            torch.cuda.set_device(local_rank)   # the current device is per thread
+            return run_hypothesis_shard("256cam128p", _gen_one((256, 128, T_, 0)), rig2, 2, dist, local_rank)
+        hyp, hyp_error, hyp_hung = guarded(hyp_run, float(os.environ.get("SE3D_BENCH_HYP_DEADLINE_S", "900")), "hypothesis shard")
     if rank == 0:
         main_res = head or serial
         def load(fn):   # committed counter summaries: this round's when present, else the previous round's
@@ -935,6 +961,8 @@ def main():
                                         "verified_equal_to_single_rank": hyp["verified_equal_to_single_rank"],
                                         "allgather_bytes_per_step": hyp["allgather_bytes_per_step"],
                                         "note": "latency mode of north_star config 5; throughput runs shard sequences (the headline / secondary values)"}
+        elif hyp_error is not None:
+            line["hypothesis_shard"] = {"error": hyp_error, "n_gpus": world}
         if sec_serial is not None:
             line["secondary"]["serial"] = {"value": round(sec_serial["value"], 2), "ms_per_step": round(sec_serial["ms_per_step"], 3), "steps": sec_serial["steps"],
                                            "contexts": 1, "frames_per_step": sec_serial["B"]}
@@ -949,6 +977,9 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
+    if hyp_hung:   # a collective of the guarded block never returned: the line is out, leave without the final barrier
+        sys.stdout.flush()
+        os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
