@@ -22,6 +22,7 @@ process per GPU; the parent never touches the GPU); under an external torchrun i
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -268,7 +269,8 @@ def memory_plan(name, n_ctx, n_frames, exchange=False, free_bytes=None):
     ex = 0
     if exchange:   # SkeletonExchange: 2 pack + 2 gather buffers of [n_ctx][n_frames][max_hyp] persons (+ counts), gather x world
         world = int(os.environ.get("WORLD_SIZE", "1"))
-        ex = 2 * (1 + world) * n_ctx * n_frames * (w["max_hyp"] * pm.person3d_dt.itemsize + 4)
+        slots = (w["n_persons"] + 0.25) if w["n_persons"] <= 16 else w["max_hyp"]   # dense exchange blocks for the small workloads
+        ex = int(2 * (1 + world) * n_ctx * n_frames * (slots * pm.person3d_dt.itemsize + 4))
     plan = {"workload": name, "contexts": n_ctx, "frames_per_context": n_frames, "bytes_per_context": per_ctx, "exchange_bytes": ex,
             "total_bytes": n_ctx * per_ctx + ex}
     if free_bytes is not None and plan["total_bytes"] > free_bytes:
@@ -307,9 +309,14 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         # (shard.SkeletonExchange, covered by tests/test_distributed_gloo.py with two gloo ranks).
         # person slots per frame carried by the exchange: crowded scenes publish spurious extra persons (256cam128p: up to ~150 per frame),
         # so only the small workloads trim the slots below the hypothesis capacity (checked: truncation is an assertion, not a silent loss)
-        XH = min(H, w["n_persons"] + 2) if stage2 and fused_walk and w["n_persons"] <= 16 else H
+        XH = min(H, w["n_persons"] + 2) if stage2 and fused_walk and w["n_persons"] <= 16 else H   # slot form (SE3D_BENCH_EXCHANGE_SLOTS=1, large workloads)
+        # Small workloads with the fused walk: the DENSE form (se3d_pack_stage2_walk_device_dense) — the published persons back to back +
+        # per-frame offsets, capacity n_persons + 0.25 persons per frame; what does not fit is counted in the block, checked below on every
+        # rank for every rank's block.  At 16cam6p a rank produces ~51 GB/s of final skeletons; the all-gather delivers (world - 1) x that
+        # into every GPU, so padding slots ([frame][n_persons + 2] before: +28 %) decide whether the exchange hides behind the step at 8 GPUs.
+        dense_cap = int(math.ceil(B * (w["n_persons"] + 0.25))) if stage2 and fused_walk and w["n_persons"] <= 16 and not os.environ.get("SE3D_BENCH_EXCHANGE_SLOTS") else 0
         streams = [torch.cuda.ExternalStream(nd_.stream_handle()) for nd_ in nodes]
-        ex = shard.SkeletonExchange(dist, NC, B * XH * psz, B, torch.device("cuda", local_rank), streams)
+        ex = shard.SkeletonExchange(dist, NC, (dense_cap if dense_cap else B * XH) * psz, B + 2 if dense_cap else B, torch.device("cuda", local_rank), streams)
 
     # One step = per context one stage-1 pass over its B resident frames and one stage-2 walk over the T time steps of its S
     # sequences (se3d_run_stage2_walk: one launch, a wavefront or workgroup per sequence; forward on even cycles, backward on odd
@@ -356,12 +363,15 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
             nd_.run_stage2_walk(np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
             if ex is not None:  # async D2D of all time steps' fused skeletons (frame-slot order) into the exchange buffer
                 pk, cn = ex.pack_target(ci)
-                nd_.pack_stage2_walk_device_slots(B, XH, pk.data_ptr(), cn.data_ptr())
+                if dense_cap:
+                    nd_.pack_stage2_walk_device_dense(B, dense_cap, pk.data_ptr(), cn.data_ptr())
+                else:
+                    nd_.pack_stage2_walk_device_slots(B, XH, pk.data_ptr(), cn.data_ptr())
                 ex.packed(ci)
             if collect is not None:
                 res = [r for k in ks for r in nd_.fetch_stage2_walk(k * S_, S_)]
                 per_frame = [r.n_persons for r in res]
-                assert ex is None or max(per_frame) <= XH, "exchange slots per frame too small: skeletons would be truncated"
+                assert ex is None or dense_cap or max(per_frame) <= XH, "exchange slots per frame too small: skeletons would be truncated"
                 max_pub[0] = max(max_pub[0], max(per_frame))
                 collect.append(sum(per_frame))
                 if ci == 0:
@@ -438,7 +448,11 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         if ex is not None:
             ex.finish()
             _, gc = ex.gathered(ex.parity ^ 1)   # gathered counts of the accounting step: nothing truncated on any rank
-            assert int(gc.max().item()) <= XH, "a remote rank published more skeletons in a frame than the exchange carries"
+            if dense_cap:   # [world][contexts][B + 2]: word B = persons written, word B + 1 = persons that did not fit
+                assert int(gc[:, :, B + 1].max().item()) == 0, "a rank's dense exchange block was too small: skeletons were dropped"
+                assert int(gc[dist.get_rank(), :, B].sum().item()) == n_skel_local, "the dense exchange blocks do not hold this rank's published skeletons"
+            else:
+                assert int(gc.max().item()) <= XH, "a remote rank published more skeletons in a frame than the exchange carries"
     else:
         n_skel_local = n_s1
     n_skel = n_skel_local
@@ -454,6 +468,8 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         "kernel_ms_per_step": {k: v[0] / steps / NC for k, v in prof.items()},   # per context and step
         "max_hyp_per_frame": int(max(r.n_hyp for r in s1)), "max_published_per_frame": int(max_pub[0]), "exchange_verified": exchange_ok,
         "lm_iterations_mean": float(np.mean(lm_iters)) if lm_iters else None, "params": node.params,
+        "exchange": None if ex is None else {"form": "dense: published persons back to back + per-frame offsets" if dense_cap else "[frame][%d person slots] + counts" % XH,
+                                             "bytes_per_rank_per_step": int(NC * (ex.sp + 4 * ex.sc))},
     }
     if reproj and stage2 and fused_walk:
         res["reprojection"] = bench_reprojection(node, rig, min(B, 16384))
@@ -915,7 +931,8 @@ def main():
                        "contexts_per_gpu": main_res["NC"], "max_hypotheses_per_frame": main_res["max_hyp_per_frame"],
                        "max_published_per_frame": main_res["max_published_per_frame"], "scene_generation_s": round(t_gen, 1),
                        "sharding": ("independent sequences per rank + RCCL all-gather of final skeletons (verified: %s)" % main_res["exchange_verified"]
-                                    if dist is not None else "single GPU")},
+                                    if dist is not None else "single GPU"),
+                       "exchange": main_res.get("exchange")},
             "roofline": roof,
         }
         if head is not None:

@@ -221,6 +221,11 @@ int se3d_pack_stage2_walk_device(se3d_ctx *ctx, int32_t n_frames, void *d_person
  * carry only as many slots as the scene can publish instead of the full hypothesis capacity; frames that published more than
  * `slots` persons are truncated in the copy (their count is still the true one, so the receiver can detect it). */
 int se3d_pack_stage2_walk_device_slots(se3d_ctx *ctx, int32_t n_frames, int32_t slots, void *d_persons, void *d_counts);
+/* Dense form for an exchange that should move skeletons, not padding: the published fused persons of frame slots 0 .. n_frames-1 back to
+ * back in frame-slot order into d_persons [capacity] and d_offsets [n_frames + 2] (int32): d_offsets[f] .. d_offsets[f + 1] is the range of
+ * frame slot f, d_offsets[n_frames] the number of persons written and d_offsets[n_frames + 1] the number that did not fit `capacity`
+ * (they are dropped from the copy, never silently: the receiver reads this word).  Asynchronous on the context's stream. */
+int se3d_pack_stage2_walk_device_dense(se3d_ctx *ctx, int32_t n_frames, int32_t capacity, void *d_persons, void *d_offsets);
 
 
 /* --- streaming ingest: frames arrive from the host every step (the reference's situation at S3D:1069) ---------------------------

@@ -15,6 +15,7 @@
 #include "se3d_device.h"
 
 extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st, int variant);
+extern "C" void se3d_launch_pack_dense(const se3d_person3d *fused, const int32_t *n_out, int n_frames, int H, int capacity, int32_t *off, se3d_person3d *dense, hipStream_t st);
 extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled, int phases, hipStream_t st_hi,
                                    hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk);
 extern "C" void se3d_launch_pair_block(const Se3dDev &D, const int2 *d_ab_one, int frame, hipStream_t st);
@@ -1106,6 +1107,16 @@ int se3d_pack_stage2_walk_device_slots(se3d_ctx *c, int32_t n_frames, int32_t sl
   HIPCHK(c, hipMemcpy2DAsync(d_persons, sizeof(se3d_person3d) * (size_t)slots, Q.fused, sizeof(se3d_person3d) * (size_t)Q.H,
                              sizeof(se3d_person3d) * (size_t)slots, (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_counts, Q.n_out, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToDevice, c->stream));
+  return SE3D_OK;
+}
+
+int se3d_pack_stage2_walk_device_dense(se3d_ctx *c, int32_t n_frames, int32_t capacity, void *d_persons, void *d_offsets) {
+  if (!c || !d_persons || !d_offsets || n_frames < 1 || n_frames > c->Q.S || capacity < 1) return SE3D_ERR_ARG;
+  if (!c->ran2) return SE3D_ERR_STATE;
+  const Se3dStage2 &Q = c->Q;
+  HIPCHK(c, hipSetDevice(c->device));
+  se3d_launch_pack_dense(Q.fused, Q.n_out, n_frames, Q.H, capacity, static_cast<int32_t *>(d_offsets), static_cast<se3d_person3d *>(d_persons), c->stream);
+  HIPCHK(c, hipGetLastError());
   return SE3D_OK;
 }
 

@@ -59,3 +59,42 @@ extern "C" void se3d_launch_stream_compact(const se3d_person3d *fused, const se3
   hipLaunchKernelGGL(se3d_k_stream_scan, dim3(1), dim3(1024), 0, st, n_out, out_off, n_frames, H);
   hipLaunchKernelGGL(se3d_k_stream_gather, dim3(n_frames), dim3(64), 0, st, fused, pred, out_off, H, dense_fused, dense_pred);
 }
+
+// Dense pack of the published fused persons for the skeleton exchange (se3d_pack_stage2_walk_device_dense): exclusive prefix of the
+// per-frame counts clipped at `capacity` persons — off[f] .. off[f + 1] is frame slot f's range in the dense array, off[n_frames] the number
+// of persons written, off[n_frames + 1] the number that did not fit (0 in a correctly sized exchange) — then one wavefront per frame slot
+// copies its persons.  An all-gather of padded [frame][slot] blocks moves 8 slots for 6 persons; this moves the persons.
+__global__ __launch_bounds__(1024) void se3d_k_pack_scan(const int32_t *__restrict__ n_out, int32_t *__restrict__ off, int n_frames, int H, int capacity) {
+  __shared__ int part[16];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n_frames; base += 1024) {
+    const int i = base + tid;
+    const int v = i < n_frames ? min(n_out[i], H) : 0;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) part[wave] = inc;
+    __syncthreads();
+    int offw = s_carry;
+    for (int w = 0; w < wave; ++w) offw += part[w];
+    if (i < n_frames) off[i] = min(offw + inc - v, capacity);
+    __syncthreads();
+    if (tid == 1023) s_carry = offw + inc;
+    __syncthreads();
+  }
+  if (tid == 0) { off[n_frames] = min(s_carry, capacity); off[n_frames + 1] = s_carry - min(s_carry, capacity); }
+}
+__global__ __launch_bounds__(64) void se3d_k_pack_gather(const se3d_person3d *__restrict__ fused, const int32_t *__restrict__ off, int H, se3d_person3d *__restrict__ dense) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  const int o0 = off[f], n = off[f + 1] - o0;
+  constexpr int W = (int)(sizeof(se3d_person3d) / 4);
+  const uint32_t *sf = reinterpret_cast<const uint32_t *>(fused + (size_t)f * H);
+  uint32_t *df = reinterpret_cast<uint32_t *>(dense + o0);
+  for (int i = lane; i < n * W; i += 64) df[i] = sf[i];
+}
+extern "C" void se3d_launch_pack_dense(const se3d_person3d *fused, const int32_t *n_out, int n_frames, int H, int capacity, int32_t *off, se3d_person3d *dense, hipStream_t st) {
+  hipLaunchKernelGGL(se3d_k_pack_scan, dim3(1), dim3(1024), 0, st, n_out, off, n_frames, H, capacity);
+  hipLaunchKernelGGL(se3d_k_pack_gather, dim3(n_frames), dim3(64), 0, st, fused, off, H, dense);
+}

@@ -39,6 +39,31 @@ def unpack_skeletons(gathered_u8, gathered_counts, max_hyp):
     return out
 
 
+def unpack_dense(persons_u8, offsets_i32, n_frames):
+    """Dense exchange form (se3d_pack_stage2_walk_device_dense) of ONE context: persons back to back + [n_frames + 2] offsets ->
+    (list over frame slots of person3d arrays, persons dropped for lack of capacity)."""
+    p = persons_u8.cpu().numpy() if hasattr(persons_u8, "cpu") else np.asarray(persons_u8)
+    o = offsets_i32.cpu().numpy() if hasattr(offsets_i32, "cpu") else np.asarray(offsets_i32)
+    persons = p.view(pm.person3d_dt)
+    return [persons[o[f]:o[f + 1]].copy() for f in range(n_frames)], int(o[n_frames + 1])
+
+
+def pack_host_dense(results, capacity):
+    """Host-side twin of se3d_pack_stage2_walk_device_dense (gloo tests): (persons uint8 [capacity * itemsize], offsets int32 [n + 2])."""
+    n = len(results)
+    buf = np.zeros(capacity, pm.person3d_dt)
+    off = np.zeros(n + 2, np.int32)
+    tot = 0
+    for f, pers in enumerate(results):
+        off[f] = min(tot, capacity)
+        k = max(0, min(len(pers), capacity - tot))
+        buf[off[f]:off[f] + k] = pers[:k]
+        tot += len(pers)
+    off[n] = min(tot, capacity)
+    off[n + 1] = tot - off[n]
+    return torch.from_numpy(buf.view(np.uint8).reshape(-1).copy()), torch.from_numpy(off)
+
+
 def pack_host(results, max_hyp):
     """Pack host-side stage results (lists of person3d arrays) like se3d_pack_stage*_device does on the GPU."""
     n = len(results)

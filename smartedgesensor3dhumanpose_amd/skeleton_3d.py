@@ -222,6 +222,11 @@ class Skeleton3D:
         self._chk(self._L.se3d_pack_stage2_walk_device_slots(C.c_void_p(self._h), int(n_frames), int(slots), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)),
                   "se3d_pack_stage2_walk_device_slots")
 
+    def pack_stage2_walk_device_dense(self, n_frames, capacity, persons_ptr, offsets_ptr):
+        """Published fused persons back to back ([capacity] persons) + [n_frames + 2] int32 offsets (…, written, dropped); asynchronous."""
+        self._chk(self._L.se3d_pack_stage2_walk_device_dense(C.c_void_p(self._h), int(n_frames), int(capacity), C.c_void_p(persons_ptr), C.c_void_p(offsets_ptr)),
+                  "se3d_pack_stage2_walk_device_dense")
+
     def pack_stage2_device(self, n_seq, persons_ptr, counts_ptr):
         """Asynchronous D2D copy of the last run_stage2 results ([n_seq][max_hyp] persons, [n_seq] counts); sync() before use."""
         self._chk(self._L.se3d_pack_stage2_device(C.c_void_p(self._h), int(n_seq), C.c_void_p(persons_ptr), C.c_void_p(counts_ptr)), "se3d_pack_stage2_device")

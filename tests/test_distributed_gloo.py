@@ -30,7 +30,7 @@ def _compute(seq):
     return O.triangulate(rig, pm.Params(pm.POSE_SIMPLE, 0, 0.045), fr, capacity=MAX_HYP, hyp_capacity=MAX_HYP).published().copy()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, form="slots"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -39,9 +39,18 @@ def _worker(rank, world, port, q):
     mine = shard.rank_sequences(N_SEQ, rank, world)
     n_slots = (N_SEQ + world - 1) // world
     results = [_compute(s) for s in mine] + [np.zeros(0, dtype=_compute(0).dtype)] * (n_slots - len(mine))
-    packed, counts = shard.pack_host(results, MAX_HYP)
-    gp, gc = shard.gather_skeletons(dist, packed, counts, MAX_HYP)
-    allp = shard.unpack_skeletons(gp, gc, MAX_HYP)
+    if form == "dense":   # the exchange form of the small workloads: persons back to back + offsets (se3d_pack_stage2_walk_device_dense)
+        packed, offs = shard.pack_host_dense(results, 4 * n_slots)
+        gp, go = shard.gather_skeletons(dist, packed, offs, MAX_HYP)
+        allp = []
+        for r in range(world):
+            persons, dropped = shard.unpack_dense(gp[r], go[r], n_slots)
+            assert dropped == 0
+            allp.append(persons)
+    else:
+        packed, counts = shard.pack_host(results, MAX_HYP)
+        gp, gc = shard.gather_skeletons(dist, packed, counts, MAX_HYP)
+        allp = shard.unpack_skeletons(gp, gc, MAX_HYP)
     # every rank now holds all skeletons: re-assemble in sequence order
     out = {}
     for r in range(world):
@@ -52,12 +61,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sequence_sharding_and_allgather(world):
+@pytest.mark.parametrize("world,form", [(2, "slots"), (4, "slots"), (2, "dense"), (4, "dense")])
+def test_sequence_sharding_and_allgather(world, form):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + 7 * world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + 7 * world + (3 if form == "dense" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, form)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in procs]

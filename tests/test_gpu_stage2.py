@@ -406,6 +406,22 @@ def test_stage2_walk_device_pack(extr_rig, device_buffer):
     u = shard.unpack_skeletons(p.numpy(np.uint8).reshape(1, -1), c.numpy(np.int32).reshape(1, -1), H)[0]
     u6 = shard.unpack_skeletons(p6.numpy(np.uint8).reshape(1, -1), c6.numpy(np.int32).reshape(1, -1), XH)[0]
     assert all(a.tobytes() == b.tobytes() for a, b in zip(u, u6))
+    # dense exchange layout: the persons back to back + offsets; with a capacity that is too small the tail is dropped and counted
+    tot = sum(len(x) for x in u)
+    pd, od = device_buffer(tot * psz), device_buffer(4 * (S_ * T_ + 2))
+    node.pack_stage2_walk_device_dense(S_ * T_, tot, pd.data_ptr(), od.data_ptr())
+    ps, os_ = device_buffer((tot - 7) * psz), device_buffer(4 * (S_ * T_ + 2))
+    node.pack_stage2_walk_device_dense(S_ * T_, tot - 7, ps.data_ptr(), os_.data_ptr())
+    node.sync()
+    ud, dropped = shard.unpack_dense(pd.numpy(np.uint8), od.numpy(np.int32), S_ * T_)
+    assert dropped == 0 and all(a.tobytes() == b.tobytes() for a, b in zip(u, ud))
+    hp, ho = shard.pack_host_dense(u, tot)   # the host twin the gloo tests use writes the same bytes
+    assert hp.numpy().tobytes() == pd.numpy(np.uint8).tobytes() and ho.numpy().tolist() == od.numpy(np.int32).tolist()
+    us, dropped = shard.unpack_dense(ps.numpy(np.uint8), os_.numpy(np.int32), S_ * T_)
+    assert dropped == 7 and sum(len(x) for x in us) == tot - 7
+    assert b"".join(x.tobytes() for x in us) == b"".join(x.tobytes() for x in u)[: (tot - 7) * psz]
+    hp, ho = shard.pack_host_dense(u, tot - 7)
+    assert ho.numpy().tolist() == os_.numpy(np.int32).tolist()
     got = 0
     for k in range(T_):
         r = node.fetch_stage2_walk(k * S_, S_)
