@@ -151,11 +151,12 @@ class SkeletonExchange:
         a checksum of what it sent (sum of counts, byte sum of the persons), the checksums are all-gathered and compared with the
         same sums over the received slices.  Call after finish(); collective (every rank must call it)."""
         self.finish()
-        mine = torch.stack([self.cnts[p].to(torch.int64).sum(), self.packs[p].to(torch.int64).sum()]).to(self.packs[p].device)
+        # (sum(dtype=int64) accumulates in 64 bits without materialising a widened copy: the gathered buffer is GBs at eight ranks)
+        mine = torch.stack([self.cnts[p].sum(dtype=torch.int64), self.packs[p].sum(dtype=torch.int64)]).to(self.packs[p].device)
         allsums = torch.empty(self.world * 2, dtype=torch.int64, device=mine.device)
         self.dist.all_gather_into_tensor(allsums, mine)
         gp, gc = self.gathered(p)
-        got = torch.stack([gc.reshape(self.world, -1).to(torch.int64).sum(1), gp.reshape(self.world, -1).to(torch.int64).sum(1)], 1).reshape(-1)
+        got = torch.stack([gc.reshape(self.world, -1).sum(1, dtype=torch.int64), gp.reshape(self.world, -1).sum(1, dtype=torch.int64)], 1).reshape(-1)
         r = self.dist.get_rank()
         own_ok = torch.equal(gp[r].reshape(-1), self.packs[p]) and torch.equal(gc[r].reshape(-1), self.cnts[p])
         return bool(torch.equal(allsums.cpu(), got.cpu())) and own_ok
