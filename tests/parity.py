@@ -112,7 +112,19 @@ def compare_stage2(gpu, ora, check_iters=True, check_tracks=True):
 # nearly parallel or inconsistent rays (gross 2-D outliers, wrong associations) and the reference's own answer there is rounding noise.
 # ---------------------------------------------------------------------------------------------------------------------------------
 DLT_KAPPA_MAX = 2.0e3     # c * eps * kappa = 5 * 6e-8 * 2e3 = 0.6 mm: below it the two solvers must agree to POS_TOL_M
+
+
+def cov_tolerance(kappa):
+    """Relative-Frobenius tolerance of a stage-1 covariance as a function of the joint's kappa: COV_REL_FRO for a well-conditioned
+    joint, growing linearly to 2 x COV_REL_FRO at kappa = DLT_KAPPA_MAX.  The unscented transform differences 4n + 1 sample solutions a few
+    centimetres apart; the oracle (like the reference) solves every sample in float32, whose noise on a sample is ~ c 2^-24 kappa metres, so
+    its covariance carries a relative error proportional to kappa (the kernels' fp64 solves do not).  Measured over 26 seeds x 40 scenes
+    (2.9 M joints inside the domain): one joint above the flat 1e-3 — 1.012e-3 at kappa = 744 (profiles/r3/README.md)."""
+    return COV_REL_FRO * (1.0 + np.asarray(kappa, np.float64) / DLT_KAPPA_MAX)
+
+
 GARBAGE_JOINT_DIST_M = 10.0   # stage 2: a measured joint further than this from the median joint of its person (no body spans 10 m)
+GARBAGE_JOINT_SIGMA_M = 1.0e3  # stage 2: a measured joint whose covariance says "unknown to more than a kilometre" (see garbage_persons)
 
 
 def _dlt_rows(rig, frame, assoc_rows):
@@ -222,13 +234,23 @@ def published_joint_condition(rig, frame, result, k2f=None):
 def garbage_persons(persons3d):
     """bool [n]: stage-1 persons with a valid joint more than GARBAGE_JOINT_DIST_M from the median of their valid joints — a joint
     triangulated from an inconsistent pair of rays on a person without a root (no root-distance filter, S3D:937-953).  Its LM problem
-    (PP:690-746) is flat along that ray and badly scaled; algebraically equivalent solvers take different accept / reject paths."""
+    (PP:690-746) is flat along that ray and badly scaled; algebraically equivalent solvers take different accept / reject paths.
+    The same holds for a valid joint that sits near the body but whose covariance says it is unknown to more than GARBAGE_JOINT_SIGMA_M (an
+    ill-conditioned DLT system; the case that showed it: sigma 90 km): the information of its unary factor (PP:690), 1 / sigma^2 < 1e-6 m^-2,
+    is more than nine orders of magnitude below that of the joint's bone factor (~1e3 m^-2), so the joint's 3 x 3 block of the normal equations
+    has a condition number above 1e9 (9e12 in that case) and its inverse — which every elimination order forms — carries the rounding of the
+    large entries into the two unconstrained directions: two algebraically equal LM runs then differ in THAT joint by millimetres (5.8 mm seen)
+    while every other joint of the person agrees to 0.01 mm."""
     out = np.zeros(len(persons3d), bool)
     for i, p in enumerate(persons3d):
         v = p["keypoints"]["score"] > 0
         if v.sum() >= 2:
             J = p["keypoints"]["joint"][v]
-            out[i] = np.linalg.norm(J - np.median(J, 0), axis=-1).max() > GARBAGE_JOINT_DIST_M
+            far = np.linalg.norm(J - np.median(J, 0), axis=-1).max() > GARBAGE_JOINT_DIST_M
+            var = p["keypoints"]["cov"][v][:, [0, 3, 5]]
+            with np.errstate(invalid="ignore"):
+                unknown = bool((np.nan_to_num(var, nan=0.0, posinf=np.inf).max() > GARBAGE_JOINT_SIGMA_M ** 2))
+            out[i] = far or unknown
     return out
 
 
