@@ -114,17 +114,39 @@ def compare_stage2(gpu, ora, check_iters=True, check_tracks=True):
 DLT_KAPPA_MAX = 2.0e3     # c * eps * kappa = 5 * 6e-8 * 2e3 = 0.6 mm: below it the two solvers must agree to POS_TOL_M
 
 
-def cov_tolerance(kappa):
-    """Relative-Frobenius tolerance of a stage-1 covariance as a function of the joint's kappa: COV_REL_FRO for a well-conditioned
-    joint, growing linearly to 2 x COV_REL_FRO at kappa = DLT_KAPPA_MAX.  The unscented transform differences 4n + 1 sample solutions a few
-    centimetres apart; the oracle (like the reference) solves every sample in float32, whose noise on a sample is ~ c 2^-24 kappa metres, so
-    its covariance carries a relative error proportional to kappa (the kernels' fp64 solves do not).  Measured over 26 seeds x 40 scenes
-    (2.9 M joints inside the domain): one joint above the flat 1e-3 — 1.012e-3 at kappa = 744 (profiles/r3/README.md)."""
-    return COV_REL_FRO * (1.0 + np.asarray(kappa, np.float64) / DLT_KAPPA_MAX)
+def cov_tolerance(kappa, cov):
+    """Relative-Frobenius tolerance of a stage-1 covariance: COV_REL_FRO + 2 * 2^-24 * kappa / sigma, sigma = sqrt(mean diagonal)
+    of the oracle's covariance `cov` [..., 6].  The unscented transform differences 4n + 1 sample solutions that lie ~sigma apart; the oracle
+    (like the reference) solves every sample in float32, whose noise on a sample is c 2^-24 kappa metres (c: median 0.31, maximum 4.91 over
+    3.1e5 joints, profiles/r3/cond_study.txt), so its covariance carries a relative error of about 2 c 2^-24 kappa / sigma — the kernels' fp64
+    solves have none of it.  The term is below 1e-4 for the bulk of the joints (kappa ~ 20, sigma ~ 2 cm) and decides the rare tail: over
+    86 seeds x 40 scenes (9.5 M asserted joints) three joints exceed the flat 1e-3 for this reason — 1.46e-3 at kappa 62 / sigma 4 mm (19
+    views), 1.01e-3 at kappa 744, 1.2e-3 — all inside this tolerance (profiles/r3/README.md)."""
+    cov = np.asarray(cov, np.float64)
+    with np.errstate(invalid="ignore"):
+        sigma = np.sqrt(np.maximum((cov[..., 0] + cov[..., 3] + cov[..., 5]) / 3.0, 1e-300))
+    return COV_REL_FRO + 2.0 * 2.0 ** -24 * np.asarray(kappa, np.float64) / sigma
+
+
+def covariance_condition(kappa, tables):
+    """kappa [n][17] of the systems a joint's COVARIANCE depends on: its own and — through the limb-length term added to the diagonal, a
+    function of the distance to the parent joint (S3D:866-872; both shoulders in the "simple" model, S3D:875-881) — its parent's.  `kappa` as
+    returned by published_joint_condition (merge partners included, also for joints the published person does not carry: a partner's parent
+    joint may have been removed by the root-distance filter after it inflated the child's covariance; seen: a sane ear with a covariance
+    of (94 km)^2 x I from a partner whose eye lay 62 km away)."""
+    par, L = tables["kpParent"], tables["limbLength"]
+    out = np.array(kappa, np.float64, copy=True)
+    for j in range(pm.NUM_KEYPOINTS):
+        if par[j] >= 0 and L[j] > 0:
+            out[:, j] = np.fmax(out[:, j], kappa[:, par[j]])
+    if tables.get("shoulderDist", 0) > 0 and par[6] >= 0 and not (L[6] > 0):
+        both = np.fmax(kappa[:, 5], kappa[:, 6])
+        out[:, 5], out[:, 6] = np.fmax(out[:, 5], both), np.fmax(out[:, 6], both)
+    return out
 
 
 GARBAGE_JOINT_DIST_M = 10.0   # stage 2: a measured joint further than this from the median joint of its person (no body spans 10 m)
-GARBAGE_JOINT_SIGMA_M = 1.0e3  # stage 2: a measured joint whose covariance says "unknown to more than a kilometre" (see garbage_persons)
+GARBAGE_JOINT_SIGMA_M = 1.0e2  # stage 2: a measured joint whose covariance says "unknown to more than 100 m" (see garbage_persons)
 
 
 def _dlt_rows(rig, frame, assoc_rows):
@@ -231,16 +253,54 @@ def published_joint_condition(rig, frame, result, k2f=None):
     return out
 
 
+def score_allowance(rig, frame, gpu, ora, k2f=None):
+    """Relative allowance [n_persons][17] for the comparison of stage-1 SCORES that comes from the position difference of the two sides.
+    A joint's score is the mean confidence of its views times min(1, g_reproj_error_max_acceptable / err) (S3D:840-844): once the
+    reprojection error err exceeds 0.05 the score carries err's dependence on the triangulated point, and err = mean |proj(X) - x| changes by
+    d / depth per metre of position difference (2e-4 of itself for 0.05 mm at 5 m and err = 0.05; without bound where a ray passes close to a
+    camera centre: err = 74 seen on a two-view joint).  Returned: |err(X_gpu) - err(X_oracle)| / min(...) in fp64 over the usable views of the
+    person's hypothesis — maximum over the full set and, with three or more views, its leave-one-view-out subsets (the outlier rejection may have
+    removed one, S3D:748-838) — where any of those errors comes within 20 % of the threshold or above it; 0 elsewhere (score = mean confidence)."""
+    n = gpu.n_persons
+    k2f = np.array(pm.KP2FUSION_SIMPLE if k2f is None else k2f)
+    rows = gpu.assoc()[gpu.person_hyp[:n]]
+    _, _, use, cf, x, y = _dlt_rows(rig, frame, rows)
+    P = rig.Rt.reshape(rig.n_cam, 3, 4).astype(np.float64)
+    cfd = np.where(use, cf.astype(np.float64), 0.0)
+    errs = []
+    for side in (gpu, ora):
+        X = side.published()["keypoints"]["joint"][:, k2f]
+        Xh = np.concatenate([X, np.ones(X.shape[:-1] + (1,))], -1)
+        pr = np.einsum("cij,pkj->pkci", P, Xh)
+        z = np.where(np.abs(pr[..., 2]) > 1e-150, pr[..., 2], 1e-150)
+        with np.errstate(over="ignore", invalid="ignore"):
+            errs.append(cfd * np.where(use, np.hypot(pr[..., 0] / z - x, pr[..., 1] / z - y), 0.0))     # [n][17][N] confidence-weighted terms
+    out = np.zeros((n, pm.NUM_KEYPOINTS))
+    nv = use.sum(-1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for drop in [None] + list(range(rig.n_cam)):
+            keep = np.ones(rig.n_cam, bool)
+            if drop is not None:
+                keep[drop] = False
+            den = np.maximum((cfd * keep).sum(-1), 1e-150)
+            eg, eo = (errs[0] * keep).sum(-1) / den, (errs[1] * keep).sum(-1) / den
+            lo = np.minimum(eg, eo)
+            rel = np.where(lo > 0, np.abs(eg - eo) / lo, 0.0)
+            applies = (np.maximum(eg, eo) > 0.8 * 0.05) & (nv >= (2 if drop is None else 3)) & (True if drop is None else use[..., drop])
+            out = np.where(applies, np.fmax(out, rel), out)
+    return np.nan_to_num(out, nan=0.0, posinf=np.inf)
+
+
 def garbage_persons(persons3d):
     """bool [n]: stage-1 persons with a valid joint more than GARBAGE_JOINT_DIST_M from the median of their valid joints — a joint
     triangulated from an inconsistent pair of rays on a person without a root (no root-distance filter, S3D:937-953).  Its LM problem
     (PP:690-746) is flat along that ray and badly scaled; algebraically equivalent solvers take different accept / reject paths.
     The same holds for a valid joint that sits near the body but whose covariance says it is unknown to more than GARBAGE_JOINT_SIGMA_M (an
-    ill-conditioned DLT system; the case that showed it: sigma 90 km): the information of its unary factor (PP:690), 1 / sigma^2 < 1e-6 m^-2,
-    is more than nine orders of magnitude below that of the joint's bone factor (~1e3 m^-2), so the joint's 3 x 3 block of the normal equations
-    has a condition number above 1e9 (9e12 in that case) and its inverse — which every elimination order forms — carries the rounding of the
-    large entries into the two unconstrained directions: two algebraically equal LM runs then differ in THAT joint by millimetres (5.8 mm seen)
-    while every other joint of the person agrees to 0.01 mm."""
+    ill-conditioned DLT system): the information of its unary factor (PP:690), 1 / sigma^2 < 1e-4 m^-2, is more than seven orders of magnitude
+    below that of the joint's bone factor (~1e3 m^-2), so the joint's 3 x 3 block of the normal equations has a condition number above 1e7 and
+    its inverse — which every elimination order forms — carries the rounding of the large entries into the two unconstrained directions.  Seen:
+    sigma 90 km (condition 9e12) — two algebraically equal LM runs differ in THAT joint by 5.8 mm while every other joint of the person agrees to
+    0.006 mm; sigma 761 m — positions equal to 1e-14 m, the joint's marginal covariance differs by 1.2e-4 (tolerance 1e-4)."""
     out = np.zeros(len(persons3d), bool)
     for i, p in enumerate(persons3d):
         v = p["keypoints"]["score"] > 0
