@@ -128,6 +128,20 @@ def cov_tolerance(kappa, cov):
     return COV_REL_FRO + 2.0 * 2.0 ** -24 * np.asarray(kappa, np.float64) / sigma
 
 
+COV_SIGMA_MAX_M = 1.0   # covariance assertion: joints whose oracle covariance stays below (1 m)^2 on the diagonal
+
+
+def covariance_in_hall(cov):
+    """bool [...]: the covariance `cov` [..., 6] says the joint is known to better than COV_SIGMA_MAX_M.  The unscented transform's samples
+    of a joint with a larger covariance land metres to tens of metres away from where the rays converge; THOSE systems are ill-conditioned
+    (kappa grows with 1 + |X|^2) whatever the base system's kappa is, and the reference's float32 solves of them are noise at the 1e-3 level
+    (seen at 32 / 48 cameras with 12 - 24 persons: spurious persons with sigma 30 - 50 m, base kappa 59 - 1150, covariances 1.3e-3 - 7.9e-3 apart,
+    positions within 0.05 mm).  Such joints leave the covariance assertion (counted), not the position / score assertions."""
+    cov = np.asarray(cov, np.float64)
+    with np.errstate(invalid="ignore"):
+        return np.nan_to_num(np.maximum(np.maximum(cov[..., 0], cov[..., 3]), cov[..., 5]), nan=np.inf) < COV_SIGMA_MAX_M ** 2
+
+
 def covariance_condition(kappa, tables):
     """kappa [n][17] of the systems a joint's COVARIANCE depends on: its own and — through the limb-length term added to the diagonal, a
     function of the distance to the parent joint (S3D:866-872; both shoulders in the "simple" model, S3D:875-881) — its parent's.  `kappa` as
@@ -250,6 +264,14 @@ def published_joint_condition(rig, frame, result, k2f=None):
             dist = np.linalg.norm(X[h2][both] - kp["joint"][i][both], axis=-1)
             if np.median(dist) < 0.5 or dist.min() < 0.02:     # close as a whole, or a joint that was taken over as it is
                 out[i] = np.where(have2, np.fmax(out[i], kap[h2]), out[i])
+    # A published joint that neither the person's own hypothesis nor a recognised partner carries (crowded scenes: chains of merges, a
+    # partner whose fp64 points lie far from the float32 ones) was taken over from SOME later unpublished hypothesis: the largest kappa among
+    # those that have the joint (conservative: the joint is asserted only if all candidates are well-conditioned)
+    for i in range(n):
+        for j in np.nonzero(np.isnan(out[i]) & (kp["score"][i] > 0))[0]:
+            cand = [kap[h2][j] for h2 in np.nonzero(~pub)[0] if h2 > hyp[i] and not np.isnan(kap[h2][j])]
+            if cand:
+                out[i, j] = max(cand)
     return out
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The randomised parity sweep as a tool over every seed used in the round (GPU box): one JSON report per line into $1
-# (default gpurun_out/fuzz_parity.log).  89 runs x 40 scenes, ~13 s each.  The suite asserts the same comparison on ten of the seeds
+# (default gpurun_out/fuzz_parity.log).  89 runs x 40 scenes (~13 s each) + 40 runs x 20 large-rig scenes (~17 s each).  The suite asserts the same comparison on ten of the seeds
 # (tests/test_gpu_fuzz_parity.py); the criteria are tests/parity.py's.
 OUT=${1:-gpurun_out/fuzz_parity.log}
 mkdir -p "$(dirname "$OUT")"
@@ -9,12 +9,14 @@ for s in 4 15 37 39 0 1 2 3 $(seq 101 112) $(seq 201 206) $(seq 301 340); do tim
 for s in 5 $(seq 341 350); do FUZZ_POSE=h36m timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
 for s in 6 $(seq 351 360); do FUZZ_NORM_HEIGHT=1 timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
 FUZZ_POSE=h36m FUZZ_NORM_HEIGHT=1 timeout 300 python tools/fuzz_parity.py 7 40 2>> "$OUT.err" | tail -1 >> "$OUT"
+# large rigs (32 / 48 cameras, 12 - 24 persons: rows pair kernel with column chunks, per-camera sweep, per-joint triangulation, per-step stage 2)
+for s in $(seq 1001 1040); do FUZZ_LARGE=1 timeout 600 python tools/fuzz_parity.py $s 20 2>> "$OUT.err" | tail -1 >> "$OUT"; done
 python3 - "$OUT" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
 bad = [r["seed"] for r in rows if r["joints_over_1mm"] or r["scores_over_rtol"] or r["cov_over_tol"] or r["stage2_numeric_failures"] or r["stage2_index_divergences"]]
 tot = lambda k: sum(r[k] for r in rows)
-print("runs %d, joints %d (excluded %d, covariance-only excluded %d), over 1 mm %d, scores %d, covariances %d (over the flat 1e-3: %d), sequence-steps %d (excluded %d), stage-2 numeric %d, index %d; runs with a miss: %s"
-      % (len(rows), tot("joints"), tot("joints_excluded"), tot("cov_excluded_by_parent"), tot("joints_over_1mm"), tot("scores_over_rtol"), tot("cov_over_tol"), tot("cov_over_flat_1e-3"),
+print("runs %d, joints %d (excluded %d, covariance-only excluded %d by the parent's system + %d by sigma > 1 m), over 1 mm %d, scores %d, covariances %d (over the flat 1e-3: %d), sequence-steps %d (excluded %d), stage-2 numeric %d, index %d; runs with a miss: %s"
+      % (len(rows), tot("joints"), tot("joints_excluded"), tot("cov_excluded_by_parent"), tot("cov_excluded_by_sigma"), tot("joints_over_1mm"), tot("scores_over_rtol"), tot("cov_over_tol"), tot("cov_over_flat_1e-3"),
          tot("seq_steps"), tot("seq_steps_excluded"), tot("stage2_numeric_failures"), tot("stage2_index_divergences"), bad))
 PY
