@@ -111,6 +111,7 @@ def compare_stage2(gpu, ora, check_iters=True, check_tracks=True):
 # kappa >= DLT_KAPPA_MAX is the exclusion set of the < 1 mm / 1e-3 assertions: such joints are triangulated far outside the hall from
 # nearly parallel or inconsistent rays (gross 2-D outliers, wrong associations) and the reference's own answer there is rounding noise.
 # ---------------------------------------------------------------------------------------------------------------------------------
+BRANCH_TIE_REL = 1.0e-6   # relative distance of a reprojection error from a decision threshold of the outlier rejection below which the joint is excluded
 DLT_KAPPA_MAX = 2.0e3     # c * eps * kappa = 5 * 6e-8 * 2e3 = 0.6 mm: below it the two solvers must agree to POS_TOL_M
 
 
@@ -230,11 +231,34 @@ def dlt_condition(rig, frame, assoc_rows, want_points=False):
         e = np.hypot(pr[..., 0] / z - x, pr[..., 1] / z - y)
         cfd = cf.astype(np.float64)
         err = (cfd * np.where(use, e, 0.0)).sum(-1) / np.maximum(cfd.sum(-1), 1e-150)
+    def sub_err(p, k, Xc, keep):     # confidence-weighted reprojection error of a point over a subset of the joint's views (S3D:425-438), fp64
+        prc = P @ np.append(Xc, 1.0)
+        zc = np.where(np.abs(prc[:, 2]) > 1e-150, prc[:, 2], 1e-150)
+        with np.errstate(over="ignore", invalid="ignore"):
+            ec = np.hypot(prc[:, 0] / zc - x[p, k], prc[:, 1] / zc - y[p, k])
+        w = cfd[p, k] * keep
+        return float((w * np.where(keep > 0, ec, 0.0)).sum() / max(w.sum(), 1e-150))
     for p, k in zip(*np.nonzero(~(err <= 0.8 * 0.05) & (nv >= 3))):
+        errs_loo = []
         for c in np.nonzero(use[p, k])[0]:
             kk_u, _ = _kappa_from_gram(Gu[p, k] - outer[p, k, c])
-            kk_w, _ = _kappa_from_gram(Gw[p, k] - outer[p, k, c] * w2[p, k, c])
+            kk_w, Xc = _kappa_from_gram(Gw[p, k] - outer[p, k, c] * w2[p, k, c])
             kappa[p, k] = max(kappa[p, k], kk_u, kk_w)
+            keep = use[p, k].astype(np.float64)
+            keep[c] = 0.0
+            errs_loo.append(sub_err(p, k, Xc, keep))
+        # Branch ties (the reference's decisions are discontinuous): the error against g_reproj_error_max_acceptable (S3D:748), the best
+        # leave-one-view-out error against 0.9 x error (S3D:830), two candidates for "best".  Within BRANCH_TIE_REL of a threshold the float32
+        # terms of the two sides decide differently and the results are different points (seen: err = 0.050000002, 368 mm) — excluded.
+        e0 = float(err[p, k])
+        tie = abs(e0 - 0.05) <= BRANCH_TIE_REL * 0.05
+        if nv[p, k] >= 4 and e0 > 0.05 * (1.0 - BRANCH_TIE_REL):
+            se = np.sort(np.array(errs_loo))
+            tie = tie or abs(se[0] - 0.9 * e0) <= BRANCH_TIE_REL * 0.9 * e0
+            if len(se) > 1 and se[0] < 0.9 * e0 * (1.0 + BRANCH_TIE_REL):
+                tie = tie or (se[1] - se[0]) <= BRANCH_TIE_REL * se[0]
+        if tie:
+            kappa[p, k] = np.inf
     kappa = np.where(nv >= 2, kappa, np.nan)
     return (kappa, X) if want_points else kappa
 
