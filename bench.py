@@ -750,7 +750,7 @@ def roofline_of(res, w, stage2, source):
             "kernel_ms_per_step": {k: round(v, 5) for k, v in per_step_ms.items()}}
 
 
-def valu_of(res, w, stage2, pmc):
+def valu_of(res, w, stage2, pmc, mix=None, kernel=None):
     """Vector-ALU roofline (SURVEY 8d asks for both): algorithmic flops per skeleton x skeletons/s against the fp32 vector peak."""
     it = res.get("lm_iterations_mean") or 0.0
     flop = w["flop_s1"]
@@ -767,6 +767,23 @@ def valu_of(res, w, stage2, pmc):
         if cyc > 0:
             out["measured_valu_issue_utilisation"] = round(sum(k["counters_per_launch"]["SQ_INSTS_VALU"] * k["launches"] for k in ks) * 2.0 / (1024.0 * cyc), 4)
             out["measured_source"] = pmc.get("_file", "profiles") + ": " + pmc.get("note", "")
+    if mix and mix[0] and mix[1]:   # committed instruction-mix passes (tools/profile_r3.sh valumix, tools/valumix.py): the dominant kernel priced by type
+        a, b = mix[0]["kernels"].get(kernel), mix[1]["kernels"].get(kernel)
+        if a and b:
+            c = dict(a["counters_per_launch"])
+            c.update(b["counters_per_launch"])
+            g = lambda n_: c.get("SQ_INSTS_VALU_" + n_, 0.0)
+            m = {"f64": g("ADD_F64") + g("MUL_F64") + g("FMA_F64"), "trans_f64": g("TRANS_F64"), "f32": g("ADD_F32") + g("MUL_F32") + g("FMA_F32"), "trans_f32": g("TRANS_F32"),
+                 "cvt": g("CVT"), "int32": g("INT32"), "int64": g("INT64")}
+            m["other"] = c.get("SQ_INSTS_VALU", 0.0) - sum(m.values())
+            cost = {"f64": 4, "trans_f64": 16, "f32": 2, "trans_f32": 8, "cvt": 4, "int32": 2, "int64": 4, "other": 2}   # issue cycles of a wave64 instruction on a SIMD
+            cyc = a["kernel_cycles"]
+            out["dominant_kernel_issue_model"] = {
+                "kernel": kernel, "issue_frac": round(sum(m[x] * cost[x] for x in m) / 1024.0 / cyc, 4),
+                "fp64_share_of_kernel_cycles": round(m["f64"] * 4 / 1024.0 / cyc, 4),
+                "fp64_tflops": round((g("ADD_F64") + g("MUL_F64") + 2 * g("FMA_F64")) * 64 / (a["avg_us"] * 1e-6) / 1e12, 2), "fp64_vector_peak_tflops": 78.6,
+                "wave_instructions_M": {x: round(m[x] / 1e6) for x in m},
+                "source": mix[0].get("_file", "profiles") + " + " + mix[1].get("_file", "profiles") + " (vector-ALU instruction counters of the serial pass, priced at their issue cost)"}
     return out
 
 
@@ -918,7 +935,8 @@ def main():
         tr = load("pmc_traffic_%s_serial.json" % headline)   # committed PMC passes of `bench.py --serial` (tools/profile_bench.sh)
         if tr and serial and serial["S"] == tr.get("sequences"):
             roof["traffic"] = tr["kernels"].get(roof["kernel"], {}).get("hbm_bytes_per_launch_corrected")
-        roof["valu"] = valu_of(main_res, w, stage2, load("pmc_sq_%s_serial.json" % headline))
+        roof["valu"] = valu_of(main_res, w, stage2, load("pmc_sq_%s_serial.json" % headline),
+                               (load("pmc_valumix64_%s_serial.json" % headline), load("pmc_valumix32_%s_serial.json" % headline)), roof.get("kernel"))
         line = {
             "metric": "3D skeletons/sec (triangulated + refined) + mm MPJPE vs the CPU oracle (`parity`), 16cam/6p (`value`) and 256cam/128p (`secondary`)",
             "value": round(main_res["value"], 2), "unit": "skeletons/s", "n_gpus": world, "steps": main_res["steps"], "warmup": main_res["warmup"],
