@@ -120,7 +120,8 @@ def cov_tolerance(kappa, cov):
     of the oracle's covariance `cov` [..., 6].  The unscented transform differences 4n + 1 sample solutions that lie ~sigma apart; the oracle
     (like the reference) solves every sample in float32, whose noise on a sample is c 2^-24 kappa metres (c: median 0.31, maximum 4.91 over
     3.1e5 joints, profiles/r3/cond_study.txt), so its covariance carries a relative error of about 2 c 2^-24 kappa / sigma — the kernels' fp64
-    solves have none of it.  The term is below 1e-4 for the bulk of the joints (kappa ~ 20, sigma ~ 2 cm) and decides the rare tail: over
+    solves have none of it (CPU study of 46 k joints, profiles/r3/cond_study.txt: the oracle's deviation from the exact unscented transform divided
+    by 2^-24 kappa / sigma has median 0.27 and 99th percentile 1.45; its far tail is the large-sigma joints of covariance_in_hall).  The term is below 1e-4 for the bulk of the joints (kappa ~ 20, sigma ~ 2 cm) and decides the rare tail: over
     86 seeds x 40 scenes (9.5 M asserted joints) three joints exceed the flat 1e-3 for this reason — 1.46e-3 at kappa 62 / sigma 4 mm (19
     views), 1.01e-3 at kappa 744, 1.2e-3 — all inside this tolerance (profiles/r3/README.md)."""
     cov = np.asarray(cov, np.float64)
