@@ -239,3 +239,16 @@ def test_shard_pack_unpack_roundtrip():
             g = np.stack([shard.pack_own(x, r, world) for r in range(world)])
             assert g.shape[2] == shard.shard_slots(H, world)
             assert np.array_equal(shard.unpack_all(g, H), x)
+
+
+def test_bench_guard_reports_exceptions_and_deadlines():
+    """bench.guarded (the wrapper of the hypothesis-shard block, which runs last so that a failure of that mode cannot lose the scaling
+    line): result, exception text, deadline."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.guarded(lambda: 41 + 1, 5.0, "block") == (42, None, False)
+    res, err, hung = bench.guarded(lambda: 1 // 0, 5.0, "block")
+    assert res is None and "ZeroDivisionError" in err and not hung
+    res, err, hung = bench.guarded(lambda: time.sleep(1.5), 0.1, "block")
+    assert res is None and "did not finish" in err and hung
