@@ -289,6 +289,18 @@ int se3d_get_fusion_constants(se3d_ctx *ctx, int32_t *indices22, double *vel_sig
  * float of the range, the quotient on n_div pseudo-random operand pairs — and returns the mismatch counts (expected: 0, 0). */
 int se3d_selftest_exact_math(se3d_ctx *ctx, uint64_t n_div, uint64_t *sqrt_mismatches, uint64_t *div_mismatches);
 
+/* --- diagnostic self-test (round 4): the float32 DLT solve of the triangulation's second pass — triangulate() + calcReprojectionError()
+ * (S3D:425-465) with the reference's arithmetic: Eigen 3.3 JacobiSVD of the float rows (scaling, ColPivHouseholderQR preconditioner unless
+ * the system is 4 x 4, two-sided Jacobi sweeps), every sum sequential, IEEE division / square root, no FMA — on n_sys caller systems of
+ * n_views views each: Rt [n_sys][n_views][12] camera matrices, pts [n_sys][n_views][3] (x, y, conf) in normalised image coordinates.
+ * X_out [n_sys][3], err_out [n_sys] (confidence-weighted reprojection error).  Bit-identical to the same sequence on any IEEE-754 host. */
+int se3d_selftest_dlt32(se3d_ctx *ctx, int32_t n_sys, int32_t n_views, const float *Rt, const float *pts, int32_t weight_by_conf, float *X_out, double *err_out);
+
+/* --- diagnostic accessor (round 4): the joints the last triangulation pass of this context (se3d_run_stage1 / _phases / se3d_triangulate* /
+ * se3d_run_dlt) handed to the float32-exact second pass: entries[i] = (frame * max_hyp + hypothesis) << 5 | input joint index (order not
+ * defined), *n_entries = their number (may exceed capacity), *total (optional) = running total since se3d_create. */
+int se3d_get_exact_list(se3d_ctx *ctx, uint32_t *entries, int32_t capacity, int32_t *n_entries, int64_t *total);
+
 /* --- device-side result access for multi-GPU exchange (RCCL all-gather of final skeletons) -------------
  * Enqueue, on the context stream, device-to-device copies of the results of the last run into caller-provided DEVICE
  * memory (e.g. torch tensors): persons as [n][max_hyp] se3d_person3d (valid entries first) and counts as [n] int32,

@@ -353,7 +353,14 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
   ok = ok && dev_alloc(c, &D.pair, (size_t)B * D.d.pair_stride * P * P);
   ok = ok && dev_alloc(c, &D.assoc, (size_t)B * H * N) && dev_alloc(c, &D.nviews, (size_t)B * H);
   ok = ok && dev_alloc(c, &D.C, (size_t)B * H * P) && dev_alloc(c, &D.mask, (size_t)B * H * P) && dev_alloc(c, &D.mwork, (size_t)B * H * P);
-  ok = ok && dev_alloc(c, &D.tri_slow, (size_t)B * H * 4);
+  {  // second pass of the triangulation (float32-exact solves of the flagged joints, se3d_k_triangulate_exact): list, counter, workspaces
+    const size_t per_wave = (size_t)64 * 8 * N * sizeof(float), joints = (size_t)B * H * SE3D_NKP;
+    D.d.exact = 1;
+    // one wavefront per 4 joints of the batch (the list is short: 0.1 % of the joints on clean scenes), 16 .. 4096 (16 per CU), <= 128 MB
+    D.d.tri_waves = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(4096, std::max<size_t>(16, joints / 4)), ((size_t)128 << 20) / per_wave));
+    ok = ok && dev_alloc(c, &D.tri_list, joints) && dev_alloc(c, &D.tri_cnt, (size_t)4) && dev_alloc(c, &D.tri_ws, (size_t)D.d.tri_waves * 64 * 8 * N);
+    if (ok && !c->dry) ok = hip_ok(c, hipMemset(D.tri_cnt, 0, 4 * sizeof(uint32_t)), "hipMemset (tri_cnt)");
+  }
   ok = ok && dev_alloc(c, &D.hypP, (size_t)B * H) && dev_alloc(c, &D.keep, (size_t)B * H);
   ok = ok && slab_build(c, c->sl_out1, [&](SlabCarver &m) {
     m.take(&D.out_count, &c->h_count, (size_t)B);
@@ -1476,6 +1483,47 @@ int se3d_selftest_exact_math(se3d_ctx *c, uint64_t n_div, uint64_t *sqrt_mismatc
   (void)hipFree(d);
   HIPCHK(c, e);
   *sqrt_mismatches = h[0]; *div_mismatches = h[1];
+  return SE3D_OK;
+}
+
+// Diagnostic: the second pass's float32 DLT solve on caller systems (se3d_k_selftest_dlt32).
+extern "C" hipError_t se3d_launch_selftest_dlt32(int n_sys, int n, const float *d_Rt, const float *d_pts, int weighted, float *d_ws, float *d_X, double *d_err, hipStream_t st);
+int se3d_selftest_dlt32(se3d_ctx *c, int32_t n_sys, int32_t n_views, const float *Rt, const float *pts, int32_t weight_by_conf, float *X_out, double *err_out) {
+  if (!c || n_sys < 1 || n_views < 2 || n_views > SE3D_MAX_CAMS || !Rt || !pts || !X_out || !err_out) return SE3D_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nb = (size_t)(n_sys + 63) / 64;
+  float *d_Rt = nullptr, *d_pts = nullptr, *d_ws = nullptr, *d_X = nullptr;
+  double *d_err = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_Rt), sizeof(float) * 12 * n_views * n_sys);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_pts), sizeof(float) * 3 * n_views * n_sys);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_ws), sizeof(float) * nb * 64 * 8 * n_views);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_X), sizeof(float) * 3 * n_sys);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_err), sizeof(double) * n_sys);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_Rt, Rt, sizeof(float) * 12 * n_views * n_sys, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pts, pts, sizeof(float) * 3 * n_views * n_sys, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = se3d_launch_selftest_dlt32(n_sys, n_views, d_Rt, d_pts, weight_by_conf, d_ws, d_X, d_err, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(X_out, d_X, sizeof(float) * 3 * n_sys, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(err_out, d_err, sizeof(double) * n_sys, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_Rt); (void)hipFree(d_pts); (void)hipFree(d_ws); (void)hipFree(d_X); (void)hipFree(d_err);
+  HIPCHK(c, e);
+  return SE3D_OK;
+}
+
+// Diagnostic: the joints the last triangulation pass of this context handed to the float32-exact second pass.
+int se3d_get_exact_list(se3d_ctx *c, uint32_t *entries, int32_t capacity, int32_t *n_entries, int64_t *total) {
+  if (!c || !n_entries || capacity < 0 || (capacity > 0 && !entries)) return SE3D_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t h[4] = {0, 0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(h, c->D.tri_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_entries = (int32_t)h[0];
+  if (total) *total = (int64_t)h[1];
+  const size_t n = std::min<size_t>((size_t)h[0], (size_t)capacity);
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(entries, c->D.tri_list, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   return SE3D_OK;
 }
 

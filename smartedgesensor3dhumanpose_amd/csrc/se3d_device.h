@@ -29,6 +29,9 @@ struct Se3dDims {
   int shard_rank, shard_world;  // hypothesis shard (se3d_set_shard): this context triangulates hypotheses h with h % world == rank
   int pair_stride;              // pair slots per frame of `pair`: npairs (whole table) or 2 x the largest column chunk (se3d_pair_plan)
   int pair_chunks;              // 0: the whole pair table is materialised; m >= 2: camera-column chunks (large rigs), see Se3dPairPlan
+  int exact;                    // 1 (default): joints the triangulation flags are redone with the reference's float32 arithmetic (se3d_exact32.h);
+                                // 0 (SE3D_EXACT=0, A/B evidence): round 3's behaviour, outlier rejection by fp64 rank updates
+  int tri_waves;                // wavefronts of se3d_k_triangulate_exact (one lane-interleaved workspace each in tri_ws)
 };
 
 // Column chunks of the pair table (large rigs, round 3).  Camera step b of the sweep (S3D:588-674) reads only the blocks (a, b), a < b —
@@ -102,7 +105,9 @@ struct Se3dDev {
   // triangulation + output
   se3d_person3d *hypP;   // [B][H]
   uint8_t *keep;         // [B][H]
-  uint32_t *tri_slow;    // [B][H][4] joints of a hypothesis (per workgroup of the hypothesis kernel: up to 4 parts) that need the outlier-rejection path
+  uint32_t *tri_list;    // [B * H * 17] (frame * H + hypothesis) << 5 | joint of every joint the fast triangulation kernels hand to the second pass
+  uint32_t *tri_cnt;     // [4]: entries of tri_list of the current launch; [1]: running total (statistics, se3d_get_exact_stats); [2]: joints triangulated
+  float *tri_ws;         // [tri_waves][8 N][64] lane-interleaved rows x 4 workspaces of the float32 solves
   se3d_person3d *outP;   // [B][H]
   int32_t *out_count;    // [B]
   int32_t *out_hyp;      // [B][H]

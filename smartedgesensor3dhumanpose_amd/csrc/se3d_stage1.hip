@@ -9,6 +9,7 @@
 #include <type_traits>
 #include "se3d_device.h"
 #include "se3d_munkres.h"
+#include "se3d_exact32.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -1405,7 +1406,7 @@ __device__ __forceinline__ double se3d_rcp64(double x) {
 #define SE3D_MAIN_PTOL 1e-10   // main solves: update below 1e-10 (1 + |p|_1); the accepted iterate is one contraction (lambda_4 / lambda_3 <= ~1e-2) better, i.e.
                                // <= 1e-12 and typically 1e-14 .. 1e-16: converged for a point that is published as float32 (1e-13 cost one more step for nothing)
 template <int NW = 1>
-__device__ __forceinline__ bool se3d_null_invit_point(const double g[10], const double v0[4], double p[3], const double tol = SE3D_SIGMA_PTOL) {
+__device__ __forceinline__ bool se3d_null_invit_point(const double g[10], const double v0[4], double p[3], const double tol = SE3D_SIGMA_PTOL, double *piv = nullptr /* [4]: the LDL^T pivots */) {
   const double tr = g[0] + g[4] + g[7] + g[9];
   const double tiny = 1e-30 * tr;
   double d0 = g[0];
@@ -1424,6 +1425,7 @@ __device__ __forceinline__ bool se3d_null_invit_point(const double g[10], const 
   const double l32 = t32 * i2;
   double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, t31, __builtin_fma(-l30, g[3], g[9])));
   if (!(d3 > tiny)) d3 = tiny;  // numerically singular: the solve still returns the null direction
+  if (piv) { piv[0] = d0; piv[1] = d1; piv[2] = d2; piv[3] = d3; }
   const double i3 = se3d_rcp64<NW>(d3);
   double x0 = v0[0], x1 = v0[1], x2 = v0[2], x3 = v0[3];
   double q0 = 0.0, q1 = 0.0, q2 = 0.0;
@@ -1455,6 +1457,79 @@ __device__ __forceinline__ void se3d_solve_point(const double g[10], const doubl
   se3d_eig4_smallest(g, e4);
   const double iw = se3d_rcp64<NW>(e4[3]);
   p[0] = e4[0] * iw; p[1] = e4[1] * iw; p[2] = e4[2] * iw;
+}
+
+// ---- which joints leave the fp64 fast path (round 4) -------------------------------------------------------------------------------------
+// The reference solves every DLT system in float32 (S3D:456); the fp64 solves here agree with it to c 2^-24 kappa metres,
+// kappa = (1 + |X|^2) s1 / (s3 - s4) over the singular values of the 2n x 4 system (c <= 4.9 over 3e5 joints, profiles/r3/cond_study.txt).
+// se3d_kappa_flag tests an UPPER bound of kappa from what a lane has in registers — the Gram matrix g and the solution p:
+//   lambda4 <= Rayleigh quotient of (p, 1);  s1 <= sqrt(trace);  lambda3 >= the smallest root of the characteristic polynomial deflated by
+//   lambda4, a cubic with three positive roots, approached from below (b3 / b2 <= lambda3 because 1/l1 + 1/l2 + 1/l3 = b2 / b3; left of its
+//   smallest root the cubic is increasing and concave, so Newton steps from there never pass the root).
+// Measured on 3.8e5 joints (tools/study/kappa_bound_study.py, profiles/r4/kappa_bound_study.txt): bound / kappa between 1.01 and 1.7 (median
+// 1.25) with two Newton steps.  A joint whose bound reaches SE3D_EXACT_KAPPA is redone by se3d_k_triangulate_exact with the reference's float32 arithmetic; the
+// worst float32-vs-fp64 deviation among the joints that stay here was 0.055 mm in that study (the contract is 1 mm).
+#define SE3D_EXACT_KAPPA 1.0e3
+// Decisions of the outlier rejection (S3D:748-844) compare the reprojection error with g_reproj_error_max_acceptable; an error within this
+// relative band below the threshold (or above it) is re-evaluated in float32 too: the two solvers' points differ by < 0.1 mm on a joint that
+// passed the kappa test, i.e. by < 1e-3 of 0.05 in the error for a camera 2 m away.
+#define SE3D_EXACT_ERR_GUARD 0.01
+// A joint whose unscented-transform covariance comes out with a variance above (1 m)^2 is redone in float32 as well: its sigma samples land
+// metres to tens of metres from where the rays converge, THOSE systems are ill conditioned whatever the base system's kappa is (seen in round 3
+// on spurious persons of crowded scenes: base kappa 59 - 1150, sigma 30 - 50 m, float32 and fp64 covariances 1.3e-3 - 7.9e-3 apart).
+#define SE3D_EXACT_VAR_MAX 1.0
+// Evaluated in float32 (half the issue cost of fp64 on this chip): only lambda3 ~ 1e-2 .. 1e-4 of the trace and the gap to lambda4 matter, the
+// threshold is met with a margin of 18 x, and the study above gives the same flags for the float32 and the fp64 evaluation (lambda3 from the
+// second-order bound b3 / sqrt(b2^2 - 2 b1 b3) <= lambda3 — 1/l1^2 + 1/l2^2 + 1/l3^2 = (b2^2 - 2 b1 b3) / b3^2 — instead of Newton steps;
+// bound / kappa 1.04 .. 2.1, median 1.4).  ~90 float operations, no division: kappa < K  <=>  (1 + |p|^2)^2 trace < K^2 (s3 - s4)^2.
+// Returns true when the joint must go to the second pass.
+__device__ __forceinline__ bool se3d_kappa_flag(const float g[10], float p0, float p1, float p2) {
+  // g packed: 00 01 02 03 11 12 13 22 23 33
+  const float a = g[0], b = g[1], c = g[2], d = g[3], e = g[4], f = g[5], h = g[6], i = g[7], k = g[8], l = g[9];
+  const float c1 = (a + e) + (i + l);
+  const float m12 = fmaf(e, i, -f * f), m13 = fmaf(e, l, -h * h), m23 = fmaf(i, l, -k * k);
+  const float c2 = (fmaf(a, e, -b * b) + fmaf(a, i, -c * c)) + (fmaf(a, l, -d * d) + m12) + (m13 + m23);
+  const float M012 = fmaf(c, fmaf(b, f, -c * e), fmaf(-b, fmaf(b, i, -c * f), a * m12));
+  const float M013 = fmaf(d, fmaf(b, h, -d * e), fmaf(-b, fmaf(b, l, -d * h), a * m13));
+  const float M023 = fmaf(d, fmaf(c, k, -d * i), fmaf(-c, fmaf(c, l, -d * k), a * m23));
+  const float M123 = fmaf(h, fmaf(f, k, -h * i), fmaf(-f, fmaf(f, l, -h * k), e * m23));
+  const float c3 = (M012 + M013) + (M023 + M123);
+  // Rayleigh quotient of v = (p, 1): an upper bound of lambda4
+  const float w0 = fmaf(a, p0, fmaf(b, p1, fmaf(c, p2, d)));
+  const float w1 = fmaf(b, p0, fmaf(e, p1, fmaf(f, p2, h)));
+  const float w2 = fmaf(c, p0, fmaf(f, p1, fmaf(i, p2, k)));
+  const float w3 = fmaf(d, p0, fmaf(h, p1, fmaf(k, p2, l)));
+  const float vv = fmaf(p0, p0, fmaf(p1, p1, fmaf(p2, p2, 1.0f)));
+  const float lam4 = fmaxf(fmaf(w0, p0, fmaf(w1, p1, fmaf(w2, p2, w3))) * __builtin_amdgcn_rcpf(vv), 0.f);
+  const float b1 = c1 - lam4, b2 = fmaf(-lam4, b1, c2), b3 = fmaf(-lam4, b2, c3);
+  const float t = fmaf(b2, b2, -2.0f * (b1 * b3));
+  const float x = b3 * __builtin_amdgcn_rsqf(t);                       // <= lambda3
+  const float gap2 = (x + lam4) - 2.0f * __builtin_amdgcn_sqrtf(x * lam4);   // (s3 - s4)^2
+  const float lhs = (vv * vv) * c1;
+  const bool fine = t > 0.f && b3 > 0.f && x > lam4 && lhs < (float)(SE3D_EXACT_KAPPA * SE3D_EXACT_KAPPA) * gap2;
+  return !fine;
+}
+// Level 1 of the conditioning test: a SUFFICIENT condition for "both systems of the joint are well conditioned" from what the weighted solve
+// leaves in registers — twelve fp64 multiplications, no division, no square root — so that se3d_kappa_flag (~90 operations: 4.8 % of the
+// hypothesis kernel when every joint took it, profiles/r4/README.md) runs only for the joints that fail it (1.4 % on the benchmark's scenes,
+// 13 % on the randomised sweep's).  g: weighted Gram matrix, piv: its LDL^T pivots, p: the solution, n: usable views (confidences in
+// [0.30, 1]: S3D:725 and the caller's check).  With B the leading 3 x 3 block (eigenvalues mu1 >= mu2 >= mu3, interlacing lambda3 >= mu3):
+//   lambda3(Gw) >= mu3 >= det B / (mu1 mu2) >= 4 d0 d1 d2 / tr(B)^2;     lambda4(Gw) <= x^T Gw x / |x|^2 at x = (p*, 1) = d3 / (1 + |p*|^2);
+//   Gu - Gw = sum (1 - c_i^2) row row^T >= 0 and Gu <= Gw / 0.09:  lambda3(Gu) >= lambda3(Gw), lambda4(Gu) <= 11.2 lambda4(Gw), tr(Gu) = 2 n.
+// If 200 d3 / vv <= lambda3_lb (so that s4 <= s3 / 4 for both systems, 10 % slack for p* vs p) then (s3 - s4)^2 >= 9/16 lambda3_lb and
+// kappa^2 <= vv^2 2n (16/9) / lambda3_lb for both.
+__device__ __forceinline__ bool se3d_cond_level1_ok(const double g[10], const double piv[4], const double p[3], int n) {
+  const double tr3 = (g[0] + g[4]) + g[7];
+  const double L4 = 4.0 * (piv[0] * piv[1]) * piv[2], T2 = tr3 * tr3;          // lambda3_lb = L4 / T2
+  const double vv = __builtin_fma(p[0], p[0], __builtin_fma(p[1], p[1], __builtin_fma(p[2], p[2], 1.0)));
+  const bool gap_ok = 200.0 * piv[3] * T2 <= L4 * vv;
+  const bool kap_ok = (vv * vv) * ((32.0 / 9.0) * (double)n) * T2 < (SE3D_EXACT_KAPPA * SE3D_EXACT_KAPPA) * L4;
+  return gap_ok && kap_ok;
+}
+// hands (frame, hypothesis, joint) to the second pass (se3d_k_triangulate_exact / _slow)
+__device__ __forceinline__ void se3d_tri_list_push(const Se3dDev &D, int f, int h, int j) {
+  const uint32_t at = atomicAdd(&D.tri_cnt[0], 1u);
+  D.tri_list[at] = ((uint32_t)(f * D.d.H + h) << 5) | (uint32_t)j;
 }
 
 // rows of the DLT system for one view: r0 = normalize(x*P2 - P0), r1 = normalize(y*P2 - P1)  (float, S3D:446-449)
@@ -1698,10 +1773,35 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   build(n);
   double pw[3];
   const double e4start[4] = {0.0, 0.0, 0.0, 1.0};  // the null vector (X, Y, Z, 1)/|.| of a finite point always has a w component
-  se3d_solve_point<2>(gw_, e4start, pw, SE3D_MAIN_PTOL);
+  double piv_[4];
+  const bool conv0 = se3d_null_invit_point<2>(gw_, e4start, pw, SE3D_MAIN_PTOL, piv_);
+  if (!conv0) {
+    double e4[4];
+    se3d_eig4_smallest(gw_, e4);
+    const double iw = se3d_rcp64<2>(e4[3]);
+    pw[0] = e4[0] * iw; pw[1] = e4[1] * iw; pw[2] = e4[2] * iw;
+  }
   float X = (float)pw[0], Y = (float)pw[1], Z = (float)pw[2];
   double err = reproj(n, X, Y, Z);
   float avg_score = (float)(sconf / n);
+  if (D.d.exact) {
+    // Round 4: a joint whose fp64 solve may differ from the reference's float32 JacobiSVD by more than the contract allows — ill-conditioned
+    // weighted or unweighted system, a solve that did not settle — or whose reprojection error is above / near the outlier threshold is handed
+    // to se3d_k_triangulate_exact (the reference's arithmetic, bit for bit).  Everything decided from here on is uniform over the wavefront.
+    bool flag = !conv0 || !(err <= REPROJ_MAX * (1.0 - SE3D_EXACT_ERR_GUARD));
+    bool hi = false;   // a confidence above 1 (the level-1 test assumes c <= 1)
+    for (int v = lane; v < n; v += 64) hi |= T.cf[v] > 1.0f;
+    if (!flag && (__ballot(hi) != 0ull || !se3d_cond_level1_ok(gw_, piv_, pw, n))) {   // uniform
+      float gwf[10], guf[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) { gwf[k] = (float)gw_[k]; guf[k] = (float)gu_[k]; }
+      flag = se3d_kappa_flag(gwf, X, Y, Z) || se3d_kappa_flag(guf, X, Y, Z);
+    }
+    if (flag) {
+      if (lane == 0) se3d_tri_list_push(D, f, h, j);
+      return;
+    }
+  }
 
   if (err > REPROJ_MAX && n == 3) {  // S3D:748-792
     float dcand = 0.f;
@@ -1829,6 +1929,10 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) cv[k] = cov_bad ? (double)__builtin_nanf("") : se3d_wave_sum(cv[k]);
+  if (D.d.exact && !cov_bad && !(cv[0] < SE3D_EXACT_VAR_MAX && cv[3] < SE3D_EXACT_VAR_MAX && cv[5] < SE3D_EXACT_VAR_MAX)) {
+    if (lane == 0) se3d_tri_list_push(D, f, h, j);   // wide covariance: the samples' systems are ill conditioned — second pass (uniform)
+    return;
+  }
   if (lane == 0) {
     se3d_keypoint3d *kp = &D.hypP[(size_t)f * H + h].keypoints[c_kp2fusion[D.d.pose_method][j]];
     kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
@@ -1968,7 +2072,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
       raw2[t] = D.raw[((size_t)(f * N + ic[t])) * D.d.P + S.det[iv[t]]].keypoints[jbase + ij[t]];
     }
   }
-  unsigned long long okm[2] = {0ull, 0ull}, badm[2] = {0ull, 0ull};
+  unsigned long long okm[2] = {0ull, 0ull}, badm[2] = {0ull, 0ull}, hicf[2] = {0ull, 0ull};   // hicf: a usable view with a confidence above 1
   bool okl[2] = {false, false};
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -1996,6 +2100,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
       for (int k = 0; k < 4; ++k) { S.rows[j][v][k] = r0[k]; S.rows[j][v][4 + k] = r1[k]; }   // zero rows for an unusable view: the Gram loop adds them
     }
     okm[t] = __ballot(ok); badm[t] = __ballot(badv);
+    hicf[t] = __ballot(ok && r.score > 1.0f);
     okl[t] = ok;
   }
   {
@@ -2047,16 +2152,50 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
   const bool active = nj >= 2;
   bool slow = false;
   float X = 0.f, Y = 0.f, Z = 0.f, avg_score = 0.f;
+  bool unsettled = false;   // the inverse iteration of the weighted system fell back to the Jacobi solver: second pass
+  bool level2 = false;      // the cheap sufficient condition for "well conditioned" failed: the full test below decides
   if (active) {
     double gw_[10], pw[3];
 #pragma unroll
     for (int k = 0; k < 10; ++k) gw_[k] = S.G[lane][10 + k];
     const double e4start[4] = {0.0, 0.0, 0.0, 1.0};
-    se3d_solve_point<2>(gw_, e4start, pw, SE3D_MAIN_PTOL);
+    double piv_[4];
+    if (!se3d_null_invit_point<2>(gw_, e4start, pw, SE3D_MAIN_PTOL, piv_)) {
+      double e4[4];
+      se3d_eig4_smallest(gw_, e4);
+      const double iw = se3d_rcp64<2>(e4[3]);
+      pw[0] = e4[0] * iw; pw[1] = e4[1] * iw; pw[2] = e4[2] * iw;
+      unsettled = true;
+    } else if (D.d.exact) {
+      level2 = !se3d_cond_level1_ok(gw_, piv_, pw, nj);
+    }
     X = (float)pw[0]; Y = (float)pw[1]; Z = (float)pw[2];
     S.X[lane] = X; S.Y[lane] = Y; S.Z[lane] = Z;   // also the start (X, Y, Z, 1) of the samples' solves
   }
   __builtin_amdgcn_wave_barrier();
+  // Conditioning (round 4): joints that failed the level-1 test above (or carry a confidence above 1, which that test does not cover) take the
+  // full test of the weighted and of the unweighted system, lane <-> (system, joint): 2 JN <= 12 lanes at once; skipped by the wavefront when no
+  // joint needs it.  The published float32 point stands in for the fp64 solution (the Rayleigh quotient only grows).
+  unsigned long long illmask = 0ull;
+  {
+    unsigned long long l2mask = __ballot(level2);
+    if ((hicf[0] | hicf[1]) != 0ull) l2mask = (1ull << JN) - 1ull;
+    if (D.d.exact && l2mask) {
+      bool ill = false;
+      if (lane < 2 * JN) {
+        const int which = lane >= JN ? 1 : 0, jq = lane - which * JN;
+        if (S.n[jq] >= 2 && ((l2mask >> jq) & 1ull)) {
+          float gq_[10];
+#pragma unroll
+          for (int k = 0; k < 10; ++k) gq_[k] = (float)S.G[jq][10 * which + k];
+#ifndef SE3D_ABLATE_NO_KAPPA   // ablation build only (tools/profile_r4.sh ablate): what the test itself costs
+          ill = se3d_kappa_flag(gq_, S.X[jq], S.Y[jq], S.Z[jq]);
+#endif
+        }
+      }
+      illmask = __ballot(ill);
+    }
+  }
   TH_STAMP(5)  // weighted solve
 #pragma unroll
   for (int t = 0; t < 2; ++t) {  // confidence-weighted reprojection errors on the same (joint, view) lanes; 0 for a view that is not usable
@@ -2081,7 +2220,9 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
     // sequences on nine lanes: the error only meets thresholds, the score is published as float32
     const double err = se * se3d_rcp64(sc);
     avg_score = (float)(sc * se3d_rcp64((double)nj));   // sc: the confidences summed in view order (what G[.][20] used to hold)
-    slow = err > REPROJ_MAX && nj >= 3;  // outlier rejection needed (S3D:748-838): per-joint routine below
+    slow = err > REPROJ_MAX && nj >= 3;  // outlier rejection needed (S3D:748-838): second pass
+    if (D.d.exact)   // round 4: also everything near / above the threshold (the score carries err), ill-conditioned systems, unsettled solves
+      slow = !(err <= REPROJ_MAX * (1.0 - SE3D_EXACT_ERR_GUARD)) || unsettled || ((illmask >> lane) & 1ull) || ((illmask >> (lane + JN)) & 1ull);
     if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX * se3d_rcp64(err)));  // S3D:840-841
   }
   const unsigned long long slowmask = __ballot(slow);
@@ -2103,10 +2244,13 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
       for (int e = 0; e < 6; ++e) kp->cov[e] = 0.0;
     }
   }
-  // ---- joints that need outlier rejection are redone by se3d_k_triangulate_slow (per-joint routine) ----
-  if (lane == 0) D.tri_slow[((size_t)f * H + h) * 4 + part_] = (uint32_t)slowmask << jbase;
-  if (lane == 0 && part_ == 0)
-    for (int q = TH_PARTS; q < 4; ++q) D.tri_slow[((size_t)f * H + h) * 4 + q] = 0u;
+  // ---- joints of the second pass (se3d_k_triangulate_exact; SE3D_EXACT=0: se3d_k_triangulate_slow) go to the list ----
+  if (slowmask) {   // uniform; rare
+    uint32_t at0 = 0u;
+    if (lane == 0) at0 = atomicAdd(&D.tri_cnt[0], (uint32_t)__popcll(slowmask));
+    at0 = (uint32_t)__shfl((int)at0, 0);
+    if (slow) D.tri_list[at0 + __popcll(slowmask & ((1ull << lane) - 1ull))] = ((uint32_t)(f * H + h) << 5) | (uint32_t)(jbase + lane);
+  }
   }
   // ---- sigma points (S3D:471-523): lanes are tied to joints (64 / JN lanes each) and stride over the joint's 4n + 1 samples, so the
   // joint's Gram matrix, start vector and centre stay in registers and the weighted outer products of the deviations are
@@ -2158,13 +2302,27 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
 #pragma unroll
     for (int e = 0; e < 6; ++e) part[lane][e] = cv[e];
     __builtin_amdgcn_wave_barrier();
-    for (int it = lane; it < JN * 6; it += 64) {
-      const int jj = it / 6, e = it - jj * 6;
-      if (S.cnt[jj] == 0) continue;
-      double acc = 0.0;
-      for (int q = 0; q < LPJ; ++q) acc += part[jj * LPJ + q][e];
-      if (S.bad[jj]) acc = (double)__builtin_nanf("");
-      D.hypP[(size_t)blockIdx.y * D.d.H + blockIdx.x / TH_PARTS].keypoints[c_kp2fusion[D.d.pose_method][jbase + jj]].cov[e] = (double)(float)acc;   // (address re-formed here: not carried across the loop)
+    static_assert(TH_JOINTS * 6 <= 64, "one trip over the (joint, entry) lanes");
+    {
+      const int it = lane, jj = it / 6, e = it - jj * 6;
+      bool wide = false;   // a variance above SE3D_EXACT_VAR_MAX: the samples' own systems are ill conditioned, the joint goes to the second pass
+      if (it < JN * 6 && S.cnt[jj] != 0) {
+        double acc = 0.0;
+        for (int q = 0; q < LPJ; ++q) acc += part[jj * LPJ + q][e];
+        if (S.bad[jj]) acc = (double)__builtin_nanf("");
+        else wide = (e == 0 || e == 3 || e == 5) && !(acc < SE3D_EXACT_VAR_MAX);
+        D.hypP[(size_t)blockIdx.y * D.d.H + blockIdx.x / TH_PARTS].keypoints[c_kp2fusion[D.d.pose_method][jbase + jj]].cov[e] = (double)(float)acc;   // (address re-formed here: not carried across the loop)
+      }
+      const unsigned long long wmask = D.d.exact ? __ballot(wide) : 0ull;
+      if (wmask) {   // uniform; rare
+        bool mine = false;
+        if (it < JN * 6 && e == 0) mine = ((wmask >> (6 * jj)) & 0x29ull) != 0ull;   // entries 0, 3, 5 of joint jj
+        const unsigned long long jm = __ballot(mine);
+        uint32_t at0 = 0u;
+        if (lane == 0) at0 = atomicAdd(&D.tri_cnt[0], (uint32_t)__popcll(jm));
+        at0 = (uint32_t)__shfl((int)at0, 0);
+        if (mine) D.tri_list[at0 + __popcll(jm & ((1ull << lane) - 1ull))] = ((uint32_t)(blockIdx.y * D.d.H + blockIdx.x / TH_PARTS) << 5) | (uint32_t)(jbase + jj);
+      }
     }
     TH_STAMP(9)  // covariance sums + writes
 #ifdef SE3D_LM_STAMPS
@@ -2173,33 +2331,309 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
   }
 }
 
-// Outlier-rejection path of the hypothesis kernel: one wavefront per hypothesis redoes the flagged joints (usually none) with the
-// per-joint routine.  A separate launch on purpose: calling the routine from se3d_k_triangulate_hyp (out of line, descriptor by
-// address) made every wavefront spill the kernel arguments to scratch at entry — 445 MB of writes per launch (PMC WRITE_SIZE).
-__global__ __launch_bounds__(64) void se3d_k_triangulate_slow(Se3dDev D, int n_entries) {
+// Second pass, SE3D_EXACT=0 (round 3's behaviour, kept as A/B evidence): the listed joints — reprojection error above the threshold with
+// >= 3 views — are redone by the per-joint fp64 routine (outlier rejection by rank updates of the Gram matrix).  A separate launch on
+// purpose: calling the routine from se3d_k_triangulate_hyp (out of line, descriptor by address) made every wavefront spill the kernel
+// arguments to scratch at entry — 445 MB of writes per launch (PMC WRITE_SIZE).
+__global__ __launch_bounds__(64) void se3d_k_triangulate_slow(Se3dDev D) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   const int N = D.d.N, H = D.d.H;
-  // each lane looks at one (frame, hypothesis) entry; the wavefront then works through the flagged ones (usually none: one load and out)
-  const int e = blockIdx.x * 64 + lane;
-  uint32_t mymask = 0u;
-  if (e < n_entries) {
-    const int f = e / H, h = e - f * H;
-    if (h < D.nhyp[f] && D.nviews[e] >= 2 && (D.d.shard_world <= 1 || h % D.d.shard_world == D.d.shard_rank)) mymask = D.tri_slow[(size_t)e * 4] | D.tri_slow[(size_t)e * 4 + 1] | D.tri_slow[(size_t)e * 4 + 2] | D.tri_slow[(size_t)e * 4 + 3];
-  }
-  unsigned long long todo = __ballot(mymask != 0u);
-  if (!todo) return;
+  const uint32_t cnt = D.tri_cnt[0];
+  if (blockIdx.x >= cnt) return;
   float *base = reinterpret_cast<float *>(smem), *sRt = base + (size_t)15 * N;
   for (int i = lane; i < 12 * N; i += 64) sRt[i] = D.Rt[i];
   __syncthreads();
-  for (; todo; todo &= todo - 1ull) {
-    const int src = __ffsll((long long)todo) - 1;
-    const int ee = blockIdx.x * 64 + src, f = ee / H, h = ee - f * H;
-    const uint32_t mask = (uint32_t)__shfl((int)mymask, src);
-    for (uint32_t m = mask; m; m &= m - 1u) {
-      se3d_tri_joint_body(D, f, h, __ffs((int)m) - 1, lane, base, sRt);
+  for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
+    const uint32_t en = D.tri_list[it];
+    const int e = (int)(en >> 5), j = (int)(en & 31u), f = e / H, h = e - f * H;
+    se3d_tri_joint_body(D, f, h, j, lane, base, sRt);
+    __syncthreads();
+  }
+}
+
+// =============================================================================================================
+// Second pass of the triangulation (round 4): rows T, P, O, U of the listed joints with the reference's float32 arithmetic.
+// One wavefront per joint, one DLT solve per lane (se3d_exact32.h):
+//   phase A  lane 0 solves the confidence-weighted system of all n usable views (S3D:746), lanes 1 .. n its leave-one-view-out subsets
+//            (S3D:793-838; with three views the subset left after the epipolar test of S3D:748-792 is one of them) — speculatively: the lanes
+//            would idle otherwise; every lane takes the reprojection error of its own point over its own views (S3D:425-438);
+//   decision the reference's scans in their order (first strict minimum wins), score = mean confidence of the kept views in float (S3D:730-742,
+//            760-762), down-weighting (S3D:840-844);
+//   phase B  the 4n' + 1 sigma samples of the kept views, one unweighted solve per lane (S3D:471-518); the weighted outer products are summed
+//            in sample order in float (S3D:521-522).
+// Every expression and every summation order is the one the CPU restatement of the reference uses (tests/: bit-identical positions, scores and
+// raw covariances on the listed joints).  LDS per wavefront: camera matrices, the view list, the views' normalised rows, the centred samples.
+// =============================================================================================================
+struct X32Views {
+  float *x, *y, *cf, *k00, *k01, *k11;   // normalised point, confidence, normalised 2x2 covariance (a00, a01 = a10, a11) per usable view
+  float *rows;                            // [n][8] DLT rows r0, r1 of the view, normalised by division (S3D:446-449), unweighted
+  int *cam;
+};
+__host__ __device__ inline size_t se3d_exact_lds_bytes(int N) {   // camera matrices, view list, rows, centred samples
+  return ((((size_t)12 * N + 6 * N + 8 * N + 3 * (4 * N + 1)) * sizeof(float) + (size_t)N * sizeof(int)) + 15) & ~(size_t)15;
+}
+
+// one triangulate() call of the reference on this lane: views 0 .. n-1 without `skip`, view `mv` (>= 0) taking the point (mx, my)
+template <typename WsPtrT>
+__device__ __forceinline__ void x32_triangulate(const X32Views &T, const float *__restrict__ sRt, int n, bool weighted, int skip, int mv, float mx, float my,
+                                                const X32MatT<WsPtrT> &A, float X[3]) {
+  int r = 0;
+  for (int v = 0; v < n; ++v) {
+    if (v == skip) continue;
+    float r0[4], r1[4];
+    if (v == mv) {
+      x32_dlt_rows(sRt + 12 * T.cam[v], mx, my, r0, r1);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r0[k] = T.rows[8 * v + k]; r1[k] = T.rows[8 * v + 4 + k]; }
+    }
+    if (weighted) {   // A.row(2i) *= conf (S3D:450-453)
+      const float cf = T.cf[v];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r0[k] = r0[k] * cf; r1[k] = r1[k] * cf; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { A.set(r, k, r0[k]); A.set(r + 1, k, r1[k]); }
+    r += 2;
+  }
+  const float4 v4 = x32_null_vector(r, A.p, A.stride, A.ld);
+  X[0] = v4.x / v4.w; X[1] = v4.y / v4.w; X[2] = v4.z / v4.w;   // hnormalized()
+}
+// calcReprojectionError (S3D:425-438) of X over the views 0 .. n-1 without `skip`
+__device__ __forceinline__ double x32_reproj_error(const X32Views &T, const float *__restrict__ sRt, int n, int skip, const float X[3]) {
+  double averageError = 0., norm = 0.;
+  for (int v = 0; v < n; ++v) {
+    if (v == skip) continue;
+    const float *M = sRt + 12 * T.cam[v];
+    const float hx = (M[0] * X[0] + (M[1] * X[1] + M[2] * X[2])) + M[3];
+    const float hy = (M[4] * X[0] + (M[5] * X[1] + M[6] * X[2])) + M[7];
+    const float hz = (M[8] * X[0] + (M[9] * X[1] + M[10] * X[2])) + M[11];
+    const float ix = hx / hz, iy = hy / hz;
+    const float dx = ix - T.x[v], dy = iy - T.y[v];
+    const float error = sqrtf(dx * dx + dy * dy);
+    averageError += (double)(T.cf[v] * error);
+    norm += (double)T.cf[v];
+  }
+  return averageError / norm;
+}
+
+__global__ __launch_bounds__(64) void se3d_k_triangulate_exact(Se3dDev D) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int N = D.d.N, H = D.d.H;
+  const uint32_t cnt = D.tri_cnt[0];
+  if (blockIdx.x == 0 && lane == 0) D.tri_cnt[1] += cnt;   // running total (se3d_get_exact_stats); launches of a context are serialised
+  if (blockIdx.x >= cnt) return;
+  float *sRt = reinterpret_cast<float *>(smem);
+  X32Views T;
+  T.x = sRt + 12 * N; T.y = T.x + N; T.cf = T.y + N; T.k00 = T.cf + N; T.k01 = T.k00 + N; T.k11 = T.k01 + N;
+  T.rows = T.k11 + N;
+  float *cen = T.rows + 8 * N;                       // [4n + 1][3] centred samples
+  T.cam = reinterpret_cast<int *>(cen + 3 * (4 * N + 1));
+  for (int i = lane; i < 12 * N; i += 64) sRt[i] = D.Rt[i];
+  // The lanes' rows x 4 matrices live in a lane-interleaved workspace in global memory (L2-resident).  In LDS (64 x 8 N floats = 32 KB per
+  // wavefront at 16 cameras) four wavefronts fit a CU and the launch took 247 us for the ~8 k listed joints of a 98 304-frame 16cam6p batch;
+  // from global memory with 16 wavefronts per CU 136 us (profiles/r4/README.md).
+  const X32Mat A{D.tri_ws + (size_t)blockIdx.x * 64 * 8 * N + lane, 64, 2 * N};
+  __syncthreads();
+  for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
+    const uint32_t en = D.tri_list[it];
+    const int e = (int)(en >> 5), j = (int)(en & 31u), f = e / H, h = e - f * H;
+    se3d_keypoint3d *kpo = &D.hypP[(size_t)f * H + h].keypoints[c_kp2fusion[D.d.pose_method][j]];
+    // ---- usable views of the joint (conf >= 0.30, S3D:724-732), ascending camera order; row N on the fly with the reference's expressions ----
+    const int32_t *arow = D.assoc + ((size_t)f * H + h) * N;
+    int n = 0;
+    for (int c0 = 0; c0 < N; c0 += 64) {
+      const int c = c0 + lane;
+      bool ok = false;
+      se3d_keypoint2d r;
+      r.x = r.y = 0.f; r.score = -1.f; r.cov[0] = r.cov[1] = r.cov[2] = 0.f;
+      if (c < N) {
+        const int k = arow[c];
+        if (k >= 0) {
+          const size_t cb = ((size_t)(f * N + c)) * D.d.P;
+          r = D.raw[cb + D.orig[cb + k]].keypoints[j];
+          ok = r.score >= TRI_THRESH;
+        }
+      }
+      const unsigned long long bl = __ballot(ok);
+      if (ok) {
+        const int pos = n + __popcll(bl & ((1ull << lane) - 1ull));
+        const float fx = D.K[c * 4 + 0], fy = D.K[c * 4 + 1], cx = D.K[c * 4 + 2], cy = D.K[c * 4 + 3];
+        T.x[pos] = (r.x - cx) / fx; T.y[pos] = (r.y - cy) / fy; T.cf[pos] = r.score;
+        T.k00[pos] = r.cov[0] / (fx * fx); T.k01[pos] = r.cov[1] / (fx * fy); T.k11[pos] = r.cov[2] / (fy * fy);   // S3D:324-326
+        T.cam[pos] = c;
+      }
+      n += __popcll(bl);
+    }
+    __syncthreads();
+    if (n < 2) {   // cannot happen for a listed joint; keep the slot defined
+      se3d_zero_kp_words(kpo, lane, 64);
+      continue;
+    }
+    for (int v = lane; v < n; v += 64) {
+      float r0[4], r1[4];
+      x32_dlt_rows(sRt + 12 * T.cam[v], T.x[v], T.y[v], r0, r1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { T.rows[8 * v + k] = r0[k]; T.rows[8 * v + 4 + k] = r1[k]; }
+    }
+    __syncthreads();
+    // ---- phase A: the weighted system (lane 0) and, with three or more views, its leave-one-view-out subsets (lanes 1 .. n) ----
+    // ... and on lane n + 1 the unweighted system of all views: the centre sample of the unscented transform if no view is removed
+    float Xl[3] = {0.f, 0.f, 0.f};
+    double el = 1e300;
+    const int n_all = n;
+    const bool centre_lane = n_all + 1 <= 63;
+    if (lane == 0 || (n >= 3 && lane <= n) || (centre_lane && lane == n + 1)) {
+      const bool wj = lane <= n;
+      x32_triangulate(T, sRt, n, wj, wj ? lane - 1 : -1, -1, 0.f, 0.f, A, Xl);
+      if (wj) el = x32_reproj_error(T, sRt, n, lane - 1, Xl);
+    }
+    float X = __shfl(Xl[0], 0), Y = __shfl(Xl[1], 0), Z = __shfl(Xl[2], 0);
+    double err = se3d_readlane_f64(el, 0);
+    float avg_score = 0.f;
+    for (int v = 0; v < n; ++v) avg_score += T.cf[v];   // S3D:730
+    avg_score /= (float)n;                               // S3D:738
+    int rm = -1;
+    if (err > REPROJ_MAX && n == 3) {  // S3D:748-792: the pair of remaining views with the smallest squared symmetric epipolar distance
+      float dcand = 0.f;
+      if (lane < 3) {
+        const int i0 = (lane == 0) ? 1 : 0, i1 = (lane == 2) ? 1 : 2;
+        const float p1x = T.x[i0], p1y = T.y[i0], p2x = T.x[i1], p2y = T.y[i1];
+        const float *F = D.F + 9 * (size_t)se3d_pair_index(T.cam[i0], T.cam[i1], N);
+        const float l1x = F[0] * p1x + (F[1] * p1y + F[2]);
+        const float l1y = F[3] * p1x + (F[4] * p1y + F[5]);
+        const float l1z = F[6] * p1x + (F[7] * p1y + F[8]);
+        const float l2x = F[0] * p2x + (F[3] * p2y + F[6]);
+        const float l2y = F[1] * p2x + (F[4] * p2y + F[7]);
+        const float l2z = F[2] * p2x + (F[5] * p2y + F[8]);
+        const float n1 = p2x * l1x + (p2y * l1y + l1z);
+        const float n2 = p1x * l2x + (p1y * l2y + l2z);
+        dcand = n1 * n1 / (l1x * l1x + l1y * l1y) + n2 * n2 / (l2x * l2x + l2y * l2y);
+      }
+      float best = (float)(err * err);
+      for (int i = 0; i < 3; ++i) {
+        const float di = __shfl(dcand, i);
+        if (di < best) { best = di; rm = i; }
+      }
+      if (rm != -1) {   // re-triangulation of the two remaining views = the leave-one-out solve of lane rm + 1
+        X = __shfl(Xl[0], rm + 1); Y = __shfl(Xl[1], rm + 1); Z = __shfl(Xl[2], rm + 1);
+        err = se3d_readlane_f64(el, rm + 1);
+        const int a = rm == 0 ? 1 : 0, b = rm == 2 ? 1 : 2;
+        avg_score = (T.cf[a] + T.cf[b]) / 2.0f;
+      }
+    } else if (err > REPROJ_MAX && n >= 4) {  // S3D:793-838: candidates in ascending view order, first strict minimum below 0.9 x err wins
+      const double err0 = err;
+      double bestErr = err;
+      for (int base = -1; base < n; base += 64) {
+        // candidate base + lane: the first pass has the full system on lane 0 and candidates 0 .. 62 on lanes 1 .. 63 (solved above),
+        // later passes (n > 63 views) solve theirs now
+        const int i = base + lane;
+        double e_i = 1e300;
+        float cx_ = 0.f, cy_ = 0.f, cz_ = 0.f;
+        if (base == -1) {
+          if (lane >= 1 && lane <= n) e_i = el;
+          cx_ = Xl[0]; cy_ = Xl[1]; cz_ = Xl[2];
+        } else if (i < n) {
+          float Xc[3];
+          x32_triangulate(T, sRt, n, true, i, -1, 0.f, 0.f, A, Xc);
+          e_i = x32_reproj_error(T, sRt, n, i, Xc);
+          cx_ = Xc[0]; cy_ = Xc[1]; cz_ = Xc[2];
+        }
+        if (!(e_i < 0.9 * err0)) e_i = 1e300;
+        double m = e_i;
+        int mi = i;
+        for (int o = 32; o > 0; o >>= 1) {
+          const double om = __shfl_xor(m, o);
+          const int oi = __shfl_xor(mi, o);
+          if (om < m || (om == m && oi < mi)) { m = om; mi = oi; }
+        }
+        if (m < bestErr) {
+          bestErr = m;
+          rm = mi;
+          X = __shfl(cx_, mi - base); Y = __shfl(cy_, mi - base); Z = __shfl(cz_, mi - base);
+        }
+      }
+      if (rm != -1) {
+        err = bestErr;
+        float tmpScore = 0.f;
+        for (int v = 0; v < n; ++v)
+          if (v != rm) tmpScore += T.cf[v];
+        avg_score = tmpScore / (float)(n - 1);
+      }
+    }
+    __syncthreads();
+    if (rm != -1) {   // erase the view, order preserved
+      if (lane == 0) {
+        for (int v = rm; v + 1 < n; ++v) {
+          T.x[v] = T.x[v + 1]; T.y[v] = T.y[v + 1]; T.cf[v] = T.cf[v + 1];
+          T.k00[v] = T.k00[v + 1]; T.k01[v] = T.k01[v + 1]; T.k11[v] = T.k11[v + 1]; T.cam[v] = T.cam[v + 1];
+          for (int k = 0; k < 8; ++k) T.rows[8 * v + k] = T.rows[8 * (v + 1) + k];
+        }
+      }
+      n -= 1;
       __syncthreads();
     }
+    if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX / err));  // S3D:840-841
+    // ---- phase B: unscented transform (S3D:471-523), one sample per lane ----
+    const int dim = 2 * n, nsamp = 4 * n + 1;
+    const float bsc = sqrtf((float)dim + 0.5f);
+    bool not_spd = false;
+    for (int v = lane; v < n; v += 64) {
+      const float l11 = sqrtf(T.k00[v]), l21 = T.k01[v] / l11, l22 = sqrtf(T.k11[v] - l21 * l21);
+      not_spd |= !(isfinite(l11) && isfinite(l21) && isfinite(l22));
+    }
+    not_spd = __ballot(not_spd) != 0ull;
+    float cov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (not_spd) {   // defined policy: all entries NaN, position and score unaffected
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cov6[k] = __builtin_nanf("");
+    } else {
+      // sample 0 (the unmoved points) was solved by lane n + 1 of phase A when no view was removed
+      const int first = (rm == -1 && centre_lane) ? 1 : 0;
+      if (first) {
+        const float c0 = __shfl(Xl[0], n_all + 1), c1 = __shfl(Xl[1], n_all + 1), c2 = __shfl(Xl[2], n_all + 1);
+        if (lane == 0) { cen[0] = c0 - X; cen[1] = c1 - Y; cen[2] = c2 - Z; }
+      }
+      for (int s0 = first; s0 < nsamp; s0 += 64) {
+        const int s = s0 + lane;
+        if (s < nsamp) {
+          int mv = -1;
+          float mx = 0.f, my = 0.f;
+          if (s > 0) {   // mod_samples (S3D:471-487): samples 4c + 1 .. 4c + 4 move view c
+            const int c = (s - 1) >> 2, kind = (s - 1) & 3;
+            const float l11 = sqrtf(T.k00[c]), l21 = T.k01[c] / l11, l22 = sqrtf(T.k11[c] - l21 * l21);
+            const float dx1 = l11 * bsc, dy1 = l21 * bsc, dy2 = l22 * bsc;
+            mv = c; mx = T.x[c]; my = T.y[c];
+            if (kind == 0) { mx = mx - dx1; my = my - dy1; }
+            else if (kind == 1) { my = my - dy2; }
+            else if (kind == 2) { mx = mx + dx1; my = my + dy1; }
+            else { my = my + dy2; }
+          }
+          float Xs[3];
+          x32_triangulate(T, sRt, n, false, -1, mv, mx, my, A, Xs);
+          cen[3 * s + 0] = Xs[0] - X; cen[3 * s + 1] = Xs[1] - Y; cen[3 * s + 2] = Xs[2] - Z;
+        }
+      }
+      __syncthreads();
+      const float wgt = 1.0f / (2.0f * ((float)dim + 0.5f));   // weights[0] = 2 kappa = 1, all / (2 (dim + kappa))
+      if (lane < 6) {   // (centred * weights) * centred^T, summed over the samples in order (S3D:521-522)
+        const int ci = lane < 3 ? 0 : (lane < 5 ? 1 : 2), cj = lane < 3 ? lane : (lane < 5 ? lane - 2 : 2);
+        float acc = 0.f;
+        for (int s = 0; s < nsamp; ++s) acc += (cen[3 * s + ci] * wgt) * cen[3 * s + cj];
+        cov6[0] = acc;
+      }
+#pragma unroll
+      for (int k = 5; k >= 0; --k) cov6[k] = __shfl(cov6[0], k);
+    }
+    if (lane == 0) {
+      kpo->joint[0] = (double)X; kpo->joint[1] = (double)Y; kpo->joint[2] = (double)Z;
+      kpo->score = avg_score; kpo->_pad = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) kpo->cov[k] = (double)cov6[k];
+    }
+    __syncthreads();
   }
 }
 
@@ -3085,6 +3519,47 @@ extern "C" hipError_t se3d_launch_selftest_exact_math(unsigned long long *d_out,
   return hipGetLastError();
 }
 
+// Diagnostic (se3d_selftest_dlt32): the float32 DLT solve of the second pass — triangulate() + calcReprojectionError() of the reference,
+// S3D:425-465 — on caller-provided systems, one system per lane; compared bit for bit with the CPU restatement in tests/test_gpu_exact32.py.
+__global__ __launch_bounds__(64) void se3d_k_selftest_dlt32(int n_sys, int n, const float *__restrict__ Rt, const float *__restrict__ pts, int weighted,
+                                                            float *__restrict__ ws, float *__restrict__ Xout, double *__restrict__ eout) {
+  const int lane = threadIdx.x, sidx = blockIdx.x * 64 + lane;
+  if (sidx >= n_sys) return;
+  const X32Mat A{ws + (size_t)blockIdx.x * 64 * 8 * n + lane, 64, 2 * n};
+  const float *M = Rt + (size_t)sidx * n * 12, *P = pts + (size_t)sidx * n * 3;
+  for (int v = 0; v < n; ++v) {
+    float r0[4], r1[4];
+    x32_dlt_rows(M + 12 * v, P[3 * v], P[3 * v + 1], r0, r1);
+    if (weighted) {
+      const float cf = P[3 * v + 2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r0[k] = r0[k] * cf; r1[k] = r1[k] * cf; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { A.set(2 * v, k, r0[k]); A.set(2 * v + 1, k, r1[k]); }
+  }
+  const float4 v4 = x32_null_vector(2 * n, A.p, A.stride, A.ld);
+  const float X[3] = {v4.x / v4.w, v4.y / v4.w, v4.z / v4.w};
+  double averageError = 0., norm = 0.;
+  for (int v = 0; v < n; ++v) {
+    const float *Mv = M + 12 * v;
+    const float hx = (Mv[0] * X[0] + (Mv[1] * X[1] + Mv[2] * X[2])) + Mv[3];
+    const float hy = (Mv[4] * X[0] + (Mv[5] * X[1] + Mv[6] * X[2])) + Mv[7];
+    const float hz = (Mv[8] * X[0] + (Mv[9] * X[1] + Mv[10] * X[2])) + Mv[11];
+    const float ix = hx / hz, iy = hy / hz;
+    const float dx = ix - P[3 * v], dy = iy - P[3 * v + 1];
+    const float error = sqrtf(dx * dx + dy * dy);
+    averageError += (double)(P[3 * v + 2] * error);
+    norm += (double)P[3 * v + 2];
+  }
+  Xout[3 * sidx] = X[0]; Xout[3 * sidx + 1] = X[1]; Xout[3 * sidx + 2] = X[2];
+  eout[sidx] = averageError / norm;
+}
+extern "C" hipError_t se3d_launch_selftest_dlt32(int n_sys, int n, const float *d_Rt, const float *d_pts, int weighted, float *d_ws, float *d_X, double *d_err, hipStream_t st) {
+  hipLaunchKernelGGL(se3d_k_selftest_dlt32, dim3((n_sys + 63) / 64), dim3(64), 0, st, n_sys, n, d_Rt, d_pts, weighted, d_ws, d_X, d_err);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void se3d_k_munkres(double *dist, int *assign, int *status, int nR, int nC) {
   __shared__ MunkresShared S;
   __shared__ int a[SE3D_MUNKRES_MAX];
@@ -3116,17 +3591,26 @@ extern "C" hipError_t se3d_stage1_init_device(void) {
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
-static void se3d_launch_triangulation(const Se3dDev &D, hipStream_t st) {
+static void se3d_launch_triangulation(const Se3dDev &D_, hipStream_t st) {
+  Se3dDev D = D_;
   const int B = D.d.B, N = D.d.N, H = D.d.H;
+  {  // SE3D_EXACT=0 (A/B switch read per launch): round 3's second pass — fp64 outlier rejection, no float32-exact solves
+    const char *e_exact = getenv("SE3D_EXACT");
+    if (e_exact && atoi(e_exact) == 0) D.d.exact = 0;
+  }
+  (void)hipMemsetAsync(D.tri_cnt, 0, sizeof(uint32_t), st);   // list of the second pass: filled by the kernel below
+  const int waves2 = (int)std::min<size_t>((size_t)D.d.tri_waves, (size_t)B * H * SE3D_NKP);
   const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
   const char *e_tri = getenv("SE3D_TRI");  // A/B switch (read per launch): joint = always one wavefront per (hypothesis, joint)
   if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) {
     // (the grid covers all H hypothesis slots; the workgroups of unused slots exit after one load — capping the grid at 12 / 16 / 24 slots
     // changed the kernel's 7.6 - 7.7 ms per 98 304 frames by less than the run-to-run spread, profiles/r3/README.md)
     hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(TH_PARTS * H, B), dim3(64), 0, st, D);
-    hipLaunchKernelGGL(se3d_k_triangulate_slow, dim3((B * H + 63) / 64), dim3(64), (size_t)27 * N * sizeof(float), st, D, B * H);
+    if (!D.d.exact) hipLaunchKernelGGL(se3d_k_triangulate_slow, dim3(waves2), dim3(64), (size_t)27 * N * sizeof(float), st, D);
   }
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
+  // second pass: the listed joints with the reference's float32 arithmetic (wavefronts beyond the list length exit at once)
+  if (D.d.exact) hipLaunchKernelGGL(se3d_k_triangulate_exact, dim3(waves2), dim3(64), se3d_exact_lds_bytes(N), st, D);
 }
 
 // phases (bit mask): 1 = normalise + pair-cost table, 8 = camera sweep, 2 = triangulation, 4 = post-processing + duplicate merge

@@ -283,6 +283,30 @@ class Skeleton3D:
         self._chk(self._L.se3d_selftest_exact_math(C.c_void_p(self._h), C.c_uint64(int(n_div)), C.byref(a), C.byref(b)), "se3d_selftest_exact_math")
         return int(a.value), int(b.value)
 
+    def selftest_dlt32(self, Rt, pts, weight_by_conf=True):
+        """The second pass's float32 DLT solve (se3d_exact32.h) on caller systems: Rt [n_sys][n][12], pts [n_sys][n][3] (x, y, conf)
+        -> (X [n_sys][3] float32, reprojection error [n_sys] float64)."""
+        Rt = np.ascontiguousarray(Rt, np.float32)
+        pts = np.ascontiguousarray(pts, np.float32)
+        n_sys, n = pts.shape[0], pts.shape[1]
+        assert Rt.shape == (n_sys, n, 12) and pts.shape == (n_sys, n, 3)
+        X = np.zeros((n_sys, 3), np.float32)
+        err = np.zeros(n_sys, np.float64)
+        self._chk(self._L.se3d_selftest_dlt32(C.c_void_p(self._h), n_sys, n, pm.fptr(Rt), pm.fptr(pts), int(bool(weight_by_conf)), pm.fptr(X),
+                                              err.ctypes.data_as(C.POINTER(C.c_double))), "se3d_selftest_dlt32")
+        return X, err
+
+    def exact_list(self):
+        """Joints the last triangulation pass handed to the float32-exact second pass: (array [n][3] of (frame, hypothesis, joint), running total)."""
+        n, total = C.c_int32(0), C.c_int64(0)
+        cap = self.limits.max_frames * self.limits.max_hyp * pm.NUM_KEYPOINTS
+        buf = np.zeros(cap, np.uint32)
+        self._chk(self._L.se3d_get_exact_list(C.c_void_p(self._h), buf.ctypes.data_as(C.POINTER(C.c_uint32)), cap, C.byref(n), C.byref(total)), "se3d_get_exact_list")
+        e = buf[:min(n.value, cap)]
+        fh = e >> 5
+        out = np.stack([fh // self.limits.max_hyp, fh % self.limits.max_hyp, e & 31], -1).astype(np.int64) if len(e) else np.zeros((0, 3), np.int64)
+        return out, int(total.value)
+
     def profile(self, on=True):
         self._chk(self._L.se3d_profile_enable(C.c_void_p(self._h), int(on)), "se3d_profile_enable")
 

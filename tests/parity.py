@@ -101,64 +101,36 @@ def compare_stage2(gpu, ora, check_iters=True, check_tracks=True):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-# Ill-conditioning criteria of the randomised sweep (tests/test_gpu_fuzz_parity.py), computed FROM THE INPUTS in float64.
+# Conditioning of the DLT systems, computed FROM THE INPUTS in float64 (tests/test_gpu_fuzz_parity.py).
 #
-# Rows T/U: the reference takes the DLT null vector from a float32 JacobiSVD (S3D:456), the kernels from an fp64 solve of the same
+# Rows T/U: the reference takes the DLT null vector from a float32 JacobiSVD (S3D:456), the fast kernels from an fp64 solve of the same
 # float32 rows.  A float32 perturbation of relative size eps = 2^-24 of the rows turns the null vector by ~ eps * s1 / (s3 - s4)
 # (singular values of the 2n x 4 system) and dehomogenising v -> v[:3] / v[3] multiplies that by ~ (1 + |X|^2): a joint whose system has
 #     kappa = (1 + |X|^2) * s1 / (s3 - s4)
-# can come out of the two solvers up to ~ c * eps * kappa metres apart (measured c <= 5 over 3e5 joints, tools: profiles/r3/README.md).
-# kappa >= DLT_KAPPA_MAX is the exclusion set of the < 1 mm / 1e-3 assertions: such joints are triangulated far outside the hall from
-# nearly parallel or inconsistent rays (gross 2-D outliers, wrong associations) and the reference's own answer there is rounding noise.
+# can come out of the two solvers up to ~ c * eps * kappa metres apart (measured c <= 5 over 3e5 joints, profiles/r3/README.md).
+# Round 3 EXCLUDED the joints with kappa >= DLT_KAPPA_MAX from the position / score / covariance assertions.  Round 4: the library flags such
+# joints itself (an in-kernel upper bound of kappa at 1e3, reprojection errors near the outlier threshold, wide covariances) and redoes them
+# with the reference's float32 arithmetic — positions and scores are asserted on EVERY valid joint, and what is left of kappa here is
+#   (i) a check of the library's flag: own-hypothesis joints with kappa >= DLT_KAPPA_MAX must be in se3d_get_exact_list, and
+#   (ii) the covariance tolerance of the joints that stay on the fp64 fast path (cov_tolerance).
 # ---------------------------------------------------------------------------------------------------------------------------------
-BRANCH_TIE_REL = 1.0e-6   # relative distance of a reprojection error from a decision threshold of the outlier rejection below which the joint is excluded
-DLT_KAPPA_MAX = 2.0e3     # c * eps * kappa = 5 * 6e-8 * 2e3 = 0.6 mm: below it the two solvers must agree to POS_TOL_M
+DLT_KAPPA_MAX = 2.0e3     # twice the library's SE3D_EXACT_KAPPA (its bound is 1.0 .. 2.1 x kappa): every joint at or above it must be listed
 
 
 def cov_tolerance(kappa, cov):
     """Relative-Frobenius tolerance of a stage-1 covariance: COV_REL_FRO + 2 * 2^-24 * kappa / sigma, sigma = sqrt(mean diagonal)
     of the oracle's covariance `cov` [..., 6].  The unscented transform differences 4n + 1 sample solutions that lie ~sigma apart; the oracle
     (like the reference) solves every sample in float32, whose noise on a sample is c 2^-24 kappa metres (c: median 0.31, maximum 4.91 over
-    3.1e5 joints, profiles/r3/cond_study.txt), so its covariance carries a relative error of about 2 c 2^-24 kappa / sigma — the kernels' fp64
-    solves have none of it (CPU study of 46 k joints, profiles/r3/cond_study.txt: the oracle's deviation from the exact unscented transform divided
-    by 2^-24 kappa / sigma has median 0.27 and 99th percentile 1.45; its far tail is the large-sigma joints of covariance_in_hall).  The term is below 1e-4 for the bulk of the joints (kappa ~ 20, sigma ~ 2 cm) and decides the rare tail: over
-    86 seeds x 40 scenes (9.5 M asserted joints) three joints exceed the flat 1e-3 for this reason — 1.46e-3 at kappa 62 / sigma 4 mm (19
-    views), 1.01e-3 at kappa 744, 1.2e-3 — all inside this tolerance (profiles/r3/README.md)."""
+    3.1e5 joints, profiles/r3/cond_study.txt), so its covariance carries a relative error of about 2 c 2^-24 kappa / sigma — the fast path's
+    fp64 sample solves have none of it (CPU study of 46 k joints, profiles/r3/cond_study.txt: the oracle's deviation from the exact unscented
+    transform divided by 2^-24 kappa / sigma has median 0.27 and 99th percentile 1.45).  The term is below 1e-4 for the bulk of the joints
+    (kappa ~ 20, sigma ~ 2 cm) and decides the rare tail: over 86 seeds x 40 scenes (9.5 M asserted joints) three joints exceeded the flat 1e-3
+    for this reason — 1.46e-3 at kappa 62 / sigma 4 mm (19 views), 1.01e-3 at kappa 744, 1.2e-3 — all inside this tolerance.
+    Callers pass min(kappa, DLT_KAPPA_MAX): joints above it went through the library's float32 second pass and carry the oracle's bits."""
     cov = np.asarray(cov, np.float64)
     with np.errstate(invalid="ignore"):
         sigma = np.sqrt(np.maximum((cov[..., 0] + cov[..., 3] + cov[..., 5]) / 3.0, 1e-300))
     return COV_REL_FRO + 2.0 * 2.0 ** -24 * np.asarray(kappa, np.float64) / sigma
-
-
-COV_SIGMA_MAX_M = 1.0   # covariance assertion: joints whose oracle covariance stays below (1 m)^2 on the diagonal
-
-
-def covariance_in_hall(cov):
-    """bool [...]: the covariance `cov` [..., 6] says the joint is known to better than COV_SIGMA_MAX_M.  The unscented transform's samples
-    of a joint with a larger covariance land metres to tens of metres away from where the rays converge; THOSE systems are ill-conditioned
-    (kappa grows with 1 + |X|^2) whatever the base system's kappa is, and the reference's float32 solves of them are noise at the 1e-3 level
-    (seen at 32 / 48 cameras with 12 - 24 persons: spurious persons with sigma 30 - 50 m, base kappa 59 - 1150, covariances 1.3e-3 - 7.9e-3 apart,
-    positions within 0.05 mm).  Such joints leave the covariance assertion (counted), not the position / score assertions."""
-    cov = np.asarray(cov, np.float64)
-    with np.errstate(invalid="ignore"):
-        return np.nan_to_num(np.maximum(np.maximum(cov[..., 0], cov[..., 3]), cov[..., 5]), nan=np.inf) < COV_SIGMA_MAX_M ** 2
-
-
-def covariance_condition(kappa, tables):
-    """kappa [n][17] of the systems a joint's COVARIANCE depends on: its own and — through the limb-length term added to the diagonal, a
-    function of the distance to the parent joint (S3D:866-872; both shoulders in the "simple" model, S3D:875-881) — its parent's.  `kappa` as
-    returned by published_joint_condition (merge partners included, also for joints the published person does not carry: a partner's parent
-    joint may have been removed by the root-distance filter after it inflated the child's covariance; seen: a sane ear with a covariance
-    of (94 km)^2 x I from a partner whose eye lay 62 km away)."""
-    par, L = tables["kpParent"], tables["limbLength"]
-    out = np.array(kappa, np.float64, copy=True)
-    for j in range(pm.NUM_KEYPOINTS):
-        if par[j] >= 0 and L[j] > 0:
-            out[:, j] = np.fmax(out[:, j], kappa[:, par[j]])
-    if tables.get("shoulderDist", 0) > 0 and par[6] >= 0 and not (L[6] > 0):
-        both = np.fmax(kappa[:, 5], kappa[:, 6])
-        out[:, 5], out[:, 6] = np.fmax(out[:, 5], both), np.fmax(out[:, 6], both)
-    return out
 
 
 GARBAGE_JOINT_DIST_M = 10.0   # stage 2: a measured joint further than this from the median joint of its person (no body spans 10 m)
@@ -205,62 +177,19 @@ def _kappa_from_gram(G):
     return np.where(np.isfinite(kappa), kappa, np.inf), X
 
 
-def dlt_condition(rig, frame, assoc_rows, want_points=False):
-    """kappa [n][17] of the DLT systems behind each (hypothesis, joint) of a frame (nan: fewer than two usable views), the maximum over the
-    confidence-weighted system of the main solve (S3D:746), the unweighted system of the sigma points (S3D:518) and — where the fp64
-    reprojection error comes near g_reproj_error_max_acceptable, so that the outlier rejection (S3D:748-838) may have removed a view —
-    their leave-one-view-out subsets.  assoc_rows: [n][n_cam] original detection indices or -1 (rows of the result's association table).
-    want_points: also the fp64 solution of the weighted system [n][17][3]."""
+def plain_condition(rig, frame, assoc_rows, want_points=False):
+    """kappa [n][17]: maximum over the confidence-weighted (S3D:746) and the unweighted (S3D:518) DLT system of each (hypothesis, joint)
+    (nan: fewer than two usable views) — the quantity the library's in-kernel flag bounds from above (csrc/se3d_stage1.hip se3d_kappa_flag).
+    assoc_rows: [n][n_cam] original detection indices or -1.  want_points: also the fp64 solution of the weighted system [n][17][3]."""
     assoc_rows = np.asarray(assoc_rows, np.int32).reshape(-1, rig.n_cam)
     r0, r1, use, cf, x, y = _dlt_rows(rig, frame, assoc_rows)
     a0, a1 = r0.astype(np.float64), r1.astype(np.float64)
-    outer = a0[..., :, None] * a0[..., None, :] + a1[..., :, None] * a1[..., None, :]          # [n,17,N,4,4]
-    u = use.astype(np.float64)
-    w2 = (cf.astype(np.float64)) ** 2
-    Gu = (outer * u[..., None, None]).sum(2)
-    Gw = (outer * w2[..., None, None]).sum(2)
-    nv = use.sum(-1)
+    outer = a0[..., :, None] * a0[..., None, :] + a1[..., :, None] * a1[..., None, :]
+    Gu = (outer * use.astype(np.float64)[..., None, None]).sum(2)
+    Gw = (outer * (cf.astype(np.float64) ** 2)[..., None, None]).sum(2)
     ku, _ = _kappa_from_gram(Gu)
     kw, X = _kappa_from_gram(Gw)
-    kappa = np.maximum(ku, kw)
-    # reprojection error of the weighted solution (S3D:425-438) in fp64
-    P = rig.Rt.reshape(rig.n_cam, 3, 4).astype(np.float64)
-    Xh = np.concatenate([X, np.ones(X.shape[:-1] + (1,))], -1)
-    pr = np.einsum("cij,pkj->pkci", P, Xh)
-    z = np.where(np.abs(pr[..., 2]) > 1e-150, pr[..., 2], 1e-150)
-    with np.errstate(over="ignore", invalid="ignore"):
-        e = np.hypot(pr[..., 0] / z - x, pr[..., 1] / z - y)
-        cfd = cf.astype(np.float64)
-        err = (cfd * np.where(use, e, 0.0)).sum(-1) / np.maximum(cfd.sum(-1), 1e-150)
-    def sub_err(p, k, Xc, keep):     # confidence-weighted reprojection error of a point over a subset of the joint's views (S3D:425-438), fp64
-        prc = P @ np.append(Xc, 1.0)
-        zc = np.where(np.abs(prc[:, 2]) > 1e-150, prc[:, 2], 1e-150)
-        with np.errstate(over="ignore", invalid="ignore"):
-            ec = np.hypot(prc[:, 0] / zc - x[p, k], prc[:, 1] / zc - y[p, k])
-        w = cfd[p, k] * keep
-        return float((w * np.where(keep > 0, ec, 0.0)).sum() / max(w.sum(), 1e-150))
-    for p, k in zip(*np.nonzero(~(err <= 0.8 * 0.05) & (nv >= 3))):
-        errs_loo = []
-        for c in np.nonzero(use[p, k])[0]:
-            kk_u, _ = _kappa_from_gram(Gu[p, k] - outer[p, k, c])
-            kk_w, Xc = _kappa_from_gram(Gw[p, k] - outer[p, k, c] * w2[p, k, c])
-            kappa[p, k] = max(kappa[p, k], kk_u, kk_w)
-            keep = use[p, k].astype(np.float64)
-            keep[c] = 0.0
-            errs_loo.append(sub_err(p, k, Xc, keep))
-        # Branch ties (the reference's decisions are discontinuous): the error against g_reproj_error_max_acceptable (S3D:748), the best
-        # leave-one-view-out error against 0.9 x error (S3D:830), two candidates for "best".  Within BRANCH_TIE_REL of a threshold the float32
-        # terms of the two sides decide differently and the results are different points (seen: err = 0.050000002, 368 mm) — excluded.
-        e0 = float(err[p, k])
-        tie = abs(e0 - 0.05) <= BRANCH_TIE_REL * 0.05
-        if nv[p, k] >= 4 and e0 > 0.05 * (1.0 - BRANCH_TIE_REL):
-            se = np.sort(np.array(errs_loo))
-            tie = tie or abs(se[0] - 0.9 * e0) <= BRANCH_TIE_REL * 0.9 * e0
-            if len(se) > 1 and se[0] < 0.9 * e0 * (1.0 + BRANCH_TIE_REL):
-                tie = tie or (se[1] - se[0]) <= BRANCH_TIE_REL * se[0]
-        if tie:
-            kappa[p, k] = np.inf
-    kappa = np.where(nv >= 2, kappa, np.nan)
+    kappa = np.where(use.sum(-1) >= 2, np.maximum(ku, kw), np.nan)
     return (kappa, X) if want_points else kappa
 
 
@@ -272,7 +201,7 @@ def published_joint_condition(rig, frame, result, k2f=None):
     does not redo) or that has one joint within 2 cm (a joint taken over unchanged) counts as a possible merge partner and contributes the maximum of its kappa."""
     n = result.n_persons
     hyp = result.person_hyp[:n]
-    kap, X = dlt_condition(rig, frame, result.assoc(), want_points=True)
+    kap, X = plain_condition(rig, frame, result.assoc(), want_points=True)
     out = kap[hyp].copy()
     pub = np.zeros(len(kap), bool)
     pub[hyp] = True
@@ -298,44 +227,6 @@ def published_joint_condition(rig, frame, result, k2f=None):
             if cand:
                 out[i, j] = max(cand)
     return out
-
-
-def score_allowance(rig, frame, gpu, ora, k2f=None):
-    """Relative allowance [n_persons][17] for the comparison of stage-1 SCORES that comes from the position difference of the two sides.
-    A joint's score is the mean confidence of its views times min(1, g_reproj_error_max_acceptable / err) (S3D:840-844): once the
-    reprojection error err exceeds 0.05 the score carries err's dependence on the triangulated point, and err = mean |proj(X) - x| changes by
-    d / depth per metre of position difference (2e-4 of itself for 0.05 mm at 5 m and err = 0.05; without bound where a ray passes close to a
-    camera centre: err = 74 seen on a two-view joint).  Returned: |err(X_gpu) - err(X_oracle)| / min(...) in fp64 over the usable views of the
-    person's hypothesis — maximum over the full set and, with three or more views, its leave-one-view-out subsets (the outlier rejection may have
-    removed one, S3D:748-838) — where any of those errors comes within 20 % of the threshold or above it; 0 elsewhere (score = mean confidence)."""
-    n = gpu.n_persons
-    k2f = np.array(pm.KP2FUSION_SIMPLE if k2f is None else k2f)
-    rows = gpu.assoc()[gpu.person_hyp[:n]]
-    _, _, use, cf, x, y = _dlt_rows(rig, frame, rows)
-    P = rig.Rt.reshape(rig.n_cam, 3, 4).astype(np.float64)
-    cfd = np.where(use, cf.astype(np.float64), 0.0)
-    errs = []
-    for side in (gpu, ora):
-        X = side.published()["keypoints"]["joint"][:, k2f]
-        Xh = np.concatenate([X, np.ones(X.shape[:-1] + (1,))], -1)
-        pr = np.einsum("cij,pkj->pkci", P, Xh)
-        z = np.where(np.abs(pr[..., 2]) > 1e-150, pr[..., 2], 1e-150)
-        with np.errstate(over="ignore", invalid="ignore"):
-            errs.append(cfd * np.where(use, np.hypot(pr[..., 0] / z - x, pr[..., 1] / z - y), 0.0))     # [n][17][N] confidence-weighted terms
-    out = np.zeros((n, pm.NUM_KEYPOINTS))
-    nv = use.sum(-1)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        for drop in [None] + list(range(rig.n_cam)):
-            keep = np.ones(rig.n_cam, bool)
-            if drop is not None:
-                keep[drop] = False
-            den = np.maximum((cfd * keep).sum(-1), 1e-150)
-            eg, eo = (errs[0] * keep).sum(-1) / den, (errs[1] * keep).sum(-1) / den
-            lo = np.minimum(eg, eo)
-            rel = np.where(lo > 0, np.abs(eg - eo) / lo, 0.0)
-            applies = (np.maximum(eg, eo) > 0.8 * 0.05) & (nv >= (2 if drop is None else 3)) & (True if drop is None else use[..., drop])
-            out = np.where(applies, np.fmax(out, rel), out)
-    return np.nan_to_num(out, nan=0.0, posinf=np.inf)
 
 
 def garbage_persons(persons3d):

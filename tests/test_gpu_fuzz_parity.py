@@ -1,9 +1,10 @@
-"""Randomised GPU-vs-oracle parity sweep inside the suite (round 2 ran it as a tool that only tallied): fixed seeds — among them 4, 15, 37,
-whose scenes made the default stage-2 path diverge from the oracle in round 2, 1, 3, 39 with joints more than 1 mm off, and 104, 203, the
-two of 18 further seeds (101 - 112, 201 - 206) that showed something new in round 3 (a joint with a 90 km covariance, a covariance 1.2 % over
-the flat tolerance at kappa = 744: tests/parity.py garbage_persons, cov_tolerance) — and the
-assertion that NOTHING outside an input-derived exclusion set deviates: tests/fuzz_core.py states what is compared and where the exclusion
-criteria (tests/parity.py: DLT_KAPPA_MAX, GARBAGE_JOINT_DIST_M, GARBAGE_JOINT_SIGMA_M) draw the line; the size of the exclusion set is asserted too."""
+"""Randomised GPU-vs-oracle parity sweep inside the suite: fixed seeds — among them 4, 15, 37, whose scenes made the default stage-2 path
+diverge from the oracle in round 2, 1, 3, 39 with joints more than 1 mm off in round 2 (up to 26.6 m: ill-conditioned DLT systems, which
+round 3 put into an exclusion set), and 104, 203 (a joint with a 90 km covariance, a covariance 1.2 % over the flat tolerance at kappa = 744).
+
+Round 4: NO exclusion set for stage-1 positions and scores — the library sends the joints its fp64 fast path cannot guarantee through a second
+pass with the reference's float32 arithmetic (csrc/se3d_exact32.h) — and the library's flag is itself checked against the inputs
+(`ill_not_listed`).  tests/fuzz_core.py states what is compared; stage 2 keeps its garbage-person exclusion (tests/parity.py)."""
 import json
 import os
 import sys
@@ -23,21 +24,22 @@ VARIANTS = [(s, "simple", False) for s in SEEDS] + [(5, "h36m", False), (6, "sim
 
 
 @pytest.mark.parametrize("seed,pose_method,norm_height", VARIANTS)
-def test_random_scenes_match_the_oracle_outside_the_ill_conditioned_set(oracle, seed, pose_method, norm_height):
+def test_random_scenes_match_the_oracle_on_every_joint(oracle, seed, pose_method, norm_height):
     rep = run_trials(oracle, seed, TRIALS, pose_method=pose_method, norm_height=norm_height)
     viol = rep.pop("violations")
     print(json.dumps(rep))
     assert rep["frames"] == TRIALS * 36 and rep["joints"] > 50_000
-    # stage 1, everything outside the exclusion set
+    # stage 1: every valid joint (positions < 1 mm, scores rtol 2e-5, covariances inside parity.cov_tolerance); nothing excluded
     assert rep["joints_over_1mm"] == 0 and rep["scores_over_rtol"] == 0 and rep["cov_over_tol"] == 0, viol[:5]
+    assert rep["joints_excluded"] == 0
+    # the library's conditioning flag covers what the inputs say is ill-conditioned
+    assert rep["ill_not_listed"] == 0, rep
     # stage 2, every sequence-step outside the exclusion set
     assert rep["stage2_index_divergences"] == 0 and rep["stage2_numeric_failures"] == 0, viol[:5]
-    # the exclusion sets stay small: joints whose DLT system is ill-conditioned, sequence-steps after a garbage person
-    assert rep["joints_excluded"] <= 0.01 * rep["joints"], rep
     assert rep["seq_steps_excluded"] <= 0.15 * rep["seq_steps"], rep
 
 
-def test_large_rig_scenes_match_the_oracle_outside_the_ill_conditioned_set():
+def test_large_rig_scenes_match_the_oracle_on_every_joint():
     """The same comparison on rigs of 32 / 48 cameras with 12 - 24 persons (FUZZ_LARGE=1: the rows pair kernel with camera-column chunks, the
     per-camera sweep launches, the per-joint triangulation kernel, the per-step stage 2), run as the tool in a child process because the
     scene sizes are module constants of tests/fuzz_scenes.py; 40 such seeds run in tools/fuzz_sweep.sh."""
@@ -50,5 +52,5 @@ def test_large_rig_scenes_match_the_oracle_outside_the_ill_conditioned_set():
     print(json.dumps({k: v for k, v in rep.items() if k != "tolerances"}))
     assert rep["frames"] == 48 and rep["joints"] > 10_000
     assert rep["joints_over_1mm"] == 0 and rep["scores_over_rtol"] == 0 and rep["cov_over_tol"] == 0
+    assert rep["joints_excluded"] == 0 and rep["ill_not_listed"] == 0
     assert rep["stage2_index_divergences"] == 0 and rep["stage2_numeric_failures"] == 0
-    assert rep["joints_excluded"] <= 0.03 * rep["joints"], rep

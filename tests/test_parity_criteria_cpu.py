@@ -18,23 +18,15 @@ def _frame_and_result(extr_rig, oracle, seed=5, **kw):
     return frames[0], res
 
 
-def test_allowances_vanish_for_identical_sides_and_grow_with_the_difference(extr_rig, oracle):
+def test_conditioning_figures_and_covariance_tolerance(extr_rig, oracle):
     fr, o = _frame_and_result(extr_rig, oracle, outlier_frac=0.05, pixel_noise=3.0)
     assert o.n_persons >= 4
-    assert np.array_equal(parity.score_allowance(extr_rig, fr, o, o), np.zeros((o.n_persons, pm.NUM_KEYPOINTS)))
     kap = parity.published_joint_condition(extr_rig, fr, o)
     v = o.published()["keypoints"]["score"][:, np.array(pm.KP2FUSION_SIMPLE)] > 0
     assert not np.isnan(kap[v]).any() and (kap[v] > 1.0).all()
-    tables = oracle.pose_tables(pm.POSE_SIMPLE)
-    kc = parity.covariance_condition(kap, tables)
+    own = parity.plain_condition(extr_rig, fr, o.assoc())[o.person_hyp[:o.n_persons]]
     with np.errstate(invalid="ignore"):
-        assert (np.nan_to_num(kc, nan=0.0) >= np.nan_to_num(kap, nan=0.0)).all()          # the parent's system can only add
-    # a side whose points are 0.5 mm off: the score allowance is non-zero exactly where the reprojection error comes near / above the threshold
-    o2 = copy.copy(o)
-    o2.persons = o.persons.copy()
-    o2.persons["keypoints"]["joint"][: o.n_persons] += 5e-4
-    sa = parity.score_allowance(extr_rig, fr, o, o2)
-    assert np.isfinite(sa).all() and (sa >= 0).all() and (sa > 0).any() and (sa == 0).any()
+        assert (np.nan_to_num(kap, nan=0.0) >= np.nan_to_num(own, nan=0.0) * (1 - 1e-12)).all()   # merge partners can only add
     # covariance tolerance: the flat 1e-3 plus a term that grows with kappa and shrinks with sigma
     cov = np.zeros(6)
     cov[[0, 3, 5]] = 0.02 ** 2
@@ -42,7 +34,93 @@ def test_allowances_vanish_for_identical_sides_and_grow_with_the_difference(extr
     assert t[0] > parity.COV_REL_FRO and np.all(np.diff(t) > 0)
     cov[[0, 3, 5]] = 0.004 ** 2
     assert parity.cov_tolerance(62.0, cov) > 1.46e-3                                            # the 19-view joint of seed 320
-    assert parity.covariance_in_hall(cov) and not parity.covariance_in_hall(np.array([1157.0, -1056.0, 404.0, 963.0, -369.0, 141.0]))
+
+
+def test_kernel_conditioning_bound_is_an_upper_bound_of_kappa(extr_rig, oracle):
+    """fp64 / float32 mirrors of the library's in-kernel tests (csrc/se3d_stage1.hip: se3d_cond_level1_ok, se3d_kappa_flag) on the systems of a
+    rough scene: level 1 never passes a joint whose kappa reaches SE3D_EXACT_KAPPA, and the full test flags every joint at or above it
+    (it bounds kappa from above: 1.04 .. 2.1 x in the study of profiles/r4)."""
+    K = 1.0e3
+    n_ill = n_tot = n_l1_pass = n_flag = 0
+    rng = np.random.default_rng(0)
+    for seed in range(3, 11):
+        fr, o = _frame_and_result(extr_rig, oracle, seed=seed, outlier_frac=0.03, pixel_noise=3.0)
+        r0, r1, use, cf, x, y = parity._dlt_rows(extr_rig, fr, o.assoc())
+        a0, a1 = r0.astype(np.float64), r1.astype(np.float64)
+        outer = a0[..., :, None] * a0[..., None, :] + a1[..., :, None] * a1[..., None, :]
+        for h, j in zip(*np.nonzero(use.sum(-1) >= 2)):
+            views = np.nonzero(use[h, j])[0]
+            for m in (0, 2, 3, len(views)):    # the joint's own system, two random sub-systems, and (m = 0) a pair of views of two DIFFERENT
+                if m > len(views):             # persons: rays that do not meet — the ill-conditioned tail the flags exist for
+                    continue
+                sel = np.zeros(extr_rig.n_cam)
+                if m == 0:
+                    h2 = (h + 1) % len(use)
+                    v2 = np.nonzero(use[h2, j])[0]
+                    v2 = v2[v2 != views[0]]
+                    if len(v2) == 0:
+                        continue
+                    b = int(rng.choice(v2))
+                    Gu = outer[h, j][views[0]] + outer[h2, j][b]
+                    Gw = outer[h, j][views[0]] * float(cf[h, j][views[0]]) ** 2 + outer[h2, j][b] * float(cf[h2, j][b]) ** 2
+                    m = 2
+                else:
+                    sel[rng.choice(views, m, replace=False)] = 1.0
+                    Gu = (outer[h, j] * sel[:, None, None]).sum(0)
+                    Gw = (outer[h, j] * (sel * cf[h, j].astype(np.float64) ** 2)[:, None, None]).sum(0)
+                (ku, _), (kw, X) = parity._kappa_from_gram(Gu), parity._kappa_from_gram(Gw)
+                kap = max(float(ku), float(kw))
+                if not np.isfinite(X).all():
+                    continue
+                n_tot += 1
+                ill = kap >= K
+                n_ill += int(ill)
+                l1 = _level1_ok(Gw, X, m, K)
+                flag = _kappa_flag(Gw.astype(np.float32), X.astype(np.float32), K) or _kappa_flag(Gu.astype(np.float32), X.astype(np.float32), K)
+                n_l1_pass += int(l1)
+                n_flag += int(flag)
+                assert not (ill and l1), ("level 1 passed an ill-conditioned joint", seed, h, j, m, kap)
+                assert flag or not ill, ("full test missed an ill-conditioned joint", seed, h, j, m, kap)
+    print("%d systems, %d ill-conditioned, level 1 passes %d, full test flags %d" % (n_tot, n_ill, n_l1_pass, n_flag))
+    assert n_ill >= 20 and n_l1_pass > 0.3 * n_tot and n_flag < 0.5 * n_tot, (n_tot, n_ill, n_l1_pass, n_flag)
+
+
+def _level1_ok(G, p, n, K):
+    """se3d_cond_level1_ok: pivots of the LDL^T factorisation in natural order = ratios of leading principal minors."""
+    d = [np.linalg.det(G[:k + 1, :k + 1]) for k in range(4)]
+    piv = [d[0], d[1] / d[0], d[2] / d[1], max(d[3] / d[2], 0.0)]
+    tr3 = G[0, 0] + G[1, 1] + G[2, 2]
+    L4, T2 = 4.0 * piv[0] * piv[1] * piv[2], tr3 * tr3
+    vv = 1.0 + p @ p
+    return bool(200.0 * piv[3] * T2 <= L4 * vv and vv * vv * (32.0 / 9.0) * n * T2 < K * K * L4)
+
+
+def _kappa_flag(g, p, K):
+    """se3d_kappa_flag in float32."""
+    f = np.float32
+    a, b, c, d = g[0, 0], g[0, 1], g[0, 2], g[0, 3]
+    e, ff, h = g[1, 1], g[1, 2], g[1, 3]
+    i, k, l = g[2, 2], g[2, 3], g[3, 3]
+    c1 = (a + e) + (i + l)
+    m12, m13, m23 = e * i - ff * ff, e * l - h * h, i * l - k * k
+    c2 = ((a * e - b * b) + (a * i - c * c)) + ((a * l - d * d) + m12) + (m13 + m23)
+    M012 = a * m12 - b * (b * i - c * ff) + c * (b * ff - c * e)
+    M013 = a * m13 - b * (b * l - d * h) + d * (b * h - d * e)
+    M023 = a * m23 - c * (c * l - d * k) + d * (c * k - d * i)
+    M123 = e * m23 - ff * (ff * l - h * k) + h * (ff * k - h * i)
+    c3 = (M012 + M013) + (M023 + M123)
+    v = np.array([p[0], p[1], p[2], f(1)], f)
+    vv = v @ v
+    lam4 = max((v @ (g @ v)) / vv, f(0))
+    b1 = c1 - lam4
+    b2 = c2 - lam4 * b1
+    b3 = c3 - lam4 * b2
+    t = b2 * b2 - f(2) * (b1 * b3)
+    if not (t > 0 and b3 > 0):
+        return True
+    xx = b3 / np.sqrt(t)
+    gap2 = (xx + lam4) - f(2) * np.sqrt(xx * lam4)
+    return not (xx > lam4 and (vv * vv) * c1 < f(K * K) * gap2)
 
 
 def test_garbage_persons_flags_distance_and_sigma():
@@ -56,40 +134,3 @@ def test_garbage_persons_flags_distance_and_sigma():
     assert parity.garbage_persons(p).tolist() == [False, True, True]
     p["keypoints"]["cov"][2, 7, [0, 3, 5]] = 50.0 ** 2                     # 50 m: still a usable (weak) unary factor
     assert parity.garbage_persons(p).tolist() == [False, True, False]
-
-
-def test_branch_tie_of_the_outlier_rejection_is_in_the_exclusion_set(extr_rig, oracle):
-    """A view is moved until the fp64 reprojection error of the weighted solution sits on g_reproj_error_max_acceptable: the criterion must
-    return inf for that joint (the two sides decide the rejection differently there), and a finite kappa a little away from the threshold."""
-    fr, o = _frame_and_result(extr_rig, oracle, seed=9)
-    h = int(o.person_hyp[0])
-    row = o.assoc()[h]
-    cams = np.nonzero(row >= 0)[0]
-    assert len(cams) >= 5
-    c, j = int(cams[0]), 5
-    det = fr.det_offset[c] + row[c]
-
-    def err_with_offset(dx):
-        f2 = copy.copy(fr)
-        f2.persons = fr.persons.copy()
-        f2.persons["keypoints"]["x"][det, j] += dx
-        _, _, use, cf, x, y = parity._dlt_rows(extr_rig, f2, o.assoc()[h:h + 1])
-        kap, X = parity.dlt_condition(extr_rig, f2, o.assoc()[h:h + 1], want_points=True)
-        P = extr_rig.Rt.reshape(extr_rig.n_cam, 3, 4).astype(np.float64)
-        pr = P @ np.append(X[0, j], 1.0)
-        e = np.hypot(pr[:, 0] / pr[:, 2] - x[0, j], pr[:, 1] / pr[:, 2] - y[0, j])
-        w = np.where(use[0, j], cf[0, j].astype(np.float64), 0.0)
-        return float((w * np.where(use[0, j], e, 0.0)).sum() / w.sum()), float(kap[0, j])
-    lo, hi = 0.0, 400.0                                                     # pixels: bisect the offset that puts the error on the threshold
-    assert err_with_offset(lo)[0] < 0.05 < err_with_offset(hi)[0]
-    for _ in range(60):
-        mid = 0.5 * (lo + hi)
-        if err_with_offset(mid)[0] < 0.05:
-            lo = mid
-        else:
-            hi = mid
-    e_tie, k_tie = err_with_offset(hi)
-    if abs(e_tie - 0.05) <= parity.BRANCH_TIE_REL * 0.05:                   # (the float32 pixel grid may not reach the band: then only the far side is checked)
-        assert k_tie == np.inf
-    e_far, k_far = err_with_offset(hi * 1.05)
-    assert abs(e_far - 0.05) > parity.BRANCH_TIE_REL * 0.05 and np.isfinite(k_far)

@@ -14,9 +14,9 @@ for s in $(seq 1001 1040); do FUZZ_LARGE=1 timeout 600 python tools/fuzz_parity.
 python3 - "$OUT" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
-bad = [r["seed"] for r in rows if r["joints_over_1mm"] or r["scores_over_rtol"] or r["cov_over_tol"] or r["stage2_numeric_failures"] or r["stage2_index_divergences"]]
+bad = [r["seed"] for r in rows if r["joints_over_1mm"] or r["scores_over_rtol"] or r["cov_over_tol"] or r["ill_not_listed"] or r["stage2_numeric_failures"] or r["stage2_index_divergences"]]
 tot = lambda k: sum(r[k] for r in rows)
-print("runs %d, joints %d (excluded %d, covariance-only excluded %d by the parent's system + %d by sigma > 1 m), over 1 mm %d, scores %d, covariances %d (over the flat 1e-3: %d), sequence-steps %d (excluded %d), stage-2 numeric %d, index %d; runs with a miss: %s"
-      % (len(rows), tot("joints"), tot("joints_excluded"), tot("cov_excluded_by_parent"), tot("cov_excluded_by_sigma"), tot("joints_over_1mm"), tot("scores_over_rtol"), tot("cov_over_tol"), tot("cov_over_flat_1e-3"),
-         tot("seq_steps"), tot("seq_steps_excluded"), tot("stage2_numeric_failures"), tot("stage2_index_divergences"), bad))
+print("runs %d, joints %d (excluded %d; second pass %d; input-derived kappa >= 2e3: %d, of them not listed %d), over 1 mm %d (worst %.4f mm), scores %d, covariances %d (over the flat 1e-3: %d, worst %.2e), sequence-steps %d (excluded %d), stage-2 numeric %d, index %d; runs with a miss: %s"
+      % (len(rows), tot("joints"), tot("joints_excluded"), tot("joints_second_pass"), tot("ill_joints"), tot("ill_not_listed"), tot("joints_over_1mm"), max(r["pos_max_mm"] for r in rows), tot("scores_over_rtol"), tot("cov_over_tol"), tot("cov_over_flat_1e-3"),
+         max(r["cov_rel_max"] for r in rows), tot("seq_steps"), tot("seq_steps_excluded"), tot("stage2_numeric_failures"), tot("stage2_index_divergences"), bad))
 PY

@@ -1,0 +1,67 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun -- bash tools/profile_r4.sh <what> ...): the rocprofv3 passes behind profiles/r4/.
+#   serial      : bench.py --serial (one context, one stream) kernel stats
+#   serial_ab   : the same with SE3D_EXACT=0 (round 3's second pass) for the cost of the conditioning flags
+#   serial_pmc  : SQ + HBM traffic PMC passes of the serial pass
+#   c256        : 256cam128p, one context: kernel stats (+ PMC with c256_pmc)
+set -u
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_r4
+mkdir -p "$OUT"
+SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+for what in "$@"; do
+case $what in
+serial)
+  rm -rf $OUT/serial_stats
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_stats -- python3 bench.py --serial --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_stats.log 2>&1
+  python3 tools/kernel_stats.py $OUT/serial_stats $OUT/serial_16cam6p_kernel_stats.csv
+  ;;
+serial_ab)
+  rm -rf $OUT/serial_stats_ab
+  export SE3D_EXACT=0
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_stats_ab -- python3 bench.py --serial --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_stats_ab.log 2>&1
+  unset SE3D_EXACT
+  python3 tools/kernel_stats.py $OUT/serial_stats_ab $OUT/serial_16cam6p_exact0_kernel_stats.csv
+  ;;
+serial_pmc)
+  rm -rf $OUT/serial_sq $OUT/serial_fetch $OUT/serial_write
+  timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/serial_sq -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_sq.log 2>&1
+  python3 tools/pmc_sq.py $OUT/serial_sq $OUT/pmc_sq_16cam6p_serial.json "bench.py --serial --steps 2 --warmup 1 (16cam6p, one context, 6144 sequences x 16 frames)"
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/serial_fetch -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_fetch.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/serial_write -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_write.log 2>&1
+  python3 tools/pmc_traffic2.py $OUT/serial_fetch $OUT/serial_write $OUT/pmc_traffic_16cam6p_serial.json 6144 "bench.py --serial --steps 2 --warmup 1"
+  ;;
+ablate)
+  # a variant library (tools/tmp/libse3d_<name>.so, built with an ablation macro) through the serial pass: ablate=<name> via ABLATE env
+  rm -rf $OUT/serial_stats_$ABLATE
+  export SE3D_LIB_OVERRIDE=$GRAFT_REPO_ROOT/tools/tmp/libse3d_$ABLATE.so
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_stats_$ABLATE -- python3 bench.py --serial --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_stats_$ABLATE.log 2>&1
+  unset SE3D_LIB_OVERRIDE
+  python3 tools/kernel_stats.py $OUT/serial_stats_$ABLATE $OUT/serial_16cam6p_${ABLATE}_kernel_stats.csv
+  ;;
+exact_waves)
+  # second pass with the workspace in global memory and W wavefronts (A/B of the LDS workspace, 4 wavefronts per CU)
+  for W in 2048 4096 8192; do
+    rm -rf $OUT/serial_stats_w$W
+    export SE3D_EXACT_WAVES=$W
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_stats_w$W -- python3 bench.py --serial --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_stats_w$W.log 2>&1
+    unset SE3D_EXACT_WAVES
+    python3 tools/kernel_stats.py $OUT/serial_stats_w$W $OUT/serial_16cam6p_w${W}_kernel_stats.csv | grep triang
+  done
+  ;;
+c256)
+  rm -rf $OUT/c256_stats1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c256_stats1 -- python3 bench.py --workload 256cam128p --contexts 1 --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $OUT/c256_bench_1ctx.log 2>&1
+  python3 tools/kernel_stats.py $OUT/c256_stats1 $OUT/c256_1ctx_kernel_stats.csv
+  ;;
+c256_pmc)
+  rm -rf $OUT/c256_sq $OUT/c256_fetch $OUT/c256_write
+  timeout 900 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/c256_sq -- python3 bench.py --workload 256cam128p --contexts 1 --steps 1 --warmup 1 --no-cpu-baseline --no-parity > $OUT/c256_bench_sq.log 2>&1
+  python3 tools/pmc_sq.py $OUT/c256_sq $OUT/pmc_sq_256cam128p_1ctx.json "bench.py --workload 256cam128p --contexts 1 --steps 1 --warmup 1"
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/c256_fetch -- python3 bench.py --workload 256cam128p --contexts 1 --steps 1 --warmup 1 --no-cpu-baseline --no-parity > $OUT/c256_bench_fetch.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/c256_write -- python3 bench.py --workload 256cam128p --contexts 1 --steps 1 --warmup 1 --no-cpu-baseline --no-parity > $OUT/c256_bench_write.log 2>&1
+  python3 tools/pmc_traffic2.py $OUT/c256_fetch $OUT/c256_write $OUT/pmc_traffic_256cam128p_1ctx.json 4 "bench.py --workload 256cam128p --contexts 1 --steps 1 --warmup 1 (one context, 4 sequences x 16 frames)"
+  ;;
+esac
+done
