@@ -1,0 +1,19 @@
+#!/bin/bash
+# Blind check of the randomised parity sweep (GPU box): seeds never run before the criteria were frozen (commit 929e612), reported unedited.
+#   bash tools/fuzz_blind.sh [out]      100 runs: 70 x default, 10 x h36m, 10 x norm_height (40 scenes each), 10 x large rigs (20 scenes)
+OUT=${1:-gpurun_out/fuzz_blind.log}
+mkdir -p "$(dirname "$OUT")"
+: > "$OUT"
+for s in $(seq 2001 2070); do timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
+for s in $(seq 2071 2080); do FUZZ_POSE=h36m timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
+for s in $(seq 2081 2090); do FUZZ_NORM_HEIGHT=1 timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
+for s in $(seq 2091 2100); do FUZZ_LARGE=1 timeout 600 python tools/fuzz_parity.py $s 20 2>> "$OUT.err" | tail -1 >> "$OUT"; done
+python3 - "$OUT" <<'PY'
+import json, sys
+rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
+bad = [r["seed"] for r in rows if r["joints_over_1mm"] or r["scores_over_rtol"] or r["cov_over_tol"] or r["ill_not_listed"] or r["stage2_numeric_failures"] or r["stage2_index_divergences"]]
+tot = lambda k: sum(r[k] for r in rows)
+print("runs %d, joints %d (excluded %d; second pass %d; input-derived kappa >= 2e3: %d, of them not listed %d), over 1 mm %d (worst %.4f mm), scores %d, covariances %d (over the flat 1e-3: %d, worst %.2e), sequence-steps %d (excluded %d), stage-2 numeric %d, index %d; runs with a miss: %s"
+      % (len(rows), tot("joints"), tot("joints_excluded"), tot("joints_second_pass"), tot("ill_joints"), tot("ill_not_listed"), tot("joints_over_1mm"), max(r["pos_max_mm"] for r in rows), tot("scores_over_rtol"), tot("cov_over_tol"), tot("cov_over_flat_1e-3"),
+         max(r["cov_rel_max"] for r in rows), tot("seq_steps"), tot("seq_steps_excluded"), tot("stage2_numeric_failures"), tot("stage2_index_divergences"), bad))
+PY
