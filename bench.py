@@ -389,7 +389,7 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
             if ex is not None:
                 ex.packed(ci)
 
-    def step(collect=None):
+    def step(collect=None, exchange=True):
         if not stage2:
             for wk in walks:
                 issue_stage1(wk)
@@ -398,7 +398,7 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
                 issue_stage1(wk) if wk["ci"] % 2 == 0 else issue_walk(wk, collect)
             for wk in walks:   # phase B
                 issue_walk(wk, collect) if wk["ci"] % 2 == 0 else issue_stage1(wk)
-        return ex.exchange() if ex is not None else None
+        return ex.exchange() if ex is not None and exchange else None
 
     for nd_ in nodes:
         nd_.run_stage1()   # phase-shifted contexts start inside the stage-2 walk: their frames need one completed stage-1 pass
@@ -411,6 +411,8 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
     for nd_ in nodes:    # HIP-event kernel timing on every context's own stream
         nd_.profile(True)
         nd_.profile_reset()
+    if ex is not None:
+        ex.timed(True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -429,12 +431,34 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    exchange_ms = dt_nx = None
+    if ex is not None:
+        ex.finish()
+        exchange_ms = ex.exchange_ms()
+        ex.timed(False)
     exchange_ok = None
     if ex is not None and verify_exchange:   # every rank's gathered buffer == concatenation of all ranks' packs (last timed step)
         ok = torch.tensor([1 if ex.verify(last_parity) else 0], dtype=torch.int32, device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         exchange_ok = bool(ok.item())
         assert exchange_ok, "RCCL exchange: a gathered buffer differs from the ranks' pack buffers"
+    # ---- diagnosis of the exchange (round 4; the scaling curve is the driver's to measure, these keys say where a loss comes from): the
+    # all-gather's own duration per step (stamped above) and the SAME step with the all-gather skipped (packs still written), one short pass ----
+    if ex is not None:
+        steps_nx = max(2, steps // 4)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps_nx):
+            step(exchange=False)
+        for nd_ in nodes:
+            nd_.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt_nx = (time.perf_counter() - t1) / steps_nx
+        tnx = torch.tensor([dt_nx], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tnx, op=dist.ReduceOp.MAX)
+        dt_nx = float(tnx.item())
     # untimed accounting pass: published skeletons of one (steady-state) step
     s1 = [r for nd_ in nodes for r in nd_.fetch_stage1(B)]
     n_s1 = sum(r.n_persons for r in s1)
@@ -467,9 +491,11 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         "n_s1": n_s1, "NC": NC, "S": S_, "T": T_, "B": B, "steps": steps, "warmup": warmup, "prof": prof,
         "kernel_ms_per_step": {k: v[0] / steps / NC for k, v in prof.items()},   # per context and step
         "max_hyp_per_frame": int(max(r.n_hyp for r in s1)), "max_published_per_frame": int(max_pub[0]), "exchange_verified": exchange_ok,
-        "lm_iterations_mean": float(np.mean(lm_iters)) if lm_iters else None, "params": node.params,
+        "lm_iterations_mean": float(np.mean(lm_iters)) if lm_iters else None, "params": node.params, "pair_chunks": node.pair_chunks(),
         "exchange": None if ex is None else {"form": "dense: published persons back to back + per-frame offsets" if dense_cap else "[frame][%d person slots] + counts" % XH,
                                              "bytes_per_rank_per_step": int(NC * (ex.sp + 4 * ex.sc))},
+        "exchange_ms_per_step": None if exchange_ms is None else round(exchange_ms[0], 4), "exchange_ms_max": None if exchange_ms is None else round(exchange_ms[1], 4),
+        "ms_per_step_no_exchange": None if dt_nx is None else dt_nx * 1e3, "value_no_exchange": None if dt_nx is None else n_skel / dt_nx,
     }
     if reproj and stage2 and fused_walk:
         res["reprojection"] = bench_reprojection(node, rig, min(B, 16384))
@@ -810,6 +836,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-only", action="store_true", help="only the B = 1 latency block (one 16cam6p frame per call), printed as its own JSON line")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity / latency blocks of a default run")
+    ap.add_argument("--hyp-shard", action="store_true", help="with --workload 256cam128p under the launcher: also run the hypothesis-shard block "
+                    "(north_star config 5 as a latency mode) that a default multi-rank run ends with")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -880,7 +908,7 @@ def main():
             sec_serial = run_workload("256cam128p", [seqs_sec[0]], rig2, args, 3, 1, None, local_rank, True)
             sec_serial["value_per_gpu"] = sec_serial["value"]
 
-    # Order of a default run: the 256cam128p measurement FIRST, on the fresh device (its four contexts take 272 of the 288 GB; behind the
+    # Order of a default run: the 256cam128p measurement FIRST, on the fresh device (its four contexts take 154 of the 288 GB — 272 in round 2, whole pair tables; behind the
     # headline's twelve contexts the same measurement came out ~8 % lower, behind the streaming contexts at half speed — measured, cause
     # not isolated), then the headline, the serial pass and the streaming pass.  SE3D_BENCH_SECONDARY_LAST=1 restores the old order.
     sec_first = want_secondary and not os.environ.get("SE3D_BENCH_SECONDARY_LAST")
@@ -914,10 +942,12 @@ def main():
     # within the deadline (ranks != 0 wait in it while rank 0 runs its serial / streaming passes: minutes at most) ends the run with the
     # line printed instead of hanging the launcher.
     hyp_error, hyp_hung = None, False
-    if want_secondary and dist is not None:
+    want_hyp = (want_secondary or (args.hyp_shard and headline == "256cam128p")) and dist is not None
+    if want_hyp:
+        rig_h = rig2 if want_secondary else rig
         def hyp_run():
             torch.cuda.set_device(local_rank)   # the current device is per thread
-            return run_hypothesis_shard("256cam128p", _gen_one((256, 128, T_, 0)), rig2, 2, dist, local_rank)
+            return run_hypothesis_shard("256cam128p", _gen_one((256, 128, T_, 0)), rig_h, 2, dist, local_rank)
         hyp, hyp_error, hyp_hung = guarded(hyp_run, float(os.environ.get("SE3D_BENCH_HYP_DEADLINE_S", "900")), "hypothesis shard")
     if rank == 0:
         main_res = head or serial
@@ -953,6 +983,15 @@ def main():
                        "exchange": main_res.get("exchange")},
             "roofline": roof,
         }
+        if dist is not None:   # what lets an N > 1 run be read (round 4): the all-gather's own time, the step without it, what RCCL reports
+            line["exchange_ms_per_step"] = main_res["exchange_ms_per_step"]
+            line["exchange_ms_max"] = main_res["exchange_ms_max"]
+            line["value_no_exchange"] = None if main_res["value_no_exchange"] is None else round(main_res["value_no_exchange"], 2)
+            line["ms_per_step_no_exchange"] = None if main_res["ms_per_step_no_exchange"] is None else round(main_res["ms_per_step_no_exchange"], 4)
+            line["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                  "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                                  "note": "exchange_ms_per_step = mean device time of the step's all-gather pair on its own stream (it overlaps the next step's "
+                                          "kernels); value_no_exchange = the same steps with the all-gather skipped, %d extra steps" % max(2, main_res["steps"] // 4)}
         if head is not None:
             line["overlapped_kernel_ms_per_step"] = {k: round(v, 5) for k, v in head["kernel_ms_per_step"].items()}
         if serial is not None and head is not None:
@@ -977,7 +1016,7 @@ def main():
                 if tr2:
                     per_launch = tr2["kernels"].get(roof2["kernel"], {}).get("hbm_bytes_per_launch_corrected")
                     # column chunks: the "launch" the HIP events bracket is the pass's whole pair phase = one kernel launch per chunk (16 from 128 cameras)
-                    n_launch = (16 if WORKLOADS["256cam128p"]["n_cam"] >= 128 else 8) if roof2["kernel"] == "epipolar_pairs" and not os.environ.get("SE3D_PAIR_CHUNKS") else 1
+                    n_launch = max(1, sec_serial["pair_chunks"]) if roof2["kernel"] == "epipolar_pairs" else 1   # what the context actually runs with (se3d_get_pair_chunks)
                     roof2["traffic"] = per_launch * n_launch if per_launch is not None else None
                     roof2["traffic_source"] = "%s: %s bytes per kernel launch x %d launches per pass" % (tr2["_file"], per_launch, n_launch)
             else:
@@ -988,6 +1027,7 @@ def main():
                                  "ms_per_step": round(sec["ms_per_step"], 3), "steps": sec["steps"], "warmup": sec["warmup"],
                                  "skeletons_per_step_per_gpu": sec["n_skel_local"], "max_hypotheses_per_frame": sec["max_hyp_per_frame"],
                                  "target": "north_star: >= 1e5 skeletons/s on 8 GPUs = 12 500 per GPU", "exchange_verified": sec["exchange_verified"],
+                                 "exchange_ms_per_step": sec["exchange_ms_per_step"], "value_no_exchange": None if sec["value_no_exchange"] is None else round(sec["value_no_exchange"], 2),
                                  "roofline": roof2}
         if hyp is not None:
             line["hypothesis_shard"] = {"workload": "ONE 256cam128p stream, %d-frame walks, every rank holds the same frames; hypotheses / detections "
@@ -1001,7 +1041,9 @@ def main():
         if sec_serial is not None:
             line["secondary"]["serial"] = {"value": round(sec_serial["value"], 2), "ms_per_step": round(sec_serial["ms_per_step"], 3), "steps": sec_serial["steps"],
                                            "contexts": 1, "frames_per_step": sec_serial["B"]}
-        if want_parity:
+        if want_parity and hyp_hung:   # the GPU may still be spinning in the collective that never returned: nothing measured after it is trustworthy
+            line["parity"] = line["latency_B1"] = {"skipped": "a collective of the hypothesis-shard block did not return within its deadline"}
+        elif want_parity:
             line["parity"] = {"16cam6p": bench_parity(headline, rig, seqs_par, 4, local_rank), "64cam32p": bench_parity("64cam32p", rig64, [seq64], 1, local_rank),
                               "note": "HIP path vs the CPU oracle (restatement of the reference, DESIGN 4) on the bench's own scenes, untimed: stage-1 joints "
                                       "(mpjpe_*), association / hypothesis / person tables identical per frame (assoc_exact_rate), refined + predicted joints "
@@ -1012,9 +1054,9 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if hyp_hung:   # a collective of the guarded block never returned: the line is out, leave without the final barrier
-        sys.stdout.flush()
-        os._exit(0)
+    if hyp_hung:   # a collective of the guarded block never returned: the line is out, leave without the final barrier — with a NON-ZERO
+        sys.stdout.flush()   # code, so that the launcher tears the other ranks down and a harness sees the failure
+        os._exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

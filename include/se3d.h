@@ -278,6 +278,10 @@ int se3d_hungarian(se3d_ctx *ctx, int32_t *assignment, double *cost, const doubl
  * se3d_run_stage1: out[det_a * max_det_per_cam + det_b] = mean symmetric epipolar distance (calcCost inner loop,
  * S3D:353-368) in FILTERED detection slots, -1 where no joint is shared; n_a/n_b receive the valid slot counts. */
 int se3d_get_pair_costs(se3d_ctx *ctx, int32_t frame, int32_t cam_a, int32_t cam_b, double *out, int32_t *n_a, int32_t *n_b);
+/* Large rigs keep camera-column chunks of the pair table instead of the whole (se3d_get_pair_chunks > 0): there se3d_get_pair_costs is not a
+ * plain read — it RECOMPUTES the block with the pass's kernel into scratch of the context (pair slot 0 of the frame, first element of the cost
+ * matrix), which the next se3d_run_stage1 overwrites anyway.  In both modes entries outside [0, n_a) x [0, n_b) are undefined. */
+int se3d_get_pair_chunks(se3d_ctx *ctx);
 
 /* --- diagnostic accessor: the FUSION_BODY_PARTS constants compiled into the kernels (fusion_body_parts.h:3-24, 33): indices22 = the joint
  * indices in the enum's declaration order, NUM_KEYPOINTS last (-1 for joints the kernels never name), vel_sigmas21 read back from the

@@ -31,6 +31,7 @@ extern "C" void se3d_launch_stream_compact(const se3d_person3d *fused, const se3
                                            se3d_person3d *dense_fused, se3d_person3d *dense_pred, hipStream_t st);
 extern "C" hipError_t se3d_stage1_init_device(void);
 extern "C" hipError_t se3d_stage2_init_device(void);
+extern "C" hipError_t se3d_reproj_init_device(void);
 
 #define SE3D_VERSION "se3d-hip 0.1.0 (gfx950)"
 
@@ -502,7 +503,8 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     for (auto &e : c->ev_hi) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
   }
   // dynamic-LDS limits of the large-LDS kernels: a per-device attribute, so it is set for every context's device
-  if (!hip_ok(c, se3d_stage1_init_device(), "hipFuncSetAttribute (stage 1)") || !hip_ok(c, se3d_stage2_init_device(), "hipFuncSetAttribute (stage 2)")) {
+  if (!hip_ok(c, se3d_stage1_init_device(), "hipFuncSetAttribute (stage 1)") || !hip_ok(c, se3d_stage2_init_device(), "hipFuncSetAttribute (stage 2)") ||
+      !hip_ok(c, se3d_reproj_init_device(), "hipFuncSetAttribute (reprojection)")) {
     create_error("se3d_create: %s", c->err.c_str());
     (void)hipStreamDestroy(c->stream);
     if (c->stream_hi) (void)hipStreamDestroy(c->stream_hi);
@@ -836,13 +838,20 @@ int se3d_get_pair_costs(se3d_ctx *c, int32_t frame, int32_t cam_a, int32_t cam_b
   if (D.d.pair_chunks) {
     // column chunks: the table of the pass is gone (every chunk buffer has been overwritten since); the block is computed again by the
     // pair kernel of the pass into slot 0 of the frame (one-entry pair list in the first element of C, free between passes)
+    // (both are scratch between passes — the next se3d_run_stage1 rewrites them — and the slot is cleared to -1 first, "no joint shared":
+    // the kernel writes nothing for a camera without valid detections)
     const int2 one = make_int2(cam_a, cam_b);
     HIPCHK(c, hipMemcpyAsync(D.C, &one, sizeof(int2), hipMemcpyHostToDevice, c->stream));
+    off = (size_t)frame * D.d.pair_stride * P * P;
+    {
+      std::vector<double> neg((size_t)P * P, -1.0);
+      HIPCHK(c, hipMemcpyAsync(D.pair + off, neg.data(), sizeof(double) * (size_t)P * P, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));   // `neg` leaves scope
+    }
     Se3dDev D1 = D;
     D1.d.B = 1;
     se3d_launch_pair_block(D1, reinterpret_cast<const int2 *>(D.C), frame, c->stream);
     HIPCHK(c, hipGetLastError());
-    off = (size_t)frame * D.d.pair_stride * P * P;
   }
   int32_t nv[2];
   HIPCHK(c, hipMemcpyAsync(out, D.pair + off, sizeof(double) * (size_t)P * P, hipMemcpyDeviceToHost, c->stream));
@@ -1485,6 +1494,9 @@ int se3d_selftest_exact_math(se3d_ctx *c, uint64_t n_div, uint64_t *sqrt_mismatc
   *sqrt_mismatches = h[0]; *div_mismatches = h[1];
   return SE3D_OK;
 }
+
+// Diagnostic: camera-column chunks of the pair table in this context (0: the whole table is materialised).
+int se3d_get_pair_chunks(se3d_ctx *c) { return c ? c->D.d.pair_chunks : SE3D_ERR_ARG; }
 
 // Diagnostic: the second pass's float32 DLT solve on caller systems (se3d_k_selftest_dlt32).
 extern "C" hipError_t se3d_launch_selftest_dlt32(int n_sys, int n, const float *d_Rt, const float *d_pts, int weighted, float *d_ws, float *d_X, double *d_err, hipStream_t st);

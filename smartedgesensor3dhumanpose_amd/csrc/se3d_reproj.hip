@@ -255,6 +255,11 @@ size_t se3d_reproj_lists_lds(int N, int T) {
   return b <= 96 * 1024 ? b : 0;
 }
 
+// Kernel attributes are per DEVICE in HIP: called by se3d_create for the context's device (after hipSetDevice), like se3d_stage1_init_device.
+extern "C" hipError_t se3d_reproj_init_device(void) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_reproject_lists), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+}
+
 hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t stream, int batch) {
   if (n_grid <= 0 || batch <= 0) {
     return hipMemsetAsync(R.det_offset, 0, sizeof(int32_t) * (R.N + 1) * (size_t)(batch > 0 ? batch : 1), stream);
@@ -262,12 +267,7 @@ hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t st
   // small rigs: one workgroup per result slot, lists written directly (SE3D_REPROJ_DENSE=1: the three-kernel form, A/B)
   const size_t lds_lists = se3d_reproj_lists_lds(R.N, R.T);
   if (lds_lists > 0) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_reproject_lists), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      if (e != hipSuccess) return e;
-      attr_set = true;
-    }
+    // (the kernel's dynamic-LDS limit is raised per device by se3d_reproj_init_device, called from se3d_create)
     hipLaunchKernelGGL(se3d_k_reproject_lists, dim3(1, 1, batch), dim3(1024), lds_lists, stream, R);
     return hipGetLastError();
   }

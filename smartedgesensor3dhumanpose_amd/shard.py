@@ -102,6 +102,8 @@ class SkeletonExchange:
         self.events = [None] * self.n_ctx
         self.parity = 0
         self.n_exchanges = 0
+        self.timing = False        # timed(True): bracket every all-gather pair with events on the exchange stream (exchange_ms())
+        self._tev = []
 
     def pack_target(self, ci):
         """(persons_u8, counts_i32) slices context ci may overwrite for the current step."""
@@ -124,14 +126,37 @@ class SkeletonExchange:
                 for ev in self.events:
                     if ev is not None:
                         self.xstream.wait_event(ev)
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self.xstream)
                 self.works[p] = (self.dist.all_gather_into_tensor(self.gath_p[p], self.packs[p], async_op=True),
                                  self.dist.all_gather_into_tensor(self.gath_c[p], self.cnts[p], async_op=True))
+                if self.timing:   # the exchange stream waits (device side) for the collectives, then stamps their end
+                    for w in self.works[p]:
+                        w.wait()
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(self.xstream)
+                    self._tev.append((e0, e1))
         else:
             self.dist.all_gather_into_tensor(self.gath_p[p], self.packs[p])
             self.dist.all_gather_into_tensor(self.gath_c[p], self.cnts[p])
         self.parity ^= 1
         self.n_exchanges += 1
         return p
+
+    def timed(self, on=True):
+        """Switch the per-exchange event timing on / off (and forget earlier stamps)."""
+        self.timing = bool(on) and self.cuda
+        self._tev = []
+
+    def exchange_ms(self):
+        """(mean, max) duration in ms of the all-gather pairs stamped since timed(True): from the moment every context's pack was complete and
+        the collective could start to its end on the device — what the all-gather itself takes under the load of the other streams, NOT what
+        it adds to the step (it overlaps the next step's kernels).  Call after finish()."""
+        if not self._tev:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self._tev]
+        return float(sum(ms) / len(ms)), float(max(ms))
 
     def finish(self):
         """Host-side wait for all outstanding collectives (end of the timed region / before reading a gathered buffer)."""

@@ -283,6 +283,10 @@ class Skeleton3D:
         self._chk(self._L.se3d_selftest_exact_math(C.c_void_p(self._h), C.c_uint64(int(n_div)), C.byref(a), C.byref(b)), "se3d_selftest_exact_math")
         return int(a.value), int(b.value)
 
+    def pair_chunks(self):
+        """Camera-column chunks of the pair table in this context (0: the whole table is materialised)."""
+        return int(self._L.se3d_get_pair_chunks(C.c_void_p(self._h)))
+
     def selftest_dlt32(self, Rt, pts, weight_by_conf=True):
         """The second pass's float32 DLT solve (se3d_exact32.h) on caller systems: Rt [n_sys][n][12], pts [n_sys][n][3] (x, y, conf)
         -> (X [n_sys][3] float32, reprojection error [n_sys] float64)."""

@@ -93,8 +93,11 @@ def compare_stage2(gpu, ora, check_iters=True, check_tracks=True):
         # A marginal covariance is a block of (J^T J)^-1 at the optimum; the range factors' Jacobians are unit bone directions, which turn by
         # delta / L when a joint moves by delta (L >= 0.05 m: the shortest bone, PP:386-479): two optima delta apart — inside the position
         # tolerance — differ by up to ~2 delta / L in the covariance.  The tolerance allows for the measured delta of this result.
-        cov_tol = MARG_COV_RTOL + 2.0 * float(d.max()) / 0.05
-        assert rel.max() < cov_tol, "%s covariance rel error %.2e (tolerance %.2e at a joint difference of %.2e m)" % (name, rel.max(), cov_tol, d.max())
+        # per person (a bone's two ends belong to one person), capped: 1e-2 is what a joint difference of 0.25 mm explains — a larger covariance
+        # deviation is a finding even when the positions are inside their tolerance.
+        dfull = np.where(vo, np.linalg.norm(g["joint"] - o["joint"], axis=-1), 0.0)
+        cov_tol = MARG_COV_RTOL + np.minimum(2.0 * dfull.max(-1, keepdims=True) / 0.05, 1e-2) * np.ones_like(dfull)
+        assert (rel < cov_tol[vo]).all(), "%s covariance rel error %.2e (tolerance %.2e at a joint difference of %.2e m)" % (name, rel.max(), cov_tol[vo][np.argmax(rel)], d.max())
     if check_iters:
         assert np.array_equal(gpu.lm_iterations[:n], ora.lm_iterations[:n]), (gpu.lm_iterations[:n], ora.lm_iterations[:n])
     return stats

@@ -28,6 +28,25 @@ def test_bench_exchange_under_launcher_world1():
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert "verified: True" in line["config"]["sharding"]
     assert line["roofline"]["frac"] > 0 and line["roofline"]["valu"]["achieved"] > 0
+    assert line["exchange_ms_per_step"] >= 0 and line["value_no_exchange"] > 0 and line["collective"]["world_size"] == 1
+
+
+def test_bench_256cam128p_under_launcher_with_hypothesis_shard_and_exchange_diagnosis():
+    """The code path of the driver's multi-GPU run at north_star's configuration, with one rank: 256cam128p under the launcher (RCCL exchange
+    of the slot form, verified), the exchange diagnosis keys of round 4, and the hypothesis-shard block behind its deadline."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SE3D_BENCH_HYP_DEADLINE_S="600")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29633",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "256cam128p", "--contexts", "1", "--seqs", "1", "--tsteps", "4", "--steps", "2", "--warmup", "1",
+           "--hyp-shard", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = _json_line(p.stdout)
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "verified: True" in line["config"]["sharding"]
+    assert line["exchange_ms_per_step"] is not None and line["exchange_ms_per_step"] >= 0 and line["value_no_exchange"] > 0
+    assert line["collective"]["world_size"] == 1 and line["collective"]["backend"] == "nccl"
+    hs = line["hypothesis_shard"]
+    assert "error" not in hs, hs
+    assert hs["verified_equal_to_single_rank"] is True and hs["skeletons_per_s"] > 0
 
 
 def test_bench_config2_line():
