@@ -356,7 +356,6 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
   ok = ok && dev_alloc(c, &D.C, (size_t)B * H * P) && dev_alloc(c, &D.mask, (size_t)B * H * P) && dev_alloc(c, &D.mwork, (size_t)B * H * P);
   {  // second pass of the triangulation (float32-exact solves of the flagged joints, se3d_k_triangulate_exact): list, counter, workspaces
     const size_t per_wave = (size_t)64 * 8 * N * sizeof(float), joints = (size_t)B * H * SE3D_NKP;
-    D.d.exact = 1;
     // one wavefront per 4 joints of the batch (the list is short: 0.1 % of the joints on clean scenes), 16 .. 4096 (16 per CU), <= 128 MB
     D.d.tri_waves = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(4096, std::max<size_t>(16, joints / 4)), ((size_t)128 << 20) / per_wave));
     ok = ok && dev_alloc(c, &D.tri_list, joints) && dev_alloc(c, &D.tri_cnt, (size_t)4) && dev_alloc(c, &D.tri_ws, (size_t)D.d.tri_waves * 64 * 8 * N);

@@ -29,8 +29,6 @@ struct Se3dDims {
   int shard_rank, shard_world;  // hypothesis shard (se3d_set_shard): this context triangulates hypotheses h with h % world == rank
   int pair_stride;              // pair slots per frame of `pair`: npairs (whole table) or 2 x the largest column chunk (se3d_pair_plan)
   int pair_chunks;              // 0: the whole pair table is materialised; m >= 2: camera-column chunks (large rigs), see Se3dPairPlan
-  int exact;                    // 1 (default): joints the triangulation flags are redone with the reference's float32 arithmetic (se3d_exact32.h);
-                                // 0 (SE3D_EXACT=0, A/B evidence): round 3's behaviour, outlier rejection by fp64 rank updates
   int tri_waves;                // wavefronts of se3d_k_triangulate_exact (one lane-interleaved workspace each in tri_ws)
 };
 

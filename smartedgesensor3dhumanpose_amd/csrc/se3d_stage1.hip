@@ -1459,6 +1459,41 @@ __device__ __forceinline__ void se3d_solve_point(const double g[10], const doubl
   p[0] = e4[0] * iw; p[1] = e4[1] * iw; p[2] = e4[2] * iw;
 }
 
+// Sigma samples (round 4): the dehomogenised null vector of a sample's Gram matrix G = [[B, u], [u^T, gamma]] from the 3 x 3 block.
+// The smallest eigenpair satisfies (B - lambda I) p = -u, lambda = u^T p + gamma, with lambda / mu3(B) ~ 1e-5 .. 1e-3 on a joint that
+// passed the conditioning test.  To first order in lambda:  p = p_a + lambda B^-1 p_a,  p_a = -B^-1 u,  lambda = d3 / (1 + |p_a|^2),
+// d3 = gamma + u^T p_a (the Schur complement = last pivot of the 4 x 4 factorisation); the neglected term is ~ c^2 / |p| for a correction of
+// size c = lambda |B^-1 p_a| (0.05 - 0.5 mm on the benchmark's scenes: 1e-9 m).  One LDL^T factorisation of the 3 x 3 block and two
+// substitutions, ~50 fp64 instructions, replace the 4 x 4 factorisation and two inverse-iteration steps (~85) of se3d_null_invit_point.
+// Returns false when a pivot is not positive or the correction is large (c^2 > 1e-5 (1 + |p|_1): second-order term above ~10 um): the caller
+// hands the joint to the float32 second pass.
+__device__ __forceinline__ bool se3d_sample_point(const double g[10], double p[3]) {
+  // g packed: 00 01 02 03 11 12 13 22 23 33
+  const double tiny = 1e-30 * ((g[0] + g[4]) + g[7]);
+  const double d0 = g[0];
+  const double i0 = se3d_rcp64<1>(d0);
+  const double l10 = g[1] * i0, l20 = g[2] * i0;
+  const double d1 = __builtin_fma(-l10, g[1], g[4]);
+  const double i1 = se3d_rcp64<1>(d1);
+  const double t21 = __builtin_fma(-l20, g[1], g[5]);
+  const double l21 = t21 * i1;
+  const double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, g[2], g[7]));
+  const double i2 = se3d_rcp64<1>(d2);
+  // p_a = -B^-1 u
+  const double y0 = -g[3], y1 = __builtin_fma(-l10, y0, -g[6]), y2 = __builtin_fma(-l21, y1, __builtin_fma(-l20, y0, -g[8]));
+  const double a2 = y2 * i2, a1 = __builtin_fma(-l21, a2, y1 * i1), a0 = __builtin_fma(-l20, a2, __builtin_fma(-l10, a1, y0 * i0));
+  const double d3 = __builtin_fma(g[3], a0, __builtin_fma(g[6], a1, __builtin_fma(g[8], a2, g[9])));
+  const double vv = __builtin_fma(a0, a0, __builtin_fma(a1, a1, __builtin_fma(a2, a2, 1.0)));
+  const double lam = fmax(d3, 0.0) * se3d_rcp64<1>(vv);
+  // q = B^-1 p_a
+  const double z1 = __builtin_fma(-l10, a0, a1), z2 = __builtin_fma(-l21, z1, __builtin_fma(-l20, a0, a2));
+  const double q2 = z2 * i2, q1 = __builtin_fma(-l21, q2, z1 * i1), q0 = __builtin_fma(-l20, q2, __builtin_fma(-l10, q1, a0 * i0));
+  const double c0 = lam * q0, c1 = lam * q1, c2 = lam * q2;
+  p[0] = a0 + c0; p[1] = a1 + c1; p[2] = a2 + c2;
+  const double c = fabs(c0) + fabs(c1) + fabs(c2);
+  return d0 > tiny && d1 > tiny && d2 > tiny && c * c < 1e-5 * (1.0 + fabs(a0) + fabs(a1) + fabs(a2));
+}
+
 // ---- which joints leave the fp64 fast path (round 4) -------------------------------------------------------------------------------------
 // The reference solves every DLT system in float32 (S3D:456); the fp64 solves here agree with it to c 2^-24 kappa metres,
 // kappa = (1 + |X|^2) s1 / (s3 - s4) over the singular values of the 2n x 4 system (c <= 4.9 over 3e5 joints, profiles/r3/cond_study.txt).
@@ -1759,17 +1794,6 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
     }
     return se3d_wave_sum(se) / se3d_wave_sum(sc);
   };
-  auto remove_view = [&](int nn, int idx) {  // erase entry idx from the LDS list, preserving order
-    // one lane per array-row keeps it simple: entries are tiny
-    if (lane == 0) {
-      for (int v = idx; v + 1 < nn; ++v) {
-        T.x[v] = T.x[v + 1]; T.y[v] = T.y[v + 1]; T.cf[v] = T.cf[v + 1];
-        T.ca[v] = T.ca[v + 1]; T.cb[v] = T.cb[v + 1]; T.cc[v] = T.cc[v + 1]; T.cam[v] = T.cam[v + 1];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  };
-
   build(n);
   double pw[3];
   const double e4start[4] = {0.0, 0.0, 0.0, 1.0};  // the null vector (X, Y, Z, 1)/|.| of a finite point always has a w component
@@ -1784,7 +1808,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   float X = (float)pw[0], Y = (float)pw[1], Z = (float)pw[2];
   double err = reproj(n, X, Y, Z);
   float avg_score = (float)(sconf / n);
-  if (D.d.exact) {
+  {
     // Round 4: a joint whose fp64 solve may differ from the reference's float32 JacobiSVD by more than the contract allows — ill-conditioned
     // weighted or unweighted system, a solve that did not settle — or whose reprojection error is above / near the outlier threshold is handed
     // to se3d_k_triangulate_exact (the reference's arithmetic, bit for bit).  Everything decided from here on is uniform over the wavefront.
@@ -1803,96 +1827,8 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
     }
   }
 
-  if (err > REPROJ_MAX && n == 3) {  // S3D:748-792
-    float dcand = 0.f;
-    if (lane < 3) {
-      const int i0 = (lane == 0) ? 1 : 0, i1 = (lane == 2) ? 1 : 2;
-      const float p1x = T.x[i0], p1y = T.y[i0], p2x = T.x[i1], p2y = T.y[i1];
-      const float *F = D.F + 9 * (size_t)se3d_pair_index(T.cam[i0], T.cam[i1], N);
-      const float l1x = F[0] * p1x + (F[1] * p1y + F[2]);
-      const float l1y = F[3] * p1x + (F[4] * p1y + F[5]);
-      const float l1z = F[6] * p1x + (F[7] * p1y + F[8]);
-      const float l2x = F[0] * p2x + (F[3] * p2y + F[6]);
-      const float l2y = F[1] * p2x + (F[4] * p2y + F[7]);
-      const float l2z = F[2] * p2x + (F[5] * p2y + F[8]);
-      const float n1 = p2x * l1x + (p2y * l1y + l1z);
-      const float n2 = p1x * l2x + (p1y * l2y + l2z);
-      dcand = n1 * n1 / (l1x * l1x + l1y * l1y) + n2 * n2 / (l2x * l2x + l2y * l2y);
-    }
-    float best = (float)(err * err);
-    int bestIndex = -1;
-    for (int i = 0; i < 3; ++i) {
-      const float di = __shfl(dcand, i);
-      if (di < best) { best = di; bestIndex = i; }
-    }
-    if (bestIndex != -1) {
-      remove_view(n, bestIndex);
-      n = 2;
-      build(n);
-      se3d_solve_point<2>(gw_, e4start, pw, SE3D_MAIN_PTOL);
-      X = (float)pw[0]; Y = (float)pw[1]; Z = (float)pw[2];
-      err = reproj(n, X, Y, Z);
-      avg_score = (T.cf[0] + T.cf[1]) / 2.0f;
-    }
-  } else if (err > REPROJ_MAX && n >= 4) {  // S3D:793-838: leave-one-out, one candidate per lane
-    double bestErr = err;
-    int bestIdx = -1;
-    float bX = 0, bY = 0, bZ = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-      const int i = i0 + lane;
-      double e_i = 1e300;
-      float cx_ = 0, cy_ = 0, cz_ = 0;
-      if (i < n) {
-        double g[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) g[k] = gw_[k];
-        float w0[4], w1[4];
-        const float cf = T.cf[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { w0[k] = T.r0[k][i] * cf; w1[k] = T.r1[k][i] * cf; }
-        se3d_gram_add<true>(g, w0); se3d_gram_add<true>(g, w1);
-        double pc[3];
-        const double wstart[4] = {pw[0], pw[1], pw[2], 1.0};   // warm start: the solution with all views
-        se3d_solve_point<2>(g, wstart, pc, SE3D_MAIN_PTOL);
-        cx_ = (float)pc[0]; cy_ = (float)pc[1]; cz_ = (float)pc[2];
-        double se = 0.0, sc = 0.0;
-        for (int v = 0; v < n; ++v) {
-          if (v == i) continue;
-          const float e = se3d_reproj1(sRt + 12 * T.cam[v], cx_, cy_, cz_, T.x[v], T.y[v]);
-          se += (double)(T.cf[v] * e);
-          sc += (double)T.cf[v];
-        }
-        e_i = se / sc;
-        if (!(e_i < 0.9 * err)) e_i = 1e300;  // "save new best results only if considerably better" (S3D:813)
-      }
-      // wave arg-min, ties -> lowest index (the reference's sequential strict '>' scan)
-      double m = e_i;
-      int mi = i;
-      for (int o = 32; o > 0; o >>= 1) {
-        const double om = __shfl_xor(m, o);
-        const int oi = __shfl_xor(mi, o);
-        if (om < m || (om == m && oi < mi)) { m = om; mi = oi; }
-      }
-      if (m < bestErr) {
-        bestErr = m;
-        bestIdx = mi;
-        const int src = mi - i0;
-        bX = __shfl(cx_, src); bY = __shfl(cy_, src); bZ = __shfl(cz_, src);
-      }
-    }
-    if (bestIdx != -1) {
-      const float cfr = T.cf[bestIdx];
-      remove_view(n, bestIdx);
-      n -= 1;
-      build(n);  // Gu of the kept views for the UT (positions come from the leave-one-out solve, not re-triangulated)
-      X = bX; Y = bY; Z = bZ;
-      err = bestErr;
-      avg_score = (float)((sconf) / n);
-      (void)cfr;
-    }
-  }
-  if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX / err));  // S3D:840-841
-
+  // (outlier rejection, S3D:748-838, and the score's down-weighting, S3D:840-844: reprojection errors near or above the threshold went to
+  // the second pass above — here err <= 0.99 g_reproj_error_max_acceptable and the score is the mean confidence)
   // ---- unscented transform (S3D:471-523): 4n+1 sigma points, each an unweighted re-triangulation ----
   // Defined policy: a kept view whose 2x2 keypoint covariance is not SPD (NaN / inf Cholesky factor, S3D:473-475) makes
   // all entries of the joint's 3-D covariance NaN; position and score are unaffected.
@@ -1904,7 +1840,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   const float wgt = 1.0f / (2.0f * ((float)dim + 0.5f));  // all weights equal because 2*kappa == 1
   double cv[6] = {0, 0, 0, 0, 0, 0};
   const int nsamp = 4 * n + 1;
-  const double vstart[4] = {(double)X, (double)Y, (double)Z, 1.0};  // warm start of the sigma-point solves: the published point (the iteration is scale-free)
+  bool sample_bad = false;   // a sample's cheap solve (se3d_sample_point) did not qualify: the joint goes to the second pass
   // samples 0 .. 2n: centre + class A (both rows rebuilt); 2n + 1 .. 4n: class B (y-only samples, r1 alone) — see se3d_sigma_gram
   for (int s0 = 0; s0 < nsamp; s0 += 64) {
     const int s = s0 + lane;
@@ -1921,7 +1857,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
         se3d_sigma_gram(g, sRt + 12 * T.cam[c], T.x[c], T.y[c], T.ca[c], T.cb[c], T.cc[c], bsc, o0, o1, (clsB ? 3 : 1) + (q & 1));
       }
       double pt[3];
-      se3d_solve_point(g, vstart, pt);
+      sample_bad |= !se3d_sample_point(g, pt);
       const float sx = (float)pt[0] - X, sy = (float)pt[1] - Y, sz = (float)pt[2] - Z;
       const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
       cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
@@ -1929,8 +1865,8 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) cv[k] = cov_bad ? (double)__builtin_nanf("") : se3d_wave_sum(cv[k]);
-  if (D.d.exact && !cov_bad && !(cv[0] < SE3D_EXACT_VAR_MAX && cv[3] < SE3D_EXACT_VAR_MAX && cv[5] < SE3D_EXACT_VAR_MAX)) {
-    if (lane == 0) se3d_tri_list_push(D, f, h, j);   // wide covariance: the samples' systems are ill conditioned — second pass (uniform)
+  if (!cov_bad && (__ballot(sample_bad) != 0ull || !(cv[0] < SE3D_EXACT_VAR_MAX && cv[3] < SE3D_EXACT_VAR_MAX && cv[5] < SE3D_EXACT_VAR_MAX))) {
+    if (lane == 0) se3d_tri_list_push(D, f, h, j);   // wide covariance / unsettled sample: the samples' systems are ill conditioned — second pass (uniform)
     return;
   }
   if (lane == 0) {
@@ -2166,7 +2102,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
       const double iw = se3d_rcp64<2>(e4[3]);
       pw[0] = e4[0] * iw; pw[1] = e4[1] * iw; pw[2] = e4[2] * iw;
       unsettled = true;
-    } else if (D.d.exact) {
+    } else {
       level2 = !se3d_cond_level1_ok(gw_, piv_, pw, nj);
     }
     X = (float)pw[0]; Y = (float)pw[1]; Z = (float)pw[2];
@@ -2180,7 +2116,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
   {
     unsigned long long l2mask = __ballot(level2);
     if ((hicf[0] | hicf[1]) != 0ull) l2mask = (1ull << JN) - 1ull;
-    if (D.d.exact && l2mask) {
+    if (l2mask) {
       bool ill = false;
       if (lane < 2 * JN) {
         const int which = lane >= JN ? 1 : 0, jq = lane - which * JN;
@@ -2220,10 +2156,9 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
     // sequences on nine lanes: the error only meets thresholds, the score is published as float32
     const double err = se * se3d_rcp64(sc);
     avg_score = (float)(sc * se3d_rcp64((double)nj));   // sc: the confidences summed in view order (what G[.][20] used to hold)
-    slow = err > REPROJ_MAX && nj >= 3;  // outlier rejection needed (S3D:748-838): second pass
-    if (D.d.exact)   // round 4: also everything near / above the threshold (the score carries err), ill-conditioned systems, unsettled solves
-      slow = !(err <= REPROJ_MAX * (1.0 - SE3D_EXACT_ERR_GUARD)) || unsettled || ((illmask >> lane) & 1ull) || ((illmask >> (lane + JN)) & 1ull);
-    if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX * se3d_rcp64(err)));  // S3D:840-841
+    // second pass (round 4): outlier rejection (S3D:748-838) and everything near / above its threshold (the score carries err, S3D:840-844),
+    // ill-conditioned systems, unsettled solves
+    slow = !(err <= REPROJ_MAX * (1.0 - SE3D_EXACT_ERR_GUARD)) || unsettled || ((illmask >> lane) & 1ull) || ((illmask >> (lane + JN)) & 1ull);
   }
   const unsigned long long slowmask = __ballot(slow);
   TH_STAMP(6)  // reprojection errors + score
@@ -2233,7 +2168,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
   {
     se3d_person3d &person0 = D.hypP[(size_t)f * H + h];
     const int pm_ = D.d.pose_method;
-  if (lane < JN && !slow) {  // slow joints are written (all fields) by se3d_k_triangulate_slow
+  if (lane < JN && !slow) {  // second-pass joints are written (all fields) by se3d_k_triangulate_exact
     se3d_keypoint3d *kp = &person0.keypoints[c_kp2fusion[pm_][jbase + lane]];
     if (active) {
       kp->joint[0] = (double)X; kp->joint[1] = (double)Y; kp->joint[2] = (double)Z;
@@ -2244,7 +2179,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
       for (int e = 0; e < 6; ++e) kp->cov[e] = 0.0;
     }
   }
-  // ---- joints of the second pass (se3d_k_triangulate_exact; SE3D_EXACT=0: se3d_k_triangulate_slow) go to the list ----
+  // ---- joints of the second pass (se3d_k_triangulate_exact) go to the list ----
   if (slowmask) {   // uniform; rare
     uint32_t at0 = 0u;
     if (lane == 0) at0 = atomicAdd(&D.tri_cnt[0], (uint32_t)__popcll(slowmask));
@@ -2267,7 +2202,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
     const float Xj = S.X[j], Yj = S.Y[j], Zj = S.Z[j];
     const float bsc = sqrtf((float)(2 * n) + 0.5f);
     const float wgt = 1.0f / (2.0f * ((float)(2 * n) + 0.5f));  // all weights equal because 2*kappa == 1
-    const double vstart[4] = {(double)Xj, (double)Yj, (double)Zj, 1.0};   // the iteration is scale-free: the published point is its start
+    bool sample_bad = false;   // a sample's cheap solve (se3d_sample_point) did not qualify: the joint goes to the second pass
     double gj[10], cv[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 10; ++k) gj[k] = S.G[j][k];
@@ -2288,13 +2223,14 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
           se3d_sigma_gram(gq, sRt + 12 * S.cam[v], S.x[j][v], S.y[j][v], S.ca[j][v], S.cb[j][v], S.cc[j][v], bsc, o0, o1, (cls == 0 ? 1 : 3) + (q & 1));
         }
         double pt[3];
-        se3d_solve_point(gq, vstart, pt);
+        sample_bad |= !se3d_sample_point(gq, pt);
         const float sx = (float)pt[0] - Xj, sy = (float)pt[1] - Yj, sz = (float)pt[2] - Zj;
         const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
         cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
       }
     }
     TH_STAMP(8)  // sigma samples
+    const unsigned long long sbad = __ballot(sample_bad);   // lane <-> (joint jl, sample stride): bits [LPJ jl, LPJ (jl + 1)) belong to joint jl
     __builtin_amdgcn_wave_barrier();   // all samples done: the rows are dead, their LDS takes the partial sums
     // (rows, and behind them re / vs / G, are all dead once the samples are done)
     static_assert(offsetof(TriHypLds, X) - offsetof(TriHypLds, rows) >= 64 * 6 * sizeof(double) && offsetof(TriHypLds, rows) % 8 == 0, "partial sums alias the rows");
@@ -2305,15 +2241,15 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
     static_assert(TH_JOINTS * 6 <= 64, "one trip over the (joint, entry) lanes");
     {
       const int it = lane, jj = it / 6, e = it - jj * 6;
-      bool wide = false;   // a variance above SE3D_EXACT_VAR_MAX: the samples' own systems are ill conditioned, the joint goes to the second pass
+      bool wide = false;   // a variance above SE3D_EXACT_VAR_MAX or a sample whose cheap solve did not qualify: the joint goes to the second pass
       if (it < JN * 6 && S.cnt[jj] != 0) {
         double acc = 0.0;
         for (int q = 0; q < LPJ; ++q) acc += part[jj * LPJ + q][e];
         if (S.bad[jj]) acc = (double)__builtin_nanf("");
-        else wide = (e == 0 || e == 3 || e == 5) && !(acc < SE3D_EXACT_VAR_MAX);
+        else wide = ((e == 0 || e == 3 || e == 5) && !(acc < SE3D_EXACT_VAR_MAX)) || (e == 0 && ((sbad >> (LPJ * jj)) & ((1ull << LPJ) - 1ull)) != 0ull);
         D.hypP[(size_t)blockIdx.y * D.d.H + blockIdx.x / TH_PARTS].keypoints[c_kp2fusion[D.d.pose_method][jbase + jj]].cov[e] = (double)(float)acc;   // (address re-formed here: not carried across the loop)
       }
-      const unsigned long long wmask = D.d.exact ? __ballot(wide) : 0ull;
+      const unsigned long long wmask = __ballot(wide);
       if (wmask) {   // uniform; rare
         bool mine = false;
         if (it < JN * 6 && e == 0) mine = ((wmask >> (6 * jj)) & 0x29ull) != 0ull;   // entries 0, 3, 5 of joint jj
@@ -2328,27 +2264,6 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
 #ifdef SE3D_LM_STAMPS
     if (threadIdx.x == 0 && ((blockIdx.x + 7 * blockIdx.y) & 63) == 0) atomicAdd(&g_th_stamps[15], 1ull);
 #endif
-  }
-}
-
-// Second pass, SE3D_EXACT=0 (round 3's behaviour, kept as A/B evidence): the listed joints — reprojection error above the threshold with
-// >= 3 views — are redone by the per-joint fp64 routine (outlier rejection by rank updates of the Gram matrix).  A separate launch on
-// purpose: calling the routine from se3d_k_triangulate_hyp (out of line, descriptor by address) made every wavefront spill the kernel
-// arguments to scratch at entry — 445 MB of writes per launch (PMC WRITE_SIZE).
-__global__ __launch_bounds__(64) void se3d_k_triangulate_slow(Se3dDev D) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x;
-  const int N = D.d.N, H = D.d.H;
-  const uint32_t cnt = D.tri_cnt[0];
-  if (blockIdx.x >= cnt) return;
-  float *base = reinterpret_cast<float *>(smem), *sRt = base + (size_t)15 * N;
-  for (int i = lane; i < 12 * N; i += 64) sRt[i] = D.Rt[i];
-  __syncthreads();
-  for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
-    const uint32_t en = D.tri_list[it];
-    const int e = (int)(en >> 5), j = (int)(en & 31u), f = e / H, h = e - f * H;
-    se3d_tri_joint_body(D, f, h, j, lane, base, sRt);
-    __syncthreads();
   }
 }
 
@@ -3591,13 +3506,8 @@ extern "C" hipError_t se3d_stage1_init_device(void) {
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
 }
-static void se3d_launch_triangulation(const Se3dDev &D_, hipStream_t st) {
-  Se3dDev D = D_;
+static void se3d_launch_triangulation(const Se3dDev &D, hipStream_t st) {
   const int B = D.d.B, N = D.d.N, H = D.d.H;
-  {  // SE3D_EXACT=0 (A/B switch read per launch): round 3's second pass — fp64 outlier rejection, no float32-exact solves
-    const char *e_exact = getenv("SE3D_EXACT");
-    if (e_exact && atoi(e_exact) == 0) D.d.exact = 0;
-  }
   (void)hipMemsetAsync(D.tri_cnt, 0, sizeof(uint32_t), st);   // list of the second pass: filled by the kernel below
   const int waves2 = (int)std::min<size_t>((size_t)D.d.tri_waves, (size_t)B * H * SE3D_NKP);
   const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
@@ -3606,11 +3516,10 @@ static void se3d_launch_triangulation(const Se3dDev &D_, hipStream_t st) {
     // (the grid covers all H hypothesis slots; the workgroups of unused slots exit after one load — capping the grid at 12 / 16 / 24 slots
     // changed the kernel's 7.6 - 7.7 ms per 98 304 frames by less than the run-to-run spread, profiles/r3/README.md)
     hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(TH_PARTS * H, B), dim3(64), 0, st, D);
-    if (!D.d.exact) hipLaunchKernelGGL(se3d_k_triangulate_slow, dim3(waves2), dim3(64), (size_t)27 * N * sizeof(float), st, D);
   }
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
   // second pass: the listed joints with the reference's float32 arithmetic (wavefronts beyond the list length exit at once)
-  if (D.d.exact) hipLaunchKernelGGL(se3d_k_triangulate_exact, dim3(waves2), dim3(64), se3d_exact_lds_bytes(N), st, D);
+  hipLaunchKernelGGL(se3d_k_triangulate_exact, dim3(waves2), dim3(64), se3d_exact_lds_bytes(N), st, D);
 }
 
 // phases (bit mask): 1 = normalise + pair-cost table, 8 = camera sweep, 2 = triangulation, 4 = post-processing + duplicate merge

@@ -155,6 +155,7 @@ def run_trials(O, seed, trials, walk_mode="wave", pose_method="simple", norm_hei
                     numeric = "mm" in msg or "cov" in msg or "marg" in msg
                     if tainted[s]:
                         rep["excluded_stage2_mismatches"] += 1
+                        rep.setdefault("excluded_stage2_messages", []).append("trial %d step %d seq %d: %s" % (trial, k, s, msg[:160]))
                         dead[s] = dead[s] or not numeric
                         continue
                     rep["stage2_numeric_failures" if numeric else "stage2_index_divergences"] += 1

@@ -147,24 +147,3 @@ def test_clean_scene_stays_on_the_fast_path(oracle, extr_rig):
     listed, triangulated = _listed_joints_equal_bitwise(oracle, extr_rig, frames)
     print("clean scene: %d of %d triangulated joints listed" % (listed, triangulated))
     assert listed <= 0.01 * triangulated
-
-
-def test_exact_switch_off_reproduces_round3_within_tolerance(oracle, extr_rig, monkeypatch):
-    """SE3D_EXACT=0 (A/B evidence): the fp64 second pass of round 3.  Same index results; positions within 1 mm of the exact path on the
-    joints whose systems are well conditioned (that is what the fp64 solves guarantee)."""
-    frames = branch_scenes.outliers(extr_rig, n_frames=3, p_miss=0.0)
-    node = Skeleton3D(extr_rig, max_epi_dist=0.045, max_frames=len(frames), max_det_per_cam=8, max_hyp=32, device=0)
-    a = node.triangulate_persons(frames)
-    monkeypatch.setenv("SE3D_EXACT", "0")
-    b = node.triangulate_persons(frames)
-    monkeypatch.delenv("SE3D_EXACT")
-    close = total = 0
-    for x, y in zip(a, b):
-        assert np.array_equal(x.assoc(), y.assoc()) and x.n_persons == y.n_persons
-        xv, yv = x.published()["keypoints"], y.published()["keypoints"]
-        both = (xv["score"] > 0) & (yv["score"] > 0)
-        d = np.linalg.norm(xv["joint"] - yv["joint"], axis=-1)[both]
-        close += int((d < 1e-3).sum())
-        total += int(both.sum())
-    node.close()
-    assert close >= 0.97 * total, (close, total)

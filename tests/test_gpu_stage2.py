@@ -472,3 +472,44 @@ def test_stage2_walk_then_per_step_share_track_state(extr_rig, monkeypatch, vari
     assert published > 0
     a.close()
     b.close()
+
+
+LM_SCENES = {
+    # the per-step LM kernel under each normal-equation form against the oracle: joints < 1 mm, iteration counts equal,
+    # marginal covariances rtol 1e-4 — on a full 16-frame sequence, a ragged one (tracks appear, vanish, time out) and the h36m /
+    # height-normalised graph (21 variables, the other bone table)
+    "six_persons": dict(cfg=dict(n_persons=6, n_frames=16, seed=0), pose="simple", nh=False, drop=()),
+    "ragged": dict(cfg=dict(n_persons=5, n_frames=20, seed=3, p_miss=0.35, low_score_frac=0.15, dt=0.1), pose="simple", nh=False, drop=(5, 6, 14, 15, 16)),
+    "h36m_norm_height": dict(cfg=dict(n_persons=4, n_frames=14, seed=6), pose="h36m", nh=True, drop=()),
+    "outliers": dict(cfg=dict(n_persons=3, n_frames=14, seed=11, outlier_frac=0.04), pose="simple", nh=False, drop=()),
+}
+
+
+@pytest.mark.parametrize("scene", sorted(LM_SCENES))
+@pytest.mark.parametrize("lm", ["tree", "tree_mfma", "schur", "dense"])
+def test_stage2_every_lm_form_matches_the_oracle(extr_rig, oracle, monkeypatch, lm, scene):
+    """north_star config 4: the batched J^T J on the matrix cores (`dense`: v_mfma_f64_16x16x4_f64 on the whole 63 x 63 product; `schur` /
+    `tree_mfma`: on the bone-factor block) and the default forest elimination, each through se3d_refine against the oracle on four scenes."""
+    sc = LM_SCENES[scene]
+    monkeypatch.setenv("SE3D_LM", lm)
+    params = pm.Params(pm.POSE_H36M if sc["pose"] == "h36m" else pm.POSE_SIMPLE, int(sc["nh"]), 0.045)
+    node = _node(extr_rig, pose_method=sc["pose"], norm_height=sc["nh"], max_frames=1, max_det_per_cam=8, max_hyp=32)
+    worst, published = _sequence_parity(node, extr_rig, oracle, params, S.SceneConfig(**sc["cfg"]), drop_frames=sc["drop"])
+    print("SE3D_LM=%s on %s: %d published persons, worst %s" % (lm, scene, published, worst))
+    assert published > 0
+    node.close()
+
+
+@pytest.mark.parametrize("n_cam,n_persons", [(32, 12), (48, 16)])
+def test_stage2_large_rig_every_step_asserted(oracle, n_cam, n_persons):
+    """A clean scene on a 32 / 48-camera rig (the per-step stage-2 kernels with the block Munkres, H = 64): EVERY sequence-step is compared
+    with the oracle — ids, track counts, LM iteration counts, refined and predicted joints, marginal covariances; nothing is exempt."""
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
+    rig = R.elliptical_rig(n_cam, seed=2)
+    rig.set_tensors(*rig_tensors(rig))
+    params = pm.Params(pm.POSE_SIMPLE, 0, 0.045)
+    node = _node(rig, max_frames=1, max_det_per_cam=24, max_hyp=64)
+    worst, published = _sequence_parity(node, rig, oracle, params, S.SceneConfig(n_persons=n_persons, n_frames=14, seed=21, spacing=1.0))
+    print("%d cameras x %d persons: %d published persons over 14 steps, worst %s" % (n_cam, n_persons, published, worst))
+    assert published >= 3 * n_persons - 2
+    node.close()

@@ -1,7 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun -- bash tools/profile_r4.sh <what> ...): the rocprofv3 passes behind profiles/r4/.
 #   serial      : bench.py --serial (one context, one stream) kernel stats
-#   serial_ab   : the same with SE3D_EXACT=0 (round 3's second pass) for the cost of the conditioning flags
 #   serial_pmc  : SQ + HBM traffic PMC passes of the serial pass
 #   c256        : 256cam128p, one context: kernel stats (+ PMC with c256_pmc)
 set -u
@@ -16,13 +15,6 @@ serial)
   rm -rf $OUT/serial_stats
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_stats -- python3 bench.py --serial --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_stats.log 2>&1
   python3 tools/kernel_stats.py $OUT/serial_stats $OUT/serial_16cam6p_kernel_stats.csv
-  ;;
-serial_ab)
-  rm -rf $OUT/serial_stats_ab
-  export SE3D_EXACT=0
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_stats_ab -- python3 bench.py --serial --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_stats_ab.log 2>&1
-  unset SE3D_EXACT
-  python3 tools/kernel_stats.py $OUT/serial_stats_ab $OUT/serial_16cam6p_exact0_kernel_stats.csv
   ;;
 serial_pmc)
   rm -rf $OUT/serial_sq $OUT/serial_fetch $OUT/serial_write
