@@ -355,10 +355,13 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
   ok = ok && dev_alloc(c, &D.assoc, (size_t)B * H * N) && dev_alloc(c, &D.nviews, (size_t)B * H);
   ok = ok && dev_alloc(c, &D.C, (size_t)B * H * P) && dev_alloc(c, &D.mask, (size_t)B * H * P) && dev_alloc(c, &D.mwork, (size_t)B * H * P);
   {  // second pass of the triangulation (float32-exact solves of the flagged joints, se3d_k_triangulate_exact): list, counter, workspaces
-    const size_t per_wave = (size_t)64 * 8 * N * sizeof(float), joints = (size_t)B * H * SE3D_NKP;
-    // one wavefront per 4 joints of the batch (the list is short: 0.1 % of the joints on clean scenes), 16 .. 4096 (16 per CU), <= 128 MB
-    D.d.tri_waves = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(4096, std::max<size_t>(16, joints / 4)), ((size_t)128 << 20) / per_wave));
-    ok = ok && dev_alloc(c, &D.tri_list, joints) && dev_alloc(c, &D.tri_cnt, (size_t)4) && dev_alloc(c, &D.tri_ws, (size_t)D.d.tri_waves * 64 * 8 * N);
+    const size_t ws_floats = (size_t)64 * 8 * N + (N <= 64 ? 0 : (((size_t)3 * (4 * N + 1) + 63) & ~(size_t)63));   // se3d_exact_ws_floats (se3d_stage1.hip)
+    const size_t per_wave = ws_floats * sizeof(float), joints = (size_t)B * H * SE3D_NKP;
+    // one wavefront per 4 joints of the batch (the list is short: 0.1 % of the joints on clean scenes), 16 .. 4096 (16 per CU); <= 128 MB on
+    // small rigs, <= 2 GB on large ones (a wavefront's workspace is 2 KB x cameras; the sigma samples of a joint seen by n views are 4 n + 1
+    // solves of a 2 n x 4 system each — what the reference pays per joint too — so large rigs need the wavefronts: 2560 are resident at 256 cameras)
+    D.d.tri_waves = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(4096, std::max<size_t>(16, joints / 4)), ((size_t)(N > 64 ? 2048 : 128) << 20) / per_wave));
+    ok = ok && dev_alloc(c, &D.tri_list, joints) && dev_alloc(c, &D.tri_cnt, (size_t)4) && dev_alloc(c, &D.tri_ws, (size_t)D.d.tri_waves * ws_floats);
     if (ok && !c->dry) ok = hip_ok(c, hipMemset(D.tri_cnt, 0, 4 * sizeof(uint32_t)), "hipMemset (tri_cnt)");
   }
   ok = ok && dev_alloc(c, &D.hypP, (size_t)B * H) && dev_alloc(c, &D.keep, (size_t)B * H);
@@ -926,7 +929,31 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
     HIPCHK(c, hipMemcpyAsync(c->d_t + seq, c->h_t_ref + seq, sizeof(double), hipMemcpyHostToDevice, c->stream));
   }
   Q.dets = c->d_in2; Q.n_det = c->d_ndet2; Q.fb_delay = c->d_fb_ref; Q.t = c->d_t;
-  se3d_launch_stage2(Q, seq, 1, c->stream, next_ev2(c), 3);
+  // One frame per call on a one-sequence context (the reference's operating point, PP:505): the step as ONE launch of the fused walk kernel
+  // (association, LM with three persons per wavefront, lifecycle; n_steps = 1) instead of five dependent launches — round 4, latency_B1.
+  // SE3D_REFINE_WALK=0 (A/B, read per call) keeps the per-step kernels.
+  bool walked = false;
+  if (Q.S == 1) {
+    const char *e_rw = getenv("SE3D_REFINE_WALK");
+    if (!(e_rw && atoi(e_rw) == 0)) {
+      Se3dWalk Wk{};
+      Wk.n_steps = 1;
+      Wk.slot0[0] = 0;
+      Wk.t = c->d_t; Wk.t_stride = 1;
+      Wk.outP = c->d_in2; Wk.out_count = c->d_ndet2; Wk.fb = c->d_fb_ref;
+      Wk.Wf = c->Q.fused; Wk.Wp = c->Q.pred; Wk.Wit = c->Q.iters; Wk.Wn = c->Q.n_out; Wk.Wdt = c->Q.pred_dt;
+      hipEvent_t *ev = next_ev2(c);
+      if (ev) { c->ev2_walk[(c->ev2_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = true; (void)hipEventRecord(ev[0], c->stream); }
+      walked = se3d_launch_stage2_walk(c->Q, Wk, 1, c->stream);
+      if (walked && ev) (void)hipEventRecord(ev[3], c->stream);
+      if (!walked && ev) {   // not applicable (limits too large for the kernel's LDS): give the event set back
+        c->ev2_walk[(c->ev2_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = false;
+        c->ev2_head = (c->ev2_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing;
+        --c->ev2_pending;
+      }
+    }
+  }
+  if (!walked) se3d_launch_stage2(Q, seq, 1, c->stream, next_ev2(c), 3);
   HIPCHK(c, hipGetLastError());
   c->ran2 = true;
   return fetch_stage2_range(c, seq, 1, out);

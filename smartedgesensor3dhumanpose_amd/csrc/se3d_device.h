@@ -105,7 +105,7 @@ struct Se3dDev {
   uint8_t *keep;         // [B][H]
   uint32_t *tri_list;    // [B * H * 17] (frame * H + hypothesis) << 5 | joint of every joint the fast triangulation kernels hand to the second pass
   uint32_t *tri_cnt;     // [4]: entries of tri_list of the current launch; [1]: running total (statistics, se3d_get_exact_stats); [2]: joints triangulated
-  float *tri_ws;         // [tri_waves][8 N][64] lane-interleaved rows x 4 workspaces of the float32 solves
+  float *tri_ws;         // [tri_waves][se3d_exact_ws_floats(N)] lane-interleaved rows x 4 workspaces of the float32 solves (8 N x 64 floats; + the centred samples on large rigs)
   se3d_person3d *outP;   // [B][H]
   int32_t *out_count;    // [B]
   int32_t *out_hyp;      // [B][H]

@@ -130,6 +130,24 @@ __device__ __forceinline__ void x32_jacobi4(float (&W)[4][4], float (&V)[4][4], 
   for (int i = 0; i < 4; ++i) v_out[i] = (m == 0) ? V[i][0] : (m == 1) ? V[i][1] : (m == 2) ? V[i][2] : V[i][3];
 }
 
+// Row loops of the QR step: the lane's column lives in memory (global workspace), every sum is sequential by definition, but the LOADS of
+// X32_BS consecutive rows are independent — they are issued together and the dependent float chain runs on registers (one memory round trip
+// per X32_BS rows instead of per row: the second pass was bound by that latency, 176 ms per 64 frames at 256 cameras; profiles/r4/README.md).
+// A masked tail element contributes nothing (the accumulation is skipped, not fed a zero: a zero could flip the sign of a zero sum).
+#define X32_BS 8
+template <typename PT>
+__device__ __forceinline__ float x32_sumsq(const X32MatT<PT> &A, int c, int i0, int rows) {   // sum_{i = i0}^{rows-1} A(i, c)^2, ascending
+  float ss = 0.f;
+  for (int i = i0; i < rows; i += X32_BS) {
+    float a[X32_BS];
+#pragma unroll
+    for (int u = 0; u < X32_BS; ++u) a[u] = (i + u < rows) ? A.get(i + u, c) : 0.f;
+#pragma unroll
+    for (int u = 0; u < X32_BS; ++u) ss = (i + u < rows) ? ss + a[u] * a[u] : ss;
+  }
+  return ss;
+}
+
 // Null vector of the rows x 4 system in A (rows >= 4; A is overwritten): JacobiSVD<Matrix<float, -1, 4>>::compute + matrixV().col(3).
 // Out of line on purpose (one copy of ~3 k instructions for the three call sites of the second pass; arguments and result in registers).
 template <typename PT>
@@ -138,10 +156,23 @@ __device__ __noinline__ float4 x32_null_vector(int rows, PT Ap, int Astride, int
   float v_out[4];
   float scale = 0.f;
   for (int c = 0; c < 4; ++c)
-    for (int i = 0; i < rows; ++i) scale = fmaxf(scale, fabsf(A.get(i, c)));
+    for (int i = 0; i < rows; i += X32_BS) {
+      float a[X32_BS];
+#pragma unroll
+      for (int u = 0; u < X32_BS; ++u) a[u] = (i + u < rows) ? A.get(i + u, c) : 0.f;
+#pragma unroll
+      for (int u = 0; u < X32_BS; ++u) scale = fmaxf(scale, fabsf(a[u]));
+    }
   if (scale == 0.f) scale = 1.f;
   for (int c = 0; c < 4; ++c)
-    for (int i = 0; i < rows; ++i) A.set(i, c, A.get(i, c) / scale);
+    for (int i = 0; i < rows; i += X32_BS) {
+      float a[X32_BS];
+#pragma unroll
+      for (int u = 0; u < X32_BS; ++u) a[u] = (i + u < rows) ? A.get(i + u, c) : 0.f;
+#pragma unroll
+      for (int u = 0; u < X32_BS; ++u)
+        if (i + u < rows) A.set(i + u, c, a[u] / scale);
+    }
   float W[4][4], V[4][4];
   if (rows == 4) {   // square input: no QR step (m_workMatrix = matrix / scale, m_matrixV.setIdentity())
 #pragma unroll
@@ -156,9 +187,7 @@ __device__ __noinline__ float4 x32_null_vector(int rows, PT Ap, int Astride, int
   float nu[4], nd[4];   // m_colNormsUpdated, m_colNormsDirect
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    float ss = 0.f;
-    for (int i = 0; i < rows; ++i) { const float a = A.get(i, k); ss += a * a; }
-    nu[k] = nd[k] = sqrtf(ss);
+    nu[k] = nd[k] = sqrtf(x32_sumsq(A, k, 0, rows));
   }
   const float norm_downdate_threshold = sqrtf(FLT_EPSILON);
 #pragma unroll
@@ -177,8 +206,7 @@ __device__ __noinline__ float4 x32_null_vector(int rows, PT Ap, int Astride, int
       }
     const int pk = perm[k];
     // makeHouseholderInPlace on A.col(k).tail(rows - k)
-    float tailSq = 0.f;
-    for (int i = k + 1; i < rows; ++i) { const float a = A.get(i, pk); tailSq += a * a; }
+    const float tailSq = x32_sumsq(A, pk, k + 1, rows);
     const float c0 = A.get(k, pk);
     float tau, beta;
     if (tailSq <= FLT_MIN) {
@@ -189,26 +217,56 @@ __device__ __noinline__ float4 x32_null_vector(int rows, PT Ap, int Astride, int
       beta = sqrtf(c0 * c0 + tailSq);
       if (c0 >= 0.f) beta = -beta;
       const float den = c0 - beta;
-      for (int i = k + 1; i < rows; ++i) A.set(i, pk, A.get(i, pk) / den);
+      for (int i = k + 1; i < rows; i += X32_BS) {
+        float a[X32_BS];
+#pragma unroll
+        for (int u = 0; u < X32_BS; ++u) a[u] = (i + u < rows) ? A.get(i + u, pk) : 0.f;
+#pragma unroll
+        for (int u = 0; u < X32_BS; ++u)
+          if (i + u < rows) A.set(i + u, pk, a[u] / den);
+      }
       tau = (beta - c0) / beta;
     }
     A.set(k, pk, beta);
     // applyHouseholderOnTheLeft to bottomRightCorner(rows - k, 3 - k)  (rows - k >= 3 here: rows >= 6)
     if (tau != 0.f && k + 1 < 4) {
+      // tmp[j] = essential^T * column j (sequential over the rows) + A(k, j); the reflector's column is loaded once per batch of rows for
+      // all trailing columns
       float tmp[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int i = k + 1; i < rows; i += X32_BS) {
+        float vk[X32_BS];
 #pragma unroll
-      for (int j = k + 1; j < 4; ++j) {
-        const int pj = perm[j];
-        float t = 0.f;
-        for (int i = k + 1; i < rows; ++i) t += A.get(i, pk) * A.get(i, pj);
-        t += A.get(k, pj);
-        tmp[j] = t;
+        for (int u = 0; u < X32_BS; ++u) vk[u] = (i + u < rows) ? A.get(i + u, pk) : 0.f;
+#pragma unroll
+        for (int j = k + 1; j < 4; ++j) {
+          const int pj = perm[j];
+          float vj[X32_BS];
+#pragma unroll
+          for (int u = 0; u < X32_BS; ++u) vj[u] = (i + u < rows) ? A.get(i + u, pj) : 0.f;
+#pragma unroll
+          for (int u = 0; u < X32_BS; ++u) tmp[j] = (i + u < rows) ? tmp[j] + vk[u] * vj[u] : tmp[j];
+        }
       }
 #pragma unroll
       for (int j = k + 1; j < 4; ++j) {
         const int pj = perm[j];
+        tmp[j] += A.get(k, pj);
         A.set(k, pj, A.get(k, pj) - tau * tmp[j]);
-        for (int i = k + 1; i < rows; ++i) A.set(i, pj, A.get(i, pj) - tau * A.get(i, pk) * tmp[j]);
+      }
+      for (int i = k + 1; i < rows; i += X32_BS) {
+        float vk[X32_BS];
+#pragma unroll
+        for (int u = 0; u < X32_BS; ++u) vk[u] = (i + u < rows) ? A.get(i + u, pk) : 0.f;
+#pragma unroll
+        for (int j = k + 1; j < 4; ++j) {
+          const int pj = perm[j];
+          float vj[X32_BS];
+#pragma unroll
+          for (int u = 0; u < X32_BS; ++u) vj[u] = (i + u < rows) ? A.get(i + u, pj) : 0.f;
+#pragma unroll
+          for (int u = 0; u < X32_BS; ++u)
+            if (i + u < rows) A.set(i + u, pj, vj[u] - tau * vk[u] * tmp[j]);
+        }
       }
     }
     // LAPACK-style column-norm downdate (lawn176)
@@ -222,9 +280,7 @@ __device__ __noinline__ float4 x32_null_vector(int rows, PT Ap, int Astride, int
         const float r = nu[j] / nd[j];
         const float temp2 = temp * (r * r);
         if (temp2 <= norm_downdate_threshold) {
-          float ss = 0.f;
-          for (int i = k + 1; i < rows; ++i) { const float a = A.get(i, pj); ss += a * a; }
-          nd[j] = sqrtf(ss);
+          nd[j] = sqrtf(x32_sumsq(A, pj, k + 1, rows));
           nu[j] = nd[j];
         } else {
           nu[j] *= sqrtf(temp);

@@ -1459,41 +1459,6 @@ __device__ __forceinline__ void se3d_solve_point(const double g[10], const doubl
   p[0] = e4[0] * iw; p[1] = e4[1] * iw; p[2] = e4[2] * iw;
 }
 
-// Sigma samples (round 4): the dehomogenised null vector of a sample's Gram matrix G = [[B, u], [u^T, gamma]] from the 3 x 3 block.
-// The smallest eigenpair satisfies (B - lambda I) p = -u, lambda = u^T p + gamma, with lambda / mu3(B) ~ 1e-5 .. 1e-3 on a joint that
-// passed the conditioning test.  To first order in lambda:  p = p_a + lambda B^-1 p_a,  p_a = -B^-1 u,  lambda = d3 / (1 + |p_a|^2),
-// d3 = gamma + u^T p_a (the Schur complement = last pivot of the 4 x 4 factorisation); the neglected term is ~ c^2 / |p| for a correction of
-// size c = lambda |B^-1 p_a| (0.05 - 0.5 mm on the benchmark's scenes: 1e-9 m).  One LDL^T factorisation of the 3 x 3 block and two
-// substitutions, ~50 fp64 instructions, replace the 4 x 4 factorisation and two inverse-iteration steps (~85) of se3d_null_invit_point.
-// Returns false when a pivot is not positive or the correction is large (c^2 > 1e-5 (1 + |p|_1): second-order term above ~10 um): the caller
-// hands the joint to the float32 second pass.
-__device__ __forceinline__ bool se3d_sample_point(const double g[10], double p[3]) {
-  // g packed: 00 01 02 03 11 12 13 22 23 33
-  const double tiny = 1e-30 * ((g[0] + g[4]) + g[7]);
-  const double d0 = g[0];
-  const double i0 = se3d_rcp64<1>(d0);
-  const double l10 = g[1] * i0, l20 = g[2] * i0;
-  const double d1 = __builtin_fma(-l10, g[1], g[4]);
-  const double i1 = se3d_rcp64<1>(d1);
-  const double t21 = __builtin_fma(-l20, g[1], g[5]);
-  const double l21 = t21 * i1;
-  const double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, g[2], g[7]));
-  const double i2 = se3d_rcp64<1>(d2);
-  // p_a = -B^-1 u
-  const double y0 = -g[3], y1 = __builtin_fma(-l10, y0, -g[6]), y2 = __builtin_fma(-l21, y1, __builtin_fma(-l20, y0, -g[8]));
-  const double a2 = y2 * i2, a1 = __builtin_fma(-l21, a2, y1 * i1), a0 = __builtin_fma(-l20, a2, __builtin_fma(-l10, a1, y0 * i0));
-  const double d3 = __builtin_fma(g[3], a0, __builtin_fma(g[6], a1, __builtin_fma(g[8], a2, g[9])));
-  const double vv = __builtin_fma(a0, a0, __builtin_fma(a1, a1, __builtin_fma(a2, a2, 1.0)));
-  const double lam = fmax(d3, 0.0) * se3d_rcp64<1>(vv);
-  // q = B^-1 p_a
-  const double z1 = __builtin_fma(-l10, a0, a1), z2 = __builtin_fma(-l21, z1, __builtin_fma(-l20, a0, a2));
-  const double q2 = z2 * i2, q1 = __builtin_fma(-l21, q2, z1 * i1), q0 = __builtin_fma(-l20, q2, __builtin_fma(-l10, q1, a0 * i0));
-  const double c0 = lam * q0, c1 = lam * q1, c2 = lam * q2;
-  p[0] = a0 + c0; p[1] = a1 + c1; p[2] = a2 + c2;
-  const double c = fabs(c0) + fabs(c1) + fabs(c2);
-  return d0 > tiny && d1 > tiny && d2 > tiny && c * c < 1e-5 * (1.0 + fabs(a0) + fabs(a1) + fabs(a2));
-}
-
 // ---- which joints leave the fp64 fast path (round 4) -------------------------------------------------------------------------------------
 // The reference solves every DLT system in float32 (S3D:456); the fp64 solves here agree with it to c 2^-24 kappa metres,
 // kappa = (1 + |X|^2) s1 / (s3 - s4) over the singular values of the 2n x 4 system (c <= 4.9 over 3e5 joints, profiles/r3/cond_study.txt).
@@ -1840,7 +1805,8 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   const float wgt = 1.0f / (2.0f * ((float)dim + 0.5f));  // all weights equal because 2*kappa == 1
   double cv[6] = {0, 0, 0, 0, 0, 0};
   const int nsamp = 4 * n + 1;
-  bool sample_bad = false;   // a sample's cheap solve (se3d_sample_point) did not qualify: the joint goes to the second pass
+  bool sample_bad = false;   // a sample's inverse iteration did not settle: the joint goes to the second pass
+  const double vstart[4] = {(double)X, (double)Y, (double)Z, 1.0};  // warm start of the sigma-point solves: the published point (the iteration is scale-free)
   // samples 0 .. 2n: centre + class A (both rows rebuilt); 2n + 1 .. 4n: class B (y-only samples, r1 alone) — see se3d_sigma_gram
   for (int s0 = 0; s0 < nsamp; s0 += 64) {
     const int s = s0 + lane;
@@ -1857,7 +1823,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
         se3d_sigma_gram(g, sRt + 12 * T.cam[c], T.x[c], T.y[c], T.ca[c], T.cb[c], T.cc[c], bsc, o0, o1, (clsB ? 3 : 1) + (q & 1));
       }
       double pt[3];
-      sample_bad |= !se3d_sample_point(g, pt);
+      sample_bad |= !se3d_null_invit_point(g, vstart, pt);   // (no Jacobi fallback here: a sample that does not settle sends the joint to the second pass)
       const float sx = (float)pt[0] - X, sy = (float)pt[1] - Y, sz = (float)pt[2] - Z;
       const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
       cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
@@ -1932,8 +1898,11 @@ struct TriHypLds {
   unsigned char vidx[TH_JOINTS][TH_MAXV];              // usable views of a joint in ascending camera order
 };
 
+// Round 4: five wavefronts per SIMD (96 VGPRs, 16 B of scratch per lane outside the sample loop).  With the Jacobi fallback out of the sample
+// loop (a sample that does not settle sends the joint to the second pass) the kernel needs 101 registers; at 96 it runs 7.58 instead of 7.71 ms
+// per 98 304 frames (profiles/r4/README.md).
 #ifndef TH_WPE
-#define TH_WPE 4
+#define TH_WPE 5
 #endif
 #ifdef SE3D_LM_STAMPS
 __device__ unsigned long long g_th_stamps[16];
@@ -2202,7 +2171,8 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
     const float Xj = S.X[j], Yj = S.Y[j], Zj = S.Z[j];
     const float bsc = sqrtf((float)(2 * n) + 0.5f);
     const float wgt = 1.0f / (2.0f * ((float)(2 * n) + 0.5f));  // all weights equal because 2*kappa == 1
-    bool sample_bad = false;   // a sample's cheap solve (se3d_sample_point) did not qualify: the joint goes to the second pass
+    bool sample_bad = false;   // a sample's inverse iteration did not settle: the joint goes to the second pass
+    const double vstart[4] = {(double)Xj, (double)Yj, (double)Zj, 1.0};   // the iteration is scale-free: the published point is its start
     double gj[10], cv[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 10; ++k) gj[k] = S.G[j][k];
@@ -2223,7 +2193,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
           se3d_sigma_gram(gq, sRt + 12 * S.cam[v], S.x[j][v], S.y[j][v], S.ca[j][v], S.cb[j][v], S.cc[j][v], bsc, o0, o1, (cls == 0 ? 1 : 3) + (q & 1));
         }
         double pt[3];
-        sample_bad |= !se3d_sample_point(gq, pt);
+        sample_bad |= !se3d_null_invit_point(gq, vstart, pt);   // (no Jacobi fallback in the loop: a sample that does not settle sends the joint to the second pass)
         const float sx = (float)pt[0] - Xj, sy = (float)pt[1] - Yj, sz = (float)pt[2] - Zj;
         const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
         cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
@@ -2241,7 +2211,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
     static_assert(TH_JOINTS * 6 <= 64, "one trip over the (joint, entry) lanes");
     {
       const int it = lane, jj = it / 6, e = it - jj * 6;
-      bool wide = false;   // a variance above SE3D_EXACT_VAR_MAX or a sample whose cheap solve did not qualify: the joint goes to the second pass
+      bool wide = false;   // a variance above SE3D_EXACT_VAR_MAX or a sample whose solve did not settle: the joint goes to the second pass
       if (it < JN * 6 && S.cnt[jj] != 0) {
         double acc = 0.0;
         for (int q = 0; q < LPJ; ++q) acc += part[jj * LPJ + q][e];
@@ -2285,8 +2255,16 @@ struct X32Views {
   float *rows;                            // [n][8] DLT rows r0, r1 of the view, normalised by division (S3D:446-449), unweighted
   int *cam;
 };
-__host__ __device__ inline size_t se3d_exact_lds_bytes(int N) {   // camera matrices, view list, rows, centred samples
-  return ((((size_t)12 * N + 6 * N + 8 * N + 3 * (4 * N + 1)) * sizeof(float) + (size_t)N * sizeof(int)) + 15) & ~(size_t)15;
+// LDS of a wavefront of the second pass: view list and rows; on small rigs also the camera matrices and the centred samples.  Large rigs
+// (N > SE3D_EXACT_SMALL_N) read the camera matrices from global memory and keep the centred samples behind the lanes' matrices in the
+// workspace: 15 KB instead of 40 KB at 256 cameras, ten wavefronts per CU instead of four.
+#define SE3D_EXACT_SMALL_N 64
+__host__ __device__ inline size_t se3d_exact_lds_bytes(int N) {
+  const size_t small = N <= SE3D_EXACT_SMALL_N ? (size_t)12 * N + 3 * (4 * N + 1) : 0;
+  return (((small + 6 * N + 8 * N) * sizeof(float) + (size_t)N * sizeof(int)) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t se3d_exact_ws_floats(int N) {   // per wavefront: 64 lane-interleaved 2N x 4 matrices (+ the centred samples on large rigs)
+  return (size_t)64 * 8 * N + (N <= SE3D_EXACT_SMALL_N ? 0 : (((size_t)3 * (4 * N + 1) + 63) & ~(size_t)63));
 }
 
 // one triangulate() call of the reference on this lane: views 0 .. n-1 without `skip`, view `mv` (>= 0) taking the point (mx, my)
@@ -2340,17 +2318,25 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_exact(Se3dDev D) {
   const uint32_t cnt = D.tri_cnt[0];
   if (blockIdx.x == 0 && lane == 0) D.tri_cnt[1] += cnt;   // running total (se3d_get_exact_stats); launches of a context are serialised
   if (blockIdx.x >= cnt) return;
-  float *sRt = reinterpret_cast<float *>(smem);
+  const bool small_rig = N <= SE3D_EXACT_SMALL_N;
+  float *const wsw = D.tri_ws + (size_t)blockIdx.x * se3d_exact_ws_floats(N);
+  float *lds = reinterpret_cast<float *>(smem);
+  const float *sRt = D.Rt;                           // camera matrices: LDS copy on small rigs, global memory (L1 / L2) on large ones
+  float *cen = wsw + (size_t)64 * 8 * N;             // [4n + 1][3] centred samples: LDS on small rigs, workspace on large ones
+  if (small_rig) {
+    for (int i = lane; i < 12 * N; i += 64) lds[i] = D.Rt[i];
+    sRt = lds;
+    cen = lds + 12 * N;
+    lds = cen + 3 * (4 * N + 1);
+  }
   X32Views T;
-  T.x = sRt + 12 * N; T.y = T.x + N; T.cf = T.y + N; T.k00 = T.cf + N; T.k01 = T.k00 + N; T.k11 = T.k01 + N;
+  T.x = lds; T.y = T.x + N; T.cf = T.y + N; T.k00 = T.cf + N; T.k01 = T.k00 + N; T.k11 = T.k01 + N;
   T.rows = T.k11 + N;
-  float *cen = T.rows + 8 * N;                       // [4n + 1][3] centred samples
-  T.cam = reinterpret_cast<int *>(cen + 3 * (4 * N + 1));
-  for (int i = lane; i < 12 * N; i += 64) sRt[i] = D.Rt[i];
+  T.cam = reinterpret_cast<int *>(T.rows + 8 * N);
   // The lanes' rows x 4 matrices live in a lane-interleaved workspace in global memory (L2-resident).  In LDS (64 x 8 N floats = 32 KB per
   // wavefront at 16 cameras) four wavefronts fit a CU and the launch took 247 us for the ~8 k listed joints of a 98 304-frame 16cam6p batch;
   // from global memory with 16 wavefronts per CU 136 us (profiles/r4/README.md).
-  const X32Mat A{D.tri_ws + (size_t)blockIdx.x * 64 * 8 * N + lane, 64, 2 * N};
+  const X32Mat A{wsw + lane, 64, 2 * N};
   __syncthreads();
   for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
     const uint32_t en = D.tri_list[it];
@@ -2398,10 +2384,12 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_exact(Se3dDev D) {
     // ... and on lane n + 1 the unweighted system of all views: the centre sample of the unscented transform if no view is removed
     float Xl[3] = {0.f, 0.f, 0.f};
     double el = 1e300;
-    const int n_all = n;
-    const bool centre_lane = n_all + 1 <= 63;
-    if (lane == 0 || (n >= 3 && lane <= n) || (centre_lane && lane == n + 1)) {
-      const bool wj = lane <= n;
+    // (joints seen by more than 62 views: no speculation — their candidates would not fit one pass anyway and are solved below when the
+    // error asks for them; the centre sample takes lane 1)
+    const bool spec = n >= 3 && n <= 62;
+    const int centre_at = spec ? n + 1 : 1;
+    if (lane == 0 || (spec && lane <= n) || lane == centre_at) {
+      const bool wj = lane != centre_at;
       x32_triangulate(T, sRt, n, wj, wj ? lane - 1 : -1, -1, 0.f, 0.f, A, Xl);
       if (wj) el = x32_reproj_error(T, sRt, n, lane - 1, Xl);
     }
@@ -2441,9 +2429,9 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_exact(Se3dDev D) {
     } else if (err > REPROJ_MAX && n >= 4) {  // S3D:793-838: candidates in ascending view order, first strict minimum below 0.9 x err wins
       const double err0 = err;
       double bestErr = err;
-      for (int base = -1; base < n; base += 64) {
-        // candidate base + lane: the first pass has the full system on lane 0 and candidates 0 .. 62 on lanes 1 .. 63 (solved above),
-        // later passes (n > 63 views) solve theirs now
+      for (int base = spec ? -1 : 0; base < n; base += 64) {
+        // candidate base + lane: with speculation the one pass has the full system on lane 0 and candidates 0 .. n - 1 on lanes 1 .. n (solved
+        // above); without it (n > 62 views) the passes solve their candidates now
         const int i = base + lane;
         double e_i = 1e300;
         float cx_ = 0.f, cy_ = 0.f, cz_ = 0.f;
@@ -2505,10 +2493,10 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_exact(Se3dDev D) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) cov6[k] = __builtin_nanf("");
     } else {
-      // sample 0 (the unmoved points) was solved by lane n + 1 of phase A when no view was removed
-      const int first = (rm == -1 && centre_lane) ? 1 : 0;
+      // sample 0 (the unmoved points) was solved in phase A (lane centre_at); it is valid when no view was removed
+      const int first = (rm == -1) ? 1 : 0;
       if (first) {
-        const float c0 = __shfl(Xl[0], n_all + 1), c1 = __shfl(Xl[1], n_all + 1), c2 = __shfl(Xl[2], n_all + 1);
+        const float c0 = __shfl(Xl[0], centre_at), c1 = __shfl(Xl[1], centre_at), c2 = __shfl(Xl[2], centre_at);
         if (lane == 0) { cen[0] = c0 - X; cen[1] = c1 - Y; cen[2] = c2 - Z; }
       }
       for (int s0 = first; s0 < nsamp; s0 += 64) {

@@ -109,7 +109,7 @@ def test_device_bytes_and_bench_memory_plan(product_lib):
     assert whole / 16 < b < whole / 5      # two chunks of ~1 / 16 of the pairs each, plus everything else
     os.environ["SE3D_PAIR_CHUNKS"] = "0"   # the whole table (A/B switch)
     try:
-        assert whole < device_bytes(256, 16, 128, 256) < whole + 2e9
+        assert whole < device_bytes(256, 16, 128, 256) < whole + 4.5e9   # (+ 2 GB of second-pass workspaces since round 4)
     finally:
         del os.environ["SE3D_PAIR_CHUNKS"]
     assert device_bytes(16, 2, 8, 12) < device_bytes(16, 4, 8, 12) < 10e6
