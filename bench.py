@@ -484,6 +484,8 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         tot = torch.tensor([n_skel_local], dtype=torch.int64, device="cuda")
         dist.all_reduce(tot)
         n_skel = int(tot.item())
+    # joints the triangulation's float32 second pass redid in the last stage-1 launch of context 0 (round 4: se3d_get_exact_list)
+    n_second_pass = len(nodes[0].exact_list()[0])
     names = STAGE1_KERNELS + (STAGE2_KERNELS if stage2 else [])
     prof = {k: tuple(sum(x) for x in zip(*[nd_.profile_get(k) for nd_ in nodes])) for k in names}   # (ms, launches) over all contexts
     res = {
@@ -492,6 +494,7 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         "kernel_ms_per_step": {k: v[0] / steps / NC for k, v in prof.items()},   # per context and step
         "max_hyp_per_frame": int(max(r.n_hyp for r in s1)), "max_published_per_frame": int(max_pub[0]), "exchange_verified": exchange_ok,
         "lm_iterations_mean": float(np.mean(lm_iters)) if lm_iters else None, "params": node.params, "pair_chunks": node.pair_chunks(),
+        "second_pass_joints": n_second_pass, "second_pass_fraction": n_second_pass / max(1.0, 17.0 * n_s1 / NC),
         "exchange": None if ex is None else {"form": "dense: published persons back to back + per-frame offsets" if dense_cap else "[frame][%d person slots] + counts" % XH,
                                              "bytes_per_rank_per_step": int(NC * (ex.sp + 4 * ex.sc))},
         "exchange_ms_per_step": None if exchange_ms is None else round(exchange_ms[0], 4), "exchange_ms_max": None if exchange_ms is None else round(exchange_ms[1], 4),
@@ -952,7 +955,7 @@ def main():
     if rank == 0:
         main_res = head or serial
         def load(fn):   # committed counter summaries: this round's when present, else the previous round's
-            for rd in ("r3", "r2"):
+            for rd in ("r4", "r3", "r2"):
                 p = os.path.join(ROOT, "profiles", rd, fn)
                 if os.path.exists(p):
                     d = json.load(open(p))
@@ -982,6 +985,10 @@ def main():
                                     if dist is not None else "single GPU"),
                        "exchange": main_res.get("exchange")},
             "roofline": roof,
+            "second_pass": {"joints_per_launch": main_res["second_pass_joints"], "per_published_joint": round(main_res["second_pass_fraction"], 6),
+                            "note": "joints the fast fp64 triangulation handed to se3d_k_triangulate_exact (the reference's float32 JacobiSVD arithmetic, "
+                                    "bit-identical to the oracle): ill-conditioned systems, reprojection errors near / above the outlier threshold, wide covariances; "
+                                    "its time is inside the `triangulate` kernel group"},
         }
         if dist is not None:   # what lets an N > 1 run be read (round 4): the all-gather's own time, the step without it, what RCCL reports
             line["exchange_ms_per_step"] = main_res["exchange_ms_per_step"]
@@ -1027,6 +1034,7 @@ def main():
                                  "ms_per_step": round(sec["ms_per_step"], 3), "steps": sec["steps"], "warmup": sec["warmup"],
                                  "skeletons_per_step_per_gpu": sec["n_skel_local"], "max_hypotheses_per_frame": sec["max_hyp_per_frame"],
                                  "target": "north_star: >= 1e5 skeletons/s on 8 GPUs = 12 500 per GPU", "exchange_verified": sec["exchange_verified"],
+                                 "second_pass_fraction": round(sec["second_pass_fraction"], 6),
                                  "exchange_ms_per_step": sec["exchange_ms_per_step"], "value_no_exchange": None if sec["value_no_exchange"] is None else round(sec["value_no_exchange"], 2),
                                  "roofline": roof2}
         if hyp is not None:

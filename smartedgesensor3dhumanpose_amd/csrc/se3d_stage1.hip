@@ -1479,9 +1479,10 @@ __device__ __forceinline__ void se3d_solve_point(const double g[10], const doubl
 // on spurious persons of crowded scenes: base kappa 59 - 1150, sigma 30 - 50 m, float32 and fp64 covariances 1.3e-3 - 7.9e-3 apart).
 #define SE3D_EXACT_VAR_MAX 1.0
 // Evaluated in float32 (half the issue cost of fp64 on this chip): only lambda3 ~ 1e-2 .. 1e-4 of the trace and the gap to lambda4 matter, the
-// threshold is met with a margin of 18 x, and the study above gives the same flags for the float32 and the fp64 evaluation (lambda3 from the
-// second-order bound b3 / sqrt(b2^2 - 2 b1 b3) <= lambda3 — 1/l1^2 + 1/l2^2 + 1/l3^2 = (b2^2 - 2 b1 b3) / b3^2 — instead of Newton steps;
-// bound / kappa 1.04 .. 2.1, median 1.4).  ~90 float operations, no division: kappa < K  <=>  (1 + |p|^2)^2 trace < K^2 (s3 - s4)^2.
+// threshold is met with a margin of 18 x, and the study above gives the same flags for the float32 and the fp64 evaluation (lambda3 starts
+// from the second-order bound b3 / sqrt(b2^2 - 2 b1 b3) <= lambda3 — 1/l1^2 + 1/l2^2 + 1/l3^2 = (b2^2 - 2 b1 b3) / b3^2; bound / kappa 1.04 .. 2.1,
+// median 1.4 — and takes two Newton steps from there: 1.01 .. 1.7, median 1.25).  ~110 float operations, no division by the gap:
+// kappa < K  <=>  (1 + |p|^2)^2 trace < K^2 (s3 - s4)^2.
 // Returns true when the joint must go to the second pass.
 __device__ __forceinline__ bool se3d_kappa_flag(const float g[10], float p0, float p1, float p2) {
   // g packed: 00 01 02 03 11 12 13 22 23 33
@@ -1503,7 +1504,13 @@ __device__ __forceinline__ bool se3d_kappa_flag(const float g[10], float p0, flo
   const float lam4 = fmaxf(fmaf(w0, p0, fmaf(w1, p1, fmaf(w2, p2, w3))) * __builtin_amdgcn_rcpf(vv), 0.f);
   const float b1 = c1 - lam4, b2 = fmaf(-lam4, b1, c2), b3 = fmaf(-lam4, b2, c3);
   const float t = fmaf(b2, b2, -2.0f * (b1 * b3));
-  const float x = b3 * __builtin_amdgcn_rsqf(t);                       // <= lambda3
+  float x = b3 * __builtin_amdgcn_rsqf(t);                             // <= lambda3 (second-order bound)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {   // two Newton steps on the deflated cubic from below (left of its smallest root it is increasing and concave:
+    const float q = fmaf(fmaf(x - b1, x, b2), x, -b3);                // the steps approach lambda3 without passing it): bound / kappa 1.01 .. 1.7
+    const float dq = fmaf(fmaf(3.0f, x, -2.0f * b1), x, b2);
+    x = fmaf(-q, __builtin_amdgcn_rcpf(dq), x);
+  }
   const float gap2 = (x + lam4) - 2.0f * __builtin_amdgcn_sqrtf(x * lam4);   // (s3 - s4)^2
   const float lhs = (vv * vv) * c1;
   const bool fine = t > 0.f && b3 > 0.f && x > lam4 && lhs < (float)(SE3D_EXACT_KAPPA * SE3D_EXACT_KAPPA) * gap2;

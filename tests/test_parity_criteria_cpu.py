@@ -119,6 +119,10 @@ def _kappa_flag(g, p, K):
     if not (t > 0 and b3 > 0):
         return True
     xx = b3 / np.sqrt(t)
+    for _ in range(2):   # two Newton steps on the deflated cubic, from below
+        q = ((xx - b1) * xx + b2) * xx - b3
+        dq = (f(3) * xx - f(2) * b1) * xx + b2
+        xx = xx - q / dq
     gap2 = (xx + lam4) - f(2) * np.sqrt(xx * lam4)
     return not (xx > lam4 and (vv * vv) * c1 < f(K * K) * gap2)
 

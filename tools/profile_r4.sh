@@ -2,7 +2,10 @@
 # Runs on the GPU box (gpurun -- bash tools/profile_r4.sh <what> ...): the rocprofv3 passes behind profiles/r4/.
 #   serial      : bench.py --serial (one context, one stream) kernel stats
 #   serial_pmc  : SQ + HBM traffic PMC passes of the serial pass
+#   valumix     : VALU instruction-mix counters of the serial pass
 #   c256        : 256cam128p, one context: kernel stats (+ PMC with c256_pmc)
+#   ablate      : a variant library tools/tmp/libse3d_$ABLATE.so through the serial pass
+#   exact_waves : (historic) second pass with W wavefronts and the workspace in global memory
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -41,6 +44,14 @@ exact_waves)
     unset SE3D_EXACT_WAVES
     python3 tools/kernel_stats.py $OUT/serial_stats_w$W $OUT/serial_16cam6p_w${W}_kernel_stats.csv | grep triang
   done
+  ;;
+valumix)
+  # instruction mix of the vector ALU per kernel (two passes: the counters do not fit one)
+  rm -rf $OUT/serial_mix64 $OUT/serial_mix32
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT GRBM_GUI_ACTIVE --output-format csv -d $OUT/serial_mix64 -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_mix64.log 2>&1
+  python3 tools/pmc_sq.py $OUT/serial_mix64 $OUT/pmc_valumix64_16cam6p_serial.json "bench.py --serial --steps 2 --warmup 1: fp64 VALU instruction counters"
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/serial_mix32 -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_mix32.log 2>&1
+  python3 tools/pmc_sq.py $OUT/serial_mix32 $OUT/pmc_valumix32_16cam6p_serial.json "bench.py --serial --steps 2 --warmup 1: fp32 / integer VALU instruction counters"
   ;;
 c256)
   rm -rf $OUT/c256_stats1
