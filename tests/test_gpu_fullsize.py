@@ -171,3 +171,36 @@ def test_crowded_128cam_64p_exact_parity_with_oracle(oracle, demo_params):
     print("128x64:", st, "oracle attached", na, "foreign", nf)
     assert g.n_persons >= 60
     node.close()
+
+
+def test_256cam_32p_exact_parity_with_oracle(oracle, demo_params):
+    """north_star's camera count with a person count the oracle can still afford (17 x 32^2 x 32 640 pair-joints: ~20 s): the 256-camera code
+    paths — pair table in 16 camera-column chunks, per-camera sweep launches with the block Munkres, per-joint triangulation, the float32
+    second pass with its workspace layout for large rigs, per-step stage 2 — against the oracle: stage 1 of a frame (association table
+    bit-exact, every joint < 1 mm, covariances 1e-3) and twelve stage-2 steps (ids, LM iteration counts, refined joints)."""
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D, rig_tensors
+    from smartedgesensor3dhumanpose_amd.pose_prior import PosePrior
+    from parity import compare_stage1, compare_stage2
+    rig = R.elliptical_rig(256, seed=4)
+    rig.set_tensors(*rig_tensors(rig))
+    frames, gt = S.generate_sequence(rig, S.SceneConfig(n_persons=32, n_frames=12, seed=9, min_coverage=6))
+    node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=1, max_det_per_cam=40, max_hyp=64)
+    assert node.pair_chunks() == 16
+    g = node.triangulate_persons(frames[:1])[0]
+    n_second = len(node.exact_list()[0])
+    o = oracle.triangulate(rig, demo_params, frames[0], capacity=64, hyp_capacity=64, omp_threads=os.cpu_count() or 1)
+    st = compare_stage1(g, o)
+    print("256x32 stage 1:", st, "| joints through the float32 second pass:", n_second)
+    assert g.n_persons >= 30
+    node.refine_reset()
+    pp, ora = PosePrior(node, 0), oracle.PosePrior(demo_params)
+    worst, published = {"pos_max_mm": 0.0, "pred_max_mm": 0.0, "cov_rel_max": 0.0}, 0
+    for fr in frames:
+        dets = node.triangulate_persons([fr])[0].published()
+        r2 = pp.skeleton_callback(dets, fr.stamp, fr.fb_delay)
+        s2 = compare_stage2(r2, ora.step(dets, rig.n_cam, fr.stamp, fr.fb_delay, capacity=64))
+        published += r2.n_persons
+        worst = {k: max(worst[k], s2[k]) for k in worst}
+    print("256x32 stage 2: %d published person-steps, worst %s" % (published, worst))
+    assert published >= 30
+    node.close()
