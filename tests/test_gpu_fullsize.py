@@ -189,8 +189,22 @@ def test_256cam_32p_exact_parity_with_oracle(oracle, demo_params):
     g = node.triangulate_persons(frames[:1])[0]
     n_second = len(node.exact_list()[0])
     o = oracle.triangulate(rig, demo_params, frames[0], capacity=64, hyp_capacity=64, omp_threads=os.cpu_count() or 1)
-    st = compare_stage1(g, o)
-    print("256x32 stage 1:", st, "| joints through the float32 second pass:", n_second)
+    st = compare_stage1(g, o, check_cov=False)
+    # covariances: with up to 256 views a joint's sigma is ~1 mm, so the float32 noise of the reference's own sample solves (2 2^-24 kappa / sigma,
+    # parity.cov_tolerance) is what bounds the agreement, not the flat 1e-3 of the small rigs
+    import parity
+    k2f = np.array(pm.KP2FUSION_SIMPLE)
+    kappa = parity.published_joint_condition(rig, frames[0], g, k2f)
+    gk, ok = g.published()["keypoints"][:, k2f], o.published()["keypoints"][:, k2f]
+    v = ok["score"] > 0
+    w6 = np.array([1, 2, 2, 1, 2, 1.0])
+    d = np.where(v, np.linalg.norm(gk["joint"] - ok["joint"], axis=-1), 0.0)
+    tables = oracle.pose_tables(pm.POSE_SIMPLE)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.maximum(np.sqrt(((gk["cov"] - ok["cov"]) ** 2 * w6).sum(-1)) - parity.inflation_allowance(tables, ok["joint"], v, d), 0.0) / np.sqrt((ok["cov"] ** 2 * w6).sum(-1))
+    tol = parity.cov_tolerance(np.minimum(kappa, parity.DLT_KAPPA_MAX), ok["cov"])
+    assert (rel[v] < tol[v]).all(), (float(rel[v].max()), float(tol[v][np.argmax(rel[v])]))
+    print("256x32 stage 1:", st, "| covariance rel. max %.2e (tolerance there %.2e) | joints through the float32 second pass: %d" % (rel[v].max(), tol[v][np.argmax(rel[v])], n_second))
     assert g.n_persons >= 30
     node.refine_reset()
     pp, ora = PosePrior(node, 0), oracle.PosePrior(demo_params)
