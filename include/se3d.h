@@ -156,7 +156,9 @@ int64_t se3d_device_bytes(int32_t n_cam, const se3d_limits *limits);
 const char *se3d_version(void);
 
 /* --- stage 1: drop-in for triangulate_persons (S3D:525-997) ------------------------------------------- */
-/* one frame, synchronous (host in, host out) */
+/* one frame, synchronous (host in, host out).  On a context with limits.max_frames == 1 — one synchronised frame per callback, the reference's
+ * operating point (S3D:1069) — the call replays ONE hipGraph (upload, kernel chain, download) captured on first use; the same holds for
+ * se3d_refine on such a context (PP:505).  Environment SE3D_GRAPH=0 or se3d_profile_enable(ctx, 1) select direct launches. */
 int se3d_triangulate(se3d_ctx *ctx, const se3d_frame_in *frame, se3d_frame_out *out);
 /* B frames, synchronous */
 int se3d_triangulate_batch(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in *frames, se3d_frame_out *outs);

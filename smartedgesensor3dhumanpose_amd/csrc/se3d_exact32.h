@@ -150,20 +150,16 @@ __device__ __forceinline__ float x32_sumsq(const X32MatT<PT> &A, int c, int i0, 
 
 // Null vector of the rows x 4 system in A (rows >= 4; A is overwritten): JacobiSVD<Matrix<float, -1, 4>>::compute + matrixV().col(3).
 // Out of line on purpose (one copy of ~3 k instructions for the three call sites of the second pass; arguments and result in registers).
+// `amax`: the largest |entry| of A (the builder of the matrix tracks it while it writes the rows: one pass over the matrix less).
 template <typename PT>
-__device__ __noinline__ float4 x32_null_vector(int rows, PT Ap, int Astride, int Ald) {
+__device__ __noinline__ float4 x32_null_vector(int rows, PT Ap, int Astride, int Ald, float amax) {
   const X32MatT<PT> A{Ap, Astride, Ald};
   float v_out[4];
-  float scale = 0.f;
-  for (int c = 0; c < 4; ++c)
-    for (int i = 0; i < rows; i += X32_BS) {
-      float a[X32_BS];
-#pragma unroll
-      for (int u = 0; u < X32_BS; ++u) a[u] = (i + u < rows) ? A.get(i + u, c) : 0.f;
-#pragma unroll
-      for (int u = 0; u < X32_BS; ++u) scale = fmaxf(scale, fabsf(a[u]));
-    }
+  float scale = amax;   // JacobiSVD::compute: scale = matrix.cwiseAbs().maxCoeff(); if (scale == 0) scale = 1
   if (scale == 0.f) scale = 1.f;
+  // matrix / scale, fused with the column norms of the QR step below (sums over the scaled entries in row order: the same values, the same order)
+  float colss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
   for (int c = 0; c < 4; ++c)
     for (int i = 0; i < rows; i += X32_BS) {
       float a[X32_BS];
@@ -171,7 +167,11 @@ __device__ __noinline__ float4 x32_null_vector(int rows, PT Ap, int Astride, int
       for (int u = 0; u < X32_BS; ++u) a[u] = (i + u < rows) ? A.get(i + u, c) : 0.f;
 #pragma unroll
       for (int u = 0; u < X32_BS; ++u)
-        if (i + u < rows) A.set(i + u, c, a[u] / scale);
+        if (i + u < rows) {
+          const float q = a[u] / scale;
+          A.set(i + u, c, q);
+          colss[c] += q * q;
+        }
     }
   float W[4][4], V[4][4];
   if (rows == 4) {   // square input: no QR step (m_workMatrix = matrix / scale, m_matrixV.setIdentity())
@@ -186,9 +186,7 @@ __device__ __noinline__ float4 x32_null_vector(int rows, PT Ap, int Astride, int
   int perm[4] = {0, 1, 2, 3};
   float nu[4], nd[4];   // m_colNormsUpdated, m_colNormsDirect
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    nu[k] = nd[k] = sqrtf(x32_sumsq(A, k, 0, rows));
-  }
+  for (int k = 0; k < 4; ++k) nu[k] = nd[k] = sqrtf(colss[k]);
   const float norm_downdate_threshold = sqrtf(FLT_EPSILON);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -208,7 +206,7 @@ __device__ __noinline__ float4 x32_null_vector(int rows, PT Ap, int Astride, int
     // makeHouseholderInPlace on A.col(k).tail(rows - k)
     const float tailSq = x32_sumsq(A, pk, k + 1, rows);
     const float c0 = A.get(k, pk);
-    float tau, beta;
+    float tau, beta, den = 1.f;   // den: the essential part (tail / den) is formed by the pass that takes the dot products below
     if (tailSq <= FLT_MIN) {
       tau = 0.f;
       beta = c0;
@@ -216,27 +214,23 @@ __device__ __noinline__ float4 x32_null_vector(int rows, PT Ap, int Astride, int
     } else {
       beta = sqrtf(c0 * c0 + tailSq);
       if (c0 >= 0.f) beta = -beta;
-      const float den = c0 - beta;
-      for (int i = k + 1; i < rows; i += X32_BS) {
-        float a[X32_BS];
-#pragma unroll
-        for (int u = 0; u < X32_BS; ++u) a[u] = (i + u < rows) ? A.get(i + u, pk) : 0.f;
-#pragma unroll
-        for (int u = 0; u < X32_BS; ++u)
-          if (i + u < rows) A.set(i + u, pk, a[u] / den);
-      }
+      den = c0 - beta;
       tau = (beta - c0) / beta;
     }
     A.set(k, pk, beta);
     // applyHouseholderOnTheLeft to bottomRightCorner(rows - k, 3 - k)  (rows - k >= 3 here: rows >= 6)
+    // (the last column's essential part is never read again — only R enters the Jacobi step — so its scaling is skipped)
     if (tau != 0.f && k + 1 < 4) {
-      // tmp[j] = essential^T * column j (sequential over the rows) + A(k, j); the reflector's column is loaded once per batch of rows for
-      // all trailing columns
+      // tmp[j] = essential^T * column j (sequential over the rows) + A(k, j); the reflector's column is scaled (tail / den, stored) and used
+      // in the same pass, loaded once per batch of rows for all trailing columns
       float tmp[4] = {0.f, 0.f, 0.f, 0.f};
       for (int i = k + 1; i < rows; i += X32_BS) {
         float vk[X32_BS];
 #pragma unroll
         for (int u = 0; u < X32_BS; ++u) vk[u] = (i + u < rows) ? A.get(i + u, pk) : 0.f;
+#pragma unroll
+        for (int u = 0; u < X32_BS; ++u)
+          if (i + u < rows) { vk[u] = vk[u] / den; A.set(i + u, pk, vk[u]); }
 #pragma unroll
         for (int j = k + 1; j < 4; ++j) {
           const int pj = perm[j];

@@ -2279,6 +2279,7 @@ template <typename WsPtrT>
 __device__ __forceinline__ void x32_triangulate(const X32Views &T, const float *__restrict__ sRt, int n, bool weighted, int skip, int mv, float mx, float my,
                                                 const X32MatT<WsPtrT> &A, float X[3]) {
   int r = 0;
+  float amax = 0.f;   // largest |entry| of the system (JacobiSVD's scale), tracked while the rows are written
   for (int v = 0; v < n; ++v) {
     if (v == skip) continue;
     float r0[4], r1[4];
@@ -2294,10 +2295,10 @@ __device__ __forceinline__ void x32_triangulate(const X32Views &T, const float *
       for (int k = 0; k < 4; ++k) { r0[k] = r0[k] * cf; r1[k] = r1[k] * cf; }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { A.set(r, k, r0[k]); A.set(r + 1, k, r1[k]); }
+    for (int k = 0; k < 4; ++k) { A.set(r, k, r0[k]); A.set(r + 1, k, r1[k]); amax = fmaxf(amax, fmaxf(fabsf(r0[k]), fabsf(r1[k]))); }
     r += 2;
   }
-  const float4 v4 = x32_null_vector(r, A.p, A.stride, A.ld);
+  const float4 v4 = x32_null_vector(r, A.p, A.stride, A.ld, amax);
   X[0] = v4.x / v4.w; X[1] = v4.y / v4.w; X[2] = v4.z / v4.w;   // hnormalized()
 }
 // calcReprojectionError (S3D:425-438) of X over the views 0 .. n-1 without `skip`
@@ -3437,6 +3438,7 @@ __global__ __launch_bounds__(64) void se3d_k_selftest_dlt32(int n_sys, int n, co
   if (sidx >= n_sys) return;
   const X32Mat A{ws + (size_t)blockIdx.x * 64 * 8 * n + lane, 64, 2 * n};
   const float *M = Rt + (size_t)sidx * n * 12, *P = pts + (size_t)sidx * n * 3;
+  float amax = 0.f;
   for (int v = 0; v < n; ++v) {
     float r0[4], r1[4];
     x32_dlt_rows(M + 12 * v, P[3 * v], P[3 * v + 1], r0, r1);
@@ -3446,9 +3448,9 @@ __global__ __launch_bounds__(64) void se3d_k_selftest_dlt32(int n_sys, int n, co
       for (int k = 0; k < 4; ++k) { r0[k] = r0[k] * cf; r1[k] = r1[k] * cf; }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { A.set(2 * v, k, r0[k]); A.set(2 * v + 1, k, r1[k]); }
+    for (int k = 0; k < 4; ++k) { A.set(2 * v, k, r0[k]); A.set(2 * v + 1, k, r1[k]); amax = fmaxf(amax, fmaxf(fabsf(r0[k]), fabsf(r1[k]))); }
   }
-  const float4 v4 = x32_null_vector(2 * n, A.p, A.stride, A.ld);
+  const float4 v4 = x32_null_vector(2 * n, A.p, A.stride, A.ld, amax);
   const float X[3] = {v4.x / v4.w, v4.y / v4.w, v4.z / v4.w};
   double averageError = 0., norm = 0.;
   for (int v = 0; v < n; ++v) {

@@ -104,6 +104,7 @@ def _xworker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from smartedgesensor3dhumanpose_amd import shard
     ex = shard.SkeletonExchange(dist, N_CTX, SLICE_P, SLICE_C, torch.device("cpu"), streams=None)
+    ex.timed(True)           # the event stamps exist on CUDA streams only: on gloo the switch must be inert (bench.py calls it on every backend)
     ok = True
     for step in range(N_STEPS):
         for ci in range(N_CTX):
@@ -121,6 +122,14 @@ def _xworker(rank, world, port, q):
                 p, c = _pattern(r, ci, step)
                 ok = ok and np.array_equal(gp[r, ci].numpy(), p) and np.array_equal(gc[r, ci].numpy(), c)
         ok = ok and ex.verify(par)
+    ok = ok and ex.exchange_ms() is None and not ex.timing
+    # a step with the all-gather skipped (bench.py's value_no_exchange pass) writes the SAME pack buffer again and leaves the gathered ones alone
+    before = ex.gath_p[par].clone()
+    pk, cn = ex.pack_target(0)
+    ok = ok and pk.data_ptr() == ex.packs[ex.parity].data_ptr()
+    pk.zero_()
+    ex.packed(0)
+    ok = ok and torch.equal(before, ex.gath_p[par]) and ex.n_exchanges == N_STEPS
     # a corrupted slice must be detected by verify() on every rank
     ex.gath_p[par][-1] ^= 0xFF
     bad = not ex.verify(par)
