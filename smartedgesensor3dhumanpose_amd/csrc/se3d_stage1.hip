@@ -1705,8 +1705,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
 
   // ---- rows + Gram matrices: Gw (confidence weighted, S3D:450-453) and Gu (unweighted, used by the UT) ----
   double gw_[10], gu_[10];
-  double sconf = 0.0;
-  // Gram entry owned by this lane in the small-n path: lanes 0-9 unweighted (00 01 02 03 11 12 13 22 23 33), 10-19 weighted, 20 sum of conf
+  // Gram entry owned by this lane in the small-n path: lanes 0-9 unweighted (00 01 02 03 11 12 13 22 23 33), 10-19 weighted
   const int ge = lane < 10 ? lane : (lane < 20 ? lane - 10 : 0);
   const int gi = (int)((0x3221110000ull >> (4 * ge)) & 0xFull), gj = (int)((0x3323213210ull >> (4 * ge)) & 0xFull);
   auto build = [&](int nn) {
@@ -1721,12 +1720,11 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
       }
       __builtin_amdgcn_wave_barrier();
       double acc = 0.0;
-      if (lane <= 20) {
+      if (lane < 20) {
         const float *ri0 = base + (6 + gi) * N, *rj0 = base + (6 + gj) * N, *ri1 = base + (10 + gi) * N, *rj1 = base + (10 + gj) * N;
         const bool weighted = lane >= 10;
         for (int v = 0; v < nn; ++v) {
           const float cf = T.cf[v];
-          if (lane == 20) { acc += (double)cf; continue; }
           float a0 = ri0[v], b0 = rj0[v], a1 = ri1[v], b1 = rj1[v];
           if (weighted) { a0 = a0 * cf; b0 = b0 * cf; a1 = a1 * cf; b1 = b1 * cf; }
           acc = __builtin_fma((double)a0, (double)b0, acc);
@@ -1735,12 +1733,10 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
       }
 #pragma unroll
       for (int k = 0; k < 10; ++k) { gu_[k] = se3d_readlane_f64(acc, k); gw_[k] = se3d_readlane_f64(acc, 10 + k); }
-      sconf = se3d_readlane_f64(acc, 20);
       return;
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) { gw_[k] = 0.0; gu_[k] = 0.0; }
-    sconf = 0.0;
     for (int v = lane; v < nn; v += 64) {
       float r0[4], r1[4], w0[4], w1[4];
       se3d_dlt_rows(sRt + 12 * T.cam[v], T.x[v], T.y[v], r0, r1);
@@ -1749,11 +1745,9 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
       for (int k = 0; k < 4; ++k) { T.r0[k][v] = r0[k]; T.r1[k][v] = r1[k]; w0[k] = r0[k] * cf; w1[k] = r1[k] * cf; }
       se3d_gram_add(gu_, r0); se3d_gram_add(gu_, r1);
       se3d_gram_add(gw_, w0); se3d_gram_add(gw_, w1);
-      sconf += (double)cf;
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) { gw_[k] = se3d_wave_sum(gw_[k]); gu_[k] = se3d_wave_sum(gu_[k]); }
-    sconf = se3d_wave_sum(sconf);
     __builtin_amdgcn_wave_barrier();  // rows in LDS are consumed by other lanes (leave-one-out, sigma points)
   };
   // weighted reprojection error of float point (X,Y,Z) over views [0,nn) except `skip` (S3D:425-438)
@@ -1779,7 +1773,9 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   }
   float X = (float)pw[0], Y = (float)pw[1], Z = (float)pw[2];
   double err = reproj(n, X, Y, Z);
-  float avg_score = (float)(sconf / n);
+  float avg_score = 0.f;   // the reference's float sum in view order and float quotient (S3D:730, 738): bit-identical scores on this path
+  for (int v = 0; v < n; ++v) avg_score += T.cf[v];
+  avg_score /= (float)n;
   {
     // Round 4: a joint whose fp64 solve may differ from the reference's float32 JacobiSVD by more than the contract allows — ill-conditioned
     // weighted or unweighted system, a solve that did not settle — or whose reprojection error is above / near the outlier threshold is handed
@@ -2123,15 +2119,19 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
   __builtin_amdgcn_wave_barrier();
   if (active) {
     double se = 0.0, sc = 0.0;
+    float scf = 0.f;
 #pragma unroll 4
     for (int v = 0; v < nv; ++v) {  // summed in view order like the per-joint kernel (the terms of the views that are not usable are zero)
+      const float cfv = fmaxf(S.cf[lane][v], 0.f);
       se += (double)S.re[lane][v];
-      sc += (double)fmaxf(S.cf[lane][v], 0.f);
+      sc += (double)cfv;
+      scf += cfv;   // the reference's own float sum over the usable views in view order (S3D:730); + 0.f is the identity
     }
-    // quotients by reciprocal (hardware seed + two Newton steps, <= 1 ulp of fp64 from the IEEE quotient) instead of three fp64 division
-    // sequences on nine lanes: the error only meets thresholds, the score is published as float32
+    // quotient by reciprocal (hardware seed + two Newton steps, <= 1 ulp of fp64 from the IEEE quotient) instead of an fp64 division
+    // sequence: the error only meets thresholds.  The score is the reference's float expression (S3D:738) — a joint that stays on this path
+    // has err <= g_reproj_error_max_acceptable, so S3D:840-841 leave it alone: bit-identical scores.
     const double err = se * se3d_rcp64(sc);
-    avg_score = (float)(sc * se3d_rcp64((double)nj));   // sc: the confidences summed in view order (what G[.][20] used to hold)
+    avg_score = scf / (float)nj;
     // second pass (round 4): outlier rejection (S3D:748-838) and everything near / above its threshold (the score carries err, S3D:840-844),
     // ill-conditioned systems, unsettled solves
     slow = !(err <= REPROJ_MAX * (1.0 - SE3D_EXACT_ERR_GUARD)) || unsettled || ((illmask >> lane) & 1ull) || ((illmask >> (lane + JN)) & 1ull);

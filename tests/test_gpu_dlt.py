@@ -32,7 +32,7 @@ def _compare(got, ref):
         return 0.0, 0.0
     d = np.linalg.norm(g["joint"] - o["joint"], axis=-1)[vo]
     assert d.max() < POS_TOL_M, "max joint error %.4f mm" % (d.max() * 1e3)
-    assert np.allclose(g["score"][vo], o["score"][vo], rtol=SCORE_RTOL, atol=1e-7)
+    assert SCORE_RTOL == 0.0 and np.array_equal(g["score"][vo], o["score"][vo])
     assert (g["joint"][~vo] == 0).all() and (g["cov"][~vo] == 0).all()   # default-constructed slots
     cg, co = g["cov"][vo], o["cov"][vo]
     w = np.array([1, 2, 2, 1, 2, 1.0])
