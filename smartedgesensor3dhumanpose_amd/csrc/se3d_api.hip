@@ -16,8 +16,9 @@
 
 extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st, int variant);
 extern "C" void se3d_launch_pack_dense(const se3d_person3d *fused, const int32_t *n_out, int n_frames, int H, int capacity, int32_t *off, se3d_person3d *dense, hipStream_t st);
-extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled, int phases, hipStream_t st_hi,
-                                   hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk);
+extern "C" int se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled, int phases, hipStream_t st_hi,
+                                  hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk);   // bit 0: the pair table of the pass is not in D.pair
+extern "C" void se3d_launch_normalize_keep(const Se3dDev &D, hipStream_t st);
 extern "C" void se3d_launch_pair_block(const Se3dDev &D, const int2 *d_ab_one, int frame, hipStream_t st);
 extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev, int phases);
 extern "C" void se3d_launch_shard_pack_hyp(const Se3dDev &D, se3d_person3d *out, hipStream_t st);
@@ -70,6 +71,7 @@ struct se3d_ctx {
   int staged_frames = 0;
   bool ran = false;
   bool tiled = false;
+  bool pair_in_hbm = true;   // false: the last pass kept its pair costs in LDS (se3d_k_front_fused); se3d_get_pair_costs computes blocks on demand
   // profiling
   bool prof = false;
   static constexpr int kRing = 96;       // event sets in flight before the oldest are harvested
@@ -421,7 +423,7 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
 static std::string graph_signature() {
   static const char *const names[] = {"SE3D_PAIRS", "SE3D_SWEEP_WAVE", "SE3D_SWEEP_FUSED_MAX", "SE3D_POST_WAVE", "SE3D_TRI", "SE3D_NP_LINES", "SE3D_NP_TILE",
                                       "SE3D_NO_SMALL_BATCH", "SE3D_SWEEP_LDS_KB", "SE3D_LM", "SE3D_WALK", "SE3D_WALK_LM", "SE3D_WALK_SHAPE", "SE3D_WALK_BOOK",
-                                      "SE3D_REFINE_WALK", "SE3D_NO_HI_STREAM"};
+                                      "SE3D_REFINE_WALK", "SE3D_NO_HI_STREAM", "SE3D_FRONT", "SE3D_FRONT_NT", "SE3D_FRONT_CAP", "SE3D_FRONT_DUMP"};
   std::string sig;
   for (const char *n : names) { const char *v = getenv(n); sig += v ? v : ""; sig += '|'; }
   return sig;
@@ -715,7 +717,7 @@ int se3d_run_stage1(se3d_ctx *c) {
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;  // grids cover the staged frames only (array strides do not depend on B)
   // the per-frame workspace (assoc, nviews, nhyp, flags, hypP) is reset by se3d_k_normalize, the first kernel of the pass
-  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);
+  c->pair_in_hbm = !(se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk) & 1);
   HIPCHK(c, hipGetLastError());
   c->ran = true;
   return SE3D_OK;
@@ -729,7 +731,8 @@ int se3d_run_stage1_phases(se3d_ctx *c, int32_t phases) {
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;
   if (phases & 1) c->cur_ev1 = next_ev1(c);   // one event set per pass, begun by the part that holds phase 1 and completed by the part with phase 4
-  se3d_launch_stage1(D, c->pair_ab, c->stream, c->cur_ev1, c->tiled, phases, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);
+  const int info = se3d_launch_stage1(D, c->pair_ab, c->stream, c->cur_ev1, c->tiled, phases, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);
+  if (phases & 1) c->pair_in_hbm = !(info & 1);
   HIPCHK(c, hipGetLastError());
   if (phases & 4) c->ran = true;
   return SE3D_OK;
@@ -792,7 +795,7 @@ int se3d_triangulate_batch(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *f
     Se3dDev D = c->D;
     const int g = graph_replay(c, c->g1, [&] {
       (void)hipMemcpyAsync(c->sl_in1.d, c->sl_in1.h, c->sl_in1.bytes, hipMemcpyHostToDevice, c->stream);
-      se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 15, nullptr, nullptr, &c->plan, nullptr);
+      c->pair_in_hbm = !(se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 15, nullptr, nullptr, &c->plan, nullptr) & 1);   // (at capture; a replay runs the same kernels)
       (void)hipMemcpyAsync(c->sl_out1.h, c->sl_out1.d, c->sl_out1.bytes, hipMemcpyDeviceToHost, c->stream);
     });
     if (g < 0) return g;
@@ -907,11 +910,18 @@ int se3d_get_pair_costs(se3d_ctx *c, int32_t frame, int32_t cam_a, int32_t cam_b
   HIPCHK(c, hipSetDevice(c->device));
   const int P = D.d.P;
   size_t off = ((size_t)frame * D.d.npairs + se3d_pair_index(cam_a, cam_b, D.d.N)) * P * P;
-  if (D.d.pair_chunks) {
+  if (D.d.pair_chunks || !c->pair_in_hbm) {
+    // fused front kernel (pair costs in LDS): the normalised points are formed again first (masks / slots are rewritten with the same
+    // values, the association workspace is left alone), then as under
     // column chunks: the table of the pass is gone (every chunk buffer has been overwritten since); the block is computed again by the
     // pair kernel of the pass into slot 0 of the frame (one-entry pair list in the first element of C, free between passes)
     // (both are scratch between passes — the next se3d_run_stage1 rewrites them — and the slot is cleared to -1 first, "no joint shared":
     // the kernel writes nothing for a camera without valid detections)
+    if (!D.d.pair_chunks) {
+      Se3dDev Dn = D;
+      Dn.d.B = c->staged_frames;
+      se3d_launch_normalize_keep(Dn, c->stream);
+    }
     const int2 one = make_int2(cam_a, cam_b);
     HIPCHK(c, hipMemcpyAsync(D.C, &one, sizeof(int2), hipMemcpyHostToDevice, c->stream));
     off = (size_t)frame * D.d.pair_stride * P * P;
@@ -1274,7 +1284,7 @@ int se3d_run_stage1_shard_pre(se3d_ctx *c, void *d_pack) {
   HIPCHK(c, hipSetDevice(c->device));
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;
-  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 11, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);   // association on every rank, triangulation of the own hypotheses
+  c->pair_in_hbm = !(se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 11, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk) & 1);   // association on every rank, triangulation of the own hypotheses
   se3d_launch_shard_pack_hyp(D, static_cast<se3d_person3d *>(d_pack), c->stream);
   HIPCHK(c, hipGetLastError());
   return SE3D_OK;
@@ -1393,7 +1403,7 @@ int se3d_stream_submit(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frame
   D.d.B = n_frames;
   se3d_launch_stream_scatter(D, sl.d_rag, sl.d_off, c->stream);
   c->staged_frames = n_frames;
-  se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);
+  c->pair_in_hbm = !(se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk) & 1);
   c->ran = true;
   c->d_fb_walk = sl.d_fb;
   rc = se3d_run_stage2_walk(c, n_seq, n_steps, frame_slot0, t);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void se3d_k_normalize(Se3dDev D, int write_kp)
   __shared__ int s_nvalid;
   const int n = min(D.nraw[f * N + c], P);
   for (int r = tid; r < P; r += blockDim.x) { cnt[r] = 0; mgt[r] = 0; mge[r] = 0; }
-  {  // per-frame workspace reset: the N workgroups of a frame share the work
+  if (!(write_kp & 2)) {  // per-frame workspace reset: the N workgroups of a frame share the work (write_kp & 2: keep it — se3d_get_pair_costs after a pass)
     const int H = D.d.H;
     for (int h = tid; h < H; h += blockDim.x) D.assoc[((size_t)f * H + h) * N + c] = -1;
     if (c == 0) {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void se3d_k_normalize(Se3dDev D, int write_kp)
   __syncthreads();
   const float fx = D.K[c * 4 + 0], fy = D.K[c * 4 + 1], cx = D.K[c * 4 + 2], cy = D.K[c * 4 + 3];
   const size_t base = ((size_t)(f * N + c)) * P;
-  for (int idx = tid; write_kp && idx < n * SE3D_NKP; idx += blockDim.x) {
+  for (int idx = tid; (write_kp & 1) && idx < n * SE3D_NKP; idx += blockDim.x) {
     const int det = idx / SE3D_NKP, j = idx - det * SE3D_NKP;
     const int k = slot[det];
     if (k < 0) continue;
@@ -268,11 +268,12 @@ __device__ __forceinline__ double se3d_pair_cost_lds(const float *__restrict__ F
 
 // Rows N of a frame for the small-rig kernels below: per-frame workspace reset, valid-joint masks, order-preserving slot compaction, the
 // normalised points of the kept detections into LDS.  256 threads; ends with the points visible to the whole workgroup.
-__device__ __forceinline__ void se3d_np_prologue(const Se3dDev &D, int f, int tid, float2 *skp, unsigned *s_mgt, int *s_slot, int *s_nv) {
+// nt: threads of the workgroup (>= N * P); s_psc (optional): the detection scores by filtered slot, for a sweep that follows in the same kernel.
+__device__ __forceinline__ void se3d_np_prologue(const Se3dDev &D, int f, int tid, float2 *skp, unsigned *s_mgt, int *s_slot, int *s_nv, int nt = 256, float *s_psc = nullptr) {
   const int N = D.d.N, P = D.d.P, H = D.d.H;
   // ---- per-frame workspace reset (assoc, nviews, nhyp, flags) ----
-  for (int i = tid; i < H * N; i += 256) D.assoc[(size_t)f * H * N + i] = -1;
-  for (int h = tid; h < H; h += 256) D.nviews[f * H + h] = 0;
+  for (int i = tid; i < H * N; i += nt) D.assoc[(size_t)f * H * N + i] = -1;
+  for (int h = tid; h < H; h += nt) D.nviews[f * H + h] = 0;
   if (tid == 0) { D.nhyp[f] = 0; D.flags[f] = 0u; }
   // ---- row N: valid-joint counts and masks, one thread per (camera, raw detection) ----
   const int c = tid / P, det = tid - c * P;
@@ -306,10 +307,11 @@ __device__ __forceinline__ void se3d_np_prologue(const Se3dDev &D, int f, int ti
     D.vmask_gt[o] = mgt;
     D.vmask_ge[o] = mge;
     s_mgt[c * P + slot] = mgt;
+    if (s_psc) s_psc[c * P + slot] = rp->score;
   }
   __syncthreads();
   // ---- normalised points of the kept detections into LDS ----
-  for (int idx = tid; idx < N * P * SE3D_NKP; idx += 256) {
+  for (int idx = tid; idx < N * P * SE3D_NKP; idx += nt) {
     const int cd = idx / SE3D_NKP, j = idx - cd * SE3D_NKP;
     const int cc = cd / P, dd = cd - cc * P;
     if (dd >= min(D.nraw[f * N + cc], P)) continue;
@@ -3275,24 +3277,27 @@ __global__ __launch_bounds__(64) void se3d_k_sweep_fused_wave(Se3dDev D) {
 // memory; assoc / nviews / nhyp are written back once at the end.  Same decisions in the same order as se3d_sweep_cost_small +
 // se3d_sweep_assign_wave (S3D:538-673): the association tables of the three launch structures are compared bytewise in
 // tests/test_gpu_stage1.py.
-__global__ __launch_bounds__(64) void se3d_k_sweep_wave_lds(Se3dDev D) {
-  extern __shared__ __align__(16) double s_sw[];
-  const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
-  const int f = blockIdx.x, lane = threadIdx.x;
-  double *W = s_sw;                                   // [H * P] Munkres working matrix
-  double *C = W + (size_t)H * P;                      // [H * P] cost, hypothesis-major like D.C
-  float *psc = reinterpret_cast<float *>(C + (size_t)H * P);     // [N * P] detection scores of the frame
-  int32_t *assoc = reinterpret_cast<int32_t *>(psc + (size_t)N * P);  // [H * N]
-  int *nviews = assoc + (size_t)H * N;                // [H]
-  int *nraw = nviews + H, *nvalid = nraw + N;         // [N] each
-  uint8_t *mask = reinterpret_cast<uint8_t *>(nvalid + N);       // [H * P]
-  for (int i = lane; i < N * P; i += 64) psc[i] = D.pscore[(size_t)f * N * P + i];
-  for (int i = lane; i < H * N; i += 64) assoc[i] = -1;
-  for (int i = lane; i < H; i += 64) nviews[i] = 0;
-  for (int i = lane; i < N; i += 64) { nraw[i] = D.nraw[f * N + i]; nvalid[i] = D.nvalid[f * N + i]; }
-  __syncthreads();
+// LDS working set of the one-wavefront sweep (se3d_k_sweep_wave_lds, and the sweep phase of se3d_k_front_fused)
+struct SweepWaveLds {
+  double *W, *C;        // [H * P] Munkres working matrix; cost, hypothesis-major like D.C
+  float *psc;           // [N * P] detection scores of the frame by filtered slot
+  int32_t *assoc;       // [H * N]
+  int *nviews;          // [H]
+  int *nraw, *nvalid;   // [N] each
+  uint8_t *mask;        // [H * P]
+};
+// The sweep of frame f by one wavefront; tab(a, k, b, q, nd): pair cost of (camera a, filtered slot k) x (camera b, filtered slot q), nd = valid
+// detections of camera b.  L.psc / nraw / nvalid hold the frame's values, assoc = -1 and nviews = 0 on entry; every __syncthreads() below is
+// reached by the one (surviving) wavefront of the workgroup only.
+template <typename Tab>
+__device__ __forceinline__ void se3d_sweep_wave_run(const Se3dDev &D, int f, int lane, const SweepWaveLds &L, Tab tab) {
+  const int N = D.d.N, P = D.d.P, H = D.d.H;
+  double *W = L.W, *C = L.C;
+  float *psc = L.psc;
+  int32_t *assoc = L.assoc;
+  int *nviews = L.nviews, *nraw = L.nraw, *nvalid = L.nvalid;
+  uint8_t *mask = L.mask;
   const double max_epi = D.d.max_epi;
-  const double *tab = D.pair + (size_t)f * np * P * P;
   int nh = 0;   // hypotheses so far: every lane derives the same value from the ballots
   for (int b = 0; b < N; ++b) {
     if (nraw[b] == 0) continue;  // S3D:538-555
@@ -3322,7 +3327,7 @@ __global__ __launch_bounds__(64) void se3d_k_sweep_wave_lds(Se3dDev D) {
         for (int u = 0; u < 8; ++u) {
           c[u] = -1.0; sc[u] = 0.f;
           if (k[u] >= 0) {
-            c[u] = tab[((size_t)se3d_pair_index(a0 + u, b, N) * P + k[u]) * P + q];
+            c[u] = tab(a0 + u, k[u], b, q, nd);
             sc[u] = psc[(size_t)(a0 + u) * P + k[u]];
           }
         }
@@ -3397,8 +3402,128 @@ __global__ __launch_bounds__(64) void se3d_k_sweep_wave_lds(Se3dDev D) {
   for (int i = lane; i < H; i += 64) D.nviews[f * H + i] = nviews[i];
   if (lane == 0) D.nhyp[f] = nh;
 }
+__global__ __launch_bounds__(64) void se3d_k_sweep_wave_lds(Se3dDev D) {
+  extern __shared__ __align__(16) double s_sw[];
+  const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
+  const int f = blockIdx.x, lane = threadIdx.x;
+  SweepWaveLds L;
+  L.W = s_sw;
+  L.C = L.W + (size_t)H * P;
+  L.psc = reinterpret_cast<float *>(L.C + (size_t)H * P);
+  L.assoc = reinterpret_cast<int32_t *>(L.psc + (size_t)N * P);
+  L.nviews = L.assoc + (size_t)H * N;
+  L.nraw = L.nviews + H; L.nvalid = L.nraw + N;
+  L.mask = reinterpret_cast<uint8_t *>(L.nvalid + N);
+  for (int i = lane; i < N * P; i += 64) L.psc[i] = D.pscore[(size_t)f * N * P + i];
+  for (int i = lane; i < H * N; i += 64) L.assoc[i] = -1;
+  for (int i = lane; i < H; i += 64) L.nviews[i] = 0;
+  for (int i = lane; i < N; i += 64) { L.nraw[i] = D.nraw[f * N + i]; L.nvalid[i] = D.nvalid[f * N + i]; }
+  __syncthreads();
+  const double *g = D.pair + (size_t)f * np * P * P;
+  se3d_sweep_wave_run(D, f, lane, L, [=](int a, int k, int b, int q, int) { return g[((size_t)se3d_pair_index(a, b, N) * P + k) * P + q]; });
+}
 static size_t se3d_sweep_wave_lds_bytes(int N, int P, int H) {
   return (size_t)H * P * 16 + (size_t)N * P * 4 + (size_t)H * N * 4 + (size_t)H * 4 + (size_t)N * 8 + (((size_t)H * P + 15) & ~(size_t)15);
+}
+
+// =============================================================================================================
+// Rows N + E + G + M of a frame in ONE kernel (round 4, small rigs: N * P <= 256): se3d_k_normalize_pairs and se3d_k_sweep_wave_lds
+// back to back in one workgroup, with the pair costs of the frame in LDS between them instead of in the [pairs][P][P] table in HBM.
+//   * prologue (se3d_np_prologue): workspace reset, valid-joint masks, slot compaction, normalised points into LDS;
+//   * the valid (det_a, det_b) entries of all camera pairs densely over the NT threads (se3d_pair_cost_lds: the float expressions of every
+//     other pair kernel), stored PACKED — entry (pair, p, q) at cum[pair] + p * n_b + q, cum = the exclusive prefix of n_a * n_b — into an
+//     LDS table of `cap` entries; a frame with more entries keeps its packed table in the frame's slice of D.pair (same indexing, read back
+//     through L2 like the stand-alone sweep does);
+//   * the wavefronts 1 .. NT/64 - 1 exit, wavefront 0 runs the camera sweep (se3d_sweep_wave_run: the decisions of S3D:538-673 in the same
+//     order) against that table.
+// What it saves: the table's write and read (1.6 + 1.8 GB per 98 304 frames at 16cam6p), the sweep's dependent L2 round trips (two batches of
+// pair-table loads per camera step), and two launches per call — at one frame per call (NT = 1024) the three kernels took 62 of the 102 us of
+// stage 1.  dump != 0 (SE3D_FRONT_DUMP=1, tests): the entries are ALSO written to D.pair in the API layout, which is how the table of this
+// kernel is compared bit for bit with the oracle's; without it se3d_get_pair_costs computes the requested block again.
+// =============================================================================================================
+static size_t se3d_front_fused_lds_bytes(int N, int P, int H, int np, int cap) {
+  size_t b = (size_t)N * P * SE3D_NKP * sizeof(float2) + (size_t)N * P * 12 + (size_t)N * 8 + (size_t)(np + 2) * 4;   // points, masks, slots, scores, counts, cum
+  b = (b + 15) & ~(size_t)15;
+  b += (size_t)cap * 8;                                                                                            // packed table
+  b += (size_t)H * P * 16 + (size_t)H * N * 4 + (size_t)H * 4 + (((size_t)H * P + 15) & ~(size_t)15);               // W, C, assoc, nviews, mask
+  return b + 16;
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void se3d_k_front_fused(Se3dDev D, const int2 *__restrict__ pair_ab, int cap, int dump) {
+  extern __shared__ __align__(16) unsigned char ff_smem[];
+  const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float2 *skp = reinterpret_cast<float2 *>(ff_smem);                               // [N * P][17] filtered slot order
+  unsigned *s_mgt = reinterpret_cast<unsigned *>(skp + (size_t)N * P * SE3D_NKP);  // [N * P] by filtered slot
+  int *s_slot = reinterpret_cast<int *>(s_mgt + N * P);                            // [N * P] by raw detection index
+  float *s_psc = reinterpret_cast<float *>(s_slot + N * P);                        // [N * P] by filtered slot
+  int *s_nv = reinterpret_cast<int *>(s_psc + N * P);                              // [N]
+  int *s_nraw = s_nv + N;                                                          // [N]
+  int *s_cum = s_nraw + N;                                                         // [np + 1]
+  double *s_tab = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(s_cum + np + 2) + 15) & ~(uintptr_t)15);   // [cap]
+  SweepWaveLds L;
+  L.W = s_tab + cap;
+  L.C = L.W + (size_t)H * P;
+  L.assoc = reinterpret_cast<int32_t *>(L.C + (size_t)H * P);
+  L.nviews = L.assoc + (size_t)H * N;
+  L.mask = reinterpret_cast<uint8_t *>(L.nviews + H);
+  L.psc = s_psc; L.nraw = s_nraw; L.nvalid = s_nv;
+  __shared__ int s_part[NT / 64];
+  for (int i = tid; i < N; i += NT) s_nraw[i] = D.nraw[f * N + i];
+  for (int i = tid; i < N * P; i += NT) s_psc[i] = 0.f;
+  for (int i = tid; i < H * N; i += NT) L.assoc[i] = -1;
+  for (int i = tid; i < H; i += NT) L.nviews[i] = 0;
+  se3d_np_prologue(D, f, tid, skp, s_mgt, s_slot, s_nv, NT, s_psc);
+  // ---- exclusive prefix of n_a * n_b over the camera pairs ----
+  int carry = 0;
+  for (int base = 0; base < np; base += NT) {
+    const int pr = base + tid;
+    int v = 0;
+    if (pr < np) { const int2 ab = pair_ab[pr]; v = s_nv[ab.x] * s_nv[ab.y]; }
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_part[wave] = inc;
+    __syncthreads();
+    int off = carry, all = 0;
+    for (int w = 0; w < NT / 64; ++w) { if (w < wave) off += s_part[w]; all += s_part[w]; }
+    if (pr < np) s_cum[pr] = off + inc - v;
+    carry += all;
+    __syncthreads();
+  }
+  if (tid == 0) s_cum[np] = carry;
+  __syncthreads();
+  // ---- row E: the valid entries of all camera pairs, densely over the threads, into the packed table ----
+  const int total = s_cum[np];
+  double *gtab = D.pair + (size_t)f * np * P * P;     // the frame's slice of the table: the packed entries of a frame that exceeds `cap`
+  const bool in_lds = total <= cap;
+  for (int e = tid; e < total; e += NT) {
+    int lo = 0, hi = np;  // largest pr with s_cum[pr] <= e
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cum[mid] <= e) lo = mid; else hi = mid; }
+    const int pr = lo;
+    const int2 ab = pair_ab[pr];
+    const int nb = s_nv[ab.y];
+    const int r = e - s_cum[pr];
+    const int p = r / nb, q = r - p * nb;
+    const int ia = ab.x * P + p, ib = ab.y * P + q;
+    const unsigned m = s_mgt[ia] & s_mgt[ib];
+    const double c = se3d_pair_cost_lds(D.F + 9 * (size_t)pr, skp + (size_t)ia * SE3D_NKP, skp + (size_t)ib * SE3D_NKP, m);
+    if (in_lds) s_tab[e] = c;
+    if (!in_lds && !dump) gtab[e] = c;
+    if (dump) gtab[((size_t)pr * P + p) * P + q] = c;   // API layout (then also what the sweep of an over-capacity frame reads)
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (wave != 0) return;   // a barrier below waits for the surviving wavefront only
+  // ---- rows G + M: the camera sweep by wavefront 0 ----
+  if (in_lds) {
+    se3d_sweep_wave_run(D, f, lane, L, [=](int a, int k, int b, int q, int nd) { return s_tab[s_cum[se3d_pair_index(a, b, N)] + k * nd + q]; });
+  } else {   // over capacity (rare): from the frame's slice of D.pair, packed or (dump) in the API layout
+    const double *g = gtab;
+    se3d_sweep_wave_run(D, f, lane, L, [=](int a, int k, int b, int q, int nd) {
+      const int pi = se3d_pair_index(a, b, N);
+      return g[dump ? ((size_t)pi * P + k) * P + q : (size_t)(s_cum[pi] + k * nd + q)];
+    });
+  }
 }
 
 // Self-test of se3d_sqrt_core / se3d_div_core against the IEEE expressions on the device (se3d_selftest_exact_math).
@@ -3522,14 +3647,59 @@ static void se3d_launch_triangulation(const Se3dDev &D, hipStream_t st) {
 // phases (bit mask): 1 = normalise + pair-cost table, 8 = camera sweep, 2 = triangulation, 4 = post-processing + duplicate merge
 // st_hi / ev_hi: optional high-priority stream (+ two events) for the per-camera sweep launches of large problems: 2 x N tiny dependent
 // launches that otherwise queue behind the millions of workgroups of other contexts' pair kernels.
+extern "C" void se3d_launch_normalize_keep(const Se3dDev &D, hipStream_t st) {   // normalised points into D.kp, association workspace untouched
+  hipLaunchKernelGGL(se3d_k_normalize, dim3(D.d.N, D.d.B), dim3(256), 0, st, D, 3);
+}
 extern "C" void se3d_launch_pair_block(const Se3dDev &D, const int2 *d_ab_one, int frame, hipStream_t st) {   // se3d_get_pair_costs under column chunks
   hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((D.d.P + RB_ROWS - 1) / RB_ROWS, 1, 1), dim3(256), 0, st, D, d_ab_one, 0, 0, frame);
 }
 
-extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, bool tiled, int phases,
-                                   hipStream_t st_hi, hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk) {
+// The fused front kernel (se3d_k_front_fused) for this launch: threads per workgroup (0: the separate kernels), LDS table capacity, dump flag.
+//   SE3D_FRONT unset: small batches only (the reference's one frame per call, NT = 1024: stage 1 of a frame 102 -> ?? us, profiles/r4);
+//   SE3D_FRONT=1: every eligible launch (NT = 256 for large batches: A/B evidence in profiles/r4/README.md); SE3D_FRONT=0: never.
+//   SE3D_FRONT_CAP = entries of the LDS table (default: what keeps three workgroups of 256 threads on a CU / what 64 KB hold at NT = 1024),
+//   SE3D_FRONT_NT = 256 | 512 | 1024, SE3D_FRONT_DUMP=1: the table also goes to D.pair in the API layout (tests).
+// Eligible: every phase of the front in this launch, no A/B switch of the separate kernels set, the one-wavefront LDS sweep's limits.
+static int se3d_front_plan(const Se3dDev &D, bool tiled, bool chunked, int phases, int *cap_out, int *dump_out) {
+  const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
+  const char *e_front = getenv("SE3D_FRONT");
+  if (e_front && atoi(e_front) == 0) return 0;
+  if (tiled || chunked || (phases & 9) != 9) return 0;
+  if (getenv("SE3D_PAIRS") || getenv("SE3D_NP_LINES") || getenv("SE3D_NP_TILE") || getenv("SE3D_SWEEP_WAVE") || getenv("SE3D_SWEEP_FUSED_MAX")) return 0;
+  if (N * P > NP_MAX_DETS || np > 2048 || H > 64 || P > 64 || N > 64 || se3d_sweep_wave_lds_bytes(N, P, H) > 16 * 1024) return 0;
+  const bool small_batch = (size_t)B * np * P * P <= ((size_t)1 << 16) && !getenv("SE3D_NO_SMALL_BATCH");
+  const bool forced = e_front && atoi(e_front) == 1;
+  if (!small_batch && !forced) return 0;
+  int nt = small_batch ? 1024 : 256;
+  if (const char *e = getenv("SE3D_FRONT_NT")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) nt = v; }
+  const size_t fixed = se3d_front_fused_lds_bytes(N, P, H, np, 0);
+  const size_t budget = nt == 256 ? (size_t)53 * 1024 : (size_t)64 * 1024;
+  if (fixed + 8 * 64 > budget) return 0;
+  int cap = (int)std::min((size_t)np * P * P, (budget - fixed) / 8);
+  if (const char *e = getenv("SE3D_FRONT_CAP")) cap = std::max(0, std::min(atoi(e), (int)(((size_t)64 * 1024 - fixed) / 8)));
+  *cap_out = cap;
+  *dump_out = getenv("SE3D_FRONT_DUMP") ? atoi(getenv("SE3D_FRONT_DUMP")) : 0;
+  return nt;
+}
+
+// Returns a bit mask: 1 = phase 1 ran without materialising the [pairs][P][P] table in D.pair (se3d_get_pair_costs computes blocks on demand).
+extern "C" int se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, bool tiled, int phases,
+                                  hipStream_t st_hi, hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk) {
   const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H;
   const bool chunked = D.d.pair_chunks > 0 && plan && plan->m == D.d.pair_chunks;
+  int info = 0;
+  int ff_cap = 0, ff_dump = 0;
+  const int ff_nt = se3d_front_plan(D, tiled, chunked, phases, &ff_cap, &ff_dump);
+  if (ff_nt) {   // rows N + E + G + M in one kernel; the events of the kernel groups: "normalize" empty, "epipolar_pairs" = this kernel, "sweep" empty
+    if (ev) { (void)hipEventRecord(ev[0], st); (void)hipEventRecord(ev[1], st); }
+    const size_t lds = se3d_front_fused_lds_bytes(N, P, H, D.d.npairs, ff_cap);
+    if (ff_nt == 1024) hipLaunchKernelGGL((se3d_k_front_fused<1024>), dim3(B), dim3(1024), lds, st, D, pair_ab, ff_cap, ff_dump);
+    else if (ff_nt == 512) hipLaunchKernelGGL((se3d_k_front_fused<512>), dim3(B), dim3(512), lds, st, D, pair_ab, ff_cap, ff_dump);
+    else hipLaunchKernelGGL((se3d_k_front_fused<256>), dim3(B), dim3(256), lds, st, D, pair_ab, ff_cap, ff_dump);
+    if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
+    if (!ff_dump) info |= 1;
+    phases &= ~9;
+  }
   if ((phases & 1) && chunked) {   // column chunks: phase 1 is the normalisation only, the pair kernel runs chunk by chunk inside phase 8
     if (ev) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D, 1);
@@ -3654,6 +3824,7 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStr
     else hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
   }
   if (ev && (phases & 4)) (void)hipEventRecord(ev[5], st);
+  return info;
 }
 
 // =============================================================================================================

@@ -5,7 +5,7 @@ What must hold (round 4: no exclusion set for stage-1 positions and scores any m
 the library itself with the reference's float32 arithmetic, csrc/se3d_exact32.h):
   * stage-1 index results (flags, hypothesis counts, association tables, published persons, sets of valid joints): identical in every frame
     (frames on which the library raised FLAG_HYP_OVERFLOW are counted; the oracle, run with room to spare, must have needed more);
-  * stage-1 positions < 1 mm and scores rtol 2e-5 on EVERY valid joint;
+  * stage-1 positions < 1 mm and scores bit-equal (SCORE_RTOL = 0) on EVERY valid joint;
   * the library's own flag is checked against the inputs: every published joint whose DLT systems have an input-derived kappa >=
     DLT_KAPPA_MAX (tests/parity.py, fp64 singular values) must be among the joints the library sent through its float32 second pass
     (se3d_get_exact_list) — counted as `ill_not_listed`, asserted zero for unmerged persons;

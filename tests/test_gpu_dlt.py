@@ -1,5 +1,5 @@
 """GPU (-m gpu): config 2 of the benchmark — se3d_triangulate_assoc (rows N, T, P, O, U with the association given) through
-the C-ABI against the oracle's se3d_oracle_triangulate_assoc on the same inputs: joints < 1 mm, scores rtol 2e-5, UT covariance within
+the C-ABI against the oracle's se3d_oracle_triangulate_assoc on the same inputs: joints < 1 mm, scores bit-equal, UT covariance within
 the stage-1 tolerance, the same joints (un)triangulated."""
 import os
 import sys

@@ -29,7 +29,7 @@ def test_random_scenes_match_the_oracle_on_every_joint(oracle, seed, pose_method
     viol = rep.pop("violations")
     print(json.dumps(rep))
     assert rep["frames"] == TRIALS * 36 and rep["joints"] > 50_000
-    # stage 1: every valid joint (positions < 1 mm, scores rtol 2e-5, covariances inside parity.cov_tolerance); nothing excluded
+    # stage 1: every valid joint (positions < 1 mm, scores bit-equal, covariances inside parity.cov_tolerance); nothing excluded
     assert rep["joints_over_1mm"] == 0 and rep["scores_over_rtol"] == 0 and rep["cov_over_tol"] == 0, viol[:5]
     assert rep["joints_excluded"] == 0
     # the library's conditioning flag covers what the inputs say is ill-conditioned

@@ -1,13 +1,15 @@
 #!/bin/bash
 # Blind check of the randomised parity sweep (GPU box): seeds never run before the criteria were frozen (commit 929e612), reported unedited.
-#   bash tools/fuzz_blind.sh [out]      100 runs: 70 x default, 10 x h36m, 10 x norm_height (40 scenes each), 10 x large rigs (20 scenes)
+#   bash tools/fuzz_blind.sh [out] [base]   100 runs from seed base + 1 (default base 2000; 3000: the second batch, after the scores became
+#   bit-equal): 70 x default, 10 x h36m, 10 x norm_height (40 scenes each), 10 x large rigs (20 scenes)
 OUT=${1:-gpurun_out/fuzz_blind.log}
+B=${2:-2000}
 mkdir -p "$(dirname "$OUT")"
 : > "$OUT"
-for s in $(seq 2001 2070); do timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
-for s in $(seq 2071 2080); do FUZZ_POSE=h36m timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
-for s in $(seq 2081 2090); do FUZZ_NORM_HEIGHT=1 timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
-for s in $(seq 2091 2100); do FUZZ_LARGE=1 timeout 600 python tools/fuzz_parity.py $s 20 2>> "$OUT.err" | tail -1 >> "$OUT"; done
+for s in $(seq $((B+1)) $((B+70))); do timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
+for s in $(seq $((B+71)) $((B+80))); do FUZZ_POSE=h36m timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
+for s in $(seq $((B+81)) $((B+90))); do FUZZ_NORM_HEIGHT=1 timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
+for s in $(seq $((B+91)) $((B+100))); do FUZZ_LARGE=1 timeout 600 python tools/fuzz_parity.py $s 20 2>> "$OUT.err" | tail -1 >> "$OUT"; done
 python3 - "$OUT" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
