@@ -242,8 +242,21 @@ __global__ __launch_bounds__(256) void se3d_k_pairs_packed(Se3dDev D, const int2
 // frame's detections live only in LDS (float2 x, y per (camera, slot, joint): 35 KB at most) — the kp / kcov copies of round 1 (two
 // float4 per joint: 428 MB of stores and 642 MB of loads per 8192-frame launch at 16 x 6) are gone; the triangulation kernels read the
 // caller's raw Person2D payload themselves.  Same float expressions as se3d_k_normalize / se3d_pair_cost -> identical table.
+// acc / n for a small integer n (the joint count 1..17 of a pair entry, S3D:365; the view counts of the sweep, S3D:616-626), correctly
+// rounded (= the IEEE quotient) in three fp64 operations instead of the ~35-instruction IEEE division sequence: with y = RN(1 / n) = (1 + d) / n,
+// q0 = RN(acc y), r = acc - n q0 (exact in an FMA: q0 is within 1.5 ulp of acc / n) the exact value of q0 + r y is acc / n + d (acc / n - q0), i.e.
+// within 1.5 x 2^-53 ulp of the quotient, while acc / n keeps a distance of at least ulp / (2 n) from every rounding boundary (acc - n m is a
+// non-zero multiple of ulp / 2 for a midpoint m): the final rounding is the quotient's for every n < 2^50 (Markstein 1990; Thm. 8.5 in Muller
+// et al., "Handbook of Floating-Point Arithmetic"); tests/test_markstein64.py checks it against IEEE division on the CPU.
+__device__ __forceinline__ double se3d_div_count(double acc, int n, double inv_n) {
+  const double q0 = acc * inv_n;
+  const double r = __fma_rn(-(double)n, q0, acc);
+  return __fma_rn(r, inv_n, q0);
+}
+
 #define NP_MAX_DETS 256
-__device__ __forceinline__ double se3d_pair_cost_lds(const float *__restrict__ F, const float2 *__restrict__ ka, const float2 *__restrict__ kb, unsigned m) {
+// inv[n] = RN(1 / n), n = 1 .. 17 (LDS): the entry's cost / n by se3d_div_count
+__device__ __forceinline__ double se3d_pair_cost_lds(const float *__restrict__ F, const float2 *__restrict__ ka, const float2 *__restrict__ kb, unsigned m, const double *inv) {
   double cost = 0.0;
   int n = 0;
   const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
@@ -263,7 +276,7 @@ __device__ __forceinline__ double se3d_pair_cost_lds(const float *__restrict__ F
       ++n;
     }
   }
-  return n > 0 ? cost / n : -1.0;
+  return n > 0 ? se3d_div_count(cost, n, inv[n]) : -1.0;
 }
 
 // Rows N of a frame for the small-rig kernels below: per-frame workspace reset, valid-joint masks, order-preserving slot compaction, the
@@ -339,6 +352,8 @@ __global__ __launch_bounds__(256) void se3d_k_normalize_pairs(Se3dDev D, const i
   int *s_nv = s_slot + N * P;                                              // [N]
   int *s_cum = s_nv + N;                                                   // [np + 1]
   __shared__ int s_part[4];
+  __shared__ double s_inv[SE3D_NKP + 1];   // RN(1 / n) for the joint count of an entry (visible after the prologue's barriers)
+  if (tid <= SE3D_NKP) s_inv[tid] = tid ? 1.0 / (double)tid : 0.0;
   se3d_np_prologue(D, f, tid, skp, s_mgt, s_slot, s_nv);
   // ---- exclusive prefix of n_a * n_b over the camera pairs ----
   int carry = 0;
@@ -370,7 +385,7 @@ __global__ __launch_bounds__(256) void se3d_k_normalize_pairs(Se3dDev D, const i
     const int p = r / nb, q = r - p * nb;
     const int ia = ab.x * P + p, ib = ab.y * P + q;
     const unsigned m = s_mgt[ia] & s_mgt[ib];
-    D.pair[(((size_t)f * np + pr) * P + p) * P + q] = se3d_pair_cost_lds(D.F + 9 * (size_t)pr, skp + (size_t)ia * SE3D_NKP, skp + (size_t)ib * SE3D_NKP, m);
+    D.pair[(((size_t)f * np + pr) * P + p) * P + q] = se3d_pair_cost_lds(D.F + 9 * (size_t)pr, skp + (size_t)ia * SE3D_NKP, skp + (size_t)ib * SE3D_NKP, m, s_inv);
   }
 }
 
@@ -881,16 +896,6 @@ __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float 
   // (se3d_rows_compute_slow) selects by the validity masks and never divides by this norm for a masked joint's contribution.
   if (!valid) { o.lx = 0.f; o.ly = 0.f; o.lz = 0.f; o.x = 0.f; o.y = 0.f; o.nrm = 1.f; o.rcp = 1.f; }
   return o;
-}
-
-// acc / n for the joint count n = 1..17 of a pair entry, correctly rounded (= the IEEE quotient of calcCost's `cost / n`) in three fp64
-// operations instead of the ~15-instruction IEEE division sequence: with y = RN(1 / n), q0 = RN(acc y), r = acc - n q0 (exact in an FMA)
-// the corrected q0 + r y rounds to RN(acc / n) for every divisor whose significand is not all ones (Markstein 1990, Thm. 8.5 in Muller et al.,
-// "Handbook of Floating-Point Arithmetic"); tests/test_markstein64.py checks 17 x 2e4 accumulators against IEEE division on the CPU.
-__device__ __forceinline__ double se3d_div_count(double acc, int n, double inv_n) {
-  const double q0 = acc * inv_n;
-  const double r = __fma_rn(-(double)n, q0, acc);
-  return __fma_rn(r, inv_n, q0);
 }
 
 template <int JN>
@@ -3277,6 +3282,19 @@ __global__ __launch_bounds__(64) void se3d_k_sweep_fused_wave(Se3dDev D) {
 // memory; assoc / nviews / nhyp are written back once at the end.  Same decisions in the same order as se3d_sweep_cost_small +
 // se3d_sweep_assign_wave (S3D:538-673): the association tables of the three launch structures are compared bytewise in
 // tests/test_gpu_stage1.py.
+#ifdef SE3D_LM_STAMPS   // diagnostic build only (make diag, tools/ff_stamps.py): cycle stamps of se3d_k_front_fused and the one-wavefront sweep
+__device__ unsigned long long g_ff_stamps[16];
+#define FF_STAMP_INIT unsigned long long ff_prev_ = __builtin_readcyclecounter();
+#define FF_STAMP(idx) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_ff_stamps[idx], now_ - ff_prev_); ff_prev_ = now_; }
+extern "C" void se3d_diag_ff_stamps(unsigned long long *out16, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ff_stamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ff_stamps), z, sizeof(z)); }
+}
+#else
+#define FF_STAMP_INIT
+#define FF_STAMP(idx)
+#endif
 // LDS working set of the one-wavefront sweep (se3d_k_sweep_wave_lds, and the sweep phase of se3d_k_front_fused)
 struct SweepWaveLds {
   double *W, *C;        // [H * P] Munkres working matrix; cost, hypothesis-major like D.C
@@ -3285,6 +3303,7 @@ struct SweepWaveLds {
   int *nviews;          // [H]
   int *nraw, *nvalid;   // [N] each
   uint8_t *mask;        // [H * P]
+  double *inv;          // [2 N + 1] RN(1 / k): the quotients by view counts (se3d_div_count and 1 / n_obs, 1 / (2 n_obs))
 };
 // The sweep of frame f by one wavefront; tab(a, k, b, q, nd): pair cost of (camera a, filtered slot k) x (camera b, filtered slot q), nd = valid
 // detections of camera b.  L.psc / nraw / nvalid hold the frame's values, assoc = -1 and nviews = 0 on entry; every __syncthreads() below is
@@ -3299,7 +3318,9 @@ __device__ __forceinline__ void se3d_sweep_wave_run(const Se3dDev &D, int f, int
   uint8_t *mask = L.mask;
   const double max_epi = D.d.max_epi;
   int nh = 0;   // hypotheses so far: every lane derives the same value from the ballots
+  FF_STAMP_INIT
   for (int b = 0; b < N; ++b) {
+    FF_STAMP(7)   // loop overhead / seeding
     if (nraw[b] == 0) continue;  // S3D:538-555
     const int nd = nvalid[b];
     if (nh == 0) {  // seeding (S3D:565-586)
@@ -3314,7 +3335,7 @@ __device__ __forceinline__ void se3d_sweep_wave_run(const Se3dDev &D, int f, int
       const int h = idx % nh, q = idx / nh;
       const int32_t *arow = assoc + (size_t)h * N;
       const int n_obs = nviews[h];
-      const double tolerance = 1.0 - 1.0 / (2 * n_obs), veto_delta = 1.0 / n_obs;
+      const double tolerance = 1.0 - L.inv[2 * n_obs], veto_delta = L.inv[n_obs];   // 1.0 / (2 * n_obs), 1.0 / n_obs (S3D:616-626): correctly rounded reciprocals
       double total = 0.0;
       int nused = 0, cnt = 0;
       for (int a0 = 0; a0 < b; a0 += 8) {  // 8 independent pair-table loads in flight, ordered accumulation
@@ -3347,12 +3368,13 @@ __device__ __forceinline__ void se3d_sweep_wave_run(const Se3dDev &D, int f, int
         veto = tmp > tolerance;
       }
       double Cv;
-      if (nused > 0) Cv = total / nused;
+      if (nused > 0) Cv = se3d_div_count(total, nused, L.inv[nused]);   // total / nused
       else { Cv = MAX_COSTS; veto = true; }
       C[h + (size_t)H * q] = Cv;
       mask[h + (size_t)H * q] = (!veto && Cv < max_epi) ? 1 : 0;
     }
     __syncthreads();
+    FF_STAMP(4)   // cost + veto mask
     // ---- assignment, attach / spawn: se3d_sweep_assign_wave ----
     int cnt = 0, assign = -1;
     if (lane < nh)
@@ -3367,6 +3389,7 @@ __device__ __forceinline__ void se3d_sweep_wave_run(const Se3dDev &D, int f, int
       const int rc = se3d_munkres_wave(W, nh, nh, nd, lane, assign);
       if (rc != 0 && lane == 0) atomicOr(&D.flags[f], SE3D_FLAG_ASSIGNMENT_FAILED);
     }
+    FF_STAMP(5)   // scans + Hungarian
     bool sp = false;
     const int det = (lane < nh) ? assign : -1;
     if (det >= 0) {
@@ -3397,6 +3420,7 @@ __device__ __forceinline__ void se3d_sweep_wave_run(const Se3dDev &D, int f, int
     if (nn > H && lane == 0) atomicOr(&D.flags[f], SE3D_FLAG_HYP_OVERFLOW);
     nh = min(nn, H);
     __syncthreads();
+    FF_STAMP(6)   // attach / spawn
   }
   for (int i = lane; i < H * N; i += 64) D.assoc[(size_t)f * H * N + i] = assoc[i];
   for (int i = lane; i < H; i += 64) D.nviews[f * H + i] = nviews[i];
@@ -3414,6 +3438,8 @@ __global__ __launch_bounds__(64) void se3d_k_sweep_wave_lds(Se3dDev D) {
   L.nviews = L.assoc + (size_t)H * N;
   L.nraw = L.nviews + H; L.nvalid = L.nraw + N;
   L.mask = reinterpret_cast<uint8_t *>(L.nvalid + N);
+  L.inv = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(L.mask + (size_t)H * P) + 15) & ~(uintptr_t)15);
+  for (int i = lane; i < 2 * N + 1; i += 64) L.inv[i] = i ? 1.0 / (double)i : 0.0;
   for (int i = lane; i < N * P; i += 64) L.psc[i] = D.pscore[(size_t)f * N * P + i];
   for (int i = lane; i < H * N; i += 64) L.assoc[i] = -1;
   for (int i = lane; i < H; i += 64) L.nviews[i] = 0;
@@ -3423,7 +3449,7 @@ __global__ __launch_bounds__(64) void se3d_k_sweep_wave_lds(Se3dDev D) {
   se3d_sweep_wave_run(D, f, lane, L, [=](int a, int k, int b, int q, int) { return g[((size_t)se3d_pair_index(a, b, N) * P + k) * P + q]; });
 }
 static size_t se3d_sweep_wave_lds_bytes(int N, int P, int H) {
-  return (size_t)H * P * 16 + (size_t)N * P * 4 + (size_t)H * N * 4 + (size_t)H * 4 + (size_t)N * 8 + (((size_t)H * P + 15) & ~(size_t)15);
+  return (size_t)H * P * 16 + (size_t)N * P * 4 + (size_t)H * N * 4 + (size_t)H * 4 + (size_t)N * 8 + (((size_t)H * P + 15) & ~(size_t)15) + 16 + (size_t)(2 * N + 1) * 8;
 }
 
 // =============================================================================================================
@@ -3446,6 +3472,7 @@ static size_t se3d_front_fused_lds_bytes(int N, int P, int H, int np, int cap) {
   b = (b + 15) & ~(size_t)15;
   b += (size_t)cap * 8;                                                                                            // packed table
   b += (size_t)H * P * 16 + (size_t)H * N * 4 + (size_t)H * 4 + (((size_t)H * P + 15) & ~(size_t)15);               // W, C, assoc, nviews, mask
+  b += 16 + (size_t)(2 * N + 1) * 8;                                                                              // reciprocals of the view counts
   return b + 16;
 }
 template <int NT>
@@ -3467,13 +3494,19 @@ __global__ __launch_bounds__(NT) void se3d_k_front_fused(Se3dDev D, const int2 *
   L.assoc = reinterpret_cast<int32_t *>(L.C + (size_t)H * P);
   L.nviews = L.assoc + (size_t)H * N;
   L.mask = reinterpret_cast<uint8_t *>(L.nviews + H);
+  L.inv = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(L.mask + (size_t)H * P) + 15) & ~(uintptr_t)15);
   L.psc = s_psc; L.nraw = s_nraw; L.nvalid = s_nv;
   __shared__ int s_part[NT / 64];
+  __shared__ double s_inv[SE3D_NKP + 1];   // RN(1 / n) for the joint count of an entry
+  if (tid <= SE3D_NKP) s_inv[tid] = tid ? 1.0 / (double)tid : 0.0;
+  for (int i = tid; i < 2 * N + 1; i += NT) L.inv[i] = i ? 1.0 / (double)i : 0.0;
   for (int i = tid; i < N; i += NT) s_nraw[i] = D.nraw[f * N + i];
   for (int i = tid; i < N * P; i += NT) s_psc[i] = 0.f;
   for (int i = tid; i < H * N; i += NT) L.assoc[i] = -1;
   for (int i = tid; i < H; i += NT) L.nviews[i] = 0;
+  FF_STAMP_INIT
   se3d_np_prologue(D, f, tid, skp, s_mgt, s_slot, s_nv, NT, s_psc);
+  FF_STAMP(0)   // prologue
   // ---- exclusive prefix of n_a * n_b over the camera pairs ----
   int carry = 0;
   for (int base = 0; base < np; base += NT) {
@@ -3492,6 +3525,7 @@ __global__ __launch_bounds__(NT) void se3d_k_front_fused(Se3dDev D, const int2 *
   }
   if (tid == 0) s_cum[np] = carry;
   __syncthreads();
+  FF_STAMP(1)   // prefix
   // ---- row E: the valid entries of all camera pairs, densely over the threads, into the packed table ----
   const int total = s_cum[np];
   double *gtab = D.pair + (size_t)f * np * P * P;     // the frame's slice of the table: the packed entries of a frame that exceeds `cap`
@@ -3506,13 +3540,14 @@ __global__ __launch_bounds__(NT) void se3d_k_front_fused(Se3dDev D, const int2 *
     const int p = r / nb, q = r - p * nb;
     const int ia = ab.x * P + p, ib = ab.y * P + q;
     const unsigned m = s_mgt[ia] & s_mgt[ib];
-    const double c = se3d_pair_cost_lds(D.F + 9 * (size_t)pr, skp + (size_t)ia * SE3D_NKP, skp + (size_t)ib * SE3D_NKP, m);
+    const double c = se3d_pair_cost_lds(D.F + 9 * (size_t)pr, skp + (size_t)ia * SE3D_NKP, skp + (size_t)ib * SE3D_NKP, m, s_inv);
     if (in_lds) s_tab[e] = c;
     if (!in_lds && !dump) gtab[e] = c;
     if (dump) gtab[((size_t)pr * P + p) * P + q] = c;   // API layout (then also what the sweep of an over-capacity frame reads)
   }
   __threadfence_block();
   __syncthreads();
+  FF_STAMP(2)   // pair costs
   if (wave != 0) return;   // a barrier below waits for the surviving wavefront only
   // ---- rows G + M: the camera sweep by wavefront 0 ----
   if (in_lds) {
@@ -3524,6 +3559,7 @@ __global__ __launch_bounds__(NT) void se3d_k_front_fused(Se3dDev D, const int2 *
       return g[dump ? ((size_t)pi * P + k) * P + q : (size_t)(s_cum[pi] + k * nd + q)];
     });
   }
+  FF_STAMP(3)   // sweep
 }
 
 // Self-test of se3d_sqrt_core / se3d_div_core against the IEEE expressions on the device (se3d_selftest_exact_math).
@@ -3655,21 +3691,21 @@ extern "C" void se3d_launch_pair_block(const Se3dDev &D, const int2 *d_ab_one, i
 }
 
 // The fused front kernel (se3d_k_front_fused) for this launch: threads per workgroup (0: the separate kernels), LDS table capacity, dump flag.
-//   SE3D_FRONT unset: small batches only (the reference's one frame per call, NT = 1024: stage 1 of a frame 102 -> ?? us, profiles/r4);
-//   SE3D_FRONT=1: every eligible launch (NT = 256 for large batches: A/B evidence in profiles/r4/README.md); SE3D_FRONT=0: never.
-//   SE3D_FRONT_CAP = entries of the LDS table (default: what keeps three workgroups of 256 threads on a CU / what 64 KB hold at NT = 1024),
-//   SE3D_FRONT_NT = 256 | 512 | 1024, SE3D_FRONT_DUMP=1: the table also goes to D.pair in the API layout (tests).
+// An A/B variant that did NOT pay (profiles/r4/README.md): SE3D_FRONT=1 selects it on every eligible launch (NT = 1024 for small batches, 256
+// otherwise; SE3D_FRONT_NT = 256 | 512 | 1024), SE3D_FRONT_CAP = entries of the LDS table (default: what keeps three workgroups of 256 threads
+// on a CU / what 64 KB hold at NT = 1024), SE3D_FRONT_DUMP=1: the table also goes to D.pair in the API layout (tests).  One frame per call:
+// 63 us against 7.8 + 13.5 + 40.2 us of the three kernels — cycle stamps (tools/ff_stamps.py): prologue 24 k, pair costs 31 k on ONE CU, and the
+// sweep 92 k cycles even with the costs in LDS: it is the wavefront's own instruction chain (cost + veto 41 k, scans + Hungarian 29 k, attach /
+// spawn 14 k), not the table reads, that takes the time.  On the large batch the 38-us sweep phase of ONE wavefront holds a third of the CU's LDS.
 // Eligible: every phase of the front in this launch, no A/B switch of the separate kernels set, the one-wavefront LDS sweep's limits.
 static int se3d_front_plan(const Se3dDev &D, bool tiled, bool chunked, int phases, int *cap_out, int *dump_out) {
   const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
   const char *e_front = getenv("SE3D_FRONT");
-  if (e_front && atoi(e_front) == 0) return 0;
   if (tiled || chunked || (phases & 9) != 9) return 0;
   if (getenv("SE3D_PAIRS") || getenv("SE3D_NP_LINES") || getenv("SE3D_NP_TILE") || getenv("SE3D_SWEEP_WAVE") || getenv("SE3D_SWEEP_FUSED_MAX")) return 0;
   if (N * P > NP_MAX_DETS || np > 2048 || H > 64 || P > 64 || N > 64 || se3d_sweep_wave_lds_bytes(N, P, H) > 16 * 1024) return 0;
   const bool small_batch = (size_t)B * np * P * P <= ((size_t)1 << 16) && !getenv("SE3D_NO_SMALL_BATCH");
-  const bool forced = e_front && atoi(e_front) == 1;
-  if (!small_batch && !forced) return 0;
+  if (!(e_front && atoi(e_front) == 1)) return 0;
   int nt = small_batch ? 1024 : 256;
   if (const char *e = getenv("SE3D_FRONT_NT")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) nt = v; }
   const size_t fixed = se3d_front_fused_lds_bytes(N, P, H, np, 0);

@@ -45,8 +45,8 @@ def test_graph_replay_equals_direct_launches(extr_rig, monkeypatch):
     monkeypatch.delenv("SE3D_REFINE_WALK")
     for a, b in zip(got, switched):
         assert a[:6] == b[:6]                      # stage 1 bytewise (post-processing forms agree bytewise), ids / counts equal
-    # the fused front kernel (normalise + pair costs + sweep, the default at one frame per call) against the separate kernels: same bytes
-    monkeypatch.setenv("SE3D_FRONT", "0")
+    # the fused front kernel (normalise + pair costs + sweep in one launch; A/B evidence, not the default) against the separate kernels: same bytes
+    monkeypatch.setenv("SE3D_FRONT", "1")
     assert _run(node, frames) == got
     monkeypatch.delenv("SE3D_FRONT")
     # kernel timing on: the calls launch directly (events between the kernels); off again: the graphs are still valid

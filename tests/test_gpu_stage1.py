@@ -87,13 +87,12 @@ def test_sweep_variants_agree_exactly(monkeypatch, rig_name, persons, max_det, m
     frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=persons, n_frames=8, seed=77, pixel_noise=4.0, low_score_frac=0.15, p_miss=0.1,
                                                        spacing=0.7, min_coverage=4 if rig_name == "extr16" else 6))
     res = {}
-    # front*: normalisation + pair costs + sweep in one kernel (se3d_k_front_fused; N * P <= 256), the frame's pair costs packed in LDS — or, over
+    # front*: normalisation + pair costs + sweep in one kernel (se3d_k_front_fused, A/B evidence; N * P <= 256), the frame's pair costs packed in LDS — or, over
     # the table's capacity (cap0: always), in the frame's slice of the global table, packed or (dump) in the API layout
     for name, env in (("steps", {"SE3D_SWEEP_FUSED_MAX": "0", "SE3D_SWEEP_WAVE": "0"}), ("fused256", {"SE3D_SWEEP_FUSED_MAX": "100000", "SE3D_SWEEP_WAVE": "0"}),
                       ("wave", {"SE3D_SWEEP_WAVE": "1"}), ("wave_global", {"SE3D_SWEEP_WAVE": "2"}), ("default", {}),
                       ("front1024", {"SE3D_FRONT": "1", "SE3D_FRONT_NT": "1024"}), ("front256", {"SE3D_FRONT": "1", "SE3D_FRONT_NT": "256"}),
-                      ("front_cap0", {"SE3D_FRONT": "1", "SE3D_FRONT_CAP": "0"}), ("front_cap0_dump", {"SE3D_FRONT": "1", "SE3D_FRONT_CAP": "0", "SE3D_FRONT_DUMP": "1"}),
-                      ("front_off", {"SE3D_FRONT": "0"})):
+                      ("front_cap0", {"SE3D_FRONT": "1", "SE3D_FRONT_CAP": "0"}), ("front_cap0_dump", {"SE3D_FRONT": "1", "SE3D_FRONT_CAP": "0", "SE3D_FRONT_DUMP": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         node = _node(rig, max_frames=8, max_det_per_cam=max_det, max_hyp=max_hyp)
@@ -191,17 +190,16 @@ def _pair_costs(node, frame_idx, a, b):
 
 @pytest.mark.parametrize("mode", ["flat", "tiled", "rows", "fused", "lines", "tile22", "small_batch", "front_dump", "front_on_demand", "front256_dump"])
 def test_pair_cost_table_is_bit_exact(extr_rig, oracle, demo_params, mode, monkeypatch):
-    if mode == "small_batch":    # <= 65 536 table entries per launch without the fused front kernel: normalize + flat kernel
+    if mode == "small_batch":    # the library's own choice for <= 65 536 table entries per launch: normalize + flat kernel
         monkeypatch.delenv("SE3D_PAIRS", raising=False)
         monkeypatch.delenv("SE3D_NO_SMALL_BATCH", raising=False)
-        monkeypatch.setenv("SE3D_FRONT", "0")
-    elif mode.startswith("front"):   # the library's own choice for small batches (round 4): se3d_k_front_fused, the frame's pair costs in LDS
+    elif mode.startswith("front"):   # se3d_k_front_fused (round 4, A/B evidence — not the default): the frame's pair costs in LDS, 1024 threads per frame
         monkeypatch.delenv("SE3D_PAIRS", raising=False)
         monkeypatch.delenv("SE3D_NO_SMALL_BATCH", raising=False)
+        monkeypatch.setenv("SE3D_FRONT", "1")
         if mode.endswith("_dump"):   # the kernel's own entries, also written to the API table; without: se3d_get_pair_costs computes the block on demand
             monkeypatch.setenv("SE3D_FRONT_DUMP", "1")
-        if mode.startswith("front256"):   # the form for large batches (A/B): 256 threads per frame
-            monkeypatch.setenv("SE3D_FRONT", "1")
+        if mode.startswith("front256"):   # the form for large batches: 256 threads per frame
             monkeypatch.setenv("SE3D_NO_SMALL_BATCH", "1")
     elif mode in ("fused", "lines") or mode.startswith("tile"):
         monkeypatch.delenv("SE3D_PAIRS", raising=False)
