@@ -282,7 +282,9 @@ int se3d_hungarian(se3d_ctx *ctx, int32_t *assignment, double *cost, const doubl
 int se3d_get_pair_costs(se3d_ctx *ctx, int32_t frame, int32_t cam_a, int32_t cam_b, double *out, int32_t *n_a, int32_t *n_b);
 /* Large rigs keep camera-column chunks of the pair table instead of the whole (se3d_get_pair_chunks > 0): there se3d_get_pair_costs is not a
  * plain read — it RECOMPUTES the block with the pass's kernel into scratch of the context (pair slot 0 of the frame, first element of the cost
- * matrix), which the next se3d_run_stage1 overwrites anyway.  In both modes entries outside [0, n_a) x [0, n_b) are undefined. */
+ * matrix), which the next se3d_run_stage1 overwrites anyway.  The same holds after a pass of the fused front kernel (SE3D_FRONT=1, an A/B
+ * variant: pair costs in LDS only; the normalised points are formed again first, the association workspace is left alone).  In every mode
+ * entries outside [0, n_a) x [0, n_b) are undefined. */
 int se3d_get_pair_chunks(se3d_ctx *ctx);
 
 /* --- diagnostic accessor: the FUSION_BODY_PARTS constants compiled into the kernels (fusion_body_parts.h:3-24, 33): indices22 = the joint
