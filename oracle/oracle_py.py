@@ -259,6 +259,29 @@ class PosePrior:
             raise RuntimeError("se3d_oracle_pp_step failed: %d" % rc)
         return res
 
+    def last_det_ids(self):
+        """Track id every detection of the last step was associated with / created (test bookkeeping, PP:570-580)."""
+        n = lib().se3d_oracle_pp_last_det_ids(C.c_void_p(self._h), None, 0)
+        ids = np.zeros(max(n, 1), np.int32)
+        lib().se3d_oracle_pp_last_det_ids(C.c_void_p(self._h), pm.iptr(ids), n)
+        return ids[:n]
+
+    def tracks(self):
+        """Live tracks after the last step, list order (test bookkeeping): dict of ids, num_obs, t_prev, height_prev, root_prev [n][3],
+        mask (joints in prevEstimate), prev [n][21][3]."""
+        n = lib().se3d_oracle_pp_tracks(C.c_void_p(self._h), None, None, 0)
+        io, st = np.zeros((max(n, 1), 2), np.int32), np.zeros((max(n, 1), 70))
+        lib().se3d_oracle_pp_tracks(C.c_void_p(self._h), pm.iptr(io), st.ctypes.data_as(C.POINTER(C.c_double)), n)
+        return dict(ids=io[:n, 0].copy(), num_obs=io[:n, 1].copy(), t_prev=st[:n, 0], height_prev=st[:n, 1], root_prev=st[:n, 2:5],
+                    mask=st[:n, 5].astype(np.uint32), prev=st[:n, 6:69].reshape(n, 21, 3))
+
+    def last_merges(self):
+        """[(removed id, surviving id)] of the track merges of the last step (PP:870-903)."""
+        n = lib().se3d_oracle_pp_last_merges(C.c_void_p(self._h), None, 0)
+        pr = np.zeros(max(2 * n, 2), np.int32)
+        lib().se3d_oracle_pp_last_merges(C.c_void_p(self._h), pm.iptr(pr), n)
+        return [(int(pr[2 * i]), int(pr[2 * i + 1])) for i in range(n)]
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().se3d_oracle_pp_destroy(C.c_void_p(self._h))

@@ -1182,6 +1182,9 @@ struct se3d_oracle_pp {  // global state of one pose_prior node (PP:54-60,123)
   double t_prev;
   int next_id;
   int frame_nr;
+  // bookkeeping of the last step for the parity tests (not part of the reference's state): the track id every detection was associated with /
+  // created (PP:570-580), and the (removed id, surviving id) pairs of the track merges (PP:870-903)
+  std::vector<int> last_det_ids, last_merges;
 };
 
 // ============================================================================================================
@@ -1542,6 +1545,8 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
   const bool norm_height = pp->params.norm_height != 0;
   auto &g_tracks = pp->tracks;
   out->n_persons = 0;
+  pp->last_det_ids.clear();
+  pp->last_merges.clear();
 
   double curr_avg_delay = 0.0;  // PP:513-526
   int n_valid_delay_meas = 0;
@@ -1590,6 +1595,7 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
     }
   }
 
+  for (int p = 0; p < n_det; ++p) pp->last_det_ids.push_back(g_tracks[track_ids[p]].id);
   std::vector<se3d_person3d> fused(n_det), fused_pred(n_det);
   std::vector<char> publish(n_det, 0);
   std::vector<int> lm_iters(n_det, 0);
@@ -1786,6 +1792,8 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
     for (size_t j = i + 1; j < g_tracks.size();) {
       if (g_tracks[i].calc_3d_dist(g_tracks[j]) < g_merge_dist_thresh) {
         const int id_to_remove = g_tracks[j].id;
+        pp->last_merges.push_back(id_to_remove);
+        pp->last_merges.push_back(g_tracks[i].id);
         g_tracks.erase(g_tracks.begin() + j);
         stat(SE3D_ORACLE_STAT_TRACK_MERGE);
         for (int p = 0; p < out->n_persons; ++p)
@@ -1797,6 +1805,35 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
   pp->t_prev = t;
   ++pp->frame_nr;
   return SE3D_OK;
+}
+
+// Test bookkeeping of the last se3d_oracle_pp_step: ids[p] = id of the track detection p updated or created; pairs[2 m], pairs[2 m + 1] =
+// the id removed by merge m and the id that survived.  Both return the number of entries (detections / merges) the step had.
+int32_t se3d_oracle_pp_last_det_ids(const se3d_oracle_pp *pp, int32_t *ids, int32_t capacity) {
+  if (!pp) return -1;
+  for (size_t i = 0; i < pp->last_det_ids.size() && (int32_t)i < capacity; ++i) ids[i] = pp->last_det_ids[i];
+  return (int32_t)pp->last_det_ids.size();
+}
+// live tracks after the last step, in list order (test bookkeeping): id_obs[2 i] = id, id_obs[2 i + 1] = num_obs; state[70 i ..] = t_prev,
+// height_prev, root_prev[3], mask of the joints in prevEstimate (as a double), prevEstimate[21][3] (zeros where absent), one spare
+int32_t se3d_oracle_pp_tracks(const se3d_oracle_pp *pp, int32_t *id_obs, double *state, int32_t capacity) {
+  if (!pp) return -1;
+  for (size_t i = 0; i < pp->tracks.size() && (int32_t)i < capacity; ++i) {
+    const TrackingHypothesis &tr = pp->tracks[i];
+    id_obs[2 * i] = tr.id; id_obs[2 * i + 1] = tr.num_obs;
+    double *st = state + 70 * i;
+    for (int q = 0; q < 70; ++q) st[q] = 0.0;
+    st[0] = tr.t_prev; st[1] = tr.height_prev; st[2] = tr.root_prev.x; st[3] = tr.root_prev.y; st[4] = tr.root_prev.z;
+    unsigned mask = 0u;
+    for (const auto &kv : tr.prevEstimate) { mask |= 1u << kv.first; st[6 + 3 * kv.first] = kv.second.x; st[7 + 3 * kv.first] = kv.second.y; st[8 + 3 * kv.first] = kv.second.z; }
+    st[5] = (double)mask;
+  }
+  return (int32_t)pp->tracks.size();
+}
+int32_t se3d_oracle_pp_last_merges(const se3d_oracle_pp *pp, int32_t *pairs, int32_t capacity_pairs) {
+  if (!pp) return -1;
+  for (size_t i = 0; i + 1 < pp->last_merges.size() && (int32_t)(i / 2) < capacity_pairs; i += 2) { pairs[i] = pp->last_merges[i]; pairs[i + 1] = pp->last_merges[i + 1]; }
+  return (int32_t)(pp->last_merges.size() / 2);
 }
 
 // fusedSkeletonCallback (REPROJ:139-235) + draw_sigma_points (REPROJ:62-75)

@@ -90,6 +90,10 @@ se3d_oracle_pp *se3d_oracle_pp_create(const se3d_params *params);
 void se3d_oracle_pp_destroy(se3d_oracle_pp *pp);
 int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *dets, int32_t n_cam,
                         const float *fb_delay_per_cam, double t, se3d_fused_out *out, int32_t omp_threads);
+/* test bookkeeping of the last step: the track id of every detection (PP:570-580); the (removed id, surviving id) pairs of its merges (PP:870-903) */
+int32_t se3d_oracle_pp_last_det_ids(const se3d_oracle_pp *pp, int32_t *ids, int32_t capacity);
+int32_t se3d_oracle_pp_last_merges(const se3d_oracle_pp *pp, int32_t *pairs, int32_t capacity_pairs);
+int32_t se3d_oracle_pp_tracks(const se3d_oracle_pp *pp, int32_t *id_obs, double *state70, int32_t capacity);   /* live tracks: (id, num_obs); t_prev, height_prev, root_prev[3], joint mask, prevEstimate[21][3] */
 
 /* LM + marginals on one explicit graph (rows F, R) for known-answer tests.
  * K variables (3-D points); unary: key, m[3], cov[9]; range: k1, k2, L, sigma. */

@@ -222,3 +222,21 @@ def test_lm_diagonal_covariance_shortcut(oracle):
     res, marg, it, err = oracle.lm(np.array([[0.1, 0.1, 0.1]]), [(0, [0, 0, 0], cov)], [])
     assert np.allclose(res[0], 0, atol=1e-9)
     assert np.allclose(marg[0], np.diag([1e-4, 4e-4, 9e-4]), rtol=1e-9)
+
+
+def test_pose_prior_bookkeeping_exports(oracle, extr_rig, demo_params):
+    """PosePrior.last_det_ids / last_merges / tracks (test bookkeeping of the oracle, used by tools/stage2_track_tables.py): one id per
+    detection, ids of published persons among them, observation counts that grow by one per associated step, and a track table whose state
+    reproduces the published root."""
+    from smartedgesensor3dhumanpose_amd import scene as S
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=3, n_frames=13, seed=3))
+    pp = oracle.PosePrior(demo_params)
+    for k, fr in enumerate(frames):
+        dets = oracle.triangulate(extr_rig, demo_params, fr, capacity=32, hyp_capacity=32).published()
+        res = pp.step(dets, 16, 100.0 + k / 30.0, fr.fb_delay, capacity=32)
+        ids = pp.last_det_ids()
+        tr = pp.tracks()
+        assert len(ids) == len(dets) == 3 and pp.last_merges() == []
+        assert sorted(tr["ids"].tolist()) == sorted(ids.tolist()) and (tr["num_obs"] == k + 1).all()
+        assert np.allclose(tr["t_prev"], 100.0 + k / 30.0) and (tr["mask"] != 0).all()
+        assert set(res.fused["id"][: res.n_persons].tolist()) == (set(ids.tolist()) if k + 1 > 10 else set())   # published from the 11th observation (PP:845)
