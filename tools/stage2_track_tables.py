@@ -63,6 +63,14 @@ for k, fr in enumerate(frames):
     print("step", k, "garbage", np.nonzero(garbage_persons(dets))[0].tolist(), "det ids", ora.last_det_ids().tolist(), "merges", ora.last_merges())
     print("   ora tracks (id, obs):", oo)
     print("   gpu tracks (id, obs):", gt, "" if gt == oo else "  <-- DIFFERENT")
+    for i_, id_ in enumerate(ot["ids"].tolist()):   # state differences of the tracks both sides have
+        if id_ in gi:
+            gtr = gi[id_]
+            dr = np.linalg.norm(gtr["root_prev"] - ot["root_prev"][i_]); dp = np.abs(gtr["prev"] - ot["prev"][i_]).max(); dh = abs(gtr["height_prev"] - ot["height_prev"][i_])
+            if max(dr, dp, dh) > 1e-6 or gtr["mask"] != int(ot["mask"][i_]):
+                jw = int(np.argmax(np.abs(gtr["prev"] - ot["prev"][i_]).max(-1)))
+                print("   track %d: root differs by %.3e m, height by %.3e, normalised joints by %.3e (joint %d: oracle %s, library %s), masks %x / %x" % (
+                    id_, dr, dh, dp, jw, np.round(ot["prev"][i_][jw], 4).tolist(), np.round(gtr["prev"][jw], 4).tolist(), int(ot["mask"][i_]), gtr["mask"]))
     if gt != oo and k > 0 and not globals().get("shown"):
         shown = True
         print("   cost matrices BEFORE this step (rows: detections, columns: track ids), oracle state / gpu state:")
