@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void se3d_k_normalize_pairs(Se3dDev D, const i
   __syncthreads();
   // ---- row E: the valid (det_a, det_b) entries of all camera pairs, densely over the threads ----
   const int total = s_cum[np];
+  double *const tabf = D.pair + (size_t)f * np * P * P;   // the frame's table: offsets inside it fit 24-bit multiplies (np <= 2048, N * P <= 256)
   for (int e = tid; e < total; e += 256) {
     int lo = 0, hi = np;  // largest pr with s_cum[pr] <= e
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cum[mid] <= e) lo = mid; else hi = mid; }
@@ -382,10 +383,10 @@ __global__ __launch_bounds__(256) void se3d_k_normalize_pairs(Se3dDev D, const i
     const int2 ab = pair_ab[pr];
     const int nb = s_nv[ab.y];
     const int r = e - s_cum[pr];
-    const int p = r / nb, q = r - p * nb;
-    const int ia = ab.x * P + p, ib = ab.y * P + q;
+    const int p = r / nb, q = r - __mul24(p, nb);
+    const int ia = __mul24(ab.x, P) + p, ib = __mul24(ab.y, P) + q;
     const unsigned m = s_mgt[ia] & s_mgt[ib];
-    D.pair[(((size_t)f * np + pr) * P + p) * P + q] = se3d_pair_cost_lds(D.F + 9 * (size_t)pr, skp + (size_t)ia * SE3D_NKP, skp + (size_t)ib * SE3D_NKP, m, s_inv);
+    tabf[__mul24(__mul24(pr, P) + p, P) + q] = se3d_pair_cost_lds(D.F + __mul24(9, pr), skp + __mul24(ia, SE3D_NKP), skp + __mul24(ib, SE3D_NKP), m, s_inv);
   }
 }
 
@@ -3446,7 +3447,9 @@ __global__ __launch_bounds__(64) void se3d_k_sweep_wave_lds(Se3dDev D) {
   for (int i = lane; i < N; i += 64) { L.nraw[i] = D.nraw[f * N + i]; L.nvalid[i] = D.nvalid[f * N + i]; }
   __syncthreads();
   const double *g = D.pair + (size_t)f * np * P * P;
-  se3d_sweep_wave_run(D, f, lane, L, [=](int a, int k, int b, int q, int) { return g[((size_t)se3d_pair_index(a, b, N) * P + k) * P + q]; });
+  // 24-bit multiplies: the launcher admits this kernel for N, P <= 64 only (pairs * P * P <= 2016 * 4096 < 2^24); the 64-bit index arithmetic
+  // of the generic expression was four quarter-rate multiplies per table entry on the wavefront's critical path
+  se3d_sweep_wave_run(D, f, lane, L, [=](int a, int k, int b, int q, int) { return g[__mul24(__mul24(se3d_pair_index(a, b, N), P) + k, P) + q]; });
 }
 static size_t se3d_sweep_wave_lds_bytes(int N, int P, int H) {
   return (size_t)H * P * 16 + (size_t)N * P * 4 + (size_t)H * N * 4 + (size_t)H * 4 + (size_t)N * 8 + (((size_t)H * P + 15) & ~(size_t)15) + 16 + (size_t)(2 * N + 1) * 8;
