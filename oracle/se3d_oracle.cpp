@@ -1348,12 +1348,24 @@ int se3d_oracle_triangulate(const se3d_rig *rig, const se3d_params *params, cons
     std::vector<double> C((size_t)n_hyp * n_det);  // column-major, rows = hypotheses
     std::vector<int> assignment(n_hyp, -1);
     std::vector<char> mask((size_t)n_hyp * n_det, 0);
+    // The cost of every (hypothesis, detection) pair first — the entries do not depend on one another, so with omp_threads > 1 they are
+    // evaluated in parallel (test convenience for the 256-camera comparisons; the reference evaluates them inside the scan below, serially) —
+    // then the reference's scan in its order: the LAST feasible detection of a hypothesis stays in `assignment` (S3D:616-626).
+    std::vector<char> vetoed((size_t)n_hyp * n_det, 0);
+    const long long n_items = (long long)n_hyp * n_det;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(std::max(1, std::min<int>(omp_threads, (int)std::min<long long>(n_items, 1 << 20)))) schedule(dynamic, 16) if (omp_threads > 1 && n_items > 64)
+#endif
+    for (long long it = 0; it < n_items; ++it) {
+      const int det_idx = (int)(it / n_hyp), hyp_idx = (int)(it - (long long)det_idx * n_hyp);
+      bool veto;
+      C[hyp_idx + (size_t)n_hyp * det_idx] = calcCost(H[hyp_idx], dets_kps[det_idx], cameraIDs[cam_idx], rig->F, NUM_CAMERAS, g_max_epipolar_error, veto);
+      vetoed[hyp_idx + (size_t)n_hyp * det_idx] = veto ? 1 : 0;
+    }
     for (int det_idx = 0; det_idx < n_det; ++det_idx)
       for (int hyp_idx = 0; hyp_idx < n_hyp; ++hyp_idx) {
-        bool veto;
-        const double c = calcCost(H[hyp_idx], dets_kps[det_idx], cameraIDs[cam_idx], rig->F, NUM_CAMERAS, g_max_epipolar_error, veto);
-        C[hyp_idx + (size_t)n_hyp * det_idx] = c;
-        if (!veto && c < g_max_epipolar_error) {
+        const double c = C[hyp_idx + (size_t)n_hyp * det_idx];
+        if (!vetoed[hyp_idx + (size_t)n_hyp * det_idx] && c < g_max_epipolar_error) {
           mask[hyp_idx + (size_t)n_hyp * det_idx] = 1;
           assignment[hyp_idx] = det_idx;
         }

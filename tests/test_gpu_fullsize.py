@@ -218,3 +218,39 @@ def test_256cam_32p_exact_parity_with_oracle(oracle, demo_params):
     print("256x32 stage 2: %d published person-steps, worst %s" % (published, worst))
     assert published >= 30
     node.close()
+
+
+def test_256cam_128p_one_frame_matches_the_oracle(oracle, demo_params):
+    """north_star's full configuration, one frame, against the oracle (OpenMP over the host's cores: 17 x 128^2 x 32 640 pair-joints and
+    ~2 200 joints with ~1 000 float32 sample solves each): association table bit-exact, every joint < 1 mm, scores bit-equal, covariances inside
+    parity.cov_tolerance — the 256-camera code paths (column chunks, per-camera sweep launches with the block Munkres, per-joint triangulation,
+    float32 second pass with its large-rig workspace) at the size bench.py's `secondary` runs them."""
+    import time
+    import parity
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D, rig_tensors
+    from parity import compare_stage1
+    rig = R.elliptical_rig(256, seed=4)
+    rig.set_tensors(*rig_tensors(rig))
+    frames, gt = S.generate_sequence(rig, S.SceneConfig(n_persons=128, n_frames=1, seed=11, min_coverage=6))
+    node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=1, max_det_per_cam=128, max_hyp=256)
+    g = node.triangulate_persons(frames[:1])[0]
+    n_second = len(node.exact_list()[0])
+    t0 = time.time()
+    o = oracle.triangulate(rig, demo_params, frames[0], capacity=256, hyp_capacity=256, omp_threads=os.cpu_count() or 1)
+    t_ora = time.time() - t0
+    st = compare_stage1(g, o, check_cov=False)
+    k2f = np.array(pm.KP2FUSION_SIMPLE)
+    kappa = parity.published_joint_condition(rig, frames[0], g, k2f)
+    gk, ok = g.published()["keypoints"][:, k2f], o.published()["keypoints"][:, k2f]
+    v = ok["score"] > 0
+    w6 = np.array([1, 2, 2, 1, 2, 1.0])
+    d = np.where(v, np.linalg.norm(gk["joint"] - ok["joint"], axis=-1), 0.0)
+    tables = oracle.pose_tables(pm.POSE_SIMPLE)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.maximum(np.sqrt(((gk["cov"] - ok["cov"]) ** 2 * w6).sum(-1)) - parity.inflation_allowance(tables, ok["joint"], v, d), 0.0) / np.sqrt((ok["cov"] ** 2 * w6).sum(-1))
+    tol = parity.cov_tolerance(np.minimum(kappa, parity.DLT_KAPPA_MAX), ok["cov"])
+    assert (rel[v] < tol[v]).all(), (float(rel[v].max()), float(tol[v][np.argmax(rel[v])]))
+    print("256x128 stage 1: %d persons, %d hypotheses, %s | covariance rel. max %.2e (tolerance there %.2e) | second pass: %d joints | oracle %.1f s on %d threads"
+          % (g.n_persons, g.n_hyp, st, rel[v].max(), tol[v][np.argmax(rel[v])], n_second, t_ora, os.cpu_count() or 1))
+    assert g.n_persons >= 120
+    node.close()

@@ -240,3 +240,15 @@ def test_pose_prior_bookkeeping_exports(oracle, extr_rig, demo_params):
         assert sorted(tr["ids"].tolist()) == sorted(ids.tolist()) and (tr["num_obs"] == k + 1).all()
         assert np.allclose(tr["t_prev"], 100.0 + k / 30.0) and (tr["mask"] != 0).all()
         assert set(res.fused["id"][: res.n_persons].tolist()) == (set(ids.tolist()) if k + 1 > 10 else set())   # published from the 11th observation (PP:845)
+
+
+def test_oracle_openmp_does_not_change_a_bit(oracle, extr_rig, demo_params):
+    """omp_threads > 1 (hypotheses of the triangulation as in S3D:676, and — test convenience — the entries of a sweep step's cost matrix):
+    the same association table and the same bytes of every published person as the serial run."""
+    from smartedgesensor3dhumanpose_amd import scene as S
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=7, n_frames=3, seed=12, p_miss=0.2, outlier_frac=0.03, low_score_frac=0.1))
+    for fr in frames:
+        a = oracle.triangulate(extr_rig, demo_params, fr, capacity=32, hyp_capacity=32, omp_threads=1)
+        b = oracle.triangulate(extr_rig, demo_params, fr, capacity=32, hyp_capacity=32, omp_threads=8)
+        assert a.n_hyp == b.n_hyp and a.n_persons == b.n_persons and a.flags == b.flags
+        assert np.array_equal(a.assoc(), b.assoc()) and a.published().tobytes() == b.published().tobytes()
