@@ -140,7 +140,7 @@ def cpu_baseline(rig, seq, params, with_stage2, budget_s=12.0):
                              "single_thread": buckets["1t"], "openmp_x%d" % ncores: buckets["omp"]}}
 
 
-def bench_parity(name, rig, seqs, n_seq=4, device=0):
+def bench_parity(name, rig, seqs, n_seq=4, device=0, omp_threads=1, max_steps=None):
     """The second half of the metric (BASELINE.json: "3D skeletons/sec + mm MPJPE vs CPU ref"; SURVEY 8d: max and mean per-joint error, association
     exact-match rate), untimed: the HIP path against the CPU oracle on the bench's OWN scenes through a context of the same limits — stage 1 per
     frame (n_seq sequences x T frames), then the resident stage-2 walk against the oracle's pose_prior fed with the same stage-1 persons."""
@@ -148,7 +148,7 @@ def bench_parity(name, rig, seqs, n_seq=4, device=0):
     from smartedgesensor3dhumanpose_amd import person_msgs as pm
     from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
     w = WORKLOADS[name]
-    seqs = seqs[:n_seq]
+    seqs = [sq[:max_steps] if max_steps else sq for sq in seqs[:n_seq]]   # (omp_threads / max_steps: the 256-camera block — the oracle's sweep and triangulation over the host's cores, one frame)
     S_, T_ = len(seqs), len(seqs[0])
     frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
     node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=S_ * T_, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=device)
@@ -159,7 +159,7 @@ def bench_parity(name, rig, seqs, n_seq=4, device=0):
     t0 = time.perf_counter()
     exact, d_all, n_skel = 0, [], 0
     for fr, g in zip(frames, r1):
-        o = O.triangulate(rig, node.params, fr, capacity=2 * w["max_hyp"], hyp_capacity=2 * w["max_hyp"])
+        o = O.triangulate(rig, node.params, fr, capacity=2 * w["max_hyp"], hyp_capacity=2 * w["max_hyp"], omp_threads=omp_threads)
         same = (g.flags == o.flags and g.n_hyp == o.n_hyp and g.n_persons == o.n_persons and np.array_equal(g.assoc(), o.assoc())
                 and np.array_equal(g.person_hyp[:g.n_persons], o.person_hyp[:g.n_persons]))
         exact += int(same)
@@ -189,7 +189,7 @@ def bench_parity(name, rig, seqs, n_seq=4, device=0):
     for k, t in enumerate(ts):
         ra = node.fetch_stage2_walk(k * S_, S_)
         for s_ in range(S_):
-            o2 = oras[s_].step(r1[k * S_ + s_].published(), rig.n_cam, t, seqs[s_][k].fb_delay, capacity=2 * w["max_hyp"])
+            o2 = oras[s_].step(r1[k * S_ + s_].published(), rig.n_cam, t, seqs[s_][k].fb_delay, capacity=2 * w["max_hyp"], omp_threads=omp_threads)
             g2 = ra[s_]
             steps2 += 1
             n = g2.n_persons
@@ -1069,10 +1069,13 @@ def main():
         if want_parity and hyp_hung:   # the GPU may still be spinning in the collective that never returned: nothing measured after it is trustworthy
             line["parity"] = line["latency_B1"] = {"skipped": "a collective of the hypothesis-shard block did not return within its deadline"}
         elif want_parity:
-            line["parity"] = {"16cam6p": bench_parity(headline, rig, seqs_par, 4, local_rank), "64cam32p": bench_parity("64cam32p", rig64, [seq64], 1, local_rank),
+            line["parity"] = {"16cam6p": bench_parity(headline, rig, seqs_par, 4, local_rank), "64cam32p": bench_parity("64cam32p", rig64, [seq64], 1, local_rank)}
+            if want_secondary and not os.environ.get("SE3D_BENCH_NO_PARITY_256"):   # north_star's configuration: one frame of the secondary's first sequence, the oracle over the host's cores (~35 s on 256 threads)
+                line["parity"]["256cam128p"] = bench_parity("256cam128p", rig2, seqs_sec[0][:1], 1, local_rank, omp_threads=os.cpu_count() or 1, max_steps=1)
+            line["parity"].update({
                               "note": "HIP path vs the CPU oracle (restatement of the reference, DESIGN 4) on the bench's own scenes, untimed: stage-1 joints "
                                       "(mpjpe_*), association / hypothesis / person tables identical per frame (assoc_exact_rate), refined + predicted joints "
-                                      "of the resident stage-2 walk (refined_*), track ids and LM iteration counts per sequence-step; tolerance of the tests: 1 mm"}
+                                      "of the resident stage-2 walk (refined_*), track ids and LM iteration counts per sequence-step; tolerance of the tests: 1 mm"})
             line["latency_B1"] = bench_latency_b1(rig, seqs_par[0], headline, local_rank)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(rig, _gen_one((w["n_cam"], w["n_persons"], T_, 1000 * seed_rank)), main_res["params"], stage2)
