@@ -254,3 +254,35 @@ def test_256cam_128p_one_frame_matches_the_oracle(oracle, demo_params):
           % (g.n_persons, g.n_hyp, st, rel[v].max(), tol[v][np.argmax(rel[v])], n_second, t_ora, os.cpu_count() or 1))
     assert g.n_persons >= 120
     node.close()
+
+
+def test_256cam_128p_stage2_matches_the_oracle(oracle, demo_params):
+    """Stage 2 at north_star's full configuration: twelve frames of 128 persons in 256 cameras through the library's stage 1, then the
+    per-step stage-2 kernels (block Munkres of the track association at ~130 x ~130, LM, lifecycle) against the oracle's pose_prior fed with the
+    same stage-1 persons — ids, LM iteration counts, refined and predicted joints, marginal covariances on every step, from the first
+    published persons (eleventh observation) on.  Steps after a badly scaled stage-1 person (parity.garbage_persons) are not compared, as in
+    the randomised sweep; a crowded frame may publish a spurious person or two, so their number is reported and bounded."""
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D, rig_tensors
+    from smartedgesensor3dhumanpose_amd.pose_prior import PosePrior
+    from parity import compare_stage2, garbage_persons
+    rig = R.elliptical_rig(256, seed=4)
+    rig.set_tensors(*rig_tensors(rig))
+    frames, gt = S.generate_sequence(rig, S.SceneConfig(n_persons=128, n_frames=12, seed=11, min_coverage=6))
+    node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=1, max_det_per_cam=128, max_hyp=256)
+    node.refine_reset()
+    pp, ora = PosePrior(node, 0), oracle.PosePrior(demo_params)
+    worst, published, compared, tainted_at = {"pos_max_mm": 0.0, "pred_max_mm": 0.0, "cov_rel_max": 0.0}, 0, 0, None
+    for k, fr in enumerate(frames):
+        dets = node.triangulate_persons([fr])[0].published()
+        if tainted_at is None and garbage_persons(dets).any():
+            tainted_at = k
+        r2 = pp.skeleton_callback(dets, fr.stamp, fr.fb_delay)
+        o2 = ora.step(dets, rig.n_cam, fr.stamp, fr.fb_delay, capacity=256, omp_threads=os.cpu_count() or 1)
+        if tainted_at is None:
+            s2 = compare_stage2(r2, o2)
+            worst = {key: max(worst[key], s2[key]) for key in worst}
+            compared += 1
+            published += r2.n_persons
+    print("256x128 stage 2: %d of %d steps compared (first badly scaled stage-1 person at step %s), %d published person-steps, worst %s" % (compared, len(frames), tainted_at, published, worst))
+    assert compared >= 11 and published >= 100
+    node.close()
