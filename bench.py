@@ -44,10 +44,11 @@ WORKLOADS = {
     # the marginals).
     "16cam6p": dict(n_cam=16, n_persons=6, seqs=512, contexts=12, max_det=8, max_hyp=12, bytes_s1=8972, bytes_s2=8900, flop_s1=0.12e6 + 1.86e6),
     "64cam32p": dict(n_cam=64, n_persons=32, seqs=32, contexts=3, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900, flop_s1=11.0e6 + 7.28e6),
-    # 256cam128p: 5 contexts x 4 sequences x 16 frames; the pair table is kept as two camera-column chunks per frame (Se3dPairPlan):
-    # 9.4 GB per 16 frames instead of 68.9 GB, 5 x 38.5 GB per GPU.  Contexts (profiles/r4/README.md section 7): 3 -> 26.1 k, 4 -> 26.9 - 27.3 k,
-    # 5 -> 28.0 - 28.3 k skeletons/s (one more set of latency-bound sweep / Munkres / LM chains under the pair kernels), 6 and 8 -> 11.6 - 15.4 k
-    "256cam128p": dict(n_cam=256, n_persons=128, seqs=4, contexts=5, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900, flop_s1=0.71e9 + 29.0e6),
+    # 256cam128p: 6 contexts x 4 sequences x 16 frames; the pair table is kept as two camera-column chunks per frame (Se3dPairPlan):
+    # 9.4 GB per 16 frames instead of 68.9 GB, 6 x 38.5 GB per GPU.  Contexts (profiles/r4/README.md section 7): 3 -> 26.1 k, 4 -> 26.9 - 27.3 k,
+    # 5 -> 27.9 - 28.7 k skeletons/s (one more set of latency-bound sweep / Munkres / LM chains under the pair kernels), 6 with one stream per
+    # context -> 28.3 - 29.2 k (with the second stream per context: 11.6 - 15.0 k), 7 -> 29.0 k (277 GB), 8 does not fit
+    "256cam128p": dict(n_cam=256, n_persons=128, seqs=4, contexts=6, max_det=128, max_hyp=256, bytes_s1=115320, bytes_s2=8900, flop_s1=0.71e9 + 29.0e6),
 }
 FLOP_S2_PER_LM_ITER = 0.74e6
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -298,11 +299,21 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
     world = dist.get_world_size() if dist is not None else 1
     memory_plan(name, NC, B, exchange=dist is not None, free_bytes=torch.cuda.mem_get_info(local_rank)[0])   # fails fast, with the figures
     nodes = []
-    for seqs in seqs_per_ctx:   # every rank (and every context) owns its own sequences: weak scaling, no data-path collective
-        frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s
-        nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank)
-        nd_.stage(frames)  # inputs resident in HBM before the timed region
-        nodes.append(nd_)
+    # More than four contexts of a large rig: ONE stream per context (SE3D_NO_HI_STREAM, read by se3d_create).  The second, high-priority stream a
+    # large-rig context owns for its sweep chains buys nothing once this many contexts interleave (5 contexts: 28.6 k without, 27.9 - 28.7 k with),
+    # and 2 x 6 streams collapse to 11.6 - 15.0 k skeletons/s (profiles/r4/README.md section 7).
+    one_stream = w["n_cam"] >= 128 and NC > 4 and "SE3D_NO_HI_STREAM" not in os.environ
+    if one_stream:
+        os.environ["SE3D_NO_HI_STREAM"] = "1"
+    try:
+        for seqs in seqs_per_ctx:   # every rank (and every context) owns its own sequences: weak scaling, no data-path collective
+            frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s
+            nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank)
+            nd_.stage(frames)  # inputs resident in HBM before the timed region
+            nodes.append(nd_)
+    finally:
+        if one_stream:
+            del os.environ["SE3D_NO_HI_STREAM"]
     node = nodes[0]
     dt_frame = 1.0 / 30.0
     H = node.limits.max_hyp
@@ -928,7 +939,7 @@ def main():
             sec_serial = run_workload("256cam128p", [seqs_sec[0]], rig2, args, 3, 1, None, local_rank, True)
             sec_serial["value_per_gpu"] = sec_serial["value"]
 
-    # Order of a default run: the 256cam128p measurement FIRST, on the fresh device (its five contexts take 192 of the 288 GB — 272 in round 2, whole pair tables; behind the
+    # Order of a default run: the 256cam128p measurement FIRST, on the fresh device (its six contexts take 231 of the 288 GB — 272 in round 2, whole pair tables; behind the
     # headline's twelve contexts the same measurement came out ~8 % lower, behind the streaming contexts at half speed — measured, cause
     # not isolated), then the headline, the serial pass and the streaming pass.  SE3D_BENCH_SECONDARY_LAST=1 restores the old order.
     sec_first = want_secondary and not os.environ.get("SE3D_BENCH_SECONDARY_LAST")
