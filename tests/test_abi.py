@@ -117,6 +117,14 @@ def test_device_bytes_and_bench_memory_plan(product_lib):
         device_bytes(1, 1, 8, 12)          # fewer than two cameras: se3d_create rejects it, so does the plan
     plan = bench.memory_plan("256cam128p", 4, 16, exchange=True)
     assert plan["total_bytes"] == 4 * b + plan["exchange_bytes"] and plan["total_bytes"] < 288e9
+    # the bench's own preset for north_star's configuration, with the exchange buffers of an eight-rank run: fits one MI355X (288 GiB = 309 GB) with room to spare
+    w = bench.WORKLOADS["256cam128p"]
+    os.environ["WORLD_SIZE"] = "8"
+    try:
+        preset = bench.memory_plan("256cam128p", w["contexts"], w["seqs"] * bench.T_STEPS, exchange=True, free_bytes=int(288e9))
+    finally:
+        del os.environ["WORLD_SIZE"]
+    assert preset["contexts"] == w["contexts"] and preset["total_bytes"] < 260e9 and preset["exchange_bytes"] < 5e9
     with pytest.raises(SystemExit) as e:
         bench.memory_plan("256cam128p", 4, 512, free_bytes=int(288e9))
     assert "needs" in str(e.value) and "GB" in str(e.value) and "--contexts" in str(e.value)
