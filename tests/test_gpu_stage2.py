@@ -513,3 +513,47 @@ def test_stage2_large_rig_every_step_asserted(oracle, n_cam, n_persons):
     print("%d cameras x %d persons: %d published persons over 14 steps, worst %s" % (n_cam, n_persons, published, worst))
     assert published >= 3 * n_persons - 2
     node.close()
+
+
+def test_pose_prior_state_moves_between_contexts_and_matches_the_oracles_tracks(extr_rig, oracle, demo_params):
+    """PosePrior.save_state / load_state / tracks (se3d_refine_save / _load): after eight frames the node's track table — ids, observation
+    counts, previous root / height, previous estimates — equals the oracle's g_tracks; the blob loaded into a context with LARGER limits makes
+    that context continue the sequence with the first context's outputs (to 1e-9 m: the round trip through the blob may cost an ulp), and both
+    stay on the oracle."""
+    from smartedgesensor3dhumanpose_amd.pose_prior import PosePrior
+    from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=5, n_frames=16, seed=21, p_miss=0.15))
+    a = Skeleton3D(extr_rig, max_epi_dist=0.045, max_frames=1, max_det_per_cam=8, max_hyp=12, device=0)
+    b = Skeleton3D(extr_rig, max_epi_dist=0.045, max_frames=1, max_det_per_cam=8, max_hyp=32, max_tracks=48, device=0)
+    a.refine_reset(); b.refine_reset()
+    pa, pb, ora = PosePrior(a, 0), PosePrior(b, 0), oracle.PosePrior(demo_params)
+    dets = [a.triangulate_persons([fr])[0].published() for fr in frames]
+    for k in range(8):
+        compare_stage2(pa.skeleton_callback(dets[k], frames[k].stamp, frames[k].fb_delay), ora.step(dets[k], 16, frames[k].stamp, frames[k].fb_delay, capacity=32))
+    tr, ot = pa.tracks(), ora.tracks()
+    assert tr["id"].tolist() == ot["ids"].tolist() and tr["num_obs"].tolist() == ot["num_obs"].tolist() and len(tr) >= 5
+    assert np.array_equal(tr["mask"], ot["mask"]) and np.allclose(tr["t_prev"], ot["t_prev"])
+    assert np.abs(tr["root_prev"] - ot["root_prev"]).max() < 1e-9 and np.abs(tr["height_prev"] - ot["height_prev"]).max() < 1e-12
+    assert np.abs(tr["prev"] - ot["prev"]).max() < 1e-6      # the previous estimates (normalised joints) of every track
+    blob = pa.save_state()
+    hd, _ = PosePrior.parse_state(blob)
+    assert int(hd["n_tracks"]) == len(tr) and int(hd["frame_nr"]) == 8
+    pb.load_state(blob)
+    tb = pb.tracks()   # the same table out of the larger context (the device keeps de-normalised copies: the round trip may cost an ulp)
+    assert tb["id"].tolist() == tr["id"].tolist() and tb["num_obs"].tolist() == tr["num_obs"].tolist() and np.array_equal(tb["mask"], tr["mask"])
+    for fld in ("t_prev", "height_prev", "root_prev", "prev", "vel"):
+        assert np.allclose(tb[fld], tr[fld], rtol=1e-14, atol=1e-14), fld
+    published = 0
+    for k in range(8, 16):
+        ra = pa.skeleton_callback(dets[k], frames[k].stamp, frames[k].fb_delay)
+        rb = pb.skeleton_callback(dets[k], frames[k].stamp, frames[k].fb_delay)
+        n = ra.n_persons
+        assert rb.n_persons == n and ra.c.n_tracks == rb.c.n_tracks
+        assert np.array_equal(ra.fused["id"][:n], rb.fused["id"][:n]) and np.array_equal(ra.lm_iterations[:n], rb.lm_iterations[:n])
+        for nm in ("fused", "fused_pred") if n else ():
+            ga, gb = getattr(ra, nm)[:n]["keypoints"], getattr(rb, nm)[:n]["keypoints"]
+            assert np.array_equal(ga["score"], gb["score"]) and np.abs(ga["joint"] - gb["joint"]).max() < 1e-9
+        compare_stage2(rb, ora.step(dets[k], 16, frames[k].stamp, frames[k].fb_delay, capacity=32))
+        published += n
+    assert published >= 20
+    a.close(); b.close()

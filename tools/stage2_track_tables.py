@@ -26,20 +26,12 @@ frames = [seqs[s][k] for k in range(T_STEPS)]
 node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=1, max_det_per_cam=MAX_DET, max_hyp=MAX_HYP, device=0)
 ora = O.PosePrior(node.params)
 node.refine_reset()
+from smartedgesensor3dhumanpose_amd.pose_prior import PosePrior
 L = node._L
-nb = L.se3d_refine_state_bytes(C.c_void_p(node._h))
+pp_gpu = PosePrior(node, 0)
 def gpu_tracks():
-    blob = (C.c_ubyte * nb)(); got = C.c_int64(0)
-    assert L.se3d_refine_save(C.c_void_p(node._h), 0, blob, C.c_int64(nb), C.byref(got)) == 0
-    b = bytes(blob)
-    n = np.frombuffer(b, np.int32, 4, 0)[1]
-    out = {}
-    for i in range(n):
-        o = 56 + 2072 * i
-        idn = np.frombuffer(b, np.int32, 2, o); has = np.frombuffer(b, np.uint32, 1, o + 8)[0]
-        d = np.frombuffer(b, np.float64, 5 + 63, o + 16)
-        out[int(idn[0])] = dict(num_obs=int(idn[1]), mask=int(has), t_prev=d[0], height_prev=d[1], root_prev=d[2:5].copy(), prev=d[5:68].reshape(21, 3).copy())
-    return out
+    return {int(r["id"]): dict(num_obs=int(r["num_obs"]), mask=int(r["mask"]), t_prev=float(r["t_prev"]), height_prev=float(r["height_prev"]),
+                               root_prev=r["root_prev"].copy(), prev=r["prev"].copy()) for r in pp_gpu.tracks()}
 def cost(det, tr, t):   # calc_normed_dist (PP:84-101)
     dt = t - tr["t_prev"]; n = 0; dist = 0.0
     for k in range(21):
