@@ -48,7 +48,8 @@ class PosePrior:
     @staticmethod
     def parse_state(blob):
         """(header record, tracks [n] of track_dt): id, num_obs, mask of the joints in prevEstimate, t_prev, height_prev, root_prev,
-        prev (the normalised previous estimate per fusion joint), vel (the three-frame velocity buffer per joint)."""
+        prev (the normalised previous estimate per fusion joint), vel (the three-frame velocity buffer per joint).  prev / vel are defined
+        for the joints of `mask` only."""
         hd = np.frombuffer(blob, _header_dt, 1, 0)[0]
         if int(hd["magic"]) != _MAGIC:
             raise ValueError("not a pose_prior state blob")

@@ -534,15 +534,18 @@ def test_pose_prior_state_moves_between_contexts_and_matches_the_oracles_tracks(
     assert tr["id"].tolist() == ot["ids"].tolist() and tr["num_obs"].tolist() == ot["num_obs"].tolist() and len(tr) >= 5
     assert np.array_equal(tr["mask"], ot["mask"]) and np.allclose(tr["t_prev"], ot["t_prev"])
     assert np.abs(tr["root_prev"] - ot["root_prev"]).max() < 1e-9 and np.abs(tr["height_prev"] - ot["height_prev"]).max() < 1e-12
-    assert np.abs(tr["prev"] - ot["prev"]).max() < 1e-6      # the previous estimates (normalised joints) of every track
+    held = ((tr["mask"][:, None] >> np.arange(pm.NUM_FUSION_KEYPOINTS)[None, :]) & 1).astype(bool)   # joints in prevEstimate (the other slots of the blob are undefined)
+    assert held.sum() > 50 and np.abs(tr["prev"] - ot["prev"])[held].max() < 1e-6      # the previous estimates (normalised joints) of every track
     blob = pa.save_state()
     hd, _ = PosePrior.parse_state(blob)
     assert int(hd["n_tracks"]) == len(tr) and int(hd["frame_nr"]) == 8
     pb.load_state(blob)
     tb = pb.tracks()   # the same table out of the larger context (the device keeps de-normalised copies: the round trip may cost an ulp)
     assert tb["id"].tolist() == tr["id"].tolist() and tb["num_obs"].tolist() == tr["num_obs"].tolist() and np.array_equal(tb["mask"], tr["mask"])
-    for fld in ("t_prev", "height_prev", "root_prev", "prev", "vel"):
+    for fld in ("t_prev", "height_prev", "root_prev"):
         assert np.allclose(tb[fld], tr[fld], rtol=1e-14, atol=1e-14), fld
+    for fld in ("prev", "vel"):
+        assert np.allclose(tb[fld][held], tr[fld][held], rtol=1e-14, atol=1e-14), fld
     published = 0
     for k in range(8, 16):
         ra = pa.skeleton_callback(dets[k], frames[k].stamp, frames[k].fb_delay)
