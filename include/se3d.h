@@ -199,7 +199,8 @@ int se3d_refine_reset(se3d_ctx *ctx);
  * context's limits: se3d_refine_save from one context, se3d_refine_load into another (e.g. one created with larger limits — the
  * reference's g_tracks grows without bound, PP:570-580; host/se3d_nodes.cpp grows its context this way instead of truncating).
  * se3d_refine_state_bytes: upper bound of a blob of this context.  Loading re-numbers the track slots (track k of the vector -> slot k);
- * results do not depend on the slot numbering.  Synchronous. */
+ * results do not depend on the slot numbering.  A blob is deterministic: joints outside a track's previous estimate are written as zeros,
+ * and save -> load -> save gives the same bytes (tests/test_gpu_stage2.py).  Synchronous. */
 int64_t se3d_refine_state_bytes(const se3d_ctx *ctx);
 int se3d_refine_save(se3d_ctx *ctx, int32_t seq, void *blob, int64_t capacity_bytes, int64_t *bytes);
 int se3d_refine_load(se3d_ctx *ctx, int32_t seq, const void *blob, int64_t bytes);

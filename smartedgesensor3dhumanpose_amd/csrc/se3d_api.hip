@@ -1115,6 +1115,11 @@ int se3d_refine_save(se3d_ctx *c, int32_t seq, void *blob, int64_t capacity_byte
     memcpy(t.root_prev, &rp[sl * 3], sizeof t.root_prev);
     memcpy(t.prev, &prev[sl * SE3D_NFU * 3], sizeof t.prev);
     memcpy(t.vel, &vel[sl * SE3D_NFU * 9], sizeof t.vel);
+    for (int j = 0; j < SE3D_NFU; ++j)   // joints outside prevEstimate: their device slots are never read and hold whatever was there — zeros in the blob
+      if (!((t.has >> j) & 1u)) {
+        for (int a = 0; a < 3; ++a) t.prev[j * 3 + a] = 0.0;
+        for (int a = 0; a < 9; ++a) t.vel[j * 9 + a] = 0.0;
+      }
     memcpy(out + sizeof h + (size_t)k * sizeof t, &t, sizeof t);
   }
   return SE3D_OK;

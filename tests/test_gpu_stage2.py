@@ -518,8 +518,8 @@ def test_stage2_large_rig_every_step_asserted(oracle, n_cam, n_persons):
 def test_pose_prior_state_moves_between_contexts_and_matches_the_oracles_tracks(extr_rig, oracle, demo_params):
     """PosePrior.save_state / load_state / tracks (se3d_refine_save / _load): after eight frames the node's track table — ids, observation
     counts, previous root / height, previous estimates — equals the oracle's g_tracks; the blob loaded into a context with LARGER limits makes
-    that context continue the sequence with the first context's outputs (to 1e-9 m: the round trip through the blob may cost an ulp), and both
-    stay on the oracle."""
+    that context hand the same bytes back and continue the sequence with the first context's outputs (to 1e-9 m: the two limits select different
+    LM kernel forms), and both stay on the oracle."""
     from smartedgesensor3dhumanpose_amd.pose_prior import PosePrior
     from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
     frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=5, n_frames=16, seed=21, p_miss=0.15))
@@ -540,12 +540,8 @@ def test_pose_prior_state_moves_between_contexts_and_matches_the_oracles_tracks(
     hd, _ = PosePrior.parse_state(blob)
     assert int(hd["n_tracks"]) == len(tr) and int(hd["frame_nr"]) == 8
     pb.load_state(blob)
-    tb = pb.tracks()   # the same table out of the larger context (the device keeps de-normalised copies: the round trip may cost an ulp)
-    assert tb["id"].tolist() == tr["id"].tolist() and tb["num_obs"].tolist() == tr["num_obs"].tolist() and np.array_equal(tb["mask"], tr["mask"])
-    for fld in ("t_prev", "height_prev", "root_prev"):
-        assert np.allclose(tb[fld], tr[fld], rtol=1e-14, atol=1e-14), fld
-    for fld in ("prev", "vel"):
-        assert np.allclose(tb[fld][held], tr[fld][held], rtol=1e-14, atol=1e-14), fld
+    assert (tr["prev"][~held] == 0).all() and (tr["vel"][~held] == 0).all()   # joints outside prevEstimate: zeros in the blob
+    assert pb.save_state() == blob                             # the same bytes out of the larger context
     published = 0
     for k in range(8, 16):
         ra = pa.skeleton_callback(dets[k], frames[k].stamp, frames[k].fb_delay)
@@ -553,7 +549,7 @@ def test_pose_prior_state_moves_between_contexts_and_matches_the_oracles_tracks(
         n = ra.n_persons
         assert rb.n_persons == n and ra.c.n_tracks == rb.c.n_tracks
         assert np.array_equal(ra.fused["id"][:n], rb.fused["id"][:n]) and np.array_equal(ra.lm_iterations[:n], rb.lm_iterations[:n])
-        for nm in ("fused", "fused_pred") if n else ():
+        for nm in ("fused", "fused_pred") if n else ():   # (limits 12 / 32 select different LM kernel forms: equal up to the summation order)
             ga, gb = getattr(ra, nm)[:n]["keypoints"], getattr(rb, nm)[:n]["keypoints"]
             assert np.array_equal(ga["score"], gb["score"]) and np.abs(ga["joint"] - gb["joint"]).max() < 1e-9
         compare_stage2(rb, ora.step(dets[k], 16, frames[k].stamp, frames[k].fb_delay, capacity=32))
