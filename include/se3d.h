@@ -298,6 +298,13 @@ int se3d_get_fusion_constants(se3d_ctx *ctx, int32_t *indices22, double *vel_sig
  * float of the range, the quotient on n_div pseudo-random operand pairs — and returns the mismatch counts (expected: 0, 0). */
 int se3d_selftest_exact_math(se3d_ctx *ctx, uint64_t n_div, uint64_t *sqrt_mismatches, uint64_t *div_mismatches);
 
+/* --- diagnostic self-test (round 5): the large-rig pair kernel (calcCost's two quotients per joint, S3D:358-361) divides by a line norm through
+ * its correctly rounded reciprocal y = RN(1 / b), staged once per (detection, joint), in three instructions: q0 = RN(a y), r = fma(-b, q0, a),
+ * q = fma(r, y, q0) (one Markstein correction; csrc/se3d_stage1.hip has the argument why one suffices).  This runs it against the device's
+ * IEEE quotient on n pseudo-random operand pairs drawn from the kernel's guarded operand range and returns the mismatch count (expected 0) and
+ * the pairs skipped because the divisor fails the guard (significand all ones: such blocks take the IEEE divide in the kernel). */
+int se3d_selftest_shared_quotient(se3d_ctx *ctx, uint64_t n, uint64_t *mismatches, uint64_t *skipped);
+
 /* --- diagnostic self-test (round 4): the float32 DLT solve of the triangulation's second pass — triangulate() + calcReprojectionError()
  * (S3D:425-465) with the reference's arithmetic: Eigen 3.3 JacobiSVD of the float rows (scaling, ColPivHouseholderQR preconditioner unless
  * the system is 4 x 4, two-sided Jacobi sweeps), every sum sequential, IEEE division / square root, no FMA — on n_sys caller systems of

@@ -1630,6 +1630,23 @@ int se3d_selftest_exact_math(se3d_ctx *c, uint64_t n_div, uint64_t *sqrt_mismatc
   return SE3D_OK;
 }
 
+// Diagnostic: the rows kernel's three-instruction quotient on the shared reciprocal against the IEEE quotient, on this device.
+extern "C" hipError_t se3d_launch_selftest_shared_quotient(unsigned long long *d_out, unsigned long long n, hipStream_t st);
+int se3d_selftest_shared_quotient(se3d_ctx *c, uint64_t n, uint64_t *mismatches, uint64_t *skipped) {
+  if (!c || !mismatches || !skipped) return SE3D_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  unsigned long long *d = nullptr, h[2] = {0, 0};
+  HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d), sizeof(h)));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(h), c->stream);
+  if (e == hipSuccess) e = se3d_launch_selftest_shared_quotient(d, (unsigned long long)n, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  HIPCHK(c, e);
+  *mismatches = h[0]; *skipped = h[1];
+  return SE3D_OK;
+}
+
 // Diagnostic: camera-column chunks of the pair table in this context (0: the whole table is materialised).
 int se3d_get_pair_chunks(se3d_ctx *c) { return c ? c->D.d.pair_chunks : SE3D_ERR_ARG; }
 

@@ -856,10 +856,10 @@ __global__ __launch_bounds__(256, 3) void se3d_k_pairs_tiled(Se3dDev D, const in
 }
 
 // =============================================================================================================
-// row E, large P, second form ("rows"): one workgroup per (48-row tile of det_a, camera pair, frame), looping over 32-column tiles
+// row E, large P ("rows"): one workgroup per (row tile of det_a, camera pair, frame), looping over 32-column tiles
 // of det_b.  A wavefront carries TWO det_a rows (lanes 0-31 / 32-63) x 32 det_b columns:
 //   * the det_b side (epipolar line F^T p2, its norm and shared reciprocal, the point, the validity weight: 8 floats per joint)
-//     stays in REGISTERS for a group of 6 joints while the wavefront walks its 12 rows;
+//     stays in REGISTERS for a group of 6 joints while the wavefront walks its rows;
 //   * the det_a side is read from LDS with two (half-wave uniform) addresses per instruction instead of the 16 distinct ds_read_b128
 //     per joint of the 4x4-register-tile kernel;
 //   * 124 VGPRs, no scratch, 38 KB of LDS: four workgroups (16 wavefronts) per CU instead of two to three.
@@ -867,12 +867,39 @@ __global__ __launch_bounds__(256, 3) void se3d_k_pairs_tiled(Se3dDev D, const in
 // double-buffered LDS tile before phase k computes, the global loads of phase k + 2 are in flight meanwhile, the table entries of a
 // finished column tile are stored one phase late, and the one barrier per phase orders LDS only.  Measured at 256 cam x 128 p per 16
 // frames (profiles/r2): 4x4 tiles 85.8 ms; rows with 9 / 8 joint groups and __syncthreads() 67.0 ms (of which, by doubling the item loop:
-// 39 ms items at the microbenchmarked issue floor, 28 ms everything else); this form 59.6 ms.
-// Same per-element float expressions in the same order (FAST: shared-reciprocal Markstein divide under the block-uniform range guard,
+// 39 ms items at the microbenchmarked issue floor, 28 ms everything else); the round-2 form 59.6 ms.
+// Same per-element float expressions in the same order (FAST: shared-reciprocal divide under the block-uniform range guard,
 // else IEEE divide) -> the table is bit-identical to every other pair kernel.
+//
+// Round 5 (profiles/r5/README.md section 1; per launch of 64 frames x 2040 pairs: 16.0 - 16.8 ms in round 4):
+//   * the two quotients of an item take THREE instructions each instead of five (se3d_div_shared): with y = RN(1 / b) staged per operand,
+//     q0 = RN(a y), r = fma(-b, q0, a), q = fma(r, y, q0) is the correctly rounded a / b.  Why ONE correction suffices (rounds 2 - 4 spent two,
+//     following the textbook sequence "1.5 ulp -> faithful -> correct"): write x = a / b in [f, f + u), u = ulp, and b y = 1 + eta with
+//     |eta| <= 2^-24 / sig(y).  Then |a y - x| = x |eta| < u, so q0 is at most 1.5 u from x, and the value the last FMA rounds is
+//     x + (r / b) eta + (rounding of r, when q0 is not faithful and r needs 25 bits): off by less than 4 x 2^-24 u.  (A) x farther than that from
+//     the midpoint f + u / 2: the rounding is x's.  (B) x within 4 x 2^-24 u of the midpoint: a q0 outside {f, f + u} would need
+//     x |eta| >= u (1 - 4 x 2^-24), i.e. sig(q) / (2 sig(y)) >= 1 - 2^-22, i.e. sig(y) <= 1 + 2^-23 with |eta| at its bound — b = 2^24 - k
+//     in units of its ulp gives |eta| 2^24 = 1 - k (k + 1) 2^-24 for odd k (tiny for even k), and the inequality leaves k = 1: the all-ones
+//     significand, which the staging guard excludes (se3d_safe_rcp) — so q0 is FAITHFUL there, r is exact and Markstein's theorem (1990;
+//     Muller et al., Handbook of Floating-Point Arithmetic, ch. 4: a faithful quotient corrected with the correctly rounded reciprocal) gives
+//     the correctly rounded quotient.  Every operand is 0 or inside [2^-30, 2^30] (staging guard) and float32 denormals are preserved
+//     (.amdhsa_float_denorm_mode_32 3), so no residual loses a bit to underflow.  Checked against the IEEE quotient: on the device on 2^33
+//     operand pairs (se3d_selftest_shared_quotient, tests/test_gpu_stage1.py); on the CPU with exact float32 arithmetic on all 2^23
+//     numerators of a binade for divisors at the edges of the guard, on 7 M quotients constructed to lie 2^-25 .. 2^-22 ulp from a midpoint and
+//     on random operands (tests/test_shared_quotient_cpu.py).  18 instead of 22 vector instructions per item: 16.8 -> 15.2 ms;
+//   * the row tiles of a camera are BALANCED (ceil(n_a / 48) tiles of equal size, the rows of a tile dealt evenly to the four wavefronts): the
+//     bench scenes hold 65 - 110 detections per camera (mean 90, not 128), and 40 % of the cameras used to need a third tile of <= 14 rows whose
+//     workgroup staged the whole det_b side for one busy wavefront;
+//   * an operand's sqrtf and 1 / nrm are the instruction-level cores of the IEEE sequences inside their range (se3d_sqrt_core, se3d_div_core):
+//     staging is a quarter of the kernel's vector instructions (the det_b side is staged once per row tile).
+// What did NOT pay (measured, same section): one row x 64 columns per wavefront with the validity as scalar branch + lane mask (19 instead of 22
+// instructions per item, but 64-column tiles compute 128 columns for every camera: 20.3 ms), and one 512-thread workgroup per camera pair with
+// all rows in a single tile (det_b staged once; 75 KB of LDS: one workgroup per CU, 24.7 ms).  The kernel is bound by vector issue AND the LDS
+// array together (8 LDS cycles per wave-item against 36 vector-issue cycles on each of four SIMDs).
 // =============================================================================================================
 #define RB_ROWS 48
 #define RB_COLS 32
+#define RB_NT 256                       // threads per workgroup
 // LDS rows are padded by one operand (32 B = 8 banks): the staging threads of a wavefront write the SAME detection slot of consecutive
 // joints, and an unpadded joint stride (48 or 32 operands) is a multiple of 128 B — every lane on the same four banks (17-way / 6-way
 // conflicts, 29 % of the LDS busy cycles in profiles/r2/pmc_lds_256cam128p_rows.json before the padding)
@@ -884,12 +911,29 @@ __global__ __launch_bounds__(256, 3) void se3d_k_pairs_tiled(Se3dDev D, const in
 #define RB_JLAST (SE3D_NKP % RB_JH ? SE3D_NKP % RB_JH : RB_JH)   // joints of the last phase
 struct __align__(16) RowOp { float lx, ly, lz, nrm, x, y, rcp, w; };
 
+// a / b, correctly rounded, from y = RN(1 / b) (see above): 3 instructions
+__device__ __forceinline__ float se3d_div_shared(float a, float b, float y) {
+  const float q0 = a * y;
+  const float r = __builtin_fmaf(-b, q0, a);
+  return __builtin_fmaf(r, y, q0);
+}
+
+// Operand of one (detection, joint): epipolar line, |(lx, ly)|, its reciprocal, the point, the validity weight.  sqrtf and 1 / nrm are the
+// IEEE results: inside the range in which the instruction-level cores are the IEEE sequences (se3d_sqrt_core / se3d_div_core, checked by
+// se3d_selftest_exact_math) the cores, else the library calls.
 __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float px, float py, bool valid, bool &unsafe) {
   RowOp o;
   o.lx = lx; o.ly = ly; o.lz = lz;
-  o.nrm = sqrtf(lx * lx + ly * ly);
+  const float ss = lx * lx + ly * ly;
+  const unsigned us = __float_as_uint(ss);
+  if (us >= SE3D_EXACT_LO && us <= SE3D_EXACT_HI) {   // then nrm lies in [2^-30, 2^30]: se3d_safe_rcp's exponent test holds
+    o.nrm = se3d_sqrt_core(ss);
+    o.rcp = (__float_as_uint(o.nrm) & 0x7fffffu) != 0x7fffffu ? se3d_div_core(1.f, o.nrm) : 0.f;
+  } else {
+    o.nrm = sqrtf(ss);
+    o.rcp = se3d_safe_rcp(o.nrm);
+  }
   o.x = px; o.y = py;
-  o.rcp = se3d_safe_rcp(o.nrm);
   o.w = valid ? 1.f : 0.f;
   unsafe |= valid && !(o.rcp != 0.f && se3d_in_safe_range(lx) && se3d_in_safe_range(ly) && se3d_in_safe_range(lz) && se3d_in_safe_range(px) && se3d_in_safe_range(py));
   // An unusable (detection, joint) is all zeros with a unit norm: every distance it is the LINE or the POINT of comes out as exactly 0, so the
@@ -910,7 +954,9 @@ __device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS_P], c
   RowOp a = A[jbase][row0];
 #pragma unroll
   for (int r = 0; r < RB_ROWS / 8; ++r) {
-    if (2 * r >= nrows_left) break;  // wave-uniform (scalar): both rows of the pair lie beyond the last detection of camera a
+    // wave-uniform (scalar) skip of the row pairs beyond the wavefront's last row.  NOT a `break`: the early exit made the compiler copy the
+    // other accumulators to the exit block's registers before every row pair (five 64-bit moves per six items).
+    if (2 * r < nrows_left) {
     const int row = row0 + 2 * r;
 #pragma unroll
     for (int jj = 0; jj < JN; ++jj) {
@@ -918,11 +964,12 @@ __device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS_P], c
       const RowOp an = A[last_j ? jbase : jbase + jj + 1][last_j ? (last_r ? row0 : row + 2) : row];
       const float n1 = fabsf(b[jj].x * a.lx + (b[jj].y * a.ly + a.lz));
       const float n2 = fabsf(a.x * b[jj].lx + (a.y * b[jj].ly + b[jj].lz));
-      const float d1 = se3d_div_markstein(n1, a.nrm, a.rcp), d2 = se3d_div_markstein(n2, b[jj].nrm, b[jj].rcp);
+      const float d1 = se3d_div_shared(n1, a.nrm, a.rcp), d2 = se3d_div_shared(n2, b[jj].nrm, b[jj].rcp);
       const float sacc = __builtin_fmaf(d1, b[jj].w, d2 * a.w);   // = d1 + d2 for a joint both sides have, exactly 0 otherwise (se3d_rowop)
       acc[r] += (double)sacc;
       asm volatile("" : "+v"(acc[r]) : : "memory");  // the item is complete (accumulated) before the fence; the next item's LDS read comes after it
       a = an;
+    }
     }
   }
 }
@@ -953,14 +1000,20 @@ __device__ __forceinline__ void se3d_lds_barrier() { asm volatile("s_waitcnt lgk
 #endif
 // list0 / slot0 / fbase: the workgroups of grid row y work on pair list0 + y of `pair_ab` and write slot slot0 + y of the frame's pair slots;
 // frame = fbase + blockIdx.z.  Whole table: list0 = slot0 = 0 over all pairs; column chunks (Se3dPairPlan): one launch per chunk.
-__global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, const int2 *__restrict__ pair_ab, int list0, int slot0, int fbase) {
+// gridDim.x = row tiles a camera can need: ceil(P / RB_ROWS).
+__global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, const int2 *__restrict__ pair_ab, int list0, int slot0, int fbase) {
   const int N = D.d.N, P = D.d.P, np = D.d.pair_stride;
   const int f = fbase + blockIdx.z;
   const int2 ab = pair_ab[list0 + blockIdx.y];
   const int pr = slot0 + blockIdx.y;
-  const int na = D.nvalid[f * N + ab.x], nb = D.nvalid[f * N + ab.y];
-  const int p0 = blockIdx.x * RB_ROWS;
-  if (p0 >= na || nb == 0) return;
+  const int na_all = D.nvalid[f * N + ab.x], nb = D.nvalid[f * N + ab.y];
+  const int ntiles = (na_all + RB_ROWS - 1) / RB_ROWS;               // balanced row tiles of the camera's detections
+  if ((int)blockIdx.x >= ntiles || nb == 0) return;
+  const int tile_rows = ((na_all + ntiles - 1) / ntiles + 1) & ~1;   // even: a wavefront carries row pairs
+  const int p0 = blockIdx.x * tile_rows;
+  if (p0 >= na_all) return;
+  const int na = min(na_all, p0 + tile_rows);                        // rows p0 .. na - 1 are this tile's
+  const int nrw = (((na - p0) + 3) / 4 + 1) & ~1;                    // rows per wavefront (even, <= RB_ROWS / 4): the tile's rows dealt evenly
   __shared__ RowOp A[SE3D_NKP][RB_ROWS_P];  // det_a side, all joints: staged once per workgroup (26 KB)
   __shared__ RowOp Bc[2][RB_JH][RB_COLS_P];  // det_b side of a (column tile, joint group) phase, double-buffered (2 x 6 KB)
   __shared__ unsigned M1[RB_ROWS], M2[2][RB_COLS];
@@ -973,7 +1026,7 @@ __global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, cons
   const size_t baseA = ((size_t)(f * N + ab.x)) * P, baseB = ((size_t)(f * N + ab.y)) * P;
   if (tid == 0) { s_unsafe_a = 0; s_unsafe_b[0] = 0; s_unsafe_b[1] = 0; s_unsafe_b[2] = 0; }
   if (tid <= SE3D_NKP) INV[tid] = tid ? 1.0 / (double)tid : 0.0;
-  constexpr int NA_ROUNDS = (RB_ROWS * SE3D_NKP + 255) / 256;
+  constexpr int NA_ROUNDS = (RB_ROWS * SE3D_NKP + RB_NT - 1) / RB_NT;
   float4 a4[NA_ROUNDS];   // all global loads of the det_a side first (in flight across the barrier): one memory latency, not five in a row
 #pragma unroll
   for (int u = 0; u < NA_ROUNDS; ++u) {
@@ -994,8 +1047,8 @@ __global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, cons
     }
     if (unsafe) s_unsafe_a = 1;
   }
-  const int row0 = wave * (RB_ROWS / 4) + half;             // this lane's first row inside the tile; row pairs r: row0 + 2 r
-  const int nrows_left = na - p0 - wave * (RB_ROWS / 4);    // rows of this wavefront that exist (wave-uniform)
+  const int row0 = wave * nrw + half;                        // this lane's first row inside the tile; row pairs r: row0 + 2 r
+  const int nrows_left = min(nrw, na - p0 - wave * nrw);     // rows of this wavefront that exist (wave-uniform)
   double *out = D.pair + ((size_t)f * np + pr) * P * P;
   double acc[RB_ROWS / 8];
   unsigned m2 = 0u;
@@ -1017,7 +1070,7 @@ __global__ __launch_bounds__(256, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, cons
 #pragma unroll
     for (int r = 0; r < RB_ROWS / 8; ++r) {
       const int row = row0 + 2 * r, p = p0 + row;
-      if (p < na && q < nb) {
+      if (2 * r < nrw && p < na && q < nb) {   // (row pairs beyond the wavefront's share belong to the next wavefront)
         const int n = __popc(M1[row] & m2);
         out[(size_t)p * P + q] = n > 0 ? se3d_div_count(acc[r], n, INV[n]) : -1.0;
       }
@@ -3594,6 +3647,35 @@ extern "C" hipError_t se3d_launch_selftest_exact_math(unsigned long long *d_out,
   return hipGetLastError();
 }
 
+// Self-test of the rows kernel's quotient (se3d_div_shared on the shared reciprocal se3d_safe_rcp) against the device's IEEE
+// quotient (se3d_selftest_shared_quotient).  Operands as the kernel has them under its range guard: divisors = line norms in [2^-30, 2^30]
+// whose significand is not all ones (others give y_h = 0 and take the IEEE path: counted in out[1] as skipped), numerators zero (every 64th
+// pair) or anywhere in [2^-83, 2^60] — a third of them within 2^12 of the divisor's magnitude, where quotients near 1 exercise the
+// binade boundary.  out[0]: mismatches, out[1]: pairs skipped.
+__global__ __launch_bounds__(256) void se3d_k_selftest_shared_quotient(unsigned long long *out, unsigned long long n) {
+  const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x, nthr = (unsigned long long)gridDim.x * 256;
+  unsigned long long bad = 0, skipped = 0;
+  for (unsigned long long i = tid; i < n; i += nthr) {
+    unsigned long long z = (i + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;   // splitmix64
+    z ^= z >> 30; z *= 0x94D049BB133111EBull; z ^= z >> 27; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 31;
+    const unsigned zb = (unsigned)(z >> 32), za = (unsigned)z;
+    const float b = __uint_as_float(0x30800000u + zb % (0x4e800000u - 0x30800000u + 1u));          // [2^-30, 2^30]
+    float a;
+    if (i % 3ull == 0ull) a = __uint_as_float((__float_as_uint(b) & 0x7f800000u) - (12u << 23) + za % (24u << 23));   // within 2^-12 .. 2^12 of b's binade
+    else a = __uint_as_float(0x16000000u + za % (0x5d800000u - 0x16000000u + 1u));                   // [2^-83, 2^60]
+    if ((i & 63ull) == 63ull) a = 0.f;
+    const float y = se3d_safe_rcp(b);
+    if (y == 0.f) { ++skipped; continue; }
+    bad += __float_as_uint(se3d_div_shared(a, b, y)) != __float_as_uint(a / b);
+  }
+  if (bad) atomicAdd(&out[0], bad);
+  if (skipped) atomicAdd(&out[1], skipped);
+}
+extern "C" hipError_t se3d_launch_selftest_shared_quotient(unsigned long long *d_out, unsigned long long n, hipStream_t st) {
+  hipLaunchKernelGGL(se3d_k_selftest_shared_quotient, dim3(256 * 64), dim3(256), 0, st, d_out, n);
+  return hipGetLastError();
+}
+
 // Diagnostic (se3d_selftest_dlt32): the float32 DLT solve of the second pass — triangulate() + calcReprojectionError() of the reference,
 // S3D:425-465 — on caller-provided systems, one system per lane; compared bit for bit with the CPU restatement in tests/test_gpu_exact32.py.
 __global__ __launch_bounds__(64) void se3d_k_selftest_dlt32(int n_sys, int n, const float *__restrict__ Rt, const float *__restrict__ pts, int weighted,
@@ -3690,7 +3772,7 @@ extern "C" void se3d_launch_normalize_keep(const Se3dDev &D, hipStream_t st) {  
   hipLaunchKernelGGL(se3d_k_normalize, dim3(D.d.N, D.d.B), dim3(256), 0, st, D, 3);
 }
 extern "C" void se3d_launch_pair_block(const Se3dDev &D, const int2 *d_ab_one, int frame, hipStream_t st) {   // se3d_get_pair_costs under column chunks
-  hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((D.d.P + RB_ROWS - 1) / RB_ROWS, 1, 1), dim3(256), 0, st, D, d_ab_one, 0, 0, frame);
+  hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((D.d.P + RB_ROWS - 1) / RB_ROWS, 1, 1), dim3(RB_NT), 0, st, D, d_ab_one, 0, 0, frame);
 }
 
 // The fused front kernel (se3d_k_front_fused) for this launch: threads per workgroup (0: the separate kernels), LDS table capacity, dump flag.
@@ -3771,7 +3853,7 @@ extern "C" int se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStre
     if (e_tile && atoi(e_tile) == 22) hipLaunchKernelGGL((se3d_k_normalize_pairs_tiles<2, 2>), dim3(B), dim3(256), lds, st, D, pair_ab);
     else hipLaunchKernelGGL(se3d_k_normalize_pairs, dim3(B), dim3(256), lds, st, D, pair_ab);
   } else if (tiled && !(e_pairs && strcmp(e_pairs, "tiled") == 0)) {  // large P: two rows x 32 columns per wavefront (default)
-    hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((P + RB_ROWS - 1) / RB_ROWS, D.d.npairs, B), dim3(256), 0, st, D, pair_ab, 0, 0, 0);
+    hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((P + RB_ROWS - 1) / RB_ROWS, D.d.npairs, B), dim3(RB_NT), 0, st, D, pair_ab, 0, 0, 0);
   } else if (tiled) {                                                  // SE3D_PAIRS=tiled: the 4x4 register-tile kernel (A/B)
     const int tiles = (P + PT - 1) / PT;
     hipLaunchKernelGGL(se3d_k_pairs_tiled, dim3(tiles * tiles, D.d.npairs, B), dim3(256), 0, st, D, pair_ab);
@@ -3799,7 +3881,7 @@ extern "C" int se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStre
     for (int j = 0; j < m; ++j) {
       const int n_pairs = plan->list0[j + 1] - plan->list0[j], slot0 = (j & 1) * cap;
       if (sw != st && j >= 2) (void)hipStreamWaitEvent(st, ev_s[j - 2], 0);
-      hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((P + RB_ROWS - 1) / RB_ROWS, n_pairs, B), dim3(256), 0, st, D, pair_ab, plan->list0[j], slot0, 0);
+      hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((P + RB_ROWS - 1) / RB_ROWS, n_pairs, B), dim3(RB_NT), 0, st, D, pair_ab, plan->list0[j], slot0, 0);
       if (sw != st) {
         (void)hipEventRecord(ev_p[j], st);
         (void)hipStreamWaitEvent(sw, ev_p[j], 0);

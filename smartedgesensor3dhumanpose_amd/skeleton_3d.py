@@ -283,6 +283,13 @@ class Skeleton3D:
         self._chk(self._L.se3d_selftest_exact_math(C.c_void_p(self._h), C.c_uint64(int(n_div)), C.byref(a), C.byref(b)), "se3d_selftest_exact_math")
         return int(a.value), int(b.value)
 
+    def selftest_shared_quotient(self, n=1 << 33):
+        """(mismatches, skipped pairs) of the large-rig pair kernel's three-instruction quotient on the shared reciprocal against the device's
+        IEEE quotient over n operand pairs of the kernel's guarded range."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.se3d_selftest_shared_quotient(C.c_void_p(self._h), C.c_uint64(int(n)), C.byref(a), C.byref(b)), "se3d_selftest_shared_quotient")
+        return int(a.value), int(b.value)
+
     def pair_chunks(self):
         """Camera-column chunks of the pair table in this context (0: the whole table is materialised)."""
         return int(self._L.se3d_get_pair_chunks(C.c_void_p(self._h)))

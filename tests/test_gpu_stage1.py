@@ -409,6 +409,17 @@ def test_exact_sqrt_and_divide_cores_match_ieee_on_the_device(extr_rig):
     assert bad_sqrt == 0 and bad_div == 0, (bad_sqrt, bad_div)
 
 
+def test_shared_reciprocal_quotient_matches_ieee_on_the_device(extr_rig):
+    """The large-rig pair kernel (se3d_k_pairs_rows) forms calcCost's quotients `abs(p.dot(l)) / l.head(2).norm()` (S3D:358-361) in three
+    instructions from the line norm's correctly rounded reciprocal (se3d_div_shared): 2^33 operand pairs of the kernel's guarded range
+    (divisors in [2^-30, 2^30], numerators zero or in [2^-83, 2^60], a third of them within 2^12 of the divisor) against the device's IEEE
+    quotient, bit for bit; tests/test_shared_quotient_cpu.py holds the constructed worst cases."""
+    node = _node(extr_rig, max_frames=1, max_det_per_cam=8, max_hyp=8)
+    bad, skipped = node.selftest_shared_quotient(1 << 33)
+    node.close()
+    assert bad == 0 and skipped < (1 << 33) // 1_000_000, (bad, skipped)
+
+
 def test_pair_table_column_chunks_equal_the_whole_table(monkeypatch, oracle, demo_params):
     """Large rigs keep the pair table as camera-column chunks (Se3dPairPlan): the pair kernel fills chunk j while the sweep walks chunk j - 1.
     A 48-camera, 24-person scene (per-camera sweep launches, 8 chunks by default) through the whole table (SE3D_PAIR_CHUNKS=0), the default,
