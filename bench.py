@@ -179,12 +179,9 @@ def bench_parity(name, rig, seqs, n_seq=4, device=0, omp_threads=1, max_steps=No
     # stage 2: the resident walk (the bench's default path) vs the oracle's pose_prior on the same stage-1 persons
     ts = [100.0 + (i + 1) / 30.0 for i in range(T_)]
     if w["max_hyp"] <= 16:   # the kernel form the headline runs (one wavefront per sequence, three persons per LM wavefront); few sequences would default to the workgroup form
-        os.environ["SE3D_WALK_SHAPE"] = "wave"
-    try:
-        node.run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in range(T_)])
-        node.sync()
-    finally:
-        os.environ.pop("SE3D_WALK_SHAPE", None)
+        node.set_options(walk_shape="wave")
+    node.run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in range(T_)])
+    node.sync()
     oras = [O.PosePrior(node.params) for _ in range(S_)]
     d2, ids_ok, it_ok, steps2, n_ref = [], 0, 0, 0, 0
     for k, t in enumerate(ts):
@@ -257,7 +254,7 @@ def bench_latency_b1(rig, seq, name, device=0, frames_timed=200):
             "host_call_ms_direct_launches": {"se3d_triangulate": round(p1 * 1e3, 4), "se3d_refine": round(p2 * 1e3, 4), "frame": round((p1 + p2) * 1e3, 4)},
             "device_ms": {"stage1": round(d1, 4), "stage2": round(d2, 4), "frame": round(d1 + d2, 4),
                           "by_kernel_group": {k: round(dev[k][0] / frames_timed, 4) for k in STAGE1_KERNELS + STAGE2_KERNELS}},
-            "note": "host_call_ms: synchronous C-ABI calls incl. H2D / D2H of pageable buffers, each call one hipGraph replay (SE3D_GRAPH=0: direct launches); "
+            "note": "host_call_ms: synchronous C-ABI calls incl. H2D / D2H of pageable buffers, each call one hipGraph replay (options.graph = -1: direct launches); "
                     "device_ms: HIP events around the kernel groups of directly launched calls (the second pass, host_call_ms_direct_launches; reference call sites "
                     "S3D:1069, PP:505); the oracle's ms per frame: cpu_baseline.per_stage_ms"}
 
@@ -299,21 +296,16 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
     world = dist.get_world_size() if dist is not None else 1
     memory_plan(name, NC, B, exchange=dist is not None, free_bytes=torch.cuda.mem_get_info(local_rank)[0])   # fails fast, with the figures
     nodes = []
-    # More than four contexts of a large rig: ONE stream per context (SE3D_NO_HI_STREAM, read by se3d_create).  The second, high-priority stream a
-    # large-rig context owns for its sweep chains buys nothing once this many contexts interleave (5 contexts: 28.6 k without, 27.9 - 28.7 k with),
-    # and 2 x 6 streams collapse to 11.6 - 15.0 k skeletons/s (profiles/r4/README.md section 7).
-    one_stream = w["n_cam"] >= 128 and NC > 4 and "SE3D_NO_HI_STREAM" not in os.environ
-    if one_stream:
-        os.environ["SE3D_NO_HI_STREAM"] = "1"
-    try:
-        for seqs in seqs_per_ctx:   # every rank (and every context) owns its own sequences: weak scaling, no data-path collective
-            frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s
-            nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank)
-            nd_.stage(frames)  # inputs resident in HBM before the timed region
-            nodes.append(nd_)
-    finally:
-        if one_stream:
-            del os.environ["SE3D_NO_HI_STREAM"]
+    # More than four contexts of a large rig: ONE stream per context (se3d_options.hi_priority_stream = -1 at se3d_create_ex).  The second,
+    # high-priority stream a large-rig context owns for its sweep chains buys nothing once this many contexts interleave (5 contexts: 28.6 k
+    # without, 27.9 - 28.7 k with), and 2 x 6 streams collapse to 11.6 - 15.0 k skeletons/s (profiles/r4/README.md section 7).
+    one_stream = w["n_cam"] >= 128 and NC > 4 and not args.hi_streams
+    for seqs in seqs_per_ctx:   # every rank (and every context) owns its own sequences: weak scaling, no data-path collective
+        frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s
+        nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank,
+                         options=dict(hi_priority_stream=-1) if one_stream else None)
+        nd_.stage(frames)  # inputs resident in HBM before the timed region
+        nodes.append(nd_)
     node = nodes[0]
     dt_frame = 1.0 / 30.0
     H = node.limits.max_hyp
@@ -326,12 +318,12 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         # (shard.SkeletonExchange, covered by tests/test_distributed_gloo.py with two gloo ranks).
         # person slots per frame carried by the exchange: crowded scenes publish spurious extra persons (256cam128p: up to ~150 per frame),
         # so only the small workloads trim the slots below the hypothesis capacity (checked: truncation is an assertion, not a silent loss)
-        XH = min(H, w["n_persons"] + 2) if stage2 and fused_walk and w["n_persons"] <= 16 else H   # slot form (SE3D_BENCH_EXCHANGE_SLOTS=1, large workloads)
+        XH = min(H, w["n_persons"] + 2) if stage2 and fused_walk and w["n_persons"] <= 16 else H   # slot form (--exchange-slots, large workloads)
         # Small workloads with the fused walk: the DENSE form (se3d_pack_stage2_walk_device_dense) — the published persons back to back +
         # per-frame offsets, capacity n_persons + 0.25 persons per frame; what does not fit is counted in the block, checked below on every
         # rank for every rank's block.  At 16cam6p a rank produces ~51 GB/s of final skeletons; the all-gather delivers (world - 1) x that
         # into every GPU, so padding slots ([frame][n_persons + 2] before: +28 %) decide whether the exchange hides behind the step at 8 GPUs.
-        dense_cap = int(math.ceil(B * (w["n_persons"] + 0.25))) if stage2 and fused_walk and w["n_persons"] <= 16 and not os.environ.get("SE3D_BENCH_EXCHANGE_SLOTS") else 0
+        dense_cap = int(math.ceil(B * (w["n_persons"] + 0.25))) if stage2 and fused_walk and w["n_persons"] <= 16 and not args.exchange_slots else 0
         streams = [torch.cuda.ExternalStream(nd_.stream_handle()) for nd_ in nodes]
         ex = shard.SkeletonExchange(dist, NC, (dense_cap if dense_cap else B * XH) * psz, B + 2 if dense_cap else B, torch.device("cuda", local_rank), streams)
 
@@ -349,7 +341,7 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
     # steps behind it are chains of small latency-bound launches.  With all contexts in the same phase the GPU alternates between
     # saturated and nearly idle; chaining the pair kernels of the contexts by events (one at a time, round robin) staggers the contexts so
     # that the latency-bound chains of two contexts run under the pair kernel of the third.
-    chain = w["n_cam"] >= 128 and NC > 1 and not os.environ.get("SE3D_BENCH_NO_CHAIN")
+    chain = w["n_cam"] >= 128 and NC > 1 and not args.no_chain
     if chain:
         tstreams = [torch.cuda.ExternalStream(nd_.stream_handle()) for nd_ in nodes] if ex is None else streams
         pair_done = [None] * NC
@@ -479,7 +471,7 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
     # untimed accounting pass: published skeletons of one (steady-state) step
     s1 = [r for nd_ in nodes for r in nd_.fetch_stage1(B)]
     n_s1 = sum(r.n_persons for r in s1)
-    if not os.environ.get("SE3D_BENCH_ABLATION"):   # ablation: kernel-timing builds that write wrong tables on purpose (tools/tmp)
+    if not args.ablation:   # ablation: kernel-timing builds that write wrong tables on purpose (tools/tmp)
         assert not any(r.flags & pm.FLAG_HYP_OVERFLOW for r in s1), "hypothesis capacity (max_hyp) exceeded: results truncated"
         assert not any(r.flags & pm.FLAG_ASSIGNMENT_FAILED for r in s1), "the sweep's Hungarian hit its iteration guard"
     if stage2:
@@ -512,6 +504,7 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         "max_hyp_per_frame": int(max(r.n_hyp for r in s1)), "max_published_per_frame": int(max_pub[0]), "exchange_verified": exchange_ok,
         "lm_iterations_mean": float(np.mean(lm_iters)) if lm_iters else None, "params": node.params, "pair_chunks": node.pair_chunks(),
         "second_pass_joints": n_second_pass, "second_pass_fraction": n_second_pass / max(1.0, 17.0 * n_s1 / NC),
+        "sweep_stats": nodes[0].sweep_stats(),   # (camera steps of the per-camera sweep with hypotheses and detections, those that ran the Hungarian): large rigs
         "exchange": None if ex is None else {"form": "dense: published persons back to back + per-frame offsets" if dense_cap else "[frame][%d person slots] + counts" % XH,
                                              "bytes_per_rank_per_step": int(NC * (ex.sp + 4 * ex.sc))},
         "exchange_ms_per_step": None if exchange_ms is None else round(exchange_ms[0], 4), "exchange_ms_max": None if exchange_ms is None else round(exchange_ms[1], 4),
@@ -867,6 +860,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-only", action="store_true", help="only the B = 1 latency block (one 16cam6p frame per call), printed as its own JSON line")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity / latency blocks of a default run")
+    ap.add_argument("--hi-streams", action="store_true", help="keep the second (high-priority) stream of large-rig contexts also with more than four contexts per GPU")
+    ap.add_argument("--exchange-slots", action="store_true", help="diagnostic: exchange the small workloads in the [frame][slot] form instead of the dense form")
+    ap.add_argument("--no-chain", action="store_true", help="diagnostic: do not chain the pair kernels of the contexts by events at 256 cameras")
+    ap.add_argument("--ablation", action="store_true", help="diagnostic: kernel-timing builds that write wrong tables on purpose (tools/tmp): skip the result checks")
+    ap.add_argument("--seed-rank", type=int, default=None, help="diagnostic: run another rank's synthetic scenes on this GPU")
+    ap.add_argument("--secondary-last", action="store_true", help="measure 256cam128p after the headline instead of first")
+    ap.add_argument("--debug-mem", action="store_true")
+    ap.add_argument("--hyp-deadline-s", type=float, default=900.0, help="deadline of the hypothesis-shard block (a collective that never returns ends the run with exit code 3)")
+    ap.add_argument("--no-parity-256", action="store_true", help="skip the one-frame 256cam128p oracle comparison of the parity block")
     ap.add_argument("--hyp-shard", action="store_true", help="with --workload 256cam128p under the launcher: also run the hypothesis-shard block "
                     "(north_star config 5 as a latency mode) that a default multi-rank run ends with")
     args = ap.parse_args()
@@ -892,7 +894,7 @@ def main():
     w = WORKLOADS[headline]
     S_, T_ = args.seqs or w["seqs"], args.tsteps
     NC = args.contexts or w["contexts"]
-    seed_rank = int(os.environ.get("SE3D_BENCH_SEED_RANK", rank))  # diagnostic: run another rank's synthetic scenes on this GPU (tools/check_rank_scenes.sh)
+    seed_rank = rank if args.seed_rank is None else args.seed_rank  # diagnostic: run another rank's synthetic scenes on this GPU (tools/check_rank_scenes.sh)
 
     # ---- scenes first: worker processes are forked before this process initialises the GPU ----
     import multiprocessing as mp
@@ -941,8 +943,8 @@ def main():
 
     # Order of a default run: the 256cam128p measurement FIRST, on the fresh device (its six contexts take 231 of the 288 GB — 272 in round 2, whole pair tables; behind the
     # headline's twelve contexts the same measurement came out ~8 % lower, behind the streaming contexts at half speed — measured, cause
-    # not isolated), then the headline, the serial pass and the streaming pass.  SE3D_BENCH_SECONDARY_LAST=1 restores the old order.
-    sec_first = want_secondary and not os.environ.get("SE3D_BENCH_SECONDARY_LAST")
+    # not isolated), then the headline, the serial pass and the streaming pass.  --secondary-last restores the old order.
+    sec_first = want_secondary and not args.secondary_last
     if sec_first:
         run_secondary()
     head = None
@@ -960,7 +962,7 @@ def main():
     seqs_stream = seqs_head[: max(1, min(args.stream_contexts, NC))]
     seqs_par = seqs_head[0][:4]
     del seqs_head
-    if os.environ.get("SE3D_BENCH_DEBUG_MEM"):
+    if args.debug_mem:
         free, total = torch.cuda.mem_get_info()
         print("free HBM after the headline / serial passes: %.1f of %.1f GB" % (free / 1e9, total / 1e9), file=sys.stderr)
     if want_secondary and not sec_first:
@@ -979,7 +981,7 @@ def main():
         def hyp_run():
             torch.cuda.set_device(local_rank)   # the current device is per thread
             return run_hypothesis_shard("256cam128p", _gen_one((256, 128, T_, 0)), rig_h, 2, dist, local_rank)
-        hyp, hyp_error, hyp_hung = guarded(hyp_run, float(os.environ.get("SE3D_BENCH_HYP_DEADLINE_S", "900")), "hypothesis shard")
+        hyp, hyp_error, hyp_hung = guarded(hyp_run, args.hyp_deadline_s, "hypothesis shard")
     if rank == 0:
         main_res = head or serial
         def load(fn):   # committed counter summaries: this round's when present, else the previous round's
@@ -1018,6 +1020,9 @@ def main():
                                     "bit-identical to the oracle): ill-conditioned systems, reprojection errors near / above the outlier threshold, wide covariances; "
                                     "its time is inside the `triangulate` kernel group"},
         }
+        if main_res["sweep_stats"][0]:   # large rigs (per-camera sweep launches): how often the sweep ran the Hungarian
+            line["sweep_steps_running_the_hungarian"] = {"steps": main_res["sweep_stats"][0], "hungarian": main_res["sweep_stats"][1],
+                                                         "fraction": round(main_res["sweep_stats"][1] / main_res["sweep_stats"][0], 6)}
         if dist is not None:   # what lets an N > 1 run be read (round 4): the all-gather's own time, the step without it, what RCCL reports
             line["exchange_ms_per_step"] = main_res["exchange_ms_per_step"]
             line["exchange_ms_max"] = main_res["exchange_ms_max"]
@@ -1063,6 +1068,10 @@ def main():
                                  "skeletons_per_step_per_gpu": sec["n_skel_local"], "max_hypotheses_per_frame": sec["max_hyp_per_frame"],
                                  "target": "north_star: >= 1e5 skeletons/s on 8 GPUs = 12 500 per GPU", "exchange_verified": sec["exchange_verified"],
                                  "second_pass_fraction": round(sec["second_pass_fraction"], 6),
+                                 "sweep_steps_running_the_hungarian": {"steps": sec["sweep_stats"][0], "hungarian": sec["sweep_stats"][1],
+                                                                       "fraction": round(sec["sweep_stats"][1] / max(1, sec["sweep_stats"][0]), 6),
+                                                                       "note": "context 0, all passes: camera steps of the sweep (S3D:588-674) that met hypotheses and detections / those "
+                                                                               "whose feasibility mask was ambiguous (S3D:628-634: the Hungarian runs on the full cost matrix)"},
                                  "exchange_ms_per_step": sec["exchange_ms_per_step"], "value_no_exchange": None if sec["value_no_exchange"] is None else round(sec["value_no_exchange"], 2),
                                  "roofline": roof2}
         if hyp is not None:
@@ -1081,7 +1090,7 @@ def main():
             line["parity"] = line["latency_B1"] = {"skipped": "a collective of the hypothesis-shard block did not return within its deadline"}
         elif want_parity:
             line["parity"] = {"16cam6p": bench_parity(headline, rig, seqs_par, 4, local_rank), "64cam32p": bench_parity("64cam32p", rig64, [seq64], 1, local_rank)}
-            if want_secondary and not os.environ.get("SE3D_BENCH_NO_PARITY_256"):   # north_star's configuration: one frame of the secondary's first sequence, the oracle over the host's cores (~35 s on 256 threads)
+            if want_secondary and not args.no_parity_256:   # north_star's configuration: one frame of the secondary's first sequence, the oracle over the host's cores (~35 s on 256 threads)
                 line["parity"]["256cam128p"] = bench_parity("256cam128p", rig2, seqs_sec[0][:1], 1, local_rank, omp_threads=os.cpu_count() or 1, max_steps=1)
             line["parity"].update({
                               "note": "HIP path vs the CPU oracle (restatement of the reference, DESIGN 4) on the bench's own scenes, untimed: stage-1 joints "

@@ -10,7 +10,8 @@ namespace se3d {
 static const double g_max_sync_diff = 0.067;  // S3D:64
 static const char* BASE_FRAME = "base";       // S3D:45
 
-Context::Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam, int max_hyp, int device) {
+Context::Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam, int max_hyp, int device, const se3d_options* options) {
+  if (options) opt_ = *options;
   n_cam_ = (int)cams.size();
   max_hyp_ = std::max(max_hyp, max_det_per_cam);   // the library wants max_hyp >= max_det_per_cam (the first camera seeds one hypothesis per detection)
   max_det_ = max_det_per_cam;
@@ -34,7 +35,7 @@ se3d_ctx* Context::create(int max_det, int max_hyp) const {
   se3d_rig rig{n_cam_, const_cast<float*>(Rt_.data()), const_cast<float*>(K_.data()), const_cast<float*>(F_.data())};
   se3d_params p{prm_.pose_method == "h36m" ? SE3D_POSE_H36M : SE3D_POSE_SIMPLE, prm_.norm_height ? 1 : 0, prm_.max_epi_dist};
   se3d_limits lim{1, max_det, max_hyp, max_hyp};
-  se3d_ctx* c = se3d_create(&rig, &p, &lim, device_);
+  se3d_ctx* c = se3d_create_ex(&rig, &p, &lim, &opt_, device_);
   if (!c) throw std::runtime_error(std::string("se3d_create failed: ") + se3d_last_error(nullptr) + " (there is no CPU fallback)");
   return c;
 }

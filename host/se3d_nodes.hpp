@@ -44,7 +44,8 @@ struct CameraCalib {
 class Context {
  public:
   static constexpr int kCapacityMax = 256;   // SE3D_MUNKRES_MAX of the library: rows / columns of the device Munkres
-  Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam = 16, int max_hyp = 64, int device = 0);
+  // options: se3d_options of the library (include/se3d.h; nullptr = defaults); kept and applied again when the context grows
+  Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam = 16, int max_hyp = 64, int device = 0, const se3d_options* options = nullptr);
   ~Context();
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
@@ -65,6 +66,7 @@ class Context {
   se3d_ctx* ctx_ = nullptr;
   int n_cam_ = 0, max_hyp_ = 0, max_det_ = 0, device_ = 0, n_grown_ = 0;
   NodeParams prm_;
+  se3d_options opt_{};
   std::vector<float> Rt_, K_, F_;
   std::vector<CameraCalib> cams_;
   std::vector<double> rp_T_, rp_P_;      // reprojection cameras, re-applied after grow()

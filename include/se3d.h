@@ -93,6 +93,62 @@ typedef struct se3d_limits {
   int32_t max_tracks;      /* stage-2 tracks per sequence */
 } se3d_limits;
 
+/* Options of a context (se3d_create_ex, se3d_set_options); all zero = the library's defaults = what se3d_create uses.  The library reads NO
+ * environment variable.  First group: what a deployment tunes (the reference has no counterpart: its nodes are single-threaded CPU code).  Second
+ * group: kernel FORMS kept in the library because a parity test runs them against each other and against the oracle — same results (association
+ * indices identical, numbers within the tolerances of DESIGN.md section 4); forms that lost their measurement and are not such a reference were
+ * removed in round 5 (profiles/r5/README.md). */
+typedef struct se3d_options {
+  /* --- deployment (the first three are fixed at creation: se3d_set_options rejects a change) */
+  int32_t pair_chunks;        /* camera-column chunks of the pair-cost table on large rigs: 0 = default (16 from 128 cameras, 8 from 32 with more than 16
+                                 detections per camera, else the whole table), -1 = always the whole table, m >= 2 = m chunks */
+  int32_t hi_priority_stream; /* second, high-priority HIP stream for the launch chains (per-camera sweep, per-step stage 2) of contexts with
+                                 max_hyp > 64: 0 = default (on), -1 = off — recommended for more than four large-rig contexts per GPU */
+  int32_t reserve_cus;        /* CUs the bulk stream leaves to the high-priority stream: 0 = default (32 from 128 cameras when the whole pair table is
+                                 materialised, else none), -1 = none, R = R CUs */
+  int32_t graph;              /* one-frame calls of a max_frames = 1 context replay one hipGraph each: 0 = default (on), -1 = direct launches */
+  int32_t walk_shape;         /* fused stage-2 walk: 0 = automatic (one wavefront per sequence from 256 sequences per launch at max_hyp <= 16),
+                                 SE3D_WALK_WAVE, SE3D_WALK_WG */
+  int32_t sweep_lds_kb;       /* chunk mode: LDS (KB, <= 128) the per-camera Munkres may use for its working matrix; 0 = L2 (default) */
+  /* --- kernel forms (parity tests; 0 = the library's choice) */
+  int32_t pairs_form;         /* SE3D_PAIRS_AUTO | _FLAT (stand-alone normalisation + one lane per table entry with IEEE divide: the reference form) |
+                                 _ROWS (the large-rig kernel on any rig) | _FUSED (one workgroup per frame even for small batches) */
+  int32_t sweep_form;         /* SE3D_SWEEP_AUTO | _PER_CAMERA (cost + assignment launch per camera) | _WAVE_GLOBAL (one wavefront per frame, state in L2) */
+  int32_t tri_form;           /* SE3D_TRI_AUTO | _JOINT (one wavefront per (hypothesis, joint) on small rigs too) */
+  int32_t post_form;          /* SE3D_POST_AUTO | _BLOCK (the thread-per-hypothesis kernel on small rigs too) */
+  int32_t lm_form;            /* normal equations of the per-step LM kernel: SE3D_LM_TREE (default) | _TREE_MFMA | _DENSE (fp64 MFMA J^T J) */
+  int32_t walk_form;          /* se3d_run_stage2_walk: SE3D_WALK_FUSED (default) | _STEPS (the per-step kernels back to back) */
+  int32_t walk_lm;            /* LM inside the fused walk: SE3D_WALK_LM_TRIO (three persons per wavefront, default) | _SOLO */
+  int32_t walk_book;          /* one-wavefront walk's per-step bookkeeping: 0 = LDS (default), 1 = global memory */
+  int32_t refine_steps;       /* se3d_refine on a one-sequence context: 0 = one fused-walk launch (default), 1 = the five per-step launches */
+  int32_t munkres_form;       /* se3d_hungarian: SE3D_MUNKRES_AUTO | _BLOCK | _WAVE */
+  int32_t reproj_form;        /* feedback reprojection: 0 = per-camera lists written directly where they fit LDS (default), 1 = dense + scan + compaction */
+  int32_t reserved[7];        /* must be 0 */
+} se3d_options;
+#define SE3D_WALK_WAVE 1
+#define SE3D_WALK_WG 2
+#define SE3D_PAIRS_AUTO 0
+#define SE3D_PAIRS_FLAT 1
+#define SE3D_PAIRS_ROWS 2
+#define SE3D_PAIRS_FUSED 3
+#define SE3D_SWEEP_AUTO 0
+#define SE3D_SWEEP_PER_CAMERA 1
+#define SE3D_SWEEP_WAVE_GLOBAL 2
+#define SE3D_TRI_AUTO 0
+#define SE3D_TRI_JOINT 1
+#define SE3D_POST_AUTO 0
+#define SE3D_POST_BLOCK 1
+#define SE3D_LM_TREE 0
+#define SE3D_LM_TREE_MFMA 1
+#define SE3D_LM_DENSE 2
+#define SE3D_WALK_FUSED 0
+#define SE3D_WALK_STEPS 1
+#define SE3D_WALK_LM_TRIO 0
+#define SE3D_WALK_LM_SOLO 1
+#define SE3D_MUNKRES_AUTO 0
+#define SE3D_MUNKRES_BLOCK 1
+#define SE3D_MUNKRES_WAVE 2
+
 /* One synchronised set of per-camera Person2DList messages (input of triangulate_persons, S3D:525). */
 typedef struct se3d_frame_in {
   int32_t n_cam;
@@ -145,6 +201,12 @@ int se3d_rig_from_transforms(int32_t n_cam, const double *T_base_to_cam, float *
  * work on the legacy null stream (plain hipMemcpy, a torch op on the default stream) then synchronises with it — keep such work out of
  * timed regions. */
 se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d_limits *limits, int32_t device_id);
+/* As se3d_create with options (NULL = defaults). */
+se3d_ctx *se3d_create_ex(const se3d_rig *rig, const se3d_params *params, const se3d_limits *limits, const se3d_options *options, int32_t device_id);
+/* Replaces the options of a live context (the creation-time fields pair_chunks, hi_priority_stream, reserve_cus must keep their values:
+ * SE3D_ERR_ARG otherwise; so must a non-zero reserved word).  Takes effect from the next call on. */
+int se3d_set_options(se3d_ctx *ctx, const se3d_options *options);
+int se3d_get_options(se3d_ctx *ctx, se3d_options *options_out);
 void se3d_destroy(se3d_ctx *ctx);
 /* ctx != NULL: message of the context's last failed call.  ctx == NULL: why the last se3d_create of the calling thread returned NULL
  * (unsupported sizes, no device, out of device memory — with the bytes the context needs and the bytes free). */
@@ -153,6 +215,7 @@ const char *se3d_last_error(const se3d_ctx *ctx);
  * streaming, reprojection and hypothesis-shard buffers of later calls are not included); -1 for sizes se3d_create rejects.  bench.py's
  * memory plan (N contexts per GPU) and a node's start-up check use it to fail with a message instead of a hipMalloc error. */
 int64_t se3d_device_bytes(int32_t n_cam, const se3d_limits *limits);
+int64_t se3d_device_bytes_ex(int32_t n_cam, const se3d_limits *limits, const se3d_options *options);
 const char *se3d_version(void);
 
 /* --- stage 1: drop-in for triangulate_persons (S3D:525-997) ------------------------------------------- */
@@ -297,6 +360,11 @@ int se3d_get_fusion_constants(se3d_ctx *ctx, int32_t *indices22, double *vel_sig
  * sequences (no operand scaling / fix-up) inside [2^-60, 2^60]; this runs both against the device's IEEE results — the square root on every
  * float of the range, the quotient on n_div pseudo-random operand pairs — and returns the mismatch counts (expected: 0, 0). */
 int se3d_selftest_exact_math(se3d_ctx *ctx, uint64_t n_div, uint64_t *sqrt_mismatches, uint64_t *div_mismatches);
+
+/* --- diagnostic (round 5): running totals of the per-camera sweep launches of this context (rigs too large for the one-wavefront sweep) —
+ * camera steps that met existing hypotheses AND detections (S3D:588-626), and those in which a row or column of the feasibility mask counted more
+ * than one entry, i.e. in which the reference runs the Hungarian on the unmasked cost matrix (S3D:628-634).  32-bit counters on the device. */
+int se3d_get_sweep_stats(se3d_ctx *ctx, uint64_t *steps, uint64_t *hungarian_steps);
 
 /* --- diagnostic self-test (round 5): the large-rig pair kernel (calcCost's two quotients per joint, S3D:358-361) divides by a line norm through
  * its correctly rounded reciprocal y = RN(1 / b), staged once per (detection, joint), in three instructions: q0 = RN(a y), r = fma(-b, q0, a),

@@ -8,10 +8,10 @@ LIB_PATH = os.environ.get("SE3D_LIB_OVERRIDE") or os.path.join(_HERE, "libse3d_h
 
 # every entry point declared in include/se3d.h (checked against the header in tests/test_abi.py)
 EXPORTS = [
-    "se3d_rig_from_transforms", "se3d_create", "se3d_destroy", "se3d_last_error", "se3d_device_bytes", "se3d_version",
+    "se3d_rig_from_transforms", "se3d_create", "se3d_create_ex", "se3d_set_options", "se3d_get_options", "se3d_destroy", "se3d_last_error", "se3d_device_bytes", "se3d_device_bytes_ex", "se3d_version",
     "se3d_triangulate", "se3d_triangulate_batch", "se3d_stage_frames", "se3d_run_stage1", "se3d_sync", "se3d_fetch_stage1",
     "se3d_refine_reset", "se3d_refine_state_bytes", "se3d_refine_save", "se3d_refine_load", "se3d_refine", "se3d_run_stage2", "se3d_fetch_stage2",
-    "se3d_hungarian", "se3d_get_pair_costs", "se3d_selftest_exact_math", "se3d_selftest_shared_quotient", "se3d_selftest_dlt32", "se3d_get_exact_list", "se3d_get_pair_chunks", "se3d_get_fusion_constants", "se3d_pack_stage1_device", "se3d_pack_stage2_device",
+    "se3d_hungarian", "se3d_get_pair_costs", "se3d_selftest_exact_math", "se3d_selftest_shared_quotient", "se3d_get_sweep_stats", "se3d_selftest_dlt32", "se3d_get_exact_list", "se3d_get_pair_chunks", "se3d_get_fusion_constants", "se3d_pack_stage1_device", "se3d_pack_stage2_device",
     "se3d_profile_enable", "se3d_profile_reset", "se3d_profile_get",
     "se3d_set_reprojection_cameras", "se3d_reproject", "se3d_reproject_resident", "se3d_reproject_resident_batch", "se3d_fetch_reprojection",
     "se3d_run_stage2_walk", "se3d_fetch_stage2_walk", "se3d_pack_stage2_walk_device", "se3d_stream_handle", "se3d_pack_stage2_walk_device_slots", "se3d_pack_stage2_walk_device_dense",
@@ -65,6 +65,7 @@ def lib():
         _preload_host_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.se3d_create.restype = C.c_void_p
+        L.se3d_create_ex.restype = C.c_void_p
         L.se3d_destroy.argtypes = [C.c_void_p]
         L.se3d_last_error.restype = C.c_char_p
         L.se3d_last_error.argtypes = [C.c_void_p]
@@ -73,7 +74,7 @@ def lib():
         L.se3d_stream_handle.argtypes = [C.c_void_p]
         for name in ("se3d_triangulate", "se3d_triangulate_batch", "se3d_stage_frames", "se3d_run_stage1", "se3d_sync", "se3d_fetch_stage1",
                      "se3d_refine_reset", "se3d_refine_state_bytes", "se3d_refine_save", "se3d_refine_load", "se3d_refine", "se3d_run_stage2", "se3d_fetch_stage2", "se3d_pack_stage1_device",
-                     "se3d_pack_stage2_device", "se3d_hungarian", "se3d_get_pair_costs", "se3d_selftest_exact_math", "se3d_selftest_shared_quotient", "se3d_selftest_dlt32", "se3d_get_exact_list", "se3d_get_pair_chunks", "se3d_get_fusion_constants", "se3d_profile_enable", "se3d_profile_reset", "se3d_profile_get",
+                     "se3d_pack_stage2_device", "se3d_hungarian", "se3d_get_pair_costs", "se3d_selftest_exact_math", "se3d_selftest_shared_quotient", "se3d_get_sweep_stats", "se3d_selftest_dlt32", "se3d_get_exact_list", "se3d_get_pair_chunks", "se3d_get_fusion_constants", "se3d_profile_enable", "se3d_profile_reset", "se3d_profile_get",
                      "se3d_set_reprojection_cameras", "se3d_reproject", "se3d_reproject_resident", "se3d_reproject_resident_batch", "se3d_fetch_reprojection",
                      "se3d_run_stage2_walk", "se3d_fetch_stage2_walk", "se3d_pack_stage2_walk_device", "se3d_pack_stage2_walk_device_slots", "se3d_pack_stage2_walk_device_dense",
                      "se3d_triangulate_assoc", "se3d_stage_assoc", "se3d_run_dlt", "se3d_fetch_dlt", "se3d_stream_submit", "se3d_stream_collect",
@@ -81,6 +82,9 @@ def lib():
             getattr(L, name).restype = C.c_int
         L.se3d_shard_bytes.restype = C.c_int64
         L.se3d_device_bytes.restype = C.c_int64
+        L.se3d_device_bytes_ex.restype = C.c_int64
+        L.se3d_set_options.restype = C.c_int
+        L.se3d_get_options.restype = C.c_int
         L.se3d_refine_state_bytes.restype = C.c_int64
         L.se3d_refine_state_bytes.argtypes = [C.c_void_p]
         L.se3d_refine_save.restype = C.c_int

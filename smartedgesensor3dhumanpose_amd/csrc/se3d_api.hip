@@ -16,17 +16,17 @@
 
 extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status, int nR, int nC, hipStream_t st, int variant);
 extern "C" void se3d_launch_pack_dense(const se3d_person3d *fused, const int32_t *n_out, int n_frames, int H, int capacity, int32_t *off, se3d_person3d *dense, hipStream_t st);
-extern "C" int se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, bool tiled, int phases, hipStream_t st_hi,
-                                  hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk);   // bit 0: the pair table of the pass is not in D.pair
+extern "C" void se3d_launch_stage1(const Se3dDev &D, const se3d_options &o, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev, int phases, hipStream_t st_hi,
+                                   hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk);
 extern "C" void se3d_launch_normalize_keep(const Se3dDev &D, hipStream_t st);
 extern "C" void se3d_launch_pair_block(const Se3dDev &D, const int2 *d_ab_one, int frame, hipStream_t st);
-extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev, int phases);
+extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, const se3d_options &o, int seq0, int nseq, hipStream_t st, hipEvent_t *ev, int phases);
 extern "C" void se3d_launch_shard_pack_hyp(const Se3dDev &D, se3d_person3d *out, hipStream_t st);
 extern "C" void se3d_launch_shard_unpack_hyp(const Se3dDev &D, const se3d_person3d *gathered, hipStream_t st);
 extern "C" void se3d_launch_shard_pack_lm(const Se3dStage2 &Q, int nseq, Se3dShardRec *out, hipStream_t st);
 extern "C" void se3d_launch_shard_unpack_lm(const Se3dStage2 &Q, int nseq, const Se3dShardRec *gathered, hipStream_t st);
-extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st);
-extern "C" void se3d_launch_dlt(const Se3dDev &D, const int32_t *d_assoc_orig, int nh, hipStream_t st, hipEvent_t *ev);
+extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const se3d_options &o, const Se3dWalk &Wk, int nseq, hipStream_t st);
+extern "C" void se3d_launch_dlt(const Se3dDev &D, const se3d_options &o, const int32_t *d_assoc_orig, int nh, hipStream_t st, hipEvent_t *ev);
 extern "C" void se3d_launch_stream_scatter(const Se3dDev &D, const se3d_person2d *rag, const int32_t *off, hipStream_t st);
 extern "C" void se3d_launch_stream_compact(const se3d_person3d *fused, const se3d_person3d *pred, const int32_t *n_out, int n_frames, int H, int32_t *out_off,
                                            se3d_person3d *dense_fused, se3d_person3d *dense_pred, hipStream_t st);
@@ -70,8 +70,8 @@ struct se3d_ctx {
   uint32_t *h_flags = nullptr;
   int staged_frames = 0;
   bool ran = false;
-  bool tiled = false;
-  bool pair_in_hbm = true;   // false: the last pass kept its pair costs in LDS (se3d_k_front_fused); se3d_get_pair_costs computes blocks on demand
+  se3d_options opt{};        // se3d_create_ex / se3d_set_options; all zero = defaults
+  unsigned opt_version = 0;  // bumped by se3d_set_options: a captured call graph of an older version is captured again
   // profiling
   bool prof = false;
   static constexpr int kRing = 96;       // event sets in flight before the oldest are harvested
@@ -128,7 +128,7 @@ struct se3d_ctx {
   int ss_head = 0, ss_tail = 0;  // next slot to submit into / oldest batch not yet collected
   // One frame per call (max_frames = 1, the reference's operating point): upload + kernels + download of se3d_triangulate / se3d_refine as
   // ONE hipGraph each, captured on first use and replayed (round 4).  Re-captured when the A/B switches the launchers read change.
-  struct CallGraph { hipGraphExec_t exec = nullptr; std::string sig; bool failed = false; } g1, g2;
+  struct CallGraph { hipGraphExec_t exec = nullptr; unsigned version = 0; bool failed = false; } g1, g2;
   Se3dStage2 Q_shard{};   // views of the se3d_run_stage2_shard_pre call, reused by its _post half
   const float *d_fb_walk = nullptr;  // fb_delay rows the next se3d_run_stage2_walk reads (streaming: the slot's; else d_fb)
   // feedback reprojection
@@ -349,10 +349,7 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
   ok = ok && dev_alloc(c, &D.pscore, (size_t)B * N * P) && dev_alloc(c, &D.vmask_gt, (size_t)B * N * P) && dev_alloc(c, &D.vmask_ge, (size_t)B * N * P);
   ok = ok && dev_alloc(c, &D.nvalid, (size_t)B * N) && dev_alloc(c, &D.orig, (size_t)B * N * P);
   {
-    const char *ec = getenv("SE3D_PAIR_CHUNKS");
-    const int m = (getenv("SE3D_PAIRS") || getenv("SE3D_SWEEP_WAVE") || getenv("SE3D_SWEEP_FUSED_MAX")) ? 0   // A/B switches of the kernels that need the whole table
-                  : (ec ? atoi(ec) : se3d_pair_chunks_default(N, P, H));
-    c->plan = se3d_pair_plan(N, se3d_pair_chunks_default(N, P, H) > 0 ? m : 0);   // chunks only where the sweep is the per-camera launch chain
+    c->plan = se3d_pair_plan(N, se3d_pair_chunks_of(c->opt, N, P, H));
     D.d.pair_chunks = c->plan.m;
     D.d.pair_stride = c->plan.m ? 2 * c->plan.cap : np;
   }
@@ -366,8 +363,8 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
     // small rigs, <= 2 GB on large ones (a wavefront's workspace is 2 KB x cameras; the sigma samples of a joint seen by n views are 4 n + 1
     // solves of a 2 n x 4 system each — what the reference pays per joint too — so large rigs need the wavefronts: 2560 are resident at 256 cameras)
     D.d.tri_waves = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(4096, std::max<size_t>(16, joints / 4)), ((size_t)(N > 64 ? 2048 : 128) << 20) / per_wave));
-    ok = ok && dev_alloc(c, &D.tri_list, joints) && dev_alloc(c, &D.tri_cnt, (size_t)4) && dev_alloc(c, &D.tri_ws, (size_t)D.d.tri_waves * ws_floats);
-    if (ok && !c->dry) ok = hip_ok(c, hipMemset(D.tri_cnt, 0, 4 * sizeof(uint32_t)), "hipMemset (tri_cnt)");
+    ok = ok && dev_alloc(c, &D.tri_list, joints) && dev_alloc(c, &D.tri_cnt, (size_t)8) && dev_alloc(c, &D.tri_ws, (size_t)D.d.tri_waves * ws_floats);
+    if (ok && !c->dry) ok = hip_ok(c, hipMemset(D.tri_cnt, 0, 8 * sizeof(uint32_t)), "hipMemset (tri_cnt)");
   }
   ok = ok && dev_alloc(c, &D.hypP, (size_t)B * H) && dev_alloc(c, &D.keep, (size_t)B * H);
   ok = ok && slab_build(c, c->sl_out1, [&](SlabCarver &m) {
@@ -419,39 +416,32 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
 // A max_frames = 1 context moves fixed-size slabs (in1 / out1, in2 / out2) and launches a fixed kernel chain with constant arguments: the whole
 // call is captured once from the context's stream and replayed with one hipGraphLaunch — one submission instead of a copy, five to seven
 // launches and a copy.  Not used while kernel timing is on (the HIP events of se3d_profile_* sit between the kernels), on rigs whose sweep runs
-// on a second stream, or with SE3D_GRAPH=0 (A/B).  `sig`: the switches the launchers read, so that a test that flips one gets a fresh capture.
-static std::string graph_signature() {
-  static const char *const names[] = {"SE3D_PAIRS", "SE3D_SWEEP_WAVE", "SE3D_SWEEP_FUSED_MAX", "SE3D_POST_WAVE", "SE3D_TRI", "SE3D_NP_LINES", "SE3D_NP_TILE",
-                                      "SE3D_NO_SMALL_BATCH", "SE3D_SWEEP_LDS_KB", "SE3D_LM", "SE3D_WALK", "SE3D_WALK_LM", "SE3D_WALK_SHAPE", "SE3D_WALK_BOOK",
-                                      "SE3D_REFINE_WALK", "SE3D_NO_HI_STREAM", "SE3D_FRONT", "SE3D_FRONT_NT", "SE3D_FRONT_CAP", "SE3D_FRONT_DUMP"};
-  std::string sig;
-  for (const char *n : names) { const char *v = getenv(n); sig += v ? v : ""; sig += '|'; }
-  return sig;
-}
+// on a second stream, or with options.graph = -1.  A capture is tied to the options version it was made under (se3d_set_options bumps it).
 static bool graph_wanted(const se3d_ctx *c) {
-  if (c->prof || c->D.d.B != 1 || c->plan.m != 0 || c->D.d.shard_world > 1) return false;
-  const char *e = getenv("SE3D_GRAPH");
-  return !(e && atoi(e) == 0);
+  return !(c->prof || c->D.d.B != 1 || c->plan.m != 0 || c->D.d.shard_world > 1 || c->opt.graph < 0);
 }
 // Runs `enqueue` (which must only enqueue work on c->stream) through the graph `g`: captured on first use / after a switch change.
 // Returns 1 if the graph was launched, 0 if the caller must enqueue directly (capture not possible), < 0 on a device error.
 template <typename F>
 static int graph_replay(se3d_ctx *c, se3d_ctx::CallGraph &g, F enqueue) {
   if (g.failed) return 0;
-  const std::string sig = graph_signature();
-  if (g.exec && g.sig != sig) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+  if (g.exec && g.version != c->opt_version) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }   // options changed since the capture
   if (!g.exec) {
     hipGraph_t graph = nullptr;
+    (void)hipGetLastError();
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { g.failed = true; (void)hipGetLastError(); return 0; }
     enqueue();
+    // A launch the runtime rejects during capture (configuration error) leaves a graph WITHOUT that node: the direct path, which checks every
+    // launch, must report it instead of a replay that silently skips a kernel.
+    const hipError_t e0 = hipGetLastError();
     const hipError_t e1 = hipStreamEndCapture(c->stream, &graph);
-    if (e1 != hipSuccess || !graph || hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    if (e0 != hipSuccess || e1 != hipSuccess || !graph || hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
       if (graph) (void)hipGraphDestroy(graph);
       g.exec = nullptr; g.failed = true; (void)hipGetLastError();
       return 0;
     }
     (void)hipGraphDestroy(graph);
-    g.sig = sig;
+    g.version = c->opt_version;
   }
   if (!hip_ok(c, hipGraphLaunch(g.exec, c->stream), "hipGraphLaunch")) return SE3D_ERR_DEVICE;
   return 1;
@@ -506,8 +496,24 @@ int se3d_rig_from_transforms(int32_t n_cam, const double *T, float *Rt_out, floa
   return SE3D_OK;
 }
 
+static bool options_valid(const se3d_options *o) {
+  if (!o) return true;
+  for (int32_t r : o->reserved) if (r != 0) return false;
+  return o->pair_chunks >= -1 && o->pair_chunks != 1 && o->pair_chunks <= SE3D_PAIR_CHUNKS_MAX && o->hi_priority_stream >= -1 && o->hi_priority_stream <= 0 && o->reserve_cus >= -1 &&
+         o->graph >= -1 && o->graph <= 0 && o->walk_shape >= 0 && o->walk_shape <= SE3D_WALK_WG && o->sweep_lds_kb >= 0 && o->sweep_lds_kb <= 128 &&
+         o->pairs_form >= 0 && o->pairs_form <= SE3D_PAIRS_FUSED && o->sweep_form >= 0 && o->sweep_form <= SE3D_SWEEP_WAVE_GLOBAL && o->tri_form >= 0 && o->tri_form <= SE3D_TRI_JOINT &&
+         o->post_form >= 0 && o->post_form <= SE3D_POST_BLOCK && o->lm_form >= 0 && o->lm_form <= SE3D_LM_DENSE && o->walk_form >= 0 && o->walk_form <= SE3D_WALK_STEPS &&
+         o->walk_lm >= 0 && o->walk_lm <= SE3D_WALK_LM_SOLO && o->walk_book >= 0 && o->walk_book <= 1 && o->refine_steps >= 0 && o->refine_steps <= 1 &&
+         o->munkres_form >= 0 && o->munkres_form <= SE3D_MUNKRES_WAVE && o->reproj_form >= 0 && o->reproj_form <= 1;
+}
+
 se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d_limits *limits, int32_t device_id) {
+  return se3d_create_ex(rig, params, limits, nullptr, device_id);
+}
+
+se3d_ctx *se3d_create_ex(const se3d_rig *rig, const se3d_params *params, const se3d_limits *limits, const se3d_options *options, int32_t device_id) {
   if (!rig || !params || !limits || !rig->Rt || !rig->K || !rig->F) return nullptr;
+  if (!options_valid(options)) { create_error("se3d_create_ex: an option is out of range (include/se3d.h: se3d_options)"); return nullptr; }
   const int N = rig->n_cam, B = limits->max_frames, P = limits->max_det_per_cam, H = limits->max_hyp;
   if (N < 2 || N > SE3D_MAX_CAMS || B < 1 || P < 1 || P > SE3D_MUNKRES_MAX || H < P || H > SE3D_MUNKRES_MAX) {
     create_error("se3d_create: unsupported sizes (n_cam %d [2..%d], det/cam %d [1..%d], hyp %d [det..%d])", N, SE3D_MAX_CAMS, P,
@@ -522,19 +528,19 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
   se3d_ctx *c = new se3d_ctx();
   c->params = *params;
   c->limits = *limits;
+  if (options) c->opt = *options;
   c->device = device_id;
   if (!hip_ok(c, hipSetDevice(device_id), "hipSetDevice")) { create_error("se3d_create: %s", c->err.c_str()); delete c; return nullptr; }
   {
-    // Large rigs (>= 128 cameras) with the WHOLE pair table (SE3D_PAIR_CHUNKS=0; the default since round 3 is column chunks without a
-    // reservation): the bulk stream of the context (pair-cost kernel: millions of workgroups, 36 KB of LDS each) is kept off 32 CUs — the
-    // mask's bits are spread round-robin over the eight XCDs, so that is ~4 CUs of every XCD, not one XCD — so that the small latency-bound launches of the camera sweep and the per-step stage 2 (high-priority stream, all
-    // CUs; a sweep workgroup wants ~100 KB of LDS for its Munkres matrix) always find a CU with room.  Measured at 256 cam x 128 p, four
-    // contexts: 21.0 k -> 22.5 k skeletons/s; 24 reserved CUs lose (20.6 k).  SE3D_RESERVE_CUS=R overrides (0 = off).
-    const char *er = getenv("SE3D_RESERVE_CUS");
+    // Large rigs (>= 128 cameras) with the WHOLE pair table (options.pair_chunks = -1; the default since round 3 is column chunks without a
+    // reservation): the bulk stream of the context (pair-cost kernel: millions of workgroups, 39 KB of LDS each) is kept off 32 CUs — the
+    // mask's bits are spread round-robin over the eight XCDs, so that is ~4 CUs of every XCD, not one XCD — so that the small latency-bound
+    // launches of the camera sweep and the per-step stage 2 (high-priority stream, all CUs; a sweep workgroup wants ~100 KB of LDS for its
+    // Munkres matrix) always find a CU with room.  Measured at 256 cam x 128 p, four contexts: 21.0 k -> 22.5 k skeletons/s; 24 reserved CUs
+    // lose (20.6 k).  options.reserve_cus = R overrides (-1 = none).
     // (column chunks of the pair table, round 3: pair kernel and sweep alternate in short launches and the Munkres matrix sits in L2 — no CUs reserved)
-    const bool chunks = !getenv("SE3D_PAIR_CHUNKS") ? se3d_pair_chunks_default(N, P, H) > 0 && !getenv("SE3D_PAIRS") && !getenv("SE3D_SWEEP_WAVE") && !getenv("SE3D_SWEEP_FUSED_MAX")
-                                                    : atoi(getenv("SE3D_PAIR_CHUNKS")) >= 2;
-    const int reserve = er ? (limits->max_hyp > 64 ? atoi(er) : 0) : (N >= 128 && !chunks ? 32 : 0);
+    const bool chunks = se3d_pair_chunks_of(c->opt, N, P, H) > 0;
+    const int reserve = c->opt.reserve_cus > 0 ? (limits->max_hyp > 64 ? c->opt.reserve_cus : 0) : c->opt.reserve_cus < 0 ? 0 : (N >= 128 && !chunks ? 32 : 0);
     hipDeviceProp_t prop;
     bool ok_stream = false;
     if (reserve > 0 && hipGetDeviceProperties(&prop, device_id) == hipSuccess && reserve < prop.multiProcessorCount) {
@@ -545,7 +551,7 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
     }
     if (!ok_stream && !hip_ok(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return nullptr; }
   }
-  if (limits->max_hyp > 64 && !getenv("SE3D_NO_HI_STREAM")) {  // large association problems: their launch chains get a high-priority queue
+  if (limits->max_hyp > 64 && c->opt.hi_priority_stream >= 0) {  // large association problems: their launch chains get a high-priority queue
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, hi) != hipSuccess) c->stream_hi = nullptr;
@@ -608,14 +614,33 @@ se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
       create_error("se3d_create failed: %s (the context needs %.2f GB of device memory, %.2f of %.2f GB are free)", c->err.c_str(),
-                   (double)se3d_device_bytes(N, limits) / 1e9, free_b / 1e9, total_b / 1e9);
+                   (double)se3d_device_bytes_ex(N, limits, &c->opt) / 1e9, free_b / 1e9, total_b / 1e9);
     }
     se3d_destroy(c);
     return nullptr;
   }
-  c->tiled = P > 16;
-  if (const char *e = getenv("SE3D_PAIRS")) c->tiled = (strcmp(e, "tiled") == 0 || strcmp(e, "rows") == 0);  // A/B: force a large-P pair kernel
   return c;
+}
+
+int se3d_set_options(se3d_ctx *c, const se3d_options *o) {
+  if (!c || !o || !options_valid(o)) return SE3D_ERR_ARG;
+  if (o->pair_chunks != c->opt.pair_chunks || o->hi_priority_stream != c->opt.hi_priority_stream || o->reserve_cus != c->opt.reserve_cus) {
+    c->err = "se3d_set_options: pair_chunks, hi_priority_stream and reserve_cus are fixed at se3d_create_ex";
+    return SE3D_ERR_ARG;
+  }
+  // the chunk plan was laid out under the creation's options: a form that needs the whole pair table cannot be switched on afterwards
+  if (c->plan.m != se3d_pair_chunks_of(*o, c->D.d.N, c->D.d.P, c->D.d.H) && c->plan.m != 0 && se3d_pair_chunks_of(*o, c->D.d.N, c->D.d.P, c->D.d.H) == 0) {
+    c->err = "se3d_set_options: this context keeps its pair table in column chunks; pairs_form / sweep_form need a context created with them (or pair_chunks = -1)";
+    return SE3D_ERR_ARG;
+  }
+  c->opt = *o;
+  ++c->opt_version;
+  return SE3D_OK;
+}
+int se3d_get_options(se3d_ctx *c, se3d_options *o) {
+  if (!c || !o) return SE3D_ERR_ARG;
+  *o = c->opt;
+  return SE3D_OK;
 }
 
 void se3d_destroy(se3d_ctx *c) {
@@ -665,14 +690,16 @@ const char *se3d_last_error(const se3d_ctx *c) { return c ? c->err.c_str() : t_c
 
 // Device memory se3d_create(rig with n_cam cameras, limits) allocates, in bytes (host arithmetic only; no device is touched): the
 // allocation list of se3d_create walked with a counting allocator.  -1 for sizes se3d_create rejects.
-int64_t se3d_device_bytes(int32_t n_cam, const se3d_limits *limits) {
-  if (!limits) return -1;
+int64_t se3d_device_bytes(int32_t n_cam, const se3d_limits *limits) { return se3d_device_bytes_ex(n_cam, limits, nullptr); }
+int64_t se3d_device_bytes_ex(int32_t n_cam, const se3d_limits *limits, const se3d_options *options) {
+  if (!limits || !options_valid(options)) return -1;
   const int N = n_cam, B = limits->max_frames, P = limits->max_det_per_cam, H = limits->max_hyp;
   const int T = limits->max_tracks > 0 ? limits->max_tracks : H;
   if (N < 2 || N > SE3D_MAX_CAMS || B < 1 || P < 1 || P > SE3D_MUNKRES_MAX || H < P || H > SE3D_MUNKRES_MAX || T > SE3D_MUNKRES_MAX) return -1;
   se3d_ctx c;
   c.dry = true;
   c.limits = *limits;
+  if (options) c.opt = *options;
   se3d_params prm{};
   RigDev rd;
   (void)alloc_device_state(&c, N, &prm, limits, rd);
@@ -717,7 +744,7 @@ int se3d_run_stage1(se3d_ctx *c) {
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;  // grids cover the staged frames only (array strides do not depend on B)
   // the per-frame workspace (assoc, nviews, nhyp, flags, hypP) is reset by se3d_k_normalize, the first kernel of the pass
-  c->pair_in_hbm = !(se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk) & 1);
+  se3d_launch_stage1(D, c->opt, c->pair_ab, c->stream, next_ev1(c), 15, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);
   HIPCHK(c, hipGetLastError());
   c->ran = true;
   return SE3D_OK;
@@ -731,8 +758,7 @@ int se3d_run_stage1_phases(se3d_ctx *c, int32_t phases) {
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;
   if (phases & 1) c->cur_ev1 = next_ev1(c);   // one event set per pass, begun by the part that holds phase 1 and completed by the part with phase 4
-  const int info = se3d_launch_stage1(D, c->pair_ab, c->stream, c->cur_ev1, c->tiled, phases, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);
-  if (phases & 1) c->pair_in_hbm = !(info & 1);
+  se3d_launch_stage1(D, c->opt, c->pair_ab, c->stream, c->cur_ev1, phases, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);
   HIPCHK(c, hipGetLastError());
   if (phases & 4) c->ran = true;
   return SE3D_OK;
@@ -795,7 +821,7 @@ int se3d_triangulate_batch(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *f
     Se3dDev D = c->D;
     const int g = graph_replay(c, c->g1, [&] {
       (void)hipMemcpyAsync(c->sl_in1.d, c->sl_in1.h, c->sl_in1.bytes, hipMemcpyHostToDevice, c->stream);
-      c->pair_in_hbm = !(se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 15, nullptr, nullptr, &c->plan, nullptr) & 1);   // (at capture; a replay runs the same kernels)
+      se3d_launch_stage1(D, c->opt, c->pair_ab, c->stream, nullptr, 15, nullptr, nullptr, &c->plan, nullptr);   // (at capture; a replay runs the same kernels)
       (void)hipMemcpyAsync(c->sl_out1.h, c->sl_out1.d, c->sl_out1.bytes, hipMemcpyDeviceToHost, c->stream);
     });
     if (g < 0) return g;
@@ -841,7 +867,7 @@ int se3d_run_dlt(se3d_ctx *c) {
   D.d.B = c->staged_frames;
   hipEvent_t *ev = next_ev1(c);
   if (ev) c->ev_dlt[(c->ev_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = true;
-  se3d_launch_dlt(D, c->d_assoc_in, c->dlt_hyp, c->stream, ev);
+  se3d_launch_dlt(D, c->opt, c->d_assoc_in, c->dlt_hyp, c->stream, ev);
   HIPCHK(c, hipGetLastError());
   c->ran_dlt = true;
   c->ran = false;  // the association workspace now holds the caller's table, not a sweep result
@@ -889,8 +915,7 @@ int se3d_hungarian(se3d_ctx *c, int32_t *assignment, double *cost, const double 
   double *d_dist = c->d_hung;           // preallocated in the context (no allocation per call, nothing to leak on an error return)
   int *d_assign = c->d_hung_assign, *d_status = d_assign + nR;
   HIPCHK(c, hipMemcpyAsync(d_dist, dist, sizeof(double) * (size_t)nR * nC, hipMemcpyHostToDevice, c->stream));
-  const char *mv = getenv("SE3D_MUNKRES");  // A/B switch for the parity tests: block | wave | (automatic)
-  se3d_launch_munkres(d_dist, d_assign, d_status, nR, nC, c->stream, (mv && strcmp(mv, "block") == 0) ? 1 : (mv && strcmp(mv, "wave") == 0) ? 2 : 0);
+  se3d_launch_munkres(d_dist, d_assign, d_status, nR, nC, c->stream, c->opt.munkres_form);   // parity tests force the block / the one-wavefront form
   std::vector<int> h(nR + 1);
   HIPCHK(c, hipMemcpyAsync(h.data(), d_assign, sizeof(int) * (size_t)(nR + 1), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -910,18 +935,11 @@ int se3d_get_pair_costs(se3d_ctx *c, int32_t frame, int32_t cam_a, int32_t cam_b
   HIPCHK(c, hipSetDevice(c->device));
   const int P = D.d.P;
   size_t off = ((size_t)frame * D.d.npairs + se3d_pair_index(cam_a, cam_b, D.d.N)) * P * P;
-  if (D.d.pair_chunks || !c->pair_in_hbm) {
-    // fused front kernel (pair costs in LDS): the normalised points are formed again first (masks / slots are rewritten with the same
-    // values, the association workspace is left alone), then as under
+  if (D.d.pair_chunks) {
     // column chunks: the table of the pass is gone (every chunk buffer has been overwritten since); the block is computed again by the
     // pair kernel of the pass into slot 0 of the frame (one-entry pair list in the first element of C, free between passes)
     // (both are scratch between passes — the next se3d_run_stage1 rewrites them — and the slot is cleared to -1 first, "no joint shared":
     // the kernel writes nothing for a camera without valid detections)
-    if (!D.d.pair_chunks) {
-      Se3dDev Dn = D;
-      Dn.d.B = c->staged_frames;
-      se3d_launch_normalize_keep(Dn, c->stream);
-    }
     const int2 one = make_int2(cam_a, cam_b);
     HIPCHK(c, hipMemcpyAsync(D.C, &one, sizeof(int2), hipMemcpyHostToDevice, c->stream));
     off = (size_t)frame * D.d.pair_stride * P * P;
@@ -1007,15 +1025,14 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
       Se3dStage2 Qg = c->Q;
       Qg.dets = c->d_in2; Qg.n_det = c->d_ndet2; Qg.fb_delay = c->d_fb_ref; Qg.t = c->d_t;
       bool walked = false;
-      const char *e_rw = getenv("SE3D_REFINE_WALK");
-      if (!(e_rw && atoi(e_rw) == 0)) {
+      if (!c->opt.refine_steps) {
         Se3dWalk Wk{};
         Wk.n_steps = 1; Wk.slot0[0] = 0; Wk.t = c->d_t; Wk.t_stride = 1;
         Wk.outP = c->d_in2; Wk.out_count = c->d_ndet2; Wk.fb = c->d_fb_ref;
         Wk.Wf = c->Q.fused; Wk.Wp = c->Q.pred; Wk.Wit = c->Q.iters; Wk.Wn = c->Q.n_out; Wk.Wdt = c->Q.pred_dt;
-        walked = se3d_launch_stage2_walk(c->Q, Wk, 1, c->stream);
+        walked = se3d_launch_stage2_walk(c->Q, c->opt, Wk, 1, c->stream);
       }
-      if (!walked) se3d_launch_stage2(Qg, 0, 1, c->stream, nullptr, 3);
+      if (!walked) se3d_launch_stage2(Qg, c->opt, 0, 1, c->stream, nullptr, 3);
       (void)hipMemcpyAsync(c->sl_out2.h, c->sl_out2.d, c->sl_out2.bytes, hipMemcpyDeviceToHost, c->stream);
     });
     if (g < 0) return g;
@@ -1035,11 +1052,10 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
   Q.dets = c->d_in2; Q.n_det = c->d_ndet2; Q.fb_delay = c->d_fb_ref; Q.t = c->d_t;
   // One frame per call on a one-sequence context (the reference's operating point, PP:505): the step as ONE launch of the fused walk kernel
   // (association, LM with three persons per wavefront, lifecycle; n_steps = 1) instead of five dependent launches — round 4, latency_B1.
-  // SE3D_REFINE_WALK=0 (A/B, read per call) keeps the per-step kernels.
+  // options.refine_steps = 1 keeps the per-step kernels.
   bool walked = false;
   if (Q.S == 1) {
-    const char *e_rw = getenv("SE3D_REFINE_WALK");
-    if (!(e_rw && atoi(e_rw) == 0)) {
+    if (!c->opt.refine_steps) {
       Se3dWalk Wk{};
       Wk.n_steps = 1;
       Wk.slot0[0] = 0;
@@ -1048,7 +1064,7 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
       Wk.Wf = c->Q.fused; Wk.Wp = c->Q.pred; Wk.Wit = c->Q.iters; Wk.Wn = c->Q.n_out; Wk.Wdt = c->Q.pred_dt;
       hipEvent_t *ev = next_ev2(c);
       if (ev) { c->ev2_walk[(c->ev2_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = true; (void)hipEventRecord(ev[0], c->stream); }
-      walked = se3d_launch_stage2_walk(c->Q, Wk, 1, c->stream);
+      walked = se3d_launch_stage2_walk(c->Q, c->opt, Wk, 1, c->stream);
       if (walked && ev) (void)hipEventRecord(ev[3], c->stream);
       if (!walked && ev) {   // not applicable (limits too large for the kernel's LDS): give the event set back
         c->ev2_walk[(c->ev2_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = false;
@@ -1057,7 +1073,7 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
       }
     }
   }
-  if (!walked) se3d_launch_stage2(Q, seq, 1, c->stream, next_ev2(c), 3);
+  if (!walked) se3d_launch_stage2(Q, c->opt, seq, 1, c->stream, next_ev2(c), 3);
   HIPCHK(c, hipGetLastError());
   c->ran2 = true;
   return fetch_stage2_range(c, seq, 1, out);
@@ -1173,7 +1189,7 @@ int se3d_run_stage2(se3d_ctx *c, int32_t n_seq, int32_t frame_slot0, const doubl
   HIPCHK(c, hipEventRecord(c->t_done[c->t_head], c->stream));
   c->t_head = (c->t_head + 1) % se3d_ctx::kRing;
   Q.dets = c->D.outP + (size_t)frame_slot0 * Q.H; Q.n_det = c->D.out_count + frame_slot0; Q.fb_delay = c->d_fb + (size_t)frame_slot0 * Q.N; Q.t = c->d_t;
-  se3d_launch_stage2(Q, 0, n_seq, c->stream, next_ev2(c), 3);
+  se3d_launch_stage2(Q, c->opt, 0, n_seq, c->stream, next_ev2(c), 3);
   HIPCHK(c, hipGetLastError());
   c->ran2 = true;
   return SE3D_OK;
@@ -1202,7 +1218,7 @@ int se3d_run_stage2_walk(se3d_ctx *c, int32_t n_seq, int32_t n_steps, const int3
   Wk.Wf = Q0.fused; Wk.Wp = Q0.pred; Wk.Wit = Q0.iters; Wk.Wn = Q0.n_out; Wk.Wdt = Q0.pred_dt;
   hipEvent_t *ev = next_ev2(c);
   if (ev) { c->ev2_walk[(c->ev2_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = true; (void)hipEventRecord(ev[0], c->stream); }
-  if (!se3d_launch_stage2_walk(Q0, Wk, n_seq, c->stream)) {
+  if (!se3d_launch_stage2_walk(Q0, c->opt, Wk, n_seq, c->stream)) {
     hipStream_t s2 = c->stream;
     if (c->stream_hi) {  // the chain of 5 x n_steps small launches on the high-priority stream
       (void)hipEventRecord(c->ev_hi[2], c->stream);
@@ -1214,7 +1230,7 @@ int se3d_run_stage2_walk(se3d_ctx *c, int32_t n_seq, int32_t n_steps, const int3
       Se3dStage2 Q = Q0;
       Q.dets = Wk.outP + f0 * Q.H; Q.n_det = Wk.out_count + f0; Q.fb_delay = Wk.fb + f0 * Q.N; Q.t = c->d_t + (size_t)k * n_seq;
       Q.fused = Q0.fused + f0 * Q.H; Q.pred = Q0.pred + f0 * Q.H; Q.iters = Q0.iters + f0 * Q.H; Q.n_out = Q0.n_out + f0; Q.pred_dt = Q0.pred_dt + f0;
-      se3d_launch_stage2(Q, 0, n_seq, s2, nullptr, 3);
+      se3d_launch_stage2(Q, c->opt, 0, n_seq, s2, nullptr, 3);
     }
     if (s2 != c->stream) {
       (void)hipEventRecord(c->ev_hi[3], s2);
@@ -1289,7 +1305,7 @@ int se3d_run_stage1_shard_pre(se3d_ctx *c, void *d_pack) {
   HIPCHK(c, hipSetDevice(c->device));
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;
-  c->pair_in_hbm = !(se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 11, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk) & 1);   // association on every rank, triangulation of the own hypotheses
+  se3d_launch_stage1(D, c->opt, c->pair_ab, c->stream, nullptr, 11, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);   // association on every rank, triangulation of the own hypotheses
   se3d_launch_shard_pack_hyp(D, static_cast<se3d_person3d *>(d_pack), c->stream);
   HIPCHK(c, hipGetLastError());
   return SE3D_OK;
@@ -1301,7 +1317,7 @@ int se3d_run_stage1_shard_post(se3d_ctx *c, const void *d_gathered) {
   Se3dDev D = c->D;
   D.d.B = c->staged_frames;
   se3d_launch_shard_unpack_hyp(D, static_cast<const se3d_person3d *>(d_gathered), c->stream);
-  se3d_launch_stage1(D, c->pair_ab, c->stream, nullptr, c->tiled, 4, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);   // post-processing + duplicate merge on every rank
+  se3d_launch_stage1(D, c->opt, c->pair_ab, c->stream, nullptr, 4, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);   // post-processing + duplicate merge on every rank
   HIPCHK(c, hipGetLastError());
   c->ran = true;
   return SE3D_OK;
@@ -1319,7 +1335,7 @@ int se3d_run_stage2_shard_pre(se3d_ctx *c, int32_t n_seq, int32_t frame_slot0, c
   c->t_head = (c->t_head + 1) % se3d_ctx::kRing;
   Q.dets = c->D.outP + (size_t)frame_slot0 * Q.H; Q.n_det = c->D.out_count + frame_slot0; Q.fb_delay = c->d_fb + (size_t)frame_slot0 * Q.N; Q.t = c->d_t;
   c->Q_shard = Q;
-  se3d_launch_stage2(Q, 0, n_seq, c->stream, nullptr, 1);   // track association on every rank, LM of the own detections
+  se3d_launch_stage2(Q, c->opt, 0, n_seq, c->stream, nullptr, 1);   // track association on every rank, LM of the own detections
   se3d_launch_shard_pack_lm(Q, n_seq, static_cast<Se3dShardRec *>(d_pack), c->stream);
   HIPCHK(c, hipGetLastError());
   return SE3D_OK;
@@ -1328,7 +1344,7 @@ int se3d_run_stage2_shard_post(se3d_ctx *c, int32_t n_seq, const void *d_gathere
   if (!c || !d_gathered || n_seq < 1) return SE3D_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   se3d_launch_shard_unpack_lm(c->Q_shard, n_seq, static_cast<const Se3dShardRec *>(d_gathered), c->stream);
-  se3d_launch_stage2(c->Q_shard, 0, n_seq, c->stream, nullptr, 2);   // merge-distance matrix, publish, lifecycle on every rank
+  se3d_launch_stage2(c->Q_shard, c->opt, 0, n_seq, c->stream, nullptr, 2);   // merge-distance matrix, publish, lifecycle on every rank
   HIPCHK(c, hipGetLastError());
   c->ran2 = true;
   return SE3D_OK;
@@ -1408,7 +1424,7 @@ int se3d_stream_submit(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frame
   D.d.B = n_frames;
   se3d_launch_stream_scatter(D, sl.d_rag, sl.d_off, c->stream);
   c->staged_frames = n_frames;
-  c->pair_in_hbm = !(se3d_launch_stage1(D, c->pair_ab, c->stream, next_ev1(c), c->tiled, 15, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk) & 1);
+  se3d_launch_stage1(D, c->opt, c->pair_ab, c->stream, next_ev1(c), 15, c->stream_hi, c->ev_hi, &c->plan, c->ev_chunk);
   c->ran = true;
   c->d_fb_walk = sl.d_fb;
   rc = se3d_run_stage2_walk(c, n_seq, n_steps, frame_slot0, t);
@@ -1517,6 +1533,7 @@ int se3d_reproject(se3d_ctx *c, int32_t n_persons, const se3d_person3d *persons,
   HIPCHK(c, hipSetDevice(c->device));
   if (n_persons > 0) HIPCHK(c, hipMemcpyAsync(c->d_rp_in, persons, sizeof(se3d_person3d) * (size_t)n_persons, hipMemcpyHostToDevice, c->stream));
   Se3dReproj R = c->R;
+  R.dense_form = c->opt.reproj_form;
   R.in = c->d_rp_in; R.n = n_persons; R.n_dev = nullptr;
   HIPCHK(c, se3d_launch_reproject(R, n_persons, c->stream));
   return reproject_fetch(c, out);
@@ -1529,6 +1546,7 @@ int se3d_reproject_resident(se3d_ctx *c, int32_t slot, se3d_reproj_out *out) {
   if (!c->ran2) { c->err = "se3d_reproject_resident: no stage-2 result"; return SE3D_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   Se3dReproj R = c->R;
+  R.dense_form = c->opt.reproj_form;
   R.in = c->Q.pred + (size_t)seq * c->Q.H; R.n = 0; R.n_dev = c->Q.n_out + seq;
   HIPCHK(c, se3d_launch_reproject(R, c->Q.H, c->stream));
   if (!out) return SE3D_OK;  // asynchronous: result stays on the device (timing / chaining)
@@ -1545,7 +1563,7 @@ int se3d_reproject_resident_batch(se3d_ctx *c, int32_t slot0, int32_t n_slots) {
   if (!c->ran2) { c->err = "se3d_reproject_resident_batch: no stage-2 result"; return SE3D_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t nt = (size_t)c->R.N * c->R.T;
-  const bool want_lists = se3d_reproj_lists_lds(c->R.N, c->R.T) > 0;
+  const bool want_lists = se3d_reproj_lists_lds(c->R.N, c->R.T, c->opt.reproj_form) > 0;
   if (n_slots > c->rpb_cap || want_lists != c->rpb_lists) {   // batch buffers: one block of every output array per slot
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // the batch buffers are OWNED by RB (never aliases of the single-list buffers of c->R): free what exists, member by member
@@ -1580,6 +1598,7 @@ int se3d_reproject_resident_batch(se3d_ctx *c, int32_t slot0, int32_t n_slots) {
     c->rpb_lists = want_lists;
   }
   Se3dReproj R = c->RB;
+  R.dense_form = c->opt.reproj_form;
   R.cam = c->R.cam; R.wh = c->R.wh; R.N = c->R.N; R.T = c->R.T; R.pose_method = c->R.pose_method;
   R.in = c->Q.pred + (size_t)slot0 * c->Q.H; R.in_stride = c->Q.H; R.n = 0; R.n_dev = c->Q.n_out + slot0;
   c->rpb_slot0 = slot0; c->rpb_n = n_slots;
@@ -1688,6 +1707,17 @@ int se3d_get_exact_list(se3d_ctx *c, uint32_t *entries, int32_t capacity, int32_
     HIPCHK(c, hipMemcpyAsync(entries, c->D.tri_list, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  return SE3D_OK;
+}
+
+// Diagnostic: how often the per-camera sweep of this context (large rigs: se3d_k_sweep_assign) met an ambiguous step (S3D:628-634).
+int se3d_get_sweep_stats(se3d_ctx *c, uint64_t *steps, uint64_t *hungarian_steps) {
+  if (!c || !steps || !hungarian_steps) return SE3D_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(h, c->D.tri_cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *steps = h[4]; *hungarian_steps = h[5];
   return SE3D_OK;
 }
 

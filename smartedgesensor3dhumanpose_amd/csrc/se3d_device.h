@@ -68,11 +68,18 @@ inline Se3dPairPlan se3d_pair_plan(int N, int m) {
   return pl;
 }
 // Which rigs run in chunks: those whose sweep is the chain of per-camera launches anyway (se3d_launch_stage1: neither the one-wavefront nor
-// the one-workgroup sweep applies) and whose table is big enough to matter.  SE3D_PAIR_CHUNKS=m overrides (0 / 1: whole table).
+// the one-wavefront sweep applies) and whose table is big enough to matter.  options.pair_chunks = m overrides (-1: whole table).
 inline int se3d_pair_chunks_default(int N, int P, int H) {
   const bool wave_sweep = H <= 64 && P <= 64 && H * P <= 2048;
-  if (P <= 16 || N < 32 || wave_sweep || H * P <= 256) return 0;
+  if (P <= 16 || N < 32 || wave_sweep) return 0;
   return N >= 128 ? 16 : 8;
+}
+// Chunks of a context: only where the default applies them (the sweep is the per-camera launch chain, the rows kernel fills the table) and no
+// kernel form that needs the whole table is forced.
+inline int se3d_pair_chunks_of(const se3d_options &o, int N, int P, int H) {
+  const int def = se3d_pair_chunks_default(N, P, H);
+  if (def == 0 || o.pair_chunks < 0 || o.pairs_form != SE3D_PAIRS_AUTO || o.sweep_form != SE3D_SWEEP_AUTO) return 0;
+  return o.pair_chunks >= 2 ? o.pair_chunks : def;
 }
 
 struct Se3dDev {
@@ -104,7 +111,7 @@ struct Se3dDev {
   se3d_person3d *hypP;   // [B][H]
   uint8_t *keep;         // [B][H]
   uint32_t *tri_list;    // [B * H * 17] (frame * H + hypothesis) << 5 | joint of every joint the fast triangulation kernels hand to the second pass
-  uint32_t *tri_cnt;     // [4]: entries of tri_list of the current launch; [1]: running total (statistics, se3d_get_exact_stats); [2]: joints triangulated
+  uint32_t *tri_cnt;     // [8] ([4], [5]: camera steps of the per-camera sweep with hypotheses and detections / those that ran the Hungarian, running totals); [0..3]: entries of tri_list of the current launch; [1]: running total (statistics, se3d_get_exact_stats); [2]: joints triangulated
   float *tri_ws;         // [tri_waves][se3d_exact_ws_floats(N)] lane-interleaved rows x 4 workspaces of the float32 solves (8 N x 64 floats; + the centred samples on large rigs)
   se3d_person3d *outP;   // [B][H]
   int32_t *out_count;    // [B]
@@ -220,6 +227,7 @@ struct Se3dWalk {
 // ---------------------------------------------------------------------------------------------------------------
 struct Se3dReproj {
   int N, T, n, pose_method;
+  int dense_form;             // host side: 1 = the three-kernel form even where the per-camera lists fit LDS (options.reproj_form; parity tests)
   int in_stride;              // batched launch (grid.z = result slot b): persons of slot b at in + b * in_stride, count n_dev[b]; every output
                               // array below holds one block per slot (dense / valid / slot / out / out_src: N * T entries, det_offset: N + 1)
   const int32_t *n_dev;       // optional device-side person count (resident chaining after stage 2); overrides n
@@ -234,4 +242,4 @@ struct Se3dReproj {
   int32_t *out_src;           // [N*T] input person index of each output entry
 };
 hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t stream, int batch = 1);
-size_t se3d_reproj_lists_lds(int N, int T);   // > 0: small rig, the one-kernel form runs and dense / valid / slot are not touched
+size_t se3d_reproj_lists_lds(int N, int T, int dense_form);   // > 0: small rig, the one-kernel form runs and dense / valid / slot are not touched

@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256) void se3d_k_reproj_compact(Se3dReproj Rb) {
 }  // namespace
 
 // dynamic LDS of the one-kernel form for a rig of N cameras and T person slots, 0 when the three-kernel form is used
-size_t se3d_reproj_lists_lds(int N, int T) {
-  if (N > 32 || getenv("SE3D_REPROJ_DENSE")) return 0;
+size_t se3d_reproj_lists_lds(int N, int T, int dense_form) {
+  if (N > 32 || dense_form) return 0;
   const size_t b = ((sizeof(se3d_person2d) * (size_t)T * N + 15) & ~(size_t)15) + (size_t)(32 / N) * SE3D_NKP * (21 * sizeof(double) + sizeof(float)) + (size_t)T * N + 16;
   return b <= 96 * 1024 ? b : 0;
 }
@@ -264,8 +264,8 @@ hipError_t se3d_launch_reproject(const Se3dReproj &R, int n_grid, hipStream_t st
   if (n_grid <= 0 || batch <= 0) {
     return hipMemsetAsync(R.det_offset, 0, sizeof(int32_t) * (R.N + 1) * (size_t)(batch > 0 ? batch : 1), stream);
   }
-  // small rigs: one workgroup per result slot, lists written directly (SE3D_REPROJ_DENSE=1: the three-kernel form, A/B)
-  const size_t lds_lists = se3d_reproj_lists_lds(R.N, R.T);
+  // small rigs: one workgroup per result slot, lists written directly (options.reproj_form = 1: the three-kernel form)
+  const size_t lds_lists = se3d_reproj_lists_lds(R.N, R.T, R.dense_form);
   if (lds_lists > 0) {
     // (the kernel's dynamic-LDS limit is raised per device by se3d_reproj_init_device, called from se3d_create)
     hipLaunchKernelGGL(se3d_k_reproject_lists, dim3(1, 1, batch), dim3(1024), lds_lists, stream, R);

@@ -196,48 +196,6 @@ __global__ __launch_bounds__(256) void se3d_k_pairs_flat(Se3dDev D, const int2 *
   }
 }
 
-// packed variant for small P: one workgroup per frame; the valid (det_a, det_b) entries of all camera pairs are enumerated densely
-// (prefix sums of n_a * n_b over the pairs), so no lane works on padding when cameras hold fewer than P detections
-// (16 cameras x 6 persons at P = 8: 36 of 64 entries per pair are valid; the flat kernel is VALU-bound at 100 % busy there).
-// Same per-entry arithmetic (se3d_pair_cost) -> identical table; padding entries are never read by the sweep.
-__global__ __launch_bounds__(256) void se3d_k_pairs_packed(Se3dDev D, const int2 *__restrict__ pair_ab) {
-  extern __shared__ int s_cum[];  // [np + 1] exclusive prefix of n_a * n_b
-  __shared__ int s_part[4];
-  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int32_t *nv = D.nvalid + (size_t)f * N;
-  int carry = 0;
-  for (int base = 0; base < np; base += 256) {  // block-wide exclusive scan, 256 pairs per round
-    const int pr = base + tid;
-    int v = 0;
-    if (pr < np) { const int2 ab = pair_ab[pr]; v = nv[ab.x] * nv[ab.y]; }
-    int inc = v;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    if (lane == 63) s_part[wave] = inc;
-    __syncthreads();
-    int off = carry;
-    for (int w = 0; w < wave; ++w) off += s_part[w];
-    if (pr < np) s_cum[pr] = off + inc - v;
-    carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    __syncthreads();
-  }
-  if (tid == 0) s_cum[np] = carry;
-  __syncthreads();
-  const int total = s_cum[np];
-  for (int e = tid; e < total; e += 256) {
-    int lo = 0, hi = np;  // largest pr with s_cum[pr] <= e
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cum[mid] <= e) lo = mid; else hi = mid; }
-    const int pr = lo;
-    const int2 ab = pair_ab[pr];
-    const int nb = nv[ab.y];
-    const int r = e - s_cum[pr];
-    const int p = r / nb, q = r - p * nb;
-    const size_t ia = ((size_t)(f * N + ab.x)) * P + p, ib = ((size_t)(f * N + ab.y)) * P + q;
-    const unsigned m = D.vmask_gt[ia] & D.vmask_gt[ib];
-    D.pair[(((size_t)f * np + pr) * P + p) * P + q] = se3d_pair_cost(D.F + 9 * (size_t)pr, D.kp + ia * SE3D_NKP, D.kp + ib * SE3D_NKP, m);
-  }
-}
-
 // Small rigs (N * P <= 256): normalisation and the packed pair-cost table in ONE workgroup per frame.  The normalised points of the
 // frame's detections live only in LDS (float2 x, y per (camera, slot, joint): 35 KB at most) — the kp / kcov copies of round 1 (two
 // float4 per joint: 428 MB of stores and 642 MB of loads per 8192-frame launch at 16 x 6) are gone; the triangulation kernels read the
@@ -390,304 +348,9 @@ __global__ __launch_bounds__(256) void se3d_k_normalize_pairs(Se3dDev D, const i
   }
 }
 
-// ---- the same table with the epipolar LINES hoisted (round 3; P <= 8; an A/B variant that lost: see the launcher) --------------------------
-// se3d_k_normalize_pairs evaluates an entry (det_a p, det_b q) on one lane and rebuilds, per joint, both epipolar lines F p1 and F^T p2, the
-// square roots of their norms and the two divisions: ~85 instructions per (entry, joint), although a line belongs to a (camera pair, detection,
-// joint) and serves n_b (n_a) entries.  Here a wavefront takes a run of camera pairs ("round": at most 64 det_b lanes and NPL_ROWS det_a rows);
-// a lane is one (pair, det_b q) and walks the det_a rows of its pair.  Per chunk of NPL_J joints: the lanes together build the det_a side's
-// operands of the round — line, sqrt(norm), the refined reciprocal of it, the point — once per (pair, p, joint) into the wavefront's own LDS
-// region (no workgroup barrier after the prologue), every lane builds the operands of its own det_b once per joint in registers, and an entry
-// costs two dot products, two five-operation quotients on the shared reciprocals, the range test and the fp64 add: ~26 instructions + two
-// 16-byte LDS reads.  The float operations are those of se3d_pair_cost_lds in the same order — the shared reciprocal is the first three
-// operations of se3d_div_core, the remaining five are applied per entry — so the table is bit-identical (tests/test_gpu_stage1.py).
-#define NPL_J 2        // joints per chunk
-#define NPL_ROWS 96    // det_a rows (pair, p) a round can stage; a round with more computes its det_a operands per entry
-#define NPL_PMAX 8     // P limit of this kernel (accumulators in registers); larger P takes se3d_k_normalize_pairs
-#define NPL_NPMAX 256  // camera pairs (one scan pass, pair list and F staged in LDS)
-struct __align__(16) NplRec { float lx, ly, lz, r, inv, px, py, pad; };
-__device__ __forceinline__ bool se3d_num_in_range(float n) {   // n >= 0: zero or inside [2^-60, 2^60]
-  const unsigned c = __float_as_uint(n);
-  return (c - 1u >= SE3D_EXACT_LO - 1u) && c <= SE3D_EXACT_HI;
-}
-// operands of one side of one joint: r = sqrt(lx^2 + ly^2) and the refined reciprocal of r (both 0: norm outside the exact range)
-__device__ __forceinline__ void se3d_line_ops(float lx, float ly, float &r, float &inv) {
-  const float s = lx * lx + ly * ly;
-  const unsigned b = __float_as_uint(s);
-  if (b >= SE3D_EXACT_LO && b <= SE3D_EXACT_HI) {
-    r = se3d_sqrt_core(s);
-    const float r0 = __builtin_amdgcn_rcpf(r);
-    const float e0 = __builtin_fmaf(-r, r0, 1.f);
-    inv = __builtin_fmaf(e0, r0, r0);
-  } else { r = 0.f; inv = 0.f; }
-}
-// n / r on the shared reciprocal (the last five operations of se3d_div_core) or, outside the exact range, the IEEE expressions on the norm
-__device__ __forceinline__ float se3d_line_dist(float n, float lx, float ly, float r, float inv) {
-  if (inv != 0.f && se3d_num_in_range(n)) {
-    const float q0 = n * inv;
-    const float e1 = __builtin_fmaf(-r, q0, n);
-    const float q1 = __builtin_fmaf(e1, inv, q0);
-    const float e2 = __builtin_fmaf(-r, q1, n);
-    return __builtin_fmaf(e2, inv, q1);
-  }
-  return n / sqrtf(lx * lx + ly * ly);
-}
-__device__ __forceinline__ NplRec se3d_npl_arec(const float *F, float2 pt) {
-  NplRec rc;
-  rc.lx = F[0] * pt.x + (F[1] * pt.y + F[2]);
-  rc.ly = F[3] * pt.x + (F[4] * pt.y + F[5]);
-  rc.lz = F[6] * pt.x + (F[7] * pt.y + F[8]);
-  se3d_line_ops(rc.lx, rc.ly, rc.r, rc.inv);
-  rc.px = pt.x; rc.py = pt.y; rc.pad = 0.f;
-  return rc;
-}
-__global__ __launch_bounds__(256) void se3d_k_normalize_pairs_lines(Se3dDev D, const int2 *__restrict__ pair_ab) {
-  extern __shared__ __align__(16) unsigned char np_smem[];
-  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  NplRec *arec = reinterpret_cast<NplRec *>(np_smem) + (size_t)wave * NPL_ROWS * NPL_J;   // [4 waves][NPL_ROWS][NPL_J], 16-byte aligned at the front
-  float2 *skp = reinterpret_cast<float2 *>(np_smem + (size_t)4 * NPL_ROWS * NPL_J * sizeof(NplRec));   // [N * P][17] filtered slot order
-  unsigned *s_mgt = reinterpret_cast<unsigned *>(skp + (size_t)N * P * SE3D_NKP);  // [N * P] by filtered slot
-  int *s_slot = reinterpret_cast<int *>(s_mgt + N * P);                    // [N * P]
-  int *s_nv = s_slot + N * P;                                              // [N]
-  int *s_cumA = s_nv + N;                                                  // [np + 1] det_a rows before pair pr
-  int *s_cumB = s_cumA + np + 1;                                           // [np + 1] det_b lanes before pair pr
-  int2 *s_ab = reinterpret_cast<int2 *>(s_cumB + np + 1 + ((np + 1) & 1)); // [np] the pair list (8-byte aligned)
-  float *s_F = reinterpret_cast<float *>(s_ab + np);                       // [np][9]
-  short2 *s_row = reinterpret_cast<short2 *>(s_F + (size_t)np * 9) + (size_t)wave * NPL_ROWS;   // [4 waves][NPL_ROWS]: (pair, det_a index ia) of a staged row
-  __shared__ int s_part[2][4];
-  // the pair list and the fundamental matrices of the rig into LDS (read many times below); overlaps the prologue's loads
-  for (int i = tid; i < np; i += 256) s_ab[i] = pair_ab[i];
-  for (int i = tid; i < np * 9; i += 256) s_F[i] = D.F[i];
-  se3d_np_prologue(D, f, tid, skp, s_mgt, s_slot, s_nv);
-  // ---- exclusive prefixes over the pairs of det_a rows and det_b lanes; a pair without detections on one side contributes nothing ----
-  {
-    int na = 0, nb = 0;
-    if (tid < np) { const int2 ab = s_ab[tid]; na = s_nv[ab.x]; nb = s_nv[ab.y]; if (na == 0 || nb == 0) { na = 0; nb = 0; } }
-    int ia = na, ib = nb;
-    for (int o = 1; o < 64; o <<= 1) { const int ta = __shfl_up(ia, o), tb = __shfl_up(ib, o); if (lane >= o) { ia += ta; ib += tb; } }
-    if (lane == 63) { s_part[0][wave] = ia; s_part[1][wave] = ib; }
-    __syncthreads();
-    int offa = 0, offb = 0;
-    for (int w = 0; w < wave; ++w) { offa += s_part[0][w]; offb += s_part[1][w]; }
-    if (tid < np) { s_cumA[tid] = offa + ia - na; s_cumB[tid] = offb + ib - nb; }
-    if (tid == np - 1) { s_cumA[np] = offa + ia; s_cumB[np] = offb + ib; }
-    __syncthreads();
-  }
-  const int totalB = s_cumB[np];
-  const int nrounds = (totalB + 63) >> 6;
-  for (int rd = wave; rd < nrounds; rd += 4) {   // a round: 64 consecutive (pair, det_b) lanes; from here on a wavefront works on its own
-    const int key = (rd << 6) + lane;
-    const bool have = key < totalB;
-    int pr;
-    {
-      const int k = have ? key : totalB - 1;
-      int lo = 0, hi = np;   // largest pr with s_cumB[pr] <= k (ties: the last one, which is the pair that owns lanes)
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cumB[mid] <= k) lo = mid; else hi = mid; }
-      pr = lo;
-    }
-    const int pr0 = __builtin_amdgcn_readfirstlane(pr);
-    const int pr1 = __builtin_amdgcn_readlane(pr, 63);   // lanes past the end were given the last lane's pair
-    const int rows0 = s_cumA[pr0], nrows = s_cumA[pr1 + 1] - rows0;
-    const bool staged = nrows <= NPL_ROWS;               // wave-uniform
-    const int2 ab = s_ab[pr];
-    const int q = (have ? key : totalB - 1) - s_cumB[pr];
-    const int na = have ? s_nv[ab.x] : 0;
-    const int rowbase = s_cumA[pr] - rows0;
-    const int ib = ab.y * P + q;
-    const unsigned mB = have ? s_mgt[ib] : 0u;
-    float Fv[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Fv[k] = s_F[pr * 9 + k];
-    unsigned mA[NPL_PMAX];
-#pragma unroll
-    for (int p_ = 0; p_ < NPL_PMAX; ++p_) mA[p_] = (p_ < na) ? (s_mgt[ab.x * P + p_] & mB) : 0u;
-    double acc[NPL_PMAX];
-#pragma unroll
-    for (int p_ = 0; p_ < NPL_PMAX; ++p_) acc[p_] = 0.0;
-    if (staged) {   // which (pair, detection) a staged row is: once per round
-      for (int row = lane; row < nrows; row += 64) {
-        const int k = rows0 + row;
-        int lo = pr0, hi = pr1 + 1;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cumA[mid] <= k) lo = mid; else hi = mid; }
-        s_row[row] = make_short2((short)lo, (short)(s_ab[lo].x * P + (k - s_cumA[lo])));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    for (int jc = 0; jc < SE3D_NKP; jc += NPL_J) {
-      const int jn = min(NPL_J, SE3D_NKP - jc);
-      if (staged) {   // ---- det_a side of the round: one (row, joint) item per lane and trip ----
-        for (int it = lane; it < nrows * NPL_J; it += 64) {
-          const int row = it / NPL_J, jj = it - row * NPL_J;
-          if (jj >= jn) continue;
-          const short2 ri = s_row[row];
-          arec[row * NPL_J + jj] = se3d_npl_arec(s_F + 9 * (int)ri.x, skp[(size_t)ri.y * SE3D_NKP + jc + jj]);
-        }
-      }
-      // ---- det_b side: this lane's own detection, in registers ----
-      float bx[NPL_J], by[NPL_J], l2x[NPL_J], l2y[NPL_J], l2z[NPL_J], r2[NPL_J], inv2[NPL_J];
-#pragma unroll
-      for (int jj = 0; jj < NPL_J; ++jj) {
-        const float2 pt = (have && jj < jn) ? skp[(size_t)ib * SE3D_NKP + jc + jj] : make_float2(0.f, 0.f);
-        bx[jj] = pt.x; by[jj] = pt.y;
-        l2x[jj] = Fv[0] * pt.x + (Fv[3] * pt.y + Fv[6]);
-        l2y[jj] = Fv[1] * pt.x + (Fv[4] * pt.y + Fv[7]);
-        l2z[jj] = Fv[2] * pt.x + (Fv[5] * pt.y + Fv[8]);
-        se3d_line_ops(l2x[jj], l2y[jj], r2[jj], inv2[jj]);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      // ---- entries: rows of this lane's pair ----
-#pragma unroll
-      for (int p_ = 0; p_ < NPL_PMAX; ++p_) {
-        if (p_ < na) {
-          const unsigned m = mA[p_] >> jc;
-#pragma unroll
-          for (int jj = 0; jj < NPL_J; ++jj) {
-            if (jj < jn && ((m >> jj) & 1u)) {
-              const NplRec a = staged ? arec[(rowbase + p_) * NPL_J + jj] : se3d_npl_arec(Fv, skp[(size_t)(ab.x * P + p_) * SE3D_NKP + jc + jj]);
-              const float n1 = fabsf(bx[jj] * a.lx + (by[jj] * a.ly + a.lz));
-              const float n2 = fabsf(a.px * l2x[jj] + (a.py * l2y[jj] + l2z[jj]));
-              const float d = se3d_line_dist(n1, a.lx, a.ly, a.r, a.inv) + se3d_line_dist(n2, l2x[jj], l2y[jj], r2[jj], inv2[jj]);
-              acc[p_] += (double)d;
-            }
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();   // the records of this chunk are dead: the next chunk overwrites them
-    }
-    if (have) {
-#pragma unroll
-      for (int p_ = 0; p_ < NPL_PMAX; ++p_) {
-        if (p_ < na) {
-          const int n = __popc(mA[p_]);
-          D.pair[(((size_t)f * np + pr) * P + p_) * P + q] = n > 0 ? acc[p_] / n : -1.0;
-        }
-      }
-    }
-  }
-}
-
-// ---- the same table with TR x TC register tiles of entries per lane (round 3) ---------------------------------------------------------------
-// The per-entry kernel rebuilds both epipolar lines, their norms' square roots and the reciprocals for every (entry, joint): ~54 of its ~81
-// instructions.  A lane that owns a TR x TC block of entries of one camera pair builds TR + TC lines per joint instead of 2 TR TC and needs no
-// LDS beyond the points: (TR + TC) / (TR TC) x 27 + 27 instructions per (entry, joint) — 54 at 2 x 2 — at the price of padding when n_a, n_b are
-// not multiples of the tile.  Same float operations in the same order as se3d_pair_cost_lds (the shared reciprocal is the first three operations
-// of se3d_div_core, see se3d_line_ops / se3d_line_dist) -> bit-identical table.
-template <int TR, int TC>
-__global__ __launch_bounds__(256) void se3d_k_normalize_pairs_tiles(Se3dDev D, const int2 *__restrict__ pair_ab) {
-  extern __shared__ __align__(16) unsigned char np_smem[];
-  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float2 *skp = reinterpret_cast<float2 *>(np_smem);                       // [N * P][17] filtered slot order
-  unsigned *s_mgt = reinterpret_cast<unsigned *>(skp + (size_t)N * P * SE3D_NKP);  // [N * P] by filtered slot
-  int *s_slot = reinterpret_cast<int *>(s_mgt + N * P);                    // [N * P]
-  int *s_nv = s_slot + N * P;                                              // [N]
-  int *s_cum = s_nv + N;                                                   // [np + 1] tiles before pair pr
-  __shared__ int s_part[4];
-  se3d_np_prologue(D, f, tid, skp, s_mgt, s_slot, s_nv);
-  int carry = 0;
-  for (int base = 0; base < np; base += 256) {   // exclusive prefix of ceil(n_a / TR) * ceil(n_b / TC) over the camera pairs
-    const int pr = base + tid;
-    int v = 0;
-    if (pr < np) { const int2 ab = pair_ab[pr]; v = ((s_nv[ab.x] + TR - 1) / TR) * ((s_nv[ab.y] + TC - 1) / TC); }
-    int inc = v;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    if (lane == 63) s_part[wave] = inc;
-    __syncthreads();
-    int off = carry;
-    for (int w = 0; w < wave; ++w) off += s_part[w];
-    if (pr < np) s_cum[pr] = off + inc - v;
-    carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    __syncthreads();
-  }
-  if (tid == 0) s_cum[np] = carry;
-  __syncthreads();
-  const int total = s_cum[np];
-  for (int e = tid; e < total; e += 256) {
-    int lo = 0, hi = np;  // largest pr with s_cum[pr] <= e
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cum[mid] <= e) lo = mid; else hi = mid; }
-    const int pr = lo;
-    const int2 ab = pair_ab[pr];
-    const int na = s_nv[ab.x], nb = s_nv[ab.y];
-    const int tcn = (nb + TC - 1) / TC;
-    const int r = e - s_cum[pr];
-    const int p0 = (r / tcn) * TR, q0 = (r - (r / tcn) * tcn) * TC;
-    const float *F = D.F + 9 * (size_t)pr;
-    const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
-    unsigned ma[TR], mb[TC], many = 0u;
-    const float2 *ka[TR], *kb[TC];
-#pragma unroll
-    for (int i = 0; i < TR; ++i) { const int p = min(p0 + i, na - 1); ma[i] = (p0 + i < na) ? s_mgt[ab.x * P + p] : 0u; ka[i] = skp + (size_t)(ab.x * P + p) * SE3D_NKP; }
-#pragma unroll
-    for (int k = 0; k < TC; ++k) { const int q = min(q0 + k, nb - 1); mb[k] = (q0 + k < nb) ? s_mgt[ab.y * P + q] : 0u; kb[k] = skp + (size_t)(ab.y * P + q) * SE3D_NKP; }
-    double acc[TR][TC];
-#pragma unroll
-    for (int i = 0; i < TR; ++i)
-#pragma unroll
-      for (int k = 0; k < TC; ++k) { acc[i][k] = 0.0; many |= ma[i] & mb[k]; }
-#pragma unroll
-    for (int j = 0; j < SE3D_NKP; ++j) {
-      if ((many >> j) & 1u) {
-        float ax[TR], ay[TR], l1x[TR], l1y[TR], l1z[TR], r1[TR], i1[TR];
-        float bx[TC], by[TC], l2x[TC], l2y[TC], l2z[TC], r2[TC], i2[TC];
-#pragma unroll
-        for (int i = 0; i < TR; ++i) {
-          const float2 pt = ka[i][j];
-          ax[i] = pt.x; ay[i] = pt.y;
-          l1x[i] = f0 * pt.x + (f1 * pt.y + f2);
-          l1y[i] = f3 * pt.x + (f4 * pt.y + f5);
-          l1z[i] = f6 * pt.x + (f7 * pt.y + f8);
-          se3d_line_ops(l1x[i], l1y[i], r1[i], i1[i]);
-        }
-#pragma unroll
-        for (int k = 0; k < TC; ++k) {
-          const float2 pt = kb[k][j];
-          bx[k] = pt.x; by[k] = pt.y;
-          l2x[k] = f0 * pt.x + (f3 * pt.y + f6);
-          l2y[k] = f1 * pt.x + (f4 * pt.y + f7);
-          l2z[k] = f2 * pt.x + (f5 * pt.y + f8);
-          se3d_line_ops(l2x[k], l2y[k], r2[k], i2[k]);
-        }
-#pragma unroll
-        for (int i = 0; i < TR; ++i)
-#pragma unroll
-          for (int k = 0; k < TC; ++k) {
-            const float n1 = fabsf(bx[k] * l1x[i] + (by[k] * l1y[i] + l1z[i]));
-            const float n2 = fabsf(ax[i] * l2x[k] + (ay[i] * l2y[k] + l2z[k]));
-            const float d = se3d_line_dist(n1, l1x[i], l1y[i], r1[i], i1[i]) + se3d_line_dist(n2, l2x[k], l2y[k], r2[k], i2[k]);
-            acc[i][k] += ((ma[i] & mb[k]) >> j) & 1u ? (double)d : 0.0;
-          }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < TR; ++i)
-#pragma unroll
-      for (int k = 0; k < TC; ++k)
-        if (p0 + i < na && q0 + k < nb) {
-          const int n = __popc(ma[i] & mb[k]);
-          D.pair[(((size_t)f * np + pr) * P + p0 + i) * P + q0 + k] = n > 0 ? acc[i][k] / n : -1.0;
-        }
-  }
-}
-
-// tiled variant for large P: one workgroup per (64x64 tile of det_a x det_b, camera pair, frame).
-// The epipolar line of a point depends on one side only, so l1 = F p1 (+ its norm) is computed once per (det_a, joint)
-// and l2 = F^T p2 once per (det_b, joint) and staged in LDS; the inner loop is 2 dot products, 2 IEEE divides and one
-// fp64 add per pair-joint.  All float operations are the ones of se3d_pair_cost in the same order -> bit-identical.
-#define PT 64
-struct __align__(16) LineLDS { float lx, ly, lz, nrm; };
-
-// Correctly rounded a / b from y = RN(1/b) (IEEE reciprocal computed once per epipolar line and shared by every pair on
-// that line): one multiply and two FMA-residual corrections (Markstein).  q0 = RN(a y) is within 1.5 ulp, the first
-// correction makes it faithful, the second rounds correctly provided y is the correctly rounded reciprocal, results stay in
-// the normal range and b's significand is not all ones (such lines carry nrm_ok = 0 and take the IEEE divide).
-// tests/test_gpu_stage1.py checks the resulting table bit-for-bit against the plain IEEE-divide kernel and the oracle.
-// Range guard for the shared-reciprocal divide: every operand of a numerator/denominator is 0 or within [2^-30, 2^30].
-// Then a non-zero numerator is >= 2^-84 and a quotient >= 2^-115, so all FMA residuals of se3d_div_markstein are exact
-// (no underflow) and its two correction steps return the correctly rounded quotient; zero numerators give exactly 0.
+// Range guard of the shared-reciprocal divide (se3d_div_shared, rows kernel): every operand of a numerator / denominator is 0 or within
+// [2^-30, 2^30].  Then a non-zero numerator is >= 2^-84 and a quotient >= 2^-115, so with float32 denormals preserved every FMA residual is
+// exact (no underflow) and the correction returns the correctly rounded quotient; zero numerators give exactly 0.
 __device__ __forceinline__ bool se3d_in_safe_range(float v) {
   const unsigned ex = (__float_as_uint(v) >> 23) & 0xffu;
   return (v == 0.f) || (ex >= 97u && ex <= 157u);
@@ -698,161 +361,6 @@ __device__ __forceinline__ float se3d_safe_rcp(float b) {
   const unsigned ex = (u >> 23) & 0xffu;
   const bool ok = (ex >= 97u && ex <= 157u) && ((u & 0x7fffffu) != 0x7fffffu);
   return ok ? 1.0f / b : 0.0f;
-}
-__device__ __forceinline__ float se3d_div_markstein(float a, float b, float y) {
-  float q = a * y;
-  float r = __builtin_fmaf(-b, q, a);
-  q = __builtin_fmaf(r, y, q);
-  r = __builtin_fmaf(-b, q, a);
-  return __builtin_fmaf(r, y, q);
-}
-
-#define JT 9  // joints staged per LDS phase (17 = 9 + 8)
-template <bool FAST, int NI, int NK>
-__device__ __forceinline__ void se3d_pairs_tile_compute(const LineLDS (*L1)[PT], const LineLDS (*L2)[PT], const float4 (*P1)[PT], const float4 (*P2)[PT],
-                                                     int jn, int jbase, int tx, int ty, const unsigned (&mm)[4][4], double (&acc)[4][4]) {
-  for (int jj = 0; jj < jn; ++jj) {
-    const int j = jbase + jj;
-    LineLDS l1[NI], l2[NK];
-    float4 a[NI], b[NK];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) { l1[i] = L1[jj][ty + 16 * i]; a[i] = P1[jj][ty + 16 * i]; }
-#pragma unroll
-    for (int k = 0; k < NK; ++k) { l2[k] = L2[jj][tx + 16 * k]; b[k] = P2[jj][tx + 16 * k]; }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-#pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const float n1 = fabsf(b[k].x * l1[i].lx + (b[k].y * l1[i].ly + l1[i].lz));
-        const float n2 = fabsf(a[i].x * l2[k].lx + (a[i].y * l2[k].ly + l2[k].lz));
-        float d1, d2;
-        if (FAST) { d1 = se3d_div_markstein(n1, l1[i].nrm, a[i].z); d2 = se3d_div_markstein(n2, l2[k].nrm, b[k].z); }
-        else { d1 = n1 / l1[i].nrm; d2 = n2 / l2[k].nrm; }
-        // joint validity as 0/1 weights staged with the points (P*.w): (d1 + d2) * 1 is exact, (d1 + d2) * 0 adds +0.0 — the same sum as
-        // the masked accumulation, two multiplies instead of a bit test and a 64-bit select per pair-joint (all operands are finite)
-        if (FAST) {
-          const float sacc = (d1 + d2) * (a[i].w * b[k].w);  // finite: the shared-reciprocal divide returns 0 for a zero / out-of-range norm
-          acc[i][k] += (double)sacc;
-        } else {
-          const float sacc = d1 + d2;                          // IEEE divide: an invalid joint may be inf / NaN, select instead of multiply
-          acc[i][k] += ((mm[i][k] >> j) & 1u) ? (double)sacc : 0.0;
-        }
-      }
-    }
-  }
-}
-
-template <bool FAST>
-__device__ __forceinline__ void se3d_pairs_tile_dispatch(const LineLDS (*L1)[PT], const LineLDS (*L2)[PT], const float4 (*P1)[PT], const float4 (*P2)[PT],
-                                                         int jn, int jbase, int tx, int ty, int ni, int nk, const unsigned (&mm)[4][4],
-                                                         double (&acc)[4][4]) {
-#define SE3D_PT_CASE(NI_, NK_) \
-  case (NI_) * 4 + (NK_) - 5: se3d_pairs_tile_compute<FAST, NI_, NK_>(L1, L2, P1, P2, jn, jbase, tx, ty, mm, acc); break;
-  switch (ni * 4 + nk - 5) {  // block-uniform
-    SE3D_PT_CASE(1, 1) SE3D_PT_CASE(1, 2) SE3D_PT_CASE(1, 3) SE3D_PT_CASE(1, 4)
-    SE3D_PT_CASE(2, 1) SE3D_PT_CASE(2, 2) SE3D_PT_CASE(2, 3) SE3D_PT_CASE(2, 4)
-    SE3D_PT_CASE(3, 1) SE3D_PT_CASE(3, 2) SE3D_PT_CASE(3, 3) SE3D_PT_CASE(3, 4)
-    SE3D_PT_CASE(4, 1) SE3D_PT_CASE(4, 2) SE3D_PT_CASE(4, 3) SE3D_PT_CASE(4, 4)
-  }
-#undef SE3D_PT_CASE
-}
-
-__global__ __launch_bounds__(256, 3) void se3d_k_pairs_tiled(Se3dDev D, const int2 *__restrict__ pair_ab) {
-  const int N = D.d.N, P = D.d.P, np = D.d.npairs;
-  const int tiles = (P + PT - 1) / PT;
-  const int tp = blockIdx.x / tiles, tq = blockIdx.x % tiles;
-  const int pr = blockIdx.y, f = blockIdx.z;
-  const int2 ab = pair_ab[pr];
-  const int na = D.nvalid[f * N + ab.x], nb = D.nvalid[f * N + ab.y];
-  const int p0 = tp * PT, q0 = tq * PT;
-  if (p0 >= na || q0 >= nb) return;
-  __shared__ LineLDS L1[JT][PT];  // [joint][det_a]: epipolar line F p1 and its norm
-  __shared__ LineLDS L2[JT][PT];  // [joint][det_b]: F^T p2
-  __shared__ float4 P1[JT][PT];   // (x, y, RN(1/norm) of the own line, -)
-  __shared__ float4 P2[JT][PT];
-  __shared__ unsigned M1[PT], M2[PT];
-  __shared__ int s_unsafe;
-  const int tid = threadIdx.x;
-  const float *F = D.F + 9 * (size_t)pr;
-  const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
-  const size_t baseA = ((size_t)(f * N + ab.x)) * P, baseB = ((size_t)(f * N + ab.y)) * P;
-  if (tid == 0) s_unsafe = 0;
-  for (int d = tid; d < PT; d += 256) {
-    M1[d] = (p0 + d < na) ? D.vmask_gt[baseA + p0 + d] : 0u;
-    M2[d] = (q0 + d < nb) ? D.vmask_gt[baseB + q0 + d] : 0u;
-  }
-  __syncthreads();
-  const int tx = tid & 15, ty = tid >> 4;  // thread tile: det_a rows ty + 16 i, det_b cols tx + 16 k (tx fastest: coalesced stores)
-  const int ni = min(4, (na - p0 + 15) >> 4), nk = min(4, (nb - q0 + 15) >> 4);  // 16-wide groups holding valid detections
-  double acc[4][4];
-  unsigned mm[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { acc[i][k] = 0.0; mm[i][k] = M1[ty + 16 * i] & M2[tx + 16 * k]; }
-  for (int jbase = 0; jbase < SE3D_NKP; jbase += JT) {
-    const int jn = min(JT, SE3D_NKP - jbase);
-    __syncthreads();  // previous phase finished reading the LDS tiles
-    bool unsafe = false;
-    for (int i = tid; i < PT * jn; i += 256) {
-      const int d = i / jn, jj = i - d * jn, k = jbase + jj;
-      {
-        const int p = p0 + d;
-        float4 A = make_float4(0.f, 0.f, -1.f, 0.f);
-        if (p < na) A = D.kp[(baseA + p) * SE3D_NKP + k];
-        LineLDS l;
-        l.lx = f0 * A.x + (f1 * A.y + f2);
-        l.ly = f3 * A.x + (f4 * A.y + f5);
-        l.lz = f6 * A.x + (f7 * A.y + f8);
-        l.nrm = sqrtf(l.lx * l.lx + l.ly * l.ly);
-        const float y = se3d_safe_rcp(l.nrm);
-        unsafe |= (p < na) && ((M1[d] >> k) & 1u) &&
-                  !(y != 0.f && se3d_in_safe_range(l.lx) && se3d_in_safe_range(l.ly) && se3d_in_safe_range(l.lz) && se3d_in_safe_range(A.x) && se3d_in_safe_range(A.y));
-        L1[jj][d] = l;
-        P1[jj][d] = make_float4(A.x, A.y, y, (p < na && ((M1[d] >> k) & 1u)) ? 1.f : 0.f);
-      }
-      {
-        const int q = q0 + d;
-        float4 Bq = make_float4(0.f, 0.f, -1.f, 0.f);
-        if (q < nb) Bq = D.kp[(baseB + q) * SE3D_NKP + k];
-        LineLDS l;
-        l.lx = f0 * Bq.x + (f3 * Bq.y + f6);
-        l.ly = f1 * Bq.x + (f4 * Bq.y + f7);
-        l.lz = f2 * Bq.x + (f5 * Bq.y + f8);
-        l.nrm = sqrtf(l.lx * l.lx + l.ly * l.ly);
-        const float y = se3d_safe_rcp(l.nrm);
-        unsafe |= (q < nb) && ((M2[d] >> k) & 1u) &&
-                  !(y != 0.f && se3d_in_safe_range(l.lx) && se3d_in_safe_range(l.ly) && se3d_in_safe_range(l.lz) && se3d_in_safe_range(Bq.x) && se3d_in_safe_range(Bq.y));
-        L2[jj][d] = l;
-        P2[jj][d] = make_float4(Bq.x, Bq.y, y, (q < nb && ((M2[d] >> k) & 1u)) ? 1.f : 0.f);
-      }
-    }
-    if (unsafe) s_unsafe = 1;
-    __syncthreads();
-    // block-uniform choice: shared-reciprocal divide (exact under the range guard) or the plain IEEE divide
-#ifndef SE3D_EXP_NOCOMPUTE
-    if (!s_unsafe) se3d_pairs_tile_dispatch<true>(L1, L2, P1, P2, jn, jbase, tx, ty, ni, nk, mm, acc);
-    else se3d_pairs_tile_dispatch<false>(L1, L2, P1, P2, jn, jbase, tx, ty, ni, nk, mm, acc);
-#else
-    acc[0][0] += L1[0][ty].lx + L2[0][tx].ly + P1[0][ty].z + P2[0][tx].z;  // ablation build only
-#endif
-  }
-  double *out = D.pair + ((size_t)f * np + pr) * P * P;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = p0 + ty + 16 * i;
-    if (p >= na) continue;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int q = q0 + tx + 16 * k;
-      if (q >= nb) continue;
-      const int n = __popc(mm[i][k]);
-#ifdef SE3D_EXP_NOSTORE
-      if (acc[i][k] == 12345.678)  // ablation build only: keeps the computation alive without the store traffic
-#endif
-      out[(size_t)p * P + q] = n > 0 ? acc[i][k] / n : -1.0;
-    }
-  }
 }
 
 // =============================================================================================================
@@ -1254,6 +762,7 @@ __device__ __forceinline__ void se3d_sweep_assign_body(const Se3dDev &D, int b, 
   }
   __syncthreads();
   S1_STAMP(0)  // mask row/column scans
+  if (tid == 0) { atomicAdd(&D.tri_cnt[4], 1u); if (s_amb) atomicAdd(&D.tri_cnt[5], 1u); }   // statistics (se3d_get_sweep_stats): steps, steps that run the Hungarian
   if (s_amb) {  // more than one feasible association: Hungarian on the full (unmasked) C (S3D:628-634)
     S1_COUNT(9)
     const double *C = D.C + (size_t)f * H * P;
@@ -1314,10 +823,8 @@ __global__ __launch_bounds__(256) void se3d_k_sweep_assign(Se3dDev D, int b, int
   se3d_sweep_assign_body(D, b, blockIdx.x, s_dynW_k, dyn_lds_bytes);
 }
 
-// Small problems (few cameras, H*P small): the whole camera sweep of a frame in ONE launch.  The per-step kernels above need the
-// whole GPU per step only when the cost gather is large; at 16 cameras x 8 detections the 2 x N dependent launches are pure launch
-// latency.  One workgroup per frame: thread <-> (hypothesis, detection) gathers its cost from the pair table in the reference's
-// accumulation order (ascending attached view), then the same assignment body runs; steps are separated by workgroup barriers.
+// Cost and veto mask of camera step b for a problem small enough that one wavefront walks the whole sweep (se3d_k_sweep_fused_wave): lane <->
+// (hypothesis, detection) gathers its cost from the pair table in the reference's accumulation order (ascending attached view).
 __device__ __forceinline__ void se3d_sweep_cost_small(const Se3dDev &D, int b, int f, int tid, int nthr) {
   const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
   if (D.nraw[f * N + b] == 0) return;
@@ -1367,18 +874,6 @@ __device__ __forceinline__ void se3d_sweep_cost_small(const Se3dDev &D, int b, i
     else { C = MAX_COSTS; veto = true; }
     D.C[(size_t)f * H * P + h + (size_t)H * q] = C;
     D.mask[(size_t)f * H * P + h + (size_t)H * q] = (!veto && C < max_epi) ? 1 : 0;
-  }
-}
-__global__ __launch_bounds__(256) void se3d_k_sweep_fused(Se3dDev D, int dyn_lds_bytes) {
-  extern __shared__ __align__(16) double s_dynW_f[];
-  const int f = blockIdx.x;
-  for (int b = 0; b < D.d.N; ++b) {
-    if (b > 0) {
-      se3d_sweep_cost_small(D, b, f, threadIdx.x, 256);
-      __syncthreads();
-    }
-    se3d_sweep_assign_body(D, b, f, s_dynW_f, dyn_lds_bytes);
-    __syncthreads();
   }
 }
 
@@ -2676,282 +2171,22 @@ __device__ __forceinline__ int se3d_post_filter(se3d_person3d &p, int pm) {
     return num_valid;
 }
 
-// Small problems (H <= 16): one wavefront per frame, the frame's hypotheses staged in LDS (27 KB at most) so that the serial
-// per-person filters, the duplicate merge and the ordered compaction run at LDS instead of L2/HBM latency, without workgroup barriers.
 #define SE3D_POST_SMALL_H 16
-__global__ __launch_bounds__(64) void se3d_k_postprocess_wave(Se3dDev D) {
-  extern __shared__ __align__(16) unsigned char post_smem[];   // H persons (not SE3D_POST_SMALL_H): 20 KB at H = 12 -> 7 wavefronts per CU
-  se3d_person3d *sp = reinterpret_cast<se3d_person3d *>(post_smem);
-  const int f = blockIdx.x, lane = threadIdx.x;
-  const int N = D.d.N, P = D.d.P, H = D.d.H;
-  const int pm = D.d.pose_method;
-  const int nh = D.nhyp[f];
-  const se3d_person3d *persons = D.hypP + (size_t)f * H;
-  constexpr int words2 = (int)(sizeof(se3d_person3d) / 8);   // a person is 211 8-byte words: half the copy instructions of a dword copy
-  int ncam = 0;
-  for (int c = lane; c < N; c += 64) ncam += (D.nraw[f * N + c] > 0) ? 1 : 0;
-  for (int o = 32; o > 0; o >>= 1) ncam += __shfl_xor(ncam, o);
-  const bool few = ncam < 2;  // S3D:557-560
-  {
-    const uint2 *src = reinterpret_cast<const uint2 *>(persons);
-    uint2 *dst = reinterpret_cast<uint2 *>(sp);
-    for (int w = lane; w < nh * words2; w += 64) dst[w] = src[w];
-  }
-  __syncthreads();
-  bool al = false;
-  if (lane < nh && !few && D.nviews[f * H + lane] >= 2) al = se3d_post_filter(sp[lane], pm) > 9;
-  __syncthreads();
-  unsigned long long alive = __ballot(al);
-  // ---- duplicate merge (S3D:984-996): sequential in i, distances to all later j in parallel ----
-  for (int i = 0; i < nh; ++i) {
-    if (!((alive >> i) & 1ull)) continue;
-    int from = i + 1;
-    for (;;) {
-      const int jj = from + lane;
-      bool hit = false;
-      if (jj < nh && ((alive >> jj) & 1ull)) {
-        int nu = 0;
-        double dist = 0.0;
-        for (int k = 0; k < SE3D_NFU; ++k) {
-          const se3d_keypoint3d &a = sp[i].keypoints[k], &bb = sp[jj].keypoints[k];
-          if (a.score > 0.f && bb.score > 0.f) {
-            const double dx = a.joint[0] - bb.joint[0], dy = a.joint[1] - bb.joint[1], dz = a.joint[2] - bb.joint[2];
-            dist += sqrt(dx * dx + dy * dy + dz * dz);
-            ++nu;
-          }
-        }
-        hit = (nu > 0 ? dist / nu : MAX_COSTS) < 0.20;
-      }
-      const unsigned long long hb = __ballot(hit);
-      if (!hb) break;
-      const int jm = from + __ffsll((long long)hb) - 1;
-      __syncthreads();
-      if (lane < SE3D_NFU) {  // merge_persons (S3D:410-423), one joint per lane
-        se3d_keypoint3d &k1 = sp[i].keypoints[lane];
-        const se3d_keypoint3d &k2 = sp[jm].keypoints[lane];
-        const double total = (double)(k1.score + k2.score);
-        if (total > 0.0) {
-          for (int a = 0; a < 3; ++a) k1.joint[a] = ((double)k1.score * k1.joint[a] + (double)k2.score * k2.joint[a]) / total;
-          k1.score = fmaxf(k1.score, k2.score);
-          for (int a = 0; a < 6; ++a) k1.cov[a] = (k1.cov[a] + k2.cov[a]) / 2.0;
-        }
-      }
-      __syncthreads();
-      alive &= ~(1ull << jm);
-      from = jm + 1;
-    }
-  }
-  // ---- compaction in ascending hypothesis order + association table in original detection indices ----
-  const int total = __popcll(alive);
-  int pos = 0;
-  for (unsigned long long m = alive; m; m &= m - 1ull, ++pos) {
-    const int h = __ffsll((long long)m) - 1;
-    const uint2 *src = reinterpret_cast<const uint2 *>(&sp[h]);
-    uint2 *dst = reinterpret_cast<uint2 *>(&D.outP[(size_t)f * H + pos]);
-    for (int w = lane; w < words2; w += 64) dst[w] = src[w];
-    if (lane == 0) D.out_hyp[(size_t)f * H + pos] = h;
-  }
-  if (lane == 0) {
-    D.out_count[f] = total;
-    if (few) {  // the reference returns before building any hypothesis (S3D:557-560)
-      atomicOr(&D.flags[f], SE3D_FLAG_FEW_CAMERAS);
-      D.nhyp[f] = 0;
-    }
-  }
-  for (int i = lane; i < nh * N; i += 64) {
-    const int h = i / N, c = i - h * N;
-    const int k = D.assoc[((size_t)f * H + h) * N + c];
-    D.out_assoc[((size_t)f * H + h) * N + c] = (k >= 0) ? D.orig[((size_t)(f * N + c)) * P + k] : -1;
-  }
-}
-
-// Lane-parallel form of se3d_k_postprocess_wave (round 2): the plausibility filter and the duplicate-merge distances run over
-// (person, joint) items instead of one lane per person walking its 17 + 21 joints (6 of 64 lanes busy, 4.7 k instructions per frame at
-// 17 % VALU issue utilisation).  Everything whose ORDER matters stays in the reference's order: a keypoint's covariance gets its own
-// limb-length term before the right-shoulder special case adds to the left shoulder (S3D:875-881), and the mean joint distance of a
-// pair of persons is summed joint by joint in ascending order by one lane — only the square roots under the sum are computed in
-// parallel.  Same results as se3d_post_filter / the sequential merge loop bit for bit (tests/test_gpu_stage1.py compares the two forms).
-__global__ __launch_bounds__(64) void se3d_k_postprocess_wave2(Se3dDev D) {
-  extern __shared__ __align__(16) unsigned char post_smem[];
-  const int f = blockIdx.x, lane = threadIdx.x;
-  const int N = D.d.N, P = D.d.P, H = D.d.H;
-  const int pm = D.d.pose_method;
-  se3d_person3d *sp = reinterpret_cast<se3d_person3d *>(post_smem);                 // [H] persons
-  double *term = reinterpret_cast<double *>(sp + H);                                  // [H][21] joint distances of (i, j) for the current i; < 0: joint not in both
-  int *cnt0 = reinterpret_cast<int *>(term + (size_t)H * SE3D_NFU), *dec = cnt0 + H;  // [H] valid input keypoints / removed fusion slots
-  const int nh = D.nhyp[f];
-  const se3d_person3d *persons = D.hypP + (size_t)f * H;
-  constexpr int words2 = (int)(sizeof(se3d_person3d) / 8);
-  int ncam = 0;
-  for (int c = lane; c < N; c += 64) ncam += (D.nraw[f * N + c] > 0) ? 1 : 0;
-  for (int o = 32; o > 0; o >>= 1) ncam += __shfl_xor(ncam, o);
-  const bool few = ncam < 2;  // S3D:557-560
-  {
-    const uint2 *src = reinterpret_cast<const uint2 *>(persons);
-    uint2 *dst = reinterpret_cast<uint2 *>(sp);
-    for (int w = lane; w < nh * words2; w += 64) dst[w] = src[w];
-  }
-  const int nv_l = (lane < nh) ? D.nviews[f * H + lane] : 0;
-  if (lane < H) { cnt0[lane] = 0; dec[lane] = 0; }
-  __syncthreads();
-  // ---- limb-length covariance inflation (S3D:861-883), own keypoint: items (person, input keypoint) ----
-  double s56 = 0.0;   // the right shoulder's term for the left shoulder (special case), applied after every own term
-  bool add56 = false;
-  int h56 = 0;
-  for (int it = lane; it < nh * SE3D_NKP; it += 64) {
-    const int h = it / SE3D_NKP, k = it - h * SE3D_NKP;
-    se3d_person3d &p = sp[h];
-    se3d_keypoint3d &kp = p.keypoints[c_kp2fusion[pm][k]];
-    if (kp.score <= 0.f) continue;
-    atomicAdd(&cnt0[h], 1);
-    const int parent = c_kpParent[pm][k];
-    if (parent < 0) continue;
-    const se3d_keypoint3d &pk = p.keypoints[c_kp2fusion[pm][parent]];
-    if (pk.score > 0.f && c_limbLength[pm][k] > 0) {
-      const double jd = se3d_jdist(kp.joint, pk.joint);
-      se3d_addcov(kp, 0.075 * (jd - c_limbLength[pm][k]) / c_limbLSigma[pm][k]);
-    } else if (pm == SE3D_POSE_SIMPLE && k == 6) {  // RShoulder special case (S3D:875-881)
-      const se3d_keypoint3d &ls = p.keypoints[c_kp2fusion[pm][5]];
-      if (ls.score > 0.f) {
-        const double jd = se3d_jdist(kp.joint, ls.joint);
-        s56 = 0.075 * (jd - 0.35) / 0.15;
-        se3d_addcov(kp, s56);
-        add56 = true;
-        h56 = h;
-      }
-    }
-  }
-  __syncthreads();
-  if (add56) se3d_addcov(sp[h56].keypoints[c_kp2fusion[pm][5]], s56);   // after the left shoulder's own term (k = 5 precedes k = 6)
-  __syncthreads();
-  // ---- distance to the root (S3D:937-953): items (person, fusion slot) ----
-  for (int it = lane; it < nh * SE3D_NFU; it += 64) {
-    const int h = it / SE3D_NFU, k = it - h * SE3D_NFU;
-    se3d_person3d &p = sp[h];
-    double root[3] = {0, 0, 0};
-    float root_score = 0.f;
-    if (p.keypoints[FU_MidHip].score > 0.f) {
-      for (int a = 0; a < 3; ++a) root[a] = p.keypoints[FU_MidHip].joint[a];
-      root_score = p.keypoints[FU_MidHip].score;
-    } else if (p.keypoints[FU_LHip].score > 0.f && p.keypoints[FU_RHip].score > 0.f) {
-      for (int a = 0; a < 3; ++a) root[a] = (p.keypoints[FU_LHip].joint[a] + p.keypoints[FU_RHip].joint[a]) / 2.;
-      root_score = (p.keypoints[FU_LHip].score + p.keypoints[FU_RHip].score) / 2.f;
-    }
-    // the reference takes a copy of the root before it starts removing keypoints (a hip farther than 2 m from the hips' midpoint is removed
-    // too): every lane reads the root here, the removals come after the barrier below
-    bool rm = false;
-    if (root_score > 0.f) {
-      se3d_keypoint3d &kp = p.keypoints[k];
-      rm = !(kp.score > 0.f) || se3d_jdist(root, kp.joint) > 2.0;
-    }
-    term[it] = rm ? 1.0 : 0.0;
-  }
-  __syncthreads();
-  for (int it = lane; it < nh * SE3D_NFU; it += 64)
-    if (term[it] != 0.0) {
-      const int h = it / SE3D_NFU, k = it - h * SE3D_NFU;
-      se3d_zero_kp(sp[h].keypoints[k]);
-      atomicAdd(&dec[h], 1);
-    }
-  __syncthreads();
-  bool al = false;
-  if (lane < nh && !few && nv_l >= 2) {
-    const se3d_person3d &p = sp[lane];
-    int num_valid = cnt0[lane] - dec[lane];
-    double feet = 0.0;  // S3D:955-966
-    if (p.keypoints[FU_LAnkle].score > 0.f && p.keypoints[FU_RAnkle].score > 0.f)
-      feet = (p.keypoints[FU_LAnkle].joint[2] + p.keypoints[FU_RAnkle].joint[2]) / 2.0;
-    else if (p.keypoints[FU_LAnkle].score > 0.f) feet = p.keypoints[FU_LAnkle].joint[2];
-    else if (p.keypoints[FU_RAnkle].score > 0.f) feet = p.keypoints[FU_RAnkle].joint[2];
-    if (fabs(feet) > 0.50) num_valid = 0;
-    al = num_valid > 9;
-  }
-  unsigned long long alive = __ballot(al);
-  // ---- duplicate merge (S3D:984-996): sequential in i; joint distances of (i, every later alive j) over the lanes, summed in joint order ----
-  for (int i = 0; i < nh; ++i) {
-    if (!((alive >> i) & 1ull)) continue;
-    int from = i + 1;
-    for (;;) {
-      if (!(alive >> from)) break;   // nobody left behind i (from < 64 here: from <= nh <= H <= 16)
-      const int nj = nh - from;
-      for (int it = lane; it < nj * SE3D_NFU; it += 64) {
-        const int jo = it / SE3D_NFU, k = it - jo * SE3D_NFU, jj = from + jo;
-        double t = -1.0;
-        if ((alive >> jj) & 1ull) {
-          const se3d_keypoint3d &a = sp[i].keypoints[k], &bb = sp[jj].keypoints[k];
-          if (a.score > 0.f && bb.score > 0.f) {
-            const double dx = a.joint[0] - bb.joint[0], dy = a.joint[1] - bb.joint[1], dz = a.joint[2] - bb.joint[2];
-            t = sqrt(dx * dx + dy * dy + dz * dz);
-          }
-        }
-        term[it] = t;
-      }
-      __syncthreads();
-      bool hit = false;
-      if (lane < nj && ((alive >> (from + lane)) & 1ull)) {
-        int nu = 0;
-        double dist = 0.0;
-        for (int k = 0; k < SE3D_NFU; ++k) {
-          const double t = term[lane * SE3D_NFU + k];
-          if (t >= 0.0) { dist += t; ++nu; }
-        }
-        hit = (nu > 0 ? dist / nu : MAX_COSTS) < 0.20;
-      }
-      const unsigned long long hb = __ballot(hit);
-      if (!hb) break;
-      const int jm = from + __ffsll((long long)hb) - 1;
-      __syncthreads();
-      if (lane < SE3D_NFU) {  // merge_persons (S3D:410-423), one joint per lane
-        se3d_keypoint3d &k1 = sp[i].keypoints[lane];
-        const se3d_keypoint3d &k2 = sp[jm].keypoints[lane];
-        const double total = (double)(k1.score + k2.score);
-        if (total > 0.0) {
-          for (int a = 0; a < 3; ++a) k1.joint[a] = ((double)k1.score * k1.joint[a] + (double)k2.score * k2.joint[a]) / total;
-          k1.score = fmaxf(k1.score, k2.score);
-          for (int a = 0; a < 6; ++a) k1.cov[a] = (k1.cov[a] + k2.cov[a]) / 2.0;
-        }
-      }
-      __syncthreads();
-      alive &= ~(1ull << jm);
-      from = jm + 1;
-      if (from >= nh) break;
-    }
-  }
-  // ---- compaction in ascending hypothesis order + association table in original detection indices ----
-  const int total = __popcll(alive);
-  int pos = 0;
-  for (unsigned long long m = alive; m; m &= m - 1ull, ++pos) {
-    const int h = __ffsll((long long)m) - 1;
-    const uint2 *src = reinterpret_cast<const uint2 *>(&sp[h]);
-    uint2 *dst = reinterpret_cast<uint2 *>(&D.outP[(size_t)f * H + pos]);
-    for (int w = lane; w < words2; w += 64) dst[w] = src[w];
-    if (lane == 0) D.out_hyp[(size_t)f * H + pos] = h;
-  }
-  if (lane == 0) {
-    D.out_count[f] = total;
-    if (few) {  // the reference returns before building any hypothesis (S3D:557-560)
-      atomicOr(&D.flags[f], SE3D_FLAG_FEW_CAMERAS);
-      D.nhyp[f] = 0;
-    }
-  }
-  for (int i = lane; i < nh * N; i += 64) {
-    const int h = i / N, c = i - h * N;
-    const int k = D.assoc[((size_t)f * H + h) * N + c];
-    D.out_assoc[((size_t)f * H + h) * N + c] = (k >= 0) ? D.orig[((size_t)(f * N + c)) * P + k] : -1;
-  }
-}
-// Third form (round 2, default for H <= 16): as se3d_k_postprocess_wave2, but the persons stay in GLOBAL memory (hypP, modified in place:
-// it is an intermediate between triangulation and this kernel) and LDS holds only what lanes read from EACH OTHER — joint position and score
-// per (person, joint): 32 B instead of the 80-B keypoint, 6.7 KB per wavefront at H = 8 instead of 14.9 KB, 23 wavefronts per CU instead
-// of 10 on a kernel that sits in s_waitcnt three quarters of the time.  Every modification goes to both copies: covariance inflation is a
-// read-modify-write of the owner lane (the left shoulder's two terms by ONE lane, in the reference's order), a removed keypoint is zeroed
-// in hypP and in LDS, a merge rewrites person i in both; the published persons are then a plain hypP -> outP copy behind a fence.
+// Small rigs (H <= 16): one wavefront per frame.  The plausibility filters (S3D:861-966) and the duplicate-merge distances (S3D:392-408) run over
+// (person, joint) lanes; whatever is ORDER-sensitive stays in the reference's order — a keypoint's own limb-length term before the right-shoulder
+// special case adds to the left shoulder (S3D:875-881), the root copied before any keypoint is removed (S3D:937-953), the mean joint distance
+// of two persons summed joint by joint by one lane (only the square roots under the sum are parallel).  The persons stay in GLOBAL memory
+// (hypP, modified in place: it is an intermediate between triangulation and this kernel) and LDS holds only what lanes read from EACH OTHER —
+// joint position and score per (person, joint): 32 B instead of the 80-B keypoint, 6.7 KB per wavefront at H = 8, 23 wavefronts per CU on a
+// kernel that sits in s_waitcnt three quarters of the time.  A removed keypoint is zeroed in hypP and in LDS, a merge rewrites person i in
+// both; the published persons are then a hypP -> outP copy behind a fence.
+// The limb-length covariance inflation — which touches three words of nearly every keypoint — is not written back into hypP: its terms wait
+// in LDS (one double per (person, joint) plus the left shoulder's second term per person) and are added, in the reference's order, where a
+// covariance is consumed: by a merge, or by the copy into outP.  hypP is then written only by the rare removals and merges instead of having
+// every line dirtied (~1 GB of write-back per 98 304-frame launch).  History (per 98 304 frames at 16cam6p): one lane per person 2.24 ms, (person,
+// joint) lanes with the persons staged in LDS 1.51 ms, persons in place 1.07 ms, inflation deferred 1.02 ms (profiles/r2).  Published persons
+// bytewise equal to the block kernel below (`post_form` option, tests/test_gpu_stage1.py).
 struct PostKp { double joint[3]; float score; float _pad; };
-// DEFER (default): the limb-length covariance inflation — which touches three words of nearly every keypoint — is not written back into hypP:
-// its terms wait in LDS (one double per (person, joint) plus the left shoulder's second term per person) and are added, in the reference's
-// order, where a covariance is consumed: by a merge, or by the copy into outP.  hypP is then written only by the rare removals and merges
-// instead of having every line dirtied (~1 GB of write-back per 98 304-frame launch).  DEFER = false: the read-modify-write form (A/B).
-template <bool DEFER>
 __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
   extern __shared__ __align__(16) unsigned char post_smem[];
   const int f = blockIdx.x, lane = threadIdx.x;
@@ -2960,7 +2195,7 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
   PostKp *sk = reinterpret_cast<PostKp *>(post_smem);                                 // [H][21]
   double *term = reinterpret_cast<double *>(sk + (size_t)H * SE3D_NFU);               // [H][21]
   int *cnt0 = reinterpret_cast<int *>(term + (size_t)H * SE3D_NFU), *dec = cnt0 + H;  // [H] valid input keypoints / removed fusion slots
-  double *infl = reinterpret_cast<double *>(dec + H);                                 // DEFER: [H][21] own limb term^2, then [H] the left shoulder's second term^2
+  double *infl = reinterpret_cast<double *>(dec + H);                                 // [H][21] own limb term^2, then [H] the left shoulder's second term^2
   double *infl2 = infl + (size_t)H * SE3D_NFU;
   const int nh = D.nhyp[f];
   se3d_person3d *persons = D.hypP + (size_t)f * H;
@@ -2975,10 +2210,10 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
     PostKp c;
     c.joint[0] = g.joint[0]; c.joint[1] = g.joint[1]; c.joint[2] = g.joint[2]; c.score = g.score; c._pad = 0.f;
     sk[it] = c;
-    if (DEFER) infl[it] = 0.0;
+    infl[it] = 0.0;
   }
   const int nv_l = (lane < nh) ? D.nviews[f * H + lane] : 0;
-  if (lane < H) { cnt0[lane] = 0; dec[lane] = 0; if (DEFER) infl2[lane] = 0.0; }
+  if (lane < H) { cnt0[lane] = 0; dec[lane] = 0; infl2[lane] = 0.0; }
   __syncthreads();
   // ---- limb-length covariance inflation (S3D:861-883): items (person, input keypoint); the owner lane adds every term of its keypoint ----
   for (int it = lane; it < nh * SE3D_NKP; it += 64) {
@@ -3007,16 +2242,8 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
       const bool rs_case1 = par6 >= 0 && pk_[c_kp2fusion[pm][par6]].score > 0.f && c_limbLength[pm][6] > 0;
       if (rs.score > 0.f && par6 >= 0 && !rs_case1) { s_56 = 0.075 * (se3d_jdist(rs.joint, kp.joint) - 0.35) / 0.15; has_56 = true; }
     }
-    if (DEFER) {
-      if (has_own) infl[(size_t)h * SE3D_NFU + fu] = s_own * s_own;
-      if (has_56) infl2[h] = s_56 * s_56;     // only the left shoulder (fusion slot 5) has a second term
-    } else if (has_own || has_56) {
-      se3d_keypoint3d &g = persons[h].keypoints[fu];
-      double c0 = g.cov[0], c3 = g.cov[3], c5 = g.cov[5];
-      if (has_own) { c0 += s_own * s_own; c3 += s_own * s_own; c5 += s_own * s_own; }
-      if (has_56) { c0 += s_56 * s_56; c3 += s_56 * s_56; c5 += s_56 * s_56; }
-      g.cov[0] = c0; g.cov[3] = c3; g.cov[5] = c5;
-    }
+    if (has_own) infl[(size_t)h * SE3D_NFU + fu] = s_own * s_own;
+    if (has_56) infl2[h] = s_56 * s_56;     // only the left shoulder (fusion slot 5) has a second term
   }
   // ---- distance to the root (S3D:937-953): items (person, fusion slot); every lane reads the root before anything is removed ----
   for (int it = lane; it < nh * SE3D_NFU; it += 64) {
@@ -3042,7 +2269,7 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
       se3d_zero_kp(persons[h].keypoints[k]);
       PostKp z; z.joint[0] = z.joint[1] = z.joint[2] = 0.0; z.score = 0.f; z._pad = 0.f;
       sk[it] = z;
-      if (DEFER) { infl[it] = 0.0; if (k == FU_LShoulder) infl2[h] = 0.0; }   // the zeroed keypoint carries no inflation
+      { infl[it] = 0.0; if (k == FU_LShoulder) infl2[h] = 0.0; }   // the zeroed keypoint carries no inflation
       atomicAdd(&dec[h], 1);
     }
   __syncthreads();
@@ -3058,7 +2285,7 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
     al = num_valid > 9;
   }
   unsigned long long alive = __ballot(al);
-  // ---- duplicate merge (S3D:984-996): as in se3d_k_postprocess_wave2, distances from the LDS copy ----
+  // ---- duplicate merge (S3D:984-996): distances from the LDS copy ----
   for (int i = 0; i < nh; ++i) {
     if (!((alive >> i) & 1ull)) continue;
     int from = i + 1;
@@ -3104,7 +2331,7 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
           k1.score = c1.score;
           double v1[6], v2[6];
           for (int a = 0; a < 6; ++a) { v1[a] = k1.cov[a]; v2[a] = k2.cov[a]; }
-          if (DEFER) {   // the pending inflation of both keypoints, in the reference's order (own term, then the left shoulder's second one)
+          {   // the pending inflation of both keypoints, in the reference's order (own term, then the left shoulder's second one)
             const double o1 = infl[(size_t)i * SE3D_NFU + lane], o2 = infl[(size_t)jm * SE3D_NFU + lane];
             const double s1 = lane == FU_LShoulder ? infl2[i] : 0.0, s2 = lane == FU_LShoulder ? infl2[jm] : 0.0;
             v1[0] = (v1[0] + o1) + s1; v1[3] = (v1[3] + o1) + s1; v1[5] = (v1[5] + o1) + s1;
@@ -3133,7 +2360,7 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
     uint2 *dst = reinterpret_cast<uint2 *>(&D.outP[(size_t)f * H + pos]);
     for (int w = lane; w < words2; w += 64) {
       uint2 v = src[w];
-      if (DEFER && w >= 1) {   // word 0: id, score; keypoint kk: words 1 + 10 kk .. 10 + 10 kk = joint[3], (score, pad), cov[6]
+      if (w >= 1) {   // word 0: id, score; keypoint kk: words 1 + 10 kk .. 10 + 10 kk = joint[3], (score, pad), cov[6]
         const int kk = (w - 1) / 10, r = (w - 1) - 10 * kk;
         if (r == 4 || r == 7 || r == 9) {   // cov[0], cov[3], cov[5]
           double c = __builtin_bit_cast(double, v);
@@ -3158,8 +2385,7 @@ __global__ __launch_bounds__(64) void se3d_k_postprocess_wave3(Se3dDev D) {
     D.out_assoc[((size_t)f * H + h) * N + c] = (k >= 0) ? D.orig[((size_t)(f * N + c)) * P + k] : -1;
   }
 }
-static size_t se3d_post_wave3_lds_bytes(int H, bool defer) { return (size_t)H * SE3D_NFU * (sizeof(PostKp) + 8) + (size_t)H * 8 + (defer ? (size_t)H * SE3D_NFU * 8 + (size_t)H * 8 : 0); }
-static size_t se3d_post_wave2_lds_bytes(int H) { return sizeof(se3d_person3d) * (size_t)H + (size_t)H * SE3D_NFU * 8 + (size_t)H * 8; }
+static size_t se3d_post_wave3_lds_bytes(int H) { return (size_t)H * SE3D_NFU * (sizeof(PostKp) + 8) + (size_t)H * 8 + (size_t)H * SE3D_NFU * 8 + (size_t)H * 8; }
 
 __global__ __launch_bounds__(256) void se3d_k_postprocess(Se3dDev D) {
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -3336,7 +2562,7 @@ __global__ __launch_bounds__(64) void se3d_k_sweep_fused_wave(Se3dDev D) {
 // memory; assoc / nviews / nhyp are written back once at the end.  Same decisions in the same order as se3d_sweep_cost_small +
 // se3d_sweep_assign_wave (S3D:538-673): the association tables of the three launch structures are compared bytewise in
 // tests/test_gpu_stage1.py.
-#ifdef SE3D_LM_STAMPS   // diagnostic build only (make diag, tools/ff_stamps.py): cycle stamps of se3d_k_front_fused and the one-wavefront sweep
+#ifdef SE3D_LM_STAMPS   // diagnostic build only (make diag, tools/ff_stamps.py): cycle stamps of the one-wavefront sweep
 __device__ unsigned long long g_ff_stamps[16];
 #define FF_STAMP_INIT unsigned long long ff_prev_ = __builtin_readcyclecounter();
 #define FF_STAMP(idx) { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_ff_stamps[idx], now_ - ff_prev_); ff_prev_ = now_; }
@@ -3349,7 +2575,7 @@ extern "C" void se3d_diag_ff_stamps(unsigned long long *out16, int reset) {
 #define FF_STAMP_INIT
 #define FF_STAMP(idx)
 #endif
-// LDS working set of the one-wavefront sweep (se3d_k_sweep_wave_lds, and the sweep phase of se3d_k_front_fused)
+// LDS working set of the one-wavefront sweep (se3d_k_sweep_wave_lds)
 struct SweepWaveLds {
   double *W, *C;        // [H * P] Munkres working matrix; cost, hypothesis-major like D.C
   float *psc;           // [N * P] detection scores of the frame by filtered slot
@@ -3508,116 +2734,6 @@ static size_t se3d_sweep_wave_lds_bytes(int N, int P, int H) {
   return (size_t)H * P * 16 + (size_t)N * P * 4 + (size_t)H * N * 4 + (size_t)H * 4 + (size_t)N * 8 + (((size_t)H * P + 15) & ~(size_t)15) + 16 + (size_t)(2 * N + 1) * 8;
 }
 
-// =============================================================================================================
-// Rows N + E + G + M of a frame in ONE kernel (round 4, small rigs: N * P <= 256): se3d_k_normalize_pairs and se3d_k_sweep_wave_lds
-// back to back in one workgroup, with the pair costs of the frame in LDS between them instead of in the [pairs][P][P] table in HBM.
-//   * prologue (se3d_np_prologue): workspace reset, valid-joint masks, slot compaction, normalised points into LDS;
-//   * the valid (det_a, det_b) entries of all camera pairs densely over the NT threads (se3d_pair_cost_lds: the float expressions of every
-//     other pair kernel), stored PACKED — entry (pair, p, q) at cum[pair] + p * n_b + q, cum = the exclusive prefix of n_a * n_b — into an
-//     LDS table of `cap` entries; a frame with more entries keeps its packed table in the frame's slice of D.pair (same indexing, read back
-//     through L2 like the stand-alone sweep does);
-//   * the wavefronts 1 .. NT/64 - 1 exit, wavefront 0 runs the camera sweep (se3d_sweep_wave_run: the decisions of S3D:538-673 in the same
-//     order) against that table.
-// What it saves: the table's write and read (1.6 + 1.8 GB per 98 304 frames at 16cam6p), the sweep's dependent L2 round trips (two batches of
-// pair-table loads per camera step), and two launches per call — at one frame per call (NT = 1024) the three kernels took 62 of the 102 us of
-// stage 1.  dump != 0 (SE3D_FRONT_DUMP=1, tests): the entries are ALSO written to D.pair in the API layout, which is how the table of this
-// kernel is compared bit for bit with the oracle's; without it se3d_get_pair_costs computes the requested block again.
-// =============================================================================================================
-static size_t se3d_front_fused_lds_bytes(int N, int P, int H, int np, int cap) {
-  size_t b = (size_t)N * P * SE3D_NKP * sizeof(float2) + (size_t)N * P * 12 + (size_t)N * 8 + (size_t)(np + 2) * 4;   // points, masks, slots, scores, counts, cum
-  b = (b + 15) & ~(size_t)15;
-  b += (size_t)cap * 8;                                                                                            // packed table
-  b += (size_t)H * P * 16 + (size_t)H * N * 4 + (size_t)H * 4 + (((size_t)H * P + 15) & ~(size_t)15);               // W, C, assoc, nviews, mask
-  b += 16 + (size_t)(2 * N + 1) * 8;                                                                              // reciprocals of the view counts
-  return b + 16;
-}
-template <int NT>
-__global__ __launch_bounds__(NT) void se3d_k_front_fused(Se3dDev D, const int2 *__restrict__ pair_ab, int cap, int dump) {
-  extern __shared__ __align__(16) unsigned char ff_smem[];
-  const int N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float2 *skp = reinterpret_cast<float2 *>(ff_smem);                               // [N * P][17] filtered slot order
-  unsigned *s_mgt = reinterpret_cast<unsigned *>(skp + (size_t)N * P * SE3D_NKP);  // [N * P] by filtered slot
-  int *s_slot = reinterpret_cast<int *>(s_mgt + N * P);                            // [N * P] by raw detection index
-  float *s_psc = reinterpret_cast<float *>(s_slot + N * P);                        // [N * P] by filtered slot
-  int *s_nv = reinterpret_cast<int *>(s_psc + N * P);                              // [N]
-  int *s_nraw = s_nv + N;                                                          // [N]
-  int *s_cum = s_nraw + N;                                                         // [np + 1]
-  double *s_tab = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(s_cum + np + 2) + 15) & ~(uintptr_t)15);   // [cap]
-  SweepWaveLds L;
-  L.W = s_tab + cap;
-  L.C = L.W + (size_t)H * P;
-  L.assoc = reinterpret_cast<int32_t *>(L.C + (size_t)H * P);
-  L.nviews = L.assoc + (size_t)H * N;
-  L.mask = reinterpret_cast<uint8_t *>(L.nviews + H);
-  L.inv = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(L.mask + (size_t)H * P) + 15) & ~(uintptr_t)15);
-  L.psc = s_psc; L.nraw = s_nraw; L.nvalid = s_nv;
-  __shared__ int s_part[NT / 64];
-  __shared__ double s_inv[SE3D_NKP + 1];   // RN(1 / n) for the joint count of an entry
-  if (tid <= SE3D_NKP) s_inv[tid] = tid ? 1.0 / (double)tid : 0.0;
-  for (int i = tid; i < 2 * N + 1; i += NT) L.inv[i] = i ? 1.0 / (double)i : 0.0;
-  for (int i = tid; i < N; i += NT) s_nraw[i] = D.nraw[f * N + i];
-  for (int i = tid; i < N * P; i += NT) s_psc[i] = 0.f;
-  for (int i = tid; i < H * N; i += NT) L.assoc[i] = -1;
-  for (int i = tid; i < H; i += NT) L.nviews[i] = 0;
-  FF_STAMP_INIT
-  se3d_np_prologue(D, f, tid, skp, s_mgt, s_slot, s_nv, NT, s_psc);
-  FF_STAMP(0)   // prologue
-  // ---- exclusive prefix of n_a * n_b over the camera pairs ----
-  int carry = 0;
-  for (int base = 0; base < np; base += NT) {
-    const int pr = base + tid;
-    int v = 0;
-    if (pr < np) { const int2 ab = pair_ab[pr]; v = s_nv[ab.x] * s_nv[ab.y]; }
-    int inc = v;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    if (lane == 63) s_part[wave] = inc;
-    __syncthreads();
-    int off = carry, all = 0;
-    for (int w = 0; w < NT / 64; ++w) { if (w < wave) off += s_part[w]; all += s_part[w]; }
-    if (pr < np) s_cum[pr] = off + inc - v;
-    carry += all;
-    __syncthreads();
-  }
-  if (tid == 0) s_cum[np] = carry;
-  __syncthreads();
-  FF_STAMP(1)   // prefix
-  // ---- row E: the valid entries of all camera pairs, densely over the threads, into the packed table ----
-  const int total = s_cum[np];
-  double *gtab = D.pair + (size_t)f * np * P * P;     // the frame's slice of the table: the packed entries of a frame that exceeds `cap`
-  const bool in_lds = total <= cap;
-  for (int e = tid; e < total; e += NT) {
-    int lo = 0, hi = np;  // largest pr with s_cum[pr] <= e
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_cum[mid] <= e) lo = mid; else hi = mid; }
-    const int pr = lo;
-    const int2 ab = pair_ab[pr];
-    const int nb = s_nv[ab.y];
-    const int r = e - s_cum[pr];
-    const int p = r / nb, q = r - p * nb;
-    const int ia = ab.x * P + p, ib = ab.y * P + q;
-    const unsigned m = s_mgt[ia] & s_mgt[ib];
-    const double c = se3d_pair_cost_lds(D.F + 9 * (size_t)pr, skp + (size_t)ia * SE3D_NKP, skp + (size_t)ib * SE3D_NKP, m, s_inv);
-    if (in_lds) s_tab[e] = c;
-    if (!in_lds && !dump) gtab[e] = c;
-    if (dump) gtab[((size_t)pr * P + p) * P + q] = c;   // API layout (then also what the sweep of an over-capacity frame reads)
-  }
-  __threadfence_block();
-  __syncthreads();
-  FF_STAMP(2)   // pair costs
-  if (wave != 0) return;   // a barrier below waits for the surviving wavefront only
-  // ---- rows G + M: the camera sweep by wavefront 0 ----
-  if (in_lds) {
-    se3d_sweep_wave_run(D, f, lane, L, [=](int a, int k, int b, int q, int nd) { return s_tab[s_cum[se3d_pair_index(a, b, N)] + k * nd + q]; });
-  } else {   // over capacity (rare): from the frame's slice of D.pair, packed or (dump) in the API layout
-    const double *g = gtab;
-    se3d_sweep_wave_run(D, f, lane, L, [=](int a, int k, int b, int q, int nd) {
-      const int pi = se3d_pair_index(a, b, N);
-      return g[dump ? ((size_t)pi * P + k) * P + q : (size_t)(s_cum[pi] + k * nd + q)];
-    });
-  }
-  FF_STAMP(3)   // sweep
-}
-
 // Self-test of se3d_sqrt_core / se3d_div_core against the IEEE expressions on the device (se3d_selftest_exact_math).
 // out[0]: square-root mismatches over every float in [2^-60, 2^60]; out[1]: quotient mismatches over n_div pseudo-random operand pairs
 // (numerator zero every 64th pair, both operands anywhere in the range).
@@ -3745,17 +2861,14 @@ extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status
 // =============================================================================================================
 // Kernel attributes are per DEVICE in HIP: called by se3d_create for the context's device (after hipSetDevice), not once per process.
 extern "C" hipError_t se3d_stage1_init_device(void) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_assign), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_assign), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
-static void se3d_launch_triangulation(const Se3dDev &D, hipStream_t st) {
+static void se3d_launch_triangulation(const Se3dDev &D, const se3d_options &o, hipStream_t st) {
   const int B = D.d.B, N = D.d.N, H = D.d.H;
   (void)hipMemsetAsync(D.tri_cnt, 0, sizeof(uint32_t), st);   // list of the second pass: filled by the kernel below
   const int waves2 = (int)std::min<size_t>((size_t)D.d.tri_waves, (size_t)B * H * SE3D_NKP);
   const size_t lds = ((size_t)4 * 15 * N + 12 * N) * sizeof(float);
-  const char *e_tri = getenv("SE3D_TRI");  // A/B switch (read per launch): joint = always one wavefront per (hypothesis, joint)
-  if (N <= TH_MAXV && !(e_tri && strcmp(e_tri, "joint") == 0)) {
+  if (N <= TH_MAXV && o.tri_form != SE3D_TRI_JOINT) {
     // (the grid covers all H hypothesis slots; the workgroups of unused slots exit after one load — capping the grid at 12 / 16 / 24 slots
     // changed the kernel's 7.6 - 7.7 ms per 98 304 frames by less than the run-to-run spread, profiles/r3/README.md)
     hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(TH_PARTS * H, B), dim3(64), 0, st, D);
@@ -3765,9 +2878,6 @@ static void se3d_launch_triangulation(const Se3dDev &D, hipStream_t st) {
   hipLaunchKernelGGL(se3d_k_triangulate_exact, dim3(waves2), dim3(64), se3d_exact_lds_bytes(N), st, D);
 }
 
-// phases (bit mask): 1 = normalise + pair-cost table, 8 = camera sweep, 2 = triangulation, 4 = post-processing + duplicate merge
-// st_hi / ev_hi: optional high-priority stream (+ two events) for the per-camera sweep launches of large problems: 2 x N tiny dependent
-// launches that otherwise queue behind the millions of workgroups of other contexts' pair kernels.
 extern "C" void se3d_launch_normalize_keep(const Se3dDev &D, hipStream_t st) {   // normalised points into D.kp, association workspace untouched
   hipLaunchKernelGGL(se3d_k_normalize, dim3(D.d.N, D.d.B), dim3(256), 0, st, D, 3);
 }
@@ -3775,106 +2885,49 @@ extern "C" void se3d_launch_pair_block(const Se3dDev &D, const int2 *d_ab_one, i
   hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((D.d.P + RB_ROWS - 1) / RB_ROWS, 1, 1), dim3(RB_NT), 0, st, D, d_ab_one, 0, 0, frame);
 }
 
-// The fused front kernel (se3d_k_front_fused) for this launch: threads per workgroup (0: the separate kernels), LDS table capacity, dump flag.
-// An A/B variant that did NOT pay (profiles/r4/README.md): SE3D_FRONT=1 selects it on every eligible launch (NT = 1024 for small batches, 256
-// otherwise; SE3D_FRONT_NT = 256 | 512 | 1024), SE3D_FRONT_CAP = entries of the LDS table (default: what keeps three workgroups of 256 threads
-// on a CU / what 64 KB hold at NT = 1024), SE3D_FRONT_DUMP=1: the table also goes to D.pair in the API layout (tests).  One frame per call:
-// 63 us against 7.8 + 13.5 + 40.2 us of the three kernels — cycle stamps (tools/ff_stamps.py): prologue 24 k, pair costs 31 k on ONE CU, and the
-// sweep 92 k cycles even with the costs in LDS: it is the wavefront's own instruction chain (cost + veto 41 k, scans + Hungarian 29 k, attach /
-// spawn 14 k), not the table reads, that takes the time.  On the large batch the 38-us sweep phase of ONE wavefront holds a third of the CU's LDS.
-// Eligible: every phase of the front in this launch, no A/B switch of the separate kernels set, the one-wavefront LDS sweep's limits.
-static int se3d_front_plan(const Se3dDev &D, bool tiled, bool chunked, int phases, int *cap_out, int *dump_out) {
-  const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H, np = D.d.npairs;
-  const char *e_front = getenv("SE3D_FRONT");
-  if (tiled || chunked || (phases & 9) != 9) return 0;
-  if (getenv("SE3D_PAIRS") || getenv("SE3D_NP_LINES") || getenv("SE3D_NP_TILE") || getenv("SE3D_SWEEP_WAVE") || getenv("SE3D_SWEEP_FUSED_MAX")) return 0;
-  if (N * P > NP_MAX_DETS || np > 2048 || H > 64 || P > 64 || N > 64 || se3d_sweep_wave_lds_bytes(N, P, H) > 16 * 1024) return 0;
-  const bool small_batch = (size_t)B * np * P * P <= ((size_t)1 << 16) && !getenv("SE3D_NO_SMALL_BATCH");
-  if (!(e_front && atoi(e_front) == 1)) return 0;
-  int nt = small_batch ? 1024 : 256;
-  if (const char *e = getenv("SE3D_FRONT_NT")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) nt = v; }
-  const size_t fixed = se3d_front_fused_lds_bytes(N, P, H, np, 0);
-  const size_t budget = nt == 256 ? (size_t)53 * 1024 : (size_t)64 * 1024;
-  if (fixed + 8 * 64 > budget) return 0;
-  int cap = (int)std::min((size_t)np * P * P, (budget - fixed) / 8);
-  if (const char *e = getenv("SE3D_FRONT_CAP")) cap = std::max(0, std::min(atoi(e), (int)(((size_t)64 * 1024 - fixed) / 8)));
-  *cap_out = cap;
-  *dump_out = getenv("SE3D_FRONT_DUMP") ? atoi(getenv("SE3D_FRONT_DUMP")) : 0;
-  return nt;
-}
-
-// Returns a bit mask: 1 = phase 1 ran without materialising the [pairs][P][P] table in D.pair (se3d_get_pair_costs computes blocks on demand).
-extern "C" int se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, bool tiled, int phases,
-                                  hipStream_t st_hi, hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk) {
+// phases (bit mask): 1 = normalise + pair-cost table, 8 = camera sweep, 2 = triangulation, 4 = post-processing + duplicate merge
+// st_hi / ev_hi: optional high-priority stream (+ two events) for the per-camera sweep launches of large problems: 2 x N tiny dependent
+// launches that otherwise queue behind the millions of workgroups of other contexts' pair kernels.
+// o: the context's options (include/se3d.h): the kernel FORMS a parity test may force; everything 0 = the library's choice.
+extern "C" void se3d_launch_stage1(const Se3dDev &D, const se3d_options &o, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, int phases,
+                                   hipStream_t st_hi, hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk) {
   const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H;
   const bool chunked = D.d.pair_chunks > 0 && plan && plan->m == D.d.pair_chunks;
-  int info = 0;
-  int ff_cap = 0, ff_dump = 0;
-  const int ff_nt = se3d_front_plan(D, tiled, chunked, phases, &ff_cap, &ff_dump);
-  if (ff_nt) {   // rows N + E + G + M in one kernel; the events of the kernel groups: "normalize" empty, "epipolar_pairs" = this kernel, "sweep" empty
-    if (ev) { (void)hipEventRecord(ev[0], st); (void)hipEventRecord(ev[1], st); }
-    const size_t lds = se3d_front_fused_lds_bytes(N, P, H, D.d.npairs, ff_cap);
-    if (ff_nt == 1024) hipLaunchKernelGGL((se3d_k_front_fused<1024>), dim3(B), dim3(1024), lds, st, D, pair_ab, ff_cap, ff_dump);
-    else if (ff_nt == 512) hipLaunchKernelGGL((se3d_k_front_fused<512>), dim3(B), dim3(512), lds, st, D, pair_ab, ff_cap, ff_dump);
-    else hipLaunchKernelGGL((se3d_k_front_fused<256>), dim3(B), dim3(256), lds, st, D, pair_ab, ff_cap, ff_dump);
-    if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
-    if (!ff_dump) info |= 1;
-    phases &= ~9;
-  }
+  const bool rows = o.pairs_form == SE3D_PAIRS_ROWS || (o.pairs_form == SE3D_PAIRS_AUTO && P > 16);   // large P: two rows x 32 columns per wavefront
   if ((phases & 1) && chunked) {   // column chunks: phase 1 is the normalisation only, the pair kernel runs chunk by chunk inside phase 8
     if (ev) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D, 1);
     if (ev) (void)hipEventRecord(ev[1], st);
   } else if (phases & 1) {
-  const char *e_pairs = getenv("SE3D_PAIRS");  // flat | packed | tiled: A/B switches that force the stand-alone pair kernels
-  // Small batches (a single frame per call is the reference's operating point, S3D:1069): the fused kernel is ONE workgroup per frame,
-  // which leaves the chip empty — the stand-alone normalisation + the flat pair kernel (one lane per table entry over the whole
-  // chip) write the same table (tests: packed == flat == fused bitwise) in 14 us instead of 47 us at B = 1 (16cam6p).  Up to 65 536 table
-  // entries per launch (8 frames of 16cam6p); SE3D_NO_SMALL_BATCH=1 keeps the fused kernel (tests of that kernel on small batches).
-  const bool small_batch = !tiled && !e_pairs && (size_t)B * D.d.npairs * P * P <= ((size_t)1 << 16) && !getenv("SE3D_NO_SMALL_BATCH");
-  const bool fused_np = !tiled && !e_pairs && !small_batch && N * P <= NP_MAX_DETS && D.d.npairs <= 2048;
-  if (ev && (phases & 1)) (void)hipEventRecord(ev[0], st);
-  if (!fused_np) hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D, 1);
-  if (ev) (void)hipEventRecord(ev[1], st);
-  // SE3D_NP_LINES=1: the line-hoisted form (round 3).  NOT the default: measured 9.55 ms per 98 304 frames against 4.86 ms of the per-entry kernel —
-  // 1.8 x fewer instructions, but 51 KB of LDS per workgroup (3 workgroups per CU instead of 8) and, per two-joint chunk, a chain of dependent LDS
-  // round trips (row descriptor -> F -> point -> record -> barrier -> entry reads) that twelve wavefronts per CU do not hide (profiles/r3/README.md)
-  const char *e_lines = getenv("SE3D_NP_LINES");
-  if (fused_np && P <= NPL_PMAX && D.d.npairs <= NPL_NPMAX && e_lines && atoi(e_lines) == 1) {
-    const size_t lds = (size_t)4 * NPL_ROWS * NPL_J * sizeof(NplRec) + (size_t)N * P * SE3D_NKP * sizeof(float2) + (size_t)N * P * 8 + (size_t)N * 4 +
-                       (size_t)(D.d.npairs + 2) * 8 + (size_t)D.d.npairs * (8 + 36) + (size_t)4 * NPL_ROWS * 4 + 16;
-    hipLaunchKernelGGL(se3d_k_normalize_pairs_lines, dim3(B), dim3(256), lds, st, D, pair_ab);
-  } else if (fused_np) {  // normalisation + packed pair table in one workgroup per frame, normalised points only in LDS
-    const size_t lds = (size_t)N * P * SE3D_NKP * sizeof(float2) + (size_t)N * P * 8 + (size_t)N * 4 + (size_t)(D.d.npairs + 1) * 4;
-    // SE3D_NP_TILE=22: 2 x 2 entries per lane (register tile; A/B evidence).  Measured per 98 304 frames (bench scenes: ~4 detections per camera):
-    // 1 x 1 (this kernel's default) 4.83 ms, 1 x 2 4.93, 2 x 2 4.78, 2 x 3 5.25, 3 x 3 6.07 — padding of the ragged n_a x n_b blocks and the
-    // registers (72 / 90 / 127 VGPRs) eat what the shared lines save (profiles/r3/README.md)
-    const char *e_tile = getenv("SE3D_NP_TILE");
-    if (e_tile && atoi(e_tile) == 22) hipLaunchKernelGGL((se3d_k_normalize_pairs_tiles<2, 2>), dim3(B), dim3(256), lds, st, D, pair_ab);
-    else hipLaunchKernelGGL(se3d_k_normalize_pairs, dim3(B), dim3(256), lds, st, D, pair_ab);
-  } else if (tiled && !(e_pairs && strcmp(e_pairs, "tiled") == 0)) {  // large P: two rows x 32 columns per wavefront (default)
-    hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((P + RB_ROWS - 1) / RB_ROWS, D.d.npairs, B), dim3(RB_NT), 0, st, D, pair_ab, 0, 0, 0);
-  } else if (tiled) {                                                  // SE3D_PAIRS=tiled: the 4x4 register-tile kernel (A/B)
-    const int tiles = (P + PT - 1) / PT;
-    hipLaunchKernelGGL(se3d_k_pairs_tiled, dim3(tiles * tiles, D.d.npairs, B), dim3(256), 0, st, D, pair_ab);
-  } else if (!small_batch && !(e_pairs && strcmp(e_pairs, "flat") == 0) && D.d.npairs < 12000) {
-    hipLaunchKernelGGL(se3d_k_pairs_packed, dim3(B), dim3(256), sizeof(int) * (D.d.npairs + 1), st, D, pair_ab);
-  } else {
-    const size_t total = (size_t)B * D.d.npairs * P * P;
-    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(se3d_k_pairs_flat, dim3(blocks), dim3(256), 0, st, D, pair_ab);
-  }
-  if (ev) (void)hipEventRecord(ev[2], st);
+    // Small batches (a single frame per call is the reference's operating point, S3D:1069): the fused kernel is ONE workgroup per frame,
+    // which leaves the chip empty — the stand-alone normalisation + the flat pair kernel (one lane per table entry over the whole
+    // chip) write the same table (tests: flat == fused == rows bitwise) in 14 us instead of 47 us at B = 1 (16cam6p).  Up to 65 536 table
+    // entries per launch (8 frames of 16cam6p).  Rigs with N * P > 256 and P <= 16 take the flat kernel as well.
+    const bool small_batch = o.pairs_form == SE3D_PAIRS_AUTO && !rows && (size_t)B * D.d.npairs * P * P <= ((size_t)1 << 16);
+    const bool fused_np = !rows && o.pairs_form != SE3D_PAIRS_FLAT && !small_batch && N * P <= NP_MAX_DETS && D.d.npairs <= 2048;
+    if (ev) (void)hipEventRecord(ev[0], st);
+    if (!fused_np) hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D, 1);
+    if (ev) (void)hipEventRecord(ev[1], st);
+    if (fused_np) {  // normalisation + pair table in one workgroup per frame, normalised points only in LDS
+      const size_t lds = (size_t)N * P * SE3D_NKP * sizeof(float2) + (size_t)N * P * 8 + (size_t)N * 4 + (size_t)(D.d.npairs + 1) * 4;
+      hipLaunchKernelGGL(se3d_k_normalize_pairs, dim3(B), dim3(256), lds, st, D, pair_ab);
+    } else if (rows) {
+      hipLaunchKernelGGL(se3d_k_pairs_rows, dim3((P + RB_ROWS - 1) / RB_ROWS, D.d.npairs, B), dim3(RB_NT), 0, st, D, pair_ab, 0, 0, 0);
+    } else {   // the reference form: one lane per (frame, pair, det_a, det_b) entry, IEEE divide
+      const size_t total = (size_t)B * D.d.npairs * P * P;
+      const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+      hipLaunchKernelGGL(se3d_k_pairs_flat, dim3(blocks), dim3(256), 0, st, D, pair_ab);
+    }
+    if (ev) (void)hipEventRecord(ev[2], st);
   }
   if ((phases & 8) && chunked) {
     // Pair kernel and camera sweep interleaved, chunk by chunk: chunk j of the pair table (columns col0[j] .. col0[j + 1] - 1) goes to
     // buffer j % 2 of the frame's pair slots on the bulk stream while the sweep of chunk j - 1 reads the other buffer on the
     // (high-priority) sweep stream; chunk j + 2 waits until the sweep has left buffer j % 2.
-    // Munkres working matrix: in L2 here (dynW = 0).  In LDS (up to 128 KB per frame's workgroup, SE3D_SWEEP_LDS_KB=128) a resident sweep
+    // Munkres working matrix: in L2 here (dynW = 0).  In LDS (up to 128 KB per frame's workgroup, options.sweep_lds_kb = 128) a resident sweep
     // workgroup leaves room for one pair-kernel workgroup on its CU instead of four; with 64 frames per context in flight that cost more
     // than the faster Munkres gave back (26.6 k vs 27.6 k skeletons/s at 256cam128p, profiles/r3/README.md).
-    int dynW = 0;
-    if (const char *e = getenv("SE3D_SWEEP_LDS_KB")) dynW = std::min((int)std::min((size_t)H * P * sizeof(double), (size_t)128 * 1024), atoi(e) * 1024);
+    const int dynW = o.sweep_lds_kb > 0 ? std::min((int)std::min((size_t)H * P * sizeof(double), (size_t)128 * 1024), o.sweep_lds_kb * 1024) : 0;
     hipStream_t sw = (st_hi && ev_chunk) ? st_hi : st;
     const int m = plan->m, cap = plan->cap;
     hipEvent_t *ev_p = ev_chunk, *ev_s = ev_chunk ? ev_chunk + SE3D_PAIR_CHUNKS_MAX : nullptr;
@@ -3896,56 +2949,43 @@ extern "C" int se3d_launch_stage1(const Se3dDev &D, const int2 *pair_ab, hipStre
     if (ev) (void)hipEventRecord(ev[2], st);   // "pairs": the bulk stream up to its last chunk (waits for free buffers included)
     if (sw != st) (void)hipStreamWaitEvent(st, ev_s[m - 1], 0);
   } else if (phases & 8) {
-  // Munkres working matrix in LDS when H*P doubles fit next to the static LDS of the kernel (<= 128 KB)
-  int dynW = (int)((size_t)H * P * sizeof(double));
-  if (dynW > 128 * 1024) dynW = 128 * 1024;
-  // (the dynamic-LDS limits of se3d_k_sweep_assign / se3d_k_sweep_fused are raised per device by se3d_stage1_init_device)
-  // A/B switches (read per launch so that the parity tests can compare the variants in one process):
-  //   SE3D_SWEEP_FUSED_MAX = H*P up to which the one-launch 256-thread sweep is used (0 = never), SE3D_SWEEP_WAVE=0 disables the
-  //   one-wavefront sweeps, 2 = the global-memory form of it
-  const char *e_fused = getenv("SE3D_SWEEP_FUSED_MAX"), *e_wave = getenv("SE3D_SWEEP_WAVE");
-  const int fused_limit = e_fused ? atoi(e_fused) : 256;
-  const int sweep_wave = e_wave ? atoi(e_wave) : 1;
-  if (sweep_wave == 1 && H <= 64 && P <= 64 && D.d.N <= 64 && se3d_sweep_wave_lds_bytes(D.d.N, P, H) <= 16 * 1024) {
-    // small rigs: the frame's association state in LDS (SE3D_SWEEP_WAVE=2 selects the global-memory form below)
-    hipLaunchKernelGGL(se3d_k_sweep_wave_lds, dim3(B), dim3(64), se3d_sweep_wave_lds_bytes(D.d.N, P, H), st, D);
-  } else if (sweep_wave && H <= 64 && P <= 64 && H * P <= 2048) {  // larger problems: one wavefront per frame is too little parallelism
-    hipLaunchKernelGGL(se3d_k_sweep_fused_wave, dim3(B), dim3(64), (size_t)dynW, st, D);
-  } else if (H * P <= fused_limit && dynW <= 64 * 1024) {
-    hipLaunchKernelGGL(se3d_k_sweep_fused, dim3(B), dim3(256), (size_t)dynW, st, D, dynW);
-  } else {
-    hipStream_t sw = st;
-    if (st_hi && ev_hi) {  // pair table complete -> the sweep chain runs on the high-priority stream -> triangulation waits for it
-      (void)hipEventRecord(ev_hi[0], st);
-      (void)hipStreamWaitEvent(st_hi, ev_hi[0], 0);
-      sw = st_hi;
+    // Three launch structures with bytewise equal association tables (tests/test_gpu_stage1.py): one wavefront per frame with the frame's
+    // state in LDS (small rigs), one wavefront per frame with the state in global memory (mid-size problems), one cost + one assignment
+    // launch per camera (everything else: one wavefront per frame is too little parallelism there).
+    // Munkres working matrix of the per-camera form in LDS when H * P doubles fit next to the static LDS of the kernel (<= 128 KB;
+    // the dynamic-LDS limit of se3d_k_sweep_assign is raised per device by se3d_stage1_init_device).
+    int dynW = (int)((size_t)H * P * sizeof(double));
+    if (dynW > 128 * 1024) dynW = 128 * 1024;
+    const bool wave_ok = H <= 64 && P <= 64 && N <= 64;
+    if (o.sweep_form == SE3D_SWEEP_AUTO && wave_ok && se3d_sweep_wave_lds_bytes(N, P, H) <= 16 * 1024) {
+      hipLaunchKernelGGL(se3d_k_sweep_wave_lds, dim3(B), dim3(64), se3d_sweep_wave_lds_bytes(N, P, H), st, D);
+    } else if (o.sweep_form != SE3D_SWEEP_PER_CAMERA && wave_ok && H * P <= 2048) {
+      hipLaunchKernelGGL(se3d_k_sweep_fused_wave, dim3(B), dim3(64), (size_t)dynW, st, D);
+    } else {
+      hipStream_t sw = st;
+      if (st_hi && ev_hi) {  // pair table complete -> the sweep chain runs on the high-priority stream -> triangulation waits for it
+        (void)hipEventRecord(ev_hi[0], st);
+        (void)hipStreamWaitEvent(st_hi, ev_hi[0], 0);
+        sw = st_hi;
+      }
+      for (int b = 0; b < N; ++b) {
+        if (b > 0) hipLaunchKernelGGL(se3d_k_sweep_cost, dim3(H, B), dim3(128), 0, sw, D, b, 0);
+        hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), (size_t)dynW, sw, D, b, dynW);
+      }
+      if (sw != st) {
+        (void)hipEventRecord(ev_hi[1], sw);
+        (void)hipStreamWaitEvent(st, ev_hi[1], 0);
+      }
     }
-    for (int b = 0; b < N; ++b) {
-      if (b > 0) hipLaunchKernelGGL(se3d_k_sweep_cost, dim3(H, B), dim3(128), 0, sw, D, b, 0);
-      hipLaunchKernelGGL(se3d_k_sweep_assign, dim3(B), dim3(256), (size_t)dynW, sw, D, b, dynW);
-    }
-    if (sw != st) {
-      (void)hipEventRecord(ev_hi[1], sw);
-      (void)hipStreamWaitEvent(st, ev_hi[1], 0);
-    }
-  }
   }
   if (ev && (phases & 8)) (void)hipEventRecord(ev[3], st);
-  if (phases & 2) se3d_launch_triangulation(D, st);
+  if (phases & 2) se3d_launch_triangulation(D, o, st);
   if (ev && (phases & 2)) (void)hipEventRecord(ev[4], st);
   if (phases & 4) {
-    const char *e_post = getenv("SE3D_POST_WAVE");   // A/B switch read per launch: 1 = one lane per person (round 1), 2 = lane-parallel with the persons in LDS, 3 = persons in place with the inflation written back, default = in place, inflation deferred
-    if (H <= SE3D_POST_SMALL_H && e_post && atoi(e_post) == 1)
-      hipLaunchKernelGGL(se3d_k_postprocess_wave, dim3(B), dim3(64), sizeof(se3d_person3d) * (size_t)H, st, D);
-    else if (H <= SE3D_POST_SMALL_H && e_post && atoi(e_post) == 2)
-      hipLaunchKernelGGL(se3d_k_postprocess_wave2, dim3(B), dim3(64), se3d_post_wave2_lds_bytes(H), st, D);
-    else if (H <= SE3D_POST_SMALL_H && e_post && atoi(e_post) == 3)
-      hipLaunchKernelGGL(se3d_k_postprocess_wave3<false>, dim3(B), dim3(64), se3d_post_wave3_lds_bytes(H, false), st, D);
-    else if (H <= SE3D_POST_SMALL_H) hipLaunchKernelGGL(se3d_k_postprocess_wave3<true>, dim3(B), dim3(64), se3d_post_wave3_lds_bytes(H, true), st, D);
+    if (H <= SE3D_POST_SMALL_H && o.post_form != SE3D_POST_BLOCK) hipLaunchKernelGGL(se3d_k_postprocess_wave3, dim3(B), dim3(64), se3d_post_wave3_lds_bytes(H), st, D);
     else hipLaunchKernelGGL(se3d_k_postprocess, dim3(B), dim3(256), 0, st, D);
   }
   if (ev && (phases & 4)) (void)hipEventRecord(ev[5], st);
-  return info;
 }
 
 // =============================================================================================================
@@ -4017,11 +3057,11 @@ __global__ __launch_bounds__(256) void se3d_k_assoc_given(Se3dDev D, const int32
   }
 }
 
-extern "C" void se3d_launch_dlt(const Se3dDev &D, const int32_t *d_assoc_orig, int nh, hipStream_t st, hipEvent_t *ev /* [2] or null */) {
+extern "C" void se3d_launch_dlt(const Se3dDev &D, const se3d_options &o, const int32_t *d_assoc_orig, int nh, hipStream_t st, hipEvent_t *ev /* [2] or null */) {
   const int B = D.d.B, N = D.d.N;
   if (ev) (void)hipEventRecord(ev[0], st);
   hipLaunchKernelGGL(se3d_k_normalize, dim3(N, B), dim3(256), 0, st, D, 0);
   hipLaunchKernelGGL(se3d_k_assoc_given, dim3(B), dim3(256), 0, st, D, d_assoc_orig, nh);
-  se3d_launch_triangulation(D, st);
+  se3d_launch_triangulation(D, o, st);
   if (ev) (void)hipEventRecord(ev[1], st);
 }

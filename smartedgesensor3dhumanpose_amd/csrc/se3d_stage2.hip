@@ -893,7 +893,7 @@ __device__ __forceinline__ void s2_cov6_to_mat(const double c[6], double M[9]) {
   M[0] = c[0]; M[1] = c[1]; M[2] = c[2]; M[3] = c[1]; M[4] = c[3]; M[5] = c[4]; M[6] = c[2]; M[7] = c[4]; M[8] = c[5];
 }
 
-// MODE 0: dense 63x63 H per wavefront (J^T J on MFMA); 1: Schur/Woodbury (MFMA) for solve and marginals; 2: forest elimination
+// MODE 0: dense 63x63 H per wavefront (J^T J on MFMA); (1: Schur / Woodbury on MFMA for solve and marginals — removed in round 5, 0.92 ms against 0.30 ms; its solve stays as the non-forest fallback of modes 2 / 3); 2: forest elimination
 // for the LM solves + Schur/Woodbury (MFMA) marginals; 3: forest elimination for solves and marginals (no matrix product left)
 template <int MODE, class LT = typename std::conditional<MODE != 0, LmSchurLds, LmLds>::type>
 __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, int lane, LT &L) {  // one wavefront
@@ -1078,9 +1078,6 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
             if (LM_ABLATE(8)) { /* diagnostic: keep the previous delta */ }
             else if (topo.forest) s2_tree_solve(L, K, lambda, lane, Av, gv, topo);
             else s2_schur_solve(L, K, nr, lambda, lane, Av, gv);
-            LM_STAMP(3)  // solve
-          } else if constexpr (MODE == 1) {
-            s2_schur_solve(L, K, nr, lambda, lane, Av, gv);
             LM_STAMP(3)  // solve
           } else {
             s2_jtj_mfma(L, K, nr, lambda, lane);
@@ -2558,7 +2555,7 @@ static_assert(S2_SCHUR_SCRATCH_DOUBLES == 1865, "se3d_api.hip allocates lm_scrat
 static_assert(S2_WALK_SEQS >= 1 && S2_WALK_SEQS <= S2_WALK_WAVES, "one association / lifecycle wavefront per sequence of the workgroup");
 #define S2_WALK_LDS_MAX (160 * 1024 - 4096)  // 160 KB per CU minus the kernel's static LDS
 template <bool TRIO, int WV, int SQ>
-static bool s2_launch_walk_shape(const Se3dStage2 &q, const Se3dWalk &Wk, int nseq, hipStream_t st) {
+static bool s2_launch_walk_shape(const Se3dStage2 &q, const Se3dWalk &Wk, int nseq, hipStream_t st, bool book_in_lds) {
   const int lds_max = S2_WALK_LDS_MAX;  // raised per device by se3d_stage2_init_device
   using WaveLds = typename std::conditional<TRIO, LmTrioLds, LmTreeLds>::type;
   const size_t tpos_bytes = (size_t)SQ * q.T * SE3D_NFU * 3 * sizeof(double);
@@ -2575,8 +2572,7 @@ static bool s2_launch_walk_shape(const Se3dStage2 &q, const Se3dWalk &Wk, int ns
   // ... and the per-step bookkeeping (cost matrix, merge rows, order, slot / publish tables, scalars) while eight workgroups still fit a CU
   const size_t book_bytes = (size_t)SQ * q.H * q.T * 8 + (size_t)SQ * q.T * (32 + 4) + (size_t)SQ * (8 + 24 + 12) + (size_t)SQ * q.H * 5 + 32;
   dyn = (dyn + 15) & ~(size_t)15;
-  const char *e_book = getenv("SE3D_WALK_BOOK");   // A/B switch (read per launch): 0 keeps the bookkeeping in global memory
-  if (WV == 1 && (w.lds_state & 2) && dyn + book_bytes <= 20 * 1024 && !(e_book && atoi(e_book) == 0)) {
+  if (WV == 1 && (w.lds_state & 2) && dyn + book_bytes <= 20 * 1024 && book_in_lds) {   // (options.walk_book = 1 keeps the bookkeeping in global memory: parity tests)
     w.lds_state |= 4;
     w.book_offset = (int)dyn;
     dyn += book_bytes;
@@ -2594,30 +2590,26 @@ extern "C" void se3d_diag_lm_stamps(unsigned long long *out16, int reset) {
   if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lm_stamps), z, sizeof(z)); }
 }
 #endif
-static int s2_lm_mode() {
-  const char *e = getenv("SE3D_LM");  // A/B evidence switch, read per launch: dense | schur | tree_mfma | tree (default)
-  return (e && strcmp(e, "dense") == 0) ? 0 : (e && strcmp(e, "schur") == 0) ? 1 : (e && strcmp(e, "tree_mfma") == 0) ? 2 : 3;
-}
+// kernel template argument of the per-step LM for options.lm_form: 3 = forest elimination (default), 2 = forest solve + MFMA marginals, 0 = dense J^T J on MFMA
+static int s2_lm_mode(const se3d_options &o) { return o.lm_form == SE3D_LM_DENSE ? 0 : o.lm_form == SE3D_LM_TREE_MFMA ? 2 : 3; }
 
 // true: the fused kernel was launched; false: not applicable (caller falls back to per-step launches)
-extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const Se3dWalk &Wk, int nseq, hipStream_t st) {
-  const char *el = getenv("SE3D_WALK_LM");     // A/B evidence switches (read per launch): solo = one person per LM wavefront
-  const char *es = getenv("SE3D_WALK_SHAPE");  // wg = 4 wavefronts / 2 sequences per workgroup, wave = one wavefront per sequence
-  const bool trio = !(el && strcmp(el, "solo") == 0);
-  const char *e = getenv("SE3D_WALK");  // steps = always use the per-step kernels
-  const bool ok = !(e && strcmp(e, "steps") == 0) && s2_lm_mode() == 3;
+extern "C" bool se3d_launch_stage2_walk(const Se3dStage2 &Q, const se3d_options &o, const Se3dWalk &Wk, int nseq, hipStream_t st) {
+  const bool trio = o.walk_lm != SE3D_WALK_LM_SOLO;   // solo: one person per LM wavefront (the per-step device code)
+  const bool ok = o.walk_form != SE3D_WALK_STEPS && s2_lm_mode(o) == 3;
   // The fused walk is right for many short sequences of few persons.  Large association problems (> 64) and few sequences of many
   // persons keep the per-step kernels (a wavefront per person over the whole GPU).
   if (!ok || Q.H > 64 || Q.T > 64 || nseq < 1 || (Q.H > 16 && nseq < 32)) return false;
   Se3dStage2 q = Q;
   q.seq0 = 0;
   // one wavefront per sequence once a launch brings enough sequences to fill wavefront slots that way (and a sequence-step is a few
-  // trios at most); otherwise the latency shape
+  // trios at most); otherwise the latency shape (options.walk_shape forces one of them)
   bool wave_shape = trio && Q.H <= 16 && nseq >= 256;
-  if (es) wave_shape = trio && strcmp(es, "wave") == 0;
-  if (wave_shape && s2_launch_walk_shape<true, 1, 1>(q, Wk, nseq, st)) return true;
-  return trio ? s2_launch_walk_shape<true, S2_WALK_WAVES, S2_WALK_SEQS>(q, Wk, nseq, st)
-              : s2_launch_walk_shape<false, S2_WALK_WAVES, S2_WALK_SEQS>(q, Wk, nseq, st);
+  if (o.walk_shape) wave_shape = trio && o.walk_shape == SE3D_WALK_WAVE;
+  const bool book = o.walk_book == 0;
+  if (wave_shape && s2_launch_walk_shape<true, 1, 1>(q, Wk, nseq, st, book)) return true;
+  return trio ? s2_launch_walk_shape<true, S2_WALK_WAVES, S2_WALK_SEQS>(q, Wk, nseq, st, book)
+              : s2_launch_walk_shape<false, S2_WALK_WAVES, S2_WALK_SEQS>(q, Wk, nseq, st, book);
 }
 
 // Diagnostic: the fusion-joint indices the kernels use by name (FU_*) and the device's vel_sigmas table, for the test that compares them
@@ -2634,7 +2626,6 @@ extern "C" hipError_t se3d_stage2_init_device(void) {
   const struct { const void *fn; int bytes; } attrs[] = {
       {reinterpret_cast<const void *>(se3d_k_track_assoc), 128 * 1024},
       {reinterpret_cast<const void *>(se3d_k_lm_refine<0>), (int)sizeof(LmLds)},
-      {reinterpret_cast<const void *>(se3d_k_lm_refine<1>), (int)sizeof(LmSchurLds)},
       {reinterpret_cast<const void *>(se3d_k_lm_refine<2>), (int)sizeof(LmSchurLds)},
       {reinterpret_cast<const void *>(se3d_k_lm_refine<3>), (int)sizeof(LmSchurLds)},
       {reinterpret_cast<const void *>(se3d_k_stage2_walk<true, 1, 1>), S2_WALK_LDS_MAX},
@@ -2696,10 +2687,10 @@ extern "C" void se3d_launch_shard_unpack_lm(const Se3dStage2 &Q, int nseq, const
 }
 
 // phases: 1 = track costs + association + LM refinement, 2 = merge-distance matrix + publish / lifecycle
-extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipStream_t st, hipEvent_t *ev, int phases) {
+extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, const se3d_options &o, int seq0, int nseq, hipStream_t st, hipEvent_t *ev, int phases) {
   Se3dStage2 q = Q;
   q.seq0 = seq0;
-  const int lm_mode = s2_lm_mode();
+  const int lm_mode = s2_lm_mode(o);
   if (ev) (void)hipEventRecord(ev[0], st);
   int dynW = (int)((size_t)q.H * q.T * sizeof(double));
   if (dynW > 128 * 1024) dynW = 128 * 1024;
@@ -2710,7 +2701,6 @@ extern "C" void se3d_launch_stage2(const Se3dStage2 &Q, int seq0, int nseq, hipS
   if (ev) (void)hipEventRecord(ev[1], st);
   if (phases & 1) {
     if (lm_mode == 0) hipLaunchKernelGGL(se3d_k_lm_refine<0>, dim3(q.H, nseq), dim3(64), sizeof(LmLds), st, q);
-    else if (lm_mode == 1) hipLaunchKernelGGL(se3d_k_lm_refine<1>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
     else if (lm_mode == 2) hipLaunchKernelGGL(se3d_k_lm_refine<2>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
     else hipLaunchKernelGGL(se3d_k_lm_refine<3>, dim3(q.H, nseq), dim3(64), sizeof(LmSchurLds), st, q);
   }

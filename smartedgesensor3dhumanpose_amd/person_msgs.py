@@ -42,6 +42,42 @@ class Limits(C.Structure):
     _fields_ = [("max_frames", C.c_int32), ("max_det_per_cam", C.c_int32), ("max_hyp", C.c_int32), ("max_tracks", C.c_int32)]
 
 
+class Options(C.Structure):
+    """se3d_options (include/se3d.h): all zero = the library's defaults.  Symbolic values: the tables below."""
+    _fields_ = [(n, C.c_int32) for n in ("pair_chunks", "hi_priority_stream", "reserve_cus", "graph", "walk_shape", "sweep_lds_kb",
+                                         "pairs_form", "sweep_form", "tri_form", "post_form", "lm_form", "walk_form", "walk_lm", "walk_book",
+                                         "refine_steps", "munkres_form", "reproj_form")] + [("reserved", C.c_int32 * 7)]
+
+
+OPTION_VALUES = {   # names of the SE3D_* constants of include/se3d.h
+    "walk_shape": {"auto": 0, "wave": 1, "wg": 2},
+    "pairs_form": {"auto": 0, "flat": 1, "rows": 2, "fused": 3},
+    "sweep_form": {"auto": 0, "per_camera": 1, "wave_global": 2},
+    "tri_form": {"auto": 0, "joint": 1},
+    "post_form": {"auto": 0, "block": 1},
+    "lm_form": {"tree": 0, "tree_mfma": 1, "dense": 2},
+    "walk_form": {"fused": 0, "steps": 1},
+    "walk_lm": {"trio": 0, "solo": 1},
+    "munkres_form": {"auto": 0, "block": 1, "wave": 2},
+}
+
+
+def make_options(base=None, **kw):
+    """Options from keyword arguments; values may be the integers of include/se3d.h or the names in OPTION_VALUES
+    (e.g. lm_form="dense", hi_priority_stream=-1)."""
+    o = Options()
+    if base is not None:
+        C.memmove(C.byref(o), C.byref(base), C.sizeof(Options))
+    names = {n for n, _ in Options._fields_} - {"reserved"}
+    for k, v in kw.items():
+        if k not in names:
+            raise KeyError("unknown se3d option %r" % k)
+        if isinstance(v, str):
+            v = OPTION_VALUES[k][v]
+        setattr(o, k, int(v))
+    return o
+
+
 class FrameIn(C.Structure):
     _fields_ = [("n_cam", C.c_int32), ("det_offset", C.POINTER(C.c_int32)), ("persons", C.c_void_p),
                 ("fb_delay", C.POINTER(C.c_float)), ("stamp", C.c_double)]

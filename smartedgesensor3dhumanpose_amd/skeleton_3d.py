@@ -25,10 +25,12 @@ def rig_tensors(rig):
     return Rt, F
 
 
-def device_bytes(n_cam, max_frames, max_det_per_cam, max_hyp, max_tracks=None):
-    """Device memory a context of these limits allocates at creation (se3d_device_bytes: host arithmetic, no GPU call)."""
+def device_bytes(n_cam, max_frames, max_det_per_cam, max_hyp, max_tracks=None, options=None):
+    """Device memory a context of these limits (and options: a dict or pm.Options) allocates at creation (se3d_device_bytes_ex: host
+    arithmetic, no GPU call)."""
     lim = pm.Limits(int(max_frames), int(max_det_per_cam), int(max_hyp), int(max_tracks or max_hyp))
-    n = _lib.lib().se3d_device_bytes(int(n_cam), C.byref(lim))
+    opt = options if isinstance(options, pm.Options) else pm.make_options(**(options or {}))
+    n = _lib.lib().se3d_device_bytes_ex(int(n_cam), C.byref(lim), C.byref(opt))
     if n < 0:
         raise Se3dError("se3d_device_bytes: unsupported sizes")
     return int(n)
@@ -38,7 +40,9 @@ class Skeleton3D:
     """One skeleton_3d node instance bound to one GPU."""
 
     def __init__(self, rig, pose_method="simple", max_epi_dist=0.050, norm_height=False, max_frames=1, max_det_per_cam=8, max_hyp=None,
-                 max_tracks=None, device=0):
+                 max_tracks=None, device=0, options=None):
+        """options: dict of se3d_options fields (include/se3d.h; values as integers or the names of person_msgs.OPTION_VALUES), e.g.
+        dict(hi_priority_stream=-1) for more than four large-rig contexts per GPU; None = the library's defaults."""
         if rig.Rt is None or rig.F is None:
             rig.set_tensors(*rig_tensors(rig))
         self.rig = rig
@@ -47,11 +51,19 @@ class Skeleton3D:
         self.limits = pm.Limits(int(max_frames), int(max_det_per_cam), int(max_hyp), int(max_tracks or max_hyp))
         self._rig_c = pm.Rig(rig.n_cam, pm.fptr(rig.Rt), pm.fptr(rig.K), pm.fptr(rig.F))
         self._L = _lib.lib()
-        self._h = self._L.se3d_create(C.byref(self._rig_c), C.byref(self.params), C.byref(self.limits), int(device))
+        self.options = options if isinstance(options, pm.Options) else pm.make_options(**(options or {}))
+        self._h = self._L.se3d_create_ex(C.byref(self._rig_c), C.byref(self.params), C.byref(self.limits), C.byref(self.options), int(device))
         if not self._h:
             why = self._L.se3d_last_error(None)
             raise Se3dError("se3d_create failed: %s; there is no CPU fallback" % (why.decode() if why else "no GPU, unsupported sizes or out of memory"))
         self._staged = 0
+
+    def set_options(self, **kw):
+        """Change launch-time options of the live context (se3d_set_options), e.g. set_options(lm_form="dense"); pair_chunks,
+        hi_priority_stream and reserve_cus are fixed at creation."""
+        opt = pm.make_options(self.options, **kw)
+        self._chk(self._L.se3d_set_options(C.c_void_p(self._h), C.byref(opt)), "se3d_set_options")
+        self.options = opt
 
     # -- error helper
     def _chk(self, rc, what):
@@ -288,6 +300,12 @@ class Skeleton3D:
         IEEE quotient over n operand pairs of the kernel's guarded range."""
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._chk(self._L.se3d_selftest_shared_quotient(C.c_void_p(self._h), C.c_uint64(int(n)), C.byref(a), C.byref(b)), "se3d_selftest_shared_quotient")
+        return int(a.value), int(b.value)
+
+    def sweep_stats(self):
+        """(camera steps of the per-camera sweep that met hypotheses and detections, those that ran the Hungarian): running totals (large rigs)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.se3d_get_sweep_stats(C.c_void_p(self._h), C.byref(a), C.byref(b)), "se3d_get_sweep_stats")
         return int(a.value), int(b.value)
 
     def pair_chunks(self):

@@ -120,17 +120,10 @@ def run_trials(O, seed, trials, walk_mode="wave", pose_method="simple", norm_hei
                 rep["violations"].append(dict(trial=trial, frame=fi, person=int(p), joint=int(k), kappa=float(kappa[p, k]), d_mm=float(d[p, k] * 1e3),
                                               cov_rel=float(relv[p, k]), score_rel=float(rs[p, k]), listed=bool(is_listed[p, k])))
         # ---- stage 2: the resident walk; ids / counts / iteration counts exact inside compare_stage2 ----
-        if walk_mode in ("wave", "wg"):
-            os.environ["SE3D_WALK_SHAPE"] = walk_mode
-        else:
-            os.environ["SE3D_WALK"] = "steps"
-        try:
-            ts = [100.0 + (i + 1) / 30.0 for i in range(T_STEPS)]
-            node.run_stage2_walk(np.repeat(np.array(ts)[:, None], N_SEQ, 1), [k * N_SEQ for k in range(T_STEPS)])
-            node.sync()
-        finally:
-            os.environ.pop("SE3D_WALK_SHAPE", None)
-            os.environ.pop("SE3D_WALK", None)
+        node.set_options(**(dict(walk_shape=walk_mode) if walk_mode in ("wave", "wg") else dict(walk_form="steps")))
+        ts = [100.0 + (i + 1) / 30.0 for i in range(T_STEPS)]
+        node.run_stage2_walk(np.repeat(np.array(ts)[:, None], N_SEQ, 1), [k * N_SEQ for k in range(T_STEPS)])
+        node.sync()
         oras = [O.PosePrior(params) for _ in range(N_SEQ)]
         dead, tainted = [False] * N_SEQ, [False] * N_SEQ
         for k, t in enumerate(ts):

@@ -107,11 +107,10 @@ def test_device_bytes_and_bench_memory_plan(product_lib):
     # round 3: large rigs keep two camera-column chunks of the pair table per frame (16 chunks at 256 cameras: 2 x 2 296 of the 32 640 pairs)
     whole = 16 * (256 * 255 // 2) * 128 * 128 * 8
     assert whole / 16 < b < whole / 5      # two chunks of ~1 / 16 of the pairs each, plus everything else
-    os.environ["SE3D_PAIR_CHUNKS"] = "0"   # the whole table (A/B switch)
-    try:
-        assert whole < device_bytes(256, 16, 128, 256) < whole + 4.5e9   # (+ 2 GB of second-pass workspaces since round 4)
-    finally:
-        del os.environ["SE3D_PAIR_CHUNKS"]
+    assert whole < device_bytes(256, 16, 128, 256, options=dict(pair_chunks=-1)) < whole + 4.5e9   # the whole table (+ 2 GB of second-pass workspaces since round 4)
+    assert device_bytes(256, 16, 128, 256, options=dict(pair_chunks=16)) == b
+    with pytest.raises(Se3dError):
+        device_bytes(256, 16, 128, 256, options=dict(pair_chunks=1))   # an option out of range: rejected like unsupported sizes
     assert device_bytes(16, 2, 8, 12) < device_bytes(16, 4, 8, 12) < 10e6
     with pytest.raises(Se3dError):
         device_bytes(1, 1, 8, 12)          # fewer than two cameras: se3d_create rejects it, so does the plan

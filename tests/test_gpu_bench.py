@@ -34,10 +34,10 @@ def test_bench_exchange_under_launcher_world1():
 def test_bench_256cam128p_under_launcher_with_hypothesis_shard_and_exchange_diagnosis():
     """The code path of the driver's multi-GPU run at north_star's configuration, with one rank: 256cam128p under the launcher (RCCL exchange
     of the slot form, verified), the exchange diagnosis keys of round 4, and the hypothesis-shard block behind its deadline."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SE3D_BENCH_HYP_DEADLINE_S="600")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29633",
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "256cam128p", "--contexts", "1", "--seqs", "1", "--tsteps", "4", "--steps", "2", "--warmup", "1",
-           "--hyp-shard", "--no-cpu-baseline"]
+           "--hyp-shard", "--hyp-deadline-s", "600", "--no-cpu-baseline"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-3000:]
     line = _json_line(p.stdout)

@@ -43,7 +43,7 @@ STAGE1_SCENES = {
 
 @pytest.mark.parametrize("tri", ["hyp", "joint"])
 @pytest.mark.parametrize("name", sorted(STAGE1_SCENES))
-def test_stage1_branch(extr_rig, oracle, demo_params, monkeypatch, name, tri):
+def test_stage1_branch(extr_rig, oracle, demo_params, name, tri):
     build, counters, hyps = STAGE1_SCENES[name]
     frames = build(extr_rig)
     oracle.stats_reset()
@@ -51,10 +51,8 @@ def test_stage1_branch(extr_rig, oracle, demo_params, monkeypatch, name, tri):
     st = oracle.stats()
     for k in counters:
         assert st[k] > 0, "scene %s did not make the oracle take branch %s" % (name, k)
-    if tri == "joint":
-        monkeypatch.setenv("SE3D_TRI", "joint")   # one wavefront per (hypothesis, joint) instead of per half hypothesis
-    for mh in hyps:
-        node = _node(extr_rig, max_frames=len(frames), max_det_per_cam=8, max_hyp=mh)
+    for mh in hyps:   # tri = joint: one wavefront per (hypothesis, joint) instead of per third of a hypothesis
+        node = _node(extr_rig, max_frames=len(frames), max_det_per_cam=8, max_hyp=mh, options=dict(tri_form="joint" if tri == "joint" else "auto"))
         got = node.triangulate_persons(frames)
         worst = 0.0
         for g, o in zip(got, ora):
@@ -87,7 +85,7 @@ def test_stage2_track_merge_and_id_rewrite_host_path(extr_rig, oracle, demo_para
 
 
 @pytest.mark.parametrize("variant", ["steps", "solo", "trio_wg", "trio_wave"])
-def test_stage2_track_merge_resident(extr_rig, oracle, demo_params, monkeypatch, variant):
+def test_stage2_track_merge_resident(extr_rig, oracle, demo_params, variant):
     """Two people who slowly walk into each other, from 2-D detections through the RESIDENT pipeline: stage 1 on the GPU, then stage 2 as
     per-step launches or as the fused walk (three kernel forms).  Around the 0.20 m threshold stage 1 still reports two persons in some
     frames while their tracks are already closer than 0.20 m -> track merge + id rewrite inside the walk (PP:870-903)."""
@@ -104,9 +102,7 @@ def test_stage2_track_merge_resident(extr_rig, oracle, demo_params, monkeypatch,
     r1 = node.fetch_stage1(S_ * T_)
     node.refine_reset()
     ts = 100.0 + (np.arange(T_) + 1) / 30.0
-    env = {"solo": {"SE3D_WALK_LM": "solo"}, "trio_wg": {"SE3D_WALK_SHAPE": "wg"}, "trio_wave": {"SE3D_WALK_SHAPE": "wave"}}.get(variant, {})
-    for k_, v_ in env.items():
-        monkeypatch.setenv(k_, v_)
+    node.set_options(**{"solo": dict(walk_lm="solo"), "trio_wg": dict(walk_shape="wg"), "trio_wave": dict(walk_shape="wave")}.get(variant, {}))
     if variant != "steps":
         node.run_stage2_walk(np.repeat(ts[:, None], S_, 1), [k * S_ for k in range(T_)])
         node.sync()
@@ -126,15 +122,14 @@ def test_stage2_track_merge_resident(extr_rig, oracle, demo_params, monkeypatch,
     node.close()
 
 
-@pytest.mark.parametrize("lm", ["tree", "tree_mfma", "schur", "dense"])
-def test_stage2_lm_failure_publishes_measurements(extr_rig, oracle, demo_params, monkeypatch, lm):
+@pytest.mark.parametrize("lm", ["tree", "tree_mfma", "dense"])
+def test_stage2_lm_failure_publishes_measurements(extr_rig, oracle, demo_params, lm):
     """An indefinite 3x3 covariance on one joint: the whitening of its unary factor fails = GTSAM's optimisation throws -> the person is
     published at its MEASUREMENTS with the default 0.10^2 covariance (PP:751-758, 788-793), zero LM iterations; the other persons of
     the frame are refined as usual."""
     from smartedgesensor3dhumanpose_amd.pose_prior import PosePrior
-    monkeypatch.setenv("SE3D_LM", lm)
     frames = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=3, n_frames=12, seed=5))[0]
-    node = _node(extr_rig, max_frames=1, max_det_per_cam=8, max_hyp=16)
+    node = _node(extr_rig, max_frames=1, max_det_per_cam=8, max_hyp=16, options=dict(lm_form=lm))   # tree: the one-launch walk; the other forms exist in the per-step LM kernel only
     node.refine_reset()
     pp, ora = PosePrior(node, 0), oracle.PosePrior(demo_params)
     le = pm.FUSION["LElbow"]

@@ -51,13 +51,11 @@ def _assoc_tables(oracle, rig, params, frames, n_hyp):
 
 @pytest.mark.parametrize("tri", ["hyp", "joint"])
 @pytest.mark.parametrize("extra", [{}, {"outlier_frac": 0.06}, {"p_miss": 0.5, "low_score_frac": 0.2}])
-def test_dlt_given_association_16cam(extr_rig, oracle, demo_params, monkeypatch, extra, tri):
-    if tri == "joint":
-        monkeypatch.setenv("SE3D_TRI", "joint")
+def test_dlt_given_association_16cam(extr_rig, oracle, demo_params, extra, tri):
     frames = sum((S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=2, seed=seed, **extra))[0] for seed in (0, 1, 2)), [])
     n_hyp = 24
     assoc = _assoc_tables(oracle, extr_rig, demo_params, frames, n_hyp)
-    node = _node(extr_rig, max_frames=len(frames), max_det_per_cam=8, max_hyp=n_hyp)
+    node = _node(extr_rig, max_frames=len(frames), max_det_per_cam=8, max_hyp=n_hyp, options=dict(tri_form="joint" if tri == "joint" else "auto"))
     got = node.triangulate_assoc(frames, assoc)
     worst = (0.0, 0.0)
     for k, fr in enumerate(frames):

@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _node(rig, **kw):
+    """kw: limits (max_frames, ...) and `options` = dict of se3d_options fields (kernel forms, include/se3d.h)."""
     from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
     return Skeleton3D(rig, max_epi_dist=0.045, **kw)
 
@@ -41,9 +42,9 @@ def test_loaded_library_is_the_hip_build(node16):
 
 
 @pytest.mark.parametrize("variant", ["auto", "block"])
-def test_device_hungarian_matches_reference_goldens(node16, monkeypatch, variant):
+def test_device_hungarian_matches_reference_goldens(node16, variant):
     """auto: problems up to 64 x 64 run the single-wavefront Munkres, larger ones the block-cooperative one; block: all sizes on the latter."""
-    monkeypatch.setenv("SE3D_MUNKRES", variant)
+    node16.set_options(munkres_form=variant)
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "hungarian_golden.json")))
     L = node16._L
     for case in gold["cases"]:
@@ -59,6 +60,7 @@ def test_device_hungarian_matches_reference_goldens(node16, monkeypatch, variant
         assert rc == 0, L.se3d_last_error(C.c_void_p(node16._h))
         assert a.tolist() == case["assignment"], (case["kind"], case["nr"], case["nc"], case["seed"])
         assert cost.value == case["cost"]
+    node16.set_options(munkres_form="auto")
 
 
 def test_device_hungarian_fuzz_vs_oracle(node16, oracle):
@@ -77,8 +79,8 @@ def test_device_hungarian_fuzz_vs_oracle(node16, oracle):
 
 
 @pytest.mark.parametrize("rig_name,persons,max_det,max_hyp", [("extr16", 6, 8, 8), ("extr16", 12, 16, 32), ("ell24", 20, 24, 48)])
-def test_sweep_variants_agree_exactly(monkeypatch, rig_name, persons, max_det, max_hyp):
-    """The launch structures of the camera sweep — per-step kernels, one 256-thread launch, one wavefront per frame with its working set in
+def test_sweep_variants_agree_exactly(rig_name, persons, max_det, max_hyp):
+    """The launch structures of the camera sweep — a cost + an assignment launch per camera, one wavefront per frame with its working set in
     LDS (default for small rigs) or in global memory — must give the same hypotheses, association tables and persons (crowded, noisy frames
     so that the Hungarian branch runs)."""
     from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
@@ -87,19 +89,10 @@ def test_sweep_variants_agree_exactly(monkeypatch, rig_name, persons, max_det, m
     frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=persons, n_frames=8, seed=77, pixel_noise=4.0, low_score_frac=0.15, p_miss=0.1,
                                                        spacing=0.7, min_coverage=4 if rig_name == "extr16" else 6))
     res = {}
-    # front*: normalisation + pair costs + sweep in one kernel (se3d_k_front_fused, A/B evidence; N * P <= 256), the frame's pair costs packed in LDS — or, over
-    # the table's capacity (cap0: always), in the frame's slice of the global table, packed or (dump) in the API layout
-    for name, env in (("steps", {"SE3D_SWEEP_FUSED_MAX": "0", "SE3D_SWEEP_WAVE": "0"}), ("fused256", {"SE3D_SWEEP_FUSED_MAX": "100000", "SE3D_SWEEP_WAVE": "0"}),
-                      ("wave", {"SE3D_SWEEP_WAVE": "1"}), ("wave_global", {"SE3D_SWEEP_WAVE": "2"}), ("default", {}),
-                      ("front1024", {"SE3D_FRONT": "1", "SE3D_FRONT_NT": "1024"}), ("front256", {"SE3D_FRONT": "1", "SE3D_FRONT_NT": "256"}),
-                      ("front_cap0", {"SE3D_FRONT": "1", "SE3D_FRONT_CAP": "0"}), ("front_cap0_dump", {"SE3D_FRONT": "1", "SE3D_FRONT_CAP": "0", "SE3D_FRONT_DUMP": "1"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        node = _node(rig, max_frames=8, max_det_per_cam=max_det, max_hyp=max_hyp)
+    for name, opt in (("steps", dict(sweep_form="per_camera")), ("wave_global", dict(sweep_form="wave_global")), ("default", {})):
+        node = _node(rig, max_frames=8, max_det_per_cam=max_det, max_hyp=max_hyp, options=opt)
         res[name] = node.triangulate_persons(frames)
         node.close()
-        for k in env:
-            monkeypatch.delenv(k)
     n_hyp = 0
     names = list(res)
     for k in range(len(frames)):
@@ -112,25 +105,21 @@ def test_sweep_variants_agree_exactly(monkeypatch, rig_name, persons, max_det, m
     assert n_hyp >= 8 * persons * 0.8
 
 
-def test_packed_pair_kernel_equals_flat_kernel_bitwise(extr_rig, monkeypatch):
-    """Small P: the packed kernel (dense enumeration of the valid entries of all camera pairs) writes exactly the flat kernel's table
-    on every valid entry, including frames with low-confidence joints and cameras without detections."""
+def test_pair_kernels_agree_bitwise_on_a_small_rig(extr_rig):
+    """Small P: the fused normalise + pair kernel (default for small rigs: one workgroup per frame, points in LDS) and the large-rig rows kernel
+    write exactly the flat kernel's table (one lane per entry, IEEE divide: the reference form) on every valid entry, including frames with
+    low-confidence joints and cameras without detections."""
     frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=7, n_frames=6, seed=31, low_score_frac=0.2, p_miss=0.15))
     tabs = {}
-    monkeypatch.setenv("SE3D_NO_SMALL_BATCH", "1")   # 6 frames: the library would pick normalize + flat by itself
-    for mode in ("flat", "packed", "fused"):   # fused (the default for small rigs): normalisation + packed pairs in one kernel, points in LDS
-        if mode == "fused":
-            monkeypatch.delenv("SE3D_PAIRS", raising=False)
-        else:
-            monkeypatch.setenv("SE3D_PAIRS", mode)
-        node = _node(extr_rig, max_frames=6, max_det_per_cam=8, max_hyp=32)
+    for mode in ("flat", "fused", "rows"):   # (6 frames: with pairs_form = auto the library would pick normalise + flat by itself)
+        node = _node(extr_rig, max_frames=6, max_det_per_cam=8, max_hyp=32, options=dict(pairs_form=mode))
         node.stage(frames)
         node.run_stage1()
         node.sync()
         tabs[mode] = [_pair_costs(node, fi, a, b) for fi in range(6) for a in range(16) for b in range(a + 1, 16)]
         node.close()
     n = 0
-    for (tf, na, nb), (tt, na2, nb2), (tu, na3, nb3) in zip(tabs["flat"], tabs["packed"], tabs["fused"]):
+    for (tf, na, nb), (tt, na2, nb2), (tu, na3, nb3) in zip(tabs["flat"], tabs["fused"], tabs["rows"]):
         assert (na, nb) == (na2, nb2) == (na3, nb3)
         assert np.array_equal(tf[:na, :nb], tt[:na, :nb]) and np.array_equal(tf[:na, :nb], tu[:na, :nb])
         n += na * nb
@@ -138,7 +127,7 @@ def test_packed_pair_kernel_equals_flat_kernel_bitwise(extr_rig, monkeypatch):
 
 
 @pytest.mark.parametrize("outliers", [0.0, 0.08])
-def test_hypothesis_wave_triangulation_equals_per_joint_kernel(extr_rig, monkeypatch, outliers):
+def test_hypothesis_wave_triangulation_equals_per_joint_kernel(extr_rig, outliers):
     """N <= 16: the one-wavefront-per-hypothesis kernel gives the per-joint kernel's triangulated points bit for bit (same solves on the
     same Gram matrices); scores and covariances differ only by the summation order of the error / covariance sums.  With gross 2-D
     outliers the rejection branches (S3D:748-838) run through the per-joint routine inside the new kernel."""
@@ -146,8 +135,7 @@ def test_hypothesis_wave_triangulation_equals_per_joint_kernel(extr_rig, monkeyp
                                                             outlier_frac=outliers, pixel_noise=3.0))
     res = {}
     for mode in ("joint", "hyp"):
-        monkeypatch.setenv("SE3D_TRI", mode)
-        node = _node(extr_rig, max_frames=8, max_det_per_cam=8, max_hyp=16)
+        node = _node(extr_rig, max_frames=8, max_det_per_cam=8, max_hyp=16, options=dict(tri_form="joint" if mode == "joint" else "auto"))
         res[mode] = node.triangulate_persons(frames)
         node.close()
     n = 0
@@ -188,29 +176,12 @@ def _pair_costs(node, frame_idx, a, b):
     return out, na.value, nb.value
 
 
-@pytest.mark.parametrize("mode", ["flat", "tiled", "rows", "fused", "lines", "tile22", "small_batch", "front_dump", "front_on_demand", "front256_dump"])
-def test_pair_cost_table_is_bit_exact(extr_rig, oracle, demo_params, mode, monkeypatch):
-    if mode == "small_batch":    # the library's own choice for <= 65 536 table entries per launch: normalize + flat kernel
-        monkeypatch.delenv("SE3D_PAIRS", raising=False)
-        monkeypatch.delenv("SE3D_NO_SMALL_BATCH", raising=False)
-    elif mode.startswith("front"):   # se3d_k_front_fused (round 4, A/B evidence — not the default): the frame's pair costs in LDS, 1024 threads per frame
-        monkeypatch.delenv("SE3D_PAIRS", raising=False)
-        monkeypatch.delenv("SE3D_NO_SMALL_BATCH", raising=False)
-        monkeypatch.setenv("SE3D_FRONT", "1")
-        if mode.endswith("_dump"):   # the kernel's own entries, also written to the API table; without: se3d_get_pair_costs computes the block on demand
-            monkeypatch.setenv("SE3D_FRONT_DUMP", "1")
-        if mode.startswith("front256"):   # the form for large batches: 256 threads per frame
-            monkeypatch.setenv("SE3D_NO_SMALL_BATCH", "1")
-    elif mode in ("fused", "lines") or mode.startswith("tile"):
-        monkeypatch.delenv("SE3D_PAIRS", raising=False)
-        monkeypatch.setenv("SE3D_NO_SMALL_BATCH", "1")
-        if mode == "lines":
-            monkeypatch.setenv("SE3D_NP_LINES", "1")   # the line-hoisted variant of the fused kernel (A/B evidence, not the default)
-        if mode.startswith("tile"):
-            monkeypatch.setenv("SE3D_NP_TILE", mode[4:])   # TR x TC entries per lane of the fused kernel
-    else:
-        monkeypatch.setenv("SE3D_PAIRS", mode)
-    node = _node(extr_rig, max_frames=2, max_det_per_cam=8, max_hyp=32)
+@pytest.mark.parametrize("mode", ["flat", "rows", "fused", "auto"])
+def test_pair_cost_table_is_bit_exact(extr_rig, oracle, demo_params, mode):
+    """calcCost's pair costs (S3D:353-365) of every retained kernel form against the oracle, double for double: flat (one lane per entry, IEEE
+    divide), rows (the large-rig kernel: shared-reciprocal quotient), fused (normalise + pairs in one workgroup per frame), auto (the library's
+    choice for two frames: the small-batch path, normalise + flat)."""
+    node = _node(extr_rig, max_frames=2, max_det_per_cam=8, max_hyp=32, options=dict(pairs_form=mode))
     frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=2, seed=11, p_miss=0.1))
     node.stage(frames)
     node.run_stage1()
@@ -286,17 +257,15 @@ def test_stage1_h36m_pose_method(extr_rig, oracle):
 
 @pytest.mark.parametrize("n_cam,persons,max_det,max_hyp", [(3, 2, 4, 8), (5, 3, 4, 8), (8, 4, 6, 16), (12, 5, 8, 16), (16, 7, 16, 32)])
 @pytest.mark.parametrize("tri", ["hyp", "joint"])
-def test_stage1_parity_small_rigs(oracle, demo_params, monkeypatch, n_cam, persons, max_det, max_hyp, tri):
+def test_stage1_parity_small_rigs(oracle, demo_params, n_cam, persons, max_det, max_hyp, tri):
     """Rigs of 3 .. 16 cameras (the one-wavefront-per-hypothesis triangulation: view slots, ballots and lane groups at every width),
     ragged views and low-confidence joints, several detection capacities; both triangulation kernels."""
     from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
-    if tri == "joint":
-        monkeypatch.setenv("SE3D_TRI", "joint")
     rig = R.elliptical_rig(n_cam, seed=3, a=5.0, b=4.0)
     rig.set_tensors(*rig_tensors(rig))
     frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=persons, n_frames=6, seed=40 + n_cam, p_miss=0.15, low_score_frac=0.15,
                                                        min_coverage=min(3, n_cam), spacing=0.9))
-    node = _node(rig, max_frames=6, max_det_per_cam=max_det, max_hyp=max_hyp)
+    node = _node(rig, max_frames=6, max_det_per_cam=max_det, max_hyp=max_hyp, options=dict(tri_form="joint" if tri == "joint" else "auto"))
     n_pub = 0
     for fr, g in zip(frames, node.triangulate_persons(frames)):
         compare_stage1(g, oracle.triangulate(rig, demo_params, fr, capacity=max_hyp, hyp_capacity=max_hyp))
@@ -342,8 +311,8 @@ def test_stage1_parity_ellipse_64cam_32p(oracle, demo_params):
     node.close()
 
 
-def test_tiled_pair_kernel_equals_flat_kernel_bitwise_large(oracle, monkeypatch):
-    """The tiled kernel's shared-reciprocal (Markstein) division must reproduce the IEEE-divide kernel bit for bit:
+def test_rows_pair_kernel_equals_flat_kernel_bitwise_large(oracle):
+    """The rows kernel's shared-reciprocal division (se3d_div_shared) must reproduce the IEEE-divide kernel bit for bit:
     every entry of the pair table for a crowded 24-camera scene (tens of thousands of pair costs, ~1e6 divisions)."""
     from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
     rig = R.elliptical_rig(24, seed=4)
@@ -354,49 +323,41 @@ def test_tiled_pair_kernel_equals_flat_kernel_bitwise_large(oracle, monkeypatch)
     kp3 = frames[0].persons[frames[0].det_offset[3] + 1]["keypoints"]
     kp3["x"][:5] = 3.0e12
     tabs = {}
-    for mode in ("flat", "tiled", "rows"):
-        monkeypatch.setenv("SE3D_PAIRS", mode)
-        node = _node(rig, max_frames=1, max_det_per_cam=48, max_hyp=96)
+    for mode in ("flat", "rows"):
+        node = _node(rig, max_frames=1, max_det_per_cam=48, max_hyp=96, options=dict(pairs_form=mode))
         node.stage(frames)
         node.run_stage1()
         node.sync()
         tabs[mode] = [_pair_costs(node, 0, a, b) for a in range(0, 24, 3) for b in range(a + 1, 24, 2)]
         node.close()
     n = 0
-    for (tf, na, nb), (tt, na2, nb2), (tr, na3, nb3) in zip(tabs["flat"], tabs["tiled"], tabs["rows"]):
-        assert (na, nb) == (na2, nb2) == (na3, nb3)
-        assert np.array_equal(tf[:na, :nb], tt[:na, :nb]) and np.array_equal(tf[:na, :nb], tr[:na, :nb])
+    for (tf, na, nb), (tr, na3, nb3) in zip(tabs["flat"], tabs["rows"]):
+        assert (na, nb) == (na3, nb3)
+        assert np.array_equal(tf[:na, :nb], tr[:na, :nb])
         n += na * nb
     assert n > 30000
 
 
-def test_postprocess_forms_agree_bytewise(extr_rig, monkeypatch):
-    """The lane-parallel post-processing kernels (persons in place in hypP with a compact LDS copy and the covariance inflation deferred to the
-    output copy: default for H <= 16; the same with the inflation written back: SE3D_POST_WAVE=3; persons staged in LDS: SE3D_POST_WAVE=2)
-    against the one-lane-per-person form of round 1: plausibility filter,
+def test_postprocess_forms_agree_bytewise(extr_rig):
+    """The lane-parallel post-processing kernel of small rigs (persons in place in hypP with a compact LDS copy, the covariance inflation deferred
+    to the output copy: default for H <= 16) against the thread-per-hypothesis kernel of large rigs (post_form = block): plausibility filter,
     limb-length covariance inflation (incl. the right-shoulder special case), duplicate merges — published persons byte for byte, on frames
     with clones (merges), a person far from its root and low-confidence joints."""
     import branch_scenes as BS
     frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=6, seed=5, pixel_noise=3.0, low_score_frac=0.2, p_miss=0.1))
     frames = frames + BS.duplicate_merge(extr_rig) + BS.root_distance_reset(extr_rig) + BS.feet_height_reject(extr_rig) + BS.outliers(extr_rig)
     res = {}
-    for name, env in (("lanes", None), ("person", "1"), ("lanes_lds", "2"), ("lanes_rmw", "3")):
-        if env:
-            monkeypatch.setenv("SE3D_POST_WAVE", env)
-        node = _node(extr_rig, max_frames=len(frames), max_det_per_cam=8, max_hyp=12)
+    for name in ("auto", "block"):
+        node = _node(extr_rig, max_frames=len(frames), max_det_per_cam=8, max_hyp=12, options=dict(post_form=name))
         res[name] = node.triangulate_persons(frames)
         node.close()
-        if env:
-            monkeypatch.delenv("SE3D_POST_WAVE")
     n = 0
-    for a, b, c, d in zip(res["lanes"], res["person"], res["lanes_lds"], res["lanes_rmw"]):
-        for o in (b, c, d):
-            assert a.n_hyp == o.n_hyp and a.n_persons == o.n_persons and a.flags == o.flags
-            assert np.array_equal(a.assoc(), o.assoc())
-            assert a.published().tobytes() == o.published().tobytes()
+    for a, o in zip(res["auto"], res["block"]):
+        assert a.n_hyp == o.n_hyp and a.n_persons == o.n_persons and a.flags == o.flags
+        assert np.array_equal(a.assoc(), o.assoc())
+        assert a.published().tobytes() == o.published().tobytes()
         n += a.n_persons
     assert n >= 30
-
 
 
 def test_exact_sqrt_and_divide_cores_match_ieee_on_the_device(extr_rig):
@@ -420,9 +381,9 @@ def test_shared_reciprocal_quotient_matches_ieee_on_the_device(extr_rig):
     assert bad == 0 and skipped < (1 << 33) // 1_000_000, (bad, skipped)
 
 
-def test_pair_table_column_chunks_equal_the_whole_table(monkeypatch, oracle, demo_params):
+def test_pair_table_column_chunks_equal_the_whole_table(oracle, demo_params):
     """Large rigs keep the pair table as camera-column chunks (Se3dPairPlan): the pair kernel fills chunk j while the sweep walks chunk j - 1.
-    A 48-camera, 24-person scene (per-camera sweep launches, 8 chunks by default) through the whole table (SE3D_PAIR_CHUNKS=0), the default,
+    A 48-camera, 24-person scene (per-camera sweep launches, 8 chunks by default) through the whole table (options.pair_chunks = -1), the default,
     3 and 32 chunks and with the Munkres matrix in LDS: hypotheses, association tables and published persons byte-equal, and equal to the
     oracle; a pair-table block fetched in chunk mode (recomputed on demand) equals the whole-table block bit for bit."""
     from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
@@ -440,17 +401,13 @@ def test_pair_table_column_chunks_equal_the_whole_table(monkeypatch, oracle, dem
     frames[3] = without(frames[3], set(range(48)) - {0, 5, 6, 31, 47})   # cameras without detections, among them the first and the last
     frames[4] = without(frames[4], {17})                                # one camera only: FLAG_FEW_CAMERAS, empty result
     res, blocks = {}, {}
-    for name, env in (("whole", {"SE3D_PAIR_CHUNKS": "0"}), ("default", {}), ("c3", {"SE3D_PAIR_CHUNKS": "3"}), ("c32", {"SE3D_PAIR_CHUNKS": "32"}),
-                      ("lds", {"SE3D_SWEEP_LDS_KB": "128"})):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        node = _node(rig, max_frames=5, max_det_per_cam=32, max_hyp=80)
+    for name, opt in (("whole", dict(pair_chunks=-1)), ("default", {}), ("c3", dict(pair_chunks=3)), ("c32", dict(pair_chunks=32)), ("lds", dict(sweep_lds_kb=128))):
+        node = _node(rig, max_frames=5, max_det_per_cam=32, max_hyp=80, options=opt)
+        assert node.pair_chunks() == {"whole": 0, "default": 8, "c3": 3, "lds": 8}.get(name, node.pair_chunks())
         res[name] = node.triangulate_persons(frames)
         if name in ("whole", "default"):
             blocks[name] = [_pair_costs(node, 1, a, b) for (a, b) in ((0, 1), (3, 40), (46, 47), (10, 11))]
         node.close()
-        for k in env:
-            monkeypatch.delenv(k)
     for (ta, na, nb), (tb, na2, nb2) in zip(blocks["whole"], blocks["default"]):
         assert (na, nb) == (na2, nb2) and na > 0 and nb > 0
         assert np.array_equal(ta[:na, :nb], tb[:na, :nb])

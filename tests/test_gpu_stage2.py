@@ -146,7 +146,7 @@ def _close_persons(x, y, n):
 
 
 @pytest.mark.parametrize("S_,T_,persons,mh,rough", [(5, 14, 4, 16, False), (3, 16, 6, 8, False), (2, 12, 9, 64, False), (4, 16, 5, 12, True)])
-def test_stage2_walk_equals_per_step_and_oracle(extr_rig, oracle, demo_params, monkeypatch, S_, T_, persons, mh, rough):
+def test_stage2_walk_equals_per_step_and_oracle(extr_rig, oracle, demo_params, S_, T_, persons, mh, rough):
     """se3d_run_stage2_walk (one fused launch for all time steps; falls back to per-step kernels for max_hyp = 64) against T
     consecutive se3d_run_stage2 calls and the oracle; walked forward then backward (bench.py's ping-pong order).  Variants of the
     fused kernel: one person per LM wavefront ("solo": the per-step device code, bitwise equal to the per-step calls), three persons
@@ -157,8 +157,8 @@ def test_stage2_walk_equals_per_step_and_oracle(extr_rig, oracle, demo_params, m
     extra = dict(p_miss=0.08, low_score_frac=0.22, outlier_frac=0.02, pixel_noise=3.0) if rough else {}
     seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=persons - (s % 2), n_frames=T_, seed=300 + s, **extra))[0] for s in range(S_)]
     frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s
-    variants = {"solo": {"SE3D_WALK_LM": "solo"}, "trio_wg": {"SE3D_WALK_SHAPE": "wg"}, "trio_wave": {"SE3D_WALK_SHAPE": "wave"}}
-    nodes = {name: _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=min(10, mh), max_hyp=mh) for name in list(variants) + ["steps"]}
+    variants = {"solo": dict(walk_lm="solo"), "trio_wg": dict(walk_shape="wg"), "trio_wave": dict(walk_shape="wave")}
+    nodes = {name: _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=min(10, mh), max_hyp=mh, options=variants.get(name)) for name in list(variants) + ["steps"]}
     for nd in nodes.values():
         nd.stage(frames)
         nd.run_stage1()
@@ -172,11 +172,7 @@ def test_stage2_walk_equals_per_step_and_oracle(extr_rig, oracle, demo_params, m
     for half in range(2):
         ks = order[half * T_:(half + 1) * T_]
         ts = t_of[half * T_:(half + 1) * T_]
-        for name, env in variants.items():
-            for key in ("SE3D_WALK_LM", "SE3D_WALK_SHAPE"):
-                monkeypatch.delenv(key, raising=False)
-            for key, val in env.items():
-                monkeypatch.setenv(key, val)
+        for name in variants:
             nodes[name].run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in ks])
             nodes[name].sync()
         for k, t in zip(ks, ts):
@@ -211,7 +207,7 @@ def test_stage2_walk_equals_per_step_and_oracle(extr_rig, oracle, demo_params, m
 
 
 @pytest.mark.parametrize("pose,nh", [("simple", True), ("h36m", False), ("h36m", True)])
-def test_stage2_walk_norm_height_and_h36m(extr_rig, oracle, monkeypatch, pose, nh):
+def test_stage2_walk_norm_height_and_h36m(extr_rig, oracle, pose, nh):
     """The fused walk (three persons per LM wavefront, both kernel shapes) with height normalisation and with the H36M joint set,
     where the belly is measured and the bone forest is rooted there: against the per-step kernels and the oracle."""
     params = pm.Params(pm.POSE_H36M if pose == "h36m" else pm.POSE_SIMPLE, int(nh), 0.045)
@@ -227,7 +223,7 @@ def test_stage2_walk_norm_height_and_h36m(extr_rig, oracle, monkeypatch, pose, n
     r1 = b.fetch_stage1(S_ * T_)
     ts = [100.0 + (i + 1) / 30.0 for i in range(T_)]
     for name in ("wg", "wave"):
-        monkeypatch.setenv("SE3D_WALK_SHAPE", name)
+        nodes[name].set_options(walk_shape=name)
         nodes[name].run_stage2_walk(np.repeat(np.array(ts)[:, None], S_, 1), [k * S_ for k in range(T_)])
         nodes[name].sync()
     oras = [oracle.PosePrior(params) for _ in range(S_)]
@@ -280,17 +276,16 @@ def test_stage2_track_capacity_flag(extr_rig, walk):
 
 
 @pytest.mark.parametrize("shape", ["wave", "wg"])
-def test_stage2_walk_is_deterministic_and_sequences_do_not_interact(extr_rig, monkeypatch, shape):
+def test_stage2_walk_is_deterministic_and_sequences_do_not_interact(extr_rig, shape):
     """Size-independent properties of the fused walk: the same batch twice gives the same bytes, and a sequence's results do not depend
     on which other sequences share the launch (reversed sequence order, i.e. other workgroup / wavefront neighbours and LDS regions)."""
-    monkeypatch.setenv("SE3D_WALK_SHAPE", shape)
     S_, T_ = 7, 14
     seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=2 + (s % 5), n_frames=T_, seed=700 + s, p_miss=0.05 * (s % 3)))[0] for s in range(S_)]
     ts = [100.0 + (i + 1) / 30.0 for i in range(T_)]
     outs = []
     for order in (list(range(S_)), list(range(S_)), list(range(S_ - 1, -1, -1))):
         frames = [seqs[s][k] for k in range(T_) for s in order]
-        node = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12)
+        node = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12, options=dict(walk_shape=shape))
         node.stage(frames)
         node.run_stage1()
         node.refine_reset()
@@ -308,19 +303,17 @@ def test_stage2_walk_is_deterministic_and_sequences_do_not_interact(extr_rig, mo
     assert sum(v[0] for v in outs[0].values()) > S_ * 3
 
 
-def test_stage2_walk_bookkeeping_in_lds_equals_global(extr_rig, monkeypatch):
+def test_stage2_walk_bookkeeping_in_lds_equals_global(extr_rig):
     """One-wavefront walk: the per-step bookkeeping (cost matrix, merge rows, order, slot / publish tables, per-sequence scalars) in LDS
-    (default when it fits) against the same tables in global memory (SE3D_WALK_BOOK=0): published persons, iteration counts, track counts and
+    (default when it fits) against the same tables in global memory (options.walk_book = 1): published persons, iteration counts, track counts and
     flags byte for byte, over a ping-pong walk of sequences with appearing / vanishing persons; then the per-step kernels continue from the
     state both left behind (order, n_tracks, next_id, frame_nr, t_prev, feedback buffer were written back)."""
-    monkeypatch.setenv("SE3D_WALK_SHAPE", "wave")
     S_, T_ = 5, 12
     seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=3 + (s % 4), n_frames=T_, seed=900 + s, p_miss=0.04 * (s % 3), low_score_frac=0.1))[0] for s in range(S_)]
     frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
     outs = []
-    for book in ("1", "0"):
-        monkeypatch.setenv("SE3D_WALK_BOOK", book)
-        node = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12)
+    for book in (0, 1):
+        node = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12, options=dict(walk_shape="wave", walk_book=book))
         node.stage(frames)
         node.run_stage1()
         node.refine_reset()
@@ -334,25 +327,21 @@ def test_stage2_walk_bookkeeping_in_lds_equals_global(extr_rig, monkeypatch):
                 for r in node.fetch_stage2_walk(k * S_, S_):
                     n = r.n_persons
                     res.append((n, r.fused[:n].tobytes(), r.fused_pred[:n].tobytes(), r.lm_iterations[:n].tobytes(), r.c.n_tracks, r.c.flags))
-        monkeypatch.setenv("SE3D_WALK", "steps")   # continue with the per-step kernels from the written-back state
-        node.run_stage2(np.full(S_, t + 1 / 30.0), frame_slot0=0)
+        node.run_stage2(np.full(S_, t + 1 / 30.0), frame_slot0=0)   # continue with the per-step kernels from the written-back state
         for r in node.fetch_stage2(S_):
             n = r.n_persons
             res.append((n, r.fused[:n].tobytes(), r.lm_iterations[:n].tobytes(), r.c.n_tracks))
-        monkeypatch.delenv("SE3D_WALK")
         outs.append(res)
         node.close()
     assert outs[0] == outs[1]
     assert sum(v[0] for v in outs[0]) > S_ * T_
 
 
-def test_stage2_walk_at_bench_size(extr_rig, oracle, demo_params, monkeypatch):
+def test_stage2_walk_at_bench_size(extr_rig, oracle, demo_params):
     """The bench.py shape of 16 cam x 6 persons: 256 sequences x 16 frames in one launch (the launcher picks the one-wavefront-per-sequence
     kernel from 256 sequences).  The distinct sequences are checked against the oracle step by step, every replica must be bitwise
     equal to its prototype, and the steady-state pass publishes every person of every frame."""
     import bench
-    monkeypatch.delenv("SE3D_WALK_SHAPE", raising=False)
-    monkeypatch.delenv("SE3D_WALK_LM", raising=False)
     w = bench.WORKLOADS["16cam6p"]
     S_, T_, U = 256, 16, 32
     seqs = bench.make_sequences(None, w, 1, S_, 4, T_)[0]   # one context: up to 32 distinct seeded sequences (4000 ...), repeated
@@ -435,16 +424,14 @@ def test_stage2_walk_device_pack(extr_rig, device_buffer):
 
 
 @pytest.mark.parametrize("variant", ["solo", "trio"])
-def test_stage2_walk_then_per_step_share_track_state(extr_rig, monkeypatch, variant):
+def test_stage2_walk_then_per_step_share_track_state(extr_rig, variant):
     """Track state written back by a fused walk (it lives in LDS during the walk) is what later per-step calls continue from:
     bitwise with the one-person-per-wavefront LM (the per-step device code), within rounding with three persons per wavefront."""
-    if variant == "solo":
-        monkeypatch.setenv("SE3D_WALK_LM", "solo")
     S_, T_ = 3, 16
     seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=5, n_frames=T_, seed=500 + s))[0] for s in range(S_)]
     frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
-    a = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=8)
-    b = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=8)
+    a = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=8, options=dict(walk_lm=variant))
+    b = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=8, options=dict(walk_lm=variant))
     for nd in (a, b):
         nd.stage(frames)
         nd.run_stage1()
@@ -486,16 +473,16 @@ LM_SCENES = {
 
 
 @pytest.mark.parametrize("scene", sorted(LM_SCENES))
-@pytest.mark.parametrize("lm", ["tree", "tree_mfma", "schur", "dense"])
-def test_stage2_every_lm_form_matches_the_oracle(extr_rig, oracle, monkeypatch, lm, scene):
-    """north_star config 4: the batched J^T J on the matrix cores (`dense`: v_mfma_f64_16x16x4_f64 on the whole 63 x 63 product; `schur` /
-    `tree_mfma`: on the bone-factor block) and the default forest elimination, each through se3d_refine against the oracle on four scenes."""
+@pytest.mark.parametrize("lm", ["tree", "tree_mfma", "dense"])
+def test_stage2_every_lm_form_matches_the_oracle(extr_rig, oracle, lm, scene):
+    """north_star config 4: the batched J^T J on the matrix cores (`dense`: v_mfma_f64_16x16x4_f64 on the whole 63 x 63 product;
+    `tree_mfma`: on the bone-factor block of the marginals) and the default forest elimination, each through se3d_refine against the oracle on
+    four scenes (the per-step LM kernel: refine_steps = 1)."""
     sc = LM_SCENES[scene]
-    monkeypatch.setenv("SE3D_LM", lm)
     params = pm.Params(pm.POSE_H36M if sc["pose"] == "h36m" else pm.POSE_SIMPLE, int(sc["nh"]), 0.045)
-    node = _node(extr_rig, pose_method=sc["pose"], norm_height=sc["nh"], max_frames=1, max_det_per_cam=8, max_hyp=32)
+    node = _node(extr_rig, pose_method=sc["pose"], norm_height=sc["nh"], max_frames=1, max_det_per_cam=8, max_hyp=32, options=dict(lm_form=lm, refine_steps=1))
     worst, published = _sequence_parity(node, extr_rig, oracle, params, S.SceneConfig(**sc["cfg"]), drop_frames=sc["drop"])
-    print("SE3D_LM=%s on %s: %d published persons, worst %s" % (lm, scene, published, worst))
+    print("lm_form=%s on %s: %d published persons, worst %s" % (lm, scene, published, worst))
     assert published > 0
     node.close()
 

@@ -7,8 +7,8 @@ WL="${@:-16cam6p 256cam128p}"
 for wl in $WL; do
 for r in 0 1 2 3 4 5 6 7; do
   st=4; [ $wl = 256cam128p ] && st=2
-  SE3D_BENCH_SEED_RANK=$r timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $((29600 + r)) \
-      bench.py --gpus 1 --workload $wl --steps $st --warmup 1 --no-cpu-baseline 2>/tmp/check_rank.err | tail -1 | python3 -c "
+  timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $((29600 + r)) \
+      bench.py --gpus 1 --workload $wl --steps $st --warmup 1 --no-cpu-baseline --seed-rank $r 2>/tmp/check_rank.err | tail -1 | python3 -c "
 import sys, json
 try:
     d = json.loads(sys.stdin.read()); c = d['config']

@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic (make -C .../csrc diag): wall time of the fused stage-2 walk at 16cam6p with parts of the LM switched off, to attribute
 the walk time without in-kernel stamps (which perturb memory phases).  Results with ablation bits set are wrong by construction.
-The switches live in the one-person-per-wavefront LM (s2_lm_body), so the tool runs the walk with SE3D_WALK_LM=solo."""
+The switches live in the one-person-per-wavefront LM (s2_lm_body), so the tool runs the walk with options.walk_lm = solo."""
 import ctypes as C, os, sys, time
-os.environ["SE3D_WALK_LM"] = "solo"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from smartedgesensor3dhumanpose_amd import _lib
@@ -16,7 +15,7 @@ S_, T_ = 128, 16
 seqs = bench.make_sequences(None, w, 1, S_, 0, T_)[0]
 frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
 from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
-node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12)
+node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12, options=dict(walk_lm="solo"))
 node.stage(frames); node.refine_reset(); node.run_stage1(); node.sync()
 L = _lib.lib()
 t = [100.0]

@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORIC: ran against the library of its round; the SE3D_* environment switches named here were replaced by se3d_options in round 5 (tools/profile_r5.sh is the current form).
 # Runs on the GPU box (gpurun): the three rocprofv3 passes behind profiles/<round>/ for one bench.py configuration.
 #   bash tools/profile_bench.sh <tag> [bench.py args...]
 # 1. --kernel-trace --stats            -> per-kernel durations (must agree with bench.py's in-library HIP-event times)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORIC: ran against the library of its round; the SE3D_* environment switches named here were replaced by se3d_options in round 5 (tools/profile_r5.sh is the current form).
 # Runs on the GPU box (gpurun -- bash tools/profile_r4.sh <what> ...): the rocprofv3 passes behind profiles/r4/.
 #   serial      : bench.py --serial (one context, one stream) kernel stats
 #   serial_pmc  : SQ + HBM traffic PMC passes of the serial pass

@@ -3,10 +3,10 @@
 #   serial      : bench.py --serial (one context, one stream) kernel stats
 #   serial_pmc  : SQ + HBM traffic PMC passes of the serial pass
 #   valumix     : VALU instruction-mix counters of the serial pass
-#   front       : serial pass with se3d_k_front_fused forced on the large batch (FRONT_VARIANTS="nt:cap ...")
 #   c256        : 256cam128p, one context: kernel stats (+ PMC with c256_pmc)
 #   ablate      : a variant library tools/tmp/libse3d_$ABLATE.so through the serial pass
-#   exact_waves : (historic) second pass with W wavefronts and the workspace in global memory
+#   c256_ab     : variant libraries tools/tmp/libse3d_<name>.so (tools/build_variants.sh) through the one-context 256cam128p pass: AB="name ..."
+#   c256_ab_pmc : SQ + LDS counters of the pair kernel for such variants
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -35,31 +35,6 @@ ablate)
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_stats_$ABLATE -- python3 bench.py --serial --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_stats_$ABLATE.log 2>&1
   unset SE3D_LIB_OVERRIDE
   python3 tools/kernel_stats.py $OUT/serial_stats_$ABLATE $OUT/serial_16cam6p_${ABLATE}_kernel_stats.csv
-  ;;
-exact_waves)
-  # second pass with the workspace in global memory and W wavefronts (A/B of the LDS workspace, 4 wavefronts per CU)
-  for W in 2048 4096 8192; do
-    rm -rf $OUT/serial_stats_w$W
-    export SE3D_EXACT_WAVES=$W
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_stats_w$W -- python3 bench.py --serial --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_stats_w$W.log 2>&1
-    unset SE3D_EXACT_WAVES
-    python3 tools/kernel_stats.py $OUT/serial_stats_w$W $OUT/serial_16cam6p_w${W}_kernel_stats.csv | grep triang
-  done
-  ;;
-front)
-  # the fused front kernel on the large batch (A/B): FRONT_VARIANTS="nt:cap ..." (cap empty = the launcher's default)
-  export SE3D_FRONT=1
-  for V in ${FRONT_VARIANTS:-256: 512: 256:2304}; do
-    NT=${V%%:*}; CAP=${V#*:}
-    export SE3D_FRONT_NT=$NT
-    if [ -n "$CAP" ]; then export SE3D_FRONT_CAP=$CAP; else unset SE3D_FRONT_CAP; fi
-    T=front${NT}_cap${CAP:-default}
-    rm -rf $OUT/serial_stats_$T
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial_stats_$T -- python3 bench.py --serial --steps 5 --warmup 1 --no-cpu-baseline --no-parity > $OUT/serial_bench_stats_$T.log 2>&1
-    python3 tools/kernel_stats.py $OUT/serial_stats_$T $OUT/serial_16cam6p_${T}_kernel_stats.csv
-    tail -1 $OUT/serial_bench_stats_$T.log | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print('$T', d['value'], d['ms_per_step'])"
-  done
-  unset SE3D_FRONT SE3D_FRONT_NT SE3D_FRONT_CAP
   ;;
 valumix)
   # instruction mix of the vector ALU per kernel (two passes: the counters do not fit one)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORIC: ran against the library of its round; the SE3D_* environment switches named here were replaced by se3d_options in round 5 (tools/profile_r5.sh is the current form).
 # Evidence run of round 3 on the GPU box (gpurun -- bash tools/r3_final.sh): the GPU suite, the default bench line, the parity sweep as a tool
 # (one JSON report per seed) and the rocprofv3 passes behind profiles/r3/.  Outputs under gpurun_out/r3_final/ and gpurun_out/prof_r3/.
 set -u
