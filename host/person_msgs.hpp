@@ -12,6 +12,10 @@ struct Header {            // std_msgs/Header (stamp as seconds)
   uint32_t seq = 0;
   double stamp = 0.0;
   std::string frame_id;
+  // The ROS stamp this header was made from, in nanoseconds (-1: none).  The host layer computes with `stamp` (what the reference's
+  // `.toSec()` yields) and only CARRIES this field along with copies of the header, so that a catkin wrapper publishes the input's sec / nsec
+  // bit for bit instead of a double's ~240 ns grid (host/ros/ros_bridge.hpp; the reference forwards ros::Time unchanged, S3D:1060-1065).
+  int64_t stamp_ns = -1;
 };
 
 struct Keypoint2D {        // Keypoint2D.msg
@@ -48,6 +52,7 @@ struct PersonCov {         // PersonCov.msg (bbox_center / bbox_size are never w
 struct PersonCovList {     // PersonCovList.msg
   Header header;
   std::vector<double> ts_per_cam;
+  std::vector<int64_t> ts_per_cam_ns;   // exact stamps alongside ts_per_cam (entries -1 / empty: none), carried like Header::stamp_ns
   std::vector<float> fb_delay_per_cam;
   std::vector<PersonCov> persons;
 };

@@ -8,6 +8,7 @@
 #pragma once
 #include <array>
 #include <chrono>
+#include <cmath>
 #include <iostream>
 
 #include <ros/ros.h>
@@ -57,7 +58,7 @@ inline std::vector<std::array<double, 16>> get_transforms(const std::vector<std:
       ros::Duration(1.0).sleep();
     }
   }
-  ROS_INFO("Sucessfully retrieved camera extrinsic transforms.");
+  ROS_INFO("Retrieved the camera extrinsic transforms.");
   return out;
 }
 
@@ -93,14 +94,23 @@ inline std::vector<se3d::CameraCalib> calibration(const std::vector<std::array<d
 }
 
 // ---- messages: generated ROS types <-> host mirrors (field for field, person_msgs/msg/*.msg) ----
+// Stamps: the host layer computes with seconds as double (what the reference's `.toSec()` yields) and carries the message's sec / nsec next to
+// it; a published stamp is the carried one whenever it still is the double's time (the reference forwards ros::Time unchanged, S3D:1060-1065,
+// PP:528-532, REPROJ:230-231 — a double resolves ~240 ns at today's epoch, which would break stamp-equality matching downstream).
+inline int64_t stamp_ns(const ros::Time& t) { return (int64_t)t.sec * 1000000000LL + (int64_t)t.nsec; }
+inline ros::Time to_ros_time(double stamp, int64_t ns) {
+  if (ns >= 0 && std::fabs((double)(ns / 1000000000LL) + 1e-9 * (double)(ns % 1000000000LL) - stamp) < 1e-6)
+    return ros::Time((uint32_t)(ns / 1000000000LL), (uint32_t)(ns % 1000000000LL));
+  return ros::Time(stamp);
+}
 inline se3d_person_msgs::Header to_host(const std_msgs::Header& h) {
   se3d_person_msgs::Header o;
-  o.seq = h.seq; o.stamp = h.stamp.toSec(); o.frame_id = h.frame_id;
+  o.seq = h.seq; o.stamp = h.stamp.toSec(); o.stamp_ns = stamp_ns(h.stamp); o.frame_id = h.frame_id;
   return o;
 }
 inline std_msgs::Header to_ros(const se3d_person_msgs::Header& h) {
   std_msgs::Header o;
-  o.seq = h.seq; o.stamp = ros::Time(h.stamp); o.frame_id = h.frame_id;
+  o.seq = h.seq; o.stamp = to_ros_time(h.stamp, h.stamp_ns); o.frame_id = h.frame_id;
   return o;
 }
 inline se3d_person_msgs::Person2DList to_host(const person_msgs::Person2DList& m) {
@@ -142,7 +152,7 @@ inline person_msgs::Person2DList to_ros(const se3d_person_msgs::Person2DList& m)
 inline se3d_person_msgs::PersonCovList to_host(const person_msgs::PersonCovList& m) {
   se3d_person_msgs::PersonCovList o;
   o.header = to_host(m.header);
-  for (const auto& t : m.ts_per_cam) o.ts_per_cam.push_back(t.toSec());
+  for (const auto& t : m.ts_per_cam) { o.ts_per_cam.push_back(t.toSec()); o.ts_per_cam_ns.push_back(stamp_ns(t)); }
   o.fb_delay_per_cam.assign(m.fb_delay_per_cam.begin(), m.fb_delay_per_cam.end());
   o.persons.resize(m.persons.size());
   for (size_t p = 0; p < m.persons.size(); ++p) {
@@ -161,7 +171,8 @@ inline se3d_person_msgs::PersonCovList to_host(const person_msgs::PersonCovList&
 inline person_msgs::PersonCovList to_ros(const se3d_person_msgs::PersonCovList& m) {
   person_msgs::PersonCovList o;
   o.header = to_ros(m.header);
-  for (const double t : m.ts_per_cam) o.ts_per_cam.push_back(ros::Time(t));
+  for (size_t i = 0; i < m.ts_per_cam.size(); ++i)
+    o.ts_per_cam.push_back(to_ros_time(m.ts_per_cam[i], i < m.ts_per_cam_ns.size() ? m.ts_per_cam_ns[i] : -1));
   o.fb_delay_per_cam.assign(m.fb_delay_per_cam.begin(), m.fb_delay_per_cam.end());
   o.persons.resize(m.persons.size());
   for (size_t p = 0; p < m.persons.size(); ++p) {

@@ -179,6 +179,7 @@ bool Skeleton3DNode::skeletonThreadStep(std::vector<person_msgs::Person2DList> p
   persons3d_msg.header = people[t_max_idx].header;  // S3D:1060-1065
   for (int i = 0; i < N; ++i) {
     persons3d_msg.ts_per_cam.push_back(people[i].header.stamp);
+    persons3d_msg.ts_per_cam_ns.push_back(people[i].header.stamp_ns);
     persons3d_msg.fb_delay_per_cam.push_back(people[i].fb_delay);
   }
   persons3d_msg.header.frame_id = BASE_FRAME;
@@ -216,6 +217,7 @@ void PosePriorNode::skeletonCallback(const person_msgs::PersonCovList& persons, 
   persons_fused = person_msgs::PersonCovList();
   persons_fused.header = persons.header;  // PP:528-532
   persons_fused.ts_per_cam = persons.ts_per_cam;
+  persons_fused.ts_per_cam_ns = persons.ts_per_cam_ns;
   persons_fused.fb_delay_per_cam.assign(persons.fb_delay_per_cam.size(), fo.pred_delta_t);
   persons_fused_pred = persons_fused;
   for (int p = 0; p < fo.n_persons; ++p) {
@@ -256,6 +258,7 @@ bool ReprojectionNode::fusedSkeletonCallback(const person_msgs::PersonCovList& h
   for (int i = 0; i < n_cam; ++i) {
     auto& l = humans_in_cam[i];
     l.header.stamp = humans.ts_per_cam[i];                                   // REPROJ:230-231
+    l.header.stamp_ns = (int)humans.ts_per_cam_ns.size() == n_cam ? humans.ts_per_cam_ns[i] : -1;
     l.header.frame_id = "cam_" + std::to_string(i);
     l.fb_delay = humans.fb_delay_per_cam[i];
     for (int k = off[i]; k < off[i + 1]; ++k) {
