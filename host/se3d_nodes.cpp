@@ -207,7 +207,7 @@ void PosePriorNode::skeletonCallback(const person_msgs::PersonCovList& persons, 
   const int H = ctx_->max_hyp();
   std::vector<se3d_person3d> fused(H), pred(H);
   std::vector<int32_t> iters(H);
-  se3d_fused_out fo{H, 0, 0, 0.f, fused.data(), pred.data(), iters.data(), 0u};
+  se3d_fused_out fo{H, 0, 0, 0.f, fused.data(), pred.data(), iters.data(), 0u, nullptr};
   const int rc = se3d_refine(ctx_->get(), seq_, (int32_t)dets.size(), dets.empty() ? nullptr : dets.data(), (int32_t)persons.fb_delay_per_cam.size(),
                              persons.fb_delay_per_cam.empty() ? nullptr : persons.fb_delay_per_cam.data(), persons.header.stamp, &fo);
   if (rc != SE3D_OK) throw std::runtime_error(std::string("se3d_refine: ") + se3d_last_error(ctx_->get()));

@@ -180,6 +180,11 @@ typedef struct se3d_fused_out {
   se3d_person3d *fused_pred; /* [capacity] */
   int32_t *lm_iterations;    /* [capacity] outer LM iterations used for each published person (diagnostic) */
   uint32_t flags;            /* out: SE3D_S2FLAG_* of the sequence, sticky since se3d_refine_reset */
+  double *lm_objective;      /* [capacity] or NULL (diagnostic, round 5): the factor graph's error at the published values, GTSAM's
+                                graph.error(result) = 0.5 sum ||whitened residual||^2 over the unary, root and range factors (PP:626-758), in the
+                                normalised coordinates the optimiser works in; -1 for a person whose optimisation failed (published at its
+                                measurements, PP:751-758).  A solver-independent yardstick: two LM implementations that stop at different points
+                                of a badly scaled problem can be compared by it. */
 } se3d_fused_out;
 
 /* per-sequence flag bits in se3d_fused_out.flags */

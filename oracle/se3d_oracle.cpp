@@ -1611,6 +1611,7 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
   std::vector<se3d_person3d> fused(n_det), fused_pred(n_det);
   std::vector<char> publish(n_det, 0);
   std::vector<int> lm_iters(n_det, 0);
+  std::vector<double> lm_obj(n_det, -1.0);   // graph.error(result) per detection (se3d_fused_out.lm_objective); -1: optimisation failed
 
   auto process_person = [&](int person_idx) {  // PP:587-853
     const se3d_person3d &person = dets[person_idx];
@@ -1726,9 +1727,11 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
 
     Values result;
     int iters = 0;
-    if (whiten_ok) result = lm_optimize(graph, curr_track.prevEstimate, &iters, nullptr);
+    double final_error = -1.0;
+    if (whiten_ok) result = lm_optimize(graph, curr_track.prevEstimate, &iters, &final_error);
     else { result = measurements; stat(SE3D_ORACLE_STAT_LM_FAILED); }  // optimisation failed -> output measurements (PP:751-758)
     lm_iters[person_idx] = iters;
+    lm_obj[person_idx] = final_error;
 
     std::map<int, std::array<double, 9>> marg;
     bool use_marginals = whiten_ok && marginal_covariances(graph, result, marg);  // PP:760-767
@@ -1797,6 +1800,7 @@ int se3d_oracle_pp_step(se3d_oracle_pp *pp, int32_t n_det, const se3d_person3d *
     out->fused[i] = fused[out_idx[i]];
     out->fused_pred[i] = fused_pred[out_idx[i]];
     if (out->lm_iterations) out->lm_iterations[i] = lm_iters[out_idx[i]];
+    if (out->lm_objective) out->lm_objective[i] = lm_obj[out_idx[i]];
   }
 
   remove_old_tracks();  // PP:867

@@ -59,7 +59,7 @@ struct se3d_ctx {
   // Slabs: the arrays that cross the bus together are carved from ONE device allocation and ONE pinned host allocation at the same
   // offsets, so that the transfer of a whole batch (a single frame for max_frames = 1, the reference's operating point) is one copy
   // instead of one per array: in1 = {nraw, fb, raw}, out1 = {out_count, nhyp, flags, outP, out_hyp, out_assoc},
-  // in2 = {n_det, t, fb_ref, dets}, out2 = {n_out, n_tracks, flags2, pred_dt, iters, fused, pred}.
+  // in2 = {n_det, t, fb_ref, dets}, out2 = {n_out, n_tracks, flags2, pred_dt, obj, iters, fused, pred}.
   struct Slab { char *d = nullptr, *h = nullptr; size_t bytes = 0; } sl_in1, sl_out1, sl_in2, sl_out2;
   size_t off_raw = 0, off_in2 = 0;   // offsets of the variable-length tails of the two input slabs
   // pinned host staging (views into the slabs)
@@ -103,6 +103,7 @@ struct se3d_ctx {
   int t_head = 0;
   se3d_person3d *h_fused = nullptr, *h_pred = nullptr;
   int32_t *h_iters = nullptr, *h_nout = nullptr, *h_ntracks = nullptr;
+  double *h_obj = nullptr;
   uint32_t *h_flags2 = nullptr;
   double *h_preddt = nullptr;
   hipEvent_t ev2[kRing][4]{};            // stage-2 sets
@@ -389,13 +390,14 @@ static bool alloc_device_state(se3d_ctx *c, int N, const se3d_params *params, co
     ok = ok && dev_alloc(c, &Q.prev, S * T * SE3D_NFU * 3) && dev_alloc(c, &Q.vel, S * T * SE3D_NFU * 9);
     ok = ok && dev_alloc(c, &Q.near, S * T * 4);
     ok = ok && dev_alloc(c, &Q.C, S * H * T) && dev_alloc(c, &Q.W, S * H * T) && dev_alloc(c, &Q.det_slot, S * H) && dev_alloc(c, &Q.pub, S * H);
-    ok = ok && dev_alloc(c, &Q.fused_det, S * H) && dev_alloc(c, &Q.pred_det, S * H) && dev_alloc(c, &Q.iters_det, S * H);
+    ok = ok && dev_alloc(c, &Q.fused_det, S * H) && dev_alloc(c, &Q.pred_det, S * H) && dev_alloc(c, &Q.iters_det, S * H) && dev_alloc(c, &Q.obj_det, S * H);
     ok = ok && dev_alloc(c, &Q.lm_scratch, S * 4 * 1865);  // [S][4 wavefronts][S2_SCHUR_SCRATCH_DOUBLES] (se3d_stage2.hip)
     ok = ok && slab_build(c, c->sl_out2, [&](SlabCarver &m) {
       m.take(&Q.n_out, &c->h_nout, S);
       m.take(&Q.n_tracks, &c->h_ntracks, S);
       m.take(&Q.flags2, &c->h_flags2, S);
       m.take(&Q.pred_dt, &c->h_preddt, S);
+      m.take(&Q.obj, &c->h_obj, S * H);
       m.take(&Q.iters, &c->h_iters, S * H);
       m.take(&Q.fused, &c->h_fused, S * H);
       m.take(&Q.pred, &c->h_pred, S * H);
@@ -981,6 +983,7 @@ static int fetch_stage2_range(se3d_ctx *c, int seq0, int n_seq, se3d_fused_out *
   HIPCHK(c, hipMemcpyAsync(c->h_fused + seq0 * H, Q.fused + seq0 * H, sizeof(se3d_person3d) * n_seq * H, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_pred + seq0 * H, Q.pred + seq0 * H, sizeof(se3d_person3d) * n_seq * H, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_iters + seq0 * H, Q.iters + seq0 * H, sizeof(int32_t) * n_seq * H, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_obj + seq0 * H, Q.obj + seq0 * H, sizeof(double) * n_seq * H, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_nout + seq0, Q.n_out + seq0, sizeof(int32_t) * n_seq, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_ntracks + seq0, Q.n_tracks + seq0, sizeof(int32_t) * n_seq, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->h_flags2 + seq0, Q.flags2 + seq0, sizeof(uint32_t) * n_seq, hipMemcpyDeviceToHost, c->stream));
@@ -1001,6 +1004,7 @@ static int fetch_stage2_range(se3d_ctx *c, int seq0, int n_seq, se3d_fused_out *
     if (np && o.fused) memcpy(o.fused, c->h_fused + s * H, sizeof(se3d_person3d) * (size_t)np);
     if (np && o.fused_pred) memcpy(o.fused_pred, c->h_pred + s * H, sizeof(se3d_person3d) * (size_t)np);
     if (np && o.lm_iterations) memcpy(o.lm_iterations, c->h_iters + s * H, sizeof(int32_t) * (size_t)np);
+    if (np && o.lm_objective) memcpy(o.lm_objective, c->h_obj + s * H, sizeof(double) * (size_t)np);
   }
   return rc;
 }
@@ -1029,7 +1033,7 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
         Se3dWalk Wk{};
         Wk.n_steps = 1; Wk.slot0[0] = 0; Wk.t = c->d_t; Wk.t_stride = 1;
         Wk.outP = c->d_in2; Wk.out_count = c->d_ndet2; Wk.fb = c->d_fb_ref;
-        Wk.Wf = c->Q.fused; Wk.Wp = c->Q.pred; Wk.Wit = c->Q.iters; Wk.Wn = c->Q.n_out; Wk.Wdt = c->Q.pred_dt;
+        Wk.Wf = c->Q.fused; Wk.Wp = c->Q.pred; Wk.Wit = c->Q.iters; Wk.Wobj = c->Q.obj; Wk.Wn = c->Q.n_out; Wk.Wdt = c->Q.pred_dt;
         walked = se3d_launch_stage2_walk(c->Q, c->opt, Wk, 1, c->stream);
       }
       if (!walked) se3d_launch_stage2(Qg, c->opt, 0, 1, c->stream, nullptr, 3);
@@ -1061,7 +1065,7 @@ int se3d_refine(se3d_ctx *c, int32_t seq, int32_t n_det, const se3d_person3d *de
       Wk.slot0[0] = 0;
       Wk.t = c->d_t; Wk.t_stride = 1;
       Wk.outP = c->d_in2; Wk.out_count = c->d_ndet2; Wk.fb = c->d_fb_ref;
-      Wk.Wf = c->Q.fused; Wk.Wp = c->Q.pred; Wk.Wit = c->Q.iters; Wk.Wn = c->Q.n_out; Wk.Wdt = c->Q.pred_dt;
+      Wk.Wf = c->Q.fused; Wk.Wp = c->Q.pred; Wk.Wit = c->Q.iters; Wk.Wobj = c->Q.obj; Wk.Wn = c->Q.n_out; Wk.Wdt = c->Q.pred_dt;
       hipEvent_t *ev = next_ev2(c);
       if (ev) { c->ev2_walk[(c->ev2_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = true; (void)hipEventRecord(ev[0], c->stream); }
       walked = se3d_launch_stage2_walk(c->Q, c->opt, Wk, 1, c->stream);
@@ -1215,7 +1219,7 @@ int se3d_run_stage2_walk(se3d_ctx *c, int32_t n_seq, int32_t n_steps, const int3
   for (int k = 0; k < n_steps; ++k) Wk.slot0[k] = frame_slot0[k];
   Wk.t = c->d_t; Wk.t_stride = n_seq;
   Wk.outP = c->D.outP; Wk.out_count = c->D.out_count; Wk.fb = c->d_fb_walk ? c->d_fb_walk : c->d_fb;
-  Wk.Wf = Q0.fused; Wk.Wp = Q0.pred; Wk.Wit = Q0.iters; Wk.Wn = Q0.n_out; Wk.Wdt = Q0.pred_dt;
+  Wk.Wf = Q0.fused; Wk.Wp = Q0.pred; Wk.Wit = Q0.iters; Wk.Wobj = Q0.obj; Wk.Wn = Q0.n_out; Wk.Wdt = Q0.pred_dt;
   hipEvent_t *ev = next_ev2(c);
   if (ev) { c->ev2_walk[(c->ev2_head + se3d_ctx::kRing - 1) % se3d_ctx::kRing] = true; (void)hipEventRecord(ev[0], c->stream); }
   if (!se3d_launch_stage2_walk(Q0, c->opt, Wk, n_seq, c->stream)) {
@@ -1229,7 +1233,7 @@ int se3d_run_stage2_walk(se3d_ctx *c, int32_t n_seq, int32_t n_steps, const int3
       const size_t f0 = (size_t)frame_slot0[k];
       Se3dStage2 Q = Q0;
       Q.dets = Wk.outP + f0 * Q.H; Q.n_det = Wk.out_count + f0; Q.fb_delay = Wk.fb + f0 * Q.N; Q.t = c->d_t + (size_t)k * n_seq;
-      Q.fused = Q0.fused + f0 * Q.H; Q.pred = Q0.pred + f0 * Q.H; Q.iters = Q0.iters + f0 * Q.H; Q.n_out = Q0.n_out + f0; Q.pred_dt = Q0.pred_dt + f0;
+      Q.fused = Q0.fused + f0 * Q.H; Q.pred = Q0.pred + f0 * Q.H; Q.iters = Q0.iters + f0 * Q.H; Q.obj = Q0.obj + f0 * Q.H; Q.n_out = Q0.n_out + f0; Q.pred_dt = Q0.pred_dt + f0;
       se3d_launch_stage2(Q, c->opt, 0, n_seq, s2, nullptr, 3);
     }
     if (s2 != c->stream) {

@@ -179,10 +179,12 @@ struct Se3dStage2 {
   se3d_person3d *fused_det;  // [S][H] per detection
   se3d_person3d *pred_det;   // [S][H]
   int32_t *iters_det;        // [S][H]
+  double *obj_det;           // [S][H] final LM objective per detection (0.5 sum ||whitened r||^2 at the published values; -1: the optimisation failed)
   // outputs
   se3d_person3d *fused;   // [S][H] compacted
   se3d_person3d *pred;    // [S][H]
   int32_t *iters;         // [S][H]
+  double *obj;            // [S][H] final LM objective of each published person (se3d_fused_out.lm_objective)
   int32_t *n_out;         // [S]
   uint32_t *flags2;       // [S]
   double *lm_scratch;     // [S][4][1865] HBM Schur workspace of the fused walk's non-forest LM fallback
@@ -201,6 +203,7 @@ struct Se3dShardRec {
   int32_t iters, num_obs;
   uint32_t has;
   uint8_t pub, pad[3];
+  double obj;
 };
 
 // Multi-step stage-2 walk (se3d_run_stage2_walk): step k consumes the stage-1 output of frame slots slot0[k] .. slot0[k]+S-1 and
@@ -218,6 +221,7 @@ struct Se3dWalk {
   const float *fb;             // [B][N]
   se3d_person3d *Wf, *Wp;      // [B][H] fused / predicted persons per frame slot
   int32_t *Wit;                // [B][H] LM iterations
+  double *Wobj;                // [B][H] final LM objectives
   int32_t *Wn;                 // [B] published persons per frame slot
   double *Wdt;                 // [B] pred_delta_t per frame slot
 };

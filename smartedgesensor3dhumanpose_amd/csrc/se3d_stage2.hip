@@ -1037,6 +1037,7 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
   LM_STAMP(0)  // setup
   // ---- LevenbergMarquardtOptimizer(graph, prevEstimate).optimize(), GTSAM 4.0.3 defaults ----
   int iterations = 0;
+  double obj_final = -1.0;   // graph.error(result) of the published values (se3d_fused_out.lm_objective); -1: the optimisation failed
   if (whiten_ok) {
     double error = s2_graph_error(L, L.xc, K, nr, lane);
     double lambda = 1e-5;
@@ -1148,6 +1149,7 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
         if (!isfinite(currentError)) break;
       }
     }
+    obj_final = error;
   } else {
     if (lane < K)
       for (int a = 0; a < 3; ++a) L.xc[lane][a] = L.mm[lane][a];  // optimisation failed: output the measurements (PP:751-758)
@@ -1248,7 +1250,7 @@ __device__ __forceinline__ void s2_lm_body(const Se3dStage2 &Q, int i, int s, in
     const int no = Q.num_obs[sl] + 1;
     Q.num_obs[sl] = no;
     Q.pub[(size_t)s * H + i] = (no > 10) ? (Q.direct_out ? (uint8_t)pubv : 1) : 0;  // g_min_num_obs_track (PP:845-848)
-    if (pubv) Q.iters[(size_t)s * H + pubv - 1] = iterations; else Q.iters_det[(size_t)s * H + i] = iterations;
+    if (pubv) { Q.iters[(size_t)s * H + pubv - 1] = iterations; Q.obj[(size_t)s * H + pubv - 1] = obj_final; } else { Q.iters_det[(size_t)s * H + i] = iterations; Q.obj_det[(size_t)s * H + i] = obj_final; }
   }
   LM_STAMP(6)  // outputs
 #ifdef SE3D_LM_STAMPS
@@ -1289,7 +1291,7 @@ __device__ __forceinline__ void s2_track_update_body(const Se3dStage2 &Q, int s)
     reinterpret_cast<uint32_t *>(&Q.fused[dst])[w] = reinterpret_cast<const uint32_t *>(&Q.fused_det[src])[w];
     reinterpret_cast<uint32_t *>(&Q.pred[dst])[w] = reinterpret_cast<const uint32_t *>(&Q.pred_det[src])[w];
   }
-  if (tid < n_out) Q.iters[(size_t)s * H + tid] = Q.iters_det[(size_t)s * H + srcdet[tid]];
+  if (tid < n_out) { Q.iters[(size_t)s * H + tid] = Q.iters_det[(size_t)s * H + srcdet[tid]]; Q.obj[(size_t)s * H + tid] = Q.obj_det[(size_t)s * H + srcdet[tid]]; }
   __syncthreads();
   s2_remove_old(Q, s, t, wsum, tmp);
   // merge overlapping tracks (PP:870-903): sequential in i, all later j in parallel (track i is not modified by a merge)
@@ -1788,6 +1790,10 @@ __device__ __forceinline__ void s2_lm_trio_body(const Se3dStage2 &Q, int s, int 
 #endif
   }
   if (valid && !wh_ok && measured) { x[0] = m[0]; x[1] = m[1]; x[2] = m[2]; }  // optimisation failed: output the measurements (PP:751-758)
+  if (valid && j == 0) {   // graph.error(result) (se3d_fused_out.lm_objective), stored here so that it is not carried through the output phase
+    const double o = wh_ok ? error : -1.0;
+    if (pubv) Q.obj[(size_t)s * H + pubv - 1] = o; else Q.obj_det[(size_t)s * H + i] = o;
+  }
 
   // ---- Marginals(graph, result): diagonal 3x3 blocks of (J^T J)^-1 at the optimum (PP:760-793), top-down over the forest ----
   const bool use_marg = valid && wh_ok;
@@ -2086,7 +2092,7 @@ __device__ __forceinline__ void s2_track_update_wave(const Se3dStage2 &Q, int s,
       const int w = lane + 64 * q;
       if (w < words) { f1[w] = a[q]; p1[w] = b[q]; }
     }
-    if (lane == 0) Q.iters[dst] = Q.iters_det[src];
+    if (lane == 0) { Q.iters[dst] = Q.iters_det[src]; Q.obj[dst] = Q.obj_det[src]; }
   }
   s2_remove_old_wave(Q, s, t, lane);
   s2_wave_mem_sync();  // order[] / n_tracks / fused[].id written above by other lanes of this wavefront
@@ -2415,7 +2421,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
     Qs.C += (size_t)sb * H * T; Qs.near += g0 * 4; Qs.det_slot += (size_t)sb * H; Qs.pub += (size_t)sb * H;
   }
   Qs.W += (size_t)sb * H * T;
-  Qs.fused_det += (size_t)sb * H; Qs.pred_det += (size_t)sb * H; Qs.iters_det += (size_t)sb * H; Qs.flags2 += sb;
+  Qs.fused_det += (size_t)sb * H; Qs.pred_det += (size_t)sb * H; Qs.iters_det += (size_t)sb * H; Qs.obj_det += (size_t)sb * H; Qs.flags2 += sb;
   const bool par_assoc = WV > 1 && (size_t)H * T * sizeof(double) <= sizeof(WaveLds);  // each association wavefront has its own Munkres scratch
   for (int k = 0; k < Wk.n_steps; ++k) {
     const size_t f0 = (size_t)Wk.slot0[k] + sb;
@@ -2427,6 +2433,7 @@ __global__ __launch_bounds__(64 * WV) __attribute__((amdgpu_waves_per_eu(TRIO ? 
     q.fused = Wk.Wf + f0 * H;
     q.pred = Wk.Wp + f0 * H;
     q.iters = Wk.Wit + f0 * H;
+    q.obj = Wk.Wobj + f0 * H;
     q.n_out = Wk.Wn + f0;
     q.pred_dt = Wk.Wdt + f0;
     q.direct_out = 1;
@@ -2651,7 +2658,7 @@ __global__ __launch_bounds__(64) void se3d_k_shard_pack_lm(Se3dStage2 Q, Se3dSha
   uint32_t *df = reinterpret_cast<uint32_t *>(&rec->fused), *dp = reinterpret_cast<uint32_t *>(&rec->pred);
   for (int k = lane; k < NW; k += 64) { df[k] = sf[k]; dp[k] = sp[k]; }
   const int slot = Q.det_slot[di];
-  if (lane == 0) { rec->iters = Q.iters_det[di]; rec->pub = Q.pub[di]; }
+  if (lane == 0) { rec->iters = Q.iters_det[di]; rec->obj = Q.obj_det[di]; rec->pub = Q.pub[di]; }
   if (slot < 0) return;
   const size_t sl = (size_t)s * Q.T + slot;
   for (int k = lane; k < SE3D_NFU * 3; k += 64) rec->prev[k] = Q.prev[sl * SE3D_NFU * 3 + k];
@@ -2669,7 +2676,7 @@ __global__ __launch_bounds__(64) void se3d_k_shard_unpack_lm(Se3dStage2 Q, const
   uint32_t *df = reinterpret_cast<uint32_t *>(Q.fused_det + di), *dp = reinterpret_cast<uint32_t *>(Q.pred_det + di);
   for (int k = lane; k < NW; k += 64) { df[k] = sf[k]; dp[k] = sp[k]; }
   const int slot = Q.det_slot[di];
-  if (lane == 0) { Q.iters_det[di] = rec->iters; Q.pub[di] = rec->pub; }
+  if (lane == 0) { Q.iters_det[di] = rec->iters; Q.obj_det[di] = rec->obj; Q.pub[di] = rec->pub; }
   if (slot < 0) return;
   const size_t sl = (size_t)s * Q.T + slot;
   for (int k = lane; k < SE3D_NFU * 3; k += 64) Q.prev[sl * SE3D_NFU * 3 + k] = rec->prev[k];

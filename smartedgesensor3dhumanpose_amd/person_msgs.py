@@ -91,7 +91,8 @@ class FrameOut(C.Structure):
 
 class FusedOut(C.Structure):
     _fields_ = [("capacity", C.c_int32), ("n_persons", C.c_int32), ("n_tracks", C.c_int32), ("pred_delta_t", C.c_float),
-                ("fused", C.c_void_p), ("fused_pred", C.c_void_p), ("lm_iterations", C.POINTER(C.c_int32)), ("flags", C.c_uint32)]
+                ("fused", C.c_void_p), ("fused_pred", C.c_void_p), ("lm_iterations", C.POINTER(C.c_int32)), ("flags", C.c_uint32),
+                ("lm_objective", C.POINTER(C.c_double))]
 
 
 class ReprojOut(C.Structure):
@@ -164,7 +165,9 @@ class FusedResult:
         self.fused = np.zeros(capacity, person3d_dt)
         self.fused_pred = np.zeros(capacity, person3d_dt)
         self.lm_iterations = np.zeros(capacity, np.int32)
-        self.c = FusedOut(capacity, 0, 0, 0.0, self.fused.ctypes.data, self.fused_pred.ctypes.data, iptr(self.lm_iterations))
+        self.lm_objective = np.zeros(capacity, np.float64)   # graph.error(result) per published person (se3d_fused_out.lm_objective; -1: optimisation failed)
+        self.c = FusedOut(capacity, 0, 0, 0.0, self.fused.ctypes.data, self.fused_pred.ctypes.data, iptr(self.lm_iterations), 0,
+                          self.lm_objective.ctypes.data_as(C.POINTER(C.c_double)))
 
     @property
     def n_persons(self):

@@ -14,7 +14,10 @@ the library itself with the reference's float32 arithmetic, csrc/se3d_exact32.h)
     reference's bits), after the allowance for what the measured position difference does to the limb-length term (parity.inflation_allowance);
   * stage-2 ids / counts / LM iteration counts identical, refined joints < 1 mm, marginal covariances rtol 1e-4 on every sequence-step of a
     sequence that has not yet seen a garbage person (parity.garbage_persons); from the first such person on the sequence is in the exclusion
-    set (counted), because its LM problem is solver-dependent and the difference lives on in the track state."""
+    set (counted), because its LM problem is solver-dependent and the difference lives on in the track state;
+  * round 5, on EVERY sequence-step (exempt or not): a published person whose refined joints differ by 1 mm or more between the two sides must
+    not have the worse final LM objective on the library's side (parity.compare_stage2_objectives; steps on which the two sides publish
+    different detections are counted as not comparable), and the mismatches INSIDE the exclusion set are bounded by the callers."""
 import os
 
 import numpy as np
@@ -22,7 +25,7 @@ import numpy as np
 from smartedgesensor3dhumanpose_amd import person_msgs as pm
 from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
 from fuzz_scenes import MAX_DET, MAX_HYP, N_SEQ, T_STEPS, draw_trial
-from parity import COV_REL_FRO, DLT_KAPPA_MAX, POS_TOL_M, SCORE_RTOL, compare_stage2, cov_tolerance, garbage_persons, inflation_allowance, published_joint_condition
+from parity import COV_REL_FRO, DLT_KAPPA_MAX, POS_TOL_M, SCORE_RTOL, compare_stage2, compare_stage2_objectives, cov_tolerance, garbage_persons, inflation_allowance, published_joint_condition
 
 W6 = np.array([1, 2, 2, 1, 2, 1.0])
 
@@ -31,7 +34,8 @@ def new_report(seed):
     return dict(seed=seed, trials=0, frames=0, frames_hyp_overflow=0, persons=0, joints=0, joints_excluded=0, joints_second_pass=0, ill_joints=0, ill_not_listed=0,
                 joints_over_1mm=0, pos_max_mm=0.0, scores_over_rtol=0, cov_over_tol=0, cov_rel_max=0.0, cov_nan=0, **{"cov_over_flat_1e-3": 0},
                 seq_steps=0, seq_steps_track_overflow=0, seq_steps_excluded=0, stage2_numeric_failures=0, stage2_index_divergences=0,
-                excluded_stage2_mismatches=0, violations=[])
+                excluded_stage2_mismatches=0, objective_persons=0, objective_disagree=0, objective_worse=0, objective_worst_excess=0.0, objective_not_comparable_steps=0,
+                violations=[])
 
 
 def dlt_condition_own(rig, frame, result):
@@ -141,6 +145,18 @@ def run_trials(O, seed, trials, walk_mode="wave", pose_method="simple", norm_hei
                 o2 = oras[s].step(dets, rig.n_cam, t, seqs[s][k].fb_delay, capacity=MAX_HYP)
                 if tainted[s]:
                     rep["seq_steps_excluded"] += 1
+                # EVERY sequence-step, exempt or not (round 5): where the two sides publish different joints, the library's optimum must not be the
+                # worse one by the factor graph's own objective (parity.compare_stage2_objectives)
+                oc = compare_stage2_objectives(ra[s], o2)
+                if oc["comparable"]:
+                    rep["objective_persons"] += oc["persons"]
+                    rep["objective_disagree"] += oc["disagree"]
+                    rep["objective_worse"] += oc["worse"]
+                    rep["objective_worst_excess"] = max(rep["objective_worst_excess"], oc["worst_excess"])
+                    if oc["worse"]:
+                        rep["violations"].append(dict(trial=trial, step=k, seq=s, objective_worse=oc["worse"], excess=oc["worst_excess"], tainted=tainted[s]))
+                else:
+                    rep["objective_not_comparable_steps"] += 1
                 try:
                     compare_stage2(ra[s], o2, check_tracks=(k == T_STEPS - 1))
                 except AssertionError as e:

@@ -37,6 +37,10 @@ def test_random_scenes_match_the_oracle_on_every_joint(oracle, seed, pose_method
     # stage 2, every sequence-step outside the exclusion set
     assert rep["stage2_index_divergences"] == 0 and rep["stage2_numeric_failures"] == 0, viol[:5]
     assert rep["seq_steps_excluded"] <= 0.15 * rep["seq_steps"], rep
+    # ... and on EVERY sequence-step, exempt or not: where the published joints differ, the library's final LM objective is not the worse one
+    assert rep["objective_worse"] == 0, viol[:5]
+    # inside the exclusion set the two sides actually differ on a small part of the steps only
+    assert rep["excluded_stage2_mismatches"] <= max(1, 0.02 * rep["seq_steps_excluded"]), rep
 
 
 def test_large_rig_scenes_match_the_oracle_on_every_joint():
@@ -54,3 +58,8 @@ def test_large_rig_scenes_match_the_oracle_on_every_joint():
     assert rep["joints_over_1mm"] == 0 and rep["scores_over_rtol"] == 0 and rep["cov_over_tol"] == 0
     assert rep["joints_excluded"] == 0 and rep["ill_not_listed"] == 0
     assert rep["stage2_index_divergences"] == 0 and rep["stage2_numeric_failures"] == 0
+    # the exempt share of this run (one garbage joint among ~400 per frame taints its sequence: 40 of 48 steps in round 4) and what differs inside it
+    print("large rigs: %d of %d sequence-steps exempt, %d mismatches inside the exempt set, %d persons with different joints, of them with the worse objective: %d"
+          % (rep["seq_steps_excluded"], rep["seq_steps"], rep["excluded_stage2_mismatches"], rep["objective_disagree"], rep["objective_worse"]))
+    assert rep["seq_steps_excluded"] <= 44 and rep["objective_worse"] == 0
+    assert rep["excluded_stage2_mismatches"] <= max(1, 0.05 * rep["seq_steps_excluded"]), rep

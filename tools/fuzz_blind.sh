@@ -1,7 +1,7 @@
 #!/bin/bash
 # Blind check of the randomised parity sweep (GPU box): seeds never run before the criteria were frozen (commit 929e612), reported unedited.
 #   bash tools/fuzz_blind.sh [out] [base]   100 runs from seed base + 1 (default base 2000; 3000: the second batch, after the scores became
-#   bit-equal): 70 x default, 10 x h36m, 10 x norm_height (40 scenes each), 10 x large rigs (20 scenes)
+#   bit-equal; 5000: round 5, with the stage-2 objective criterion on every sequence-step, criteria frozen at the commit that added it): 70 x default, 10 x h36m, 10 x norm_height (40 scenes each), 10 x large rigs (20 scenes)
 OUT=${1:-gpurun_out/fuzz_blind.log}
 B=${2:-2000}
 mkdir -p "$(dirname "$OUT")"
@@ -13,8 +13,11 @@ for s in $(seq $((B+91)) $((B+100))); do FUZZ_LARGE=1 timeout 600 python tools/f
 python3 - "$OUT" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
-bad = [r["seed"] for r in rows if r["joints_over_1mm"] or r["scores_over_rtol"] or r["cov_over_tol"] or r["ill_not_listed"] or r["stage2_numeric_failures"] or r["stage2_index_divergences"]]
+bad = [r["seed"] for r in rows if r["joints_over_1mm"] or r["scores_over_rtol"] or r["cov_over_tol"] or r["ill_not_listed"] or r["stage2_numeric_failures"] or r["stage2_index_divergences"] or r.get("objective_worse", 0)]
 tot = lambda k: sum(r[k] for r in rows)
+print("stage 2 on EVERY sequence-step (round 5): %d published persons compared, %d with joints >= 1 mm apart, of them with the WORSE objective on the library's side: %d (worst excess %.3g); steps not comparable (different detections published): %d; mismatches inside the exclusion set: %d of %d exempt steps (%.2f %%)"
+      % (tot("objective_persons"), tot("objective_disagree"), tot("objective_worse"), max(r.get("objective_worst_excess", 0.0) for r in rows), tot("objective_not_comparable_steps"),
+         tot("excluded_stage2_mismatches"), tot("seq_steps_excluded"), 100.0 * tot("excluded_stage2_mismatches") / max(1, tot("seq_steps_excluded"))))
 print("runs %d, joints %d (excluded %d; second pass %d; input-derived kappa >= 2e3: %d, of them not listed %d), over 1 mm %d (worst %.4f mm), scores %d, covariances %d (over the flat 1e-3: %d, worst %.2e), sequence-steps %d (excluded %d), stage-2 numeric %d, index %d; runs with a miss: %s"
       % (len(rows), tot("joints"), tot("joints_excluded"), tot("joints_second_pass"), tot("ill_joints"), tot("ill_not_listed"), tot("joints_over_1mm"), max(r["pos_max_mm"] for r in rows), tot("scores_over_rtol"), tot("cov_over_tol"), tot("cov_over_flat_1e-3"),
          max(r["cov_rel_max"] for r in rows), tot("seq_steps"), tot("seq_steps_excluded"), tot("stage2_numeric_failures"), tot("stage2_index_divergences"), bad))
