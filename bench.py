@@ -860,6 +860,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-only", action="store_true", help="only the B = 1 latency block (one 16cam6p frame per call), printed as its own JSON line")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity / latency blocks of a default run")
+    ap.add_argument("--exchange-backend", default="nccl", choices=["nccl", "gloo-staged"], help="nccl (= RCCL over xGMI, default) | gloo-staged: TEST ONLY — device "
+                    "buffers staged through host memory and exchanged by gloo, so that the N > 1 code path can run with several ranks on one GPU")
     ap.add_argument("--hi-streams", action="store_true", help="keep the second (high-priority) stream of large-rig contexts also with more than four contexts per GPU")
     ap.add_argument("--exchange-slots", action="store_true", help="diagnostic: exchange the small workloads in the [frame][slot] form instead of the dense form")
     ap.add_argument("--no-chain", action="store_true", help="diagnostic: do not chain the pair kernels of the contexts by events at 256 cameras")
@@ -922,9 +924,17 @@ def main():
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: exercises the exchange path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        if args.exchange_backend == "gloo-staged":   # TEST ONLY: several ranks on one GPU (RCCL refuses that): shard.HostStagedDist
+            from smartedgesensor3dhumanpose_amd.shard import HostStagedDist
+            local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+            assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+            dist = HostStagedDist(dist)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
 

@@ -201,8 +201,8 @@ typedef struct se3d_ctx se3d_ctx;
 int se3d_rig_from_transforms(int32_t n_cam, const double *T_base_to_cam, float *Rt_out, float *F_out);
 
 /* --- context ------------------------------------------------------------------------------------------- */
-/* Stream semantics: a context works on its own non-blocking HIP stream (se3d_stream_handle).  One exception: with SE3D_RESERVE_CUS > 0 (or
- * a rig of >= 128 cameras run with SE3D_PAIR_CHUNKS=0) the stream is created by hipExtStreamCreateWithCUMask, which yields a BLOCKING stream:
+/* Stream semantics: a context works on its own non-blocking HIP stream (se3d_stream_handle).  One exception: with options.reserve_cus > 0 (or
+ * a rig of >= 128 cameras run with options.pair_chunks = -1) the stream is created by hipExtStreamCreateWithCUMask, which yields a BLOCKING stream:
  * work on the legacy null stream (plain hipMemcpy, a torch op on the default stream) then synchronises with it — keep such work out of
  * timed regions. */
 se3d_ctx *se3d_create(const se3d_rig *rig, const se3d_params *params, const se3d_limits *limits, int32_t device_id);
@@ -226,7 +226,7 @@ const char *se3d_version(void);
 /* --- stage 1: drop-in for triangulate_persons (S3D:525-997) ------------------------------------------- */
 /* one frame, synchronous (host in, host out).  On a context with limits.max_frames == 1 — one synchronised frame per callback, the reference's
  * operating point (S3D:1069) — the call replays ONE hipGraph (upload, kernel chain, download) captured on first use; the same holds for
- * se3d_refine on such a context (PP:505).  Environment SE3D_GRAPH=0 or se3d_profile_enable(ctx, 1) select direct launches. */
+ * se3d_refine on such a context (PP:505).  options.graph = -1 or se3d_profile_enable(ctx, 1) select direct launches. */
 int se3d_triangulate(se3d_ctx *ctx, const se3d_frame_in *frame, se3d_frame_out *out);
 /* B frames, synchronous */
 int se3d_triangulate_batch(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in *frames, se3d_frame_out *outs);

@@ -8,6 +8,62 @@ import torch
 from . import person_msgs as pm
 
 
+class HostStagedDist:
+    """TEST-ONLY collective backend with the interface this module and bench.py use of torch.distributed, for running the N > 1 code path with
+    several ranks on ONE GPU (RCCL refuses two ranks on one device): device tensors are staged through host memory and exchanged by a gloo
+    process group.  Ordering as with RCCL: a collective is enqueued "on the current stream" — the stream is drained first (what it enqueued
+    before is complete), the result is copied back on it, and the returned work's wait() makes the caller's current stream wait for that copy.
+    Nothing about its speed means anything; `get_backend()` says what it is."""
+
+    class _Work:
+        def __init__(self, event):
+            self.event = event
+
+        def wait(self):
+            if self.event is not None:
+                torch.cuda.current_stream().wait_event(self.event)
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def get_world_size(self):
+        return self._d.get_world_size()
+
+    def get_rank(self):
+        return self._d.get_rank()
+
+    def get_backend(self):
+        return "gloo, device buffers staged through host memory (test only)"
+
+    def barrier(self):
+        self._d.barrier()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+    def _staged(self, fn, out, inp, async_op):
+        if not inp.is_cuda:
+            fn(out, inp)
+            return self._Work(None) if async_op else None
+        st = torch.cuda.current_stream()
+        st.synchronize()
+        h_in, h_out = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
+        fn(h_out, h_in)
+        out.copy_(h_out, non_blocking=False)
+        ev = st.record_event()
+        return self._Work(ev) if async_op else None
+
+    def all_gather_into_tensor(self, out, inp, async_op=False):
+        return self._staged(lambda o, i: self._d.all_gather_into_tensor(o, i), out, inp, async_op)
+
+    def all_reduce(self, t, op=None):
+        def fn(o, i):
+            o.copy_(i)
+            self._d.all_reduce(o, **({} if op is None else {"op": op}))
+        self._staged(fn, t, t, False)
+
+
 def rank_sequences(n_total, rank, world):
     """Sequence ids owned by `rank`: round-robin (sequence s lives on rank s % world; tracks never migrate)."""
     return list(range(rank, n_total, world))
