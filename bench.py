@@ -420,8 +420,6 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
     for nd_ in nodes:    # HIP-event kernel timing on every context's own stream
         nd_.profile(True)
         nd_.profile_reset()
-    if ex is not None:
-        ex.timed(True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -443,8 +441,6 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
     exchange_ms = dt_nx = None
     if ex is not None:
         ex.finish()
-        exchange_ms = ex.exchange_ms()
-        ex.timed(False)
     exchange_ok = None
     if ex is not None and verify_exchange:   # every rank's gathered buffer == concatenation of all ranks' packs (last timed step)
         ok = torch.tensor([1 if ex.verify(last_parity) else 0], dtype=torch.int32, device="cuda")
@@ -468,6 +464,19 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         tnx = torch.tensor([dt_nx], dtype=torch.float64, device="cuda")
         dist.all_reduce(tnx, op=dist.ReduceOp.MAX)
         dt_nx = float(tnx.item())
+        # ... and the all-gather's own duration, stamped with events on the exchange stream in a pass of its own (the stamps add
+        # event records and device-side waits, which do not belong into the headline's timed region)
+        ex.timed(True)
+        dist.barrier()
+        for _ in range(steps_nx):
+            step()
+        for nd_ in nodes:
+            nd_.sync()
+        torch.cuda.synchronize()
+        ex.finish()
+        exchange_ms = ex.exchange_ms()
+        ex.timed(False)
+        dist.barrier()
     # untimed accounting pass: published skeletons of one (steady-state) step
     s1 = [r for nd_ in nodes for r in nd_.fetch_stage1(B)]
     n_s1 = sum(r.n_persons for r in s1)
@@ -994,14 +1003,21 @@ def main():
         hyp, hyp_error, hyp_hung = guarded(hyp_run, args.hyp_deadline_s, "hypothesis shard")
     if rank == 0:
         main_res = head or serial
-        def load(fn):   # committed counter summaries: this round's when present, else the previous round's
-            for rd in ("r4", "r3", "r2"):
+        def load(fn):   # committed counter summaries of THIS build: the kernels' instruction counts are properties of the code, so a summary is used only
+            # when it carries the fingerprint of the kernel sources it was collected on (tools/pmc_sq.py, _lib.source_hash) — else the
+            # line says which file was skipped and falls back to the model figures
+            from smartedgesensor3dhumanpose_amd._lib import source_hash
+            for rd in ("r5", "r4", "r3", "r2"):
                 p = os.path.join(ROOT, "profiles", rd, fn)
                 if os.path.exists(p):
                     d = json.load(open(p))
                     d["_file"] = "profiles/%s/%s" % (rd, fn)
+                    if d.get("source_hash") != source_hash():
+                        stale_pmc.append(d["_file"])
+                        return None
                     return d
             return None
+        stale_pmc = []
         roof_src = serial or head
         roof = roofline_of(roof_src, w, stage2, "serial pass: one context, one stream, %d sequences x %d frames (%.0f skeletons/s alone)"
                            % (roof_src["S"], roof_src["T"], roof_src["value"]) if serial else "overlapped contexts (no serial pass in this run)")
@@ -1021,10 +1037,11 @@ def main():
                        "n_cam": w["n_cam"], "n_persons": w["n_persons"], "n_joints": 17, "frames_per_step": main_res["NC"] * main_res["B"],
                        "contexts_per_gpu": main_res["NC"], "max_hypotheses_per_frame": main_res["max_hyp_per_frame"],
                        "max_published_per_frame": main_res["max_published_per_frame"], "scene_generation_s": round(t_gen, 1),
-                       "sharding": ("independent sequences per rank + RCCL all-gather of final skeletons (verified: %s)" % main_res["exchange_verified"]
+                       "sharding": ("independent sequences per rank + %s all-gather of final skeletons (verified: %s)" % ("RCCL" if args.exchange_backend == "nccl" else "gloo-staged (test-only)", main_res["exchange_verified"])
                                     if dist is not None else "single GPU"),
                        "exchange": main_res.get("exchange")},
             "roofline": roof,
+            "pmc_summaries_skipped": stale_pmc,   # committed counter summaries collected on OTHER kernel sources than this build's (not used)
             "second_pass": {"joints_per_launch": main_res["second_pass_joints"], "per_published_joint": round(main_res["second_pass_fraction"], 6),
                             "note": "joints the fast fp64 triangulation handed to se3d_k_triangulate_exact (the reference's float32 JacobiSVD arithmetic, "
                                     "bit-identical to the oracle): ill-conditioned systems, reprojection errors near / above the outlier threshold, wide covariances; "
@@ -1041,7 +1058,7 @@ def main():
             line["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                   "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
                                   "note": "exchange_ms_per_step = mean device time of the step's all-gather pair on its own stream (it overlaps the next step's "
-                                          "kernels); value_no_exchange = the same steps with the all-gather skipped, %d extra steps" % max(2, main_res["steps"] // 4)}
+                                          "kernels), stamped in a pass of its own of %d steps; value_no_exchange = the same steps with the all-gather skipped, %d extra steps" % (max(2, main_res["steps"] // 4), max(2, main_res["steps"] // 4))}
         if head is not None:
             line["overlapped_kernel_ms_per_step"] = {k: round(v, 5) for k, v in head["kernel_ms_per_step"].items()}
         if serial is not None and head is not None:

@@ -20,6 +20,18 @@ EXPORTS = [
 ]
 
 
+def source_hash():
+    """Fingerprint of the kernel sources (csrc/*.hip, *.h, include/se3d.h): 16 hex digits.  tools/pmc_sq.py stamps the counter summaries it writes with
+    it and bench.py uses a committed summary only when it matches (instruction counts are properties of the code they were collected on)."""
+    import hashlib
+    src_dir = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h"))) + [os.path.join(_HERE, "..", "include", "se3d.h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")

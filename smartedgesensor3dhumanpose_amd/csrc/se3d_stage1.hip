@@ -206,10 +206,12 @@ __global__ __launch_bounds__(256) void se3d_k_pairs_flat(Se3dDev D, const int2 *
 // within 1.5 x 2^-53 ulp of the quotient, while acc / n keeps a distance of at least ulp / (2 n) from every rounding boundary (acc - n m is a
 // non-zero multiple of ulp / 2 for a midpoint m): the final rounding is the quotient's for every n < 2^50 (Markstein 1990; Thm. 8.5 in Muller
 // et al., "Handbook of Floating-Point Arithmetic"); tests/test_markstein64.py checks it against IEEE division on the CPU.
+// An infinite (or NaN) accumulator — a degenerate epipolar line, norm 0 — keeps IEEE division's result: inf - inf inside the residual would
+// turn acc = inf into NaN where acc / n, the reference and the flat kernel give inf.
 __device__ __forceinline__ double se3d_div_count(double acc, int n, double inv_n) {
   const double q0 = acc * inv_n;
   const double r = __fma_rn(-(double)n, q0, acc);
-  return __fma_rn(r, inv_n, q0);
+  return __builtin_isfinite(q0) ? __fma_rn(r, inv_n, q0) : q0;
 }
 
 #define NP_MAX_DETS 256

@@ -13,6 +13,8 @@ def _fma(a, b, c):
 def _div_count(acc, n):
     y = 1.0 / n
     q0 = acc * y
+    if not np.isfinite(q0):   # the device returns q0 for a non-finite accumulator (inf - inf in the residual would make it NaN)
+        return q0
     r = _fma(-float(n), q0, acc)
     return _fma(r, y, q0)
 
@@ -44,4 +46,14 @@ def test_count_divide_for_the_sweeps_view_counts_and_near_rounding_boundaries():
             a0 = float(mid * n)
             acc += [a0, float(np.nextafter(a0, np.inf)), float(np.nextafter(a0, -np.inf))]
         for a in acc:
+            assert _div_count(a, n) == a / n, (a, n)
+
+
+def test_count_divide_keeps_infinite_and_huge_accumulators():
+    """A degenerate epipolar line (norm 0) makes a distance, hence the accumulator, infinite: IEEE division keeps inf, and so must the device's
+    three-operation form (the unguarded residual gave NaN); NaN stays NaN; accumulators next to the overflow threshold divide exactly."""
+    for n in (1, 2, 3, 7, 16, 17, 64):
+        assert _div_count(float("inf"), n) == float("inf")
+        assert np.isnan(_div_count(float("nan"), n))
+        for a in (1.7e308, 8.9e307, 1e300, 2.0 ** 1023):
             assert _div_count(a, n) == a / n, (a, n)

@@ -69,5 +69,8 @@ for k in sorted(tot):
     if us > 0 and c.get("GRBM_GUI_ACTIVE"):
         e["effective_clock_ghz"] = round(cycles / (us * 1e-6) / 1e9, 3)
     res["kernels"][k] = e
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from smartedgesensor3dhumanpose_amd._lib import source_hash  # noqa: E402
+res["source_hash"] = source_hash()   # the kernel sources these counts were collected on (bench.py uses the summary only for the same sources)
 json.dump(res, open(out_json, "w"), indent=1)
 print(json.dumps({k: {a: b for a, b in v.items() if a != "counters_per_launch"} for k, v in res["kernels"].items()}, indent=1))

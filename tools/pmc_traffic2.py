@@ -51,5 +51,8 @@ for k in sorted(set(ft) | set(wt)):
     res["kernels"][k] = {"fetch_size_kb_per_launch": round(f, 1), "write_size_kb_per_launch": round(w_, 1), "launches_sampled": int(fc.get(k, 0)),
                          "hbm_bytes_per_launch_corrected": b}
 res["pipeline_bytes_per_step_corrected"] = total
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from smartedgesensor3dhumanpose_amd._lib import source_hash  # noqa: E402
+res["source_hash"] = source_hash()   # the kernel sources these counts were collected on (bench.py uses the summary only for the same sources)
 json.dump(res, open(out_json, "w"), indent=1)
 print(json.dumps({k: v["hbm_bytes_per_launch_corrected"] for k, v in res["kernels"].items()}), total)
