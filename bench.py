@@ -636,7 +636,7 @@ def bench_dlt(args):
     print(json.dumps(line), flush=True)
 
 
-def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank):
+def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out=0):
     """PCIe-inclusive rate (never `value`): every step each context receives its batch of frames from HOST memory (se3d_stream_submit:
     ragged payload into pinned memory, H2D on a copy stream, expansion on the device, stage 1, stage-2 walk, device compaction of the
     published persons, D2H) and hands the published fused / predicted persons back in host memory (se3d_stream_collect); two batches per
@@ -650,7 +650,7 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank):
     in_bytes = 0
     for seqs in seqs_per_ctx:
         frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
-        nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank)
+        nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank, options=dict(stream_out=stream_out))
         nd_.refine_reset()
         nodes.append(nd_)
         prepared.append(nd_.stream_prepare(frames))
@@ -865,6 +865,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the 256cam128p secondary measurement of a default run")
     ap.add_argument("--no-serial", action="store_true", help="skip the serial per-kernel pass of a default run")
     ap.add_argument("--no-streaming", action="store_true", help="skip the PCIe-inclusive streaming measurement (value_streaming) of a default run")
+    ap.add_argument("--stream-out", type=int, default=0, choices=[0, 1], help="se3d_options.stream_out of the streaming measurement: 0 = device buffers + D2H copies (default), "
+                    "1 = the compaction kernel writes the published persons into pinned host memory")
     ap.add_argument("--stream-contexts", type=int, default=8, help="contexts of the streaming measurement (each pins two batches of host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-only", action="store_true", help="only the B = 1 latency block (one 16cam6p frame per call), printed as its own JSON line")
@@ -988,7 +990,7 @@ def main():
         run_secondary()
     streaming = None
     if default_run and not args.no_streaming and stage2 and rank == 0:
-        streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps // 2), 2, local_rank)
+        streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps // 2), 2, local_rank, args.stream_out)
     # ---- latency mode of north_star config 5, LAST and guarded: one 256cam128p stream with its hypotheses sharded over the ranks.  Every
     # measurement of the line above is already taken; an exception here is reported in the block, and a collective that does not return
     # within the deadline (ranks != 0 wait in it while rank 0 runs its serial / streaming passes: minutes at most) ends the run with the

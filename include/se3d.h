@@ -123,7 +123,10 @@ typedef struct se3d_options {
   int32_t refine_steps;       /* se3d_refine on a one-sequence context: 0 = one fused-walk launch (default), 1 = the five per-step launches */
   int32_t munkres_form;       /* se3d_hungarian: SE3D_MUNKRES_AUTO | _BLOCK | _WAVE */
   int32_t reproj_form;        /* feedback reprojection: 0 = per-camera lists written directly where they fit LDS (default), 1 = dense + scan + compaction */
-  int32_t reserved[7];        /* must be 0 */
+  int32_t stream_out;         /* se3d_stream_submit / _collect: 0 = device buffers + D2H copies on the slot's own stream (default), 1 = the compaction kernel
+                                 writes the published persons straight into the pinned host buffers (no copy engine, no host round trip for the size;
+                                 measured equal in round 5: the H2D direction bounds the streaming rate, profiles/r5/README.md) */
+  int32_t reserved[6];        /* must be 0 */
 } se3d_options;
 #define SE3D_WALK_WAVE 1
 #define SE3D_WALK_WG 2

@@ -18,7 +18,9 @@ __global__ __launch_bounds__(128) void se3d_k_stream_scatter(Se3dDev D, const se
 
 // Published persons of a walk, compacted: exclusive prefix of the per-frame-slot counts (one workgroup), then one wavefront per frame
 // slot copies its persons (fused and predicted) to their place in the dense arrays.
-__global__ __launch_bounds__(1024) void se3d_k_stream_scan(const int32_t *__restrict__ n_out, int32_t *__restrict__ out_off, int n_frames, int cap) {
+// mirror (optional): a second copy of the offsets — the slot's pinned HOST buffer when the persons are written there directly (the gather kernel
+// reads the device copy: reads over PCIe are round trips)
+__global__ __launch_bounds__(1024) void se3d_k_stream_scan(const int32_t *__restrict__ n_out, int32_t *__restrict__ out_off, int32_t *__restrict__ mirror, int n_frames, int cap) {
   __shared__ int part[16];
   __shared__ int s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -33,12 +35,12 @@ __global__ __launch_bounds__(1024) void se3d_k_stream_scan(const int32_t *__rest
     __syncthreads();
     int offw = s_carry;
     for (int w = 0; w < wave; ++w) offw += part[w];
-    if (i < n_frames) out_off[i] = offw + inc - v;
+    if (i < n_frames) { out_off[i] = offw + inc - v; if (mirror) mirror[i] = offw + inc - v; }
     __syncthreads();
     if (tid == 1023) s_carry = offw + inc;
     __syncthreads();
   }
-  if (tid == 0) out_off[n_frames] = s_carry;
+  if (tid == 0) { out_off[n_frames] = s_carry; if (mirror) mirror[n_frames] = s_carry; }
 }
 
 __global__ __launch_bounds__(64) void se3d_k_stream_gather(const se3d_person3d *__restrict__ fused, const se3d_person3d *__restrict__ pred, const int32_t *__restrict__ out_off,
@@ -55,8 +57,8 @@ extern "C" void se3d_launch_stream_scatter(const Se3dDev &D, const se3d_person2d
   hipLaunchKernelGGL(se3d_k_stream_scatter, dim3(D.d.N, D.d.B), dim3(128), 0, st, D, rag, off);
 }
 extern "C" void se3d_launch_stream_compact(const se3d_person3d *fused, const se3d_person3d *pred, const int32_t *n_out, int n_frames, int H, int32_t *out_off,
-                                           se3d_person3d *dense_fused, se3d_person3d *dense_pred, hipStream_t st) {
-  hipLaunchKernelGGL(se3d_k_stream_scan, dim3(1), dim3(1024), 0, st, n_out, out_off, n_frames, H);
+                                           int32_t *out_off_mirror, se3d_person3d *dense_fused, se3d_person3d *dense_pred, hipStream_t st) {
+  hipLaunchKernelGGL(se3d_k_stream_scan, dim3(1), dim3(1024), 0, st, n_out, out_off, out_off_mirror, n_frames, H);
   hipLaunchKernelGGL(se3d_k_stream_gather, dim3(n_frames), dim3(64), 0, st, fused, pred, out_off, H, dense_fused, dense_pred);
 }
 

@@ -46,7 +46,7 @@ class Options(C.Structure):
     """se3d_options (include/se3d.h): all zero = the library's defaults.  Symbolic values: the tables below."""
     _fields_ = [(n, C.c_int32) for n in ("pair_chunks", "hi_priority_stream", "reserve_cus", "graph", "walk_shape", "sweep_lds_kb",
                                          "pairs_form", "sweep_form", "tri_form", "post_form", "lm_form", "walk_form", "walk_lm", "walk_book",
-                                         "refine_steps", "munkres_form", "reproj_form")] + [("reserved", C.c_int32 * 7)]
+                                         "refine_steps", "munkres_form", "reproj_form", "stream_out")] + [("reserved", C.c_int32 * 6)]
 
 
 OPTION_VALUES = {   # names of the SE3D_* constants of include/se3d.h

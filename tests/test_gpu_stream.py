@@ -14,10 +14,11 @@ def _node(rig, **kw):
     return Skeleton3D(rig, max_epi_dist=0.045, **kw)
 
 
-def test_streaming_equals_resident(extr_rig):
+@pytest.mark.parametrize("stream_out", [0, 1])   # 0: device buffers + D2H copies (default), 1: the compaction kernel writes the pinned host buffers
+def test_streaming_equals_resident(extr_rig, stream_out):
     S_, T_, n_batches = 6, 16, 5
     seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=3 + s % 4, n_frames=T_ * n_batches, seed=900 + s, p_miss=0.05 * (s % 3)))[0] for s in range(S_)]
-    res, stream = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12), _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12)
+    res, stream = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12), _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12, options=dict(stream_out=stream_out))
     res.refine_reset()
     stream.refine_reset()
     slots = [k * S_ for k in range(T_)]
