@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -121,11 +122,10 @@ struct se3d_ctx {
     int32_t *d_out_off = nullptr, *h_out_off = nullptr; // [B + 1]
     float *h_fb = nullptr, *d_fb = nullptr;             // [B][N] fb_delay of the batch (per slot: batch k + 1 is copied while batch k walks)
     hipEvent_t in_done = nullptr, compute_done = nullptr, off_done = nullptr;
-    hipStream_t s_out = nullptr;                        // the slot's OWN D2H stream: collect(k) never queues behind compute_done(k + 1)
     int n_frames = 0;
     bool busy = false;
   } ss[2];
-  hipStream_t s_h2d = nullptr;
+  hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // the DEVICE's shared upload / download streams (shared_copy_stream): not owned by the context
   bool dry = false;          // dev_alloc only counts (se3d_device_bytes)
   size_t dry_bytes = 0;
   bool stream_ready = false;
@@ -671,9 +671,7 @@ void se3d_destroy(se3d_ctx *c) {
     if (sl.compute_done) (void)hipEventDestroy(sl.compute_done);
     if (sl.off_done) (void)hipEventDestroy(sl.off_done);
   }
-  if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
   for (auto &sl : c->ss)
-    if (sl.s_out) (void)hipStreamDestroy(sl.s_out);
   for (auto &set : c->ev2)
     for (auto &e : set)
       if (e) (void)hipEventDestroy(e);
@@ -1358,12 +1356,29 @@ int se3d_run_stage2_shard_post(se3d_ctx *c, int32_t n_seq, const void *d_gathere
 }
 
 // ---- streaming ingest: ragged pinned H2D -> device expansion -> stage 1 -> walk -> device compaction -> D2H of the published persons ----
+// ONE upload stream per device, shared by every context of the process (round 5).  tools/microbench/pcie_bw_multi.hip on the box: H2D alone
+// 57.5 GB/s on any number of streams; H2D + D2H at once 56.5 + 45.5 GB/s with ONE stream per direction but 37 - 43 + 30 - 34 GB/s with two
+// or more streams per direction (copies of both directions interleave on the same engines) — which is what eight contexts with a copy stream
+// each produced (32 - 34.5 GB/s H2D whatever the number of contexts).  Uploads have no device-side dependency (a slot is reused only after its
+// batch was collected), so a shared FIFO cannot block; it lives as long as the process.
+// The download direction likewise: ONE shared stream per device.  A download waits for its batch's kernels; enqueued with a device-side wait it
+// would block every other context's download behind it, so se3d_stream_collect waits for the batch on the HOST (compute_done), reads the number of
+// published persons from the offsets the scan kernel mirrored into pinned memory, and only then enqueues the two copies.
+static hipStream_t shared_copy_stream(int device, int dir /* 0: H2D, 1: D2H */) {
+  static std::mutex mu;
+  static hipStream_t streams[2][64] = {};
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0 || device >= 64) return nullptr;
+  if (!streams[dir][device] && hipStreamCreateWithFlags(&streams[dir][device], hipStreamNonBlocking) != hipSuccess) streams[dir][device] = nullptr;
+  return streams[dir][device];
+}
 static int stream_init(se3d_ctx *c) {
   if (c->stream_ready) return SE3D_OK;
   const size_t B = c->D.d.B, N = c->D.d.N, P = c->D.d.P, H = c->D.d.H;
-  HIPCHK(c, hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
+  c->s_h2d = shared_copy_stream(c->device, 0);
+  c->s_d2h = shared_copy_stream(c->device, 1);
+  if (!c->s_h2d || !c->s_d2h) { c->err = "se3d_stream_submit: no copy stream"; return SE3D_ERR_DEVICE; }
   for (auto &sl : c->ss) {
-    HIPCHK(c, hipStreamCreateWithFlags(&sl.s_out, hipStreamNonBlocking));
     HIPCHK(c, hipHostMalloc((void **)&sl.h_rag, sizeof(se3d_person2d) * B * N * P, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void **)&sl.h_off, sizeof(int32_t) * B * (N + 1), hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void **)&sl.h_fused, sizeof(se3d_person3d) * B * H, hipHostMallocDefault));
@@ -1440,21 +1455,15 @@ int se3d_stream_submit(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frame
   rc = se3d_run_stage2_walk(c, n_seq, n_steps, frame_slot0, t);
   c->d_fb_walk = nullptr;
   if (rc != SE3D_OK) return rc;
-  // Published persons back to the host: device buffers + D2H copies on the slot's own stream (default), or (options.stream_out = 1, round 5) the
-  // compaction kernel WRITES them, and the offsets, straight into the slot's pinned host buffers (posted PCIe writes from the shader; the kernel's
-  // end releases them at system scope, the host waits for compute_done): no copy engine for the D2H direction, no host round trip to learn the
-  // size of the copy.  Measured equal (7.68 vs 7.73 M skeletons/s on one box): the H2D direction bounds the rate (profiles/r5/README.md section 4).
+  // Published persons back to the host.  The scan kernel mirrors the offsets into the slot's pinned buffer (a few KB of posted PCIe writes), so the
+  // host knows the size without a copy + round trip.  Default: se3d_stream_collect downloads the persons on the device's shared download stream.
+  // options.stream_out = 1: the compaction kernel WRITES the persons straight into the pinned host buffers (posted PCIe writes from the shader; the
+  // kernel's end releases them at system scope): no copy engine at all — measured slower than the shared download stream (~28 GB/s of shader writes).
   sl.direct = c->opt.stream_out == 1;
   if (sl.direct) se3d_launch_stream_compact(c->Q.fused, c->Q.pred, c->Q.n_out, n_frames, c->Q.H, sl.d_out_off, sl.hd_out_off, sl.hd_fused, sl.hd_pred, c->stream);
-  else se3d_launch_stream_compact(c->Q.fused, c->Q.pred, c->Q.n_out, n_frames, c->Q.H, sl.d_out_off, nullptr, sl.d_fused, sl.d_pred, c->stream);
+  else se3d_launch_stream_compact(c->Q.fused, c->Q.pred, c->Q.n_out, n_frames, c->Q.H, sl.d_out_off, sl.hd_out_off, sl.d_fused, sl.d_pred, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(sl.compute_done, c->stream));
-  if (!sl.direct) {
-    // ---- D2H stream: the offsets first (the host needs the total before it can size the copy of the persons) ----
-    HIPCHK(c, hipStreamWaitEvent(sl.s_out, sl.compute_done, 0));
-    HIPCHK(c, hipMemcpyAsync(sl.h_out_off, sl.d_out_off, sizeof(int32_t) * (size_t)(n_frames + 1), hipMemcpyDeviceToHost, sl.s_out));
-    HIPCHK(c, hipEventRecord(sl.off_done, sl.s_out));
-  }
   sl.n_frames = n_frames;
   sl.busy = true;
   c->ss_head ^= 1;
@@ -1466,18 +1475,13 @@ int se3d_stream_collect(se3d_ctx *c, se3d_stream_result *out) {
   se3d_ctx::StreamSlot &sl = c->ss[c->ss_tail];
   if (!c->stream_ready || !sl.busy) { c->err = "se3d_stream_collect: no batch in flight"; return SE3D_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
-  int total = 0;
-  if (sl.direct) {   // the kernels wrote the pinned buffers themselves
-    HIPCHK(c, hipEventSynchronize(sl.compute_done));
-    total = sl.h_out_off[sl.n_frames];
-  } else {
-    HIPCHK(c, hipEventSynchronize(sl.off_done));
-    total = sl.h_out_off[sl.n_frames];
-    if (total > 0) {
-      HIPCHK(c, hipMemcpyAsync(sl.h_fused, sl.d_fused, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, sl.s_out));
-      HIPCHK(c, hipMemcpyAsync(sl.h_pred, sl.d_pred, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, sl.s_out));
-    }
-    HIPCHK(c, hipStreamSynchronize(sl.s_out));
+  HIPCHK(c, hipEventSynchronize(sl.compute_done));   // the batch's kernels are done; the offsets are in pinned memory (mirror)
+  const int total = sl.h_out_off[sl.n_frames];
+  if (!sl.direct && total > 0) {   // (direct: the kernels wrote the pinned buffers themselves)
+    HIPCHK(c, hipMemcpyAsync(sl.h_fused, sl.d_fused, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, c->s_d2h));
+    HIPCHK(c, hipMemcpyAsync(sl.h_pred, sl.d_pred, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, c->s_d2h));
+    HIPCHK(c, hipEventRecord(sl.off_done, c->s_d2h));
+    HIPCHK(c, hipEventSynchronize(sl.off_done));   // (an event, not the stream: the stream also carries the other contexts' downloads)
   }
   out->n_frames = sl.n_frames;
   out->n_persons = total;
