@@ -35,10 +35,23 @@ extern "C" void se3d_diag_s1_stamps(unsigned long long *out16, int reset) {
   (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_s1_stamps), sizeof(unsigned long long) * 16);
   if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_s1_stamps), z, sizeof(z)); }
 }
+// ... and of se3d_k_pairs_rows: cycles of wavefront 0 (stages operands) and of wavefront 3 (does not) of every 16th workgroup, by phase part
+__device__ unsigned long long g_rb_stamps[2][16];
+#define RB_STAMP_INIT unsigned long long rb_prev_ = __builtin_readcyclecounter(); const bool rb_on_ = (tid & 63) == 0 && ((tid >> 6) == 0 || (tid >> 6) == 3) && ((blockIdx.y + 3 * blockIdx.z) & 15) == 0;
+#define RB_STAMP(idx) { const unsigned long long now_ = __builtin_readcyclecounter(); if (rb_on_) atomicAdd(&g_rb_stamps[(tid >> 6) == 3][idx], now_ - rb_prev_); rb_prev_ = __builtin_readcyclecounter(); }
+#define RB_COUNT(idx) if (rb_on_) atomicAdd(&g_rb_stamps[(tid >> 6) == 3][idx], 1ull);
+extern "C" void se3d_diag_rb_stamps(unsigned long long *out32, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_rb_stamps), sizeof(unsigned long long) * 32);
+  if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rb_stamps), z, sizeof(z)); }
+}
 #else
 #define S1_STAMP(idx)
 #define S1_STAMP_INIT
 #define S1_COUNT(idx)
+#define RB_STAMP_INIT
+#define RB_STAMP(idx)
+#define RB_COUNT(idx)
 #endif
 
 #define TRI_THRESH 0.30f
@@ -434,7 +447,8 @@ __device__ __forceinline__ float se3d_div_shared(float a, float b, float y) {
 __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float px, float py, bool valid, bool &unsafe) {
   RowOp o;
   o.lx = lx; o.ly = ly; o.lz = lz;
-  const float ss = lx * lx + ly * ly;
+  // (an unusable operand — zero line, norm forced to 1 below — must not drag its wavefront through the IEEE branch: it computes on 1.0)
+  const float ss = valid ? lx * lx + ly * ly : 1.f;
   const unsigned us = __float_as_uint(ss);
   if (us >= SE3D_EXACT_LO && us <= SE3D_EXACT_HI) {   // then nrm lies in [2^-30, 2^30]: se3d_safe_rcp's exponent test holds
     o.nrm = se3d_sqrt_core(ss);
@@ -445,7 +459,12 @@ __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float 
   }
   o.x = px; o.y = py;
   o.w = valid ? 1.f : 0.f;
-  unsafe |= valid && !(o.rcp != 0.f && se3d_in_safe_range(lx) && se3d_in_safe_range(ly) && se3d_in_safe_range(lz) && se3d_in_safe_range(px) && se3d_in_safe_range(py));
+  // Range guard of the shared-reciprocal quotient: an operand outside it is marked by rcp = 0 (a usable operand's reciprocal is never 0); the
+  // wavefronts that meet one take the IEEE-divide form for that phase.  Both forms give the correctly rounded quotients, hence the same bits, so
+  // the choice need not be uniform over the workgroup (rounds 2 - 4 kept block-wide flags in LDS: one more LDS round trip per phase).
+  const bool bad = valid && !(o.rcp != 0.f && se3d_in_safe_range(lx) && se3d_in_safe_range(ly) && se3d_in_safe_range(lz) && se3d_in_safe_range(px) && se3d_in_safe_range(py));
+  unsafe |= bad;
+  if (bad) o.rcp = 0.f;
   // An unusable (detection, joint) is all zeros with a unit norm: every distance it is the LINE or the POINT of comes out as exactly 0, so the
   // item needs the other side's weight only: d1 * w_b + d2 * w_a (one FMA) instead of (d1 + d2) * (w_a * w_b).  The IEEE-divide path
   // (se3d_rows_compute_slow) selects by the validity masks and never divides by this norm for a masked joint's contribution.
@@ -527,14 +546,16 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
   __shared__ RowOp A[SE3D_NKP][RB_ROWS_P];  // det_a side, all joints: staged once per workgroup (26 KB)
   __shared__ RowOp Bc[2][RB_JH][RB_COLS_P];  // det_b side of a (column tile, joint group) phase, double-buffered (2 x 6 KB)
   __shared__ unsigned M1[RB_ROWS], M2[2][RB_COLS];
-  __shared__ int s_unsafe_a, s_unsafe_b[3];   // range-guard flags: det_a side; det_b side of phase ph in [ph % 3]
+  __shared__ int s_unsafe_a;   // range-guard flag of the det_a side (the det_b side: rcp = 0 in the operand, tested from registers)
   __shared__ double INV[SE3D_NKP + 1];     // RN(1 / n) for the joint count of an entry
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, ql = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it is a uniform branch, not an exec mask
   const float *F = D.F + 9 * (size_t)se3d_pair_index(ab.x, ab.y, N);   // F is stored in the reference's pair order (get_fundamental_idx)
   const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
   const size_t baseA = ((size_t)(f * N + ab.x)) * P, baseB = ((size_t)(f * N + ab.y)) * P;
-  if (tid == 0) { s_unsafe_a = 0; s_unsafe_b[0] = 0; s_unsafe_b[1] = 0; s_unsafe_b[2] = 0; }
+  RB_STAMP_INIT
+  RB_COUNT(15)
+  if (tid == 0) s_unsafe_a = 0;
   if (tid <= SE3D_NKP) INV[tid] = tid ? 1.0 / (double)tid : 0.0;
   constexpr int NA_ROUNDS = (RB_ROWS * SE3D_NKP + RB_NT - 1) / RB_NT;
   float4 a4[NA_ROUNDS];   // all global loads of the det_a side first (in flight across the barrier): one memory latency, not five in a row
@@ -546,6 +567,7 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
   }
   for (int d = tid; d < RB_ROWS; d += 256) M1[d] = (p0 + d < na) ? D.vmask_gt[baseA + p0 + d] : 0u;
   __syncthreads();
+  RB_STAMP(0)   // entry: F, counts, det_a global loads + first barrier
   {
     bool unsafe = false;
 #pragma unroll
@@ -569,21 +591,30 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
   static_assert(RB_COLS * RB_JH <= 256, "one staging item per thread");
   float4 pre4 = make_float4(0.f, 0.f, -1.f, 0.f);
   unsigned premq = 0u;
+  // the thread's (column, joint) of a phase with RB_JH / RB_JLAST joints: constant over the phases
+  const int sd6 = tid / RB_JH, sj6 = tid - sd6 * RB_JH, sd5 = tid / RB_JLAST, sj5 = tid - sd5 * RB_JLAST;
+  const float4 *kpB = D.kp + baseB * SE3D_NKP;
+  const uint32_t *vmB = D.vmask_gt + baseB;
   auto prefetch = [&](int q0, int jbase, int jn) {
-    const int d = tid / jn, jj = tid - d * jn, q = q0 + d;   // jn in {RB_JH, RB_JLAST}: two constant divisions selected by a uniform branch
+    const int d = jn == RB_JH ? sd6 : sd5, jj = jn == RB_JH ? sj6 : sj5, q = q0 + d;
     pre4 = make_float4(0.f, 0.f, -1.f, 0.f);
     premq = 0u;
-    if (tid < RB_COLS * jn && q < nb) { pre4 = D.kp[(baseB + q) * SE3D_NKP + jbase + jj]; premq = D.vmask_gt[baseB + q]; }
+    if (tid < RB_COLS * jn && q < nb) { pre4 = kpB[q * SE3D_NKP + jbase + jj]; premq = vmB[q]; }
   };
-  auto flush = [&](int q0_done) {
+  auto flush = [&](int q0_done) {   // the LDS reads of the six entries first (two batches of independent reads), then the arithmetic and the stores
     const int q = q0_done + ql;
+    int nn[RB_ROWS / 8];
+    double iv[RB_ROWS / 8];
+#pragma unroll
+    for (int r = 0; r < RB_ROWS / 8; ++r) nn[r] = __popc(M1[row0 + 2 * r] & m2);
+#pragma unroll
+    for (int r = 0; r < RB_ROWS / 8; ++r) iv[r] = INV[nn[r]];
+    double *o = out + (size_t)(p0 + row0) * P + q;
 #pragma unroll
     for (int r = 0; r < RB_ROWS / 8; ++r) {
-      const int row = row0 + 2 * r, p = p0 + row;
-      if (2 * r < nrw && p < na && q < nb) {   // (row pairs beyond the wavefront's share belong to the next wavefront)
-        const int n = __popc(M1[row] & m2);
-        out[(size_t)p * P + q] = n > 0 ? se3d_div_count(acc[r], n, INV[n]) : -1.0;
-      }
+      const int p = p0 + row0 + 2 * r;
+      if (2 * r < nrw && p < na && q < nb)   // (row pairs beyond the wavefront's share belong to the next wavefront)
+        o[(size_t)(2 * r) * P] = nn[r] > 0 ? se3d_div_count(acc[r], nn[r], iv[r]) : -1.0;
     }
   };
   // Phase ph = (column tile ph / NPH, joint group ph % NPH).  While a phase computes from registers, the operands of the NEXT phase are
@@ -594,47 +625,62 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
   auto jn_of = [](int ph_) { return min(RB_JH, SE3D_NKP - (ph_ % NPH) * RB_JH); };
   auto stage = [&](int ph_) {   // pre4 / premq (operand of phase ph_) -> Bc[ph_ & 1], M2[(ph_ / NPH) & 1], flag[ph_ % 3]
     const int jn = jn_of(ph_), jbase = (ph_ % NPH) * RB_JH, q0 = (ph_ / NPH) * RB_COLS;
-    const int d = jn == RB_JH ? tid / RB_JH : tid / RB_JLAST, jj = tid - d * jn, k = jbase + jj, q = q0 + d;
+    const int d = jn == RB_JH ? sd6 : sd5, jj = jn == RB_JH ? sj6 : sj5, k = jbase + jj, q = q0 + d;
     bool unsafe = false;
     if (tid < RB_COLS * jn) {
       Bc[ph_ & 1][jj][d] = se3d_rowop(f0 * pre4.x + (f3 * pre4.y + f6), f1 * pre4.x + (f4 * pre4.y + f7), f2 * pre4.x + (f5 * pre4.y + f8),
                                       pre4.x, pre4.y, q < nb && ((premq >> k) & 1u), unsafe);
       if (jj == 0 && jbase == 0) M2[(ph_ / NPH) & 1][d] = premq;
     }
-    if (unsafe) s_unsafe_b[ph_ % 3] = 1;
   };
   auto prefetch_ph = [&](int ph_) {
     if (ph_ >= nph) return;
     const int jbase = (ph_ % NPH) * RB_JH, q0 = (ph_ / NPH) * RB_COLS;
     if (jn_of(ph_) == RB_JH) prefetch(q0, jbase, RB_JH); else prefetch(q0, jbase, RB_JLAST);
   };
+  RB_STAMP(1)   // det_a operands (RowOp of the tile's rows) into LDS
   prefetch_ph(0);
   stage(0);
   prefetch_ph(1);
-  se3d_lds_barrier();   // A, M1, the flags and phase 0 of Bc are visible
+  se3d_lds_barrier();   // A, M1, the flag and phase 0 of Bc are visible
+  const int unsafe_a = __builtin_amdgcn_readfirstlane(s_unsafe_a);   // read ONCE: the det_a side is staged once per workgroup
+  RB_STAMP(2)   // first det_b phase: load + stage + barrier
   for (int ph = 0; ph < nph; ++ph) {
     const int jn = jn_of(ph), jbase = (ph % NPH) * RB_JH, q0 = (ph / NPH) * RB_COLS;
-    const int any_unsafe = s_unsafe_b[ph % 3] | s_unsafe_a;  // block-uniform: shared-reciprocal divide or IEEE divide
-    if (tid == 0) s_unsafe_b[(ph + 2) % 3] = 0;              // last read in phase ph - 1, next written in phase ph + 1
+    RB_COUNT(14)
+    RB_STAMP(3)   // flag read
     if (ph + 1 < nph) stage(ph + 1);   // consumes the prefetched registers before any store of this phase is issued
+    RB_STAMP(4)   // stage the next phase's det_b operands
     if (jbase == 0) {
       if (ph > 0) flush(q0 - RB_COLS);
 #pragma unroll
       for (int r = 0; r < RB_ROWS / 8; ++r) acc[r] = 0.0;
       m2 = M2[(ph / NPH) & 1][ql];
     }
+    RB_STAMP(5)   // flush of the finished column tile + accumulator reset
     prefetch_ph(ph + 2);
     RowOp b[RB_JH];
 #pragma unroll
     for (int jj = 0; jj < RB_JH; ++jj) b[jj] = Bc[ph & 1][jj < jn ? jj : 0][ql];
+    bool bad_b = false;
+#pragma unroll
+    for (int jj = 0; jj < RB_JH; ++jj) bad_b |= b[jj].rcp == 0.f;
+    const bool any_unsafe = unsafe_a != 0 || __ballot(bad_b) != 0ull;   // wave-uniform: shared-reciprocal divide or IEEE divide
+#ifdef SE3D_LM_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    RB_STAMP(6)   // prefetch issue + det_b operands LDS -> registers
     if (nrows_left > 0) {
       if (any_unsafe) se3d_rows_compute_slow(A, Bc[ph & 1], ql, jbase, jn, row0, m2, M1, acc);
       else if (jn == RB_JH) se3d_rows_compute<RB_JH>(A, b, jbase, row0, nrows_left, acc);
       else se3d_rows_compute<RB_JLAST>(A, b, jbase, row0, nrows_left, acc);
     }
+    RB_STAMP(7)   // items
     se3d_lds_barrier();   // phase ph + 1 is staged; nobody reads Bc[ph & 1] any more (its next writer is the staging of phase ph + 2)
+    RB_STAMP(8)   // barrier wait
   }
   flush(((nb - 1) / RB_COLS) * RB_COLS);
+  RB_STAMP(9)   // last flush
 }
 
 // =============================================================================================================

@@ -54,7 +54,7 @@ c256_ab)
   for V in $AB; do
     rm -rf $OUT/c256_stats_$V
     export SE3D_LIB_OVERRIDE=$GRAFT_REPO_ROOT/tools/tmp/libse3d_$V.so
-    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c256_stats_$V -- python3 bench.py --workload 256cam128p --contexts 1 --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $OUT/c256_bench_1ctx_$V.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c256_stats_$V -- python3 bench.py --workload 256cam128p --contexts 1 --steps 2 --warmup 1 --no-cpu-baseline --no-parity ${AB_FLAGS:-} > $OUT/c256_bench_1ctx_$V.log 2>&1
     unset SE3D_LIB_OVERRIDE
     python3 tools/kernel_stats.py $OUT/c256_stats_$V $OUT/c256_1ctx_${V}_kernel_stats.csv | grep pairs_rows | sed "s/^/$V: /"
   done
