@@ -423,6 +423,7 @@ __device__ __forceinline__ float se3d_safe_rcp(float b) {
 #define RB_ROWS 48
 #define RB_COLS 32
 #define RB_NT 256                       // threads per workgroup
+#define RB_WPAIRS (RB_ROWS / 8)          // row pairs a wavefront can carry (one accumulator each)
 // LDS rows are padded by one operand (32 B = 8 banks): the staging threads of a wavefront write the SAME detection slot of consecutive
 // joints, and an unpadded joint stride (48 or 32 operands) is a multiple of 128 B — every lane on the same four banks (17-way / 6-way
 // conflicts, 29 % of the LDS busy cycles in profiles/r2/pmc_lds_256cam128p_rows.json before the padding)
@@ -474,7 +475,7 @@ __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float 
 
 template <int JN>
 __device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS_P], const RowOp (&b)[RB_JH], int jbase, int row0, int nrows_left,
-                                                  double (&acc)[RB_ROWS / 8]) {
+                                                  double (&acc)[RB_WPAIRS]) {
   // Straight-line code over (row pair, joint).  The det_a operand of the NEXT item is fetched from LDS while the current item is
   // computed (two RowOp in flight = 16 registers).  The memory-clobbering empty asm after every item is what keeps it that way: without
   // it the det_a operands — which do not change from one column tile to the next — are lifted out of the column loop by loop-invariant
@@ -482,14 +483,14 @@ __device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS_P], c
   asm volatile("" ::: "memory");
   RowOp a = A[jbase][row0];
 #pragma unroll
-  for (int r = 0; r < RB_ROWS / 8; ++r) {
+  for (int r = 0; r < RB_WPAIRS; ++r) {
     // wave-uniform (scalar) skip of the row pairs beyond the wavefront's last row.  NOT a `break`: the early exit made the compiler copy the
     // other accumulators to the exit block's registers before every row pair (five 64-bit moves per six items).
     if (2 * r < nrows_left) {
     const int row = row0 + 2 * r;
 #pragma unroll
     for (int jj = 0; jj < JN; ++jj) {
-      const bool last_j = jj + 1 == JN, last_r = r + 1 == RB_ROWS / 8;
+      const bool last_j = jj + 1 == JN, last_r = r + 1 == RB_WPAIRS;
       const RowOp an = A[last_j ? jbase : jbase + jj + 1][last_j ? (last_r ? row0 : row + 2) : row];
       const float n1 = fabsf(b[jj].x * a.lx + (b[jj].y * a.ly + a.lz));
       const float n2 = fabsf(a.x * b[jj].lx + (a.y * b[jj].ly + b[jj].lz));
@@ -505,9 +506,9 @@ __device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS_P], c
 // IEEE-divide form for blocks whose operands fail the range guard of the shared-reciprocal divide (practically never): compact loops, both
 // operands from LDS.
 __device__ __forceinline__ void se3d_rows_compute_slow(const RowOp (*A)[RB_ROWS_P], const RowOp (*Bc)[RB_COLS_P], int ql, int jbase, int jn, int row0,
-                                                       unsigned m2, const unsigned *M1, double (&acc)[RB_ROWS / 8]) {
+                                                       unsigned m2, const unsigned *M1, double (&acc)[RB_WPAIRS]) {
 #pragma unroll
-  for (int r = 0; r < RB_ROWS / 8; ++r) {
+  for (int r = 0; r < RB_WPAIRS; ++r) {
     const int row = row0 + 2 * r;
     const unsigned mm = M1[row] & m2;
 #pragma unroll 1
@@ -542,7 +543,14 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
   const int p0 = blockIdx.x * tile_rows;
   if (p0 >= na_all) return;
   const int na = min(na_all, p0 + tile_rows);                        // rows p0 .. na - 1 are this tile's
-  const int nrw = (((na - p0) + 3) / 4 + 1) & ~1;                    // rows per wavefront (even, <= RB_ROWS / 4): the tile's rows dealt evenly
+  // The tile's rows dealt to the four wavefronts (even shares, a wavefront carries row pairs).  NOT evenly: wavefronts 0 - 2 also stage the det_b
+  // operands of the next phase (RB_COLS x RB_JH = 192 threads) — 17 % of the kernel's time by ablation, as long as ~3.7 row pairs of items by the
+  // cycle stamps (tools/rb_stamps.py) — while wavefront 3 waited at the barrier for them (35 % of its cycles).  So wavefront 3 takes its full
+  // 12 rows first and the staging wavefronts share the rest: nrw rows each, the smallest even number with 3 nrw + 12 >= rows
+  // (14.31 -> 14.15 ms per launch at 256cam128p; with seven accumulators and 14 rows for wavefront 3: 14.23, 128 VGPRs).
+  const int nt = na - p0;
+  const int nrw = min(RB_ROWS / 4, max(2, ((max(0, nt - 2 * RB_WPAIRS) + 2) / 3 + 1) & ~1));   // rows of each staging wavefront
+  const int nr3 = min(2 * RB_WPAIRS, RB_ROWS - 3 * nrw);                            // rows wavefront 3 can take (>= nt - 3 nrw by construction)
   __shared__ RowOp A[SE3D_NKP][RB_ROWS_P];  // det_a side, all joints: staged once per workgroup (26 KB)
   __shared__ RowOp Bc[2][RB_JH][RB_COLS_P];  // det_b side of a (column tile, joint group) phase, double-buffered (2 x 6 KB)
   __shared__ unsigned M1[RB_ROWS], M2[2][RB_COLS];
@@ -580,9 +588,10 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
     if (unsafe) s_unsafe_a = 1;
   }
   const int row0 = wave * nrw + half;                        // this lane's first row inside the tile; row pairs r: row0 + 2 r
-  const int nrows_left = min(nrw, na - p0 - wave * nrw);     // rows of this wavefront that exist (wave-uniform)
+  const int nshare = wave == 3 ? nr3 : nrw;                  // rows this wavefront owns (wave-uniform)
+  const int nrows_left = min(nshare, nt - wave * nrw);       // ... and those of them that exist
   double *out = D.pair + ((size_t)f * np + pr) * P * P;
-  double acc[RB_ROWS / 8];
+  double acc[RB_WPAIRS];
   unsigned m2 = 0u;
   // One (detection, joint) operand of the det_b side per thread and phase (RB_COLS x RB_JH <= 256).  Its global loads are issued a whole
   // phase ahead (before the barrier and the compute of the current phase), and the entries of a finished column tile are stored one
@@ -603,17 +612,17 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
   };
   auto flush = [&](int q0_done) {   // the LDS reads of the six entries first (two batches of independent reads), then the arithmetic and the stores
     const int q = q0_done + ql;
-    int nn[RB_ROWS / 8];
-    double iv[RB_ROWS / 8];
+    int nn[RB_WPAIRS];
+    double iv[RB_WPAIRS];
 #pragma unroll
-    for (int r = 0; r < RB_ROWS / 8; ++r) nn[r] = __popc(M1[row0 + 2 * r] & m2);
+    for (int r = 0; r < RB_WPAIRS; ++r) nn[r] = __popc(M1[row0 + 2 * r] & m2);
 #pragma unroll
-    for (int r = 0; r < RB_ROWS / 8; ++r) iv[r] = INV[nn[r]];
+    for (int r = 0; r < RB_WPAIRS; ++r) iv[r] = INV[nn[r]];
     double *o = out + (size_t)(p0 + row0) * P + q;
 #pragma unroll
-    for (int r = 0; r < RB_ROWS / 8; ++r) {
+    for (int r = 0; r < RB_WPAIRS; ++r) {
       const int p = p0 + row0 + 2 * r;
-      if (2 * r < nrw && p < na && q < nb)   // (row pairs beyond the wavefront's share belong to the next wavefront)
+      if (2 * r < nshare && p < na && q < nb)   // (row pairs beyond the wavefront's share belong to the next wavefront)
         o[(size_t)(2 * r) * P] = nn[r] > 0 ? se3d_div_count(acc[r], nn[r], iv[r]) : -1.0;
     }
   };
@@ -654,7 +663,7 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
     if (jbase == 0) {
       if (ph > 0) flush(q0 - RB_COLS);
 #pragma unroll
-      for (int r = 0; r < RB_ROWS / 8; ++r) acc[r] = 0.0;
+      for (int r = 0; r < RB_WPAIRS; ++r) acc[r] = 0.0;
       m2 = M2[(ph / NPH) & 1][ql];
     }
     RB_STAMP(5)   // flush of the finished column tile + accumulator reset
