@@ -366,9 +366,13 @@ __global__ __launch_bounds__(256) void se3d_k_normalize_pairs(Se3dDev D, const i
 // Range guard of the shared-reciprocal divide (se3d_div_shared, rows kernel): every operand of a numerator / denominator is 0 or within
 // [2^-30, 2^30].  Then a non-zero numerator is >= 2^-84 and a quotient >= 2^-115, so with float32 denormals preserved every FMA residual is
 // exact (no underflow) and the correction returns the correctly rounded quotient; zero numerators give exactly 0.
-__device__ __forceinline__ bool se3d_in_safe_range(float v) {
-  const unsigned ex = (__float_as_uint(v) >> 23) & 0xffu;
-  return (v == 0.f) || (ex >= 97u && ex <= 157u);
+// The test on the five floats of an operand at once: |v| as an integer orders like |v|, and |v| - 1 wraps zero to the top (v_min3 / v_max3).
+__device__ __forceinline__ bool se3d_all_in_safe_range(float a, float b, float c, float d, float e) {
+  const unsigned ua = __float_as_uint(a) & 0x7fffffffu, ub = __float_as_uint(b) & 0x7fffffffu, uc = __float_as_uint(c) & 0x7fffffffu,
+                 ud = __float_as_uint(d) & 0x7fffffffu, ue = __float_as_uint(e) & 0x7fffffffu;
+  const unsigned hi = max(max(max(ua, ub), uc), max(ud, ue));
+  const unsigned lo = min(min(min(ua - 1u, ub - 1u), uc - 1u), min(ud - 1u, ue - 1u));
+  return hi <= ((158u << 23) - 1u) && lo >= (97u << 23) - 1u;
 }
 // y = RN(1/b) for divisors where Markstein's theorem applies (normal range, significand not all ones), else 0
 __device__ __forceinline__ float se3d_safe_rcp(float b) {
@@ -463,7 +467,7 @@ __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float 
   // Range guard of the shared-reciprocal quotient: an operand outside it is marked by rcp = 0 (a usable operand's reciprocal is never 0); the
   // wavefronts that meet one take the IEEE-divide form for that phase.  Both forms give the correctly rounded quotients, hence the same bits, so
   // the choice need not be uniform over the workgroup (rounds 2 - 4 kept block-wide flags in LDS: one more LDS round trip per phase).
-  const bool bad = valid && !(o.rcp != 0.f && se3d_in_safe_range(lx) && se3d_in_safe_range(ly) && se3d_in_safe_range(lz) && se3d_in_safe_range(px) && se3d_in_safe_range(py));
+  const bool bad = valid && !(o.rcp != 0.f && se3d_all_in_safe_range(lx, ly, lz, px, py));
   unsafe |= bad;
   if (bad) o.rcp = 0.f;
   // An unusable (detection, joint) is all zeros with a unit norm: every distance it is the LINE or the POINT of comes out as exactly 0, so the
