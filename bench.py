@@ -1033,9 +1033,12 @@ def main():
             "value": round(main_res["value"], 2), "unit": "skeletons/s", "n_gpus": world, "steps": main_res["steps"], "warmup": main_res["warmup"],
             "ms_per_step": round(main_res["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 geometry, f64 accumulation/eigen/LM", "data": "synthetic",
-            "config": {"workload": "%s, stage %s, %d contexts x %d sequences x %d frames resident per GPU (%d frames, %d published skeletons per step per GPU; stage-1 persons %d)"
+            "config": {"workload": "%s, stage %s, %d contexts x %d sequences x %d frames resident per GPU (%d frames, %d published skeletons per step per GPU; stage-1 persons %d); "
+                                   "%d distinct seeded sequences per context, each resident %d times in its own memory"
                                    % (headline, "1+2 (association+triangulation+UT covariance, then tracking+LM refinement+marginals)" if stage2 else "1",
-                                      main_res["NC"], main_res["S"], main_res["T"], main_res["NC"] * main_res["B"], main_res["n_skel_local"], main_res["n_s1"]),
+                                      main_res["NC"], main_res["S"], main_res["T"], main_res["NC"] * main_res["B"], main_res["n_skel_local"], main_res["n_s1"],
+                                      min(main_res["S"], 32), max(1, main_res["S"] // min(main_res["S"], 32))),
+                       "distinct_sequences_per_context": min(main_res["S"], 32),
                        "n_cam": w["n_cam"], "n_persons": w["n_persons"], "n_joints": 17, "frames_per_step": main_res["NC"] * main_res["B"],
                        "contexts_per_gpu": main_res["NC"], "max_hypotheses_per_frame": main_res["max_hyp_per_frame"],
                        "max_published_per_frame": main_res["max_published_per_frame"], "scene_generation_s": round(t_gen, 1),
@@ -1045,8 +1048,8 @@ def main():
             "roofline": roof,
             "pmc_summaries_skipped": stale_pmc,   # committed counter summaries collected on OTHER kernel sources than this build's (not used)
             "second_pass": {"joints_per_launch": main_res["second_pass_joints"], "per_published_joint": round(main_res["second_pass_fraction"], 6),
-                            "note": "joints the fast fp64 triangulation handed to se3d_k_triangulate_exact (the reference's float32 JacobiSVD arithmetic, "
-                                    "bit-identical to the oracle): ill-conditioned systems, reprojection errors near / above the outlier threshold, wide covariances; "
+                            "note": "joints the fast fp64 triangulation handed to se3d_k_triangulate_exact (the oracle's restatement of the reference's float32 JacobiSVD arithmetic, "
+                                    "bit-identical to that oracle): ill-conditioned systems, reprojection errors near / above the outlier threshold, wide covariances; "
                                     "its time is inside the `triangulate` kernel group"},
         }
         if main_res["sweep_stats"][0]:   # large rigs (per-camera sweep launches): how often the sweep ran the Hungarian

@@ -382,7 +382,7 @@ int se3d_get_sweep_stats(se3d_ctx *ctx, uint64_t *steps, uint64_t *hungarian_ste
 int se3d_selftest_shared_quotient(se3d_ctx *ctx, uint64_t n, uint64_t *mismatches, uint64_t *skipped);
 
 /* --- diagnostic self-test (round 4): the float32 DLT solve of the triangulation's second pass — triangulate() + calcReprojectionError()
- * (S3D:425-465) with the reference's arithmetic: Eigen 3.3 JacobiSVD of the float rows (scaling, ColPivHouseholderQR preconditioner unless
+ * (S3D:425-465) with the oracle's restatement of the reference's arithmetic: Eigen 3.3 JacobiSVD of the float rows (scaling, ColPivHouseholderQR preconditioner unless
  * the system is 4 x 4, two-sided Jacobi sweeps), every sum sequential, IEEE division / square root, no FMA — on n_sys caller systems of
  * n_views views each: Rt [n_sys][n_views][12] camera matrices, pts [n_sys][n_views][3] (x, y, conf) in normalised image coordinates.
  * X_out [n_sys][3], err_out [n_sys] (confidence-weighted reprojection error).  Bit-identical to the same sequence on any IEEE-754 host. */

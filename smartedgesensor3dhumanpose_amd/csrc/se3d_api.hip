@@ -624,6 +624,15 @@ se3d_ctx *se3d_create_ex(const se3d_rig *rig, const se3d_params *params, const s
     se3d_destroy(c);
     return nullptr;
   }
+  // The fills above are hipMemset calls on the NULL stream: they return before the fill has run, and the context's streams are non-blocking, i.e.
+  // they do not wait for the null stream.  Without this wait the zero fill of nraw could overtake the upload of the first se3d_stage_frames: the
+  // pass then saw a frame set without detections (FEW_CAMERAS, no persons).  Latent since round 1, seen in round 5 in ~2 % of the runs once 14
+  // processes shared the GPU (tests/test_gpu_fuzz_parity.py starts its runs side by side) and the fill was queued for milliseconds.
+  if (!hip_ok(c, hipStreamSynchronize(nullptr), "hipStreamSynchronize (create-time fills)") || !hip_ok(c, hipStreamSynchronize(c->stream), "hipStreamSynchronize")) {
+    create_error("se3d_create: %s", c->err.c_str());
+    se3d_destroy(c);
+    return nullptr;
+  }
   return c;
 }
 
@@ -671,7 +680,6 @@ void se3d_destroy(se3d_ctx *c) {
     if (sl.compute_done) (void)hipEventDestroy(sl.compute_done);
     if (sl.off_done) (void)hipEventDestroy(sl.off_done);
   }
-  for (auto &sl : c->ss)
   for (auto &set : c->ev2)
     for (auto &e : set)
       if (e) (void)hipEventDestroy(e);

@@ -1,4 +1,4 @@
-// se3d_exact32.h — the reference's float32 DLT solve, operation for operation (round 4).
+// se3d_exact32.h — the oracle's restatement of the reference's float32 DLT solve, operation for operation (round 4).
 //
 // skeleton_3d takes the null vector of every DLT system — the published point (S3D:746), each leave-one-view-out candidate (S3D:793-838)
 // and each of the 4n + 1 sigma samples of the unscented transform (S3D:518) — from Eigen 3.3's JacobiSVD in FLOAT (S3D:456:

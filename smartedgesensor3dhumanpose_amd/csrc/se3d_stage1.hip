@@ -1084,7 +1084,7 @@ __device__ __forceinline__ void se3d_solve_point(const double g[10], const doubl
 //   lambda4, a cubic with three positive roots, approached from below (b3 / b2 <= lambda3 because 1/l1 + 1/l2 + 1/l3 = b2 / b3; left of its
 //   smallest root the cubic is increasing and concave, so Newton steps from there never pass the root).
 // Measured on 3.8e5 joints (tools/study/kappa_bound_study.py, profiles/r4/kappa_bound_study.txt): bound / kappa between 1.01 and 1.7 (median
-// 1.25) with two Newton steps.  A joint whose bound reaches SE3D_EXACT_KAPPA is redone by se3d_k_triangulate_exact with the reference's float32 arithmetic; the
+// 1.25) with two Newton steps.  A joint whose bound reaches SE3D_EXACT_KAPPA is redone by se3d_k_triangulate_exact with the oracle's restatement of the reference's float32 arithmetic; the
 // worst float32-vs-fp64 deviation among the joints that stay here was 0.055 mm in that study (the contract is 1 mm).
 #define SE3D_EXACT_KAPPA 1.0e3
 // Decisions of the outlier rejection (S3D:748-844) compare the reprojection error with g_reproj_error_max_acceptable; an error within this
@@ -1394,9 +1394,9 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   for (int v = 0; v < n; ++v) avg_score += T.cf[v];
   avg_score /= (float)n;
   {
-    // Round 4: a joint whose fp64 solve may differ from the reference's float32 JacobiSVD by more than the contract allows — ill-conditioned
+    // Round 4: a joint whose fp64 solve may differ from the float32 JacobiSVD result (as the oracle restates it) by more than the contract allows — ill-conditioned
     // weighted or unweighted system, a solve that did not settle — or whose reprojection error is above / near the outlier threshold is handed
-    // to se3d_k_triangulate_exact (the reference's arithmetic, bit for bit).  Everything decided from here on is uniform over the wavefront.
+    // to se3d_k_triangulate_exact (the oracle's restatement of the reference's arithmetic, bit for bit).  Everything decided from here on is uniform over the wavefront.
     bool flag = !conv0 || !(err <= REPROJ_MAX * (1.0 - SE3D_EXACT_ERR_GUARD));
     bool hi = false;   // a confidence above 1 (the level-1 test assumes c <= 1)
     for (int v = lane; v < n; v += 64) hi |= T.cf[v] > 1.0f;
@@ -1862,7 +1862,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
 }
 
 // =============================================================================================================
-// Second pass of the triangulation (round 4): rows T, P, O, U of the listed joints with the reference's float32 arithmetic.
+// Second pass of the triangulation (round 4): rows T, P, O, U of the listed joints with the oracle's restatement of the reference's float32 arithmetic.
 // One wavefront per joint, one DLT solve per lane (se3d_exact32.h):
 //   phase A  lane 0 solves the confidence-weighted system of all n usable views (S3D:746), lanes 1 .. n its leave-one-view-out subsets
 //            (S3D:793-838; with three views the subset left after the epipolar test of S3D:748-792 is one of them) — speculatively: the lanes
@@ -2935,7 +2935,7 @@ static void se3d_launch_triangulation(const Se3dDev &D, const se3d_options &o, h
     hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(TH_PARTS * H, B), dim3(64), 0, st, D);
   }
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
-  // second pass: the listed joints with the reference's float32 arithmetic (wavefronts beyond the list length exit at once)
+  // second pass: the listed joints with the oracle's restatement of the reference's float32 arithmetic (wavefronts beyond the list length exit at once)
   hipLaunchKernelGGL(se3d_k_triangulate_exact, dim3(waves2), dim3(64), se3d_exact_lds_bytes(N), st, D);
 }
 

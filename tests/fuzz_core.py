@@ -2,7 +2,7 @@
 through the C-ABI against the CPU oracle on the scenes of tests/fuzz_scenes.py — stage 1 per frame, the resident stage-2 walk per sequence.
 
 What must hold (round 4: no exclusion set for stage-1 positions and scores any more — joints the fp64 fast path cannot guarantee are redone by
-the library itself with the reference's float32 arithmetic, csrc/se3d_exact32.h):
+the library itself with the oracle's restatement of the reference's float32 arithmetic, csrc/se3d_exact32.h):
   * stage-1 index results (flags, hypothesis counts, association tables, published persons, sets of valid joints): identical in every frame
     (frames on which the library raised FLAG_HYP_OVERFLOW are counted; the oracle, run with room to spare, must have needed more);
   * stage-1 positions < 1 mm and scores bit-equal (SCORE_RTOL = 0) on EVERY valid joint;
@@ -75,7 +75,8 @@ def run_trials(O, seed, trials, walk_mode="wave", pose_method="simple", norm_hei
                 assert o.n_hyp > MAX_HYP, ("overflow flag without overflow", seed, trial, fi, o.n_hyp)
                 rep["frames_hyp_overflow"] += 1
                 continue
-            assert g.flags == o.flags and o.n_hyp <= MAX_HYP, ("flags", seed, trial, fi, g.flags, o.flags, o.n_hyp)
+            assert g.flags == o.flags and o.n_hyp <= MAX_HYP, ("flags", seed, trial, fi, g.flags, o.flags, o.n_hyp, "library: hypotheses, persons", g.n_hyp, g.n_persons,
+                                                               "oracle persons", o.n_persons, "cameras with detections", int((np.diff(np.asarray(fr.det_offset)) > 0).sum()))
             assert g.n_hyp == o.n_hyp, ("hypotheses", seed, trial, fi, g.n_hyp, o.n_hyp)
             assert np.array_equal(g.assoc(), o.assoc()), ("association table", seed, trial, fi)
             assert g.n_persons == o.n_persons and np.array_equal(g.person_hyp[:g.n_persons], o.person_hyp[:g.n_persons]), ("published persons", seed, trial, fi)

@@ -147,7 +147,7 @@ def compare_stage2_objectives(gpu, ora):
 # can come out of the two solvers up to ~ c * eps * kappa metres apart (measured c <= 5 over 3e5 joints, profiles/r3/README.md).
 # Round 3 EXCLUDED the joints with kappa >= DLT_KAPPA_MAX from the position / score / covariance assertions.  Round 4: the library flags such
 # joints itself (an in-kernel upper bound of kappa at 1e3, reprojection errors near the outlier threshold, wide covariances) and redoes them
-# with the reference's float32 arithmetic — positions and scores are asserted on EVERY valid joint, and what is left of kappa here is
+# with the oracle's restatement of the reference's float32 arithmetic — positions and scores are asserted on EVERY valid joint, and what is left of kappa here is
 #   (i) a check of the library's flag: own-hypothesis joints with kappa >= DLT_KAPPA_MAX must be in se3d_get_exact_list, and
 #   (ii) the covariance tolerance of the joints that stay on the fp64 fast path (cov_tolerance).
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -3,31 +3,67 @@ diverge from the oracle in round 2, 1, 3, 39 with joints more than 1 mm off in r
 round 3 put into an exclusion set), and 104, 203 (a joint with a 90 km covariance, a covariance 1.2 % over the flat tolerance at kappa = 744).
 
 Round 4: NO exclusion set for stage-1 positions and scores — the library sends the joints its fp64 fast path cannot guarantee through a second
-pass with the reference's float32 arithmetic (csrc/se3d_exact32.h) — and the library's flag is itself checked against the inputs
+pass with the oracle's restatement of the reference's float32 arithmetic (csrc/se3d_exact32.h) — and the library's flag is itself checked against the inputs
 (`ill_not_listed`).  tests/fuzz_core.py states what is compared; stage 2 keeps its garbage-person exclusion (tests/parity.py)."""
 import json
 import os
+import subprocess
 import sys
 
 import pytest
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from fuzz_core import run_trials  # noqa: E402
-
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEEDS = [4, 15, 37, 39, 0, 1, 2, 3, 104, 203]
 TRIALS = 40   # 40 scenes x 3 sequences x 12 frames per seed: ~1 440 frames, ~110 k joints, ~1 430 sequence-steps
 
 
 VARIANTS = [(s, "simple", False) for s in SEEDS] + [(5, "h36m", False), (6, "simple", True), (7, "h36m", True)]   # the nodes' other configurations
+LARGE = (1004, "large", False)
+
+
+def _launch(seed, pose_method, norm_height, trials):
+    env = dict(os.environ)
+    if pose_method == "large":
+        env["FUZZ_LARGE"] = "1"
+    elif pose_method != "simple":
+        env["FUZZ_POSE"] = pose_method
+    if norm_height:
+        env["FUZZ_NORM_HEIGHT"] = "1"
+    return subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), str(seed), str(trials)], env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True)
+
+
+@pytest.fixture(scope="module")
+def reports(oracle):   # (the fixture: the oracle library is built before the children import it)
+    """Every run of this module as its own process (tools/fuzz_parity.py: tests/fuzz_core.run_trials, the report on stdout, the violations on stderr),
+    all of them at once: a run is a single host thread of oracle and numpy work around small launches (13 s each, 180 s one after the other in round 4's
+    suite).  A stage-1 index mismatch ends its run with the assertion on stderr."""
+    procs = {v: _launch(*v, TRIALS) for v in VARIANTS}
+    procs[LARGE] = _launch(*LARGE, 8)
+    out = {}
+    for v, p in procs.items():
+        try:
+            so, se = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            so, se = p.communicate()
+        out[v] = (p.returncode, so, se)
+    return out
+
+
+def _report(reports, key):
+    rc, so, se = reports[key]
+    assert rc == 0, se[-3000:]
+    rep = json.loads(so.strip().split("\n")[-1])
+    print(json.dumps({k: v for k, v in rep.items() if k != "tolerances"}))
+    return rep, [ln for ln in se.split("\n") if ln.startswith("violation:")]
 
 
 @pytest.mark.parametrize("seed,pose_method,norm_height", VARIANTS)
-def test_random_scenes_match_the_oracle_on_every_joint(oracle, seed, pose_method, norm_height):
-    rep = run_trials(oracle, seed, TRIALS, pose_method=pose_method, norm_height=norm_height)
-    viol = rep.pop("violations")
-    print(json.dumps(rep))
+def test_random_scenes_match_the_oracle_on_every_joint(reports, seed, pose_method, norm_height):
+    rep, viol = _report(reports, (seed, pose_method, norm_height))
     assert rep["frames"] == TRIALS * 36 and rep["joints"] > 50_000
     # stage 1: every valid joint (positions < 1 mm, scores bit-equal, covariances inside parity.cov_tolerance); nothing excluded
     assert rep["joints_over_1mm"] == 0 and rep["scores_over_rtol"] == 0 and rep["cov_over_tol"] == 0, viol[:5]
@@ -43,17 +79,11 @@ def test_random_scenes_match_the_oracle_on_every_joint(oracle, seed, pose_method
     assert rep["excluded_stage2_mismatches"] <= max(1, 0.02 * rep["seq_steps_excluded"]), rep
 
 
-def test_large_rig_scenes_match_the_oracle_on_every_joint():
+def test_large_rig_scenes_match_the_oracle_on_every_joint(reports):
     """The same comparison on rigs of 32 / 48 cameras with 12 - 24 persons (FUZZ_LARGE=1: the rows pair kernel with camera-column chunks, the
-    per-camera sweep launches, the per-joint triangulation kernel, the per-step stage 2), run as the tool in a child process because the
-    scene sizes are module constants of tests/fuzz_scenes.py; 40 such seeds run in tools/fuzz_sweep.sh."""
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FUZZ_LARGE="1")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "1004", "8"], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    rep = json.loads(out.stdout.strip().split("\n")[-1])
-    print(json.dumps({k: v for k, v in rep.items() if k != "tolerances"}))
+    per-camera sweep launches, the per-joint triangulation kernel, the per-step stage 2; the scene sizes are module constants of
+    tests/fuzz_scenes.py read from the environment); 40 such seeds run in tools/fuzz_sweep.sh."""
+    rep, _ = _report(reports, LARGE)
     assert rep["frames"] == 48 and rep["joints"] > 10_000
     assert rep["joints_over_1mm"] == 0 and rep["scores_over_rtol"] == 0 and rep["cov_over_tol"] == 0
     assert rep["joints_excluded"] == 0 and rep["ill_not_listed"] == 0
