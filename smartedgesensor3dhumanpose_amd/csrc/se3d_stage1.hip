@@ -437,7 +437,7 @@ __device__ __forceinline__ float se3d_safe_rcp(float b) {
 #define RB_JH 6
 #endif
 #define RB_JLAST (SE3D_NKP % RB_JH ? SE3D_NKP % RB_JH : RB_JH)   // joints of the last phase
-struct __align__(16) RowOp { float lx, ly, lz, nrm, x, y, rcp, w; };
+struct __align__(16) RowOp { float lx, ly, lz, nrm, x, y, rcp, z; };   // z: the point's homogeneous coordinate, 1 (usable) or 0
 
 // a / b, correctly rounded, from y = RN(1 / b) (see above): 3 instructions
 __device__ __forceinline__ float se3d_div_shared(float a, float b, float y) {
@@ -446,7 +446,7 @@ __device__ __forceinline__ float se3d_div_shared(float a, float b, float y) {
   return __builtin_fmaf(r, y, q0);
 }
 
-// Operand of one (detection, joint): epipolar line, |(lx, ly)|, its reciprocal, the point, the validity weight.  sqrtf and 1 / nrm are the
+// Operand of one (detection, joint): epipolar line, |(lx, ly)|, its reciprocal, the point (x, y, z = 1; all zero when the joint is unusable).  sqrtf and 1 / nrm are the
 // IEEE results: inside the range in which the instruction-level cores are the IEEE sequences (se3d_sqrt_core / se3d_div_core, checked by
 // se3d_selftest_exact_math) the cores, else the library calls.
 __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float px, float py, bool valid, bool &unsafe) {
@@ -463,15 +463,17 @@ __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float 
     o.rcp = se3d_safe_rcp(o.nrm);
   }
   o.x = px; o.y = py;
-  o.w = valid ? 1.f : 0.f;
+  o.z = valid ? 1.f : 0.f;
   // Range guard of the shared-reciprocal quotient: an operand outside it is marked by rcp = 0 (a usable operand's reciprocal is never 0); the
   // wavefronts that meet one take the IEEE-divide form for that phase.  Both forms give the correctly rounded quotients, hence the same bits, so
   // the choice need not be uniform over the workgroup (rounds 2 - 4 kept block-wide flags in LDS: one more LDS round trip per phase).
   const bool bad = valid && !(o.rcp != 0.f && se3d_all_in_safe_range(lx, ly, lz, px, py));
   unsafe |= bad;
   if (bad) o.rcp = 0.f;
-  // An unusable (detection, joint) is all zeros with a unit norm: every distance it is the LINE or the POINT of comes out as exactly 0, so the
-  // item needs the other side's weight only: d1 * w_b + d2 * w_a (one FMA) instead of (d1 + d2) * (w_a * w_b).  The IEEE-divide path
+  // An unusable (detection, joint) is all zeros — line, point AND the point's homogeneous coordinate z — with a unit norm.  The item forms the
+  // numerators as |p.x l.x + (p.y l.y + p.z l.z)|: with p.z = 1 the FMA p.z l.z + t rounds exactly like the reference's addition l.z + t, and with
+  // either side unusable BOTH numerators are exactly 0 (zero point x finite line, finite point x zero line), so the item is d1 + d2 — no validity
+  // weights (rounds 2 - 5a spent a multiply and an FMA on d1 * w_b + d2 * w_a: 18 -> 17 vector instructions per item).  The IEEE-divide path
   // (se3d_rows_compute_slow) selects by the validity masks and never divides by this norm for a masked joint's contribution.
   if (!valid) { o.lx = 0.f; o.ly = 0.f; o.lz = 0.f; o.x = 0.f; o.y = 0.f; o.nrm = 1.f; o.rcp = 1.f; }
   return o;
@@ -496,10 +498,10 @@ __device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS_P], c
     for (int jj = 0; jj < JN; ++jj) {
       const bool last_j = jj + 1 == JN, last_r = r + 1 == RB_WPAIRS;
       const RowOp an = A[last_j ? jbase : jbase + jj + 1][last_j ? (last_r ? row0 : row + 2) : row];
-      const float n1 = fabsf(b[jj].x * a.lx + (b[jj].y * a.ly + a.lz));
-      const float n2 = fabsf(a.x * b[jj].lx + (a.y * b[jj].ly + b[jj].lz));
+      const float n1 = fabsf(b[jj].x * a.lx + __builtin_fmaf(b[jj].z, a.lz, b[jj].y * a.ly));   // z = 1: RN(a.lz + t), the reference's addition
+      const float n2 = fabsf(a.x * b[jj].lx + __builtin_fmaf(a.z, b[jj].lz, a.y * b[jj].ly));
       const float d1 = se3d_div_shared(n1, a.nrm, a.rcp), d2 = se3d_div_shared(n2, b[jj].nrm, b[jj].rcp);
-      const float sacc = __builtin_fmaf(d1, b[jj].w, d2 * a.w);   // = d1 + d2 for a joint both sides have, exactly 0 otherwise (se3d_rowop)
+      const float sacc = d1 + d2;   // exactly 0 unless both sides have the joint (se3d_rowop)
       acc[r] += (double)sacc;
       asm volatile("" : "+v"(acc[r]) : : "memory");  // the item is complete (accumulated) before the fence; the next item's LDS read comes after it
       a = an;
