@@ -636,7 +636,24 @@ def bench_dlt(args):
     print(json.dumps(line), flush=True)
 
 
-def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out=0):
+def gpu_local_cpus(device):
+    """The CPUs of the NUMA node the GPU's PCIe root hangs on (sysfs `local_cpulist` of its PCI function), restricted to the CPUs this process may
+    use; None when that cannot be read."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device)
+        txt = open("/sys/bus/pci/devices/%04x:%02x:%02x.0/local_cpulist" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)).read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        return cpus or None
+    except Exception:
+        return None
+
+
+def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out=0, affinity="local"):
     """PCIe-inclusive rate (never `value`): every step each context receives its batch of frames from HOST memory (se3d_stream_submit:
     ragged payload into pinned memory, H2D on a copy stream, expansion on the device, stage 1, stage-2 walk, device compaction of the
     published persons, D2H) and hands the published fused / predicted persons back in host memory (se3d_stream_collect); two batches per
@@ -648,6 +665,11 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
     B = S_ * T_
     nodes, prepared = [], []
     in_bytes = 0
+    # host side of a host-fed deployment: the feeding threads (and the pinned buffers they first touch) on the NUMA node of the GPU's PCIe root, so
+    # that neither the copy into pinned memory nor the DMA out of it crosses the socket interconnect (affinity="none": wherever the scheduler puts them)
+    all_cpus, local = os.sched_getaffinity(0), (gpu_local_cpus(local_rank) if affinity == "local" else None)
+    if local:
+        os.sched_setaffinity(0, local)
     for seqs in seqs_per_ctx:
         frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
         nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank, options=dict(stream_out=stream_out))
@@ -690,8 +712,11 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
         th.join()
     for nd_ in nodes:
         nd_.close()
+    if local:
+        os.sched_setaffinity(0, all_cpus)
     n_skel = sum(c[0] for c in counts)
     return {"value": n_skel / dt, "ms_per_step": dt / steps * 1e3, "contexts": NC, "sequences_per_context": S_, "steps": steps,
+            "host_threads": ("on the %d CPUs of the GPU's NUMA node" % len(local)) if local else "unpinned",
             "h2d_gb_per_s": in_bytes * steps / dt / 1e9, "d2h_gb_per_s": sum(c[1] for c in counts) / dt / 1e9,
             "h2d_mb_per_step": in_bytes / 1e6, "skeletons_per_step": n_skel // steps}
 
@@ -867,6 +892,7 @@ def main():
     ap.add_argument("--no-streaming", action="store_true", help="skip the PCIe-inclusive streaming measurement (value_streaming) of a default run")
     ap.add_argument("--stream-out", type=int, default=0, choices=[0, 1], help="se3d_options.stream_out of the streaming measurement: 0 = device buffers + D2H copies (default), "
                     "1 = the compaction kernel writes the published persons into pinned host memory")
+    ap.add_argument("--stream-affinity", choices=["local", "none"], default="local", help="streaming pass: host threads on the GPU's NUMA node (sysfs local_cpulist) or unpinned")
     ap.add_argument("--stream-contexts", type=int, default=8, help="contexts of the streaming measurement (each pins two batches of host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-only", action="store_true", help="only the B = 1 latency block (one 16cam6p frame per call), printed as its own JSON line")
@@ -990,7 +1016,7 @@ def main():
         run_secondary()
     streaming = None
     if default_run and not args.no_streaming and stage2 and rank == 0:
-        streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps // 2), 2, local_rank, args.stream_out)
+        streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps // 2), 2, local_rank, args.stream_out, args.stream_affinity)
     # ---- latency mode of north_star config 5, LAST and guarded: one 256cam128p stream with its hypotheses sharded over the ranks.  Every
     # measurement of the line above is already taken; an exception here is reported in the block, and a collective that does not return
     # within the deadline (ranks != 0 wait in it while rank 0 runs its serial / streaming passes: minutes at most) ends the run with the
@@ -1075,7 +1101,7 @@ def main():
             line["value_streaming"] = round(streaming["value"], 2)
             line["streaming"] = {"value": round(streaming["value"], 2), "unit": "skeletons/s", "fraction_of_resident": round(streaming["value"] / main_res["value_per_gpu"], 4),
                                  "ms_per_step": round(streaming["ms_per_step"], 3), "contexts": streaming["contexts"], "sequences_per_context": streaming["sequences_per_context"],
-                                 "h2d_GB_per_s": round(streaming["h2d_gb_per_s"], 2), "d2h_GB_per_s": round(streaming["d2h_gb_per_s"], 2),
+                                 "h2d_GB_per_s": round(streaming["h2d_gb_per_s"], 2), "d2h_GB_per_s": round(streaming["d2h_gb_per_s"], 2), "host_threads": streaming["host_threads"],
                                  "h2d_MB_per_step": round(streaming["h2d_mb_per_step"], 1), "n_gpus": 1,
                                  "note": "PCIe-inclusive: every step's frames come from host memory (ragged, pinned, double-buffered) and the published "
                                          "persons go back to host memory; never `value`.  At 16cam6p a frame is ~40 KB in and ~20 KB out: PCIe Gen5 x16 "
