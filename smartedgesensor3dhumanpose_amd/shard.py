@@ -154,6 +154,8 @@ class SkeletonExchange:
         self.cnts = [torch.zeros(self.n_ctx * self.sc, dtype=torch.int32, device=device) for _ in range(2)]
         self.gath_p = [torch.empty(self.world * self.n_ctx * self.sp, dtype=torch.uint8, device=device) for _ in range(2)]
         self.gath_c = [torch.empty(self.world * self.n_ctx * self.sc, dtype=torch.int32, device=device) for _ in range(2)]
+        if self.cuda:   # torch.zeros fills on torch's current stream; the contexts' streams are non-blocking and would not wait for that fill
+            torch.cuda.current_stream(device).synchronize()
         self.works = [None, None]
         self.events = [None] * self.n_ctx
         self.parity = 0
@@ -288,6 +290,8 @@ class HypothesisShard:
         self.g1 = torch.zeros(b1 * self.world, dtype=torch.uint8, device=device)
         self.p2 = torch.zeros(b2, dtype=torch.uint8, device=device)
         self.g2 = torch.zeros(b2 * self.world, dtype=torch.uint8, device=device)
+        if self.p1.is_cuda:   # the zero fills run on torch's current stream, which the context's non-blocking stream does not wait for
+            torch.cuda.current_stream(device).synchronize()
         self.bytes_per_step = (b1 + n_frames // max(n_seq, 1) * b2) * self.world
 
     def run_stage1(self):

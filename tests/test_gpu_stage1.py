@@ -202,6 +202,23 @@ def test_pair_cost_table_is_bit_exact(extr_rig, oracle, demo_params, mode):
     node.close()
 
 
+def test_create_waits_for_its_own_fills(extr_rig):
+    """se3d_create zero-fills the resident detection arrays with hipMemset on the NULL stream, which returns before the fill has run, and the
+    context's stream is non-blocking (it does not wait for the null stream).  Until round 5 nothing ordered that fill before the first upload: with
+    the null stream busy — here a one-second spin queued on it, in round 5's suite fourteen processes sharing the GPU — the fill landed AFTER
+    se3d_stage_frames had uploaded the detection counts, and the pass saw a frame set without detections (FLAG_FEW_CAMERAS, no persons)."""
+    import torch
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=2, seed=11))
+    torch.cuda._sleep(2_000_000_000)   # ~1 s on torch's default (= the null) stream, asynchronous
+    node = _node(extr_rig, max_frames=2, max_det_per_cam=8, max_hyp=32)   # its fills queue behind the spin
+    res = node.triangulate_persons(frames)
+    torch.cuda.synchronize()
+    again = node.triangulate_persons(frames)
+    node.close()
+    for g, h in zip(res, again):
+        assert g.flags == 0 and g.n_persons >= 5 and g.n_persons == h.n_persons and g.n_hyp == h.n_hyp, (g.flags, g.n_persons, h.n_persons)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_stage1_parity_16cam_6p(node16, extr_rig, oracle, demo_params, seed):
     frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=4, seed=seed))
