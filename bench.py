@@ -1016,7 +1016,7 @@ def main():
         run_secondary()
     streaming = None
     if default_run and not args.no_streaming and stage2 and rank == 0:
-        streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps // 2), 2, local_rank, args.stream_out, args.stream_affinity)
+        streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps), 2, local_rank, args.stream_out, args.stream_affinity)   # ~0.7 s timed at the default 20 steps
     # ---- latency mode of north_star config 5, LAST and guarded: one 256cam128p stream with its hypotheses sharded over the ranks.  Every
     # measurement of the line above is already taken; an exception here is reported in the block, and a collective that does not return
     # within the deadline (ranks != 0 wait in it while rank 0 runs its serial / streaming passes: minutes at most) ends the run with the
