@@ -1024,7 +1024,10 @@ __device__ __forceinline__ double se3d_rcp64(double x) {
                                // (5e-7: same covariances to all printed digits, 2 % slower; 3e-5: the outlier scenes' covariance error grows from 7e-5 to 5e-4)
 #define SE3D_MAIN_PTOL 1e-10   // main solves: update below 1e-10 (1 + |p|_1); the accepted iterate is one contraction (lambda_4 / lambda_3 <= ~1e-2) better, i.e.
                                // <= 1e-12 and typically 1e-14 .. 1e-16: converged for a point that is published as float32 (1e-13 cost one more step for nothing)
-template <int NW = 1>
+// MAXIT: steps allowed.  The main solves get 12 (round 5): a joint seen by ~120 cameras that carries one or two mismatched views has
+// lambda_4 / lambda_3 ~ 0.05 and needs 9 - 10 steps from (0, 0, 0, 1) to 1e-10; with 8 its solve counted as not settled and the joint — well
+// conditioned, kappa ~ 50 — took the float32 second pass: 59 of the 276 listed joints of four 256cam128p frames (profiles/r5/README.md section 7).
+template <int NW = 1, int MAXIT = 8>
 __device__ __forceinline__ bool se3d_null_invit_point(const double g[10], const double v0[4], double p[3], const double tol = SE3D_SIGMA_PTOL, double *piv = nullptr /* [4]: the LDL^T pivots */) {
   const double tr = g[0] + g[4] + g[7] + g[9];
   const double tiny = 1e-30 * tr;
@@ -1049,7 +1052,7 @@ __device__ __forceinline__ bool se3d_null_invit_point(const double g[10], const 
   double x0 = v0[0], x1 = v0[1], x2 = v0[2], x3 = v0[3];
   double q0 = 0.0, q1 = 0.0, q2 = 0.0;
   bool conv = false;
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < MAXIT; ++it) {
     const double y0 = x0, y1 = __builtin_fma(-l10, y0, x1), y2 = __builtin_fma(-l21, y1, __builtin_fma(-l20, y0, x2)),
                  y3 = __builtin_fma(-l32, y2, __builtin_fma(-l31, y1, __builtin_fma(-l30, y0, x3)));
     const double w3 = y3 * i3, w2 = __builtin_fma(-l32, w3, y2 * i2), w1 = __builtin_fma(-l31, w3, __builtin_fma(-l21, w2, y1 * i1)),
@@ -1383,7 +1386,7 @@ __device__ __forceinline__ void se3d_tri_joint_body(const Se3dDev &D, int f, int
   double pw[3];
   const double e4start[4] = {0.0, 0.0, 0.0, 1.0};  // the null vector (X, Y, Z, 1)/|.| of a finite point always has a w component
   double piv_[4];
-  const bool conv0 = se3d_null_invit_point<2>(gw_, e4start, pw, SE3D_MAIN_PTOL, piv_);
+  const bool conv0 = se3d_null_invit_point<2, 12>(gw_, e4start, pw, SE3D_MAIN_PTOL, piv_);
   if (!conv0) {
     double e4[4];
     se3d_eig4_smallest(gw_, e4);
@@ -1687,7 +1690,7 @@ __global__ __launch_bounds__(64, TH_WPE) void se3d_k_triangulate_hyp(Se3dDev D) 
     for (int k = 0; k < 10; ++k) gw_[k] = S.G[lane][10 + k];
     const double e4start[4] = {0.0, 0.0, 0.0, 1.0};
     double piv_[4];
-    if (!se3d_null_invit_point<2>(gw_, e4start, pw, SE3D_MAIN_PTOL, piv_)) {
+    if (!se3d_null_invit_point<2, 12>(gw_, e4start, pw, SE3D_MAIN_PTOL, piv_)) {
       double e4[4];
       se3d_eig4_smallest(gw_, e4);
       const double iw = se3d_rcp64<2>(e4[3]);
