@@ -123,32 +123,33 @@ __global__ __launch_bounds__(256) void se3d_k_normalize(Se3dDev D, int write_kp)
   if (tid == 0) D.nvalid[f * N + c] = s_nvalid;
 }
 
-// ---- correctly rounded float32 square root and quotient without the special-case scaffolding -------------------------------------------------
+// ---- correctly rounded float32 square root, reciprocal and quotient without the special-case scaffolding --------------------------------------
 // sqrtf(x) and a / b compile to the IEEE sequences of the AMDGPU back end: v_sqrt_f32 + a one-ulp correction from two FMA residuals, and
 // v_rcp_f32 + six FMA / multiply refinements — wrapped in operand scaling (v_div_scale_f32, x * 2^32), v_div_fmas / v_div_fixup and class
-// tests for denormal, huge, zero and infinite operands: 16 and ~14 instructions where the arithmetic core is 9 and 8.  The pair cost needs
-// two of each per (entry, joint) — 60 of its ~105 instructions.  The cores below are the SAME operation sequences, so inside the operand
-// range in which the scaffolding is the identity (se3d_pair_ops_in_range: everything within [2^-60, 2^60], numerators also zero) they return
-// the same bits; outside it the caller takes the IEEE expressions.  se3d_selftest_exact_math (C-ABI, tests/test_gpu_stage1.py) checks the
-// square root on EVERY float of the range and the quotient on 2^33 operand pairs against sqrtf / operator/ on the device.
-__device__ __forceinline__ float se3d_sqrt_core(float x) {
-  float s = __builtin_amdgcn_sqrtf(x);
-  const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1), su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
-  const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
-  s = rd <= 0.f ? sd : s;
-  s = ru > 0.f ? su : s;
-  return s;
+// tests for denormal, huge, zero and infinite operands: 16 and ~14 instructions.  The pair cost needs two of each per (entry, joint).
+// Rounds 2 - 4 used the arithmetic cores of those sequences (9 + 8 instructions and two transcendental ones per distance n / sqrtf(s)).
+// Round 5: ONE v_rsq_f32 and 9 more instructions per distance, each step decided by enumeration or by a theorem:
+//   * y = rsq(s); s0 = s y; h = y / 2; root = fma(fma(-s0, s0, s), h, s0) — one Newton correction of a 1-ulp estimate — returns sqrtf(s) on
+//     EVERY float in [2^-60, 2^60] (1 006 632 961 values; the same with v_sqrt_f32 and a reciprocal as the correction's factor fails on 60);
+//   * rcp = fma(fma(-root, y, 1), y, y) — one Newton step on the same seed — is RN(1 / root) for every one of those radicands except the 120
+//     whose root has an all-ones significand (1 / root lies 2^-24 ulp from a rounding boundary there);
+//   * the quotient is the rows kernel's se3d_div_shared on that reciprocal: q0 = RN(n rcp), r = fma(-root, q0, n), q = fma(r, rcp, q0) — the
+//     correctly rounded n / root by the one-correction theorem stated above se3d_k_pairs_rows (root not all ones; here root in [2^-30, 2^30]
+//     and n zero or in [2^-60, 2^60], so q0 and the residual's quantum 2^-46 n stay normal).
+// (The back end's refinement seeded with y instead of v_rcp_f32 — two instructions fewer than rounds 2 - 4, no reciprocal — matched a / b on
+// 2^34 random operand pairs and FAILS on 14 278 numerators against all-ones roots: tools/microbench/div_rsq_seed.hip.  Random pairs do not
+// decide such a sequence.)  se3d_selftest_exact_math runs the two enumerations on the device (tests/test_gpu_stage1.py),
+// tools/microbench/sqrt_candidates.hip holds the candidates that were compared.  Inside the operand range in which the scaffolding is the identity
+// (se3d_pair_ops_in_range) and for roots that are not all ones these return the bits of the IEEE expressions; otherwise the callers take the
+// IEEE expressions themselves.
+__device__ __forceinline__ float se3d_sqrt_rcp_core(float x, float &rcp) {   // returns sqrtf(x); rcp = RN(1 / sqrtf(x)) unless the root is all ones
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float s0 = x * y, h = 0.5f * y;
+  const float b = __builtin_fmaf(__builtin_fmaf(-s0, s0, x), h, s0);
+  rcp = __builtin_fmaf(__builtin_fmaf(-b, y, 1.f), y, y);
+  return b;
 }
-__device__ __forceinline__ float se3d_div_core(float a, float b) {
-  const float r0 = __builtin_amdgcn_rcpf(b);
-  const float e0 = __builtin_fmaf(-b, r0, 1.f);
-  const float r1 = __builtin_fmaf(e0, r0, r0);
-  const float q0 = a * r1;
-  const float e1 = __builtin_fmaf(-b, q0, a);
-  const float q1 = __builtin_fmaf(e1, r1, q0);
-  const float e2 = __builtin_fmaf(-b, q1, a);
-  return __builtin_fmaf(e2, r1, q1);
-}
+__device__ __forceinline__ bool se3d_all_ones(float b) { return (__float_as_uint(b) & 0x7fffffu) == 0x7fffffu; }
 #define SE3D_EXACT_LO 0x21800000u   // 2^-60
 #define SE3D_EXACT_HI 0x5d800000u   // 2^60
 // s1, s2: arguments of the square roots (their roots, in [2^-30, 2^30], are the divisors); n1, n2 >= 0: the numerators.  Non-negative floats
@@ -158,9 +159,14 @@ __device__ __forceinline__ bool se3d_pair_ops_in_range(float s1, float s2, float
   const unsigned hi = max(max(a, b), max(c, d)), lo_s = min(a, b), lo_n = min(c - 1u, d - 1u);
   return hi <= SE3D_EXACT_HI && lo_s >= SE3D_EXACT_LO && lo_n >= SE3D_EXACT_LO - 1u;
 }
+__device__ __forceinline__ float se3d_div_shared(float a, float b, float y);   // a / b from y = RN(1 / b): defined with the rows kernel
 // d1 + d2 of one joint of one (det_a, det_b) pair: the two point-to-epipolar-line distances (S3D:358-361)
 __device__ __forceinline__ float se3d_pair_joint_dist(float n1, float s1, float n2, float s2) {
-  if (se3d_pair_ops_in_range(s1, s2, n1, n2)) return se3d_div_core(n1, se3d_sqrt_core(s1)) + se3d_div_core(n2, se3d_sqrt_core(s2));
+  if (se3d_pair_ops_in_range(s1, s2, n1, n2)) {
+    float y1, y2;
+    const float b1 = se3d_sqrt_rcp_core(s1, y1), b2 = se3d_sqrt_rcp_core(s2, y2);
+    if (!(se3d_all_ones(b1) || se3d_all_ones(b2))) return se3d_div_shared(n1, b1, y1) + se3d_div_shared(n2, b2, y2);
+  }
   return n1 / sqrtf(s1) + n2 / sqrtf(s2);
 }
 
@@ -417,7 +423,7 @@ __device__ __forceinline__ float se3d_safe_rcp(float b) {
 //   * the row tiles of a camera are BALANCED (ceil(n_a / 48) tiles of equal size, the rows of a tile dealt evenly to the four wavefronts): the
 //     bench scenes hold 65 - 110 detections per camera (mean 90, not 128), and 40 % of the cameras used to need a third tile of <= 14 rows whose
 //     workgroup staged the whole det_b side for one busy wavefront;
-//   * an operand's sqrtf and 1 / nrm are the instruction-level cores of the IEEE sequences inside their range (se3d_sqrt_core, se3d_div_core):
+//   * an operand's sqrtf and 1 / nrm are the instruction-level cores of the IEEE sequences inside their range (se3d_sqrt_rcp_core):
 //     staging is a quarter of the kernel's vector instructions (the det_b side is staged once per row tile).
 // What did NOT pay (measured, same section): one row x 64 columns per wavefront with the validity as scalar branch + lane mask (19 instead of 22
 // instructions per item, but 64-column tiles compute 128 columns for every camera: 20.3 ms), and one 512-thread workgroup per camera pair with
@@ -447,7 +453,7 @@ __device__ __forceinline__ float se3d_div_shared(float a, float b, float y) {
 }
 
 // Operand of one (detection, joint): epipolar line, |(lx, ly)|, its reciprocal, the point (x, y, z = 1; all zero when the joint is unusable).  sqrtf and 1 / nrm are the
-// IEEE results: inside the range in which the instruction-level cores are the IEEE sequences (se3d_sqrt_core / se3d_div_core, checked by
+// IEEE results: inside the range in which the instruction-level cores are the IEEE sequences (se3d_sqrt_rcp_core, checked by
 // se3d_selftest_exact_math) the cores, else the library calls.
 __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float px, float py, bool valid, bool &unsafe) {
   RowOp o;
@@ -456,8 +462,9 @@ __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float 
   const float ss = valid ? lx * lx + ly * ly : 1.f;
   const unsigned us = __float_as_uint(ss);
   if (us >= SE3D_EXACT_LO && us <= SE3D_EXACT_HI) {   // then nrm lies in [2^-30, 2^30]: se3d_safe_rcp's exponent test holds
-    o.nrm = se3d_sqrt_core(ss);
-    o.rcp = (__float_as_uint(o.nrm) & 0x7fffffu) != 0x7fffffu ? se3d_div_core(1.f, o.nrm) : 0.f;
+    float y;
+    o.nrm = se3d_sqrt_rcp_core(ss, y);
+    o.rcp = se3d_all_ones(o.nrm) ? 0.f : y;
   } else {
     o.nrm = sqrtf(ss);
     o.rcp = se3d_safe_rcp(o.nrm);
@@ -2800,26 +2807,31 @@ static size_t se3d_sweep_wave_lds_bytes(int N, int P, int H) {
   return (size_t)H * P * 16 + (size_t)N * P * 4 + (size_t)H * N * 4 + (size_t)H * 4 + (size_t)N * 8 + (((size_t)H * P + 15) & ~(size_t)15) + 16 + (size_t)(2 * N + 1) * 8;
 }
 
-// Self-test of se3d_sqrt_core / se3d_div_core against the IEEE expressions on the device (se3d_selftest_exact_math).
-// out[0]: square-root mismatches over every float in [2^-60, 2^60]; out[1]: quotient mismatches over n_div pseudo-random operand pairs
-// (numerator zero every 64th pair, both operands anywhere in the range).
+// Self-test of se3d_sqrt_rcp_core / se3d_pair_joint_dist against the IEEE expressions on the device (se3d_selftest_exact_math).
+// out[0]: square-root and reciprocal-of-the-root mismatches over every float in [2^-60, 2^60]; out[1]: mismatches of n / sqrtf(s) over n_div
+// pseudo-random operand pairs.
 __global__ __launch_bounds__(256) void se3d_k_selftest_exact_math(unsigned long long *out, unsigned long long n_div) {
   const unsigned long long tid = (unsigned long long)blockIdx.x * 256 + threadIdx.x, nthr = (unsigned long long)gridDim.x * 256;
   unsigned long long bad_s = 0, bad_d = 0;
   for (unsigned long long u = SE3D_EXACT_LO + tid; u <= SE3D_EXACT_HI; u += nthr) {
     const float x = __uint_as_float((unsigned)u);
-    bad_s += __float_as_uint(se3d_sqrt_core(x)) != __float_as_uint(sqrtf(x));
+    float y;
+    const float r = se3d_sqrt_rcp_core(x, y);
+    bad_s += __float_as_uint(r) != __float_as_uint(sqrtf(x));
+    bad_s += !se3d_all_ones(r) && __float_as_uint(y) != __float_as_uint(1.f / r);   // the shared reciprocal RN(1 / root)
   }
   const unsigned span = SE3D_EXACT_HI - SE3D_EXACT_LO + 1u;
   for (unsigned long long i = tid; i < n_div; i += nthr) {
     unsigned long long z = (i + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;   // splitmix64
     z ^= z >> 30; z *= 0x94D049BB133111EBull; z ^= z >> 27; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 31;
-    float a = __uint_as_float(SE3D_EXACT_LO + (unsigned)(z & 0xffffffffull) % span);
-    // divisors as the pair cost has them (roots: [2^-30, 2^30]) on odd i, anywhere in the range on even i
-    const unsigned bs = (unsigned)(z >> 32) % span;
-    float b = __uint_as_float(SE3D_EXACT_LO + ((i & 1ull) ? (0x30800000u - SE3D_EXACT_LO) + bs % (0x4e800000u - 0x30800000u + 1u) : bs));
+    // the distance n / sqrtf(s) as the pair cost forms it: s anywhere in the range (its root is the divisor), the numerator zero every 64th
+    // pair, within 2^12 of the root's magnitude on every third pair (quotients around the binade boundary), else anywhere in the range
+    const float sq = __uint_as_float(SE3D_EXACT_LO + (unsigned)(z >> 32) % span);
+    const float b = sqrtf(sq);
+    float a = (i % 3ull == 0ull) ? __uint_as_float((__float_as_uint(b) & 0x7f800000u) - (12u << 23) + (unsigned)z % (24u << 23))
+                                 : __uint_as_float(SE3D_EXACT_LO + (unsigned)(z & 0xffffffffull) % span);
     if ((i & 63ull) == 63ull) a = 0.f;
-    bad_d += __float_as_uint(se3d_div_core(a, b)) != __float_as_uint(a / b);
+    bad_d += __float_as_uint(se3d_pair_joint_dist(a, sq, 0.f, 1.f)) != __float_as_uint(a / b + 0.f / 1.f);
   }
   if (bad_s) atomicAdd(&out[0], bad_s);
   if (bad_d) atomicAdd(&out[1], bad_d);

@@ -375,9 +375,11 @@ def test_postprocess_forms_agree_bytewise(extr_rig):
 
 
 def test_exact_sqrt_and_divide_cores_match_ieee_on_the_device(extr_rig):
-    """The pair-cost kernels take sqrtf and operator/ of calcCost (S3D:358-361) as the arithmetic cores of the IEEE sequences inside
-    [2^-60, 2^60] (csrc/se3d_stage1.hip: se3d_sqrt_core / se3d_div_core): exhaustive for the square root (1.0e9 floats), 2^33 operand
-    pairs for the quotient (every 64th numerator zero; divisors half in the roots' range, half anywhere) — bit for bit."""
+    """The pair-cost kernels form calcCost's n / sqrtf(s) (S3D:358-361) inside [2^-60, 2^60] from ONE v_rsq_f32 (csrc/se3d_stage1.hip:
+    se3d_sqrt_rcp_core — the root by one Newton correction of s * rsq(s), its reciprocal by one Newton step on the same seed — and the
+    one-correction quotient se3d_div_shared): on the device, every float of the range for the root (== sqrtf) and for the reciprocal
+    (== 1 / root unless the root's significand is all ones, which the kernels send through the IEEE expressions), and 2^33 (numerator,
+    radicand) pairs for the distance (every 64th numerator zero, a third within 2^12 of the root's magnitude) — bit for bit."""
     node = _node(extr_rig, max_frames=1, max_det_per_cam=8, max_hyp=8)
     bad_sqrt, bad_div = node.selftest_exact_math(1 << 33)
     node.close()
