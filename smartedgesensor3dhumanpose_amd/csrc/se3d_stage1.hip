@@ -1168,18 +1168,29 @@ __device__ __forceinline__ void se3d_tri_list_push(const Se3dDev &D, int f, int 
   D.tri_list[at] = ((uint32_t)(f * D.d.H + h) << 5) | (uint32_t)j;
 }
 
+// 1.0f / sqrtf(z), both IEEE: from se3d_sqrt_rcp_core inside its range, else the expressions themselves
+__device__ __forceinline__ float se3d_rsqrt_exact(float z) {
+  const unsigned u = __float_as_uint(z);
+  if (u >= SE3D_EXACT_LO && u <= SE3D_EXACT_HI) {
+    float inv;
+    const float root = se3d_sqrt_rcp_core(z, inv);
+    if (!se3d_all_ones(root)) return inv;
+  }
+  return 1.0f / sqrtf(z);
+}
 // rows of the DLT system for one view: r0 = normalize(x*P2 - P0), r1 = normalize(y*P2 - P1)  (float, S3D:446-449)
 __device__ __forceinline__ void se3d_dlt_rows(const float *__restrict__ M, float x, float y, float r0[4], float r1[4]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) { r0[k] = x * M[8 + k] - M[k]; r1[k] = y * M[8 + k] - M[4 + k]; }
   // L2 normalisation (S3D:448-449): one correctly rounded reciprocal per row and four multiplies instead of four IEEE divides
   // (<= 1 ulp of float per component, 5 orders of magnitude below the 1 mm parity tolerance on the triangulated point)
+  // (round 5: 1.0f / sqrtf(z) from one v_rsq_f32 where se3d_sqrt_rcp_core is the IEEE result — z in [2^-60, 2^60], root not all ones)
   const float z0 = (r0[0] * r0[0] + r0[1] * r0[1]) + (r0[2] * r0[2] + r0[3] * r0[3]);
-  if (z0 > 0.f) { const float inv = 1.0f / sqrtf(z0);
+  if (z0 > 0.f) { const float inv = se3d_rsqrt_exact(z0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) r0[k] = r0[k] * inv; }
   const float z1 = (r1[0] * r1[0] + r1[1] * r1[1]) + (r1[2] * r1[2] + r1[3] * r1[3]);
-  if (z1 > 0.f) { const float inv = 1.0f / sqrtf(z1);
+  if (z1 > 0.f) { const float inv = se3d_rsqrt_exact(z1);
 #pragma unroll
     for (int k = 0; k < 4; ++k) r1[k] = r1[k] * inv; }
 }
@@ -1243,8 +1254,12 @@ __device__ __forceinline__ float se3d_reproj1(const float *__restrict__ M, float
   const float hx = (M[0] * X + (M[1] * Y + M[2] * Z)) + M[3];
   const float hy = (M[4] * X + (M[5] * Y + M[6] * Z)) + M[7];
   const float hz = (M[8] * X + (M[9] * Y + M[10] * Z)) + M[11];
-  const float dx = hx / hz - px, dy = hy / hz - py;
-  return sqrtf(dx * dx + dy * dy);
+  // Hardware reciprocal and square root (1 ulp each) instead of two IEEE divisions and an IEEE root (round 5): this error only meets thresholds —
+  // the outlier gate with its 1 % guard band (SE3D_EXACT_ERR_GUARD: everything within it goes to the float32 second pass, which forms its own
+  // errors with the reference's expressions) — and never reaches a published number.  hz = 0: infinite / NaN error, i.e. the second pass.
+  const float iz = __builtin_amdgcn_rcpf(hz);
+  const float dx = hx * iz - px, dy = hy * iz - py;
+  return __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
 }
 
 // The 2x2 keypoint covariance in normalised image coordinates and its lower Cholesky factor (S3D:476-480).  They feed only the sigma offsets
