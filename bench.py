@@ -678,6 +678,7 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
         prepared.append(nd_.stream_prepare(frames))
         in_bytes += sum(int(f.det_offset[-1]) for f in frames) * 428
     counts = [[0, 0] for _ in nodes]   # published persons, bytes out per context (timed region)
+    step_ms = []
     go, done = threading.Barrier(NC + 1), threading.Barrier(NC + 1)
 
     def worker(ci):
@@ -694,11 +695,16 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
             submit()
             nd_.stream_collect(copy=False)
         go.wait()
+        t_prev = time.perf_counter()
         for _ in range(steps):
             submit()
             off, fused, _pred = nd_.stream_collect(copy=False)
             counts[ci][0] += int(off[-1])
             counts[ci][1] += 2 * int(off[-1]) * 1688 + 4 * len(off)
+            if ci == 0:   # context 0's step times: tells a uniformly slow run (both copy directions at ~60 %: one run in ten, cause open) from a transient
+                t_now = time.perf_counter()
+                step_ms.append(round((t_now - t_prev) * 1e3, 2))
+                t_prev = t_now
         nd_.stream_collect(copy=False)
         done.wait()
     threads = [threading.Thread(target=worker, args=(ci,)) for ci in range(NC)]
@@ -716,7 +722,7 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
         os.sched_setaffinity(0, all_cpus)
     n_skel = sum(c[0] for c in counts)
     return {"value": n_skel / dt, "ms_per_step": dt / steps * 1e3, "contexts": NC, "sequences_per_context": S_, "steps": steps,
-            "host_threads": ("on the %d CPUs of the GPU's NUMA node" % len(local)) if local else "unpinned",
+            "host_threads": ("on the %d CPUs of the GPU's NUMA node" % len(local)) if local else "unpinned", "step_ms_context0": step_ms,
             "h2d_gb_per_s": in_bytes * steps / dt / 1e9, "d2h_gb_per_s": sum(c[1] for c in counts) / dt / 1e9,
             "h2d_mb_per_step": in_bytes / 1e6, "skeletons_per_step": n_skel // steps}
 
@@ -1101,7 +1107,7 @@ def main():
             line["value_streaming"] = round(streaming["value"], 2)
             line["streaming"] = {"value": round(streaming["value"], 2), "unit": "skeletons/s", "fraction_of_resident": round(streaming["value"] / main_res["value_per_gpu"], 4),
                                  "ms_per_step": round(streaming["ms_per_step"], 3), "contexts": streaming["contexts"], "sequences_per_context": streaming["sequences_per_context"],
-                                 "h2d_GB_per_s": round(streaming["h2d_gb_per_s"], 2), "d2h_GB_per_s": round(streaming["d2h_gb_per_s"], 2), "host_threads": streaming["host_threads"],
+                                 "h2d_GB_per_s": round(streaming["h2d_gb_per_s"], 2), "d2h_GB_per_s": round(streaming["d2h_gb_per_s"], 2), "host_threads": streaming["host_threads"], "step_ms_context0": streaming["step_ms_context0"],
                                  "h2d_MB_per_step": round(streaming["h2d_mb_per_step"], 1), "n_gpus": 1,
                                  "note": "PCIe-inclusive: every step's frames come from host memory (ragged, pinned, double-buffered) and the published "
                                          "persons go back to host memory; never `value`.  At 16cam6p a frame is ~40 KB in and ~20 KB out: PCIe Gen5 x16 "

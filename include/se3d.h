@@ -123,9 +123,9 @@ typedef struct se3d_options {
   int32_t refine_steps;       /* se3d_refine on a one-sequence context: 0 = one fused-walk launch (default), 1 = the five per-step launches */
   int32_t munkres_form;       /* se3d_hungarian: SE3D_MUNKRES_AUTO | _BLOCK | _WAVE */
   int32_t reproj_form;        /* feedback reprojection: 0 = per-camera lists written directly where they fit LDS (default), 1 = dense + scan + compaction */
-  int32_t stream_out;         /* se3d_stream_submit / _collect: 0 = device buffers + D2H copies on the slot's own stream (default), 1 = the compaction kernel
-                                 writes the published persons straight into the pinned host buffers (no copy engine, no host round trip for the size;
-                                 measured equal in round 5: the H2D direction bounds the streaming rate, profiles/r5/README.md) */
+  int32_t stream_out;         /* se3d_stream_submit / _collect: 0 = device buffers + D2H copies on the device's shared download stream (default), 1 = the
+                                 compaction kernel writes the published persons straight into the pinned host buffers (no copy engine; measured slower in
+                                 round 5: 8.3 M against 10 - 11 M skeletons/s, profiles/r5/README.md section 5) */
   int32_t reserved[6];        /* must be 0 */
 } se3d_options;
 #define SE3D_WALK_WAVE 1
@@ -320,7 +320,6 @@ typedef struct se3d_stream_result {
 int se3d_stream_submit(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in *frames, int32_t n_seq, int32_t n_steps, const int32_t *frame_slot0,
                        const double *t);
 int se3d_stream_collect(se3d_ctx *ctx, se3d_stream_result *out);
-
 /* --- feedback reprojection: drop-in for fusedSkeletonCallback (pose_reprojection/src/skeleton_reproj_mult_node.cpp:139-235) --
  * Projects fused/predicted 3D skeletons and their covariances (7-sigma-point unscented transform, :62-75) into every camera and
  * returns one Person2DList payload per camera (topic <cam>/skel_pred).  Cameras in double precision as the node uses them:
