@@ -1,15 +1,23 @@
 #!/bin/bash
 # Blind check of the randomised parity sweep (GPU box): seeds never run before the criteria were frozen (commit 929e612), reported unedited.
 #   bash tools/fuzz_blind.sh [out] [base]   100 runs from seed base + 1 (default base 2000; 3000: the second batch, after the scores became
-#   bit-equal; 5000: round 5, with the stage-2 objective criterion on every sequence-step, criteria frozen at the commit that added it): 70 x default, 10 x h36m, 10 x norm_height (40 scenes each), 10 x large rigs (20 scenes)
+#   bit-equal; 5000: round 5, with the stage-2 objective criterion on every sequence-step, criteria frozen at the commit that added it; 6000: the final code of round 5, after the late arithmetic changes): 70 x default, 10 x h36m, 10 x norm_height (40 scenes each), 10 x large rigs (20 scenes)
 OUT=${1:-gpurun_out/fuzz_blind.log}
 B=${2:-2000}
 mkdir -p "$(dirname "$OUT")"
 : > "$OUT"
-for s in $(seq $((B+1)) $((B+70))); do timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
-for s in $(seq $((B+71)) $((B+80))); do FUZZ_POSE=h36m timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
-for s in $(seq $((B+81)) $((B+90))); do FUZZ_NORM_HEIGHT=1 timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
-for s in $(seq $((B+91)) $((B+100))); do FUZZ_LARGE=1 timeout 600 python tools/fuzz_parity.py $s 20 2>> "$OUT.err" | tail -1 >> "$OUT"; done
+# PAR (default 1): runs side by side (each is one host thread of oracle + numpy work around small launches; 8 at a time: ~4 minutes for the batch)
+PAR=${PAR:-1}
+run() {   # seed trials [ENV=value]
+  local s=$1 n=$2 e=${3:-_X=0}
+  env $e timeout 600 python tools/fuzz_parity.py $s $n 2>> "$OUT.err.$s" | tail -1 > "$OUT.part.$s"
+}
+export -f run; export OUT
+{ for s in $(seq $((B+1)) $((B+70))); do echo "$s 40"; done
+  for s in $(seq $((B+71)) $((B+80))); do echo "$s 40 FUZZ_POSE=h36m"; done
+  for s in $(seq $((B+81)) $((B+90))); do echo "$s 40 FUZZ_NORM_HEIGHT=1"; done
+  for s in $(seq $((B+91)) $((B+100))); do echo "$s 20 FUZZ_LARGE=1"; done; } | xargs -P $PAR -L 1 bash -c 'run $0 $1 $2'
+for s in $(seq $((B+1)) $((B+100))); do cat "$OUT.part.$s" >> "$OUT"; cat "$OUT.err.$s" >> "$OUT.err" 2>/dev/null; rm -f "$OUT.part.$s" "$OUT.err.$s"; done
 python3 - "$OUT" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
