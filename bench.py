@@ -43,6 +43,9 @@ WORKLOADS = {
     # flops per skeleton (association + triangulation/UT covariance, fp32-class); stage 2: 0.74 MFLOP (fp64) per LM iteration (+1 for
     # the marginals).
     "16cam6p": dict(n_cam=16, n_persons=6, seqs=512, contexts=12, max_det=8, max_hyp=12, bytes_s1=8972, bytes_s2=8900, flop_s1=0.12e6 + 1.86e6),
+    # the `robust` block (round 6): the 16cam6p shape on rough scenes (scene.ROUGH: 0.6 % gross 2-D outliers, 8 % missing views, 15 % low-confidence
+    # joints, 2 px noise) — the reference's outlier path (S3D:748-838) and the float32 second pass of the triangulation are hot here
+    "16cam6p_rough": dict(n_cam=16, n_persons=6, seqs=512, contexts=12, max_det=8, max_hyp=16, bytes_s1=8972, bytes_s2=8900, flop_s1=0.12e6 + 1.86e6, rough=True),
     "64cam32p": dict(n_cam=64, n_persons=32, seqs=32, contexts=3, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900, flop_s1=11.0e6 + 7.28e6),
     # 256cam128p: 6 contexts x 4 sequences x 16 frames; the pair table is kept as two camera-column chunks per frame (Se3dPairPlan):
     # 9.4 GB per 16 frames instead of 68.9 GB, 6 x 38.5 GB per GPU.  Contexts (profiles/r4/README.md section 7): 3 -> 26.1 k, 4 -> 26.9 - 27.3 k,
@@ -84,18 +87,26 @@ def make_rig(w):
 
 
 def _gen_one(job):
-    n_cam, n_persons, t_steps, seed = job
+    n_cam, n_persons, t_steps, seed = job[:4]
+    rough = len(job) > 4 and job[4]
     from smartedgesensor3dhumanpose_amd import rig as R, scene as S
     rig = R.extr_rig_16cam() if n_cam == 16 else R.elliptical_rig(n_cam, seed=0)
-    cfg = S.SceneConfig(n_persons=n_persons, n_frames=t_steps, seed=seed, min_coverage=4 if n_cam == 16 else 6)
+    cov = 4 if n_cam == 16 else 6
+    cfg = S.rough_config(n_persons, t_steps, seed, min_coverage=cov) if rough else S.SceneConfig(n_persons=n_persons, n_frames=t_steps, seed=seed, min_coverage=cov)
     return S.generate_sequence(rig, cfg)[0]
 
 
-def make_sequences(pool, w, n_ctx, n_seq, seed_rank, t_steps):
-    """Per context: n_seq synthetic sequences of t_steps frames (up to 32 distinct seeded sequences per context, repeated)."""
-    n_uniq = min(n_seq, 32)
-    jobs = [(w["n_cam"], w["n_persons"], t_steps, 1000 * seed_rank + 100 * ci + i) for ci in range(n_ctx) for i in range(n_uniq)]
-    uniq = pool.map(_gen_one, jobs, chunksize=1) if pool is not None else [_gen_one(j) for j in jobs]
+DISTINCT_DEFAULT = 32
+
+
+def make_sequences(pool, w, n_ctx, n_seq, seed_rank, t_steps, distinct=DISTINCT_DEFAULT):
+    """Per context: n_seq synthetic sequences of t_steps frames — `distinct` seeded sequences per context, each resident n_seq / distinct
+    times in its own memory (default 32; --distinct all: every resident sequence its own scene).  Seeds: 1000 x rank + 100 x context + i for
+    the default (the scenes of every earlier round), 10^6 x (rank + 1) + n_seq x context + i when a context holds more than 100."""
+    n_uniq = min(n_seq, distinct)
+    base = (lambda ci, i: 1000 * seed_rank + 100 * ci + i) if n_uniq <= 100 else (lambda ci, i: 1000000 * (seed_rank + 1) + n_seq * ci + i)
+    jobs = [(w["n_cam"], w["n_persons"], t_steps, base(ci, i), bool(w.get("rough"))) for ci in range(n_ctx) for i in range(n_uniq)]
+    uniq = pool.map(_gen_one, jobs, chunksize=4 if len(jobs) > 1024 else 1) if pool is not None else [_gen_one(j) for j in jobs]
     return [[uniq[ci * n_uniq + s % n_uniq] for s in range(n_seq)] for ci in range(n_ctx)]
 
 
@@ -504,7 +515,7 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         n_skel = int(tot.item())
     # joints the triangulation's float32 second pass redid in the last stage-1 launch of context 0 (round 4: se3d_get_exact_list)
     n_second_pass = len(nodes[0].exact_list()[0])
-    names = STAGE1_KERNELS + (STAGE2_KERNELS if stage2 else [])
+    names = STAGE1_KERNELS + ["triangulate_exact"] + (STAGE2_KERNELS if stage2 else [])
     prof = {k: tuple(sum(x) for x in zip(*[nd_.profile_get(k) for nd_ in nodes])) for k in names}   # (ms, launches) over all contexts
     res = {
         "workload": name, "value": n_skel * steps / dt, "ms_per_step": dt / steps * 1e3, "n_skel": n_skel, "n_skel_local": n_skel_local,
@@ -901,6 +912,9 @@ def main():
     ap.add_argument("--stream-affinity", choices=["local", "none"], default="local", help="streaming pass: host threads on the GPU's NUMA node (sysfs local_cpulist) or unpinned")
     ap.add_argument("--stream-contexts", type=int, default=8, help="contexts of the streaming measurement (each pins two batches of host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-robust", action="store_true", help="skip the `robust` block of a default run (the 16cam6p shape on rough scenes: scene.ROUGH)")
+    ap.add_argument("--distinct", default=str(DISTINCT_DEFAULT), help="distinct seeded sequences per context (default %d, each resident seqs / %d times); "
+                    "'all': every resident sequence its own scene (control run; generation takes ~10 s on 32 processes)" % (DISTINCT_DEFAULT, DISTINCT_DEFAULT))
     ap.add_argument("--latency-only", action="store_true", help="only the B = 1 latency block (one 16cam6p frame per call), printed as its own JSON line")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity / latency blocks of a default run")
     ap.add_argument("--exchange-backend", default="nccl", choices=["nccl", "gloo-staged"], help="nccl (= RCCL over xGMI, default) | gloo-staged: TEST ONLY — device "
@@ -947,7 +961,11 @@ def main():
     pool = mp.get_context("fork").Pool(nproc) if nproc > 1 else None
     t_gen = time.perf_counter()
     rig = make_rig(w)
-    seqs_head = make_sequences(pool, w, NC, S_, seed_rank, T_)
+    distinct = S_ if args.distinct == "all" else max(1, int(args.distinct))
+    seqs_head = make_sequences(pool, w, NC, S_, seed_rank, T_, distinct)
+    want_robust = default_run and stage2 and rank == 0 and not args.no_robust
+    if want_robust:
+        seqs_rough = make_sequences(pool, WORKLOADS["16cam6p_rough"], NC, S_, seed_rank, T_, distinct)
     want_secondary = default_run and not args.no_secondary and stage2
     if want_secondary:
         w2 = WORKLOADS["256cam128p"]
@@ -1012,6 +1030,15 @@ def main():
         serial = run_workload(headline, [all_seqs], rig, args, args.steps if args.serial else max(3, args.steps // 4), args.warmup if args.serial else 1,
                               None, local_rank, stage2, reproj=True)
         serial["value_per_gpu"] = serial["value"]
+    # ---- `robust` (round 6): the same 12-context shape on rough scenes (scene.ROUGH) — gross 2-D outliers, missing views, low-confidence joints:
+    # the reference's outlier path (S3D:748-838) and the triangulation's float32 second pass are hot; then one serial pass of the same scenes for the
+    # per-kernel times (rank 0's GPU only, like the serial pass above) ----
+    robust = robust_serial = None
+    if want_robust:
+        robust = run_workload("16cam6p_rough", seqs_rough, rig, args, max(5, args.steps // 2), 2, None, local_rank, True)
+        if not args.no_serial:
+            robust_serial = run_workload("16cam6p_rough", [[s for ctx_seqs in seqs_rough for s in ctx_seqs]], rig, args, 3, 1, None, local_rank, True)
+        del seqs_rough
     seqs_stream = seqs_head[: max(1, min(args.stream_contexts, NC))]
     seqs_par = seqs_head[0][:4]
     del seqs_head
@@ -1069,8 +1096,8 @@ def main():
                                    "%d distinct seeded sequences per context, each resident %d times in its own memory"
                                    % (headline, "1+2 (association+triangulation+UT covariance, then tracking+LM refinement+marginals)" if stage2 else "1",
                                       main_res["NC"], main_res["S"], main_res["T"], main_res["NC"] * main_res["B"], main_res["n_skel_local"], main_res["n_s1"],
-                                      min(main_res["S"], 32), max(1, main_res["S"] // min(main_res["S"], 32))),
-                       "distinct_sequences_per_context": min(main_res["S"], 32),
+                                      min(main_res["S"], distinct), max(1, main_res["S"] // min(main_res["S"], distinct))),
+                       "distinct_sequences_per_context": min(main_res["S"], distinct),
                        "n_cam": w["n_cam"], "n_persons": w["n_persons"], "n_joints": 17, "frames_per_step": main_res["NC"] * main_res["B"],
                        "contexts_per_gpu": main_res["NC"], "max_hypotheses_per_frame": main_res["max_hyp_per_frame"],
                        "max_published_per_frame": main_res["max_published_per_frame"], "scene_generation_s": round(t_gen, 1),
@@ -1103,6 +1130,22 @@ def main():
                               "sequences": serial["S"], "n_gpus": 1}
         if serial is not None and serial.get("reprojection"):
             line["reprojection"] = serial["reprojection"]   # the stage after the path, on the serial pass's resident results
+        if robust is not None:
+            from smartedgesensor3dhumanpose_amd import scene as _scene
+            rs = robust_serial
+            line["robust"] = {"workload": "16cam6p shape on ROUGH scenes (%s; scene.rough_config), stage 1+2, %d contexts x %d sequences x %d frames resident per GPU, max_hyp %d"
+                                          % (", ".join("%s %g" % kv for kv in sorted(_scene.ROUGH.items())), robust["NC"], robust["S"], robust["T"], WORKLOADS["16cam6p_rough"]["max_hyp"]),
+                              "value": round(robust["value"], 2), "unit": "skeletons/s", "n_gpus": 1, "ms_per_step": round(robust["ms_per_step"], 4), "steps": robust["steps"],
+                              "fraction_of_clean_value": round(robust["value"] / main_res["value_per_gpu"], 4), "published_skeletons_per_step": robust["n_skel_local"],
+                              "stage1_persons_per_step": robust["n_s1"], "second_pass_fraction": round(robust["second_pass_fraction"], 6),
+                              "second_pass_joints_per_launch_context0": robust["second_pass_joints"],
+                              "overlapped_kernel_ms_per_step": {k: round(v, 5) for k, v in robust["kernel_ms_per_step"].items()},
+                              "serial": None if rs is None else {"value": round(rs["value"], 2), "ms_per_step": round(rs["ms_per_step"], 4), "sequences": rs["S"],
+                                                                 "second_pass_fraction": round(rs["second_pass_fraction"], 6), "second_pass_joints_per_launch": rs["second_pass_joints"],
+                                                                 "second_pass_ms_per_step": round(rs["kernel_ms_per_step"]["triangulate_exact"], 5),
+                                                                 "kernel_ms_per_step": {k: round(v, 5) for k, v in rs["kernel_ms_per_step"].items()}},
+                              "note": "the headline's scenes are SURVEY's clean generator (second_pass.per_published_joint of the joints take the float32 second pass); here "
+                                      "second_pass_fraction of them do, as in the randomised parity sweep's scenes; `triangulate_exact` (se3d_k_triangulate_exact alone) is also inside `triangulate`"}
         if streaming is not None:
             line["value_streaming"] = round(streaming["value"], 2)
             line["streaming"] = {"value": round(streaming["value"], 2), "unit": "skeletons/s", "fraction_of_resident": round(streaming["value"] / main_res["value_per_gpu"], 4),

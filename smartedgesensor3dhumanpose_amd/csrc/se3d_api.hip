@@ -38,9 +38,9 @@ extern "C" hipError_t se3d_reproj_init_device(void);
 #define SE3D_VERSION "se3d-hip 0.1.0 (gfx950)"
 
 namespace {
-enum ProfSlot { PS_NORMALIZE = 0, PS_PAIRS, PS_SWEEP, PS_TRI, PS_POST, PS_ASSOC2, PS_LM, PS_UPDATE2, PS_WALK, PS_DLT, PS_COUNT };
+enum ProfSlot { PS_NORMALIZE = 0, PS_PAIRS, PS_SWEEP, PS_TRI, PS_POST, PS_ASSOC2, PS_LM, PS_UPDATE2, PS_WALK, PS_DLT, PS_TRI_EXACT, PS_COUNT };
 const int kStage1Slots = 5, kStage2Slots = 3;
-const char *kProfNames[PS_COUNT] = {"normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess", "track_assoc", "lm_refine", "track_update", "stage2_walk", "dlt"};
+const char *kProfNames[PS_COUNT] = {"normalize", "epipolar_pairs", "sweep", "triangulate", "postprocess", "track_assoc", "lm_refine", "track_update", "stage2_walk", "dlt", "triangulate_exact"};
 }  // namespace
 
 struct se3d_ctx {
@@ -76,7 +76,7 @@ struct se3d_ctx {
   // profiling
   bool prof = false;
   static constexpr int kRing = 96;       // event sets in flight before the oldest are harvested
-  hipEvent_t ev[kRing][6]{};             // stage-1 sets
+  hipEvent_t ev[kRing][7]{};             // stage-1 sets (event 6: between the first and the second pass of the triangulation)
   bool ev_dlt[kRing]{};                  // set brackets one config-2 pass (events 0 and 1 only)
   int32_t *d_assoc_in = nullptr;         // [B][H][N] caller's association table (config 2, se3d_stage_assoc)
   int dlt_hyp = 0;                       // hypotheses per frame of the staged table (0: none staged)
@@ -213,6 +213,10 @@ void collect_profile(se3d_ctx *c, bool all = true) {
     for (int i = 0; i < kStage1Slots; ++i) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, c->ev[idx][i], c->ev[idx][i + 1]) == hipSuccess) { c->prof_ms[i] += ms; c->prof_n[i] += 1; }
+    }
+    {   // the float32 second pass of the triangulation on its own (its time is also inside "triangulate")
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c->ev[idx][6], c->ev[idx][4]) == hipSuccess) { c->prof_ms[PS_TRI_EXACT] += ms; c->prof_n[PS_TRI_EXACT] += 1; }
     }
     --c->ev_pending;
   }

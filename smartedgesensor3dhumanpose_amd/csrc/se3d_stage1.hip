@@ -2956,7 +2956,7 @@ extern "C" void se3d_launch_munkres(double *d_dist, int *d_assign, int *d_status
 extern "C" hipError_t se3d_stage1_init_device(void) {
   return hipFuncSetAttribute(reinterpret_cast<const void *>(se3d_k_sweep_assign), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
 }
-static void se3d_launch_triangulation(const Se3dDev &D, const se3d_options &o, hipStream_t st) {
+static void se3d_launch_triangulation(const Se3dDev &D, const se3d_options &o, hipStream_t st, hipEvent_t ev_mid = nullptr) {
   const int B = D.d.B, N = D.d.N, H = D.d.H;
   (void)hipMemsetAsync(D.tri_cnt, 0, sizeof(uint32_t), st);   // list of the second pass: filled by the kernel below
   const int waves2 = (int)std::min<size_t>((size_t)D.d.tri_waves, (size_t)B * H * SE3D_NKP);
@@ -2967,6 +2967,7 @@ static void se3d_launch_triangulation(const Se3dDev &D, const se3d_options &o, h
     hipLaunchKernelGGL(se3d_k_triangulate_hyp, dim3(TH_PARTS * H, B), dim3(64), 0, st, D);
   }
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
+  if (ev_mid) (void)hipEventRecord(ev_mid, st);
   // second pass: the listed joints with the oracle's restatement of the reference's float32 arithmetic (wavefronts beyond the list length exit at once)
   hipLaunchKernelGGL(se3d_k_triangulate_exact, dim3(waves2), dim3(64), se3d_exact_lds_bytes(N), st, D);
 }
@@ -2982,7 +2983,7 @@ extern "C" void se3d_launch_pair_block(const Se3dDev &D, const int2 *d_ab_one, i
 // st_hi / ev_hi: optional high-priority stream (+ two events) for the per-camera sweep launches of large problems: 2 x N tiny dependent
 // launches that otherwise queue behind the millions of workgroups of other contexts' pair kernels.
 // o: the context's options (include/se3d.h): the kernel FORMS a parity test may force; everything 0 = the library's choice.
-extern "C" void se3d_launch_stage1(const Se3dDev &D, const se3d_options &o, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null */, int phases,
+extern "C" void se3d_launch_stage1(const Se3dDev &D, const se3d_options &o, const int2 *pair_ab, hipStream_t st, hipEvent_t *ev /* [7] or null; [6] sits between the two passes of the triangulation */, int phases,
                                    hipStream_t st_hi, hipEvent_t *ev_hi, const Se3dPairPlan *plan, hipEvent_t *ev_chunk) {
   const int B = D.d.B, N = D.d.N, P = D.d.P, H = D.d.H;
   const bool chunked = D.d.pair_chunks > 0 && plan && plan->m == D.d.pair_chunks;
@@ -3072,7 +3073,7 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const se3d_options &o, cons
     }
   }
   if (ev && (phases & 8)) (void)hipEventRecord(ev[3], st);
-  if (phases & 2) se3d_launch_triangulation(D, o, st);
+  if (phases & 2) se3d_launch_triangulation(D, o, st, ev ? ev[6] : nullptr);
   if (ev && (phases & 2)) (void)hipEventRecord(ev[4], st);
   if (phases & 4) {
     if (H <= SE3D_POST_SMALL_H && o.post_form != SE3D_POST_BLOCK) hipLaunchKernelGGL(se3d_k_postprocess_wave3, dim3(B), dim3(64), se3d_post_wave3_lds_bytes(H), st, D);

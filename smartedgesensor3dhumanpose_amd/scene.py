@@ -65,6 +65,24 @@ class SceneConfig:
     joint_offset: Optional[np.ndarray] = None  # [P,17,3] added to the body-frame joints after rotation (e.g. a wrist 2.5 m away, a person 0.6 m above ground)
 
 
+# Rough scenes: the fixed parameters of bench.py's `robust` block — the middle of the ranges the randomised parity sweep draws from
+# (draw_rough_params below; tests/fuzz_scenes.py): gross 2-D outliers exercise the reference's outlier path (S3D:748-838), missing views and
+# low-confidence joints the gates of S3D:321 / 725.
+ROUGH = dict(p_miss=0.08, low_score_frac=0.15, outlier_frac=0.006, pixel_noise=2.0)
+
+
+def rough_config(n_persons, n_frames, seed, **kw):
+    """SceneConfig of a rough scene with the fixed ROUGH parameters (keyword arguments override)."""
+    return SceneConfig(n_persons=n_persons, n_frames=n_frames, seed=seed, **{**ROUGH, **kw})
+
+
+def draw_rough_params(rng):
+    """Scene parameters of one trial of the randomised parity sweep: up to 15 % missing views, up to 30 % low-confidence joints, up to
+    1.2 % gross 2-D outliers, 0.5 - 4 px noise, persons 0.5 - 1.2 m apart.  Five draws from `rng` in this order."""
+    return dict(p_miss=float(rng.uniform(0, 0.15)), low_score_frac=float(rng.uniform(0, 0.3)), outlier_frac=float(rng.uniform(0, 0.012)),
+                pixel_noise=float(rng.uniform(0.5, 4.0)), spacing=float(rng.uniform(0.5, 1.2)))
+
+
 def _place_persons(rig, n_persons, rng, spacing, min_coverage):
     c = rig.centres()
     lo, hi = c[:, :2].min(0) - 1.0, c[:, :2].max(0) + 1.0

@@ -20,7 +20,6 @@ def draw_trial(rng):
     rig = R.extr_rig_16cam() if ncam == 16 else R.elliptical_rig(ncam, seed=int(rng.integers(100)))
     rig.set_tensors(*rig_tensors(rig))
     persons = int(rng.integers(12, 25)) if LARGE else int(rng.integers(2, 8))
-    extra = dict(p_miss=float(rng.uniform(0, 0.15)), low_score_frac=float(rng.uniform(0, 0.3)), outlier_frac=float(rng.uniform(0, 0.012)),
-                 pixel_noise=float(rng.uniform(0.5, 4.0)), spacing=float(rng.uniform(0.5, 1.2)))
+    extra = S.draw_rough_params(rng)   # the parameter ranges live next to the generator (scene.py; bench.py's `robust` block uses their middle)
     seqs = [S.generate_sequence(rig, S.SceneConfig(n_persons=persons, n_frames=T_STEPS, seed=int(rng.integers(1 << 30)), **extra))[0] for _ in range(N_SEQ)]
     return rig, persons, seqs, extra

@@ -1,0 +1,61 @@
+#!/bin/bash
+# Round 6's measurements on the GPU box (gpurun --timeout N -- bash tools/r6.sh <parts>): written to gpurun_out/r6/, the summaries that are
+# quoted are copied into profiles/r6/ by hand.
+#   robust [tag]   : bench.py headline + serial + `robust` block (rough scenes) without the other blocks -> robust_<tag>.log
+#   robust_prof [tag]: rocprofv3 kernel stats of the rough-scene serial pass -> serial_16cam6p_rough_<tag>_kernel_stats.csv
+#   sdma           : tools/microbench/sdma_pair (does an upload stream + a download stream overlap, and what decides it), two processes
+#   c256 [tag]     : 256cam128p one context, kernel stats
+#   suite          : pytest -m gpu
+#   bench N        : N default bench.py runs
+set -u
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r6
+mkdir -p $O
+while [ $# -gt 0 ]; do
+part=$1; shift
+case $part in
+robust)
+  tag=${1:-x}; shift || true
+  timeout 900 python bench.py --no-secondary --no-streaming --no-parity --no-cpu-baseline > $O/robust_$tag.log 2> $O/robust_$tag.err
+  tail -1 $O/robust_$tag.log | python3 -c "
+import json, sys
+d = json.loads(sys.stdin.readline())
+r = d['robust']
+print('clean', d['value'], d['ms_per_step'], '| robust', r['value'], r['ms_per_step'], 'frac_of_clean', r['fraction_of_clean_value'], 'second pass', r['second_pass_fraction'], 'serial', json.dumps(r['serial']))"
+  tail -3 $O/robust_$tag.err
+  ;;
+robust_prof)
+  tag=${1:-x}; shift || true
+  rm -rf $O/rough_stats_$tag
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rough_stats_$tag -- python3 bench.py --workload 16cam6p_rough --serial --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/rough_serial_$tag.log 2>&1
+  python3 tools/kernel_stats.py $O/rough_stats_$tag $O/serial_16cam6p_rough_${tag}_kernel_stats.csv | head -12
+  rm -rf $O/rough_stats_$tag
+  ;;
+sdma)
+  for i in 1 2; do timeout 300 tools/microbench/sdma_pair 3 > $O/sdma_pair_$i.txt 2>&1; done
+  cat $O/sdma_pair_1.txt
+  ;;
+c256)
+  tag=${1:-x}; shift || true
+  rm -rf $O/c256_stats_$tag
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c256_stats_$tag -- python3 bench.py --workload 256cam128p --contexts 1 --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/c256_bench_1ctx_$tag.log 2>&1
+  python3 tools/kernel_stats.py $O/c256_stats_$tag $O/c256_1ctx_${tag}_kernel_stats.csv | head -12
+  rm -rf $O/c256_stats_$tag
+  ;;
+suite)
+  timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > $O/pytest_gpu.log 2>&1
+  tail -5 $O/pytest_gpu.log
+  ;;
+bench)
+  n=${1:-1}; shift || true
+  for i in $(seq 1 $n); do
+    timeout 900 python bench.py > $O/bench_default_$i.log 2> $O/bench_default_$i.err
+    tail -1 $O/bench_default_$i.log | python3 -c "
+import json, sys
+d = json.loads(sys.stdin.readline())
+print('run $i:', d['value'], d['ms_per_step'], 'secondary', d['secondary']['value'], 'streaming', d['value_streaming'], d['streaming'].get('h2d_GB_per_s'), d['streaming'].get('step_ms_context0'), 'robust', d.get('robust', {}).get('value'), 'frac', d['roofline']['frac'])"
+  done
+  ;;
+esac
+done
