@@ -273,6 +273,11 @@ def bench_latency_b1(rig, seq, name, device=0, frames_timed=200):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # one measurement: NC contexts x S sequences x T frames resident on this rank's GPU
 # ---------------------------------------------------------------------------------------------------------------------------------
+def dense_slots_per_frame(w):
+    """Person capacity per frame of the dense exchange blocks (se3d_pack_stage2_walk_device_dense)."""
+    return w["n_persons"] + 0.25 if w["n_persons"] <= 16 else 1.125 * w["n_persons"] + 2
+
+
 def memory_plan(name, n_ctx, n_frames, exchange=False, free_bytes=None):
     """Device memory one rank's GPU needs for `n_ctx` contexts of `n_frames` resident frames each (se3d_device_bytes: the library's own
     allocation list, host arithmetic) + the exchange's pack / gather buffers; raises SystemExit with the figures when it exceeds what is
@@ -284,7 +289,7 @@ def memory_plan(name, n_ctx, n_frames, exchange=False, free_bytes=None):
     ex = 0
     if exchange:   # SkeletonExchange: 2 pack + 2 gather buffers of [n_ctx][n_frames][max_hyp] persons (+ counts), gather x world
         world = int(os.environ.get("WORLD_SIZE", "1"))
-        slots = (w["n_persons"] + 0.25) if w["n_persons"] <= 16 else w["max_hyp"]   # dense exchange blocks for the small workloads
+        slots = dense_slots_per_frame(w)   # dense exchange blocks
         ex = int(2 * (1 + world) * n_ctx * n_frames * (slots * pm.person3d_dt.itemsize + 4))
     plan = {"workload": name, "contexts": n_ctx, "frames_per_context": n_frames, "bytes_per_context": per_ctx, "exchange_bytes": ex,
             "total_bytes": n_ctx * per_ctx + ex}
@@ -334,7 +339,9 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         # per-frame offsets, capacity n_persons + 0.25 persons per frame; what does not fit is counted in the block, checked below on every
         # rank for every rank's block.  At 16cam6p a rank produces ~51 GB/s of final skeletons; the all-gather delivers (world - 1) x that
         # into every GPU, so padding slots ([frame][n_persons + 2] before: +28 %) decide whether the exchange hides behind the step at 8 GPUs.
-        dense_cap = int(math.ceil(B * (w["n_persons"] + 0.25))) if stage2 and fused_walk and w["n_persons"] <= 16 and not args.exchange_slots else 0
+        # Round 6: the dense form also at 256cam128p ([frame][256 slots] carried 2 x padding over the <= 132 persons a frame publishes): capacity
+        # 1.125 x n_persons + 2 per frame there (crowded scenes publish spurious extra persons; what does not fit is counted and asserted to be zero)
+        dense_cap = int(math.ceil(B * dense_slots_per_frame(w))) if stage2 and fused_walk and not args.exchange_slots else 0
         streams = [torch.cuda.ExternalStream(nd_.stream_handle()) for nd_ in nodes]
         ex = shard.SkeletonExchange(dist, NC, (dense_cap if dense_cap else B * XH) * psz, B + 2 if dense_cap else B, torch.device("cuda", local_rank), streams)
 
@@ -514,7 +521,8 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         dist.all_reduce(tot)
         n_skel = int(tot.item())
     # joints the triangulation's float32 second pass redid in the last stage-1 launch of context 0 (round 4: se3d_get_exact_list)
-    n_second_pass = len(nodes[0].exact_list()[0])
+    _xl, _x64, _ = nodes[0].exact_list(flags=True)
+    n_second_pass, n_second_cov64 = len(_xl), int(_x64.sum())
     names = STAGE1_KERNELS + ["triangulate_exact"] + (STAGE2_KERNELS if stage2 else [])
     prof = {k: tuple(sum(x) for x in zip(*[nd_.profile_get(k) for nd_ in nodes])) for k in names}   # (ms, launches) over all contexts
     res = {
@@ -523,7 +531,7 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
         "kernel_ms_per_step": {k: v[0] / steps / NC for k, v in prof.items()},   # per context and step
         "max_hyp_per_frame": int(max(r.n_hyp for r in s1)), "max_published_per_frame": int(max_pub[0]), "exchange_verified": exchange_ok,
         "lm_iterations_mean": float(np.mean(lm_iters)) if lm_iters else None, "params": node.params, "pair_chunks": node.pair_chunks(),
-        "second_pass_joints": n_second_pass, "second_pass_fraction": n_second_pass / max(1.0, 17.0 * n_s1 / NC),
+        "second_pass_joints": n_second_pass, "second_pass_fraction": n_second_pass / max(1.0, 17.0 * n_s1 / NC), "second_pass_cov64": n_second_cov64,
         "sweep_stats": nodes[0].sweep_stats(),   # (camera steps of the per-camera sweep with hypotheses and detections, those that ran the Hungarian): large rigs
         "exchange": None if ex is None else {"form": "dense: published persons back to back + per-frame offsets" if dense_cap else "[frame][%d person slots] + counts" % XH,
                                              "bytes_per_rank_per_step": int(NC * (ex.sp + 4 * ex.sc))},
@@ -681,56 +689,58 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
     all_cpus, local = os.sched_getaffinity(0), (gpu_local_cpus(local_rank) if affinity == "local" else None)
     if local:
         os.sched_setaffinity(0, local)
-    for seqs in seqs_per_ctx:
-        frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
-        nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank, options=dict(stream_out=stream_out))
-        nd_.refine_reset()
-        nodes.append(nd_)
-        prepared.append(nd_.stream_prepare(frames))
-        in_bytes += sum(int(f.det_offset[-1]) for f in frames) * 428
-    counts = [[0, 0] for _ in nodes]   # published persons, bytes out per context (timed region)
-    step_ms = []
-    go, done = threading.Barrier(NC + 1), threading.Barrier(NC + 1)
+    try:   # (an exception in the streaming pass must not leave the later passes pinned to one NUMA node)
+        for seqs in seqs_per_ctx:
+            frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
+            nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank, options=dict(stream_out=stream_out))
+            nd_.refine_reset()
+            nodes.append(nd_)
+            prepared.append(nd_.stream_prepare(frames))
+            in_bytes += sum(int(f.det_offset[-1]) for f in frames) * 428
+        counts = [[0, 0] for _ in nodes]   # published persons, bytes out per context (timed region)
+        step_ms = []
+        go, done = threading.Barrier(NC + 1), threading.Barrier(NC + 1)
 
-    def worker(ci):
-        nd_, t, cyc = nodes[ci], 100.0, 0
+        def worker(ci):
+            nd_, t, cyc = nodes[ci], 100.0, 0
 
-        def submit():
-            nonlocal t, cyc
-            ks = list(range(T_)) if cyc % 2 == 0 else list(range(T_ - 1, -1, -1))
-            ts = t + (1.0 / 30.0) * np.arange(1, T_ + 1)
-            t, cyc = float(ts[-1]), cyc + 1
-            nd_.stream_submit(prepared[ci], np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
-        submit()
-        for _ in range(warmup):
+            def submit():
+                nonlocal t, cyc
+                ks = list(range(T_)) if cyc % 2 == 0 else list(range(T_ - 1, -1, -1))
+                ts = t + (1.0 / 30.0) * np.arange(1, T_ + 1)
+                t, cyc = float(ts[-1]), cyc + 1
+                nd_.stream_submit(prepared[ci], np.repeat(ts[:, None], S_, 1), [k * S_ for k in ks])
             submit()
+            for _ in range(warmup):
+                submit()
+                nd_.stream_collect(copy=False)
+            go.wait()
+            t_prev = time.perf_counter()
+            for _ in range(steps):
+                submit()
+                off, fused, _pred = nd_.stream_collect(copy=False)
+                counts[ci][0] += int(off[-1])
+                counts[ci][1] += 2 * int(off[-1]) * 1688 + 4 * len(off)
+                if ci == 0:   # context 0's step times: tells a uniformly slow run (both copy directions at ~60 %: one run in ten, cause open) from a transient
+                    t_now = time.perf_counter()
+                    step_ms.append(round((t_now - t_prev) * 1e3, 2))
+                    t_prev = t_now
             nd_.stream_collect(copy=False)
+            done.wait()
+        threads = [threading.Thread(target=worker, args=(ci,)) for ci in range(NC)]
+        for th in threads:
+            th.start()
         go.wait()
-        t_prev = time.perf_counter()
-        for _ in range(steps):
-            submit()
-            off, fused, _pred = nd_.stream_collect(copy=False)
-            counts[ci][0] += int(off[-1])
-            counts[ci][1] += 2 * int(off[-1]) * 1688 + 4 * len(off)
-            if ci == 0:   # context 0's step times: tells a uniformly slow run (both copy directions at ~60 %: one run in ten, cause open) from a transient
-                t_now = time.perf_counter()
-                step_ms.append(round((t_now - t_prev) * 1e3, 2))
-                t_prev = t_now
-        nd_.stream_collect(copy=False)
+        t0 = time.perf_counter()
         done.wait()
-    threads = [threading.Thread(target=worker, args=(ci,)) for ci in range(NC)]
-    for th in threads:
-        th.start()
-    go.wait()
-    t0 = time.perf_counter()
-    done.wait()
-    dt = time.perf_counter() - t0
-    for th in threads:
-        th.join()
-    for nd_ in nodes:
-        nd_.close()
-    if local:
-        os.sched_setaffinity(0, all_cpus)
+        dt = time.perf_counter() - t0
+        for th in threads:
+            th.join()
+        for nd_ in nodes:
+            nd_.close()
+    finally:
+        if local:
+            os.sched_setaffinity(0, all_cpus)
     n_skel = sum(c[0] for c in counts)
     return {"value": n_skel / dt, "ms_per_step": dt / steps * 1e3, "contexts": NC, "sequences_per_context": S_, "steps": steps,
             "host_threads": ("on the %d CPUs of the GPU's NUMA node" % len(local)) if local else "unpinned", "step_ms_context0": step_ms,
@@ -833,7 +843,12 @@ def roofline_of(res, w, stage2, source):
     bytes_per_skel = w["bytes_s1"] if dom in STAGE1_KERNELS else w["bytes_s2"]
     units_per_launch = res["n_skel_local"] / NC / max(launches_per_step, 1e-9)
     achieved = bytes_per_skel * units_per_launch / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
-    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # `bound`: the resource the committed PMC passes show as binding for this kernel (profiles/r5, r6 READMEs) — none of the large kernels of this
+    # path is HBM-bound (~9 KB of algorithmic bytes per skeleton against ~2 MFLOP); achieved / peak / frac remain the HBM figures the
+    # contract asks for (`frac_basis`)
+    binding = {"triangulate": "valu (fp64 vector issue; HBM at %.0f %% of peak)", "epipolar_pairs": "valu+lds (fp32 vector issue and the LDS read pipe; HBM at %.0f %% of peak)",
+               "stage2_walk": "valu latency (dependent fp64 chain; HBM at %.0f %% of peak)"}.get(dom, "hbm (%.0f %% of peak)") % (100.0 * achieved / HBM_PEAK_GBS)
+    return {"bound": binding, "frac_basis": "hbm: algorithmic bytes per launch / launch time / 8 TB/s", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(ms_dom, 5),
             "algorithmic_bytes_per_skeleton": bytes_per_skel, "skeletons_per_launch": round(units_per_launch, 1), "source": source,
             "sum_kernel_ms_per_step": round(sum(per_step_ms.values()), 4),
@@ -912,6 +927,7 @@ def main():
     ap.add_argument("--stream-affinity", choices=["local", "none"], default="local", help="streaming pass: host threads on the GPU's NUMA node (sysfs local_cpulist) or unpinned")
     ap.add_argument("--stream-contexts", type=int, default=8, help="contexts of the streaming measurement (each pins two batches of host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rough", default="", help="diagnostic: overrides of scene.ROUGH for the rough-scene workload, e.g. pixel_noise=3.5,outlier_frac=0.012")
     ap.add_argument("--no-robust", action="store_true", help="skip the `robust` block of a default run (the 16cam6p shape on rough scenes: scene.ROUGH)")
     ap.add_argument("--distinct", default=str(DISTINCT_DEFAULT), help="distinct seeded sequences per context (default %d, each resident seqs / %d times); "
                     "'all': every resident sequence its own scene (control run; generation takes ~10 s on 32 processes)" % (DISTINCT_DEFAULT, DISTINCT_DEFAULT))
@@ -932,6 +948,9 @@ def main():
                     "(north_star config 5 as a latency mode) that a default multi-rank run ends with")
     args = ap.parse_args()
 
+    if args.rough:   # before the scene workers are forked: they read scene.ROUGH
+        from smartedgesensor3dhumanpose_amd import scene as _sc
+        _sc.ROUGH.update({k: float(v) for k, v in (kv.split("=") for kv in args.rough.split(","))})
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args.gpus))   # the children print the JSON line (rank 0)
 
@@ -1068,12 +1087,12 @@ def main():
             # when it carries the fingerprint of the kernel sources it was collected on (tools/pmc_sq.py, _lib.source_hash) — else the
             # line says which file was skipped and falls back to the model figures
             from smartedgesensor3dhumanpose_amd._lib import source_hash
-            for rd in ("r5", "r4", "r3", "r2"):
+            for rd in ("r6", "r5", "r4", "r3", "r2"):
                 p = os.path.join(ROOT, "profiles", rd, fn)
                 if os.path.exists(p):
                     d = json.load(open(p))
                     d["_file"] = "profiles/%s/%s" % (rd, fn)
-                    if d.get("source_hash") != source_hash():
+                    if source_hash() is None or d.get("source_hash") != source_hash():   # (None: a package without its sources — nothing matches)
                         stale_pmc.append(d["_file"])
                         return None
                     return d
@@ -1107,6 +1126,7 @@ def main():
             "roofline": roof,
             "pmc_summaries_skipped": stale_pmc,   # committed counter summaries collected on OTHER kernel sources than this build's (not used)
             "second_pass": {"joints_per_launch": main_res["second_pass_joints"], "per_published_joint": round(main_res["second_pass_fraction"], 6),
+                            "of_them_with_fp64_sample_covariance": main_res["second_pass_cov64"],
                             "note": "joints the fast fp64 triangulation handed to se3d_k_triangulate_exact (the oracle's restatement of the reference's float32 JacobiSVD arithmetic, "
                                     "bit-identical to that oracle): ill-conditioned systems, reprojection errors near / above the outlier threshold, wide covariances; "
                                     "its time is inside the `triangulate` kernel group"},
@@ -1141,7 +1161,7 @@ def main():
                               "second_pass_joints_per_launch_context0": robust["second_pass_joints"],
                               "overlapped_kernel_ms_per_step": {k: round(v, 5) for k, v in robust["kernel_ms_per_step"].items()},
                               "serial": None if rs is None else {"value": round(rs["value"], 2), "ms_per_step": round(rs["ms_per_step"], 4), "sequences": rs["S"],
-                                                                 "second_pass_fraction": round(rs["second_pass_fraction"], 6), "second_pass_joints_per_launch": rs["second_pass_joints"],
+                                                                 "second_pass_fraction": round(rs["second_pass_fraction"], 6), "second_pass_joints_per_launch": rs["second_pass_joints"], "of_them_with_fp64_sample_covariance": rs["second_pass_cov64"],
                                                                  "second_pass_ms_per_step": round(rs["kernel_ms_per_step"]["triangulate_exact"], 5),
                                                                  "kernel_ms_per_step": {k: round(v, 5) for k, v in rs["kernel_ms_per_step"].items()}},
                               "note": "the headline's scenes are SURVEY's clean generator (second_pass.per_published_joint of the joints take the float32 second pass); here "

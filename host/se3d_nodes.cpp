@@ -35,6 +35,9 @@ se3d_ctx* Context::create(int max_det, int max_hyp) const {
   se3d_rig rig{n_cam_, const_cast<float*>(Rt_.data()), const_cast<float*>(K_.data()), const_cast<float*>(F_.data())};
   se3d_params p{prm_.pose_method == "h36m" ? SE3D_POSE_H36M : SE3D_POSE_SIMPLE, prm_.norm_height ? 1 : 0, prm_.max_epi_dist};
   se3d_limits lim{1, max_det, max_hyp, max_hyp};
+  if (se3d_abi_version() != SE3D_ABI_VERSION)   // the library's structs have another layout than the header this file was compiled with
+    throw std::runtime_error("libse3d_hip.so has struct layout version " + std::to_string(se3d_abi_version()) + ", this host layer was built against " +
+                             std::to_string(SE3D_ABI_VERSION) + " (include/se3d.h: SE3D_ABI_VERSION)");
   se3d_ctx* c = se3d_create_ex(&rig, &p, &lim, &opt_, device_);
   if (!c) throw std::runtime_error(std::string("se3d_create failed: ") + se3d_last_error(nullptr) + " (there is no CPU fallback)");
   return c;

@@ -126,8 +126,14 @@ typedef struct se3d_options {
   int32_t stream_out;         /* se3d_stream_submit / _collect: 0 = device buffers + D2H copies on the device's shared download stream (default), 1 = the
                                  compaction kernel writes the published persons straight into the pinned host buffers (no copy engine; measured slower in
                                  round 5: 8.3 M against 10 - 11 M skeletons/s, profiles/r5/README.md section 5) */
-  int32_t reserved[6];        /* must be 0 */
+  int32_t exact_cov;          /* covariances of the joints the triangulation's float32 second pass redoes: SE3D_EXACT_COV_AUTO (default: float32 sigma
+                                 samples only where the kept views' systems are ill conditioned or the covariance is wide, the fast path's fp64 samples
+                                 around the float32 point elsewhere — se3d_get_exact_list marks those entries) | SE3D_EXACT_COV_F32 (float32 samples for
+                                 every listed joint: the oracle's covariance bits on all of them, the form of rounds 4 - 5) */
+  int32_t reserved[5];        /* must be 0 */
 } se3d_options;
+#define SE3D_EXACT_COV_AUTO 0
+#define SE3D_EXACT_COV_F32 1
 #define SE3D_WALK_WAVE 1
 #define SE3D_WALK_WG 2
 #define SE3D_PAIRS_AUTO 0
@@ -225,6 +231,12 @@ const char *se3d_last_error(const se3d_ctx *ctx);
 int64_t se3d_device_bytes(int32_t n_cam, const se3d_limits *limits);
 int64_t se3d_device_bytes_ex(int32_t n_cam, const se3d_limits *limits, const se3d_options *options);
 const char *se3d_version(void);
+/* Layout version of the structs of this header: bumped whenever a struct gains, loses or moves a field (6: se3d_options.exact_cov; 5:
+ * se3d_fused_out.lm_objective).  The out-structs carry no size field, so a caller compiled against another layout would make the library
+ * read or write past its structs: compare se3d_abi_version() of the loaded library with the SE3D_ABI_VERSION the caller was compiled with
+ * before the first call (host/se3d_nodes.cpp and the Python mirror refuse a mismatch). */
+#define SE3D_ABI_VERSION 6
+int32_t se3d_abi_version(void);
 
 /* --- stage 1: drop-in for triangulate_persons (S3D:525-997) ------------------------------------------- */
 /* one frame, synchronous (host in, host out).  On a context with limits.max_frames == 1 — one synchronised frame per callback, the reference's
@@ -353,9 +365,7 @@ int se3d_hungarian(se3d_ctx *ctx, int32_t *assignment, double *cost, const doubl
 int se3d_get_pair_costs(se3d_ctx *ctx, int32_t frame, int32_t cam_a, int32_t cam_b, double *out, int32_t *n_a, int32_t *n_b);
 /* Large rigs keep camera-column chunks of the pair table instead of the whole (se3d_get_pair_chunks > 0): there se3d_get_pair_costs is not a
  * plain read — it RECOMPUTES the block with the pass's kernel into scratch of the context (pair slot 0 of the frame, first element of the cost
- * matrix), which the next se3d_run_stage1 overwrites anyway.  The same holds after a pass of the fused front kernel (SE3D_FRONT=1, an A/B
- * variant: pair costs in LDS only; the normalised points are formed again first, the association workspace is left alone).  In every mode
- * entries outside [0, n_a) x [0, n_b) are undefined. */
+ * matrix), which the next se3d_run_stage1 overwrites anyway.  In every mode entries outside [0, n_a) x [0, n_b) are undefined. */
 int se3d_get_pair_chunks(se3d_ctx *ctx);
 
 /* --- diagnostic accessor: the FUSION_BODY_PARTS constants compiled into the kernels (fusion_body_parts.h:3-24, 33): indices22 = the joint
@@ -389,7 +399,8 @@ int se3d_selftest_dlt32(se3d_ctx *ctx, int32_t n_sys, int32_t n_views, const flo
 
 /* --- diagnostic accessor (round 4): the joints the last triangulation pass of this context (se3d_run_stage1 / _phases / se3d_triangulate* /
  * se3d_run_dlt) handed to the float32-exact second pass: entries[i] = (frame * max_hyp + hypothesis) << 5 | input joint index (order not
- * defined), *n_entries = their number (may exceed capacity), *total (optional) = running total since se3d_create. */
+ * defined; bit 31 set (round 6): the joint's covariance came from fp64 sigma samples around the float32 point, options.exact_cov),
+ * *n_entries = their number (may exceed capacity), *total (optional) = running total since se3d_create. */
 int se3d_get_exact_list(se3d_ctx *ctx, uint32_t *entries, int32_t capacity, int32_t *n_entries, int64_t *total);
 
 /* --- device-side result access for multi-GPU exchange (RCCL all-gather of final skeletons) -------------

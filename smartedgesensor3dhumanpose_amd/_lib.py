@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("SE3D_LIB_OVERRIDE") or os.path.join(_HERE, "libse3d_h
 
 # every entry point declared in include/se3d.h (checked against the header in tests/test_abi.py)
 EXPORTS = [
-    "se3d_rig_from_transforms", "se3d_create", "se3d_create_ex", "se3d_set_options", "se3d_get_options", "se3d_destroy", "se3d_last_error", "se3d_device_bytes", "se3d_device_bytes_ex", "se3d_version",
+    "se3d_rig_from_transforms", "se3d_create", "se3d_create_ex", "se3d_set_options", "se3d_get_options", "se3d_destroy", "se3d_last_error", "se3d_device_bytes", "se3d_device_bytes_ex", "se3d_version", "se3d_abi_version",
     "se3d_triangulate", "se3d_triangulate_batch", "se3d_stage_frames", "se3d_run_stage1", "se3d_sync", "se3d_fetch_stage1",
     "se3d_refine_reset", "se3d_refine_state_bytes", "se3d_refine_save", "se3d_refine_load", "se3d_refine", "se3d_run_stage2", "se3d_fetch_stage2",
     "se3d_hungarian", "se3d_get_pair_costs", "se3d_selftest_exact_math", "se3d_selftest_shared_quotient", "se3d_get_sweep_stats", "se3d_selftest_dlt32", "se3d_get_exact_list", "se3d_get_pair_chunks", "se3d_get_fusion_constants", "se3d_pack_stage1_device", "se3d_pack_stage2_device",
@@ -25,10 +25,13 @@ def source_hash():
     it and bench.py uses a committed summary only when it matches (instruction counts are properties of the code they were collected on)."""
     import hashlib
     src_dir = os.path.join(_HERE, "csrc")
+    if not os.path.isdir(src_dir):
+        return None   # an installed package without its sources: no fingerprint (callers treat None as "does not match")
     files = sorted(os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h"))) + [os.path.join(_HERE, "..", "include", "se3d.h")]
     h = hashlib.sha256()
     for f in files:
-        h.update(open(f, "rb").read())
+        if os.path.exists(f):   # (the header lives outside the package directory)
+            h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -82,6 +85,11 @@ def lib():
         L.se3d_last_error.restype = C.c_char_p
         L.se3d_last_error.argtypes = [C.c_void_p]
         L.se3d_version.restype = C.c_char_p
+        L.se3d_abi_version.restype = C.c_int32
+        from .person_msgs import ABI_VERSION   # the struct layouts this mirror was written against (include/se3d.h: SE3D_ABI_VERSION)
+        if L.se3d_abi_version() != ABI_VERSION:
+            raise RuntimeError("libse3d_hip.so has struct layout version %d, the Python mirror %d (include/se3d.h: SE3D_ABI_VERSION): rebuild the library"
+                               % (L.se3d_abi_version(), ABI_VERSION))
         L.se3d_stream_handle.restype = C.c_void_p
         L.se3d_stream_handle.argtypes = [C.c_void_p]
         for name in ("se3d_triangulate", "se3d_triangulate_batch", "se3d_stage_frames", "se3d_run_stage1", "se3d_sync", "se3d_fetch_stage1",

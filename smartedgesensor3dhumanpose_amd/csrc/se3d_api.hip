@@ -35,7 +35,7 @@ extern "C" hipError_t se3d_stage1_init_device(void);
 extern "C" hipError_t se3d_stage2_init_device(void);
 extern "C" hipError_t se3d_reproj_init_device(void);
 
-#define SE3D_VERSION "se3d-hip 0.1.0 (gfx950)"
+#define SE3D_VERSION "se3d-hip 0.6.0 (gfx950)"
 
 namespace {
 enum ProfSlot { PS_NORMALIZE = 0, PS_PAIRS, PS_SWEEP, PS_TRI, PS_POST, PS_ASSOC2, PS_LM, PS_UPDATE2, PS_WALK, PS_DLT, PS_TRI_EXACT, PS_COUNT };
@@ -461,6 +461,7 @@ static int graph_replay(se3d_ctx *c, se3d_ctx::CallGraph &g, F enqueue) {
 extern "C" {
 
 const char *se3d_version(void) { return SE3D_VERSION; }
+int32_t se3d_abi_version(void) { return SE3D_ABI_VERSION; }
 
 // Host set-up of the static rig tensors (replaces S3D:1187-1211).  F_ij = [P_j C_i]_x P_j P_i^+ in fp64, stored as float.
 int se3d_rig_from_transforms(int32_t n_cam, const double *T, float *Rt_out, float *F_out) {
@@ -512,7 +513,7 @@ static bool options_valid(const se3d_options *o) {
          o->graph >= -1 && o->graph <= 0 && o->walk_shape >= 0 && o->walk_shape <= SE3D_WALK_WG && o->sweep_lds_kb >= 0 && o->sweep_lds_kb <= 128 &&
          o->pairs_form >= 0 && o->pairs_form <= SE3D_PAIRS_FUSED && o->sweep_form >= 0 && o->sweep_form <= SE3D_SWEEP_WAVE_GLOBAL && o->tri_form >= 0 && o->tri_form <= SE3D_TRI_JOINT &&
          o->post_form >= 0 && o->post_form <= SE3D_POST_BLOCK && o->lm_form >= 0 && o->lm_form <= SE3D_LM_DENSE && o->walk_form >= 0 && o->walk_form <= SE3D_WALK_STEPS &&
-         o->walk_lm >= 0 && o->walk_lm <= SE3D_WALK_LM_SOLO && o->walk_book >= 0 && o->walk_book <= 1 && o->refine_steps >= 0 && o->refine_steps <= 1 &&
+         o->exact_cov >= 0 && o->exact_cov <= SE3D_EXACT_COV_F32 && o->walk_lm >= 0 && o->walk_lm <= SE3D_WALK_LM_SOLO && o->walk_book >= 0 && o->walk_book <= 1 && o->refine_steps >= 0 && o->refine_steps <= 1 &&
          o->munkres_form >= 0 && o->munkres_form <= SE3D_MUNKRES_WAVE && o->reproj_form >= 0 && o->reproj_form <= 1 && o->stream_out >= 0 && o->stream_out <= 1;
 }
 
@@ -527,6 +528,10 @@ se3d_ctx *se3d_create_ex(const se3d_rig *rig, const se3d_params *params, const s
   if (N < 2 || N > SE3D_MAX_CAMS || B < 1 || P < 1 || P > SE3D_MUNKRES_MAX || H < P || H > SE3D_MUNKRES_MAX) {
     create_error("se3d_create: unsupported sizes (n_cam %d [2..%d], det/cam %d [1..%d], hyp %d [det..%d])", N, SE3D_MAX_CAMS, P,
                  SE3D_MUNKRES_MAX, H, SE3D_MUNKRES_MAX);
+    return nullptr;
+  }
+  if ((int64_t)B * H >= ((int64_t)1 << 26)) {   // tri_list entries: (frame * max_hyp + hypothesis) << 5 | joint, bit 31 = the covariance flag
+    create_error("se3d_create: max_frames x max_hyp = %lld exceeds 2^26 - 1 hypothesis slots per context", (long long)B * H);
     return nullptr;
   }
   int ndev = 0;
@@ -710,7 +715,7 @@ int64_t se3d_device_bytes_ex(int32_t n_cam, const se3d_limits *limits, const se3
   if (!limits || !options_valid(options)) return -1;
   const int N = n_cam, B = limits->max_frames, P = limits->max_det_per_cam, H = limits->max_hyp;
   const int T = limits->max_tracks > 0 ? limits->max_tracks : H;
-  if (N < 2 || N > SE3D_MAX_CAMS || B < 1 || P < 1 || P > SE3D_MUNKRES_MAX || H < P || H > SE3D_MUNKRES_MAX || T > SE3D_MUNKRES_MAX) return -1;
+  if (N < 2 || N > SE3D_MAX_CAMS || B < 1 || P < 1 || P > SE3D_MUNKRES_MAX || H < P || H > SE3D_MUNKRES_MAX || T > SE3D_MUNKRES_MAX || (int64_t)B * H >= ((int64_t)1 << 26)) return -1;
   se3d_ctx c;
   c.dry = true;
   c.limits = *limits;

@@ -69,8 +69,11 @@ inline Se3dPairPlan se3d_pair_plan(int N, int m) {
 }
 // Which rigs run in chunks: those whose sweep is the chain of per-camera launches anyway (se3d_launch_stage1: neither the one-wavefront nor
 // the one-wavefront sweep applies) and whose table is big enough to matter.  options.pair_chunks = m overrides (-1: whole table).
+// One predicate for the launcher and the chunk default: the one-wavefront sweep with its state in global memory
+// (se3d_k_sweep_fused_wave) takes any number of cameras; only its LDS form (se3d_k_sweep_wave_lds) is limited to N <= 64.
+inline bool se3d_sweep_wave_global_ok(int P, int H) { return H <= 64 && P <= 64 && H * P <= 2048; }
 inline int se3d_pair_chunks_default(int N, int P, int H) {
-  const bool wave_sweep = H <= 64 && P <= 64 && H * P <= 2048;
+  const bool wave_sweep = se3d_sweep_wave_global_ok(P, H);
   if (P <= 16 || N < 32 || wave_sweep) return 0;
   return N >= 128 ? 16 : 8;
 }

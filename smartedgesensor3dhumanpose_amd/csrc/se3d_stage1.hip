@@ -1963,7 +1963,10 @@ __device__ __forceinline__ double x32_reproj_error(const X32Views &T, const floa
   return averageError / norm;
 }
 
-__global__ __launch_bounds__(64) void se3d_k_triangulate_exact(Se3dDev D) {
+#ifndef X32_WPE
+#define X32_WPE 3   // wavefronts per SIMD the second pass is compiled for: 164 VGPRs without scratch (4: 128 VGPRs + 80 B of scratch per lane)
+#endif
+__global__ __launch_bounds__(64, X32_WPE) void se3d_k_triangulate_exact(Se3dDev D, int cov32 /* options.exact_cov: float32 samples for every listed joint */) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   const int N = D.d.N, H = D.d.H;
@@ -1991,7 +1994,7 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_exact(Se3dDev D) {
   const X32Mat A{wsw + lane, 64, 2 * N};
   __syncthreads();
   for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
-    const uint32_t en = D.tri_list[it];
+    const uint32_t en = D.tri_list[it] & 0x7fffffffu;   // (bit 31: set below when the covariance comes from the fp64 sample path)
     const int e = (int)(en >> 5), j = (int)(en & 31u), f = e / H, h = e - f * H;
     se3d_keypoint3d *kpo = &D.hypP[(size_t)f * H + h].keypoints[c_kp2fusion[D.d.pose_method][j]];
     // ---- usable views of the joint (conf >= 0.30, S3D:724-732), ascending camera order; row N on the fly with the reference's expressions ----
@@ -2131,7 +2134,14 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_exact(Se3dDev D) {
       __syncthreads();
     }
     if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX / err));  // S3D:840-841
-    // ---- phase B: unscented transform (S3D:471-523), one sample per lane ----
+    // ---- phase B: unscented transform (S3D:471-523) ----
+    // Round 6: WHICH arithmetic the 4n' + 1 sample solves need is decided here, on the kept views.  A joint is listed because its published point
+    // or a decision of the outlier rejection needs the float32 sequence (phase A above: done) — its covariance needs float32 SAMPLES only when the
+    // kept views' systems are ill conditioned (se3d_kappa_flag, the first pass's own test) or the covariance comes out wide / a sample does not
+    // settle (SE3D_EXACT_VAR_MAX: those samples' systems are ill conditioned whatever the base system is).  Everything else — joints listed for the
+    // reprojection-error band, for an outlier that phase A has just removed, for a main solve that took too many steps — gets the fast path's
+    // fp64 sample solves around the float32 point (S3D:847: calc_covariance is handed the weighted result), i.e. the covariance contract of every
+    // joint that never left the fast path (tests/parity.py cov_tolerance), at ~1/30 of the instructions.  Such an entry gets bit 31 set in tri_list.
     const int dim = 2 * n, nsamp = 4 * n + 1;
     const float bsc = sqrtf((float)dim + 0.5f);
     bool not_spd = false;
@@ -2141,10 +2151,66 @@ __global__ __launch_bounds__(64) void se3d_k_triangulate_exact(Se3dDev D) {
     }
     not_spd = __ballot(not_spd) != 0ull;
     float cov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (not_spd) {   // defined policy: all entries NaN, position and score unaffected
+    bool cov64 = false;
+    if (!not_spd && !cov32) {
+      double gu_[10], gw_[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) { gu_[k] = 0.0; gw_[k] = 0.0; }
+      for (int v = lane; v < n; v += 64) {
+        float r0[4], r1[4], w0[4], w1[4];
+        const float cf = T.cf[v];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { r0[k] = T.rows[8 * v + k]; r1[k] = T.rows[8 * v + 4 + k]; w0[k] = r0[k] * cf; w1[k] = r1[k] * cf; }
+        se3d_gram_add(gu_, r0); se3d_gram_add(gu_, r1);
+        se3d_gram_add(gw_, w0); se3d_gram_add(gw_, w1);
+      }
+      float gwf[10], guf[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) { gu_[k] = se3d_wave_sum(gu_[k]); gw_[k] = se3d_wave_sum(gw_[k]); guf[k] = (float)gu_[k]; gwf[k] = (float)gw_[k]; }
+      if (!(se3d_kappa_flag(gwf, X, Y, Z) || se3d_kappa_flag(guf, X, Y, Z))) {   // uniform: every lane holds the same sums and the same point
+        const float wgt = 1.0f / (2.0f * ((float)dim + 0.5f));
+        double cv[6] = {0., 0., 0., 0., 0., 0.};
+        bool sample_bad = false;
+        const double vstart[4] = {(double)X, (double)Y, (double)Z, 1.0};
+        // samples 0 .. 2n: centre + class A (both rows rebuilt); 2n + 1 .. 4n: class B (r1 alone) — se3d_sigma_gram, as in se3d_tri_joint_body
+        for (int s0 = 0; s0 < nsamp; s0 += 64) {
+          const int s = s0 + lane;
+          if (s < nsamp) {
+            double g[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) g[k] = gu_[k];
+            if (s > 0) {
+              const bool clsB = s > 2 * n;
+              const int q = clsB ? s - 2 * n - 1 : s - 1, c = q >> 1;
+              float o0[4], o1[4], l11, l21, l22;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { o0[k] = T.rows[8 * c + k]; o1[k] = T.rows[8 * c + 4 + k]; }
+              se3d_chol2(T.k00[c], T.k01[c], T.k11[c], l11, l21, l22);
+              se3d_sigma_gram(g, sRt + 12 * T.cam[c], T.x[c], T.y[c], l11, l21, l22, bsc, o0, o1, (clsB ? 3 : 1) + (q & 1));
+            }
+            double pt[3];
+            sample_bad |= !se3d_null_invit_point(g, vstart, pt);
+            const float sx = (float)pt[0] - X, sy = (float)pt[1] - Y, sz = (float)pt[2] - Z;
+            const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
+            cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cv[k] = se3d_wave_sum(cv[k]);
+        if (__ballot(sample_bad) == 0ull && cv[0] < SE3D_EXACT_VAR_MAX && cv[3] < SE3D_EXACT_VAR_MAX && cv[5] < SE3D_EXACT_VAR_MAX) {   // uniform
+          cov64 = true;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) cov6[k] = (float)cv[k];
+        }
+      }
+    }
+    if (cov64) {
+      if (lane == 0) D.tri_list[it] = en | 0x80000000u;
+    } else if (not_spd) {   // defined policy: all entries NaN, position and score unaffected
 #pragma unroll
       for (int k = 0; k < 6; ++k) cov6[k] = __builtin_nanf("");
     } else {
+      // float32 samples, one per lane (S3D:471-518); the weighted outer products are summed in sample order in float (S3D:521-522)
       // sample 0 (the unmoved points) was solved in phase A (lane centre_at); it is valid when no view was removed
       const int first = (rm == -1) ? 1 : 0;
       if (first) {
@@ -2969,7 +3035,7 @@ static void se3d_launch_triangulation(const Se3dDev &D, const se3d_options &o, h
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
   if (ev_mid) (void)hipEventRecord(ev_mid, st);
   // second pass: the listed joints with the oracle's restatement of the reference's float32 arithmetic (wavefronts beyond the list length exit at once)
-  hipLaunchKernelGGL(se3d_k_triangulate_exact, dim3(waves2), dim3(64), se3d_exact_lds_bytes(N), st, D);
+  hipLaunchKernelGGL(se3d_k_triangulate_exact, dim3(waves2), dim3(64), se3d_exact_lds_bytes(N), st, D, o.exact_cov == SE3D_EXACT_COV_F32 ? 1 : 0);
 }
 
 extern "C" void se3d_launch_normalize_keep(const Se3dDev &D, hipStream_t st) {   // normalised points into D.kp, association workspace untouched
@@ -3050,10 +3116,10 @@ extern "C" void se3d_launch_stage1(const Se3dDev &D, const se3d_options &o, cons
     // the dynamic-LDS limit of se3d_k_sweep_assign is raised per device by se3d_stage1_init_device).
     int dynW = (int)((size_t)H * P * sizeof(double));
     if (dynW > 128 * 1024) dynW = 128 * 1024;
-    const bool wave_ok = H <= 64 && P <= 64 && N <= 64;
-    if (o.sweep_form == SE3D_SWEEP_AUTO && wave_ok && se3d_sweep_wave_lds_bytes(N, P, H) <= 16 * 1024) {
+    const bool wave_lds_ok = H <= 64 && P <= 64 && N <= 64;   // (the LDS form holds per-camera words for N <= 64 cameras)
+    if (o.sweep_form == SE3D_SWEEP_AUTO && wave_lds_ok && se3d_sweep_wave_lds_bytes(N, P, H) <= 16 * 1024) {
       hipLaunchKernelGGL(se3d_k_sweep_wave_lds, dim3(B), dim3(64), se3d_sweep_wave_lds_bytes(N, P, H), st, D);
-    } else if (o.sweep_form != SE3D_SWEEP_PER_CAMERA && wave_ok && H * P <= 2048) {
+    } else if (o.sweep_form != SE3D_SWEEP_PER_CAMERA && se3d_sweep_wave_global_ok(P, H)) {   // any N (N > 64 with a small H x P lost this form in round 5)
       hipLaunchKernelGGL(se3d_k_sweep_fused_wave, dim3(B), dim3(64), (size_t)dynW, st, D);
     } else {
       hipStream_t sw = st;

@@ -38,6 +38,9 @@ class Params(C.Structure):
     _fields_ = [("pose_method", C.c_int32), ("norm_height", C.c_int32), ("max_epi_dist", C.c_double)]
 
 
+ABI_VERSION = 6   # SE3D_ABI_VERSION of include/se3d.h the ctypes mirrors below follow (checked against the loaded library by _lib.lib())
+
+
 class Limits(C.Structure):
     _fields_ = [("max_frames", C.c_int32), ("max_det_per_cam", C.c_int32), ("max_hyp", C.c_int32), ("max_tracks", C.c_int32)]
 
@@ -46,7 +49,7 @@ class Options(C.Structure):
     """se3d_options (include/se3d.h): all zero = the library's defaults.  Symbolic values: the tables below."""
     _fields_ = [(n, C.c_int32) for n in ("pair_chunks", "hi_priority_stream", "reserve_cus", "graph", "walk_shape", "sweep_lds_kb",
                                          "pairs_form", "sweep_form", "tri_form", "post_form", "lm_form", "walk_form", "walk_lm", "walk_book",
-                                         "refine_steps", "munkres_form", "reproj_form", "stream_out")] + [("reserved", C.c_int32 * 6)]
+                                         "refine_steps", "munkres_form", "reproj_form", "stream_out", "exact_cov")] + [("reserved", C.c_int32 * 5)]
 
 
 OPTION_VALUES = {   # names of the SE3D_* constants of include/se3d.h
@@ -59,6 +62,7 @@ OPTION_VALUES = {   # names of the SE3D_* constants of include/se3d.h
     "walk_form": {"fused": 0, "steps": 1},
     "walk_lm": {"trio": 0, "solo": 1},
     "munkres_form": {"auto": 0, "block": 1, "wave": 2},
+    "exact_cov": {"auto": 0, "f32": 1},
 }
 
 

@@ -325,15 +325,19 @@ class Skeleton3D:
                                               err.ctypes.data_as(C.POINTER(C.c_double))), "se3d_selftest_dlt32")
         return X, err
 
-    def exact_list(self):
-        """Joints the last triangulation pass handed to the float32-exact second pass: (array [n][3] of (frame, hypothesis, joint), running total)."""
+    def exact_list(self, flags=False):
+        """Joints the last triangulation pass handed to the float32-exact second pass: (array [n][3] of (frame, hypothesis, joint), running total).
+        flags=True: (array, cov64 [n] bool, total) — cov64: the joint's covariance came from fp64 sigma samples around the float32 point (bit 31 of
+        the entry; options.exact_cov), position, score and outlier decisions from the float32 sequence like every listed joint."""
         n, total = C.c_int32(0), C.c_int64(0)
         cap = self.limits.max_frames * self.limits.max_hyp * pm.NUM_KEYPOINTS
         buf = np.zeros(cap, np.uint32)
         self._chk(self._L.se3d_get_exact_list(C.c_void_p(self._h), buf.ctypes.data_as(C.POINTER(C.c_uint32)), cap, C.byref(n), C.byref(total)), "se3d_get_exact_list")
         e = buf[:min(n.value, cap)]
-        fh = e >> 5
+        fh = (e & 0x7fffffff) >> 5
         out = np.stack([fh // self.limits.max_hyp, fh % self.limits.max_hyp, e & 31], -1).astype(np.int64) if len(e) else np.zeros((0, 3), np.int64)
+        if flags:
+            return out, (e >> 31).astype(bool), int(total.value)
         return out, int(total.value)
 
     def profile(self, on=True):

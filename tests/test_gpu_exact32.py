@@ -68,30 +68,52 @@ def test_float32_dlt_solve_on_large_rigs(oracle, n_cam, n):
     node.close()
 
 
-def _listed_joints_equal_bitwise(oracle, rig, frames, pose_method="simple", n_hyp=32, max_det=8):
+W6 = np.array([1, 2, 2, 1, 2, 1.0])
+COV64 = {"listed": 0, "cov64": 0, "rel_max": 0.0}   # tally over the module's runs (printed by the last test)
+
+
+def _listed_joints_equal_bitwise(oracle, rig, frames, pose_method="simple", n_hyp=32, max_det=8, exact_cov="auto"):
     """Config 2 (rows N, T, P, O, U with the association given: no plausibility filters, no duplicate merge, no limb-length inflation) on
-    `frames` with the association the oracle's sweep finds: every joint that went through the second pass must carry the oracle's position,
-    score AND raw covariance bits.  Returns (listed joints compared, joints triangulated)."""
-    node = Skeleton3D(rig, pose_method=pose_method, max_epi_dist=0.045, max_frames=len(frames), max_det_per_cam=max_det, max_hyp=n_hyp, device=0)
+    `frames` with the association the oracle's sweep finds: every joint that went through the second pass must carry the oracle's position
+    and score bits, and its raw covariance bits too when its sigma samples were solved in float32 — every listed joint with
+    exact_cov="f32" (the form of rounds 4 - 5), the joints whose kept views are ill conditioned / whose covariance is wide by default (round 6).
+    The other listed joints (bit 31 of the list entry) take the fast path's fp64 samples around the float32 point: their covariance is held
+    to the fast path's contract, parity.cov_tolerance with the input-derived kappa.  Returns (listed joints compared, joints triangulated)."""
+    from parity import cov_tolerance, plain_condition, DLT_KAPPA_MAX
+    node = Skeleton3D(rig, pose_method=pose_method, max_epi_dist=0.045, max_frames=len(frames), max_det_per_cam=max_det, max_hyp=n_hyp, device=0,
+                      options=dict(exact_cov=exact_cov))
     k2f = np.array(oracle.pose_tables(pm.POSE_H36M if pose_method == "h36m" else pm.POSE_SIMPLE)["kp2fusion"])
     assoc = np.full((len(frames), n_hyp, rig.n_cam), -1, np.int32)
     for k, fr in enumerate(frames):
         a = oracle.triangulate(rig, node.params, fr, capacity=n_hyp, hyp_capacity=n_hyp).assoc()
         assoc[k, :len(a)] = a
     got = node.triangulate_assoc(frames, assoc)
-    listed, _ = node.exact_list()
+    listed, cov64, _ = node.exact_list(flags=True)
+    assert exact_cov == "auto" or not cov64.any(), "exact_cov = f32 must solve every listed joint's samples in float32"
     triangulated = 0
     for k, fr in enumerate(frames):
         ref = oracle.triangulate_assoc(rig, node.params, fr, assoc[k])
         gk, ok = got[k]["keypoints"][:, k2f], ref["keypoints"][:, k2f]
         assert np.array_equal(gk["score"] > 0, ok["score"] > 0)
         triangulated += int((ok["score"] > 0).sum())
-        for f_, h, j in listed[listed[:, 0] == k]:
+        kappa = None
+        sel = listed[:, 0] == k
+        for (f_, h, j), c64 in zip(listed[sel], cov64[sel]):
             assert ok["score"][h, j] > 0, ("listed joint the oracle did not triangulate", k, h, j)
             assert np.array_equal(gk["joint"][h, j], ok["joint"][h, j]), ("position bits", k, h, j, gk["joint"][h, j], ok["joint"][h, j])
             assert gk["score"][h, j].tobytes() == ok["score"][h, j].tobytes(), ("score bits", k, h, j, gk["score"][h, j], ok["score"][h, j])
             cg, co = gk["cov"][h, j], ok["cov"][h, j]
-            assert cg.tobytes() == co.tobytes() or (np.isnan(cg).all() and np.isnan(co).all()), ("covariance bits", k, h, j, cg, co)
+            COV64["listed"] += 1
+            if not c64:
+                assert cg.tobytes() == co.tobytes() or (np.isnan(cg).all() and np.isnan(co).all()), ("covariance bits", k, h, j, cg, co)
+                continue
+            if kappa is None:
+                kappa = plain_condition(rig, fr, assoc[k])
+            rel = float(np.sqrt(((cg - co) ** 2 * W6).sum()) / np.sqrt((co ** 2 * W6).sum()))
+            tol = float(cov_tolerance(min(kappa[h, j], DLT_KAPPA_MAX), co))
+            COV64["cov64"] += 1
+            COV64["rel_max"] = max(COV64["rel_max"], rel)
+            assert rel < tol, ("fp64-sample covariance of a listed joint outside the fast path's tolerance", k, h, j, rel, tol, kappa[h, j])
         # everything else: the fast path's contract
         rest = ok["score"] > 0
         rest[tuple(listed[listed[:, 0] == k][:, 1:].T)] = False
@@ -104,10 +126,10 @@ def _listed_joints_equal_bitwise(oracle, rig, frames, pose_method="simple", n_hy
 def test_outlier_scenes_second_pass_is_bit_identical(oracle, extr_rig):
     """8 % gross 2-D outliers, with and without missing views: 3-view epipolar rejection, leave-one-out rejection and score down-weighting all
     run in the second pass and give the oracle's bits — positions, scores and unscented-transform covariances."""
-    for p_miss in (0.0, 0.6):
+    for p_miss, exact_cov in ((0.0, "auto"), (0.0, "f32"), (0.6, "auto"), (0.6, "f32")):
         oracle.stats_reset()
         frames = branch_scenes.outliers(extr_rig, n_frames=6, p_miss=p_miss)
-        listed, triangulated = _listed_joints_equal_bitwise(oracle, extr_rig, frames)
+        listed, triangulated = _listed_joints_equal_bitwise(oracle, extr_rig, frames, exact_cov=exact_cov)
         st = oracle.stats()
         print("p_miss %.1f: %d of %d triangulated joints went through the second pass, all bit-identical; oracle branches %s" % (
             p_miss, listed, triangulated, {k: st[k] for k in ("outlier3_removed", "outlier_loo_removed", "score_downweighted")}))
@@ -115,8 +137,8 @@ def test_outlier_scenes_second_pass_is_bit_identical(oracle, extr_rig):
         assert st["outlier_loo_removed"] > 0 if p_miss == 0.0 else st["outlier3_removed"] > 0
 
 
-@pytest.mark.parametrize("pose_method", ["simple", "h36m"])
-def test_random_rough_scenes_second_pass_is_bit_identical(oracle, extr_rig, pose_method):
+@pytest.mark.parametrize("pose_method,exact_cov", [("simple", "auto"), ("simple", "f32"), ("h36m", "auto")])
+def test_random_rough_scenes_second_pass_is_bit_identical(oracle, extr_rig, pose_method, exact_cov):
     """Scenes of the randomised sweep's kind (missing views, low confidences, gross outliers, close persons) on the 16-camera rig."""
     rng = np.random.default_rng(7)
     tot = 0
@@ -125,14 +147,14 @@ def test_random_rough_scenes_second_pass_is_bit_identical(oracle, extr_rig, pose
                             low_score_frac=float(rng.uniform(0, 0.3)), outlier_frac=float(rng.uniform(0, 0.05)), pixel_noise=float(rng.uniform(0.5, 4.0)),
                             spacing=float(rng.uniform(0.5, 1.2)))
         frames = S.generate_sequence(extr_rig, cfg)[0]
-        listed, triangulated = _listed_joints_equal_bitwise(oracle, extr_rig, frames, pose_method=pose_method, max_det=12)
+        listed, triangulated = _listed_joints_equal_bitwise(oracle, extr_rig, frames, pose_method=pose_method, max_det=12, exact_cov=exact_cov)
         tot += listed
-    print("%s: %d listed joints, all bit-identical" % (pose_method, tot))
+    print("%s / exact_cov %s: %d listed joints, all bit-identical (so far in this module: %s)" % (pose_method, exact_cov, tot, COV64))
     assert tot > 20
 
 
-@pytest.mark.parametrize("n_cam,p_miss", [(32, 0.3), (96, 0.0)])
-def test_large_rig_second_pass_is_bit_identical(oracle, n_cam, p_miss):
+@pytest.mark.parametrize("n_cam,p_miss,exact_cov", [(32, 0.3, "auto"), (96, 0.0, "auto"), (96, 0.0, "f32")])
+def test_large_rig_second_pass_is_bit_identical(oracle, n_cam, p_miss, exact_cov):
     """32 / 96 cameras: the per-joint fast kernel hands its flagged joints to the second pass; at 96 cameras the camera matrices come from
     global memory, the centred samples live in the workspace, and joints seen by more than 62 views take the leave-one-out passes without
     speculation (gross outliers on 5 % of the keypoints force them)."""
@@ -140,7 +162,7 @@ def test_large_rig_second_pass_is_bit_identical(oracle, n_cam, p_miss):
     rig.set_tensors(*rig_tensors(rig))
     frames = S.generate_sequence(rig, S.SceneConfig(n_persons=5, n_frames=2, seed=3, outlier_frac=0.05, p_miss=p_miss))[0]
     oracle.stats_reset()
-    listed, triangulated = _listed_joints_equal_bitwise(oracle, rig, frames, n_hyp=48, max_det=12)
+    listed, triangulated = _listed_joints_equal_bitwise(oracle, rig, frames, n_hyp=48, max_det=12, exact_cov=exact_cov)
     st = oracle.stats()
     print("%d cameras: %d of %d joints listed, all bit-identical; oracle branches %s" % (n_cam, listed, triangulated, {k: st[k] for k in ("outlier_loo_removed", "score_downweighted")}))
     assert listed > 10 and st["outlier_loo_removed"] > 0
@@ -150,5 +172,6 @@ def test_clean_scene_stays_on_the_fast_path(oracle, extr_rig):
     """The benchmark's kind of scene (no gross outliers, all views): a fraction of a percent is listed — the second pass costs the headline little."""
     frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=8, seed=0))
     listed, triangulated = _listed_joints_equal_bitwise(oracle, extr_rig, frames)
-    print("clean scene: %d of %d triangulated joints listed" % (listed, triangulated))
+    print("clean scene: %d of %d triangulated joints listed; module tally of the covariance forms: %s" % (listed, triangulated, COV64))
     assert listed <= 0.01 * triangulated
+    assert COV64["cov64"] > 0 and COV64["cov64"] < COV64["listed"], "both covariance forms of the second pass must have been exercised"

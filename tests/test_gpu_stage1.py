@@ -78,13 +78,15 @@ def test_device_hungarian_fuzz_vs_oracle(node16, oracle):
         assert cost.value == c0
 
 
-@pytest.mark.parametrize("rig_name,persons,max_det,max_hyp", [("extr16", 6, 8, 8), ("extr16", 12, 16, 32), ("ell24", 20, 24, 48)])
+@pytest.mark.parametrize("rig_name,persons,max_det,max_hyp", [("extr16", 6, 8, 8), ("extr16", 12, 16, 32), ("ell24", 20, 24, 48), ("ell96", 5, 8, 16)])
 def test_sweep_variants_agree_exactly(rig_name, persons, max_det, max_hyp):
     """The launch structures of the camera sweep — a cost + an assignment launch per camera, one wavefront per frame with its working set in
     LDS (default for small rigs) or in global memory — must give the same hypotheses, association tables and persons (crowded, noisy frames
     so that the Hungarian branch runs)."""
     from smartedgesensor3dhumanpose_amd.skeleton_3d import rig_tensors
-    rig = R.extr_rig_16cam() if rig_name == "extr16" else R.elliptical_rig(24, seed=4)
+    # ("ell96": more than 64 cameras with a small hypothesis x detection matrix — the default must be the one-launch sweep with its state in
+    # global memory there, not 2 N dependent launches: ADVICE r5)
+    rig = R.extr_rig_16cam() if rig_name == "extr16" else R.elliptical_rig(int(rig_name[3:]), seed=4)
     rig.set_tensors(*rig_tensors(rig))
     frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=persons, n_frames=8, seed=77, pixel_noise=4.0, low_score_frac=0.15, p_miss=0.1,
                                                        spacing=0.7, min_coverage=4 if rig_name == "extr16" else 6))

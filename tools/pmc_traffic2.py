@@ -40,17 +40,22 @@ res = {"workload": note, "sequences": seqs, "source": "rocprofv3 --kernel-trace 
        "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide streaming reads; gather "
                      "kernels may be overstated by the x2; MI355X_MICROARCH.md, HBM)", "kernels": {}}
 total = 0
+# launches per pass of a kernel = its sampled launches / those of the post-processing kernel, which runs exactly once per stage-1 pass (round 6:
+# round 5's total summed ONE launch per kernel although the pair kernel runs once per column chunk and the sweep kernels once per camera)
+passes = max([fc.get(k, 0) for k in ("postprocess", "postprocess_block")] + [wc.get(k, 0) for k in ("postprocess", "postprocess_block")] + [1])
 for k in sorted(set(ft) | set(wt)):
     if k.startswith("__amd"):
         continue
     f = ft[k] / max(fc.get(k, 1), 1)
     w_ = wt[k] / max(wc.get(k, 1), 1)
     b = int((2 * f + w_) * 1024)
+    per_pass = max(fc.get(k, 0), wc.get(k, 0)) / passes
     if "reproj" not in k:   # the feedback reprojection follows the path; `pipeline` = one step of stage 1 + stage 2
-        total += b
+        total += int(b * per_pass)
     res["kernels"][k] = {"fetch_size_kb_per_launch": round(f, 1), "write_size_kb_per_launch": round(w_, 1), "launches_sampled": int(fc.get(k, 0)),
-                         "hbm_bytes_per_launch_corrected": b}
-res["pipeline_bytes_per_step_corrected"] = total
+                         "launches_per_pass": round(per_pass, 3), "hbm_bytes_per_launch_corrected": b}
+res["passes_sampled"] = passes
+res["pipeline_bytes_per_step_corrected"] = total   # sum over the kernels of bytes per launch x launches per pass
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smartedgesensor3dhumanpose_amd._lib import source_hash  # noqa: E402
 res["source_hash"] = source_hash()   # the kernel sources these counts were collected on (bench.py uses the summary only for the same sources)

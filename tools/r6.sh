@@ -32,6 +32,39 @@ robust_prof)
   python3 tools/kernel_stats.py $O/rough_stats_$tag $O/serial_16cam6p_rough_${tag}_kernel_stats.csv | head -12
   rm -rf $O/rough_stats_$tag
   ;;
+rough_ab)
+  # variant libraries tools/tmp/libse3d_<name>.so (tools/build_variants.sh) through the rough-scene serial pass: AB="name ..."
+  for V in ${AB:-}; do
+    rm -rf $O/rough_stats_$V
+    export SE3D_LIB_OVERRIDE=$GRAFT_REPO_ROOT/tools/tmp/libse3d_$V.so
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rough_stats_$V -- python3 bench.py --workload 16cam6p_rough --serial --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/rough_serial_$V.log 2>&1
+    unset SE3D_LIB_OVERRIDE
+    python3 tools/kernel_stats.py $O/rough_stats_$V $O/serial_16cam6p_rough_${V}_kernel_stats.csv | grep "triangulate" | sed "s/^/$V: /"
+    rm -rf $O/rough_stats_$V
+  done
+  ;;
+rough_pmc)
+  tag=${1:-x}; shift || true
+  SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+  rm -rf $O/rough_sq_$tag
+  timeout 600 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/rough_sq_$tag -- python3 bench.py --workload 16cam6p_rough --serial --steps 2 --warmup 1 --no-cpu-baseline --no-parity > $O/rough_sq_$tag.log 2>&1
+  python3 tools/pmc_sq.py $O/rough_sq_$tag $O/pmc_sq_16cam6p_rough_$tag.json "bench.py --workload 16cam6p_rough --serial --steps 2 --warmup 1"
+  python3 -c "
+import json
+d = json.load(open('$O/pmc_sq_16cam6p_rough_$tag.json'))['kernels']
+for k in ('triangulate_second_pass', 'triangulate'):
+    print(k, json.dumps(d.get(k)))"
+  rm -rf $O/rough_sq_$tag
+  ;;
+rough_scan)
+  # second-pass fraction and rates of the rough-scene serial pass under parameter overrides: ROUGHS="a=b,c=d e=f ..."
+  for R in ${ROUGHS:-}; do
+    timeout 600 python3 bench.py --workload 16cam6p_rough --serial --steps 3 --warmup 1 --no-cpu-baseline --no-parity --rough "$R" 2>/dev/null | tail -1 | python3 -c "
+import json, sys
+d = json.loads(sys.stdin.readline())
+print('$R', d['value'], d['ms_per_step'], d['second_pass'], {k: v for k, v in d['roofline'].items() if k in ('kernel', 'avg_launch_ms')})"
+  done
+  ;;
 sdma)
   for i in 1 2; do timeout 300 tools/microbench/sdma_pair 3 > $O/sdma_pair_$i.txt 2>&1; done
   cat $O/sdma_pair_1.txt
