@@ -433,14 +433,30 @@ __device__ __forceinline__ float se3d_safe_rcp(float b) {
 #define RB_ROWS 48
 #define RB_COLS 32
 #define RB_NT 256                       // threads per workgroup
-#define RB_WPAIRS (RB_ROWS / 8)          // row pairs a wavefront can carry (one accumulator each)
+// Lanes per det_a row.  32 (default, rounds 2 - 6): a wavefront-instruction carries TWO rows x 32 columns, one det_b column per lane, and every item
+// pays one det_a operand read (two ds_read_b128 with two half-wave-uniform addresses).  16 (round 6, -DRB_RL=16, kept as a compile-time form):
+// FOUR rows x 16 lanes, each lane carrying TWO det_b columns (ql, ql + 16), so that one operand read serves two items per lane — the lever
+// round 5's review named ("the LDS pipe, not the VALU, is the wall").  Built, bit-identical, and SLOWER in every joint grouping that fits
+// (profiles/r6/ab/: 3 joints per phase 15.25 ms, 4: 14.98, 5 at three wavefronts per SIMD: 16.58, 6 at three: 15.58, against 14.02 - 14.08 for this
+// layout on the same box).  The counters say why (profiles/r6/ab/pmc_*_rl32.json, *_rl16j3.json): the vector ALU is busy the whole time in BOTH
+// forms (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles) = 1.19 / 1.08; 7.87 G / 8.52 G VALU wave-instructions per launch at ~3.4 cycles each — the
+// item's v_cvt_f64_f32 and v_add_f64 hold the port 4.3 cycles, profiles/r2/microbench_valu_rates.txt), LDS instructions fall only from 0.97 G to
+// 0.79 G (the det_b operands are fetched per lane and phase: twice as many with two columns) while VALU instructions rise 8 % and SALU 52 %
+// (twice the phases).  The 5.7 ms that round 5's `nolds` ablation attributed to the LDS reads is read-to-use LATENCY inside a VALU-saturated
+// schedule, not LDS bandwidth: the kernel is bound by vector issue, and fewer instructions per item is the only lever left.
+#ifndef RB_RL
+#define RB_RL 32
+#endif
+#define RB_CPL (RB_COLS / RB_RL)          // det_b columns per lane
+#define RB_RPI (64 / RB_RL)               // det_a rows per wavefront-instruction
+#define RB_WSTEPS (RB_ROWS / 4 / RB_RPI)  // row steps a wavefront can carry (RB_CPL accumulators each)
 // LDS rows are padded by one operand (32 B = 8 banks): the staging threads of a wavefront write the SAME detection slot of consecutive
 // joints, and an unpadded joint stride (48 or 32 operands) is a multiple of 128 B — every lane on the same four banks (17-way / 6-way
 // conflicts, 29 % of the LDS busy cycles in profiles/r2/pmc_lds_256cam128p_rows.json before the padding)
 #define RB_ROWS_P (RB_ROWS + 1)
 #define RB_COLS_P (RB_COLS + 1)
 #ifndef RB_JH
-#define RB_JH 6
+#define RB_JH (RB_RL == 16 ? 3 : 6)
 #endif
 #define RB_JLAST (SE3D_NKP % RB_JH ? SE3D_NKP % RB_JH : RB_JH)   // joints of the last phase
 struct __align__(16) RowOp { float lx, ly, lz, nrm, x, y, rcp, z; };   // z: the point's homogeneous coordinate, 1 (usable) or 0
@@ -487,30 +503,35 @@ __device__ __forceinline__ RowOp se3d_rowop(float lx, float ly, float lz, float 
 }
 
 template <int JN>
-__device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS_P], const RowOp (&b)[RB_JH], int jbase, int row0, int nrows_left,
-                                                  double (&acc)[RB_WPAIRS]) {
-  // Straight-line code over (row pair, joint).  The det_a operand of the NEXT item is fetched from LDS while the current item is
+__device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS_P], const RowOp (&b)[RB_CPL][RB_JH], int jbase, int row0, int nrows_left,
+                                                  double (&acc)[RB_WSTEPS][RB_CPL]) {
+  // Straight-line code over (row step, joint).  The det_a operand of the NEXT item is fetched from LDS while the current one is
   // computed (two RowOp in flight = 16 registers).  The memory-clobbering empty asm after every item is what keeps it that way: without
   // it the det_a operands — which do not change from one column tile to the next — are lifted out of the column loop by loop-invariant
   // code motion, and the independent LDS reads of the block are all issued first (102 reads = 816 registers, 2 KB of scratch per lane).
   asm volatile("" ::: "memory");
   RowOp a = A[jbase][row0];
 #pragma unroll
-  for (int r = 0; r < RB_WPAIRS; ++r) {
-    // wave-uniform (scalar) skip of the row pairs beyond the wavefront's last row.  NOT a `break`: the early exit made the compiler copy the
-    // other accumulators to the exit block's registers before every row pair (five 64-bit moves per six items).
-    if (2 * r < nrows_left) {
-    const int row = row0 + 2 * r;
+  for (int r = 0; r < RB_WSTEPS; ++r) {
+    // wave-uniform (scalar) skip of the row steps beyond the wavefront's last row.  NOT a `break`: the early exit made the compiler copy the
+    // other accumulators to the exit block's registers before every row step (five 64-bit moves per six items).
+    if (RB_RPI * r < nrows_left) {
+    const int row = row0 + RB_RPI * r;
 #pragma unroll
     for (int jj = 0; jj < JN; ++jj) {
-      const bool last_j = jj + 1 == JN, last_r = r + 1 == RB_WPAIRS;
-      const RowOp an = A[last_j ? jbase : jbase + jj + 1][last_j ? (last_r ? row0 : row + 2) : row];
-      const float n1 = fabsf(b[jj].x * a.lx + __builtin_fmaf(b[jj].z, a.lz, b[jj].y * a.ly));   // z = 1: RN(a.lz + t), the reference's addition
-      const float n2 = fabsf(a.x * b[jj].lx + __builtin_fmaf(a.z, b[jj].lz, a.y * b[jj].ly));
-      const float d1 = se3d_div_shared(n1, a.nrm, a.rcp), d2 = se3d_div_shared(n2, b[jj].nrm, b[jj].rcp);
-      const float sacc = d1 + d2;   // exactly 0 unless both sides have the joint (se3d_rowop)
-      acc[r] += (double)sacc;
-      asm volatile("" : "+v"(acc[r]) : : "memory");  // the item is complete (accumulated) before the fence; the next item's LDS read comes after it
+      const bool last_j = jj + 1 == JN, last_r = r + 1 == RB_WSTEPS;
+      const RowOp an = A[last_j ? jbase : jbase + jj + 1][last_j ? (last_r ? row0 : row + RB_RPI) : row];
+#pragma unroll
+      for (int c = 0; c < RB_CPL; ++c) {   // one det_a operand, RB_CPL det_b columns
+        const float n1 = fabsf(b[c][jj].x * a.lx + __builtin_fmaf(b[c][jj].z, a.lz, b[c][jj].y * a.ly));   // z = 1: RN(a.lz + t), the reference's addition
+        const float n2 = fabsf(a.x * b[c][jj].lx + __builtin_fmaf(a.z, b[c][jj].lz, a.y * b[c][jj].ly));
+        const float d1 = se3d_div_shared(n1, a.nrm, a.rcp), d2 = se3d_div_shared(n2, b[c][jj].nrm, b[c][jj].rcp);
+        const float sacc = d1 + d2;   // exactly 0 unless both sides have the joint (se3d_rowop)
+        acc[r][c] += (double)sacc;
+      }
+      // the item is complete (accumulated) before the fence; the next item's LDS read comes after it
+      if (RB_CPL == 2) asm volatile("" : "+v"(acc[r][0]), "+v"(acc[r][RB_CPL - 1]) : : "memory");
+      else asm volatile("" : "+v"(acc[r][0]) : : "memory");
       a = an;
     }
     }
@@ -519,18 +540,21 @@ __device__ __forceinline__ void se3d_rows_compute(const RowOp (*A)[RB_ROWS_P], c
 // IEEE-divide form for blocks whose operands fail the range guard of the shared-reciprocal divide (practically never): compact loops, both
 // operands from LDS.
 __device__ __forceinline__ void se3d_rows_compute_slow(const RowOp (*A)[RB_ROWS_P], const RowOp (*Bc)[RB_COLS_P], int ql, int jbase, int jn, int row0,
-                                                       unsigned m2, const unsigned *M1, double (&acc)[RB_WPAIRS]) {
+                                                       const unsigned (&m2)[RB_CPL], const unsigned *M1, double (&acc)[RB_WSTEPS][RB_CPL]) {
 #pragma unroll
-  for (int r = 0; r < RB_WPAIRS; ++r) {
-    const int row = row0 + 2 * r;
-    const unsigned mm = M1[row] & m2;
+  for (int r = 0; r < RB_WSTEPS; ++r) {
+    const int row = row0 + RB_RPI * r;
+#pragma unroll
+    for (int c = 0; c < RB_CPL; ++c) {
+      const unsigned mm = M1[row] & m2[c];
 #pragma unroll 1
-    for (int jj = 0; jj < jn; ++jj) {
-      const RowOp a = A[jbase + jj][row], bq = Bc[jj][ql];
-      const float n1 = fabsf(bq.x * a.lx + (bq.y * a.ly + a.lz));
-      const float n2 = fabsf(a.x * bq.lx + (a.y * bq.ly + bq.lz));
-      const float sacc = n1 / a.nrm + n2 / bq.nrm;
-      acc[r] += ((mm >> (jbase + jj)) & 1u) ? (double)sacc : 0.0;
+      for (int jj = 0; jj < jn; ++jj) {
+        const RowOp a = A[jbase + jj][row], bq = Bc[jj][ql + RB_RL * c];
+        const float n1 = fabsf(bq.x * a.lx + (bq.y * a.ly + a.lz));
+        const float n2 = fabsf(a.x * bq.lx + (a.y * bq.ly + bq.lz));
+        const float sacc = n1 / a.nrm + n2 / bq.nrm;
+        acc[r][c] += ((mm >> (jbase + jj)) & 1u) ? (double)sacc : 0.0;
+      }
     }
   }
 }
@@ -552,7 +576,7 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
   const int na_all = D.nvalid[f * N + ab.x], nb = D.nvalid[f * N + ab.y];
   const int ntiles = (na_all + RB_ROWS - 1) / RB_ROWS;               // balanced row tiles of the camera's detections
   if ((int)blockIdx.x >= ntiles || nb == 0) return;
-  const int tile_rows = ((na_all + ntiles - 1) / ntiles + 1) & ~1;   // even: a wavefront carries row pairs
+  const int tile_rows = ((na_all + ntiles - 1) / ntiles + RB_RPI - 1) & ~(RB_RPI - 1);   // a wavefront-instruction carries RB_RPI rows
   const int p0 = blockIdx.x * tile_rows;
   if (p0 >= na_all) return;
   const int na = min(na_all, p0 + tile_rows);                        // rows p0 .. na - 1 are this tile's
@@ -562,14 +586,14 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
   // 12 rows first and the staging wavefronts share the rest: nrw rows each, the smallest even number with 3 nrw + 12 >= rows
   // (14.31 -> 14.15 ms per launch at 256cam128p; with seven accumulators and 14 rows for wavefront 3: 14.23, 128 VGPRs).
   const int nt = na - p0;
-  const int nrw = min(RB_ROWS / 4, max(2, ((max(0, nt - 2 * RB_WPAIRS) + 2) / 3 + 1) & ~1));   // rows of each staging wavefront
-  const int nr3 = min(2 * RB_WPAIRS, RB_ROWS - 3 * nrw);                            // rows wavefront 3 can take (>= nt - 3 nrw by construction)
+  const int nrw = min(RB_ROWS / 4, max(RB_RPI, ((max(0, nt - RB_ROWS / 4) + 2) / 3 + RB_RPI - 1) & ~(RB_RPI - 1)));   // rows of each of wavefronts 0 - 2
+  const int nr3 = min(RB_ROWS / 4, RB_ROWS - 3 * nrw);                              // rows wavefront 3 can take (>= nt - 3 nrw by construction)
   __shared__ RowOp A[SE3D_NKP][RB_ROWS_P];  // det_a side, all joints: staged once per workgroup (26 KB)
   __shared__ RowOp Bc[2][RB_JH][RB_COLS_P];  // det_b side of a (column tile, joint group) phase, double-buffered (2 x 6 KB)
   __shared__ unsigned M1[RB_ROWS], M2[2][RB_COLS];
   __shared__ int s_unsafe_a;   // range-guard flag of the det_a side (the det_b side: rcp = 0 in the operand, tested from registers)
   __shared__ double INV[SE3D_NKP + 1];     // RN(1 / n) for the joint count of an entry
-  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, ql = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, sub = lane / RB_RL, ql = lane % RB_RL;   // sub: the lane's row inside a wavefront-instruction
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything derived from it is a uniform branch, not an exec mask
   const float *F = D.F + 9 * (size_t)se3d_pair_index(ab.x, ab.y, N);   // F is stored in the reference's pair order (get_fundamental_idx)
   const float f0 = F[0], f1 = F[1], f2 = F[2], f3 = F[3], f4 = F[4], f5 = F[5], f6 = F[6], f7 = F[7], f8 = F[8];
@@ -600,12 +624,14 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
     }
     if (unsafe) s_unsafe_a = 1;
   }
-  const int row0 = wave * nrw + half;                        // this lane's first row inside the tile; row pairs r: row0 + 2 r
+  const int row0 = wave * nrw + sub;                         // this lane's first row inside the tile; row steps r: row0 + RB_RPI r
   const int nshare = wave == 3 ? nr3 : nrw;                  // rows this wavefront owns (wave-uniform)
   const int nrows_left = min(nshare, nt - wave * nrw);       // ... and those of them that exist
   double *out = D.pair + ((size_t)f * np + pr) * P * P;
-  double acc[RB_WPAIRS];
-  unsigned m2 = 0u;
+  double acc[RB_WSTEPS][RB_CPL];
+  unsigned m2[RB_CPL];
+#pragma unroll
+  for (int c = 0; c < RB_CPL; ++c) m2[c] = 0u;
   // One (detection, joint) operand of the det_b side per thread and phase (RB_COLS x RB_JH <= 256).  Its global loads are issued a whole
   // phase ahead (before the barrier and the compute of the current phase), and the entries of a finished column tile are stored one
   // phase late, after those loads have been consumed: loads and stores retire through one in-order counter (vmcnt), so a load issued
@@ -623,20 +649,25 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
     premq = 0u;
     if (tid < RB_COLS * jn && q < nb) { pre4 = kpB[q * SE3D_NKP + jbase + jj]; premq = vmB[q]; }
   };
-  auto flush = [&](int q0_done) {   // the LDS reads of the six entries first (two batches of independent reads), then the arithmetic and the stores
-    const int q = q0_done + ql;
-    int nn[RB_WPAIRS];
-    double iv[RB_WPAIRS];
+  auto flush = [&](int q0_done) {   // the LDS reads of the entries first (batches of independent reads), then the arithmetic and the stores
+    int nn[RB_WSTEPS][RB_CPL];
+    double iv[RB_WSTEPS][RB_CPL];
 #pragma unroll
-    for (int r = 0; r < RB_WPAIRS; ++r) nn[r] = __popc(M1[row0 + 2 * r] & m2);
+    for (int r = 0; r < RB_WSTEPS; ++r)
 #pragma unroll
-    for (int r = 0; r < RB_WPAIRS; ++r) iv[r] = INV[nn[r]];
-    double *o = out + (size_t)(p0 + row0) * P + q;
+      for (int c = 0; c < RB_CPL; ++c) nn[r][c] = __popc(M1[row0 + RB_RPI * r] & m2[c]);
 #pragma unroll
-    for (int r = 0; r < RB_WPAIRS; ++r) {
-      const int p = p0 + row0 + 2 * r;
-      if (2 * r < nshare && p < na && q < nb)   // (row pairs beyond the wavefront's share belong to the next wavefront)
-        o[(size_t)(2 * r) * P] = nn[r] > 0 ? se3d_div_count(acc[r], nn[r], iv[r]) : -1.0;
+    for (int r = 0; r < RB_WSTEPS; ++r)
+#pragma unroll
+      for (int c = 0; c < RB_CPL; ++c) iv[r][c] = INV[nn[r][c]];
+    double *o = out + (size_t)(p0 + row0) * P + q0_done + ql;
+#pragma unroll
+    for (int r = 0; r < RB_WSTEPS; ++r) {
+      const int p = p0 + row0 + RB_RPI * r;
+#pragma unroll
+      for (int c = 0; c < RB_CPL; ++c)
+        if (RB_RPI * r < nshare && p < na && q0_done + ql + RB_RL * c < nb)   // (row steps beyond the wavefront's share belong to the next wavefront)
+          o[(size_t)(RB_RPI * r) * P + RB_RL * c] = nn[r][c] > 0 ? se3d_div_count(acc[r][c], nn[r][c], iv[r][c]) : -1.0;
     }
   };
   // Phase ph = (column tile ph / NPH, joint group ph % NPH).  While a phase computes from registers, the operands of the NEXT phase are
@@ -676,17 +707,24 @@ __global__ __launch_bounds__(RB_NT, RB_WPE) void se3d_k_pairs_rows(Se3dDev D, co
     if (jbase == 0) {
       if (ph > 0) flush(q0 - RB_COLS);
 #pragma unroll
-      for (int r = 0; r < RB_WPAIRS; ++r) acc[r] = 0.0;
-      m2 = M2[(ph / NPH) & 1][ql];
+      for (int r = 0; r < RB_WSTEPS; ++r)
+#pragma unroll
+        for (int c = 0; c < RB_CPL; ++c) acc[r][c] = 0.0;
+#pragma unroll
+      for (int c = 0; c < RB_CPL; ++c) m2[c] = M2[(ph / NPH) & 1][ql + RB_RL * c];
     }
     RB_STAMP(5)   // flush of the finished column tile + accumulator reset
     prefetch_ph(ph + 2);
-    RowOp b[RB_JH];
+    RowOp b[RB_CPL][RB_JH];
 #pragma unroll
-    for (int jj = 0; jj < RB_JH; ++jj) b[jj] = Bc[ph & 1][jj < jn ? jj : 0][ql];
+    for (int c = 0; c < RB_CPL; ++c)
+#pragma unroll
+      for (int jj = 0; jj < RB_JH; ++jj) b[c][jj] = Bc[ph & 1][jj < jn ? jj : 0][ql + RB_RL * c];
     bool bad_b = false;
 #pragma unroll
-    for (int jj = 0; jj < RB_JH; ++jj) bad_b |= b[jj].rcp == 0.f;
+    for (int c = 0; c < RB_CPL; ++c)
+#pragma unroll
+      for (int jj = 0; jj < RB_JH; ++jj) bad_b |= b[c][jj].rcp == 0.f;
     const bool any_unsafe = unsafe_a != 0 || __ballot(bad_b) != 0ull;   // wave-uniform: shared-reciprocal divide or IEEE divide
 #ifdef SE3D_LM_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

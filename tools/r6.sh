@@ -76,6 +76,22 @@ c256)
   python3 tools/kernel_stats.py $O/c256_stats_$tag $O/c256_1ctx_${tag}_kernel_stats.csv | head -12
   rm -rf $O/c256_stats_$tag
   ;;
+c256_ab)
+  # variant libraries through the one-context 256cam128p pass: AB="name ..."
+  for V in ${AB:-}; do
+    rm -rf $O/c256_stats_$V
+    export SE3D_LIB_OVERRIDE=$GRAFT_REPO_ROOT/tools/tmp/libse3d_$V.so
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c256_stats_$V -- python3 bench.py --workload 256cam128p --contexts 1 --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/c256_bench_1ctx_$V.log 2>&1
+    unset SE3D_LIB_OVERRIDE
+    python3 tools/kernel_stats.py $O/c256_stats_$V $O/c256_1ctx_${V}_kernel_stats.csv | grep "pairs_rows" | sed "s/^/$V: /"
+    rm -rf $O/c256_stats_$V
+  done
+  ;;
+tests)
+  # selected test files: TESTS="tests/a.py tests/b.py"
+  timeout 1500 python -m pytest ${TESTS:-tests} -m gpu -q -x > $O/pytest_sel.log 2>&1
+  tail -5 $O/pytest_sel.log
+  ;;
 suite)
   timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > $O/pytest_gpu.log 2>&1
   tail -5 $O/pytest_gpu.log
