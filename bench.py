@@ -672,6 +672,23 @@ def gpu_local_cpus(device):
         return None
 
 
+def numa_nodes_of(addr, nbytes, samples=8):
+    """NUMA node of `samples` pages spread over [addr, addr + nbytes): move_pages(2) in query mode (x86-64 syscall 279); None when the kernel refuses."""
+    import ctypes
+    try:
+        libc = ctypes.CDLL(None, use_errno=True)
+        out = []
+        for i in range(samples):
+            page = ctypes.c_void_p((addr + (nbytes * i) // samples) & ~4095)
+            status = ctypes.c_int(-1000)
+            if libc.syscall(279, 0, 1, ctypes.byref(page), None, ctypes.byref(status), 0) != 0:
+                return None
+            out.append(int(status.value))
+        return out
+    except Exception:
+        return None
+
+
 def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out=0, affinity="local"):
     """PCIe-inclusive rate (never `value`): every step each context receives its batch of frames from HOST memory (se3d_stream_submit:
     ragged payload into pinned memory, H2D on a copy stream, expansion on the device, stage 1, stage-2 walk, device compaction of the
@@ -699,6 +716,7 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
             in_bytes += sum(int(f.det_offset[-1]) for f in frames) * 428
         counts = [[0, 0] for _ in nodes]   # published persons, bytes out per context (timed region)
         step_ms = []
+        diag = {}
         go, done = threading.Barrier(NC + 1), threading.Barrier(NC + 1)
 
         def worker(ci):
@@ -717,11 +735,19 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
             go.wait()
             t_prev = time.perf_counter()
             for _ in range(steps):
+                ta = time.perf_counter()
                 submit()
+                tb = time.perf_counter()
                 off, fused, _pred = nd_.stream_collect(copy=False)
+                if ci == 0:   # host time of the two calls (context 0): submit = copy into pinned memory + enqueue, collect = wait for the oldest batch + its download
+                    diag.setdefault("submit_ms", []).append((tb - ta) * 1e3)
+                    diag.setdefault("collect_ms", []).append((time.perf_counter() - tb) * 1e3)
                 counts[ci][0] += int(off[-1])
                 counts[ci][1] += 2 * int(off[-1]) * 1688 + 4 * len(off)
                 if ci == 0:   # context 0's step times: tells a uniformly slow run (both copy directions at ~60 %: one run in ten, cause open) from a transient
+                    if "numa" not in diag and len(fused):   # where the context's pinned output buffer lives, and where this thread runs
+                        diag["numa"] = numa_nodes_of(fused.ctypes.data, fused.nbytes)
+                        diag["cpu"] = os.sched_getcpu() if hasattr(os, "sched_getcpu") else None
                     t_now = time.perf_counter()
                     step_ms.append(round((t_now - t_prev) * 1e3, 2))
                     t_prev = t_now
@@ -736,6 +762,7 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
         dt = time.perf_counter() - t0
         for th in threads:
             th.join()
+        diag["probe"] = nodes[0].copy_stream_probe()   # untimed, after the measurement: do the device's two copy streams (still) overlap?
         for nd_ in nodes:
             nd_.close()
     finally:
@@ -744,6 +771,8 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
     n_skel = sum(c[0] for c in counts)
     return {"value": n_skel / dt, "ms_per_step": dt / steps * 1e3, "contexts": NC, "sequences_per_context": S_, "steps": steps,
             "host_threads": ("on the %d CPUs of the GPU's NUMA node" % len(local)) if local else "unpinned", "step_ms_context0": step_ms,
+            "pinned_output_numa_nodes_context0": diag.get("numa"), "worker_cpu_context0": diag.get("cpu"), "copy_stream_probe": diag.get("probe"),
+            "host_call_ms_context0": {"submit_mean": round(float(np.mean(diag.get("submit_ms", [0]))), 2), "collect_mean": round(float(np.mean(diag.get("collect_ms", [0]))), 2)},
             "h2d_gb_per_s": in_bytes * steps / dt / 1e9, "d2h_gb_per_s": sum(c[1] for c in counts) / dt / 1e9,
             "h2d_mb_per_step": in_bytes / 1e6, "skeletons_per_step": n_skel // steps}
 
@@ -925,6 +954,8 @@ def main():
     ap.add_argument("--stream-out", type=int, default=0, choices=[0, 1], help="se3d_options.stream_out of the streaming measurement: 0 = device buffers + D2H copies (default), "
                     "1 = the compaction kernel writes the published persons into pinned host memory")
     ap.add_argument("--stream-affinity", choices=["local", "none"], default="local", help="streaming pass: host threads on the GPU's NUMA node (sysfs local_cpulist) or unpinned")
+    ap.add_argument("--stream-repeat", type=int, default=1, help="diagnostic: repeat the streaming measurement this many times in the process (each with fresh contexts); "
+                    "every result goes to stderr, the last into the line")
     ap.add_argument("--stream-contexts", type=int, default=8, help="contexts of the streaming measurement (each pins two batches of host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rough", default="", help="diagnostic: overrides of scene.ROUGH for the rough-scene workload, e.g. pixel_noise=3.5,outlier_frac=0.012")
@@ -1068,7 +1099,12 @@ def main():
         run_secondary()
     streaming = None
     if default_run and not args.no_streaming and stage2 and rank == 0:
-        streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps), 2, local_rank, args.stream_out, args.stream_affinity)   # ~0.7 s timed at the default 20 steps
+        for rep in range(max(1, args.stream_repeat)):
+            streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps), 2, local_rank, args.stream_out, args.stream_affinity)   # ~0.7 s timed at the default 20 steps
+            if args.stream_repeat > 1:
+                print("streaming pass %d: %.2f M skeletons/s, H2D %.1f GB/s, D2H %.1f GB/s, step ms %s, pinned output on NUMA nodes %s, copy-stream probe %s"
+                      % (rep, streaming["value"] / 1e6, streaming["h2d_gb_per_s"], streaming["d2h_gb_per_s"], streaming["step_ms_context0"],
+                         streaming["pinned_output_numa_nodes_context0"], dict(streaming["copy_stream_probe"], **streaming["host_call_ms_context0"])), file=sys.stderr, flush=True)
     # ---- latency mode of north_star config 5, LAST and guarded: one 256cam128p stream with its hypotheses sharded over the ranks.  Every
     # measurement of the line above is already taken; an exception here is reported in the block, and a collective that does not return
     # within the deadline (ranks != 0 wait in it while rank 0 runs its serial / streaming passes: minutes at most) ends the run with the
@@ -1171,6 +1207,7 @@ def main():
             line["streaming"] = {"value": round(streaming["value"], 2), "unit": "skeletons/s", "fraction_of_resident": round(streaming["value"] / main_res["value_per_gpu"], 4),
                                  "ms_per_step": round(streaming["ms_per_step"], 3), "contexts": streaming["contexts"], "sequences_per_context": streaming["sequences_per_context"],
                                  "h2d_GB_per_s": round(streaming["h2d_gb_per_s"], 2), "d2h_GB_per_s": round(streaming["d2h_gb_per_s"], 2), "host_threads": streaming["host_threads"], "step_ms_context0": streaming["step_ms_context0"],
+                                 "pinned_output_numa_nodes_context0": streaming["pinned_output_numa_nodes_context0"], "copy_stream_probe": streaming["copy_stream_probe"], "host_call_ms_context0": streaming["host_call_ms_context0"],
                                  "h2d_MB_per_step": round(streaming["h2d_mb_per_step"], 1), "n_gpus": 1,
                                  "note": "PCIe-inclusive: every step's frames come from host memory (ragged, pinned, double-buffered) and the published "
                                          "persons go back to host memory; never `value`.  At 16cam6p a frame is ~40 KB in and ~20 KB out: PCIe Gen5 x16 "

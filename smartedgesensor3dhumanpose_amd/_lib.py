@@ -15,7 +15,7 @@ EXPORTS = [
     "se3d_profile_enable", "se3d_profile_reset", "se3d_profile_get",
     "se3d_set_reprojection_cameras", "se3d_reproject", "se3d_reproject_resident", "se3d_reproject_resident_batch", "se3d_fetch_reprojection",
     "se3d_run_stage2_walk", "se3d_fetch_stage2_walk", "se3d_pack_stage2_walk_device", "se3d_stream_handle", "se3d_pack_stage2_walk_device_slots", "se3d_pack_stage2_walk_device_dense",
-    "se3d_triangulate_assoc", "se3d_stage_assoc", "se3d_run_dlt", "se3d_fetch_dlt", "se3d_stream_submit", "se3d_stream_collect",
+    "se3d_triangulate_assoc", "se3d_stage_assoc", "se3d_run_dlt", "se3d_fetch_dlt", "se3d_stream_submit", "se3d_stream_collect", "se3d_copy_stream_probe",
     "se3d_run_stage1_phases", "se3d_set_shard", "se3d_shard_bytes", "se3d_run_stage1_shard_pre", "se3d_run_stage1_shard_post", "se3d_run_stage2_shard_pre", "se3d_run_stage2_shard_post",
 ]
 
@@ -100,6 +100,7 @@ def lib():
                      "se3d_triangulate_assoc", "se3d_stage_assoc", "se3d_run_dlt", "se3d_fetch_dlt", "se3d_stream_submit", "se3d_stream_collect",
                      "se3d_run_stage1_phases", "se3d_set_shard", "se3d_run_stage1_shard_pre", "se3d_run_stage1_shard_post", "se3d_run_stage2_shard_pre", "se3d_run_stage2_shard_post"):
             getattr(L, name).restype = C.c_int
+        L.se3d_copy_stream_probe.restype = C.c_int
         L.se3d_shard_bytes.restype = C.c_int64
         L.se3d_device_bytes.restype = C.c_int64
         L.se3d_device_bytes_ex.restype = C.c_int64

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1381,13 +1382,75 @@ int se3d_run_stage2_shard_post(se3d_ctx *c, int32_t n_seq, const void *d_gathere
 // The download direction likewise: ONE shared stream per device.  A download waits for its batch's kernels; enqueued with a device-side wait it
 // would block every other context's download behind it, so se3d_stream_collect waits for the batch on the HOST (compute_done), reads the number of
 // published persons from the offsets the scan kernel mirrored into pinned memory, and only then enqueues the two copies.
-static hipStream_t shared_copy_stream(int device, int dir /* 0: H2D, 1: D2H */) {
-  static std::mutex mu;
-  static hipStream_t streams[2][64] = {};
-  std::lock_guard<std::mutex> lk(mu);
+static std::mutex g_copy_mu;
+static hipStream_t g_copy_streams[2][64] = {};
+static int g_copy_recreated[64] = {};     // how often the pair of a device was re-created by the start-up probe (se3d_copy_stream_probe reports it)
+// Do an upload and a download on the device's two copy streams run side by side?  Four 32 MB copies per direction, queued back to back: each
+// direction alone, then both at once (host clock around enqueue + synchronise; ~10 ms in all).  out: GB/s {up alone, down alone, up | both, down | both}.
+static bool probe_copy_pair(hipStream_t up, hipStream_t down, double out[4]) {
+  const size_t n = (size_t)32 << 20;
+  const int reps = 4;
+  void *h0 = nullptr, *h1 = nullptr, *d0 = nullptr, *d1 = nullptr;
+  bool ok = hipHostMalloc(&h0, n, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&h1, n, hipHostMallocDefault) == hipSuccess &&
+            hipMalloc(&d0, n) == hipSuccess && hipMalloc(&d1, n) == hipSuccess;
+  auto run = [&](bool u, bool d) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < reps; ++k) {
+      if (u) ok = ok && hipMemcpyAsync(d0, h0, n, hipMemcpyHostToDevice, up) == hipSuccess;
+      if (d) ok = ok && hipMemcpyAsync(h1, d1, n, hipMemcpyDeviceToHost, down) == hipSuccess;
+    }
+    if (u) ok = ok && hipStreamSynchronize(up) == hipSuccess;
+    if (d) ok = ok && hipStreamSynchronize(down) == hipSuccess;
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  };
+  if (ok) {
+    (void)run(true, true);   // first touch of the buffers, first use of the streams
+    const double tu = run(true, false), td = run(false, true), tb = run(true, true);
+    const double gb = (double)reps * (double)n / 1e9;
+    out[0] = gb / tu; out[1] = gb / td; out[2] = gb / tb; out[3] = gb / tb;
+  }
+  if (h0) (void)hipHostFree(h0);
+  if (h1) (void)hipHostFree(h1);
+  if (d0) (void)hipFree(d0);
+  if (d1) (void)hipFree(d1);
+  return ok;
+}
+// (caller holds g_copy_mu and has made `device` current)
+static hipStream_t shared_copy_stream_locked(int device, int dir /* 0: H2D, 1: D2H */) {
   if (device < 0 || device >= 64) return nullptr;
-  if (!streams[dir][device] && hipStreamCreateWithFlags(&streams[dir][device], hipStreamNonBlocking) != hipSuccess) streams[dir][device] = nullptr;
-  return streams[dir][device];
+  if (!g_copy_streams[0][device] || !g_copy_streams[1][device]) {
+    // The pair is created together and PROBED (round 6).  One default bench.py run in about ten of round 5 streamed at 60 % of its rate for the whole
+    // run: every step took what the step's uploads and downloads take one after the other (profiles/r5/README.md section 5) — the signature of the two
+    // directions sharing one copy engine, which the runtime assigns to a stream at its first copies and keeps.  If both directions at once take
+    // longer than 80 % of the two alone, the pair is destroyed and created again (at most four times; se3d_copy_stream_probe reports the count).
+    for (int attempt = 0; attempt < 5; ++attempt) {
+      for (int d = 0; d < 2; ++d)
+        if (!g_copy_streams[d][device] && hipStreamCreateWithFlags(&g_copy_streams[d][device], hipStreamNonBlocking) != hipSuccess) g_copy_streams[d][device] = nullptr;
+      if (!g_copy_streams[0][device] || !g_copy_streams[1][device]) break;
+      double r[4] = {0, 0, 0, 0};
+      if (!probe_copy_pair(g_copy_streams[0][device], g_copy_streams[1][device], r)) break;   // (no memory for the probe: keep the pair)
+      const double t_alone = 1.0 / r[0] + 1.0 / r[1], t_both = 1.0 / r[2];
+      if (t_both < 0.8 * t_alone || attempt == 4) break;
+      for (int d = 0; d < 2; ++d) { (void)hipStreamDestroy(g_copy_streams[d][device]); g_copy_streams[d][device] = nullptr; }
+      ++g_copy_recreated[device];
+    }
+  }
+  return g_copy_streams[dir][device];
+}
+static hipStream_t shared_copy_stream(int device, int dir) {
+  std::lock_guard<std::mutex> lk(g_copy_mu);
+  return shared_copy_stream_locked(device, dir);
+}
+// Diagnostic (include/se3d.h): the probe on the device's CURRENT pair of copy streams (created if there is none yet), without re-creating anything.
+int se3d_copy_stream_probe(int32_t device, double *gbps4, int32_t *recreated) {
+  if (!gbps4 || device < 0 || device >= 64) return SE3D_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return SE3D_ERR_DEVICE;
+  std::lock_guard<std::mutex> lk(g_copy_mu);
+  hipStream_t up = shared_copy_stream_locked(device, 0), down = shared_copy_stream_locked(device, 1);
+  if (!up || !down) return SE3D_ERR_DEVICE;
+  if (!probe_copy_pair(up, down, gbps4)) return SE3D_ERR_DEVICE;
+  if (recreated) *recreated = g_copy_recreated[device];
+  return SE3D_OK;
 }
 static int stream_init(se3d_ctx *c) {
   if (c->stream_ready) return SE3D_OK;

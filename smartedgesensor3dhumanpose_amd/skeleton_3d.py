@@ -57,6 +57,7 @@ class Skeleton3D:
             why = self._L.se3d_last_error(None)
             raise Se3dError("se3d_create failed: %s; there is no CPU fallback" % (why.decode() if why else "no GPU, unsupported sizes or out of memory"))
         self._staged = 0
+        self.device = int(device)
 
     def set_options(self, **kw):
         """Change launch-time options of the live context (se3d_set_options), e.g. set_options(lm_form="dense"); pair_chunks,
@@ -153,6 +154,14 @@ class Skeleton3D:
         fused = np.frombuffer((C.c_char * (n * pm.person3d_dt.itemsize)).from_address(r.fused), dtype=pm.person3d_dt)
         pred = np.frombuffer((C.c_char * (n * pm.person3d_dt.itemsize)).from_address(r.fused_pred), dtype=pm.person3d_dt)
         return (off.copy(), fused.copy(), pred.copy()) if copy else (off, fused, pred)
+
+    def copy_stream_probe(self):
+        """Diagnostic: do the device's shared upload and download streams overlap?  dict(up_alone, down_alone, up_both, down_both in GB/s, recreated)."""
+        r = (C.c_double * 4)()
+        n = C.c_int32(0)
+        self._chk(self._L.se3d_copy_stream_probe(C.c_int32(self.device), r, C.byref(n)), "se3d_copy_stream_probe")
+        return {"up_alone_GBps": round(r[0], 1), "down_alone_GBps": round(r[1], 1), "up_both_GBps": round(r[2], 1), "down_both_GBps": round(r[3], 1),
+                "pair_recreated_at_start": int(n.value)}
 
     # -- resident pipeline
     def stage(self, frames):

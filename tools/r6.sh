@@ -65,6 +65,18 @@ d = json.loads(sys.stdin.readline())
 print('$R', d['value'], d['ms_per_step'], d['second_pass'], {k: v for k, v in d['roofline'].items() if k in ('kernel', 'avg_launch_ms')})"
   done
   ;;
+stream_diag)
+  # the default run's passes (secondary, headline, serial) followed by REPEATED streaming passes in the same process: n processes x r passes
+  n=${1:-3}; shift || true
+  r=${1:-6}; shift || true
+  grep -H "MemFree\|MemTotal" /sys/devices/system/node/node*/meminfo > $O/stream_diag_numa.txt 2>&1
+  for i in $(seq 1 $n); do
+    timeout 900 python bench.py --no-parity --no-cpu-baseline --no-robust --stream-repeat $r ${STREAM_FLAGS:-} > $O/stream_diag_$i.log 2> $O/stream_diag_$i.err
+    grep "streaming pass" $O/stream_diag_$i.err | sed "s/^/proc $i: /"
+    grep -H "MemFree" /sys/devices/system/node/node*/meminfo >> $O/stream_diag_numa.txt 2>&1
+  done
+  cat $O/stream_diag_numa.txt | head -8
+  ;;
 sdma)
   for i in 1 2; do timeout 300 tools/microbench/sdma_pair 3 > $O/sdma_pair_$i.txt 2>&1; done
   cat $O/sdma_pair_1.txt
