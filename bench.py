@@ -717,6 +717,8 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
         counts = [[0, 0] for _ in nodes]   # published persons, bytes out per context (timed region)
         step_ms = []
         diag = {}
+        slowest = [[-1, 0.0, 0.0] for _ in nodes]
+        diag["slowest"] = slowest
         go, done = threading.Barrier(NC + 1), threading.Barrier(NC + 1)
 
         def worker(ci):
@@ -739,6 +741,9 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
                 submit()
                 tb = time.perf_counter()
                 off, fused, _pred = nd_.stream_collect(copy=False)
+                t_end = time.perf_counter()
+                if (t_end - ta) * 1e3 > slowest[ci][1]:
+                    slowest[ci] = [_, round((t_end - ta) * 1e3, 1), round((tb - ta) * 1e3, 1)]   # step index, whole step ms, of it submit ms
                 if ci == 0:   # host time of the two calls (context 0): submit = copy into pinned memory + enqueue, collect = wait for the oldest batch + its download
                     diag.setdefault("submit_ms", []).append((tb - ta) * 1e3)
                     diag.setdefault("collect_ms", []).append((time.perf_counter() - tb) * 1e3)
@@ -772,7 +777,10 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
     return {"value": n_skel / dt, "ms_per_step": dt / steps * 1e3, "contexts": NC, "sequences_per_context": S_, "steps": steps,
             "host_threads": ("on the %d CPUs of the GPU's NUMA node" % len(local)) if local else "unpinned", "step_ms_context0": step_ms,
             "pinned_output_numa_nodes_context0": diag.get("numa"), "worker_cpu_context0": diag.get("cpu"), "copy_stream_probe": diag.get("probe"),
-            "host_call_ms_context0": {"submit_mean": round(float(np.mean(diag.get("submit_ms", [0]))), 2), "collect_mean": round(float(np.mean(diag.get("collect_ms", [0]))), 2)},
+            "host_call_ms_context0": {"submit_mean": round(float(np.mean(diag.get("submit_ms", [0]))), 2), "collect_mean": round(float(np.mean(diag.get("collect_ms", [0]))), 2),
+                                      "submit_max": round(float(np.max(diag.get("submit_ms", [0]))), 2), "collect_max": round(float(np.max(diag.get("collect_ms", [0]))), 2),
+                                      "slowest_step": int(np.argmax(step_ms)) if step_ms else None,
+                                      "slowest_step_per_context": diag.get("slowest")},
             "h2d_gb_per_s": in_bytes * steps / dt / 1e9, "d2h_gb_per_s": sum(c[1] for c in counts) / dt / 1e9,
             "h2d_mb_per_step": in_bytes / 1e6, "skeletons_per_step": n_skel // steps}
 
@@ -1100,7 +1108,7 @@ def main():
     streaming = None
     if default_run and not args.no_streaming and stage2 and rank == 0:
         for rep in range(max(1, args.stream_repeat)):
-            streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps), 2, local_rank, args.stream_out, args.stream_affinity)   # ~0.7 s timed at the default 20 steps
+            streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps), 4, local_rank, args.stream_out, args.stream_affinity)   # ~0.7 s timed at the default 20 steps
             if args.stream_repeat > 1:
                 print("streaming pass %d: %.2f M skeletons/s, H2D %.1f GB/s, D2H %.1f GB/s, step ms %s, pinned output on NUMA nodes %s, copy-stream probe %s"
                       % (rep, streaming["value"] / 1e6, streaming["h2d_gb_per_s"], streaming["d2h_gb_per_s"], streaming["step_ms_context0"],

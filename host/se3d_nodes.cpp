@@ -1,5 +1,6 @@
 // se3d_nodes.cpp — see se3d_nodes.hpp.  Host plumbing only; no numerics of the path are evaluated here.
 #include "se3d_nodes.hpp"
+#include "se3d_exchange.hpp"
 
 #include <chrono>
 #include <cstring>
@@ -129,7 +130,10 @@ void Skeleton3DNode::triangulate_persons(const std::vector<person_msgs::Person2D
   }
   int max_per_cam = 0;
   for (int i = 0; i < N; ++i) max_per_cam = std::max(max_per_cam, off[i + 1] - off[i]);
-  if (max_per_cam > ctx_->max_det_per_cam()) ctx_->grow(max_per_cam, 0, "more detections in one camera than limits.max_det_per_cam");
+  if (max_per_cam > ctx_->max_det_per_cam()) {
+    if (shard_) throw std::runtime_error("hypothesis shard: more detections in one camera than limits.max_det_per_cam (the limits are fixed in this mode)");
+    ctx_->grow(max_per_cam, 0, "more detections in one camera than limits.max_det_per_cam");
+  }
   std::vector<se3d_person3d> out;
   std::vector<int32_t> hyp, asc;
   se3d_frame_in in{N, off.data(), flat.empty() ? nullptr : flat.data(), fb.data(), persons3d_msg.header.stamp};
@@ -140,6 +144,13 @@ void Skeleton3DNode::triangulate_persons(const std::vector<person_msgs::Person2D
     hyp.assign(H, 0);
     asc.assign((size_t)H * N, -1);
     res = se3d_frame_out{H, H, 0, 0, 0u, out.data(), hyp.data(), asc.data()};
+    if (shard_) {   // hypotheses split over the ranks: stage the frame, association + own triangulation, all-gather, post-processing, fetch
+      if (se3d_stage_frames(ctx_->get(), 1, &in) != SE3D_OK) throw std::runtime_error(std::string("se3d_stage_frames: ") + se3d_last_error(ctx_->get()));
+      shard_->run_stage1();
+      if (se3d_fetch_stage1(ctx_->get(), 1, &res) != SE3D_OK) throw std::runtime_error(std::string("se3d_fetch_stage1: ") + se3d_last_error(ctx_->get()));
+      if (res.flags & SE3D_FLAG_HYP_OVERFLOW) throw std::runtime_error("hypothesis shard: SE3D_FLAG_HYP_OVERFLOW (the limits are fixed in this mode: start with a larger max_hyp)");
+      break;
+    }
     const int rc = se3d_triangulate(ctx_->get(), &in, &res);
     if (rc != SE3D_OK) throw std::runtime_error(std::string("se3d_triangulate: ") + se3d_last_error(ctx_->get()));
     if (!(res.flags & SE3D_FLAG_HYP_OVERFLOW)) break;
@@ -206,13 +217,23 @@ void PosePriorNode::skeletonCallback(const person_msgs::PersonCovList& persons, 
   // after it are at most n_tracks_ + n_det: raise the limits BEFORE the call when that bound does not fit (a truncated step could not
   // be undone: it has already changed the track state).
   const int need = std::max((int)dets.size(), n_tracks_ + (int)dets.size());
-  if (need > ctx_->max_hyp()) ctx_->grow(0, need, "more detections + live tracks than limits.max_hyp / max_tracks");
+  if (need > ctx_->max_hyp()) {
+    if (shard_) throw std::runtime_error("hypothesis shard: more detections + live tracks than limits.max_hyp / max_tracks (the limits are fixed in this mode)");
+    ctx_->grow(0, need, "more detections + live tracks than limits.max_hyp / max_tracks");
+  }
   const int H = ctx_->max_hyp();
   std::vector<se3d_person3d> fused(H), pred(H);
   std::vector<int32_t> iters(H);
   se3d_fused_out fo{H, 0, 0, 0.f, fused.data(), pred.data(), iters.data(), 0u, nullptr};
-  const int rc = se3d_refine(ctx_->get(), seq_, (int32_t)dets.size(), dets.empty() ? nullptr : dets.data(), (int32_t)persons.fb_delay_per_cam.size(),
-                             persons.fb_delay_per_cam.empty() ? nullptr : persons.fb_delay_per_cam.data(), persons.header.stamp, &fo);
+  int rc;
+  if (shard_) {   // detections split over the ranks: the resident stage-1 persons of frame slot 0 (the list in `persons`), fb_delay as staged with the frame
+    const double t = persons.header.stamp;
+    shard_->run_stage2(&t, 0);
+    rc = se3d_fetch_stage2(ctx_->get(), 1, &fo);
+  } else {
+    rc = se3d_refine(ctx_->get(), seq_, (int32_t)dets.size(), dets.empty() ? nullptr : dets.data(), (int32_t)persons.fb_delay_per_cam.size(),
+                     persons.fb_delay_per_cam.empty() ? nullptr : persons.fb_delay_per_cam.data(), persons.header.stamp, &fo);
+  }
   if (rc != SE3D_OK) throw std::runtime_error(std::string("se3d_refine: ") + se3d_last_error(ctx_->get()));
   if (fo.flags & SE3D_S2FLAG_TRACK_OVERFLOW) throw std::runtime_error("se3d_refine: SE3D_S2FLAG_TRACK_OVERFLOW although the limits were raised beforehand");
   if (fo.flags & SE3D_S2FLAG_ASSIGNMENT_FAILED) throw std::runtime_error("se3d_refine: SE3D_S2FLAG_ASSIGNMENT_FAILED (non-finite track association costs)");

@@ -22,6 +22,8 @@
 
 namespace se3d {
 
+class HypothesisShard;   // se3d_exchange.hpp: the hypotheses / detections of ONE stream split over the ranks of a node (north_star config 5)
+
 struct NodeParams {                 // ROS private parameters (S3D:1095-1097, PP:930-932)
   std::string pose_method = "simple";
   double max_epi_dist = 0.050;
@@ -85,9 +87,14 @@ class Skeleton3DNode {
   // "avg runtime" report of S3D:1234-1241: index 0 = all frames, n = frames with n output persons (n < 10)
   const std::vector<double>& timings_ms() const { return timings_; }
   const std::vector<int>& timing_counts() const { return timing_cnt_; }
+  // Multi-GPU latency mode (one process per GPU, every rank fed the same messages): triangulate_persons runs the resident shard calls —
+  // association on every rank, the own hypotheses' triangulation, one all-gather, post-processing on every rank — instead of se3d_triangulate;
+  // every rank publishes the single-rank result bit for bit.  The limits are fixed in this mode (an overflow throws instead of growing).
+  void set_shard(HypothesisShard* shard) { shard_ = shard; }
 
  private:
   std::shared_ptr<Context> ctx_;
+  HypothesisShard* shard_ = nullptr;
   double last_stamp_ = 0.0;
   std::vector<double> timings_ = std::vector<double>(10, 0.0);
   std::vector<int> timing_cnt_ = std::vector<int>(10, 0);
@@ -120,9 +127,14 @@ class PosePriorNode {
   // replaced by the predicted latency, PP:528-532)
   void skeletonCallback(const person_msgs::PersonCovList& persons, person_msgs::PersonCovList& persons_fused,
                         person_msgs::PersonCovList& persons_fused_pred);
+  // Multi-GPU latency mode: the callback refines the stage-1 persons RESIDENT in the context (frame slot 0: what the sharded
+  // Skeleton3DNode::triangulate_persons of the same context has just produced — `persons` carries the same list) with the detections split over
+  // the ranks: se3d_run_stage2_shard_pre -> all-gather -> _post.
+  void set_shard(HypothesisShard* shard) { shard_ = shard; }
 
  private:
   std::shared_ptr<Context> ctx_;
+  HypothesisShard* shard_ = nullptr;
   int seq_;
   int n_tracks_ = 0;   // live tracks after the last callback: a step adds at most one track per detection, so n_tracks_ + n_det is a bound
 };

@@ -1,15 +1,23 @@
 // se3d_replay.cpp — ROS-free replay harness: feeds recorded/synthetic per-camera Person2DList streams through the C++ host
 // layer (Skeleton3DNode::skeletonThreadStep -> PosePriorNode::skeletonCallback) exactly like the node pipeline of
 // pose_triangulate_demo.launch would, and dumps what the nodes would publish.  Used by tests/test_gpu_host_cpp.py.
-//   se3d_replay <scene.bin> <out.bin> [reproj.bin [width height]]
+//   se3d_replay <scene.bin> <out.bin> [reproj.bin [width height]] [--ranks N [--backend rccl|staged]]
 // With a third path the predicted skeletons are also fed through ReprojectionNode::fusedSkeletonCallback and the per-camera
 // Person2DList payloads (<cam>/skel_pred) are dumped.
+// --ranks N (round 6; north_star config 5 in the C++ host layer): the process starts N fresh children — one per GPU, before anything has touched
+// the GPU — that all replay the scene with the hypotheses / detections split over the ranks (se3d::HypothesisShard: RCCL all-gathers on the
+// contexts' streams; --backend staged: the test-only host-staged collective, all ranks on GPU 0).  Rank r writes <out.bin>.rank<r>; every rank's
+// file must equal the single-process <out.bin> byte for byte (tests/test_gpu_host_cpp.py).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
 
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include "se3d_exchange.hpp"
 #include "se3d_markers.hpp"
 #include "se3d_nodes.hpp"
 
@@ -32,8 +40,57 @@ static void write_list(std::ofstream& o, const person_msgs::PersonCovList& l) {
   }
 }
 
-int main(int argc, char** argv) {
-  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [reproj.bin [width height]]\n", argv[0]); return 2; }
+// --ranks N: start the ranks as fresh child processes (fork + exec of this binary with SE3D_RANK / SE3D_WORLD / SE3D_RDV_DIR in the environment) and
+// wait for them.  Nothing in this process has touched the GPU.
+static int launch_ranks(int n, const std::string& backend, char** argv) {
+  char tmpl[] = "/tmp/se3d_replay_rdv_XXXXXX";
+  const char* dir = mkdtemp(tmpl);
+  if (!dir) { std::perror("mkdtemp"); return 2; }
+  std::vector<pid_t> pids;
+  for (int r = 0; r < n; ++r) {
+    const pid_t pid = fork();
+    if (pid < 0) { std::perror("fork"); return 2; }
+    if (pid == 0) {
+      setenv("SE3D_RANK", std::to_string(r).c_str(), 1);
+      setenv("SE3D_WORLD", std::to_string(n).c_str(), 1);
+      setenv("SE3D_RDV_DIR", dir, 1);
+      setenv("SE3D_BACKEND", backend.c_str(), 1);
+      setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+      execv(argv[0], argv);
+      std::perror("execv");
+      _exit(127);
+    }
+    pids.push_back(pid);
+  }
+  int worst = 0;
+  for (pid_t pid : pids) {
+    int st = 0;
+    (void)waitpid(pid, &st, 0);
+    const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+    worst = std::max(worst, code);
+  }
+  const std::string rm = std::string("rm -rf '") + dir + "'";
+  if (std::system(rm.c_str()) != 0) std::fprintf(stderr, "could not remove %s\n", dir);
+  return worst;
+}
+
+int main(int argc_all, char** argv_all) {
+  // options anywhere on the line; the positional arguments keep their places
+  std::vector<char*> pos;
+  int ranks = 0;
+  std::string backend = "rccl";
+  for (int i = 0; i < argc_all; ++i) {
+    if (!std::strcmp(argv_all[i], "--ranks") && i + 1 < argc_all) ranks = std::atoi(argv_all[++i]);
+    else if (!std::strcmp(argv_all[i], "--backend") && i + 1 < argc_all) backend = argv_all[++i];
+    else pos.push_back(argv_all[i]);
+  }
+  const int argc = (int)pos.size();
+  char** argv = pos.data();
+  if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin [reproj.bin [width height]] [--ranks N [--backend rccl|staged]]\n", argv[0]); return 2; }
+  const bool is_rank = std::getenv("SE3D_RANK") != nullptr;
+  if (ranks >= 1 && !is_rank) return launch_ranks(ranks, backend, argv_all);
+  const int my_rank = is_rank ? std::atoi(std::getenv("SE3D_RANK")) : 0, world = is_rank ? std::atoi(std::getenv("SE3D_WORLD")) : 1;
+  if (is_rank) backend = std::getenv("SE3D_BACKEND") ? std::getenv("SE3D_BACKEND") : backend;
   std::ifstream in(argv[1], std::ios::binary);
   char magic[8];
   in.read(magic, 8);
@@ -55,10 +112,23 @@ int main(int argc, char** argv) {
     // initial limits (SE3D_REPLAY_MAX_DET / SE3D_REPLAY_MAX_HYP: tests start far below what the scene needs; the nodes raise them)
     const int det0 = std::getenv("SE3D_REPLAY_MAX_DET") ? std::atoi(std::getenv("SE3D_REPLAY_MAX_DET")) : 16;
     const int hyp0 = std::getenv("SE3D_REPLAY_MAX_HYP") ? std::atoi(std::getenv("SE3D_REPLAY_MAX_HYP")) : 64;
-    auto ctx = std::make_shared<se3d::Context>(cams, prm, det0, hyp0, 0);
+    const int device = is_rank && backend != "staged" ? my_rank : 0;   // one GPU per rank; the test-only staged backend shares GPU 0
+    auto ctx = std::make_shared<se3d::Context>(cams, prm, det0, hyp0, device);
     se3d::Skeleton3DNode skel(ctx);
     se3d::PosePriorNode prior(ctx);
-    std::ofstream out(argv[2], std::ios::binary);
+    std::unique_ptr<se3d::Collective> coll;
+    std::unique_ptr<se3d::HypothesisShard> shard;
+    if (is_rank) {
+      const std::string dir = std::getenv("SE3D_RDV_DIR") ? std::getenv("SE3D_RDV_DIR") : "/tmp";
+      coll = backend == "staged" ? se3d::make_staged_collective(my_rank, world, dir) : se3d::make_rccl_collective(my_rank, world, device, dir);
+      shard.reset(new se3d::HypothesisShard(ctx->get(), *coll, 1, 1));   // one frame and one sequence per callback: the reference's operating point
+      skel.set_shard(shard.get());
+      prior.set_shard(shard.get());
+      prior.reset();
+      std::cout << "rank " << my_rank << " of " << world << " on device " << device << ", collective: " << coll->name() << ", all-gather bytes per frame: "
+                << shard->allgather_bytes_stage1() << " + " << shard->allgather_bytes_stage2() << std::endl;
+    }
+    std::ofstream out(is_rank ? std::string(argv[2]) + ".rank" + std::to_string(my_rank) : std::string(argv[2]), std::ios::binary);
     wr<int32_t>(out, n_frames);
     std::unique_ptr<se3d::ReprojectionNode> reproj;
     std::ofstream rout;

@@ -333,13 +333,15 @@ int se3d_stream_submit(se3d_ctx *ctx, int32_t n_frames, const se3d_frame_in *fra
                        const double *t);
 int se3d_stream_collect(se3d_ctx *ctx, se3d_stream_result *out);
 /* The streaming entry points move every context's uploads over ONE stream per device and every download over another (copies of one direction on
- * several streams interleave on the copy engines: 37 - 43 GB/s instead of 56).  The pair is created by the first se3d_stream_submit on the device,
- * lives as long as the process (at most 64 devices; a hipDeviceReset invalidates it) and is PROBED when it is created (round 6): if an upload and a
- * download queued at once take more than 80 % of what they take one after the other — both directions landed on one copy engine, which the runtime
- * keeps for the life of a stream — the pair is destroyed and created again, at most four times.  Diagnostic: the same probe on the device's current
- * pair (~10 ms, 2 x 32 MB of pinned and device memory for its duration): gbps4 = {upload alone, download alone, upload with both queued, download
- * with both queued} in GB/s, *recreated (optional) = how often the start-up probe re-created the pair in this process. */
-int se3d_copy_stream_probe(int32_t device, double *gbps4, int32_t *recreated);
+ * several streams interleave on the copy engines: 37 - 43 GB/s instead of 56).  The pair is created by the first se3d_stream_submit on the device and
+ * lives as long as the process (at most 64 devices; a hipDeviceReset invalidates it).  Its health is WATCHED (round 6): a burst of downloads while
+ * the upload stream is idle can leave both directions on one copy engine for good — the streaming rate then drops to 60 % until the streams are
+ * re-created, which round 5 saw in one run of ten.  Every download of >= 8 MB is timed with events on the download stream; six in a row below
+ * 30 GB/s replace the pair by a new one (pending copies of the old pair finish; at most 16 repairs per device and process).
+ * Diagnostic: *gbps_both = GB/s per direction of four 32 MB uploads and four 32 MB downloads queued at once on the device's current pair (~48
+ * healthy, ~28 serialised; ~10 ms, 2 x 32 MB of pinned and of device memory for its duration; only call it with no batch in flight), *repairs
+ * (optional) = how often the pair was replaced in this process, *last_download_gbps (optional) = rate of the last timed download. */
+int se3d_copy_stream_probe(int32_t device, double *gbps_both, int32_t *repairs, double *last_download_gbps);
 /* --- feedback reprojection: drop-in for fusedSkeletonCallback (pose_reprojection/src/skeleton_reproj_mult_node.cpp:139-235) --
  * Projects fused/predicted 3D skeletons and their covariances (7-sigma-point unscented transform, :62-75) into every camera and
  * returns one Person2DList payload per camera (topic <cam>/skel_pred).  Cameras in double precision as the node uses them:

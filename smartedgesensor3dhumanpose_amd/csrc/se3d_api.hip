@@ -122,11 +122,10 @@ struct se3d_ctx {
     bool direct = false;                                     // this batch was written straight into the pinned buffers (options.stream_out = 1)
     int32_t *d_out_off = nullptr, *h_out_off = nullptr; // [B + 1]
     float *h_fb = nullptr, *d_fb = nullptr;             // [B][N] fb_delay of the batch (per slot: batch k + 1 is copied while batch k walks)
-    hipEvent_t in_done = nullptr, compute_done = nullptr, off_done = nullptr;
+    hipEvent_t in_done = nullptr, compute_done = nullptr, off_done = nullptr, d2h_start = nullptr;
     int n_frames = 0;
     bool busy = false;
   } ss[2];
-  hipStream_t s_h2d = nullptr, s_d2h = nullptr;   // the DEVICE's shared upload / download streams (shared_copy_stream): not owned by the context
   bool dry = false;          // dev_alloc only counts (se3d_device_bytes)
   size_t dry_bytes = 0;
   bool stream_ready = false;
@@ -689,6 +688,7 @@ void se3d_destroy(se3d_ctx *c) {
     if (sl.in_done) (void)hipEventDestroy(sl.in_done);
     if (sl.compute_done) (void)hipEventDestroy(sl.compute_done);
     if (sl.off_done) (void)hipEventDestroy(sl.off_done);
+    if (sl.d2h_start) (void)hipEventDestroy(sl.d2h_start);
   }
   for (auto &set : c->ev2)
     for (auto &e : set)
@@ -1382,12 +1382,63 @@ int se3d_run_stage2_shard_post(se3d_ctx *c, int32_t n_seq, const void *d_gathere
 // The download direction likewise: ONE shared stream per device.  A download waits for its batch's kernels; enqueued with a device-side wait it
 // would block every other context's download behind it, so se3d_stream_collect waits for the batch on the HOST (compute_done), reads the number of
 // published persons from the offsets the scan kernel mirrored into pinned memory, and only then enqueues the two copies.
+// ---- the pair's health (round 6) ------------------------------------------------------------------------------------------------------------
+// Round 5 saw one default bench.py run in about ten stream at 60 % of its rate for the WHOLE run: every step took what its uploads and its
+// downloads take one after the other.  Round 6 found the mechanism with a probe on the pair (profiles/r6/README.md section 3): a healthy pair —
+// both directions queued at once move 48 + 48 GB/s — turns into a serialised one (28 + 28 GB/s: both directions on one copy engine) after a burst of
+// DOWNLOADS WITH THE UPLOAD STREAM IDLE, which is what the head of a streaming run produces when every feeding thread waits for its first batch,
+// and stays serialised whatever runs afterwards; no copy pattern brings the overlap back, re-creating the two streams does, at once.  (Not
+// reproducible with the same copies in a stand-alone program, tools/microbench/sdma_seq.hip: the trigger needs the process the contexts live in.)
+// So the library watches the pair and repairs it:
+//   * every download of at least 8 MB is bracketed by two timing events on the download stream (what lies between them is the copies alone; the
+//     stream is a FIFO) — a healthy download runs at 37 - 56 GB/s with or without uploads next to it, one that shares its engine with the uploads
+//     queues behind 200 MB uploads and comes out far below 30;
+//   * six downloads in a row below 30 GB/s: a NEW pair of streams replaces the old one (whose pending copies finish: hipStreamDestroy releases a
+//     stream when its work is done; the events recorded on it stay valid).  At most 16 repairs per device and process.
+// Every enqueue on the pair happens under g_copy_mu, so no thread can hold a handle that another thread destroys.
+struct CopyPair {
+  hipStream_t s[2] = {nullptr, nullptr};
+  int repairs = 0, slow_streak = 0;
+  long downloads_timed = 0;
+  double last_rate = 0.0;   // GB/s of the last timed download
+};
 static std::mutex g_copy_mu;
-static hipStream_t g_copy_streams[2][64] = {};
-static int g_copy_recreated[64] = {};     // how often the pair of a device was re-created by the start-up probe (se3d_copy_stream_probe reports it)
-// Do an upload and a download on the device's two copy streams run side by side?  Four 32 MB copies per direction, queued back to back: each
-// direction alone, then both at once (host clock around enqueue + synchronise; ~10 ms in all).  out: GB/s {up alone, down alone, up | both, down | both}.
-static bool probe_copy_pair(hipStream_t up, hipStream_t down, double out[4]) {
+static CopyPair g_pair[64];
+static constexpr double kPairSlowGBps = 30.0;
+static constexpr int kPairSlowStreak = 6, kPairMaxRepairs = 16;
+static constexpr size_t kPairTimedBytes = (size_t)8 << 20;
+// (caller holds g_copy_mu and has made `device` current)
+static bool copy_pair_locked(int device, hipStream_t &up, hipStream_t &down) {
+  if (device < 0 || device >= 64) return false;
+  CopyPair &p = g_pair[device];
+  for (int d = 0; d < 2; ++d)
+    if (!p.s[d] && hipStreamCreateWithFlags(&p.s[d], hipStreamNonBlocking) != hipSuccess) p.s[d] = nullptr;
+  up = p.s[0]; down = p.s[1];
+  return up && down;
+}
+static void copy_pair_recreate_locked(int device) {
+  CopyPair &p = g_pair[device];
+  hipStream_t fresh[2] = {nullptr, nullptr};
+  if (hipStreamCreateWithFlags(&fresh[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&fresh[1], hipStreamNonBlocking) != hipSuccess) {
+    if (fresh[0]) (void)hipStreamDestroy(fresh[0]);
+    return;   // keep the old pair
+  }
+  for (int d = 0; d < 2; ++d) { if (p.s[d]) (void)hipStreamDestroy(p.s[d]); p.s[d] = fresh[d]; }
+  ++p.repairs;
+  p.slow_streak = 0;
+}
+// one timed download of `bytes` bytes took `ms` on the download stream (caller holds g_copy_mu)
+static void copy_pair_note_download_locked(int device, size_t bytes, float ms) {
+  CopyPair &p = g_pair[device];
+  if (!(ms > 0.f)) return;
+  p.last_rate = (double)bytes / ((double)ms * 1e6);
+  ++p.downloads_timed;
+  p.slow_streak = p.last_rate < kPairSlowGBps ? p.slow_streak + 1 : 0;
+  if (p.slow_streak >= kPairSlowStreak && p.repairs < kPairMaxRepairs) copy_pair_recreate_locked(device);
+}
+// Four 32 MB uploads and four 32 MB downloads queued at once on the pair: GB/s of each direction over the wall time of the lot (~48 when the
+// directions overlap, ~28 when they share an engine).  Both directions only: a burst of downloads alone is what breaks a healthy pair.
+static bool probe_copy_pair(hipStream_t up, hipStream_t down, double *gbps_both) {
   const size_t n = (size_t)32 << 20;
   const int reps = 4;
   void *h0 = nullptr, *h1 = nullptr, *d0 = nullptr, *d1 = nullptr;
@@ -1404,10 +1455,18 @@ static bool probe_copy_pair(hipStream_t up, hipStream_t down, double out[4]) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   };
   if (ok) {
-    (void)run(true, true);   // first touch of the buffers, first use of the streams
-    const double tu = run(true, false), td = run(false, true), tb = run(true, true);
-    const double gb = (double)reps * (double)n / 1e9;
-    out[0] = gb / tu; out[1] = gb / td; out[2] = gb / tb; out[3] = gb / tb;
+#ifdef SE3D_PROBE_DIAG   // diagnostic build only (tools/tmp, never shipped): SE3D_PROBE_MODE bit mask 1 warm both, 2 uploads alone, 4 downloads alone, 8 both
+    const int mode = getenv("SE3D_PROBE_MODE") ? atoi(getenv("SE3D_PROBE_MODE")) : 9;
+    double tb = 1.0;
+    if (mode & 1) (void)run(true, true);
+    if (mode & 2) (void)run(true, false);
+    if (mode & 4) (void)run(false, true);
+    if (mode & 8) tb = run(true, true);
+#else
+    (void)run(true, true);   // first touch of the buffers
+    const double tb = run(true, true);
+#endif
+    *gbps_both = (double)reps * (double)n / 1e9 / tb;
   }
   if (h0) (void)hipHostFree(h0);
   if (h1) (void)hipHostFree(h1);
@@ -1415,49 +1474,26 @@ static bool probe_copy_pair(hipStream_t up, hipStream_t down, double out[4]) {
   if (d1) (void)hipFree(d1);
   return ok;
 }
-// (caller holds g_copy_mu and has made `device` current)
-static hipStream_t shared_copy_stream_locked(int device, int dir /* 0: H2D, 1: D2H */) {
-  if (device < 0 || device >= 64) return nullptr;
-  if (!g_copy_streams[0][device] || !g_copy_streams[1][device]) {
-    // The pair is created together and PROBED (round 6).  One default bench.py run in about ten of round 5 streamed at 60 % of its rate for the whole
-    // run: every step took what the step's uploads and downloads take one after the other (profiles/r5/README.md section 5) — the signature of the two
-    // directions sharing one copy engine, which the runtime assigns to a stream at its first copies and keeps.  If both directions at once take
-    // longer than 80 % of the two alone, the pair is destroyed and created again (at most four times; se3d_copy_stream_probe reports the count).
-    for (int attempt = 0; attempt < 5; ++attempt) {
-      for (int d = 0; d < 2; ++d)
-        if (!g_copy_streams[d][device] && hipStreamCreateWithFlags(&g_copy_streams[d][device], hipStreamNonBlocking) != hipSuccess) g_copy_streams[d][device] = nullptr;
-      if (!g_copy_streams[0][device] || !g_copy_streams[1][device]) break;
-      double r[4] = {0, 0, 0, 0};
-      if (!probe_copy_pair(g_copy_streams[0][device], g_copy_streams[1][device], r)) break;   // (no memory for the probe: keep the pair)
-      const double t_alone = 1.0 / r[0] + 1.0 / r[1], t_both = 1.0 / r[2];
-      if (t_both < 0.8 * t_alone || attempt == 4) break;
-      for (int d = 0; d < 2; ++d) { (void)hipStreamDestroy(g_copy_streams[d][device]); g_copy_streams[d][device] = nullptr; }
-      ++g_copy_recreated[device];
-    }
-  }
-  return g_copy_streams[dir][device];
-}
-static hipStream_t shared_copy_stream(int device, int dir) {
-  std::lock_guard<std::mutex> lk(g_copy_mu);
-  return shared_copy_stream_locked(device, dir);
-}
-// Diagnostic (include/se3d.h): the probe on the device's CURRENT pair of copy streams (created if there is none yet), without re-creating anything.
-int se3d_copy_stream_probe(int32_t device, double *gbps4, int32_t *recreated) {
-  if (!gbps4 || device < 0 || device >= 64) return SE3D_ERR_ARG;
+// Diagnostic (include/se3d.h): the state of the device's pair.
+int se3d_copy_stream_probe(int32_t device, double *gbps_both, int32_t *repairs, double *last_download_gbps) {
+  if (!gbps_both || device < 0 || device >= 64) return SE3D_ERR_ARG;
   if (hipSetDevice(device) != hipSuccess) return SE3D_ERR_DEVICE;
   std::lock_guard<std::mutex> lk(g_copy_mu);
-  hipStream_t up = shared_copy_stream_locked(device, 0), down = shared_copy_stream_locked(device, 1);
-  if (!up || !down) return SE3D_ERR_DEVICE;
-  if (!probe_copy_pair(up, down, gbps4)) return SE3D_ERR_DEVICE;
-  if (recreated) *recreated = g_copy_recreated[device];
+  hipStream_t up = nullptr, down = nullptr;
+  if (!copy_pair_locked(device, up, down)) return SE3D_ERR_DEVICE;
+  if (!probe_copy_pair(up, down, gbps_both)) return SE3D_ERR_DEVICE;
+  if (repairs) *repairs = g_pair[device].repairs;
+  if (last_download_gbps) *last_download_gbps = g_pair[device].last_rate;
   return SE3D_OK;
 }
 static int stream_init(se3d_ctx *c) {
   if (c->stream_ready) return SE3D_OK;
   const size_t B = c->D.d.B, N = c->D.d.N, P = c->D.d.P, H = c->D.d.H;
-  c->s_h2d = shared_copy_stream(c->device, 0);
-  c->s_d2h = shared_copy_stream(c->device, 1);
-  if (!c->s_h2d || !c->s_d2h) { c->err = "se3d_stream_submit: no copy stream"; return SE3D_ERR_DEVICE; }
+  {
+    std::lock_guard<std::mutex> lk(g_copy_mu);
+    hipStream_t up = nullptr, down = nullptr;
+    if (!copy_pair_locked(c->device, up, down)) { c->err = "se3d_stream_submit: no copy stream (at most 64 devices)"; return SE3D_ERR_DEVICE; }
+  }
   for (auto &sl : c->ss) {
     HIPCHK(c, hipHostMalloc((void **)&sl.h_rag, sizeof(se3d_person2d) * B * N * P, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void **)&sl.h_off, sizeof(int32_t) * B * (N + 1), hipHostMallocDefault));
@@ -1474,7 +1510,8 @@ static int stream_init(se3d_ctx *c) {
       return SE3D_ERR_DEVICE;
     HIPCHK(c, hipEventCreateWithFlags(&sl.in_done, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&sl.compute_done, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&sl.off_done, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreate(&sl.off_done));     // timing events: they bracket the batch's download on the shared stream (copy_pair_note_download_locked)
+    HIPCHK(c, hipEventCreate(&sl.d2h_start));
   }
   c->stream_ready = true;
   return SE3D_OK;
@@ -1519,10 +1556,15 @@ int se3d_stream_submit(se3d_ctx *c, int32_t n_frames, const se3d_frame_in *frame
     for (auto &x : th) x.join();
   }
   // ---- H2D on the copy stream (no padding crosses PCIe), ordered after the previous use of this slot's device buffers ----
-  HIPCHK(c, hipMemcpyAsync(sl.d_rag, sl.h_rag, sizeof(se3d_person2d) * (size_t)total, hipMemcpyHostToDevice, c->s_h2d));
-  HIPCHK(c, hipMemcpyAsync(sl.d_off, sl.h_off, sizeof(int32_t) * (size_t)n_frames * (N + 1), hipMemcpyHostToDevice, c->s_h2d));
-  HIPCHK(c, hipMemcpyAsync(sl.d_fb, sl.h_fb, sizeof(float) * (size_t)n_frames * N, hipMemcpyHostToDevice, c->s_h2d));
-  HIPCHK(c, hipEventRecord(sl.in_done, c->s_h2d));
+  {
+    std::lock_guard<std::mutex> lk(g_copy_mu);   // (the pair may be replaced by another thread's repair: handles are read and used under the lock)
+    hipStream_t up = nullptr, down = nullptr;
+    if (!copy_pair_locked(c->device, up, down)) { c->err = "se3d_stream_submit: no copy stream"; return SE3D_ERR_DEVICE; }
+    HIPCHK(c, hipMemcpyAsync(sl.d_rag, sl.h_rag, sizeof(se3d_person2d) * (size_t)total, hipMemcpyHostToDevice, up));
+    HIPCHK(c, hipMemcpyAsync(sl.d_off, sl.h_off, sizeof(int32_t) * (size_t)n_frames * (N + 1), hipMemcpyHostToDevice, up));
+    HIPCHK(c, hipMemcpyAsync(sl.d_fb, sl.h_fb, sizeof(float) * (size_t)n_frames * N, hipMemcpyHostToDevice, up));
+    HIPCHK(c, hipEventRecord(sl.in_done, up));
+  }
   // ---- compute stream: expand, stage 1, walk, compact ----
   HIPCHK(c, hipStreamWaitEvent(c->stream, sl.in_done, 0));
   Se3dDev D = c->D;
@@ -1558,10 +1600,22 @@ int se3d_stream_collect(se3d_ctx *c, se3d_stream_result *out) {
   HIPCHK(c, hipEventSynchronize(sl.compute_done));   // the batch's kernels are done; the offsets are in pinned memory (mirror)
   const int total = sl.h_out_off[sl.n_frames];
   if (!sl.direct && total > 0) {   // (direct: the kernels wrote the pinned buffers themselves)
-    HIPCHK(c, hipMemcpyAsync(sl.h_fused, sl.d_fused, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, c->s_d2h));
-    HIPCHK(c, hipMemcpyAsync(sl.h_pred, sl.d_pred, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, c->s_d2h));
-    HIPCHK(c, hipEventRecord(sl.off_done, c->s_d2h));
+    const size_t bytes = 2 * sizeof(se3d_person3d) * (size_t)total;
+    {
+      std::lock_guard<std::mutex> lk(g_copy_mu);
+      hipStream_t up = nullptr, down = nullptr;
+      if (!copy_pair_locked(c->device, up, down)) { c->err = "se3d_stream_collect: no copy stream"; return SE3D_ERR_DEVICE; }
+      HIPCHK(c, hipEventRecord(sl.d2h_start, down));
+      HIPCHK(c, hipMemcpyAsync(sl.h_fused, sl.d_fused, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, down));
+      HIPCHK(c, hipMemcpyAsync(sl.h_pred, sl.d_pred, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, down));
+      HIPCHK(c, hipEventRecord(sl.off_done, down));
+    }
     HIPCHK(c, hipEventSynchronize(sl.off_done));   // (an event, not the stream: the stream also carries the other contexts' downloads)
+    float ms = 0.f;
+    if (bytes >= kPairTimedBytes && hipEventElapsedTime(&ms, sl.d2h_start, sl.off_done) == hipSuccess) {   // the pair's health: see CopyPair
+      std::lock_guard<std::mutex> lk(g_copy_mu);
+      copy_pair_note_download_locked(c->device, bytes, ms);
+    }
   }
   out->n_frames = sl.n_frames;
   out->n_persons = total;

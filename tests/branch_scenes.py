@@ -81,3 +81,24 @@ def non_spd_cov3d(dets):
     d = dets.copy()
     d[0]["keypoints"]["cov"][6] = [0.01, 0.02, 0.0, 0.01, 0.0, 0.01]
     return d
+
+
+def garbage_joint(rig, dets, person=0, joint=9, dist=30.0, sigma=30.0, cam=0):
+    """Stage-2 input with a GARBAGE joint (round 6): fusion joint `joint` of stage-1 person `person` moved `dist` metres along the ray from camera
+    `cam` through it, its covariance sigma^2 along that ray and (2 cm)^2 across — what two nearly parallel rays triangulate to on a person whose
+    root survives the plausibility filters (S3D:937-953 checks the distance to the root only when the root exists; SURVEY 7 hard part 4).  The
+    person's LM problem (PP:690-746) is flat along the ray: algebraically equivalent solvers stop at different points, which is what the
+    solver-independent objective criterion of tests/parity.py is for.  Returns a copy of `dets`."""
+    out = np.array(dets, copy=True)
+    if len(out) <= person or out[person]["keypoints"]["score"][joint] <= 0:
+        return out
+    c = rig.centres()[cam]
+    x = out[person]["keypoints"]["joint"][joint]
+    u = (x - c) / np.linalg.norm(x - c)
+    out[person]["keypoints"]["joint"][joint] = x + dist * u
+    a, b = np.cross(u, [0.0, 0.0, 1.0]), None
+    a /= np.linalg.norm(a)
+    b = np.cross(u, a)
+    C3 = sigma ** 2 * np.outer(u, u) + 0.02 ** 2 * (np.outer(a, a) + np.outer(b, b))
+    out[person]["keypoints"]["cov"][joint] = [C3[0, 0], C3[0, 1], C3[0, 2], C3[1, 1], C3[1, 2], C3[2, 2]]
+    return out

@@ -17,7 +17,9 @@ the library itself with the oracle's restatement of the reference's float32 arit
     set (counted), because its LM problem is solver-dependent and the difference lives on in the track state;
   * round 5, on EVERY sequence-step (exempt or not): a published person whose refined joints differ by 1 mm or more between the two sides must
     not have the worse final LM objective on the library's side (parity.compare_stage2_objectives; steps on which the two sides publish
-    different detections are counted as not comparable), and the mismatches INSIDE the exclusion set are bounded by the callers."""
+    different detections are counted as not comparable), and the mismatches INSIDE the exclusion set are bounded by the callers;
+  * round 6: those mismatches are counted by KIND (parity.classify_stage2) — a different person / track count or id is an index divergence and has
+    its own, tighter bound; a predicted joint >= 1 mm apart under refined joints that agree (a velocity-history difference) its own counter."""
 import os
 
 import numpy as np
@@ -25,7 +27,7 @@ import numpy as np
 from smartedgesensor3dhumanpose_amd import person_msgs as pm
 from smartedgesensor3dhumanpose_amd.skeleton_3d import Skeleton3D
 from fuzz_scenes import MAX_DET, MAX_HYP, N_SEQ, T_STEPS, draw_trial
-from parity import COV_REL_FRO, DLT_KAPPA_MAX, POS_TOL_M, SCORE_RTOL, compare_stage2, compare_stage2_objectives, cov_tolerance, garbage_persons, inflation_allowance, published_joint_condition
+from parity import COV_REL_FRO, DLT_KAPPA_MAX, POS_TOL_M, SCORE_RTOL, classify_stage2, compare_stage2, compare_stage2_objectives, cov_tolerance, garbage_persons, inflation_allowance, published_joint_condition
 
 W6 = np.array([1, 2, 2, 1, 2, 1.0])
 
@@ -34,7 +36,7 @@ def new_report(seed):
     return dict(seed=seed, trials=0, frames=0, frames_hyp_overflow=0, persons=0, joints=0, joints_excluded=0, joints_second_pass=0, ill_joints=0, ill_not_listed=0,
                 joints_over_1mm=0, pos_max_mm=0.0, scores_over_rtol=0, cov_over_tol=0, cov_rel_max=0.0, cov_nan=0, **{"cov_over_flat_1e-3": 0},
                 seq_steps=0, seq_steps_track_overflow=0, seq_steps_excluded=0, stage2_numeric_failures=0, stage2_index_divergences=0,
-                excluded_stage2_mismatches=0, objective_persons=0, objective_disagree=0, objective_worse=0, objective_worst_excess=0.0, objective_not_comparable_steps=0,
+                excluded_stage2_mismatches=0, excluded_count_mismatches=0, excluded_pred_only_mismatches=0, excluded_mismatch_kinds={}, objective_pred_only=0, objective_persons=0, objective_disagree=0, objective_worse=0, objective_worst_excess=0.0, objective_not_comparable_steps=0,
                 violations=[])
 
 
@@ -153,6 +155,7 @@ def run_trials(O, seed, trials, walk_mode="wave", pose_method="simple", norm_hei
                     rep["objective_persons"] += oc["persons"]
                     rep["objective_disagree"] += oc["disagree"]
                     rep["objective_worse"] += oc["worse"]
+                    rep["objective_pred_only"] += oc["pred_only"]
                     rep["objective_worst_excess"] = max(rep["objective_worst_excess"], oc["worst_excess"])
                     if oc["worse"]:
                         rep["violations"].append(dict(trial=trial, step=k, seq=s, objective_worse=oc["worse"], excess=oc["worst_excess"], tainted=tainted[s]))
@@ -165,6 +168,10 @@ def run_trials(O, seed, trials, walk_mode="wave", pose_method="simple", norm_hei
                     numeric = "mm" in msg or "cov" in msg or "marg" in msg
                     if tainted[s]:
                         rep["excluded_stage2_mismatches"] += 1
+                        kind = classify_stage2(ra[s], o2) or "other"   # round 6: by kind — a different person COUNT is an index divergence, not a numeric one
+                        rep["excluded_mismatch_kinds"][kind] = rep["excluded_mismatch_kinds"].get(kind, 0) + 1
+                        rep["excluded_count_mismatches"] += int(kind in ("count", "ids"))
+                        rep["excluded_pred_only_mismatches"] += int(kind == "pred")
                         rep.setdefault("excluded_stage2_messages", []).append("trial %d step %d seq %d: %s" % (trial, k, s, msg[:160]))
                         dead[s] = dead[s] or not numeric
                         continue

@@ -103,6 +103,36 @@ def compare_stage2(gpu, ora, check_iters=True, check_tracks=True):
     return stats
 
 
+def classify_stage2(gpu, ora):
+    """What kind of difference compare_stage2 would trip over first (round 6: the mismatches inside stage 2's exempt set are counted by kind):
+    "count" (published persons or live tracks), "ids", "valid" (sets of valid joints / scores), "fused" (a refined joint >= 1 mm apart),
+    "pred" (refined joints inside 1 mm, a PREDICTED joint >= 1 mm apart: the two sides carry different velocity histories), "cov", "iters", or None."""
+    if gpu.n_persons != ora.n_persons or gpu.c.n_tracks != ora.c.n_tracks:
+        return "count"
+    n = gpu.n_persons
+    if n == 0:
+        return None
+    if not (np.array_equal(gpu.fused["id"][:n], ora.fused["id"][:n]) and np.array_equal(gpu.fused_pred["id"][:n], ora.fused_pred["id"][:n])):
+        return "ids"
+    kind = None
+    for name in ("fused", "fused_pred"):
+        g, o = getattr(gpu, name)[:n]["keypoints"], getattr(ora, name)[:n]["keypoints"]
+        if not np.array_equal(g["score"], o["score"]):
+            return "valid"
+        vo = o["score"] > 0
+        d = np.linalg.norm(g["joint"] - o["joint"], axis=-1)[vo]
+        if d.size and d.max() >= REFINE_TOL_M:
+            return "fused" if name == "fused" else "pred"
+        rel = np.abs(g["cov"][vo] - o["cov"][vo]).max(-1) / np.abs(o["cov"][vo]).max(-1)
+        if rel.size and rel.max() >= MARG_COV_RTOL + 1e-2:
+            kind = kind or "cov"
+    if kind:
+        return kind
+    if not np.array_equal(gpu.lm_iterations[:n], ora.lm_iterations[:n]):
+        return "iters"
+    return "cov"   # compare_stage2 failed on a covariance inside the 1e-2 cap of its tolerance
+
+
 OBJECTIVE_RTOL = 1e-9   # stage 2: where the two LMs publish different joints, the library's final objective may exceed the oracle's by this much at most
 
 
@@ -112,7 +142,7 @@ def compare_stage2_objectives(gpu, ora):
     se3d_fused_out.lm_objective — is not above the oracle's (x (1 + OBJECTIVE_RTOL)).  Both sides refine the SAME stage-1 persons, so the objective
     FUNCTION of a person is the same on both sides whatever the track state; it is comparable whenever both sides publish the same detections
     (equal counts, equal measured scores).  Returns dict(comparable, persons, disagree, worse, worst_excess)."""
-    out = dict(comparable=False, persons=0, disagree=0, worse=0, worst_excess=0.0)
+    out = dict(comparable=False, persons=0, disagree=0, worse=0, worst_excess=0.0, pred_only=0)
     n = gpu.n_persons
     if n != ora.n_persons:
         return out
@@ -127,8 +157,15 @@ def compare_stage2_objectives(gpu, ora):
     d = np.where(v, np.linalg.norm(g["joint"] - o["joint"], axis=-1), 0.0).max(-1)
     og, oo = gpu.lm_objective[:n], ora.lm_objective[:n]
     out["persons"] = int(n)
+    # round 6: the PREDICTED joints (fused_pred = refined joint + velocity x predicted latency, PP:795-837).  A person whose refined joints agree but
+    # whose predicted joints do not carries a different velocity history on the two sides (an earlier step's refined joints differed): the objective
+    # says nothing about it — counted on its own (`pred_only`) and bounded by the callers
+    gp, op_ = gpu.fused_pred[:n]["keypoints"], ora.fused_pred[:n]["keypoints"]
+    vp = op_["score"] > 0
+    dp = np.where(vp & (gp["score"] > 0), np.linalg.norm(gp["joint"] - op_["joint"], axis=-1), 0.0).max(-1)
     for p in range(n):
         if d[p] < REFINE_TOL_M:
+            out["pred_only"] += int(dp[p] >= REFINE_TOL_M)
             continue
         out["disagree"] += 1
         if (og[p] < 0) != (oo[p] < 0) or og[p] > oo[p] * (1.0 + OBJECTIVE_RTOL):

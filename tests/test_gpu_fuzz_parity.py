@@ -75,8 +75,28 @@ def test_random_scenes_match_the_oracle_on_every_joint(reports, seed, pose_metho
     assert rep["seq_steps_excluded"] <= 0.15 * rep["seq_steps"], rep
     # ... and on EVERY sequence-step, exempt or not: where the published joints differ, the library's final LM objective is not the worse one
     assert rep["objective_worse"] == 0, viol[:5]
-    # inside the exclusion set the two sides actually differ on a small part of the steps only
-    assert rep["excluded_stage2_mismatches"] <= max(1, 0.02 * rep["seq_steps_excluded"]), rep
+    # inside the exclusion set the two sides actually differ on a small part of the steps only (round 6: 0.5 % — measured 0.08 - 0.15 % over the blind
+    # batches of round 5 — with one mismatch per run allowed: a run has ~100 - 170 exempt steps; the aggregate bounds are test_exempt_set_budget_*)
+    assert rep["excluded_stage2_mismatches"] <= max(1, 0.005 * rep["seq_steps_excluded"]), rep
+
+
+def test_exempt_set_budget_over_the_suite_runs(reports):
+    """Round 6: the budgets of stage 2's exempt set over ALL small-rig runs of the module together (per run the numbers are too small to bound
+    below one event): mismatches of any kind <= 0.5 % of the exempt steps, person- / track-count or id divergences <= 0.1 % (at least one event
+    allowed), predicted-only differences counted.  tools/fuzz_blind.sh asserts the same over its 100 seeds."""
+    reps = [_report(reports, v)[0] for v in VARIANTS]
+    exempt = sum(r["seq_steps_excluded"] for r in reps)
+    mism = sum(r["excluded_stage2_mismatches"] for r in reps)
+    count = sum(r["excluded_count_mismatches"] for r in reps)
+    kinds = {}
+    for r in reps:
+        for k, v in r["excluded_mismatch_kinds"].items():
+            kinds[k] = kinds.get(k, 0) + v
+    print("exempt steps %d of %d; mismatches inside %d (%s); count / id divergences %d; predicted-only person differences on comparable steps %d"
+          % (exempt, sum(r["seq_steps"] for r in reps), mism, kinds, count, sum(r["objective_pred_only"] for r in reps)))
+    assert exempt > 500
+    assert mism <= max(2, 0.005 * exempt), (mism, exempt, kinds)
+    assert count <= max(1, 0.001 * exempt), (count, exempt, kinds)
 
 
 def test_large_rig_scenes_match_the_oracle_on_every_joint(reports):
@@ -92,4 +112,4 @@ def test_large_rig_scenes_match_the_oracle_on_every_joint(reports):
     print("large rigs: %d of %d sequence-steps exempt, %d mismatches inside the exempt set, %d persons with different joints, of them with the worse objective: %d"
           % (rep["seq_steps_excluded"], rep["seq_steps"], rep["excluded_stage2_mismatches"], rep["objective_disagree"], rep["objective_worse"]))
     assert rep["seq_steps_excluded"] <= 44 and rep["objective_worse"] == 0
-    assert rep["excluded_stage2_mismatches"] <= max(1, 0.05 * rep["seq_steps_excluded"]), rep
+    assert rep["excluded_stage2_mismatches"] <= max(1, 0.02 * rep["seq_steps_excluded"]), rep   # (5 % until round 5; 40 exempt steps: one event)

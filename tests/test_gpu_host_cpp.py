@@ -159,3 +159,37 @@ def test_cpp_replay_grows_its_limits_instead_of_truncating(tmp_path, oracle, ext
         assert len(gfused.persons) == len(ofused.persons)
         if len(ofused.persons):
             assert np.array_equal(gfused.persons["id"], ofused.persons["id"])
+
+
+def _sharded_replay_equals_single_process(tmp_path, extr_rig, demo_params, ranks, backend):
+    """se3d_replay --ranks N: N fresh child processes replay the scene with the hypotheses / detections split over the ranks
+    (host/se3d_exchange.cpp: se3d::HypothesisShard on a Collective); every rank's output file must equal the single-process replay's byte for
+    byte — stage-1 persons, fused and predicted persons, ids, headers."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")], stdout=subprocess.DEVNULL)
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=6, n_frames=14, seed=21, p_miss=0.1, low_score_frac=0.1, outlier_frac=0.02))
+    stream = Hn.stream_from_frames(frames)
+    scene, out, out_s = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin"), str(tmp_path / "out_sharded.bin")
+    Hn.write_replay_scene(scene, extr_rig, demo_params, stream)
+    env = dict(os.environ, SE3D_REPLAY_MAX_DET="8", SE3D_REPLAY_MAX_HYP="16")   # the same (fixed) limits on both sides
+    exe = os.path.join(ROOT, "host", "se3d_replay")
+    subprocess.run([exe, scene, out], check=True, env=env, capture_output=True)
+    log = subprocess.run([exe, scene, out_s, "--ranks", str(ranks), "--backend", backend], check=True, env=env, capture_output=True, text=True, timeout=300).stdout
+    ref = open(out, "rb").read()
+    assert sum(len(g[1].persons) for g in Hn.read_replay_output(out) if g is not None) > 10
+    for r in range(ranks):
+        assert open("%s.rank%d" % (out_s, r), "rb").read() == ref, "rank %d of %d published something else than the single process" % (r, ranks)
+    return log
+
+
+def test_cpp_replay_rccl_world1(tmp_path, extr_rig, demo_params):
+    """The RCCL backend of the C++ exchange (librccl.so through dlopen: ncclGetUniqueId / ncclCommInitRank / ncclAllGather on the context's
+    stream) with one rank — all this box has; the collective runs and the result equals the un-sharded replay."""
+    log = _sharded_replay_equals_single_process(tmp_path, extr_rig, demo_params, 1, "rccl")
+    assert "collective: rccl" in log, log
+
+
+def test_cpp_replay_two_ranks_host_staged(tmp_path, extr_rig, demo_params):
+    """Two ranks on the ONE GPU through the test-only host-staged collective (RCCL refuses two ranks on one device): the N > 1 code path of the
+    C++ host layer end to end — launcher, rendezvous, shard layout, both all-gathers per frame, replicated association and lifecycle."""
+    log = _sharded_replay_equals_single_process(tmp_path, extr_rig, demo_params, 2, "staged")
+    assert log.count("host-staged files") == 2, log

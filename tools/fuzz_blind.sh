@@ -1,7 +1,7 @@
 #!/bin/bash
 # Blind check of the randomised parity sweep (GPU box): seeds never run before the criteria were frozen (commit 929e612), reported unedited.
 #   bash tools/fuzz_blind.sh [out] [base]   100 runs from seed base + 1 (default base 2000; 3000: the second batch, after the scores became
-#   bit-equal; 5000: round 5, with the stage-2 objective criterion on every sequence-step, criteria frozen at the commit that added it; 6000: the final code of round 5, after the late arithmetic changes): 70 x default, 10 x h36m, 10 x norm_height (40 scenes each), 10 x large rigs (20 scenes)
+#   bit-equal; 5000: round 5, with the stage-2 objective criterion on every sequence-step, criteria frozen at the commit that added it; 6000: the final code of round 5, after the late arithmetic changes; 7000: round 6, exempt-set mismatches counted by kind with the 0.5 % / 0.1 % budgets, second pass with fp64 sample covariances): 70 x default, 10 x h36m, 10 x norm_height (40 scenes each), 10 x large rigs (20 scenes)
 OUT=${1:-gpurun_out/fuzz_blind.log}
 B=${2:-2000}
 mkdir -p "$(dirname "$OUT")"
@@ -26,6 +26,15 @@ tot = lambda k: sum(r[k] for r in rows)
 print("stage 2 on EVERY sequence-step (round 5): %d published persons compared, %d with joints >= 1 mm apart, of them with the WORSE objective on the library's side: %d (worst excess %.3g); steps not comparable (different detections published): %d; mismatches inside the exclusion set: %d of %d exempt steps (%.2f %%)"
       % (tot("objective_persons"), tot("objective_disagree"), tot("objective_worse"), max(r.get("objective_worst_excess", 0.0) for r in rows), tot("objective_not_comparable_steps"),
          tot("excluded_stage2_mismatches"), tot("seq_steps_excluded"), 100.0 * tot("excluded_stage2_mismatches") / max(1, tot("seq_steps_excluded"))))
+kinds = {}
+for r in rows:
+    for k, v in r.get("excluded_mismatch_kinds", {}).items():
+        kinds[k] = kinds.get(k, 0) + v
+ex, mm, cm = tot("seq_steps_excluded"), tot("excluded_stage2_mismatches"), sum(r.get("excluded_count_mismatches", 0) for r in rows)
+print("exempt-set budgets (round 6): mismatches by kind %s; all kinds %d of %d exempt steps (budget 0.5 %%: %s); person / track count or id divergences %d (budget 0.1 %%: %s); "
+      "predicted-only person differences on comparable steps: %d of %d persons"
+      % (kinds, mm, ex, "ok" if mm <= max(2, 0.005 * ex) else "EXCEEDED", cm, "ok" if cm <= max(1, 0.001 * ex) else "EXCEEDED",
+         sum(r.get("objective_pred_only", 0) for r in rows), tot("objective_persons")))
 print("runs %d, joints %d (excluded %d; second pass %d; input-derived kappa >= 2e3: %d, of them not listed %d), over 1 mm %d (worst %.4f mm), scores %d, covariances %d (over the flat 1e-3: %d, worst %.2e), sequence-steps %d (excluded %d), stage-2 numeric %d, index %d; runs with a miss: %s"
       % (len(rows), tot("joints"), tot("joints_excluded"), tot("joints_second_pass"), tot("ill_joints"), tot("ill_not_listed"), tot("joints_over_1mm"), max(r["pos_max_mm"] for r in rows), tot("scores_over_rtol"), tot("cov_over_tol"), tot("cov_over_flat_1e-3"),
          max(r["cov_rel_max"] for r in rows), tot("seq_steps"), tot("seq_steps_excluded"), tot("stage2_numeric_failures"), tot("stage2_index_divergences"), bad))
