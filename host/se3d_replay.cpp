@@ -113,7 +113,11 @@ int main(int argc_all, char** argv_all) {
     const int det0 = std::getenv("SE3D_REPLAY_MAX_DET") ? std::atoi(std::getenv("SE3D_REPLAY_MAX_DET")) : 16;
     const int hyp0 = std::getenv("SE3D_REPLAY_MAX_HYP") ? std::atoi(std::getenv("SE3D_REPLAY_MAX_HYP")) : 64;
     const int device = is_rank && backend != "staged" ? my_rank : 0;   // one GPU per rank; the test-only staged backend shares GPU 0
-    auto ctx = std::make_shared<se3d::Context>(cams, prm, det0, hyp0, device);
+    // SE3D_REPLAY_REFINE_STEPS=1: se3d_refine as the five per-step launches instead of one fused-walk launch (se3d_options.refine_steps) — the kernels the
+    // hypothesis-shard calls use, so that a sharded replay can be compared with a single-process one byte for byte (the two LM forms sum in another order)
+    se3d_options opt{};
+    opt.refine_steps = std::getenv("SE3D_REPLAY_REFINE_STEPS") ? std::atoi(std::getenv("SE3D_REPLAY_REFINE_STEPS")) : 0;
+    auto ctx = std::make_shared<se3d::Context>(cams, prm, det0, hyp0, device, &opt);
     se3d::Skeleton3DNode skel(ctx);
     se3d::PosePriorNode prior(ctx);
     std::unique_ptr<se3d::Collective> coll;

@@ -170,7 +170,9 @@ def _sharded_replay_equals_single_process(tmp_path, extr_rig, demo_params, ranks
     stream = Hn.stream_from_frames(frames)
     scene, out, out_s = str(tmp_path / "scene.bin"), str(tmp_path / "out.bin"), str(tmp_path / "out_sharded.bin")
     Hn.write_replay_scene(scene, extr_rig, demo_params, stream)
-    env = dict(os.environ, SE3D_REPLAY_MAX_DET="8", SE3D_REPLAY_MAX_HYP="16")   # the same (fixed) limits on both sides
+    # the same (fixed) limits on both sides, and se3d_refine as per-step launches: the shard calls run the per-step LM kernel, whose sums differ from the
+    # fused walk's three-persons-per-wavefront LM in the last bits
+    env = dict(os.environ, SE3D_REPLAY_MAX_DET="8", SE3D_REPLAY_MAX_HYP="16", SE3D_REPLAY_REFINE_STEPS="1")
     exe = os.path.join(ROOT, "host", "se3d_replay")
     subprocess.run([exe, scene, out], check=True, env=env, capture_output=True)
     log = subprocess.run([exe, scene, out_s, "--ranks", str(ranks), "--backend", backend], check=True, env=env, capture_output=True, text=True, timeout=300).stdout

@@ -26,8 +26,8 @@ def main():
     params = pm.Params(pm.POSE_SIMPLE, 0, 0.045)
     frames, _ = S.generate_sequence(rig, S.SceneConfig(n_persons=4, n_frames=16, seed=3))
     s1 = [O.triangulate(rig, params, fr, capacity=32, hyp_capacity=32).published() for fr in frames]
-    for dist in (5.0, 30.0, 150.0):
-        for sigma in (3.0, 30.0, 300.0):
+    for dist in (0.0, 0.3):
+        for sigma in (3e2, 1e3, 3e3, 1e4, 1e5):
             node = Skeleton3D(rig, max_epi_dist=0.045, max_frames=1, max_det_per_cam=8, max_hyp=16, device=0)
             pp, ora = PosePrior(node, 0), O.PosePrior(params)
             tot = dict(persons=0, disagree=0, worse=0, not_comparable=0, worst=0.0, max_mm=0.0)
@@ -41,6 +41,14 @@ def main():
                     continue
                 tot["persons"] += oc["persons"]; tot["disagree"] += oc["disagree"]; tot["worse"] += oc["worse"]; tot["worst"] = max(tot["worst"], oc["worst_excess"])
                 n = g.n_persons
+                if n and oc["disagree"]:
+                    dd = np.linalg.norm(g.fused[:n]["keypoints"]["joint"] - o.fused[:n]["keypoints"]["joint"], axis=-1)
+                    vv = o.fused[:n]["keypoints"]["score"] > 0
+                    for p in range(n):
+                        if (dd[p] * vv[p]).max() >= 1e-3:
+                            print("   step %d person %d: max joint diff %.3f mm at joint %d, objective lib %.9g oracle %.9g, iterations lib %d oracle %d, ids %d %d"
+                                  % (k, p, (dd[p] * vv[p]).max() * 1e3, int(np.argmax(dd[p] * vv[p])), g.lm_objective[p], o.lm_objective[p], g.lm_iterations[p], o.lm_iterations[p],
+                                     g.fused["id"][p], o.fused["id"][p]))
                 if n:
                     v = o.fused[:n]["keypoints"]["score"] > 0
                     d = np.linalg.norm(g.fused[:n]["keypoints"]["joint"] - o.fused[:n]["keypoints"]["joint"], axis=-1)
