@@ -176,7 +176,10 @@ def run_trials(O, seed, trials, walk_mode="wave", pose_method="simple", norm_hei
                         dead[s] = dead[s] or not numeric
                         continue
                     rep["stage2_numeric_failures" if numeric else "stage2_index_divergences"] += 1
-                    rep["violations"].append(dict(trial=trial, step=k, seq=s, stage2=msg[:200]))
+                    with np.errstate(invalid="ignore"):   # what the step's INPUT looked like: the widest measured joint (stage-1 sigma) and the farthest from its person
+                        vv = dets["keypoints"]["score"] > 0
+                        sig = np.sqrt(np.nanmax(np.where(vv[..., None], dets["keypoints"]["cov"][..., [0, 3, 5]], 0.0))) if len(dets) else 0.0
+                    rep["violations"].append(dict(trial=trial, step=k, seq=s, stage2=msg[:200], widest_input_sigma_m=float(sig)))
                     dead[s] = dead[s] or not numeric
         node.close()
         rep["trials"] += 1
