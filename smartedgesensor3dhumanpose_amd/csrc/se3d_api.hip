@@ -530,8 +530,8 @@ se3d_ctx *se3d_create_ex(const se3d_rig *rig, const se3d_params *params, const s
                  SE3D_MUNKRES_MAX, H, SE3D_MUNKRES_MAX);
     return nullptr;
   }
-  if ((int64_t)B * H >= ((int64_t)1 << 26)) {   // tri_list entries: (frame * max_hyp + hypothesis) << 5 | joint, bit 31 = the covariance flag
-    create_error("se3d_create: max_frames x max_hyp = %lld exceeds 2^26 - 1 hypothesis slots per context", (long long)B * H);
+  if ((int64_t)B * H >= ((int64_t)1 << 25)) {   // tri_list entries: (frame * max_hyp + hypothesis) << 5 | joint, bit 31 = the covariance flag, bit 30 = internal mark
+    create_error("se3d_create: max_frames x max_hyp = %lld exceeds 2^25 - 1 hypothesis slots per context", (long long)B * H);
     return nullptr;
   }
   int ndev = 0;
@@ -716,7 +716,7 @@ int64_t se3d_device_bytes_ex(int32_t n_cam, const se3d_limits *limits, const se3
   if (!limits || !options_valid(options)) return -1;
   const int N = n_cam, B = limits->max_frames, P = limits->max_det_per_cam, H = limits->max_hyp;
   const int T = limits->max_tracks > 0 ? limits->max_tracks : H;
-  if (N < 2 || N > SE3D_MAX_CAMS || B < 1 || P < 1 || P > SE3D_MUNKRES_MAX || H < P || H > SE3D_MUNKRES_MAX || T > SE3D_MUNKRES_MAX || (int64_t)B * H >= ((int64_t)1 << 26)) return -1;
+  if (N < 2 || N > SE3D_MAX_CAMS || B < 1 || P < 1 || P > SE3D_MUNKRES_MAX || H < P || H > SE3D_MUNKRES_MAX || T > SE3D_MUNKRES_MAX || (int64_t)B * H >= ((int64_t)1 << 25)) return -1;
   se3d_ctx c;
   c.dry = true;
   c.limits = *limits;

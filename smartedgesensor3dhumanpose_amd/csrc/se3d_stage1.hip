@@ -2001,10 +2001,253 @@ __device__ __forceinline__ double x32_reproj_error(const X32Views &T, const floa
   return averageError / norm;
 }
 
+// =============================================================================================================
+// Round 6: FOUR listed joints per wavefront on small rigs (N <= 16).  The one-joint kernel below keeps n + 2 of its 64 lanes busy in phase A — the
+// weighted system and its n leave-one-view-out subsets, ~11 lanes at the benchmark's 9 views per joint — and the counters of the rough-scene pass
+// (profiles/r6/pmc_sq_16cam6p_rough_split.json) show the vector ALU 78 % busy at that lane utilisation: the pass is bound by wave-INSTRUCTIONS, so the
+// lever is lanes per instruction.  Here a 16-lane group carries one joint (lane 0 the weighted system, lanes 1 .. n its subsets: n <= 15), four
+// groups share every instruction of the solve; the decisions of S3D:748-844 are taken per group with shuffles inside the group; phase B runs the fp64
+// sample solves (the covariance contract of the fast path) 16 samples per group and round.  What this kernel does NOT do it hands to the one-joint
+// kernel by setting bit 30 of the list entry: a quad with a joint seen by all 16 cameras, and every joint whose samples need float32 arithmetic (ill
+// conditioned kept views, wide covariance, unsettled sample: ~8 % of the listed joints of the rough scenes).  Same device functions, same expressions
+// and orders per joint as the one-joint kernel: positions, scores and decisions carry the oracle's bits (tests/test_gpu_exact32.py).
+// =============================================================================================================
+#define X4_GL 16                       // lanes per joint
+#define X4_G (64 / X4_GL)              // joints per wavefront
+#define SE3D_EXACT4_MAX_N 16           // rigs this kernel is launched for
+__host__ __device__ inline size_t se3d_exact4_lds_bytes(int N) {   // camera matrices + per group the view list (6 N floats), its rows (8 N) and cameras (N ints)
+  return (((size_t)12 * N + (size_t)X4_G * (14 * N)) * sizeof(float) + (size_t)X4_G * N * sizeof(int) + 15) & ~(size_t)15;
+}
+__device__ __forceinline__ double x4_group_sum(double v) {
+#pragma unroll
+  for (int o = X4_GL / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double x4_shfl_f64(double v, int src) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__shfl((int)(unsigned)u, src), hi = (unsigned)__shfl((int)(unsigned)(u >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__global__ __launch_bounds__(64, 3) void se3d_k_triangulate_exact4(Se3dDev D) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x, grp = lane / X4_GL, gl = lane % X4_GL, base = grp * X4_GL;
+  const int N = D.d.N, H = D.d.H;
+  const uint32_t cnt = D.tri_cnt[0];
+  const uint32_t nquads = (cnt + X4_G - 1) / X4_G;
+  if (blockIdx.x >= nquads) return;
+  float *sRt = reinterpret_cast<float *>(smem);
+  for (int i = lane; i < 12 * N; i += 64) sRt[i] = D.Rt[i];
+  float *gbase = sRt + 12 * N + (size_t)grp * 14 * N;
+  X32Views T;
+  T.x = gbase; T.y = T.x + N; T.cf = T.y + N; T.k00 = T.cf + N; T.k01 = T.k00 + N; T.k11 = T.k01 + N;
+  T.rows = T.k11 + N;
+  T.cam = reinterpret_cast<int *>(sRt + 12 * N + (size_t)X4_G * 14 * N) + grp * N;
+  const X32Mat A{D.tri_ws + (size_t)blockIdx.x * se3d_exact_ws_floats(N) + lane, 64, 2 * N};
+  __syncthreads();
+  for (uint32_t quad = blockIdx.x; quad < nquads; quad += gridDim.x) {
+    const uint32_t it = quad * X4_G + grp;
+    const bool have = it < cnt;
+    const uint32_t en = have ? (D.tri_list[it] & 0x3fffffffu) : 0u;
+    const int e = (int)(en >> 5), j = (int)(en & 31u), f = e / H, h = e - f * H;
+    // ---- usable views of the group's joint (conf >= 0.30, S3D:724-732), ascending camera order: lane gl <-> camera gl (N <= 16) ----
+    bool ok = false;
+    se3d_keypoint2d r;
+    r.x = r.y = 0.f; r.score = -1.f; r.cov[0] = r.cov[1] = r.cov[2] = 0.f;
+    if (have && gl < N) {
+      const int k = D.assoc[((size_t)f * H + h) * N + gl];
+      if (k >= 0) {
+        const size_t cb = ((size_t)(f * N + gl)) * D.d.P;
+        r = D.raw[cb + D.orig[cb + k]].keypoints[j];
+        ok = r.score >= TRI_THRESH;
+      }
+    }
+    const unsigned bl = (unsigned)((__ballot(ok) >> base) & 0xffffull);
+    int n = __popc(bl);
+    if (ok) {
+      const int pos = __popc(bl & ((1u << gl) - 1u));
+      const float fx = D.K[gl * 4 + 0], fy = D.K[gl * 4 + 1], cx = D.K[gl * 4 + 2], cy = D.K[gl * 4 + 3];
+      T.x[pos] = (r.x - cx) / fx; T.y[pos] = (r.y - cy) / fy; T.cf[pos] = r.score;
+      T.k00[pos] = r.cov[0] / (fx * fx); T.k01[pos] = r.cov[1] / (fx * fy); T.k11[pos] = r.cov[2] / (fy * fy);   // S3D:324-326
+      T.cam[pos] = gl;
+    }
+    // a quad with a joint that does not fit a group (n + 1 > 16 lanes) or cannot be triangulated goes to the one-joint kernel as a whole (uniform)
+    if (__ballot(have && (n > X4_GL - 1 || n < 2)) != 0ull) {
+      if (have && gl == 0) D.tri_list[it] = en | 0x40000000u;
+      __syncthreads();
+      continue;
+    }
+    __syncthreads();
+    if (have && gl < n) {
+      float r0[4], r1[4];
+      x32_dlt_rows(sRt + 12 * T.cam[gl], T.x[gl], T.y[gl], r0, r1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { T.rows[8 * gl + k] = r0[k]; T.rows[8 * gl + 4 + k] = r1[k]; }
+    }
+    __syncthreads();
+    // ---- phase A: the weighted system (group lane 0) and, with three or more views, its leave-one-view-out subsets (group lanes 1 .. n) ----
+    float Xl[3] = {0.f, 0.f, 0.f};
+    double el = 1e300;
+    if (have && (gl == 0 || (n >= 3 && gl <= n))) {
+      x32_triangulate(T, sRt, n, true, gl - 1, -1, 0.f, 0.f, A, Xl);
+      el = x32_reproj_error(T, sRt, n, gl - 1, Xl);
+    }
+    float X = __shfl(Xl[0], base), Y = __shfl(Xl[1], base), Z = __shfl(Xl[2], base);
+    double err = x4_shfl_f64(el, base);
+    float avg_score = 0.f;
+    for (int v = 0; v < n; ++v) avg_score += T.cf[v];   // S3D:730 (every lane of the group forms the same sum)
+    avg_score /= (float)(n > 0 ? n : 1);                // S3D:738
+    int rm = -1;
+    {   // S3D:748-792 (three views): the pair of remaining views with the smallest squared symmetric epipolar distance
+      const bool three = have && err > REPROJ_MAX && n == 3;
+      float dcand = 0.f;
+      if (three && gl < 3) {
+        const int i0 = (gl == 0) ? 1 : 0, i1 = (gl == 2) ? 1 : 2;
+        const float p1x = T.x[i0], p1y = T.y[i0], p2x = T.x[i1], p2y = T.y[i1];
+        const float *F = D.F + 9 * (size_t)se3d_pair_index(T.cam[i0], T.cam[i1], N);
+        const float l1x = F[0] * p1x + (F[1] * p1y + F[2]);
+        const float l1y = F[3] * p1x + (F[4] * p1y + F[5]);
+        const float l1z = F[6] * p1x + (F[7] * p1y + F[8]);
+        const float l2x = F[0] * p2x + (F[3] * p2y + F[6]);
+        const float l2y = F[1] * p2x + (F[4] * p2y + F[7]);
+        const float l2z = F[2] * p2x + (F[5] * p2y + F[8]);
+        const float n1 = p2x * l1x + (p2y * l1y + l1z);
+        const float n2 = p1x * l2x + (p1y * l2y + l2z);
+        dcand = n1 * n1 / (l1x * l1x + l1y * l1y) + n2 * n2 / (l2x * l2x + l2y * l2y);
+      }
+      float best = (float)(err * err);
+      int rm3 = -1;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float di = __shfl(dcand, base + i);
+        if (di < best) { best = di; rm3 = i; }
+      }
+      // S3D:793-838 (four or more views): candidates in ascending view order, first strict minimum below 0.9 x err wins
+      const bool loo = have && err > REPROJ_MAX && n >= 4;
+      double m = (loo && gl >= 1 && gl <= n && el < 0.9 * err) ? el : 1e300;
+      int mi = gl - 1;
+#pragma unroll
+      for (int o = X4_GL / 2; o > 0; o >>= 1) {
+        const double om = x4_shfl_f64(m, lane ^ o);
+        const int oi = __shfl_xor(mi, o);
+        if (om < m || (om == m && oi < mi)) { m = om; mi = oi; }
+      }
+      if (three && rm3 != -1) rm = rm3;
+      if (loo && m < err) rm = mi;
+      // (the shuffles below are executed by every lane; groups without a removal read their own lane 0 + (-1 + 1))
+      const int src = base + (rm != -1 ? rm + 1 : 0);
+      const float Xn = __shfl(Xl[0], src), Yn = __shfl(Xl[1], src), Zn = __shfl(Xl[2], src);
+      const double en_ = x4_shfl_f64(el, src);
+      if (rm != -1) {
+        X = Xn; Y = Yn; Z = Zn;
+        err = en_;
+        if (n == 3) {
+          const int a = rm == 0 ? 1 : 0, b = rm == 2 ? 1 : 2;
+          avg_score = (T.cf[a] + T.cf[b]) / 2.0f;
+        } else {
+          float tmpScore = 0.f;
+          for (int v = 0; v < n; ++v)
+            if (v != rm) tmpScore += T.cf[v];
+          avg_score = tmpScore / (float)(n - 1);
+        }
+      }
+    }
+    __syncthreads();
+    if (rm != -1 && gl == 0) {   // erase the view, order preserved (one lane per group)
+      for (int v = rm; v + 1 < n; ++v) {
+        T.x[v] = T.x[v + 1]; T.y[v] = T.y[v + 1]; T.cf[v] = T.cf[v + 1];
+        T.k00[v] = T.k00[v + 1]; T.k01[v] = T.k01[v + 1]; T.k11[v] = T.k11[v + 1]; T.cam[v] = T.cam[v + 1];
+        for (int k = 0; k < 8; ++k) T.rows[8 * v + k] = T.rows[8 * (v + 1) + k];
+      }
+    }
+    if (rm != -1) n -= 1;
+    __syncthreads();
+    if (err > REPROJ_MAX) avg_score = (float)((double)avg_score * (REPROJ_MAX / err));  // S3D:840-841
+    // ---- phase B: fp64 sample solves around the float32 point where the kept views are well conditioned (see the one-joint kernel), else bit 30 ----
+    const int dim = 2 * n, nsamp = 4 * n + 1;
+    const float bsc = sqrtf((float)dim + 0.5f);
+    bool not_spd = false;
+    if (have && gl < n) {
+      const float l11 = sqrtf(T.k00[gl]), l21 = T.k01[gl] / l11, l22 = sqrtf(T.k11[gl] - l21 * l21);
+      not_spd = !(isfinite(l11) && isfinite(l21) && isfinite(l22));
+    }
+    not_spd = ((__ballot(not_spd) >> base) & 0xffffull) != 0ull;
+    double gu_[10], gw_[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { gu_[k] = 0.0; gw_[k] = 0.0; }
+    if (have && gl < n) {
+      float r0[4], r1[4], w0[4], w1[4];
+      const float cf = T.cf[gl];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { r0[k] = T.rows[8 * gl + k]; r1[k] = T.rows[8 * gl + 4 + k]; w0[k] = r0[k] * cf; w1[k] = r1[k] * cf; }
+      se3d_gram_add(gu_, r0); se3d_gram_add(gu_, r1);
+      se3d_gram_add(gw_, w0); se3d_gram_add(gw_, w1);
+    }
+    float gwf[10], guf[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { gu_[k] = x4_group_sum(gu_[k]); gw_[k] = x4_group_sum(gw_[k]); guf[k] = (float)gu_[k]; gwf[k] = (float)gw_[k]; }
+    bool cov64 = false;
+    float cov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool well = have && !not_spd && !(se3d_kappa_flag(gwf, X, Y, Z) || se3d_kappa_flag(guf, X, Y, Z));   // uniform per group
+    {
+      const float wgt = 1.0f / (2.0f * ((float)dim + 0.5f));
+      double cv[6] = {0., 0., 0., 0., 0., 0.};
+      bool sample_bad = false;
+      const double vstart[4] = {(double)X, (double)Y, (double)Z, 1.0};
+      for (int s0 = 0; s0 < 4 * (X4_GL - 1) + 1; s0 += X4_GL) {   // (<= 61 samples: four rounds; the trip count is uniform, the lanes are predicated)
+        const int s = s0 + gl;
+        if (well && s < nsamp) {
+          double g[10];
+#pragma unroll
+          for (int k = 0; k < 10; ++k) g[k] = gu_[k];
+          if (s > 0) {
+            const bool clsB = s > 2 * n;
+            const int q = clsB ? s - 2 * n - 1 : s - 1, c = q >> 1;
+            float o0[4], o1[4], l11, l21, l22;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o0[k] = T.rows[8 * c + k]; o1[k] = T.rows[8 * c + 4 + k]; }
+            se3d_chol2(T.k00[c], T.k01[c], T.k11[c], l11, l21, l22);
+            se3d_sigma_gram(g, sRt + 12 * T.cam[c], T.x[c], T.y[c], l11, l21, l22, bsc, o0, o1, (clsB ? 3 : 1) + (q & 1));
+          }
+          double pt[3];
+          sample_bad |= !se3d_null_invit_point(g, vstart, pt);
+          const float sx = (float)pt[0] - X, sy = (float)pt[1] - Y, sz = (float)pt[2] - Z;
+          const double wx = (double)(sx * wgt), wy = (double)(sy * wgt), wz = (double)(sz * wgt);
+          cv[0] += wx * sx; cv[1] += wx * sy; cv[2] += wx * sz; cv[3] += wy * sy; cv[4] += wy * sz; cv[5] += wz * sz;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cv[k] = x4_group_sum(cv[k]);
+      const bool any_bad = ((__ballot(sample_bad) >> base) & 0xffffull) != 0ull;
+      if (well && !any_bad && cv[0] < SE3D_EXACT_VAR_MAX && cv[3] < SE3D_EXACT_VAR_MAX && cv[5] < SE3D_EXACT_VAR_MAX) {
+        cov64 = true;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov6[k] = (float)cv[k];
+      }
+    }
+    if (not_spd) {   // defined policy: all entries NaN, position and score unaffected
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cov6[k] = __builtin_nanf("");
+    }
+    if (have && gl == 0) {
+      if (cov64 || not_spd) {
+        se3d_keypoint3d *kpo = &D.hypP[(size_t)f * H + h].keypoints[c_kp2fusion[D.d.pose_method][j]];
+        kpo->joint[0] = (double)X; kpo->joint[1] = (double)Y; kpo->joint[2] = (double)Z;
+        kpo->score = avg_score; kpo->_pad = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) kpo->cov[k] = (double)cov6[k];
+        if (cov64) D.tri_list[it] = en | 0x80000000u;
+      } else {
+        D.tri_list[it] = en | 0x40000000u;   // float32 samples needed: the one-joint kernel redoes this joint
+      }
+    }
+    __syncthreads();
+  }
+}
+
 #ifndef X32_WPE
 #define X32_WPE 3   // wavefronts per SIMD the second pass is compiled for: 164 VGPRs without scratch (4: 128 VGPRs + 80 B of scratch per lane)
 #endif
-__global__ __launch_bounds__(64, X32_WPE) void se3d_k_triangulate_exact(Se3dDev D, int cov32 /* options.exact_cov: float32 samples for every listed joint */) {
+__global__ __launch_bounds__(64, X32_WPE) void se3d_k_triangulate_exact(Se3dDev D, int cov32 /* options.exact_cov: float32 samples for every listed joint */, int only_marked /* the four-joint kernel ran first: only the entries it marked */) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   const int N = D.d.N, H = D.d.H;
@@ -2032,7 +2275,9 @@ __global__ __launch_bounds__(64, X32_WPE) void se3d_k_triangulate_exact(Se3dDev 
   const X32Mat A{wsw + lane, 64, 2 * N};
   __syncthreads();
   for (uint32_t it = blockIdx.x; it < cnt; it += gridDim.x) {
-    const uint32_t en = D.tri_list[it] & 0x7fffffffu;   // (bit 31: set below when the covariance comes from the fp64 sample path)
+    const uint32_t raw_en = D.tri_list[it];
+    if (only_marked && !(raw_en & 0x40000000u)) continue;   // handled by se3d_k_triangulate_exact4 (uniform: one entry per wavefront)
+    const uint32_t en = raw_en & 0x3fffffffu;   // (bit 31: set below when the covariance comes from the fp64 sample path; bit 30: the four-joint kernel's hand-over mark)
     const int e = (int)(en >> 5), j = (int)(en & 31u), f = e / H, h = e - f * H;
     se3d_keypoint3d *kpo = &D.hypP[(size_t)f * H + h].keypoints[c_kp2fusion[D.d.pose_method][j]];
     // ---- usable views of the joint (conf >= 0.30, S3D:724-732), ascending camera order; row N on the fly with the reference's expressions ----
@@ -2242,8 +2487,8 @@ __global__ __launch_bounds__(64, X32_WPE) void se3d_k_triangulate_exact(Se3dDev 
         }
       }
     }
+    if (lane == 0) D.tri_list[it] = cov64 ? (en | 0x80000000u) : en;   // (clears the hand-over mark)
     if (cov64) {
-      if (lane == 0) D.tri_list[it] = en | 0x80000000u;
     } else if (not_spd) {   // defined policy: all entries NaN, position and score unaffected
 #pragma unroll
       for (int k = 0; k < 6; ++k) cov6[k] = __builtin_nanf("");
@@ -3073,7 +3318,11 @@ static void se3d_launch_triangulation(const Se3dDev &D, const se3d_options &o, h
   else hipLaunchKernelGGL(se3d_k_triangulate, dim3((H * SE3D_NKP + 3) / 4, B), dim3(256), lds, st, D);
   if (ev_mid) (void)hipEventRecord(ev_mid, st);
   // second pass: the listed joints with the oracle's restatement of the reference's float32 arithmetic (wavefronts beyond the list length exit at once)
-  hipLaunchKernelGGL(se3d_k_triangulate_exact, dim3(waves2), dim3(64), se3d_exact_lds_bytes(N), st, D, o.exact_cov == SE3D_EXACT_COV_F32 ? 1 : 0);
+  // small rigs: four joints per wavefront first (phase A and the fp64 sample covariances); what it marks — and everything when options.exact_cov asks for
+  // float32 samples on every listed joint — goes through the one-joint kernel
+  const bool quad = N <= SE3D_EXACT4_MAX_N && o.exact_cov != SE3D_EXACT_COV_F32;
+  if (quad) hipLaunchKernelGGL(se3d_k_triangulate_exact4, dim3(waves2), dim3(64), se3d_exact4_lds_bytes(N), st, D);
+  hipLaunchKernelGGL(se3d_k_triangulate_exact, dim3(waves2), dim3(64), se3d_exact_lds_bytes(N), st, D, o.exact_cov == SE3D_EXACT_COV_F32 ? 1 : 0, quad ? 1 : 0);
 }
 
 extern "C" void se3d_launch_normalize_keep(const Se3dDev &D, hipStream_t st) {   // normalised points into D.kp, association workspace untouched

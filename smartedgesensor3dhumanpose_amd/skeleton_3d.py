@@ -343,7 +343,7 @@ class Skeleton3D:
         buf = np.zeros(cap, np.uint32)
         self._chk(self._L.se3d_get_exact_list(C.c_void_p(self._h), buf.ctypes.data_as(C.POINTER(C.c_uint32)), cap, C.byref(n), C.byref(total)), "se3d_get_exact_list")
         e = buf[:min(n.value, cap)]
-        fh = (e & 0x7fffffff) >> 5
+        fh = (e & 0x3fffffff) >> 5
         out = np.stack([fh // self.limits.max_hyp, fh % self.limits.max_hyp, e & 31], -1).astype(np.int64) if len(e) else np.zeros((0, 3), np.int64)
         if flags:
             return out, (e >> 31).astype(bool), int(total.value)

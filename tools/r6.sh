@@ -22,7 +22,8 @@ robust)
 import json, sys
 d = json.loads(sys.stdin.readline())
 r = d['robust']
-print('clean', d['value'], d['ms_per_step'], '| robust', r['value'], r['ms_per_step'], 'frac_of_clean', r['fraction_of_clean_value'], 'second pass', r['second_pass_fraction'], 'serial', json.dumps(r['serial']))"
+print('clean', d['value'], d['ms_per_step'], '| robust', r['value'], r['ms_per_step'], 'frac_of_clean', r['fraction_of_clean_value'], 'second pass', r['second_pass_fraction'], 'serial', json.dumps(r['serial']))
+print('outlier-heavy serial', json.dumps(r.get('outlier_heavy_serial')))"
   tail -3 $O/robust_$tag.err
   ;;
 robust_prof)
