@@ -14,8 +14,12 @@ def _node(rig, **kw):
     return Skeleton3D(rig, max_epi_dist=0.045, **kw)
 
 
-@pytest.mark.parametrize("stream_out", [0, 1])   # 0: device buffers + D2H copies (default), 1: the compaction kernel writes the pinned host buffers
+# 0: device buffers + D2H copies (default), 1: the compaction kernel writes the pinned host buffers, "toggle": the option changes between batches IN
+# FLIGHT (se3d_set_options between two submits: a batch keeps the form it was submitted with — ADVICE r5)
+@pytest.mark.parametrize("stream_out", [0, 1, "toggle"])
 def test_streaming_equals_resident(extr_rig, stream_out):
+    toggle = stream_out == "toggle"
+    stream_out = 0 if toggle else stream_out
     S_, T_, n_batches = 6, 16, 5
     seqs = [S.generate_sequence(extr_rig, S.SceneConfig(n_persons=3 + s % 4, n_frames=T_ * n_batches, seed=900 + s, p_miss=0.05 * (s % 3)))[0] for s in range(S_)]
     res, stream = _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12), _node(extr_rig, max_frames=S_ * T_, max_det_per_cam=8, max_hyp=12, options=dict(stream_out=stream_out))
@@ -39,6 +43,8 @@ def test_streaming_equals_resident(extr_rig, stream_out):
     out = []
     stream.stream_submit(batches[0], stamps[0], slots)
     for b in range(1, n_batches):
+        if toggle:
+            stream.set_options(stream_out=b % 2)
         stream.stream_submit(batches[b], stamps[b], slots)
         out.append(stream.stream_collect())
     out.append(stream.stream_collect())

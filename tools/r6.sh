@@ -29,7 +29,7 @@ print('outlier-heavy serial', json.dumps(r.get('outlier_heavy_serial')))"
 robust_prof)
   tag=${1:-x}; shift || true
   rm -rf $O/rough_stats_$tag
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rough_stats_$tag -- python3 bench.py --workload 16cam6p_rough --serial --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/rough_serial_$tag.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rough_stats_$tag -- python3 bench.py --workload ${ROUGH_WORKLOAD:-16cam6p_rough} --serial --steps 3 --warmup 1 --no-cpu-baseline --no-parity > $O/rough_serial_$tag.log 2>&1
   python3 tools/kernel_stats.py $O/rough_stats_$tag $O/serial_16cam6p_rough_${tag}_kernel_stats.csv | head -12
   rm -rf $O/rough_stats_$tag
   ;;
