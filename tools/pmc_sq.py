@@ -22,7 +22,7 @@ note = sys.argv[3] if len(sys.argv) > 3 else ""
 NAMES = {"se3d_k_normalize": "normalize", "se3d_k_normalize_pairs": "epipolar_pairs", "se3d_k_front_fused": "front_fused", "se3d_k_pairs_rows": "epipolar_pairs", "se3d_k_postprocess_wave3": "postprocess", "se3d_k_pairs_flat": "epipolar_pairs", "se3d_k_pairs_packed": "epipolar_pairs",
          "se3d_k_postprocess_wave": "postprocess", "se3d_k_postprocess_wave2": "postprocess", "se3d_k_sweep_wave_lds": "sweep", "se3d_k_pairs_tiled": "epipolar_pairs_tiled", "se3d_k_sweep_fused_wave": "sweep", "se3d_k_sweep_fused": "sweep",
          "se3d_k_sweep_cost": "sweep_cost", "se3d_k_sweep_assign": "sweep_assign", "se3d_k_triangulate": "triangulate_joint", "se3d_k_triangulate_hyp": "triangulate",
-         "se3d_k_triangulate_slow": "triangulate_outliers", "se3d_k_triangulate_exact": "triangulate_second_pass", "se3d_k_postprocess": "postprocess_block", "se3d_k_stage2_walk": "stage2_walk",
+         "se3d_k_triangulate_slow": "triangulate_outliers", "se3d_k_triangulate_exact": "triangulate_second_pass", "se3d_k_triangulate_exact4": "triangulate_second_pass_quad", "se3d_k_postprocess": "postprocess_block", "se3d_k_stage2_walk": "stage2_walk",
          "se3d_k_track_cost": "track_cost", "se3d_k_track_assoc": "track_assoc", "se3d_k_lm_refine": "lm_refine", "se3d_k_track_near": "track_near",
          "se3d_k_track_update": "track_update", "se3d_k_assoc_given": "assoc_given"}
 
