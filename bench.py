@@ -696,7 +696,7 @@ def numa_nodes_of(addr, nbytes, samples=8):
         return None
 
 
-def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out=0, affinity="local"):
+def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out=0, affinity="local", local_source=True):
     """PCIe-inclusive rate (never `value`): every step each context receives its batch of frames from HOST memory (se3d_stream_submit:
     ragged payload into pinned memory, H2D on a copy stream, expansion on the device, stage 1, stage-2 walk, device compaction of the
     published persons, D2H) and hands the published fused / predicted persons back in host memory (se3d_stream_collect); two batches per
@@ -708,14 +708,31 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
     B = S_ * T_
     nodes, prepared = [], []
     in_bytes = 0
+    diag = {}
     # host side of a host-fed deployment: the feeding threads (and the pinned buffers they first touch) on the NUMA node of the GPU's PCIe root, so
     # that neither the copy into pinned memory nor the DMA out of it crosses the socket interconnect (affinity="none": wherever the scheduler puts them)
     all_cpus, local = os.sched_getaffinity(0), (gpu_local_cpus(local_rank) if affinity == "local" else None)
     if local:
         os.sched_setaffinity(0, local)
     try:   # (an exception in the streaming pass must not leave the later passes pinned to one NUMA node)
+        from smartedgesensor3dhumanpose_amd.person_msgs import Frame
         for seqs in seqs_per_ctx:
             frames = [seqs[s][k] for k in range(T_) for s in range(S_)]
+            # Where the SOURCE frames live (round 6).  The scene generator's results were unpickled by the main thread wherever the scheduler had it at the
+            # time; the feeding threads run on the GPU's NUMA node.  With the frames on the other node, about a third of the runs of rounds 4 - 6 showed ONE
+            # step of 83 - 95 ms among ~32 ms ones, on every context at once, ~0.7 s into the pass, and faster steps after it (profiles/r6/README.md
+            # section 3: the signature of the kernel's automatic NUMA balancing moving the pages to the node that reads them).  A host-fed deployment
+            # receives its messages on the node it runs on; the pass copies the frames once from a local CPU (this thread's affinity is already set).
+            if local_source and local:   # ONE fresh block per context (a new mapping: its pages are first touched here), the frames are views into it
+                blob = np.empty(sum(len(f.persons) for f in frames), frames[0].persons.dtype)
+                o, local_frames = 0, []
+                for f in frames:
+                    blob[o:o + len(f.persons)] = f.persons
+                    local_frames.append(Frame(f.n_cam, np.array(f.det_offset, copy=True), blob[o:o + len(f.persons)], np.array(f.fb_delay, copy=True), f.stamp))
+                    o += len(f.persons)
+                frames = local_frames
+            if "source_numa" not in diag and len(frames) and len(frames[0].persons):
+                diag["source_numa"] = numa_nodes_of(frames[0].persons.ctypes.data, frames[0].persons.nbytes, 2)
             nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank, options=dict(stream_out=stream_out))
             nd_.refine_reset()
             nodes.append(nd_)
@@ -723,7 +740,6 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
             in_bytes += sum(int(f.det_offset[-1]) for f in frames) * 428
         counts = [[0, 0] for _ in nodes]   # published persons, bytes out per context (timed region)
         step_ms = []
-        diag = {}
         slowest = [[-1, 0.0, 0.0] for _ in nodes]
         diag["slowest"] = slowest
         go, done = threading.Barrier(NC + 1), threading.Barrier(NC + 1)
@@ -772,6 +788,10 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
         t0 = time.perf_counter()
         done.wait()
         dt = time.perf_counter() - t0
+        try:
+            diag["numa_balancing"] = int(open("/proc/sys/kernel/numa_balancing").read())
+        except (OSError, ValueError):
+            diag["numa_balancing"] = None
         for th in threads:
             th.join()
         diag["probe"] = nodes[0].copy_stream_probe()   # untimed, after the measurement: do the device's two copy streams (still) overlap?
@@ -783,7 +803,8 @@ def run_streaming(name, seqs_per_ctx, rig, steps, warmup, local_rank, stream_out
     n_skel = sum(c[0] for c in counts)
     return {"value": n_skel / dt, "ms_per_step": dt / steps * 1e3, "contexts": NC, "sequences_per_context": S_, "steps": steps,
             "host_threads": ("on the %d CPUs of the GPU's NUMA node" % len(local)) if local else "unpinned", "step_ms_context0": step_ms,
-            "pinned_output_numa_nodes_context0": diag.get("numa"), "worker_cpu_context0": diag.get("cpu"), "copy_stream_probe": diag.get("probe"),
+            "pinned_output_numa_nodes_context0": diag.get("numa"), "source_frames_numa_nodes": diag.get("source_numa"), "worker_cpu_context0": diag.get("cpu"),
+            "kernel_numa_balancing": diag.get("numa_balancing"), "copy_stream_probe": diag.get("probe"),
             "host_call_ms_context0": {"submit_mean": round(float(np.mean(diag.get("submit_ms", [0]))), 2), "collect_mean": round(float(np.mean(diag.get("collect_ms", [0]))), 2),
                                       "submit_max": round(float(np.max(diag.get("submit_ms", [0]))), 2), "collect_max": round(float(np.max(diag.get("collect_ms", [0]))), 2),
                                       "slowest_step": int(np.argmax(step_ms)) if step_ms else None,
@@ -969,6 +990,11 @@ def main():
     ap.add_argument("--stream-out", type=int, default=0, choices=[0, 1], help="se3d_options.stream_out of the streaming measurement: 0 = device buffers + D2H copies (default), "
                     "1 = the compaction kernel writes the published persons into pinned host memory")
     ap.add_argument("--stream-affinity", choices=["local", "none"], default="local", help="streaming pass: host threads on the GPU's NUMA node (sysfs local_cpulist) or unpinned")
+    ap.add_argument("--stream-source", choices=["local", "as-is"], default="local", help="streaming pass: the frames the feeding threads read are copied once, by a thread on the GPU's "
+                    "NUMA node, before the pass (local: default) or left where the scene generator's results were unpickled (as-is: diagnostic)")
+    ap.add_argument("--stream-prefree-gb", type=float, default=0.0, help="diagnostic: allocate, touch and free this much device memory right before the streaming pass")
+    ap.add_argument("--stream-settle-s", type=float, default=-1.0, help="seconds to wait between the last freed context and the streaming pass (default: 3 s in a default run, "
+                    "0 otherwise; profiles/r6/README.md section 3)")
     ap.add_argument("--stream-repeat", type=int, default=1, help="diagnostic: repeat the streaming measurement this many times in the process (each with fresh contexts); "
                     "every result goes to stderr, the last into the line")
     ap.add_argument("--stream-contexts", type=int, default=8, help="contexts of the streaming measurement (each pins two batches of host memory)")
@@ -1117,8 +1143,21 @@ def main():
         run_secondary()
     streaming = None
     if default_run and not args.no_streaming and stage2 and rank == 0:
+        if args.stream_prefree_gb > 0:   # diagnostic: what a big free right before the pass does to it
+            blocks = [torch.empty(int(1e9), dtype=torch.uint8, device="cuda").fill_(1) for _ in range(int(args.stream_prefree_gb))]
+            torch.cuda.synchronize()
+            del blocks
+            torch.cuda.empty_cache()
+        # The passes before this one have just freed ~100 GB of device memory (a default run: the contexts of the headline, the serial and the robust passes),
+        # which the driver wipes in the background.  Measured (profiles/r6/README.md section 3): a streaming pass that starts right behind a 150 GB free shows
+        # ~100 ms stalls every third step in one run of six (6.2 M instead of 11.1 M) and single 83 - 95 ms steps in a third of the default runs of rounds
+        # 4 - 6; behind a 3 s pause: none in six.  The pass measures the streaming path, not the previous pass's clean-up: it waits 3 s in a default run.
+        settle = args.stream_settle_s if args.stream_settle_s >= 0 else (3.0 if default_run else 0.0)
+        if settle > 0:
+            torch.cuda.synchronize()
+            time.sleep(settle)
         for rep in range(max(1, args.stream_repeat)):
-            streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps), 4, local_rank, args.stream_out, args.stream_affinity)   # ~0.7 s timed at the default 20 steps
+            streaming = run_streaming(headline, seqs_stream, rig, max(3, args.steps), 4, local_rank, args.stream_out, args.stream_affinity, local_source=args.stream_source == "local")   # ~0.7 s timed at the default 20 steps
             if args.stream_repeat > 1:
                 print("streaming pass %d: %.2f M skeletons/s, H2D %.1f GB/s, D2H %.1f GB/s, step ms %s, pinned output on NUMA nodes %s, copy-stream probe %s"
                       % (rep, streaming["value"] / 1e6, streaming["h2d_gb_per_s"], streaming["d2h_gb_per_s"], streaming["step_ms_context0"],
@@ -1234,7 +1273,8 @@ def main():
             line["streaming"] = {"value": round(streaming["value"], 2), "unit": "skeletons/s", "fraction_of_resident": round(streaming["value"] / main_res["value_per_gpu"], 4),
                                  "ms_per_step": round(streaming["ms_per_step"], 3), "contexts": streaming["contexts"], "sequences_per_context": streaming["sequences_per_context"],
                                  "h2d_GB_per_s": round(streaming["h2d_gb_per_s"], 2), "d2h_GB_per_s": round(streaming["d2h_gb_per_s"], 2), "host_threads": streaming["host_threads"], "step_ms_context0": streaming["step_ms_context0"],
-                                 "pinned_output_numa_nodes_context0": streaming["pinned_output_numa_nodes_context0"], "copy_stream_probe": streaming["copy_stream_probe"], "host_call_ms_context0": streaming["host_call_ms_context0"],
+                                 "pinned_output_numa_nodes_context0": streaming["pinned_output_numa_nodes_context0"], "source_frames_numa_nodes": streaming["source_frames_numa_nodes"], "kernel_numa_balancing": streaming["kernel_numa_balancing"],
+                                 "settle_s_before_the_pass": settle, "copy_stream_probe": streaming["copy_stream_probe"], "host_call_ms_context0": streaming["host_call_ms_context0"],
                                  "h2d_MB_per_step": round(streaming["h2d_mb_per_step"], 1), "n_gpus": 1,
                                  "note": "PCIe-inclusive: every step's frames come from host memory (ragged, pinned, double-buffered) and the published "
                                          "persons go back to host memory; never `value`.  At 16cam6p a frame is ~40 KB in and ~20 KB out: PCIe Gen5 x16 "

@@ -122,11 +122,11 @@ suite)
 bench)
   n=${1:-1}; shift || true
   for i in $(seq 1 $n); do
-    timeout 900 python bench.py > $O/bench_default_$i.log 2> $O/bench_default_$i.err
+    timeout 900 python bench.py ${BENCH_FLAGS:-} > $O/bench_default_$i.log 2> $O/bench_default_$i.err
     tail -1 $O/bench_default_$i.log | python3 -c "
 import json, sys
 d = json.loads(sys.stdin.readline())
-print('run $i:', d['value'], d['ms_per_step'], 'secondary', d['secondary']['value'], 'streaming', d['value_streaming'], d['streaming'].get('h2d_GB_per_s'), d['streaming'].get('step_ms_context0'), 'robust', d.get('robust', {}).get('value'), 'frac', d['roofline']['frac'])"
+print('run $i:', d['value'], d['ms_per_step'], 'secondary', d['secondary']['value'], 'streaming', d['value_streaming'], d['streaming'].get('h2d_GB_per_s'), 'max step', max(d['streaming'].get('step_ms_context0')), 'gc', d['streaming'].get('python_gc'), 'probe', d['streaming'].get('copy_stream_probe'), 'robust', d.get('robust', {}).get('value'), 'frac', d['roofline']['frac'])"
   done
   ;;
 esac

@@ -14,4 +14,9 @@ LD_PRELOAD="$ASAN_LIB" ASAN_OPTIONS=detect_leaks=0 python -m pytest -q -s \
 if grep -q "runtime error\|AddressSanitizer" /tmp/sanitize_oracle.log; then echo "SANITIZER FINDINGS (oracle): /tmp/sanitize_oracle.log"; exit 1; fi
 make -s -B -C host CXXFLAGS="$SAN -std=c++17 -fPIC -Wall -Wextra -fno-sanitize-recover=undefined" se3d_sync_test se3d_markers_test
 python -m pytest -q tests/test_sync_cpu.py tests/test_markers_cpu.py | tail -2
+# round 6: the staged all-gather's rendezvous of the C++ exchange (threads as ranks, plain host memory as device memory)
+g++ $SAN -std=c++17 -fPIC -Wall -Wextra -fno-sanitize-recover=undefined -o /tmp/se3d_exchange_test_san host/se3d_exchange_test.cpp host/se3d_exchange.cpp \
+  -Lsmartedgesensor3dhumanpose_amd -lse3d_hip -ldl -lpthread -Wl,-rpath,"$PWD/smartedgesensor3dhumanpose_amd"
+ASAN_OPTIONS=detect_leaks=0 /tmp/se3d_exchange_test_san 5 9 2>&1 | tee /tmp/sanitize_exchange.log | tail -2
+if grep -q "runtime error\|AddressSanitizer" /tmp/sanitize_exchange.log; then echo "SANITIZER FINDINGS (exchange): /tmp/sanitize_exchange.log"; exit 1; fi
 echo "sanitize_cpu: clean"
