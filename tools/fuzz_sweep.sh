@@ -5,12 +5,23 @@
 OUT=${1:-gpurun_out/fuzz_parity.log}
 mkdir -p "$(dirname "$OUT")"
 : > "$OUT"
-for s in 4 15 37 39 0 1 2 3 $(seq 101 112) $(seq 201 206) $(seq 301 340); do timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
-for s in 5 $(seq 341 350); do FUZZ_POSE=h36m timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
-for s in 6 $(seq 351 360); do FUZZ_NORM_HEIGHT=1 timeout 300 python tools/fuzz_parity.py $s 40 2>> "$OUT.err" | tail -1 >> "$OUT"; done
-FUZZ_POSE=h36m FUZZ_NORM_HEIGHT=1 timeout 300 python tools/fuzz_parity.py 7 40 2>> "$OUT.err" | tail -1 >> "$OUT"
-# large rigs (32 / 48 cameras, 12 - 24 persons: rows pair kernel with column chunks, per-camera sweep, per-joint triangulation, per-step stage 2)
-for s in $(seq 1001 1040); do FUZZ_LARGE=1 timeout 600 python tools/fuzz_parity.py $s 20 2>> "$OUT.err" | tail -1 >> "$OUT"; done
+# PAR (default 1): runs side by side (each is one host thread of oracle + numpy work around small launches; round 6: PAR=10, ~5 minutes for the sweep)
+PAR=${PAR:-1}
+run() {   # seed trials [ENV=value ...]
+  local s=$1 n=$2; shift 2
+  env "${@:-_X=0}" timeout 600 python tools/fuzz_parity.py $s $n 2>> "$OUT.err.$s" | tail -1 > "$OUT.part.$s"
+}
+export -f run; export OUT
+SMALL="4 15 37 39 0 1 2 3 $(seq -s ' ' 101 112) $(seq -s ' ' 201 206) $(seq -s ' ' 301 340)"
+{ for s in $SMALL; do echo "$s 40"; done
+  for s in 5 $(seq 341 350); do echo "$s 40 FUZZ_POSE=h36m"; done
+  for s in 6 $(seq 351 360); do echo "$s 40 FUZZ_NORM_HEIGHT=1"; done
+  echo "7 40 FUZZ_POSE=h36m FUZZ_NORM_HEIGHT=1"
+  # large rigs (32 / 48 cameras, 12 - 24 persons: rows pair kernel with column chunks, per-camera sweep, per-joint triangulation, per-step stage 2)
+  for s in $(seq 1001 1040); do echo "$s 20 FUZZ_LARGE=1"; done; } > "$OUT.jobs"
+xargs -P $PAR -L 1 bash -c 'run "$@"' _ < "$OUT.jobs"
+while read s rest; do cat "$OUT.part.$s" >> "$OUT"; cat "$OUT.err.$s" >> "$OUT.err" 2>/dev/null; rm -f "$OUT.part.$s" "$OUT.err.$s"; done < "$OUT.jobs"
+rm -f "$OUT.jobs"
 python3 - "$OUT" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
