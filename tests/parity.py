@@ -114,23 +114,21 @@ def classify_stage2(gpu, ora):
         return None
     if not (np.array_equal(gpu.fused["id"][:n], ora.fused["id"][:n]) and np.array_equal(gpu.fused_pred["id"][:n], ora.fused_pred["id"][:n])):
         return "ids"
-    kind = None
+    cov = False
     for name in ("fused", "fused_pred"):
         g, o = getattr(gpu, name)[:n]["keypoints"], getattr(ora, name)[:n]["keypoints"]
         if not np.array_equal(g["score"], o["score"]):
             return "valid"
         vo = o["score"] > 0
-        d = np.linalg.norm(g["joint"] - o["joint"], axis=-1)[vo]
-        if d.size and d.max() >= REFINE_TOL_M:
+        dfull = np.where(vo, np.linalg.norm(g["joint"] - o["joint"], axis=-1), 0.0)
+        if dfull.max() >= REFINE_TOL_M:
             return "fused" if name == "fused" else "pred"
         rel = np.abs(g["cov"][vo] - o["cov"][vo]).max(-1) / np.abs(o["cov"][vo]).max(-1)
-        if rel.size and rel.max() >= MARG_COV_RTOL + 1e-2:
-            kind = kind or "cov"
-    if kind:
-        return kind
+        tol = (MARG_COV_RTOL + np.minimum(2.0 * dfull.max(-1, keepdims=True) / 0.05, 1e-2) * np.ones_like(dfull))[vo]   # compare_stage2's tolerance
+        cov = cov or bool((rel >= tol).any())
     if not np.array_equal(gpu.lm_iterations[:n], ora.lm_iterations[:n]):
-        return "iters"
-    return "cov"   # compare_stage2 failed on a covariance inside the 1e-2 cap of its tolerance
+        return "iters" if not cov else "cov"
+    return "cov" if cov else None
 
 
 OBJECTIVE_RTOL = 1e-9   # stage 2: where the two LMs publish different joints, the library's final objective may exceed the oracle's by this much at most

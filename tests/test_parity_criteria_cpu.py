@@ -138,3 +138,83 @@ def test_garbage_persons_flags_distance_and_sigma():
     assert parity.garbage_persons(p).tolist() == [False, True, True]
     p["keypoints"]["cov"][2, 7, [0, 3, 5]] = 50.0 ** 2                     # 50 m: still a usable (weak) unary factor
     assert parity.garbage_persons(p).tolist() == [False, True, False]
+
+
+def _stage2_pair(extr_rig, oracle, demo_params):
+    """Two identical published stage-2 results of one step (the oracle run twice on the same inputs): the starting point the criteria are perturbed from."""
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=4, n_frames=13, seed=3))
+    out = []
+    for _ in range(2):
+        pp = oracle.PosePrior(demo_params)
+        for fr in frames:
+            dets = oracle.triangulate(extr_rig, demo_params, fr, capacity=32, hyp_capacity=32).published()
+            r = pp.step(dets, extr_rig.n_cam, fr.stamp, fr.fb_delay, capacity=16)
+        out.append(r)
+    assert out[0].n_persons >= 3
+    return out
+
+
+def test_stage2_mismatch_kinds_and_the_predicted_only_counter(extr_rig, oracle, demo_params):
+    """Round 6: parity.classify_stage2 names what differs on a step (the exempt set's mismatches are counted by kind) and
+    parity.compare_stage2_objectives counts persons whose PREDICTED joints differ under agreeing refined ones."""
+    a, b = _stage2_pair(extr_rig, oracle, demo_params)
+    assert parity.classify_stage2(a, b) is None
+    oc = parity.compare_stage2_objectives(a, b)
+    assert oc["comparable"] and oc["disagree"] == 0 and oc["pred_only"] == 0 and oc["persons"] == a.n_persons
+    j = int(np.nonzero(b.fused[0]["keypoints"]["score"] > 0)[0][0])
+
+    def variant(edit):
+        c = pm.FusedResult(len(b.fused))
+        c.fused[:], c.fused_pred[:], c.lm_iterations[:], c.lm_objective[:] = b.fused, b.fused_pred, b.lm_iterations, b.lm_objective
+        c.c.n_persons, c.c.n_tracks, c.c.pred_delta_t, c.c.flags = b.c.n_persons, b.c.n_tracks, b.c.pred_delta_t, b.c.flags
+        edit(c)
+        return c
+
+    def moved_pred(c):
+        c.fused_pred[0]["keypoints"]["joint"][j, 0] += 0.004
+    assert parity.classify_stage2(a, variant(moved_pred)) == "pred"
+    oc = parity.compare_stage2_objectives(variant(moved_pred), a)
+    assert oc["pred_only"] == 1 and oc["disagree"] == 0
+
+    def moved_fused(c):
+        c.fused[0]["keypoints"]["joint"][j, 1] -= 0.003
+        c.lm_objective[0] *= 1.5
+    assert parity.classify_stage2(a, variant(moved_fused)) == "fused"
+    oc = parity.compare_stage2_objectives(variant(moved_fused), a)       # the edited side plays the library: different joints AND the larger objective
+    assert oc["disagree"] == 1 and oc["worse"] == 1 and oc["pred_only"] == 0
+    oc = parity.compare_stage2_objectives(a, variant(moved_fused))       # the other way round: different joints, the smaller objective: accepted
+    assert oc["disagree"] == 1 and oc["worse"] == 0
+
+    def one_fewer(c):
+        c.c.n_persons -= 1
+    assert parity.classify_stage2(a, variant(one_fewer)) == "count"
+    assert not parity.compare_stage2_objectives(a, variant(one_fewer))["comparable"]
+
+    def other_id(c):
+        c.fused["id"][0] += 7
+    assert parity.classify_stage2(a, variant(other_id)) == "ids"
+
+    def more_iterations(c):
+        c.lm_iterations[0] += 3
+    assert parity.classify_stage2(a, variant(more_iterations)) == "iters"
+
+    def wider_cov(c):
+        c.fused[0]["keypoints"]["cov"][j] *= 1.05
+    assert parity.classify_stage2(a, variant(wider_cov)) == "cov"
+
+
+def test_rough_scene_parameters_are_fixed_and_the_sweep_draws_around_them():
+    """scene.ROUGH (bench.py's `robust` block) are fixed numbers inside the ranges the randomised sweep draws from (scene.draw_rough_params: five draws in a
+    fixed order, so that (seed, trial) keeps naming the scenes of rounds 3 - 5)."""
+    assert S.ROUGH == dict(p_miss=0.08, low_score_frac=0.15, outlier_frac=0.006, pixel_noise=2.0)
+    cfg = S.rough_config(6, 16, 11, min_coverage=4)
+    assert (cfg.n_persons, cfg.n_frames, cfg.seed, cfg.p_miss, cfg.outlier_frac, cfg.min_coverage) == (6, 16, 11, 0.08, 0.006, 4)
+    assert S.rough_config(6, 16, 11, outlier_px=60.0, outlier_frac=0.04).outlier_px == 60.0
+    rng_a, rng_b = np.random.default_rng(9), np.random.default_rng(9)
+    drawn = S.draw_rough_params(rng_a)
+    expect = dict(p_miss=float(rng_b.uniform(0, 0.15)), low_score_frac=float(rng_b.uniform(0, 0.3)), outlier_frac=float(rng_b.uniform(0, 0.012)),
+                  pixel_noise=float(rng_b.uniform(0.5, 4.0)), spacing=float(rng_b.uniform(0.5, 1.2)))
+    assert drawn == expect
+    for k, v in S.ROUGH.items():
+        lo, hi = dict(p_miss=(0, 0.15), low_score_frac=(0, 0.3), outlier_frac=(0, 0.012), pixel_noise=(0.5, 4.0))[k]
+        assert lo < v < hi
