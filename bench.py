@@ -50,6 +50,9 @@ WORKLOADS = {
     # leave-one-out rejection itself (S3D:793-838) and more sit in the threshold band — the level at which the second pass carries >= 5 % of the joints
     "16cam6p_outliers": dict(n_cam=16, n_persons=6, seqs=512, contexts=12, max_det=8, max_hyp=16, bytes_s1=8972, bytes_s2=8900, flop_s1=0.12e6 + 1.86e6, rough=dict(outlier_frac=0.04, outlier_px=60.0)),
     "64cam32p": dict(n_cam=64, n_persons=32, seqs=32, contexts=3, max_det=40, max_hyp=96, bytes_s1=30072, bytes_s2=8900, flop_s1=11.0e6 + 7.28e6),
+    # diagnostic: a mid-size rig with P <= 16 and N x P > 256 — the stand-alone normalisation + the flat pair kernel (one lane per table entry) and the
+    # one-wavefront sweep with its state in global memory; byte / flop figures interpolated from the two neighbours, not a bench line
+    "32cam12p": dict(n_cam=32, n_persons=12, seqs=64, contexts=4, max_det=16, max_hyp=32, bytes_s1=15000, bytes_s2=8900, flop_s1=2.5e6 + 3.6e6),
     # 256cam128p: 6 contexts x 4 sequences x 16 frames; the pair table is kept as two camera-column chunks per frame (Se3dPairPlan):
     # 9.4 GB per 16 frames instead of 68.9 GB, 6 x 38.5 GB per GPU.  Contexts (profiles/r4/README.md section 7): 3 -> 26.1 k, 4 -> 26.9 - 27.3 k,
     # 5 -> 27.9 - 28.7 k skeletons/s (one more set of latency-bound sweep / Munkres / LM chains under the pair kernels), 6 with one stream per
@@ -323,7 +326,7 @@ def run_workload(name, seqs_per_ctx, rig, args, steps, warmup, dist, local_rank,
     for seqs in seqs_per_ctx:   # every rank (and every context) owns its own sequences: weak scaling, no data-path collective
         frames = [seqs[s][k] for k in range(T_) for s in range(S_)]   # frame slot = k * S + s
         nd_ = Skeleton3D(rig, max_epi_dist=0.045, max_frames=B, max_det_per_cam=w["max_det"], max_hyp=w["max_hyp"], device=local_rank,
-                         options=dict(hi_priority_stream=-1) if one_stream else None)
+                         options=dict(**(dict(hi_priority_stream=-1) if one_stream else {}), **(dict(pairs_form=args.pairs_form) if getattr(args, "pairs_form", None) else {})) or None)
         nd_.stage(frames)  # inputs resident in HBM before the timed region
         nodes.append(nd_)
     node = nodes[0]
@@ -1000,6 +1003,7 @@ def main():
     ap.add_argument("--stream-contexts", type=int, default=8, help="contexts of the streaming measurement (each pins two batches of host memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rough", default="", help="diagnostic: overrides of scene.ROUGH for the rough-scene workload, e.g. pixel_noise=3.5,outlier_frac=0.012")
+    ap.add_argument("--pairs-form", default=None, choices=["flat", "rows", "fused"], help="diagnostic: se3d_options.pairs_form of every context (default: the library's choice)")
     ap.add_argument("--no-robust", action="store_true", help="skip the `robust` block of a default run (the 16cam6p shape on rough scenes: scene.ROUGH)")
     ap.add_argument("--distinct", default=str(DISTINCT_DEFAULT), help="distinct seeded sequences per context (default %d, each resident seqs / %d times); "
                     "'all': every resident sequence its own scene (control run; generation takes ~10 s on 32 processes)" % (DISTINCT_DEFAULT, DISTINCT_DEFAULT))
