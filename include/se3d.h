@@ -336,8 +336,9 @@ int se3d_stream_collect(se3d_ctx *ctx, se3d_stream_result *out);
  * several streams interleave on the copy engines: 37 - 43 GB/s instead of 56).  The pair is created by the first se3d_stream_submit on the device and
  * lives as long as the process (at most 64 devices; a hipDeviceReset invalidates it).  Its health is WATCHED (round 6): a burst of downloads while
  * the upload stream is idle can leave both directions on one copy engine for good — the streaming rate then drops to 60 % until the streams are
- * re-created, which round 5 saw in one run of ten.  Every download of >= 8 MB is timed with events on the download stream; six in a row below
- * 30 GB/s replace the pair by a new one (pending copies of the old pair finish; at most 16 repairs per device and process).
+ * re-created, which round 5 saw in one run of ten.  se3d_stream_collect enqueues a 1 MB companion upload next to every batch's downloads (a download
+ * that never starts with the upload stream idle does not trigger it), and every download of >= 8 MB is timed with events on the download stream: six in
+ * a row below 30 GB/s replace the pair by a new one (pending copies of the old pair finish; at most 16 repairs per device and process).
  * Diagnostic: *gbps_both = GB/s per direction of four 32 MB uploads and four 32 MB downloads queued at once on the device's current pair (~48
  * healthy, ~28 serialised; ~10 ms, 2 x 32 MB of pinned and of device memory for its duration; only call it with no batch in flight), *repairs
  * (optional) = how often the pair was replaced in this process, *last_download_gbps (optional) = rate of the last timed download. */

@@ -1393,11 +1393,16 @@ int se3d_run_stage2_shard_post(se3d_ctx *c, int32_t n_seq, const void *d_gathere
 //   * every download of at least 8 MB is bracketed by two timing events on the download stream (what lies between them is the copies alone; the
 //     stream is a FIFO) — a healthy download runs at 37 - 56 GB/s with or without uploads next to it, one that shares its engine with the uploads
 //     queues behind 200 MB uploads and comes out far below 30;
+//   * PREVENTION (late round 6): the flip needs uploads alone FOLLOWED BY downloads alone (both, uploads alone, downloads alone, both: serialised every
+//     time; the same with a small upload issued next to every download of the burst — 64 KB, 1 MB or 8 MB — never, in 12 of 12 probes:
+//     profiles/r6/stream_companion.txt).  se3d_stream_collect therefore enqueues a 1 MB COMPANION upload (scratch to scratch, 0.5 % of a batch's upload
+//     bytes) on the upload stream right before a batch's downloads: a download never starts with the upload stream idle;
 //   * six downloads in a row below 30 GB/s: a NEW pair of streams replaces the old one (whose pending copies finish: hipStreamDestroy releases a
 //     stream when its work is done; the events recorded on it stay valid).  At most 16 repairs per device and process.
 // Every enqueue on the pair happens under g_copy_mu, so no thread can hold a handle that another thread destroys.
 struct CopyPair {
   hipStream_t s[2] = {nullptr, nullptr};
+  void *comp_h = nullptr, *comp_d = nullptr;   // companion upload (below): 1 MB of pinned host memory and of device memory
   int repairs = 0, slow_streak = 0;
   long downloads_timed = 0;
   double last_rate = 0.0;   // GB/s of the last timed download
@@ -1407,6 +1412,7 @@ static CopyPair g_pair[64];
 static constexpr double kPairSlowGBps = 30.0;
 static constexpr int kPairSlowStreak = 6, kPairMaxRepairs = 16;
 static constexpr size_t kPairTimedBytes = (size_t)8 << 20;
+static constexpr size_t kPairCompanionBytes = (size_t)1 << 20;
 // (caller holds g_copy_mu and has made `device` current)
 static bool copy_pair_locked(int device, hipStream_t &up, hipStream_t &down) {
   if (device < 0 || device >= 64) return false;
@@ -1414,7 +1420,14 @@ static bool copy_pair_locked(int device, hipStream_t &up, hipStream_t &down) {
   for (int d = 0; d < 2; ++d)
     if (!p.s[d] && hipStreamCreateWithFlags(&p.s[d], hipStreamNonBlocking) != hipSuccess) p.s[d] = nullptr;
   up = p.s[0]; down = p.s[1];
+  if (!p.comp_h && hipHostMalloc(&p.comp_h, kPairCompanionBytes, hipHostMallocDefault) == hipSuccess) std::memset(p.comp_h, 0, kPairCompanionBytes);
+  if (!p.comp_d) (void)hipMalloc(&p.comp_d, kPairCompanionBytes);
   return up && down;
+}
+// (caller holds g_copy_mu) the companion upload of a download that is about to be enqueued; a failure is not an error of the caller's batch
+static void copy_pair_companion_locked(int device) {
+  CopyPair &p = g_pair[device];
+  if (p.comp_h && p.comp_d && p.s[0]) (void)hipMemcpyAsync(p.comp_d, p.comp_h, kPairCompanionBytes, hipMemcpyHostToDevice, p.s[0]);
 }
 static void copy_pair_recreate_locked(int device) {
   CopyPair &p = g_pair[device];
@@ -1455,12 +1468,20 @@ static bool probe_copy_pair(hipStream_t up, hipStream_t down, double *gbps_both)
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   };
   if (ok) {
-#ifdef SE3D_PROBE_DIAG   // diagnostic build only (tools/tmp, never shipped): SE3D_PROBE_MODE bit mask 1 warm both, 2 uploads alone, 4 downloads alone, 8 both
+#ifdef SE3D_PROBE_DIAG   // diagnostic build only (tools/tmp, never shipped): SE3D_PROBE_MODE bit mask 1 warm both, 2 uploads alone, 4 downloads alone, 16 downloads with companion uploads, 8 both
     const int mode = getenv("SE3D_PROBE_MODE") ? atoi(getenv("SE3D_PROBE_MODE")) : 9;
     double tb = 1.0;
     if (mode & 1) (void)run(true, true);
     if (mode & 2) (void)run(true, false);
     if (mode & 4) (void)run(false, true);
+    if (mode & 16) {   // downloads, each preceded by a small COMPANION upload (SE3D_PROBE_COMPANION_KB, default 1024): does that keep the burst from flipping the pair?
+      const size_t small = (size_t)(getenv("SE3D_PROBE_COMPANION_KB") ? atoi(getenv("SE3D_PROBE_COMPANION_KB")) : 1024) << 10;
+      for (int k = 0; k < reps; ++k) {
+        ok = ok && hipMemcpyAsync(d0, h0, small, hipMemcpyHostToDevice, up) == hipSuccess;
+        ok = ok && hipMemcpyAsync(h1, d1, n, hipMemcpyDeviceToHost, down) == hipSuccess;
+      }
+      ok = ok && hipStreamSynchronize(up) == hipSuccess && hipStreamSynchronize(down) == hipSuccess;
+    }
     if (mode & 8) tb = run(true, true);
 #else
     (void)run(true, true);   // first touch of the buffers
@@ -1605,6 +1626,7 @@ int se3d_stream_collect(se3d_ctx *c, se3d_stream_result *out) {
       std::lock_guard<std::mutex> lk(g_copy_mu);
       hipStream_t up = nullptr, down = nullptr;
       if (!copy_pair_locked(c->device, up, down)) { c->err = "se3d_stream_collect: no copy stream"; return SE3D_ERR_DEVICE; }
+      copy_pair_companion_locked(c->device);   // the upload stream is never idle when a download starts (CopyPair)
       HIPCHK(c, hipEventRecord(sl.d2h_start, down));
       HIPCHK(c, hipMemcpyAsync(sl.h_fused, sl.d_fused, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, down));
       HIPCHK(c, hipMemcpyAsync(sl.h_pred, sl.d_pred, sizeof(se3d_person3d) * (size_t)total, hipMemcpyDeviceToHost, down));
