@@ -1468,14 +1468,18 @@ static bool probe_copy_pair(hipStream_t up, hipStream_t down, double *gbps_both)
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   };
   if (ok) {
-#ifdef SE3D_PROBE_DIAG   // diagnostic build only (tools/tmp, never shipped): SE3D_PROBE_MODE bit mask 1 warm both, 2 uploads alone, 4 downloads alone, 16 downloads with companion uploads, 8 both
-    const int mode = getenv("SE3D_PROBE_MODE") ? atoi(getenv("SE3D_PROBE_MODE")) : 9;
+#ifdef SE3D_PROBE_DIAG   // diagnostic builds only (tools/tmp, never shipped; -DSE3D_PROBE_DIAG=<bit mask>): 1 warm both, 2 uploads alone, 4 downloads alone,
+    // 16 downloads with companion uploads of SE3D_PROBE_COMPANION_KB, 8 both (tools/r6.sh probe_bisect, tools/stream_companion_probe.sh)
+#ifndef SE3D_PROBE_COMPANION_KB
+#define SE3D_PROBE_COMPANION_KB 1024
+#endif
+    const int mode = SE3D_PROBE_DIAG;
     double tb = 1.0;
     if (mode & 1) (void)run(true, true);
     if (mode & 2) (void)run(true, false);
     if (mode & 4) (void)run(false, true);
-    if (mode & 16) {   // downloads, each preceded by a small COMPANION upload (SE3D_PROBE_COMPANION_KB, default 1024): does that keep the burst from flipping the pair?
-      const size_t small = (size_t)(getenv("SE3D_PROBE_COMPANION_KB") ? atoi(getenv("SE3D_PROBE_COMPANION_KB")) : 1024) << 10;
+    if (mode & 16) {   // downloads, each preceded by a small COMPANION upload: does that keep the burst from flipping the pair?
+      const size_t small = (size_t)SE3D_PROBE_COMPANION_KB << 10;
       for (int k = 0; k < reps; ++k) {
         ok = ok && hipMemcpyAsync(d0, h0, small, hipMemcpyHostToDevice, up) == hipSuccess;
         ok = ok && hipMemcpyAsync(h1, d1, n, hipMemcpyDeviceToHost, down) == hipSuccess;

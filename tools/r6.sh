@@ -79,14 +79,13 @@ stream_diag)
   cat $O/stream_diag_numa.txt | head -8
   ;;
 probe_bisect)
-  # which part of se3d_copy_stream_probe (diagnostic build tools/tmp/libse3d_probediag.so, SE3D_PROBE_MODE bit mask: 1 warm both, 2 up alone, 4 down alone, 8 both)
+  # which part of se3d_copy_stream_probe (diagnostic builds tools/tmp/libse3d_probediag<mode>.so, -DSE3D_PROBE_DIAG=<bit mask>: 1 warm both, 2 up alone, 4 down alone, 8 both)
   # flips the streaming path into its slow mode?  three streaming passes per process, the probe runs after each
-  export SE3D_LIB_OVERRIDE=$GRAFT_REPO_ROOT/tools/tmp/libse3d_probediag.so
+  # (build first: for M in 15 9 2 4 0; do tools/build_variants.sh probediag$M "-DSE3D_PROBE_DIAG=$M" "" api; done — the mode is a compile-time constant: no getenv in csrc/)
   for M in ${MODES:-15 9 2 4 0}; do
-    SE3D_PROBE_MODE=$M timeout 600 python bench.py --no-secondary --no-serial --no-parity --no-cpu-baseline --no-robust --stream-repeat ${PASSES:-3} > $O/probe_bisect_$M.log 2> $O/probe_bisect_$M.err
+    SE3D_LIB_OVERRIDE=$GRAFT_REPO_ROOT/tools/tmp/libse3d_probediag$M.so timeout 600 python bench.py --no-secondary --no-serial --no-parity --no-cpu-baseline --no-robust --stream-repeat ${PASSES:-3} > $O/probe_bisect_$M.log 2> $O/probe_bisect_$M.err
     grep "streaming pass\|probe-repair" $O/probe_bisect_$M.err | cut -c1-${CUT:-90} | sed "s/^/mode $M: /"
   done
-  unset SE3D_LIB_OVERRIDE
   ;;
 sdma)
   for i in 1 2; do timeout 300 tools/microbench/sdma_pair 3 > $O/sdma_pair_$i.txt 2>&1; done
