@@ -11,8 +11,9 @@ namespace se3d {
 static const double g_max_sync_diff = 0.067;  // S3D:64
 static const char* BASE_FRAME = "base";       // S3D:45
 
-Context::Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam, int max_hyp, int device, const se3d_options* options) {
+Context::Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam, int max_hyp, int device, const se3d_options* options, int max_frames) {
   if (options) opt_ = *options;
+  max_frames_ = std::max(1, max_frames);
   n_cam_ = (int)cams.size();
   max_hyp_ = std::max(max_hyp, max_det_per_cam);   // the library wants max_hyp >= max_det_per_cam (the first camera seeds one hypothesis per detection)
   max_det_ = max_det_per_cam;
@@ -35,7 +36,7 @@ Context::Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, in
 se3d_ctx* Context::create(int max_det, int max_hyp) const {
   se3d_rig rig{n_cam_, const_cast<float*>(Rt_.data()), const_cast<float*>(K_.data()), const_cast<float*>(F_.data())};
   se3d_params p{prm_.pose_method == "h36m" ? SE3D_POSE_H36M : SE3D_POSE_SIMPLE, prm_.norm_height ? 1 : 0, prm_.max_epi_dist};
-  se3d_limits lim{1, max_det, max_hyp, max_hyp};
+  se3d_limits lim{max_frames_, max_det, max_hyp, max_hyp};
   if (se3d_abi_version() != SE3D_ABI_VERSION)   // the library's structs have another layout than the header this file was compiled with
     throw std::runtime_error("libse3d_hip.so has struct layout version " + std::to_string(se3d_abi_version()) + ", this host layer was built against " +
                              std::to_string(SE3D_ABI_VERSION) + " (include/se3d.h: SE3D_ABI_VERSION)");
@@ -114,6 +115,19 @@ static void to_pod3(const person_msgs::PersonCov& s, se3d_person3d& d) {
     d.keypoints[k].score = s.keypoints[k].score;
     for (int a = 0; a < 6; ++a) d.keypoints[k].cov[a] = s.keypoints[k].cov[a];
   }
+}
+
+void flatten_frame(const std::vector<person_msgs::Person2DList>& people, double stamp, FlatFrame& out) {
+  const int N = (int)people.size();
+  out.off.assign(N + 1, 0);
+  out.flat.clear();
+  out.fb.assign(N, -1.f);
+  for (int i = 0; i < N; ++i) {
+    for (const auto& p : people[i].persons) { out.flat.emplace_back(); to_pod(p, out.flat.back()); }
+    out.off[i + 1] = (int32_t)out.flat.size();
+    out.fb[i] = people[i].fb_delay;
+  }
+  out.in = se3d_frame_in{N, out.off.data(), out.flat.empty() ? nullptr : out.flat.data(), out.fb.data(), stamp};
 }
 
 void Skeleton3DNode::triangulate_persons(const std::vector<person_msgs::Person2DList>& people, person_msgs::PersonCovList& persons3d_msg,

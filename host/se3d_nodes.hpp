@@ -47,7 +47,10 @@ class Context {
  public:
   static constexpr int kCapacityMax = 256;   // SE3D_MUNKRES_MAX of the library: rows / columns of the device Munkres
   // options: se3d_options of the library (include/se3d.h; nullptr = defaults); kept and applied again when the context grows
-  Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam = 16, int max_hyp = 64, int device = 0, const se3d_options* options = nullptr);
+  // max_frames: frames a resident batch may hold (1: the nodes' operating point, one synchronised frame per callback; larger for the resident calls
+  // se3d_stage_frames / se3d_run_stage1 / se3d_run_stage2_walk on get(), e.g. a replayed walk exchanged by se3d::SkeletonExchange)
+  Context(const std::vector<CameraCalib>& cams, const NodeParams& prm, int max_det_per_cam = 16, int max_hyp = 64, int device = 0, const se3d_options* options = nullptr,
+          int max_frames = 1);
   ~Context();
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
@@ -66,7 +69,7 @@ class Context {
  private:
   se3d_ctx* create(int max_det, int max_hyp) const;
   se3d_ctx* ctx_ = nullptr;
-  int n_cam_ = 0, max_hyp_ = 0, max_det_ = 0, device_ = 0, n_grown_ = 0;
+  int n_cam_ = 0, max_hyp_ = 0, max_det_ = 0, device_ = 0, n_grown_ = 0, max_frames_ = 1;
   NodeParams prm_;
   se3d_options opt_{};
   std::vector<float> Rt_, K_, F_;
@@ -74,6 +77,16 @@ class Context {
   std::vector<double> rp_T_, rp_P_;      // reprojection cameras, re-applied after grow()
   std::vector<int32_t> rp_wh_;
 };
+
+// One synchronised set of per-camera messages as the C-ABI takes it (se3d_frame_in over storage owned by this object): what
+// Skeleton3DNode::triangulate_persons builds per callback, exposed for callers of the resident entry points (se3d_stage_frames).
+struct FlatFrame {
+  std::vector<int32_t> off;
+  std::vector<se3d_person2d> flat;
+  std::vector<float> fb;
+  se3d_frame_in in{};
+};
+void flatten_frame(const std::vector<person_msgs::Person2DList>& people, double stamp, FlatFrame& out);
 
 class Skeleton3DNode {
  public:

@@ -8,6 +8,9 @@
 // the GPU — that all replay the scene with the hypotheses / detections split over the ranks (se3d::HypothesisShard: RCCL all-gathers on the
 // contexts' streams; --backend staged: the test-only host-staged collective, all ranks on GPU 0).  Rank r writes <out.bin>.rank<r>; every rank's
 // file must equal the single-process <out.bin> byte for byte (tests/test_gpu_host_cpp.py).
+// --walk-exchange (with --ranks): the throughput sharding's exchange instead — every rank stages the scene's frames as ONE resident batch, runs stage 1 and the
+// stage-2 walk over them, packs the published persons densely on the device and all-gathers them (se3d::SkeletonExchange); every rank checks that its own block
+// equals what se3d_fetch_stage2_walk returns slot by slot and that every other rank's block equals its own (all ranks replay the same scene).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -78,10 +81,12 @@ int main(int argc_all, char** argv_all) {
   // options anywhere on the line; the positional arguments keep their places
   std::vector<char*> pos;
   int ranks = 0;
+  bool walk_exchange = false;
   std::string backend = "rccl";
   for (int i = 0; i < argc_all; ++i) {
     if (!std::strcmp(argv_all[i], "--ranks") && i + 1 < argc_all) ranks = std::atoi(argv_all[++i]);
     else if (!std::strcmp(argv_all[i], "--backend") && i + 1 < argc_all) backend = argv_all[++i];
+    else if (!std::strcmp(argv_all[i], "--walk-exchange")) walk_exchange = true;
     else pos.push_back(argv_all[i]);
   }
   const int argc = (int)pos.size();
@@ -131,6 +136,70 @@ int main(int argc_all, char** argv_all) {
       prior.reset();
       std::cout << "rank " << my_rank << " of " << world << " on device " << device << ", collective: " << coll->name() << ", all-gather bytes per frame: "
                 << shard->allgather_bytes_stage1() << " + " << shard->allgather_bytes_stage2() << std::endl;
+    }
+    if (walk_exchange) {
+      if (!is_rank) { std::fprintf(stderr, "--walk-exchange needs --ranks N\n"); return 2; }
+      if (n_frames > 64) { std::fprintf(stderr, "--walk-exchange: at most 64 frames (one walk)\n"); return 2; }
+      shard.reset();   // (the constructor above switched the hypothesis shard on for ctx; this mode uses a context of its own)
+      skel.set_shard(nullptr); prior.set_shard(nullptr);
+      auto wctx = std::make_shared<se3d::Context>(cams, prm, det0, hyp0, device, &opt, n_frames);
+      std::vector<se3d::FlatFrame> ff(n_frames);
+      std::vector<se3d_frame_in> fin(n_frames);
+      std::vector<double> ts(n_frames);
+      std::vector<int32_t> slots(n_frames);
+      for (int f = 0; f < n_frames; ++f) {
+        std::vector<person_msgs::Person2DList> people(n_cam);
+        double stamp = 0.0;
+        for (int c = 0; c < n_cam; ++c) {
+          people[c].header.stamp = rd<double>(in);
+          stamp = std::max(stamp, people[c].header.stamp);
+          people[c].fb_delay = rd<float>(in);
+          const int np = rd<int32_t>(in);
+          people[c].persons.resize(np);
+          for (auto& p : people[c].persons) {
+            p.score = rd<float>(in);
+            for (float& b : p.bbox) b = rd<float>(in);
+            p.keypoints.resize(17);
+            for (auto& k : p.keypoints) { k.x = rd<float>(in); k.y = rd<float>(in); k.score = rd<float>(in); for (float& cv : k.cov) cv = rd<float>(in); }
+          }
+        }
+        se3d::flatten_frame(people, stamp, ff[f]);
+        fin[f] = ff[f].in;
+        ts[f] = stamp;
+        slots[f] = f;
+      }
+      se3d_ctx* c = wctx->get();
+      auto chk = [&](int rc, const char* what) { if (rc != SE3D_OK) throw std::runtime_error(std::string(what) + ": " + se3d_last_error(c)); };
+      chk(se3d_stage_frames(c, n_frames, fin.data()), "se3d_stage_frames");
+      chk(se3d_run_stage1(c), "se3d_run_stage1");
+      chk(se3d_refine_reset(c), "se3d_refine_reset");
+      chk(se3d_run_stage2_walk(c, 1, n_frames, slots.data(), ts.data()), "se3d_run_stage2_walk");
+      const int cap = n_frames * hyp0;
+      se3d::SkeletonExchange ex(c, *coll, n_frames, cap);
+      ex.exchange();
+      std::vector<std::vector<se3d_person3d>> persons;
+      std::vector<std::vector<int32_t>> offsets;
+      ex.fetch(persons, offsets);
+      // own block against the host fetch, slot by slot
+      size_t total = 0;
+      std::vector<se3d_person3d> fused(hyp0), pred(hyp0);
+      std::vector<int32_t> iters(hyp0);
+      for (int f = 0; f < n_frames; ++f) {
+        se3d_fused_out fo{hyp0, 0, 0, 0.f, fused.data(), pred.data(), iters.data(), 0u, nullptr};
+        chk(se3d_fetch_stage2_walk(c, f, 1, &fo), "se3d_fetch_stage2_walk");
+        const int o0 = offsets[my_rank][f], o1 = offsets[my_rank][f + 1];
+        if (o1 - o0 != fo.n_persons || (fo.n_persons && std::memcmp(&persons[my_rank][o0], fused.data(), sizeof(se3d_person3d) * (size_t)fo.n_persons) != 0))
+          throw std::runtime_error("walk exchange: frame slot " + std::to_string(f) + " of the own block differs from se3d_fetch_stage2_walk");
+        total += (size_t)fo.n_persons;
+      }
+      if (offsets[my_rank][n_frames] != (int32_t)total || offsets[my_rank][n_frames + 1] != 0) throw std::runtime_error("walk exchange: totals of the own block are wrong");
+      for (int r = 0; r < world; ++r)
+        if (offsets[r] != offsets[my_rank] || persons[r].size() != persons[my_rank].size() ||
+            (total && std::memcmp(persons[r].data(), persons[my_rank].data(), sizeof(se3d_person3d) * total) != 0))
+          throw std::runtime_error("walk exchange: the block of rank " + std::to_string(r) + " differs from this rank's (all ranks replay the same scene)");
+      std::cout << "walk exchange ok: rank " << my_rank << " of " << world << ", " << total << " published persons in " << n_frames << " frame slots from every rank, collective: "
+                << coll->name() << std::endl;
+      return 0;
     }
     std::ofstream out(is_rank ? std::string(argv[2]) + ".rank" + std::to_string(my_rank) : std::string(argv[2]), std::ios::binary);
     wr<int32_t>(out, n_frames);

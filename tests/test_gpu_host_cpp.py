@@ -195,3 +195,21 @@ def test_cpp_replay_two_ranks_host_staged(tmp_path, extr_rig, demo_params):
     C++ host layer end to end — launcher, rendezvous, shard layout, both all-gathers per frame, replicated association and lifecycle."""
     log = _sharded_replay_equals_single_process(tmp_path, extr_rig, demo_params, 2, "staged")
     assert log.count("host-staged files") == 2, log
+
+
+@pytest.mark.parametrize("ranks,backend", [(1, "rccl"), (2, "staged")])
+def test_cpp_walk_exchange(tmp_path, extr_rig, demo_params, ranks, backend):
+    """The throughput sharding's exchange from the C++ host layer (se3d::SkeletonExchange): every rank runs stage 1 and the stage-2 walk over the scene as one
+    resident batch, packs the published persons densely on the device and all-gathers persons and offsets on the context's stream; se3d_replay --walk-exchange
+    checks inside every rank that its own block equals se3d_fetch_stage2_walk slot by slot and that every rank's block is the same (same scene)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")], stdout=subprocess.DEVNULL)
+    frames, _ = S.generate_sequence(extr_rig, S.SceneConfig(n_persons=5, n_frames=14, seed=8, p_miss=0.05))
+    scene = str(tmp_path / "scene.bin")
+    Hn.write_replay_scene(scene, extr_rig, demo_params, Hn.stream_from_frames(frames))
+    env = dict(os.environ, SE3D_REPLAY_MAX_DET="8", SE3D_REPLAY_MAX_HYP="16")
+    r = subprocess.run([os.path.join(ROOT, "host", "se3d_replay"), scene, str(tmp_path / "unused.bin"), "--ranks", str(ranks), "--backend", backend, "--walk-exchange"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    ok = [ln for ln in r.stdout.split("\n") if ln.startswith("walk exchange ok")]
+    assert len(ok) == ranks, r.stdout
+    assert all(int(ln.split(",")[1].split()[0]) > 10 for ln in ok), ok   # published persons (the tracks publish from the 11th observation on)
